@@ -1,0 +1,221 @@
+/*
+ * qn_hip.h -- C ABI of libqn_hip.so: the MI355X (gfx950) quasi-Newton / line-search inner loop.
+ *
+ * This is the drop-in boundary for the hot path of fedemagnani/optimization-solvers
+ * (src/ls_solver.rs, src/quasi_newton/{bfgs,dfp}.rs, src/line_search/{mod,backtracking,morethuente}.rs).
+ * The reference has no FFI on this path -- its "operator API" is the Rust trait surface -- so every entry
+ * point below names the reference item it replaces (file:line relative to the reference repo).  A Rust
+ * shim implementing `ComputeDirection` / `LineSearchSolver` on top of these is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; all host matrices are dense f64; `*_host` pointers are host
+ * memory, `*_dev` device memory of the context's GPU.  Every function returns a qn_status unless stated;
+ * on QN_ABNORMAL_TERMINATION / QN_ERROR_INPUT_PARAMS qn_last_error_message() explains.  There is no CPU
+ * fallback: without a usable GPU qn_context_create fails.  All calls on one context must come from one
+ * thread at a time (the reference is `&mut self` everywhere: ls_solver.rs:23-112); host callbacks run on
+ * the calling thread.
+ */
+#ifndef QN_HIP_H
+#define QN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QN_ABI_VERSION 1
+
+/* SolverError (ls_solver.rs:10-20); 0 is Ok(()) */
+typedef enum {
+    QN_OK = 0,
+    QN_MAX_ITER_REACHED = 1,     /* "Max iter reached"          ls_solver.rs:12-13,110 */
+    QN_OUT_OF_DOMAIN = 2,        /* "Out of domain"             ls_solver.rs:14-15,37-40 */
+    QN_ERROR_INPUT_PARAMS = 3,   /* "Error in input parameters" ls_solver.rs:16-17 */
+    QN_ABNORMAL_TERMINATION = 4  /* "Abnormal termination"      ls_solver.rs:18-19 (HIP / RCCL failures map here) */
+} qn_status;
+
+const char* qn_status_string(int status); /* the Display strings of ls_solver.rs:12-19 */
+const char* qn_last_error_message(void);  /* thread-local detail of the last non-OK return */
+int qn_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Context: one GPU, one HIP stream, optionally one rank of a row-sharded group.
+ * The reference has no device or process boundary; this is new.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct qn_context qn_context;
+
+int qn_device_count(int* out);
+int qn_context_create(int device, qn_context** out);
+
+/* Row-sharded group: rank p of `world` owns rows [p*rpr, (p+1)*rpr) of H and of the objective's matrix;
+ * all n-vectors are replicated; mat-vec slices are exchanged with one RCCL all-gather per pass.
+ * `unique_id` is the 128-byte ncclUniqueId produced by qn_comm_unique_id on rank 0 and distributed by the
+ * caller (torch.distributed / MPI / a file). */
+#define QN_UNIQUE_ID_BYTES 128
+int qn_comm_unique_id(void* out_128_bytes);
+int qn_context_create_sharded(int device, int rank, int world, const void* unique_id, qn_context** out);
+
+/* Test / bring-up alternative to RCCL: the caller performs the exchange on host buffers (e.g. with
+ * torch.distributed gloo).  `fn(user, sendbuf, recvbuf, count)`: recvbuf[r*count .. (r+1)*count) must
+ * receive rank r's sendbuf (an all-gather of `count` doubles per rank).  Returns 0 on success. */
+typedef int (*qn_host_allgather_fn)(void* user, const double* sendbuf, double* recvbuf, size_t count);
+int qn_context_create_sharded_host_exchange(int device, int rank, int world, qn_host_allgather_fn fn, void* user,
+                                            qn_context** out);
+void qn_context_destroy(qn_context* ctx);
+int qn_context_synchronize(qn_context* ctx);
+int qn_context_rank(const qn_context* ctx);
+int qn_context_world(const qn_context* ctx);
+void* qn_context_stream(qn_context* ctx); /* hipStream_t */
+
+/* ---------------------------------------------------------------------------------------------
+ * Line searches.  Plain structs by value, as the reference's are plain data.
+ *   QN_LS_MORETHUENTE : MoreThuente        (morethuente.rs:6-62, compute_step_len :165-297)
+ *   QN_LS_BACKTRACKING: BackTracking       (backtracking.rs:3-58)
+ * ------------------------------------------------------------------------------------------- */
+enum { QN_LS_MORETHUENTE = 0, QN_LS_BACKTRACKING = 1 };
+typedef struct {
+    int32_t kind;
+    int32_t _pad;
+    double c1, c2, t_min, t_max, delta_min, delta, delta_max; /* More-Thuente fields, morethuente.rs:6-14 */
+    double bt_c1, bt_beta;                                    /* BackTracking{c1, beta}, backtracking.rs:3-6 */
+} qn_linesearch;
+
+void qn_morethuente_default(qn_linesearch* ls);                      /* MoreThuente::default, morethuente.rs:16-28 */
+int qn_morethuente_with_deltas(qn_linesearch* ls, double dmin, double d, double dmax); /* :31-41 */
+int qn_morethuente_with_t_min(qn_linesearch* ls, double t_min);      /* :42-45 */
+int qn_morethuente_with_t_max(qn_linesearch* ls, double t_max);      /* :46-49 */
+int qn_morethuente_with_c1(qn_linesearch* ls, double c1);            /* :50-55; the assert!s become QN_ERROR_INPUT_PARAMS */
+int qn_morethuente_with_c2(qn_linesearch* ls, double c2);            /* :56-62 */
+void qn_backtracking_new(qn_linesearch* ls, double c1, double beta); /* BackTracking::new, backtracking.rs:8-10 */
+
+/* ---------------------------------------------------------------------------------------------
+ * Oracle: `impl FnMut(&DVector<f64>) -> FuncEvalMultivariate` (ls_solver.rs:69, func_eval.rs:4-41).
+ * ------------------------------------------------------------------------------------------- */
+/* host closure: writes *f and g[0..n); return value 0 (the reference closure cannot fail; non-zero aborts
+ * the run with QN_ABNORMAL_TERMINATION). */
+typedef int (*qn_host_oracle_fn)(void* user, const double* x_host, size_t n, double* f, double* g_host);
+/* device closure: enqueue work on `stream` that reads x_dev[0..n) and writes *f_dev and g_dev[0..n). */
+typedef int (*qn_device_oracle_fn)(void* user, void* stream, const double* x_dev, size_t n, double* f_dev, double* g_dev);
+
+typedef struct qn_objective qn_objective; /* a device-resident objective owned by the library */
+
+enum { QN_ORACLE_HOST = 0, QN_ORACLE_DEVICE_FN = 1, QN_ORACLE_OBJECTIVE = 2 };
+typedef struct {
+    int32_t kind;
+    /* 0: reproduce the reference's call sequence exactly (loop-top call ls_solver.rs:79, every line-search
+     *    call incl. the per-iteration re-evaluation at tl morethuente.rs:217, and bfgs.rs:98);
+     * 1: evaluate each DISTINCT point once (the oracle must then be a pure function of x).  The values fed
+     *    to the algorithm are identical; only the number of evaluations changes (5 -> 2 per iteration for
+     *    More-Thuente on a quadratic). */
+    int32_t memoize;
+    qn_host_oracle_fn host_fn;
+    void* host_user;
+    qn_device_oracle_fn device_fn;
+    void* device_user;
+    qn_objective* objective;
+} qn_oracle;
+
+/* Built-in benchmark objective (build-defined): f = 1/2 x'Qx - b'x, g = Qx - b.
+ * `q_rowmajor_host` is the full symmetric n x n matrix; each rank uploads only its own rows. */
+int qn_quadratic_create(qn_context* ctx, size_t n, const double* q_rowmajor_host, const double* b_host, qn_objective** out);
+/* Same objective with Q generated on the device, shard-locally: off-diagonal Q_ij = u(seed,min,max)/n,
+ * u in [-1,1) from a counter-based splitmix64 hash; diagonal given (SPD if diag_i >= 1). */
+int qn_quadratic_create_synthetic(qn_context* ctx, size_t n, uint64_t seed, const double* diag_host, const double* b_host,
+                                  qn_objective** out);
+/* f = log sum_i exp(a_i'x + c_i) + mu/2 ||x||^2; A is m x n row-major, rows sharded. */
+int qn_logsumexp_create(qn_context* ctx, size_t m, size_t n, const double* a_rowmajor_host, const double* c_host, double mu,
+                        qn_objective** out);
+void qn_objective_destroy(qn_objective* obj);
+/* one evaluation at a host point (tests, and `let eval = f_and_g(x)` after minimize as in examples/quadratic.rs:39) */
+int qn_objective_eval(qn_objective* obj, const double* x_host, double* f, double* g_host);
+/* download rows [row0,row0+nrows) of this rank's matrix shard (row-major, n columns); rows outside the shard fail */
+int qn_objective_get_rows(qn_objective* obj, size_t row0, size_t nrows, double* out_host);
+
+/* ---------------------------------------------------------------------------------------------
+ * Solvers: BFGS (bfgs.rs:4-127), DFP (dfp.rs), GradientDescent (gradient_descent.rs:7-82).
+ * ------------------------------------------------------------------------------------------- */
+enum { QN_BFGS = 0, QN_DFP = 1, QN_GRADIENT_DESCENT = 2 };
+typedef struct qn_solver qn_solver;
+
+/* BFGS::new(tol, x0) / DFP::new / GradientDescent::new(grad_tol, x0): H = I (no identity copy is kept) */
+int qn_solver_create(qn_context* ctx, int method, double tol, const double* x0_host, size_t n, qn_solver** out);
+void qn_solver_destroy(qn_solver* s);
+
+/* callback: Option<&mut dyn FnMut(&Self)> (ls_solver.rs:72,105-107); called after k += 1 */
+typedef void (*qn_callback_fn)(void* user, qn_solver* solver);
+
+/* LineSearchSolver::minimize (ls_solver.rs:66-111).  Resets k only (warm restart keeps x, H, s_norm, y_norm). */
+int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracle* oracle, size_t max_iter_solver,
+                size_t max_iter_line_search, qn_callback_fn callback, void* callback_user);
+
+/* getters generated by derive_getters on bfgs.rs:3-12, plus LineSearchSolver::xk/k (bfgs.rs:52-63) */
+size_t qn_solver_n(const qn_solver* s);
+size_t qn_solver_k(const qn_solver* s);                    /* k() */
+double qn_solver_tol(const qn_solver* s);                  /* tol() */
+int qn_solver_get_x(qn_solver* s, double* out_host);       /* x() / xk() */
+int qn_solver_set_x(qn_solver* s, const double* x_host);   /* xk_mut() */
+int qn_solver_s_norm(qn_solver* s, double* out, int* is_some); /* s_norm(): Option<f64> */
+int qn_solver_y_norm(qn_solver* s, double* out, int* is_some); /* y_norm(): Option<f64> */
+int qn_solver_next_iterate_too_close(qn_solver* s, int* out);          /* bfgs.rs:15-20 */
+int qn_solver_gradient_next_iterate_too_close(qn_solver* s, int* out); /* bfgs.rs:21-26 */
+/* approx_inv_hessian(): column-major n x n.  Lazy: applies the pending rank-2 update and gathers this rank's
+ * rows; rows of other ranks are left untouched unless `all_ranks` (then an all-gather fills everything). */
+int qn_solver_get_inv_hessian(qn_solver* s, double* out_colmajor_host, int all_ranks);
+int qn_solver_set_inv_hessian(qn_solver* s, const double* h_colmajor_host);
+
+/* ---- build-side instrumentation (not in the reference) ---- */
+typedef struct {
+    double f, gnorm, t, s_norm, y_norm; /* f(x_k), ||g_k|| (inf-norm for gradient descent), step, ||s||, ||y|| */
+    int32_t n_evals;   /* oracle calls of the reference's sequence in this iteration (memoised ones included) */
+    int32_t ls_iters;  /* line-search inner iterations started */
+    int32_t ls_cases;  /* More-Thuente: base-8 digits, one per inner iteration: 1..4 trial case, 0 returned */
+    int32_t updated;   /* 1 if the inverse Hessian was updated */
+} qn_trace_rec;
+/* record up to `cap` iterations of the next qn_minimize calls; x_trace (optional) gets x_{k+1} rows */
+int qn_solver_set_trace(qn_solver* s, size_t cap, int with_x);
+int qn_solver_get_trace(qn_solver* s, qn_trace_rec* out_host, size_t cap, size_t* len, double* x_trace_host);
+
+typedef struct {
+    uint64_t iterations;       /* outer iterations completed by the last qn_minimize */
+    uint64_t oracle_calls;     /* calls of the reference's sequence */
+    uint64_t oracle_evals;     /* evaluations actually performed (distinct points when memoize = 1) */
+    uint64_t h_passes;         /* passes over the inverse Hessian */
+    uint64_t h_bytes;          /* algorithmic bytes moved over H by those passes (this rank) */
+    uint64_t obj_bytes;        /* algorithmic bytes read from the objective's matrix (this rank) */
+    uint64_t launches;         /* kernels enqueued */
+    uint64_t host_syncs;       /* stream synchronisations */
+    double   t_hpass_ms, t_eval_ms, t_ctl_ms, t_comm_ms; /* HIP-event time per kernel class (profiling mode) */
+    uint64_t n_hpass_timed, n_eval_timed, n_ctl_timed, n_comm_timed;
+} qn_stats;
+int qn_solver_get_stats(qn_solver* s, qn_stats* out);
+/* profiling != 0: bracket every launch with HIP events on the solver's stream (slower; for roofline reports) */
+int qn_solver_set_profiling(qn_solver* s, int on);
+/* 0 = pipelined (device-resident control, no host sync per decision; default for memoised device objectives),
+ * 1 = synchronous (host reads the control block after every step; always used with host oracles / callbacks) */
+int qn_solver_set_sync_mode(qn_solver* s, int sync);
+/* tuning: rows per workgroup tile (4, 8 or 16), column splits (>= 1); 0 keeps the default */
+int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits);
+
+/* ---------------------------------------------------------------------------------------------
+ * Thin kernel-level FFI (what a Rust host loop would bind if it keeps `minimize` in Rust):
+ * the BLAS-2 / rank-2 / vector primitives as individual calls on device buffers.
+ * ------------------------------------------------------------------------------------------- */
+int qn_dev_alloc(qn_context* ctx, size_t bytes, void** out_dev);
+int qn_dev_free(qn_context* ctx, void* dev);
+int qn_h2d(qn_context* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int qn_d2h(qn_context* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* y = A x for `nrows` rows of a row-major matrix with leading dimension ld (bfgs.rs:47 H*g, dfp.rs:118 H*y) */
+int qn_gemv(qn_context* ctx, const double* a_dev, size_t ld, size_t nrows, size_t ncols, const double* x_dev, double* y_dev);
+/* H_rows += c_su (s u' + u s') + c_ss s s' + c_uu u u' on rows [row0,row0+nrows) (bfgs.rs:115-124, dfp.rs:115-120) */
+int qn_rank2_update(qn_context* ctx, double* h_dev, size_t ld, size_t row0, size_t nrows, size_t n, const double* s_dev,
+                    const double* u_dev, double c_ss, double c_su, double c_uu);
+/* out = x + t*d, two roundings per element (ls_solver.rs:60, bfgs.rs:94, backtracking.rs:32, morethuente.rs:182) */
+int qn_axpy(qn_context* ctx, size_t n, const double* x_dev, double t, const double* d_dev, double* out_dev);
+int qn_dot(qn_context* ctx, size_t n, const double* a_dev, const double* b_dev, double* out_host);  /* mod.rs:35,47,55 */
+int qn_nrm2(qn_context* ctx, size_t n, const double* a_dev, double* out_host);                      /* bfgs.rs:74,97,99 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QN_HIP_H */

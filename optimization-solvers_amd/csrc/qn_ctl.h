@@ -1,0 +1,96 @@
+// qn_ctl.h -- the device-resident control block shared by host pump and kernels.
+//
+// The whole solver (ls_solver.rs:66-111 driver, bfgs.rs:64-127 / dfp.rs hooks, morethuente.rs:165-297,
+// backtracking.rs:20-58) runs as ONE state machine inside the single-workgroup kernel `ctl_step`; it
+// yields only when it needs an oracle evaluation, a pass over H, or a host callback.  The host never takes
+// a line-search decision: it services requests (sync mode) or enqueues a fixed pattern of predicated
+// kernels and polls `phase` now and then (pipelined mode).
+#pragma once
+#include <stdint.h>
+
+// what the state machine is waiting for
+enum QnPhase : int32_t {
+    QN_PH_IDLE = 0,      // between qn_minimize calls / ready to start
+    QN_PH_REQ_EVAL = 1,  // evaluate the oracle at (req_kind, req_t)
+    QN_PH_REQ_HPASS = 2, // run h_pass with hp_nrhs right-hand sides
+    QN_PH_ITER_DONE = 3, // host callback wanted (ls_solver.rs:105-107)
+    QN_PH_DONE = 4       // finished: status holds the SolverError code
+};
+
+enum QnReqKind : int32_t { QN_REQ_X = 0 /* at x_k itself */, QN_REQ_T = 1 /* at x_k + t d_k */ };
+
+enum QnState : int32_t {
+    QN_ST_BEGIN = 0,
+    QN_ST_LOOP_TOP,
+    QN_ST_AFTER_EVALX,
+    QN_ST_CHECK,
+    QN_ST_AFTER_DIR,
+    QN_ST_LS_BEGIN,
+    QN_ST_MT_LOOP,
+    QN_ST_MT_AFTER_T,
+    QN_ST_MT_AFTER_TL,
+    QN_ST_MT_AFTER_TU,
+    QN_ST_MT_FINISH,
+    QN_ST_BT_LOOP,
+    QN_ST_BT_AFTER,
+    QN_ST_AFTER_LS,
+    QN_ST_AFTER_NEXT,
+    QN_ST_AFTER_U,
+    QN_ST_ITER_END
+};
+
+struct QnTraceRec { // == qn_trace_rec (include/qn_hip.h)
+    double f, gnorm, t, s_norm, y_norm;
+    int32_t n_evals, ls_iters, ls_cases, updated;
+};
+
+struct QnCtl {
+    // ---- configuration (written by the host before a run) ----
+    double tol;
+    int64_t max_iter, max_iter_ls;
+    int32_t method, ls_kind, memoize, callback_mode;
+    double mt_c1, mt_c2, mt_tmin, mt_tmax, mt_delta;
+    double bt_c1, bt_beta;
+    int64_t trace_cap;
+    int32_t trace_x, _pad0;
+
+    // ---- solver state ----
+    int32_t phase, state, status, after_state;
+    int64_t k;
+    int32_t has_s_norm, has_y_norm;
+    double s_norm, y_norm;
+    double f_k;   // f(x_k)
+    double gd0;   // g_k . d_k
+    double gnorm; // ||g_k||
+    int32_t have_cur_eval; // g / f_k hold the evaluation at the current x (memoised loop-top call)
+    int32_t have_dir;      // d / gd0 already hold the direction for the current x (lazy H+ g+)
+
+    // ---- request ----
+    int32_t req_kind, req_need_vectors;
+    double req_t;
+    int32_t hp_nrhs, hp_lazy;
+
+    // ---- pending symmetric rank-2 update: H_true = H_stored + c_su (sp up' + up sp') + c_ss sp sp' + c_uu up up'
+    int32_t pending, _pad1;
+    double c_ss, c_su, c_uu;
+
+    // ---- evaluation results / memo ----
+    double f_e, gd_e;            // result handed to the state machine
+    int32_t last_valid, d_finite; // (xt, gt, f_last, gd_last) hold the evaluation at x + last_t d
+    double last_t, f_last, gd_last;
+
+    // ---- line-search state ----
+    int64_t ls_i;
+    double t, tl, tu, ls_result;
+    int32_t use_mod, conv;
+    double phi_t_f, phi_t_g, psi_t_f, psi_t_g;
+    double sel_f_tl, sel_g_tl, sel_f_t, sel_g_t; // the (f_tl, g_tl, f_t, g_t) tuple of morethuente.rs:221-226
+    double ys;
+
+    // ---- per-iteration trace scratch ----
+    double tr_f, tr_gnorm;
+    int32_t tr_n_evals, tr_ls_iters, tr_ls_cases, tr_ndigits, tr_updated, _pad2;
+
+    // ---- counters ----
+    uint64_t n_oracle_calls, n_oracle_evals, n_hpasses, n_hpass_rw, n_iterations;
+};

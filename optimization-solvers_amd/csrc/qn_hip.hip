@@ -1,0 +1,916 @@
+// qn_hip.hip -- host side of libqn_hip.so: the C ABI of include/qn_hip.h, the request pump that drives the
+// device-resident state machine (qn_ctl.h), objectives, and the RCCL exchange for row-sharded runs.
+//
+// No CPU compute path exists here: every flop of the hot path runs in the kernels of qn_kernels.hip.h.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qn_hip.h"
+#include "qn_kernels.hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int status, const std::string& msg) {
+    g_err = msg;
+    return status;
+}
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess)                                                                              \
+            return fail(QN_ABNORMAL_TERMINATION, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+    } while (0)
+#define QNCHK(expr)                        \
+    do {                                   \
+        int _s = (expr);                   \
+        if (_s != QN_OK) return _s;        \
+    } while (0)
+
+extern "C" const char* qn_last_error_message(void) { return g_err.c_str(); }
+extern "C" int qn_abi_version(void) { return QN_ABI_VERSION; }
+extern "C" const char* qn_status_string(int status) {
+    switch (status) { // Display strings of ls_solver.rs:12-19
+    case QN_OK: return "Ok";
+    case QN_MAX_ITER_REACHED: return "Max iter reached";
+    case QN_OUT_OF_DOMAIN: return "Out of domain";
+    case QN_ERROR_INPUT_PARAMS: return "Error in input parameters";
+    case QN_ABNORMAL_TERMINATION: return "Abnormal termination";
+    default: return "Unknown status";
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, loaded lazily so the library itself has no link-time dependency on it
+// ------------------------------------------------------------------------------------------------
+struct RcclUniqueId { char internal[QN_UNIQUE_ID_BYTES]; };
+typedef void* RcclComm;
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+    int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static const int kRcclDouble = 8; // ncclFloat64 / ncclDouble (rccl.h)
+
+static int rccl_load() {
+    if (g_rccl.handle) return QN_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* nm : names) {
+        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(QN_ABNORMAL_TERMINATION, std::string("cannot load librccl: ") + dlerror());
+    g_rccl.GetUniqueId = (int (*)(RcclUniqueId*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(RcclComm*, int, RcclUniqueId, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (int (*)(RcclComm))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather)
+        return fail(QN_ABNORMAL_TERMINATION, "librccl is missing a required symbol");
+    g_rccl.handle = h;
+    return QN_OK;
+}
+#define RCCLCHK(expr)                                                                                             \
+    do {                                                                                                          \
+        int _r = (expr);                                                                                          \
+        if (_r != 0)                                                                                              \
+            return fail(QN_ABNORMAL_TERMINATION,                                                                  \
+                        std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error")); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct qn_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int rank = 0, world = 1;
+    RcclComm comm = nullptr;
+    qn_host_allgather_fn host_xchg = nullptr;
+    void* host_xchg_user = nullptr;
+    std::vector<double> xchg_send, xchg_recv;
+    uint64_t n_comm = 0;
+};
+
+extern "C" int qn_device_count(int* out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *out = 0; return fail(QN_ABNORMAL_TERMINATION, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *out = n;
+    return QN_OK;
+}
+
+static int context_base(int device, qn_context** out) {
+    if (!out) return fail(QN_ERROR_INPUT_PARAMS, "out is null");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(QN_ABNORMAL_TERMINATION, "no HIP device visible: libqn_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(QN_ERROR_INPUT_PARAMS, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    qn_context* c = new qn_context();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(QN_ABNORMAL_TERMINATION, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    *out = c;
+    return QN_OK;
+}
+
+extern "C" int qn_context_create(int device, qn_context** out) { return context_base(device, out); }
+
+extern "C" int qn_comm_unique_id(void* out_128_bytes) {
+    QNCHK(rccl_load());
+    RcclUniqueId id;
+    RCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(out_128_bytes, &id, sizeof(id));
+    return QN_OK;
+}
+
+extern "C" int qn_context_create_sharded(int device, int rank, int world, const void* unique_id, qn_context** out) {
+    if (world < 1 || rank < 0 || rank >= world) return fail(QN_ERROR_INPUT_PARAMS, "bad rank/world");
+    QNCHK(context_base(device, out));
+    qn_context* c = *out;
+    c->rank = rank;
+    c->world = world;
+    if (world > 1) {
+        if (!unique_id) { qn_context_destroy(c); *out = nullptr; return fail(QN_ERROR_INPUT_PARAMS, "unique_id is null"); }
+        int s = rccl_load();
+        if (s != QN_OK) { qn_context_destroy(c); *out = nullptr; return s; }
+        RcclUniqueId id;
+        memcpy(&id, unique_id, sizeof(id));
+        int r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+        if (r != 0) {
+            qn_context_destroy(c); *out = nullptr;
+            return fail(QN_ABNORMAL_TERMINATION, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+        }
+    }
+    return QN_OK;
+}
+
+extern "C" int qn_context_create_sharded_host_exchange(int device, int rank, int world, qn_host_allgather_fn fn, void* user,
+                                                       qn_context** out) {
+    if (world < 1 || rank < 0 || rank >= world) return fail(QN_ERROR_INPUT_PARAMS, "bad rank/world");
+    if (world > 1 && !fn) return fail(QN_ERROR_INPUT_PARAMS, "exchange function is null");
+    QNCHK(context_base(device, out));
+    (*out)->rank = rank;
+    (*out)->world = world;
+    (*out)->host_xchg = fn;
+    (*out)->host_xchg_user = user;
+    return QN_OK;
+}
+
+extern "C" void qn_context_destroy(qn_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" int qn_context_synchronize(qn_context* c) { HIPCHK(hipStreamSynchronize(c->stream)); return QN_OK; }
+extern "C" int qn_context_rank(const qn_context* c) { return c->rank; }
+extern "C" int qn_context_world(const qn_context* c) { return c->world; }
+extern "C" void* qn_context_stream(qn_context* c) { return (void*)c->stream; }
+
+// All-gather of `count` doubles per rank, in place: rank r's slice lives at buf + r*count.
+static int exchange(qn_context* c, double* buf, size_t count) {
+    if (c->world == 1) return QN_OK;
+    c->n_comm++;
+    if (c->comm) {
+        RCCLCHK(g_rccl.AllGather(buf + (size_t)c->rank * count, buf, count, kRcclDouble, c->comm, c->stream));
+        return QN_OK;
+    }
+    // host-staged exchange (tests / bring-up)
+    c->xchg_send.resize(count);
+    c->xchg_recv.resize(count * (size_t)c->world);
+    HIPCHK(hipMemcpyAsync(c->xchg_send.data(), buf + (size_t)c->rank * count, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->host_xchg(c->host_xchg_user, c->xchg_send.data(), c->xchg_recv.data(), count) != 0)
+        return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed");
+    HIPCHK(hipMemcpyAsync(buf, c->xchg_recv.data(), count * (size_t)c->world * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return QN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// partition: rank p owns rows [p*rpr, (p+1)*rpr); rpr is a multiple of 16 so every row tile is full
+// ------------------------------------------------------------------------------------------------
+static int part_rpr(size_t n, int world) {
+    size_t per = (n + (size_t)world - 1) / (size_t)world;
+    per = (per + 15) / 16 * 16;
+    if (per == 0) per = 16;
+    return (int)per;
+}
+static QnTile make_tile(size_t n, const qn_context* c, int cs) {
+    QnTile T;
+    T.n = (int)n;
+    T.rpr = part_rpr(n, c->world);
+    T.n_pad = T.rpr * c->world;
+    T.row_off = T.rpr * c->rank;
+    T.cs = cs;
+    T.rank = c->rank;
+    return T;
+}
+
+static int dev_alloc_zero(double** p, size_t count, hipStream_t st) {
+    HIPCHK(hipMalloc((void**)p, count * sizeof(double)));
+    HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(double), st));
+    return QN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// line-search parameter structs
+// ------------------------------------------------------------------------------------------------
+extern "C" void qn_morethuente_default(qn_linesearch* ls) { // morethuente.rs:16-28
+    memset(ls, 0, sizeof(*ls));
+    ls->kind = QN_LS_MORETHUENTE;
+    ls->c1 = 1e-4; ls->c2 = 0.9; ls->t_min = 0.0; ls->t_max = INFINITY;
+    ls->delta_min = 0.58333333; ls->delta = 0.66; ls->delta_max = 1.1;
+}
+extern "C" int qn_morethuente_with_deltas(qn_linesearch* ls, double dmin, double d, double dmax) {
+    ls->delta_min = dmin; ls->delta = d; ls->delta_max = dmax; return QN_OK;
+}
+extern "C" int qn_morethuente_with_t_min(qn_linesearch* ls, double t_min) { ls->t_min = t_min; return QN_OK; }
+extern "C" int qn_morethuente_with_t_max(qn_linesearch* ls, double t_max) { ls->t_max = t_max; return QN_OK; }
+extern "C" int qn_morethuente_with_c1(qn_linesearch* ls, double c1) { // asserts of morethuente.rs:51-52
+    if (!(c1 > 0.0)) return fail(QN_ERROR_INPUT_PARAMS, "c1 must be positive");
+    if (!(c1 < ls->c2)) return fail(QN_ERROR_INPUT_PARAMS, "c1 must be less than c2");
+    ls->c1 = c1; return QN_OK;
+}
+extern "C" int qn_morethuente_with_c2(qn_linesearch* ls, double c2) { // asserts of morethuente.rs:57-59
+    if (!(c2 > 0.0)) return fail(QN_ERROR_INPUT_PARAMS, "c2 must be positive");
+    if (!(c2 < 1.0)) return fail(QN_ERROR_INPUT_PARAMS, "c2 must be less than 1");
+    if (!(c2 > ls->c1)) return fail(QN_ERROR_INPUT_PARAMS, "c2 must be greater than c1");
+    ls->c2 = c2; return QN_OK;
+}
+extern "C" void qn_backtracking_new(qn_linesearch* ls, double c1, double beta) { // backtracking.rs:8-10
+    memset(ls, 0, sizeof(*ls));
+    ls->kind = QN_LS_BACKTRACKING;
+    ls->bt_c1 = c1; ls->bt_beta = beta;
+}
+
+// ------------------------------------------------------------------------------------------------
+// objectives
+// ------------------------------------------------------------------------------------------------
+enum { OBJ_QUADRATIC = 1, OBJ_LOGSUMEXP = 2 };
+struct qn_objective {
+    qn_context* ctx = nullptr;
+    int kind = 0;
+    size_t n = 0;
+    QnTile T{};
+    double* Q = nullptr; // this rank's rows, [rpr][n_pad]
+    double* b = nullptr; // n_pad
+    // scratch for qn_objective_eval
+    double *ex = nullptr, *eq = nullptr, *eg = nullptr, *ef = nullptr;
+};
+
+static int objective_base(qn_context* ctx, size_t n, const double* b_host, qn_objective** out) {
+    if (!ctx || !out || !b_host || n == 0) return fail(QN_ERROR_INPUT_PARAMS, "null argument or n == 0");
+    if (n > (size_t)1 << 30) return fail(QN_ERROR_INPUT_PARAMS, "n too large");
+    HIPCHK(hipSetDevice(ctx->device));
+    qn_objective* o = new qn_objective();
+    o->ctx = ctx;
+    o->kind = OBJ_QUADRATIC;
+    o->n = n;
+    o->T = make_tile(n, ctx, 1);
+    *out = o;
+    QNCHK(dev_alloc_zero(&o->Q, (size_t)o->T.rpr * o->T.n_pad, ctx->stream));
+    QNCHK(dev_alloc_zero(&o->b, o->T.n_pad, ctx->stream));
+    HIPCHK(hipMemcpyAsync(o->b, b_host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return QN_OK;
+}
+
+extern "C" int qn_quadratic_create(qn_context* ctx, size_t n, const double* q_host, const double* b_host, qn_objective** out) {
+    if (!q_host) return fail(QN_ERROR_INPUT_PARAMS, "q is null");
+    QNCHK(objective_base(ctx, n, b_host, out));
+    qn_objective* o = *out;
+    const size_t r0 = (size_t)o->T.row_off;
+    if (r0 < n) {
+        const size_t nr = std::min((size_t)o->T.rpr, n - r0);
+        HIPCHK(hipMemcpy2D(o->Q, (size_t)o->T.n_pad * sizeof(double), q_host + r0 * n, n * sizeof(double), n * sizeof(double), nr,
+                           hipMemcpyHostToDevice));
+    }
+    return QN_OK;
+}
+
+extern "C" int qn_quadratic_create_synthetic(qn_context* ctx, size_t n, uint64_t seed, const double* diag_host,
+                                             const double* b_host, qn_objective** out) {
+    if (!diag_host) return fail(QN_ERROR_INPUT_PARAMS, "diag is null");
+    QNCHK(objective_base(ctx, n, b_host, out));
+    qn_objective* o = *out;
+    double* diag = nullptr;
+    HIPCHK(hipMalloc((void**)&diag, n * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(diag, diag_host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(2048), dim3(256), 0, ctx->stream, o->Q, o->T, seed, diag, 1.0 / (double)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(diag));
+    return QN_OK;
+}
+
+extern "C" int qn_logsumexp_create(qn_context*, size_t, size_t, const double*, const double*, double, qn_objective**) {
+    return fail(QN_ERROR_INPUT_PARAMS, "log-sum-exp objective: not built yet (SURVEY.md 8(f) row f1)");
+}
+
+extern "C" void qn_objective_destroy(qn_objective* o) {
+    if (!o) return;
+    (void)hipSetDevice(o->ctx->device);
+    (void)hipFree(o->Q); (void)hipFree(o->b);
+    (void)hipFree(o->ex); (void)hipFree(o->eq); (void)hipFree(o->eg); (void)hipFree(o->ef);
+    delete o;
+}
+
+extern "C" int qn_objective_get_rows(qn_objective* o, size_t row0, size_t nrows, double* out_host) {
+    const size_t lo = (size_t)o->T.row_off, hi = std::min(o->n, lo + (size_t)o->T.rpr);
+    if (row0 < lo || row0 + nrows > hi) return fail(QN_ERROR_INPUT_PARAMS, "rows outside this rank's shard");
+    HIPCHK(hipSetDevice(o->ctx->device));
+    HIPCHK(hipMemcpy2D(out_host, o->n * sizeof(double), o->Q + (row0 - lo) * (size_t)o->T.n_pad, (size_t)o->T.n_pad * sizeof(double),
+                       o->n * sizeof(double), nrows, hipMemcpyDeviceToHost));
+    return QN_OK;
+}
+
+template <int R>
+static void launch_quad(hipStream_t st, const QnQuadArgs& a) {
+    dim3 grid(a.T.rpr / R, a.T.cs);
+    hipLaunchKernelGGL(quad_matvec_kernel<R>, grid, dim3(QN_TPB), 0, st, a);
+}
+static int launch_quad_R(int R, hipStream_t st, const QnQuadArgs& a) {
+    switch (R) {
+    case 4: launch_quad<4>(st, a); break;
+    case 16: launch_quad<16>(st, a); break;
+    default: launch_quad<8>(st, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    return QN_OK;
+}
+
+__global__ __launch_bounds__(QN_CTL_TPB) void quad_finish_kernel(const QnVecs V, double* f_out, double* g_out) {
+    __shared__ double lds[32];
+    double p[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < V.n_pad; i += QN_CTL_TPB) {
+        const double qi = q_val(V, i), xi = V.xt[i], bi = V.b[i];
+        p[0] = __builtin_fma(xi, qi, p[0]);
+        p[1] = __builtin_fma(bi, xi, p[1]);
+        g_out[i] = qi - bi;
+    }
+    ctl_block_sum<2>(p, lds);
+    if (threadIdx.x == 0) *f_out = 0.5 * p[0] - p[1];
+}
+
+extern "C" int qn_objective_eval(qn_objective* o, const double* x_host, double* f, double* g_host) {
+    qn_context* c = o->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (o->kind != OBJ_QUADRATIC) return fail(QN_ERROR_INPUT_PARAMS, "unsupported objective");
+    const size_t np = o->T.n_pad;
+    if (!o->ex) {
+        QNCHK(dev_alloc_zero(&o->ex, 2 * np, c->stream)); // x and xt
+        QNCHK(dev_alloc_zero(&o->eq, np, c->stream));
+        QNCHK(dev_alloc_zero(&o->eg, np, c->stream));
+        QNCHK(dev_alloc_zero(&o->ef, 2, c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(o->ex, x_host, o->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    QnQuadArgs a{};
+    a.Q = o->Q; a.T = o->T; a.x = o->ex; a.d = o->ex; a.xt = o->ex + np;
+    a.out = o->eq + (size_t)c->rank * o->T.rpr;
+    a.ctl = nullptr; a.expect_phase = -1; a.force_kind = QN_REQ_X; a.force_t = 0.0;
+    QNCHK(launch_quad_R(8, c->stream, a));
+    QNCHK(exchange(c, o->eq, (size_t)o->T.rpr));
+    QnVecs V{};
+    V.q = o->eq; V.xt = o->ex + np; V.b = o->b; V.n = (int)o->n; V.n_pad = (int)np; V.rpr = o->T.rpr; V.world = c->world; V.qcs = 1; V.hcs = 1;
+    hipLaunchKernelGGL(quad_finish_kernel, dim3(1), dim3(QN_CTL_TPB), 0, c->stream, V, o->ef, o->eg);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(f, o->ef, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(g_host, o->eg, o->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return QN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// solver
+// ------------------------------------------------------------------------------------------------
+enum { KC_HPASS = 0, KC_EVAL = 1, KC_CTL = 2, KC_COMM = 3, KC_COUNT = 4 };
+struct TimedEvent { hipEvent_t a, b; int cls; };
+
+struct qn_solver {
+    qn_context* ctx = nullptr;
+    int method = QN_BFGS;
+    size_t n = 0;
+    double tol = 0.0;
+    QnTile T{};
+    int R = 8, hcs = 1, qcs = 1;
+    double* H = nullptr;
+    double* vec_block = nullptr; // one allocation holding all n_pad vectors
+    QnVecs V{};
+    double* f_dev = nullptr;
+    QnCtl* ctl = nullptr;  // device
+    QnCtl* hctl = nullptr; // pinned host mirror
+    double *hx = nullptr, *hg = nullptr; // pinned staging for host oracles
+    size_t trace_cap = 0;
+    int trace_x = 0;
+    int sync_mode = -1; // -1 auto
+    int profiling = 0;
+    std::vector<TimedEvent> events;
+    std::vector<hipEvent_t> event_pool;
+    qn_stats stats{};
+};
+
+static hipEvent_t ev_get(qn_solver* s) {
+    if (!s->event_pool.empty()) { hipEvent_t e = s->event_pool.back(); s->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope { // brackets one launch (or one exchange) with events when profiling is on
+    qn_solver* s; int cls; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(qn_solver* s_, int cls_) : s(s_), cls(cls_) {
+        if (s->profiling && s->events.size() < 200000) { a = ev_get(s); b = ev_get(s); (void)hipEventRecord(a, s->ctx->stream); }
+    }
+    ~ProfScope() { if (a) { (void)hipEventRecord(b, s->ctx->stream); s->events.push_back({a, b, cls}); } }
+};
+static void prof_collect(qn_solver* s) {
+    if (s->events.empty()) return;
+    (void)hipStreamSynchronize(s->ctx->stream);
+    for (auto& e : s->events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            switch (e.cls) {
+            case KC_HPASS: s->stats.t_hpass_ms += ms; s->stats.n_hpass_timed++; break;
+            case KC_EVAL: s->stats.t_eval_ms += ms; s->stats.n_eval_timed++; break;
+            case KC_CTL: s->stats.t_ctl_ms += ms; s->stats.n_ctl_timed++; break;
+            default: s->stats.t_comm_ms += ms; s->stats.n_comm_timed++; break;
+            }
+        }
+        s->event_pool.push_back(e.a);
+        s->event_pool.push_back(e.b);
+    }
+    s->events.clear();
+}
+
+static int solver_alloc_hp(qn_solver* s) {
+    if (s->V.hp) { HIPCHK(hipFree(s->V.hp)); s->V.hp = nullptr; }
+    if (s->V.q) { HIPCHK(hipFree(s->V.q)); s->V.q = nullptr; }
+    QNCHK(dev_alloc_zero(&s->V.hp, (size_t)s->ctx->world * s->hcs * 2 * s->T.rpr, s->ctx->stream));
+    QNCHK(dev_alloc_zero(&s->V.q, (size_t)s->ctx->world * s->qcs * s->T.rpr, s->ctx->stream));
+    s->V.hcs = s->hcs;
+    s->V.qcs = s->qcs;
+    return QN_OK;
+}
+
+extern "C" int qn_solver_create(qn_context* ctx, int method, double tol, const double* x0_host, size_t n, qn_solver** out) {
+    if (!ctx || !x0_host || !out || n == 0) return fail(QN_ERROR_INPUT_PARAMS, "null argument or n == 0");
+    if (method != QN_BFGS && method != QN_DFP && method != QN_GRADIENT_DESCENT) return fail(QN_ERROR_INPUT_PARAMS, "unknown method");
+    if (n > (size_t)1 << 30) return fail(QN_ERROR_INPUT_PARAMS, "n too large");
+    HIPCHK(hipSetDevice(ctx->device));
+    qn_solver* s = new qn_solver();
+    *out = s;
+    s->ctx = ctx; s->method = method; s->n = n; s->tol = tol;
+    s->T = make_tile(n, ctx, 1);
+    const size_t np = s->T.n_pad;
+    hipStream_t st = ctx->stream;
+    if (method != QN_GRADIENT_DESCENT) {
+        QNCHK(dev_alloc_zero(&s->H, (size_t)s->T.rpr * np, st));
+        hipLaunchKernelGGL(identity_fill_kernel, dim3(2048), dim3(256), 0, st, s->H, s->T); // bfgs.rs:27-39: H = I
+        HIPCHK(hipGetLastError());
+    }
+    QNCHK(dev_alloc_zero(&s->vec_block, 9 * np, st));
+    double* p = s->vec_block;
+    s->V.x = p; s->V.g = p + np; s->V.d = p + 2 * np; s->V.xt = p + 3 * np; s->V.gt = p + 4 * np;
+    s->V.s = p + 5 * np; s->V.y = p + 6 * np; s->V.sp = p + 7 * np; s->V.up = p + 8 * np;
+    s->V.n = (int)n; s->V.n_pad = (int)np; s->V.rpr = s->T.rpr; s->V.world = ctx->world;
+    QNCHK(solver_alloc_hp(s));
+    QNCHK(dev_alloc_zero(&s->f_dev, 2, st));
+    s->V.f_dev = s->f_dev;
+    HIPCHK(hipMalloc((void**)&s->ctl, sizeof(QnCtl)));
+    HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(QnCtl), st));
+    HIPCHK(hipHostMalloc((void**)&s->hctl, sizeof(QnCtl), hipHostMallocDefault));
+    memset(s->hctl, 0, sizeof(QnCtl));
+    HIPCHK(hipHostMalloc((void**)&s->hx, n * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&s->hg, (n + 1) * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(s->V.x, x0_host, n * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return QN_OK;
+}
+
+extern "C" void qn_solver_destroy(qn_solver* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    for (auto& e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : s->event_pool) (void)hipEventDestroy(e);
+    (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
+    (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
+    (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
+    delete s;
+}
+
+extern "C" int qn_solver_set_trace(qn_solver* s, size_t cap, int with_x) {
+    HIPCHK(hipSetDevice(s->ctx->device));
+    if (s->V.trace) { HIPCHK(hipFree(s->V.trace)); s->V.trace = nullptr; }
+    if (s->V.xtrace) { HIPCHK(hipFree(s->V.xtrace)); s->V.xtrace = nullptr; }
+    s->trace_cap = cap;
+    s->trace_x = with_x && cap;
+    if (cap) {
+        HIPCHK(hipMalloc((void**)&s->V.trace, cap * sizeof(QnTraceRec)));
+        HIPCHK(hipMemset(s->V.trace, 0, cap * sizeof(QnTraceRec)));
+        if (with_x) QNCHK(dev_alloc_zero(&s->V.xtrace, cap * s->n, s->ctx->stream));
+    }
+    return QN_OK;
+}
+
+extern "C" int qn_solver_get_trace(qn_solver* s, qn_trace_rec* out_host, size_t cap, size_t* len, double* x_trace_host) {
+    HIPCHK(hipSetDevice(s->ctx->device));
+    size_t m = std::min<size_t>(std::min(cap, s->trace_cap), (size_t)s->hctl->n_iterations);
+    if (len) *len = m;
+    static_assert(sizeof(qn_trace_rec) == sizeof(QnTraceRec), "trace record layout");
+    if (m && out_host) HIPCHK(hipMemcpy(out_host, s->V.trace, m * sizeof(QnTraceRec), hipMemcpyDeviceToHost));
+    if (m && x_trace_host && s->V.xtrace) HIPCHK(hipMemcpy(x_trace_host, s->V.xtrace, m * s->n * sizeof(double), hipMemcpyDeviceToHost));
+    return QN_OK;
+}
+
+extern "C" int qn_solver_set_profiling(qn_solver* s, int on) { s->profiling = on; return QN_OK; }
+extern "C" int qn_solver_set_sync_mode(qn_solver* s, int sync) { s->sync_mode = sync; return QN_OK; }
+extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits) {
+    if (rows_per_block != 0 && rows_per_block != 4 && rows_per_block != 8 && rows_per_block != 16)
+        return fail(QN_ERROR_INPUT_PARAMS, "rows_per_block must be 4, 8 or 16");
+    if (col_splits < 0 || col_splits > 64) return fail(QN_ERROR_INPUT_PARAMS, "col_splits out of range");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    if (rows_per_block) s->R = rows_per_block;
+    if (col_splits) { s->hcs = col_splits; s->qcs = col_splits; }
+    return solver_alloc_hp(s);
+}
+
+extern "C" size_t qn_solver_n(const qn_solver* s) { return s->n; }
+extern "C" size_t qn_solver_k(const qn_solver* s) { return (size_t)s->hctl->k; }
+extern "C" double qn_solver_tol(const qn_solver* s) { return s->tol; }
+
+extern "C" int qn_solver_get_x(qn_solver* s, double* out) {
+    HIPCHK(hipSetDevice(s->ctx->device));
+    HIPCHK(hipMemcpyAsync(out, s->V.x, s->n * sizeof(double), hipMemcpyDeviceToHost, s->ctx->stream));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    return QN_OK;
+}
+
+static int poke_ctl(qn_solver* s) { // host mirror -> device
+    HIPCHK(hipMemcpyAsync(s->ctl, s->hctl, sizeof(QnCtl), hipMemcpyHostToDevice, s->ctx->stream));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    return QN_OK;
+}
+static int peek_ctl(qn_solver* s) { // device -> host mirror
+    HIPCHK(hipMemcpyAsync(s->hctl, s->ctl, sizeof(QnCtl), hipMemcpyDeviceToHost, s->ctx->stream));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    s->stats.host_syncs++;
+    return QN_OK;
+}
+
+extern "C" int qn_solver_set_x(qn_solver* s, const double* x_host) {
+    HIPCHK(hipSetDevice(s->ctx->device));
+    HIPCHK(hipMemcpyAsync(s->V.x, x_host, s->n * sizeof(double), hipMemcpyHostToDevice, s->ctx->stream));
+    s->hctl->have_cur_eval = 0; s->hctl->have_dir = 0; s->hctl->last_valid = 0;
+    return poke_ctl(s);
+}
+extern "C" int qn_solver_s_norm(qn_solver* s, double* out, int* is_some) {
+    if (is_some) *is_some = s->hctl->has_s_norm;
+    if (out) *out = s->hctl->s_norm;
+    return QN_OK;
+}
+extern "C" int qn_solver_y_norm(qn_solver* s, double* out, int* is_some) {
+    if (is_some) *is_some = s->hctl->has_y_norm;
+    if (out) *out = s->hctl->y_norm;
+    return QN_OK;
+}
+extern "C" int qn_solver_next_iterate_too_close(qn_solver* s, int* out) { // bfgs.rs:15-20
+    *out = s->hctl->has_s_norm && s->hctl->s_norm < s->tol;
+    return QN_OK;
+}
+extern "C" int qn_solver_gradient_next_iterate_too_close(qn_solver* s, int* out) { // bfgs.rs:21-26
+    *out = s->hctl->has_y_norm && s->hctl->y_norm < s->tol;
+    return QN_OK;
+}
+
+// ---- launches ----
+template <int R>
+static void launch_hpass(hipStream_t st, const QnHPassArgs& a) {
+    dim3 grid(a.T.rpr / R, a.T.cs);
+    hipLaunchKernelGGL(h_pass_kernel<R>, grid, dim3(QN_TPB), 0, st, a);
+}
+static int launch_hpass_R(qn_solver* s, const QnHPassArgs& a) {
+    ProfScope ps(s, KC_HPASS);
+    switch (s->R) {
+    case 4: launch_hpass<4>(s->ctx->stream, a); break;
+    case 16: launch_hpass<16>(s->ctx->stream, a); break;
+    default: launch_hpass<8>(s->ctx->stream, a); break;
+    }
+    s->stats.launches++;
+    HIPCHK(hipGetLastError());
+    return QN_OK;
+}
+
+static QnHPassArgs hpass_args(qn_solver* s, int expect_phase) {
+    QnHPassArgs a{};
+    a.H = s->H;
+    a.T = s->T; a.T.cs = s->hcs;
+    a.sp = s->V.sp; a.up = s->V.up;
+    a.vy = s->V.y; a.vg = s->V.g;
+    a.r0 = nullptr; a.r1 = nullptr;
+    a.hp = s->V.hp;
+    a.ctl = s->ctl;
+    a.expect_phase = expect_phase;
+    return a;
+}
+
+static int flush_pending(qn_solver* s) { // H_stored <- H_true
+    if (!s->H || !s->hctl->pending) return QN_OK;
+    QnHPassArgs a = hpass_args(s, -1);
+    a.force_nrhs = 0; a.force_pending = 1;
+    a.c_ss = s->hctl->c_ss; a.c_su = s->hctl->c_su; a.c_uu = s->hctl->c_uu;
+    QNCHK(launch_hpass_R(s, a));
+    s->hctl->pending = 0;
+    return poke_ctl(s);
+}
+
+extern "C" int qn_solver_get_inv_hessian(qn_solver* s, double* out, int all_ranks) {
+    if (!s->H) return fail(QN_ERROR_INPUT_PARAMS, "gradient descent keeps no inverse Hessian");
+    qn_context* c = s->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    QNCHK(flush_pending(s));
+    const size_t n = s->n, np = s->T.n_pad, rpr = s->T.rpr;
+    const size_t chunk = 16;
+    std::vector<double> rows(chunk * np * (all_ranks ? c->world : 1));
+    double* tmp = nullptr;
+    if (all_ranks && c->world > 1) HIPCHK(hipMalloc((void**)&tmp, (size_t)c->world * chunk * np * sizeof(double)));
+    for (size_t r0 = 0; r0 < rpr; r0 += chunk) {
+        if (all_ranks && c->world > 1) {
+            HIPCHK(hipMemcpyAsync(tmp + (size_t)c->rank * chunk * np, s->H + r0 * np, chunk * np * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            QNCHK(exchange(c, tmp, chunk * np));
+            HIPCHK(hipMemcpyAsync(rows.data(), tmp, (size_t)c->world * chunk * np * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (int p = 0; p < c->world; ++p)
+                for (size_t r = 0; r < chunk; ++r) {
+                    const size_t i = (size_t)p * rpr + r0 + r;
+                    if (i >= n) continue;
+                    const double* row = rows.data() + ((size_t)p * chunk + r) * np;
+                    for (size_t j = 0; j < n; ++j) out[i + j * n] = row[j];
+                }
+        } else {
+            HIPCHK(hipMemcpyAsync(rows.data(), s->H + r0 * np, chunk * np * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (size_t r = 0; r < chunk; ++r) {
+                const size_t i = (size_t)s->T.row_off + r0 + r;
+                if (i >= n) continue;
+                const double* row = rows.data() + r * np;
+                for (size_t j = 0; j < n; ++j) out[i + j * n] = row[j];
+            }
+        }
+    }
+    if (tmp) HIPCHK(hipFree(tmp));
+    return QN_OK;
+}
+
+extern "C" int qn_solver_set_inv_hessian(qn_solver* s, const double* h) {
+    if (!s->H) return fail(QN_ERROR_INPUT_PARAMS, "gradient descent keeps no inverse Hessian");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    const size_t n = s->n, np = s->T.n_pad;
+    std::vector<double> rows((size_t)s->T.rpr * np, 0.0);
+    for (size_t r = 0; r < (size_t)s->T.rpr; ++r) {
+        const size_t i = (size_t)s->T.row_off + r;
+        if (i >= n) break;
+        for (size_t j = 0; j < n; ++j) rows[r * np + j] = h[i + j * n];
+    }
+    HIPCHK(hipMemcpy(s->H, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
+    s->hctl->pending = 0; s->hctl->have_dir = 0;
+    return poke_ctl(s);
+}
+
+extern "C" int qn_solver_get_stats(qn_solver* s, qn_stats* out) {
+    HIPCHK(hipSetDevice(s->ctx->device));
+    prof_collect(s);
+    *out = s->stats;
+    return QN_OK;
+}
+
+// ---- the pump ----
+struct Run {
+    qn_solver* s;
+    const qn_oracle* o;
+    qn_objective* obj;
+    int oracle_tpl; // QN_ORACLE_GENERIC / QN_ORACLE_QUAD
+};
+
+static int launch_ctl(Run& r, int expect_phase) {
+    qn_solver* s = r.s;
+    ProfScope ps(s, KC_CTL);
+    if (r.oracle_tpl == QN_ORACLE_QUAD)
+        hipLaunchKernelGGL(ctl_step_kernel<QN_ORACLE_QUAD>, dim3(1), dim3(QN_CTL_TPB), 0, s->ctx->stream, s->ctl, s->V, expect_phase);
+    else
+        hipLaunchKernelGGL(ctl_step_kernel<QN_ORACLE_GENERIC>, dim3(1), dim3(QN_CTL_TPB), 0, s->ctx->stream, s->ctl, s->V, expect_phase);
+    s->stats.launches++;
+    HIPCHK(hipGetLastError());
+    return QN_OK;
+}
+
+// enqueue the evaluation of the oracle at the requested point (predicated on phase == REQ_EVAL)
+static int enqueue_eval(Run& r) {
+    qn_solver* s = r.s;
+    qn_context* c = s->ctx;
+    if (r.oracle_tpl == QN_ORACLE_QUAD) {
+        QnQuadArgs a{};
+        a.Q = r.obj->Q; a.T = s->T; a.T.cs = s->qcs;
+        a.x = s->V.x; a.d = s->V.d; a.xt = s->V.xt;
+        a.out = s->V.q + (size_t)c->rank * s->qcs * s->T.rpr;
+        a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_EVAL;
+        {
+            ProfScope ps(s, KC_EVAL);
+            QNCHK(launch_quad_R(s->R, c->stream, a));
+            s->stats.launches++;
+        }
+        if (c->world > 1) {
+            ProfScope ps(s, KC_COMM);
+            QNCHK(exchange(c, s->V.q, (size_t)s->qcs * s->T.rpr));
+        }
+        return QN_OK;
+    }
+    hipLaunchKernelGGL(trial_point_kernel, dim3(std::min(1024, (s->T.n_pad + 255) / 256)), dim3(256), 0, c->stream, s->V.x, s->V.d,
+                       s->V.xt, s->T.n_pad, s->ctl, (int)QN_PH_REQ_EVAL);
+    s->stats.launches++;
+    HIPCHK(hipGetLastError());
+    if (r.o->kind == QN_ORACLE_HOST) {
+        HIPCHK(hipMemcpyAsync(s->hx, s->V.xt, s->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        s->stats.host_syncs++;
+        double f = NAN;
+        if (r.o->host_fn(r.o->host_user, s->hx, s->n, &f, s->hg) != 0) return fail(QN_ABNORMAL_TERMINATION, "host oracle returned non-zero");
+        s->hg[s->n] = f; // pinned staging: g[0..n) then f
+        HIPCHK(hipMemcpyAsync(s->V.gt, s->hg, s->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(s->f_dev, s->hg + s->n, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return QN_OK;
+    }
+    // device closure
+    if (r.o->device_fn(r.o->device_user, (void*)c->stream, s->V.xt, s->n, s->f_dev, s->V.gt) != 0)
+        return fail(QN_ABNORMAL_TERMINATION, "device oracle returned non-zero");
+    return QN_OK;
+}
+
+static int enqueue_hpass_req(Run& r) {
+    qn_solver* s = r.s;
+    qn_context* c = s->ctx;
+    QnHPassArgs a = hpass_args(s, QN_PH_REQ_HPASS);
+    {
+        ProfScope ps(s, KC_HPASS);
+        QNCHK(launch_hpass_R(s, a));
+    }
+    if (c->world > 1) {
+        ProfScope ps(s, KC_COMM);
+        QNCHK(exchange(c, s->V.hp, (size_t)s->hcs * 2 * s->T.rpr));
+    }
+    return QN_OK;
+}
+
+extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracle* o, size_t max_iter_solver,
+                           size_t max_iter_line_search, qn_callback_fn callback, void* callback_user) {
+    if (!s || !ls || !o) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
+    qn_context* c = s->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    Run r{s, o, nullptr, QN_ORACLE_GENERIC};
+    if (o->kind == QN_ORACLE_OBJECTIVE) {
+        if (!o->objective) return fail(QN_ERROR_INPUT_PARAMS, "objective is null");
+        if (o->objective->ctx != c || o->objective->n != s->n) return fail(QN_ERROR_INPUT_PARAMS, "objective does not match the solver");
+        r.obj = o->objective;
+        if (r.obj->kind == OBJ_QUADRATIC) { r.oracle_tpl = QN_ORACLE_QUAD; s->V.b = r.obj->b; }
+        else return fail(QN_ERROR_INPUT_PARAMS, "unsupported objective");
+    } else if (o->kind == QN_ORACLE_HOST) {
+        if (!o->host_fn) return fail(QN_ERROR_INPUT_PARAMS, "host oracle is null");
+    } else if (o->kind == QN_ORACLE_DEVICE_FN) {
+        if (!o->device_fn) return fail(QN_ERROR_INPUT_PARAMS, "device oracle is null");
+    } else return fail(QN_ERROR_INPUT_PARAMS, "unknown oracle kind");
+    if (ls->kind != QN_LS_MORETHUENTE && ls->kind != QN_LS_BACKTRACKING) return fail(QN_ERROR_INPUT_PARAMS, "unknown line search");
+
+    // configuration -> control block (state carried over from earlier runs: x, H, pending update, s_norm, y_norm)
+    QnCtl* h = s->hctl;
+    h->tol = s->tol;
+    h->max_iter = (int64_t)std::min<size_t>(max_iter_solver, (size_t)1 << 62);
+    h->max_iter_ls = (int64_t)std::min<size_t>(max_iter_line_search, (size_t)1 << 62);
+    h->method = s->method;
+    h->ls_kind = ls->kind;
+    h->memoize = o->memoize ? 1 : 0;
+    h->callback_mode = callback ? 1 : 0;
+    h->mt_c1 = ls->c1; h->mt_c2 = ls->c2; h->mt_tmin = ls->t_min; h->mt_tmax = ls->t_max; h->mt_delta = ls->delta;
+    h->bt_c1 = ls->bt_c1; h->bt_beta = ls->bt_beta;
+    h->trace_cap = (int64_t)s->trace_cap;
+    h->trace_x = s->trace_x;
+    h->phase = QN_PH_IDLE;
+    h->status = -1;
+    QNCHK(poke_ctl(s));
+
+    const bool can_pipeline = (o->kind != QN_ORACLE_HOST) && !callback && !(c->world > 1 && !c->comm);
+    const bool sync = s->sync_mode == 1 || (s->sync_mode == -1 && !(can_pipeline && o->memoize)) || !can_pipeline;
+
+    QNCHK(launch_ctl(r, QN_PH_IDLE));
+    int status = QN_ABNORMAL_TERMINATION;
+    if (sync) {
+        for (;;) {
+            QNCHK(peek_ctl(s));
+            const int ph = h->phase;
+            if (ph == QN_PH_DONE) { status = h->status; break; }
+            if (ph == QN_PH_REQ_EVAL) { QNCHK(enqueue_eval(r)); QNCHK(launch_ctl(r, QN_PH_REQ_EVAL)); }
+            else if (ph == QN_PH_REQ_HPASS) { QNCHK(enqueue_hpass_req(r)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS)); }
+            else if (ph == QN_PH_ITER_DONE) { callback(callback_user, s); QNCHK(launch_ctl(r, QN_PH_ITER_DONE)); }
+            else return fail(QN_ABNORMAL_TERMINATION, "control block in an unexpected phase");
+        }
+    } else {
+        // pipelined: every kernel is predicated on the control block, so a fixed pattern can be enqueued ahead
+        // of the decisions; one period = [eval, step] x slots, [h_pass, step], and advances at most one iteration.
+        const int slots = (ls->kind == QN_LS_MORETHUENTE) ? 2 : 4;
+        const int gd = s->method == QN_GRADIENT_DESCENT;
+        for (;;) {
+            QNCHK(peek_ctl(s));
+            if (h->phase == QN_PH_DONE) { status = h->status; break; }
+            int64_t remaining = h->max_iter - h->k;
+            if (remaining < 1) remaining = 1;
+            const int64_t periods = std::min<int64_t>(remaining, 256);
+            for (int64_t p = 0; p < periods; ++p) {
+                for (int e = 0; e < slots; ++e) { QNCHK(enqueue_eval(r)); QNCHK(launch_ctl(r, QN_PH_REQ_EVAL)); }
+                if (!gd) { QNCHK(enqueue_hpass_req(r)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS)); }
+            }
+        }
+    }
+    s->stats.iterations = h->n_iterations;
+    s->stats.oracle_calls = h->n_oracle_calls;
+    s->stats.oracle_evals = h->n_oracle_evals;
+    s->stats.h_passes = h->n_hpasses;
+    const uint64_t shard = (uint64_t)s->T.rpr * (uint64_t)s->T.n_pad * 8ull;
+    s->stats.h_bytes = (h->n_hpasses + h->n_hpass_rw) * shard;
+    s->stats.obj_bytes = (r.oracle_tpl == QN_ORACLE_QUAD) ? h->n_oracle_evals * shard : 0;
+    if (status == QN_ABNORMAL_TERMINATION) return fail(status, "solver state machine aborted");
+    return status;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel-level FFI
+// ------------------------------------------------------------------------------------------------
+extern "C" int qn_dev_alloc(qn_context* c, size_t bytes, void** out) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipMalloc(out, bytes)); return QN_OK; }
+extern "C" int qn_dev_free(qn_context* c, void* p) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipFree(p)); return QN_OK; }
+extern "C" int qn_h2d(qn_context* c, void* dst, const void* src, size_t bytes) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return QN_OK;
+}
+extern "C" int qn_d2h(qn_context* c, void* dst, const void* src, size_t bytes) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return QN_OK;
+}
+extern "C" int qn_gemv(qn_context* c, const double* a, size_t ld, size_t nrows, size_t ncols, const double* x, double* y) {
+    HIPCHK(hipSetDevice(c->device));
+    if (nrows == 0) return QN_OK;
+    hipLaunchKernelGGL(prim_gemv_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, a, ld, (int)nrows, (int)ncols, x, y);
+    HIPCHK(hipGetLastError());
+    return QN_OK;
+}
+extern "C" int qn_rank2_update(qn_context* c, double* h, size_t ld, size_t row0, size_t nrows, size_t n, const double* s_dev,
+                               const double* u_dev, double c_ss, double c_su, double c_uu) {
+    HIPCHK(hipSetDevice(c->device));
+    if (nrows == 0 || n == 0) return QN_OK;
+    dim3 grid((unsigned)std::min<size_t>((n + 255) / 256, 64), (unsigned)nrows);
+    hipLaunchKernelGGL(prim_rank2_kernel, grid, dim3(256), 0, c->stream, h, ld, (int)row0, (int)nrows, (int)n, s_dev, u_dev, c_ss, c_su, c_uu);
+    HIPCHK(hipGetLastError());
+    return QN_OK;
+}
+extern "C" int qn_axpy(qn_context* c, size_t n, const double* x, double t, const double* d, double* out) {
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0) return QN_OK;
+    hipLaunchKernelGGL(prim_axpy_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, c->stream, (int)n, x, t, d, out);
+    HIPCHK(hipGetLastError());
+    return QN_OK;
+}
+extern "C" int qn_dot(qn_context* c, size_t n, const double* a, const double* b, double* out_host) {
+    HIPCHK(hipSetDevice(c->device));
+    double* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, sizeof(double)));
+    hipLaunchKernelGGL(prim_dot_kernel, dim3(1), dim3(QN_CTL_TPB), 0, c->stream, (int)n, a, b, tmp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_host, tmp, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(tmp));
+    return QN_OK;
+}
+extern "C" int qn_nrm2(qn_context* c, size_t n, const double* a, double* out_host) { // norm = sqrt(dot(a, a)), bfgs.rs:74,97,99
+    double d = 0.0;
+    QNCHK(qn_dot(c, n, a, a, &d));
+    *out_host = std::sqrt(d);
+    return QN_OK;
+}

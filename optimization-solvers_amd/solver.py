@@ -1,0 +1,451 @@
+"""Host-side mirror of the reference's trait surface over the C ABI (include/qn_hip.h).
+
+Names, argument meaning and error behaviour follow the Rust crate so the parity tests read like the
+reference's own tests:
+
+    BFGS::new(tol, x0)                          -> BFGS(tol, x0)                      (bfgs.rs:27-39)
+    MoreThuente::default().with_c1(..)          -> MoreThuente().with_c1(..)          (morethuente.rs:16-62)
+    BackTracking::new(c1, beta)                 -> BackTracking(c1, beta)             (backtracking.rs:8-10)
+    solver.minimize(&mut ls, oracle, a, b, cb)  -> solver.minimize(ls, oracle, a, b, callback)   (ls_solver.rs:66-111)
+    Result<(), SolverError>                     -> returns None / raises SolverError  (ls_solver.rs:10-20)
+    FuncEvalMultivariate::new(f, g)             -> FuncEvalMultivariate(f, g) or a plain (f, g) tuple (func_eval.rs:4-41)
+
+Everything numeric happens in libqn_hip.so on the GPU; this file only marshals.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+
+
+class SolverError(Exception):
+    """ls_solver.rs:10-20"""
+    code = A.ABNORMAL_TERMINATION
+
+    def __init__(self, msg=None):
+        super().__init__(msg or A.lib().qn_status_string(self.code).decode())
+
+
+class MaxIterReached(SolverError):
+    code = A.MAX_ITER_REACHED
+
+
+class OutOfDomain(SolverError):
+    code = A.OUT_OF_DOMAIN
+
+
+class ErrorInputParams(SolverError):
+    code = A.ERROR_INPUT_PARAMS
+
+
+class AbnormalTermination(SolverError):
+    code = A.ABNORMAL_TERMINATION
+
+
+_ERRORS = {A.MAX_ITER_REACHED: MaxIterReached, A.OUT_OF_DOMAIN: OutOfDomain, A.ERROR_INPUT_PARAMS: ErrorInputParams,
+           A.ABNORMAL_TERMINATION: AbnormalTermination}
+
+
+def _check(status):
+    if status == A.OK:
+        return
+    detail = A.lib().qn_last_error_message().decode()
+    cls = _ERRORS.get(status, AbnormalTermination)
+    if status in (A.ERROR_INPUT_PARAMS, A.ABNORMAL_TERMINATION) and detail:
+        raise cls(f"{A.lib().qn_status_string(status).decode()}: {detail}")
+    raise cls()
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(A.dp)
+
+
+class FuncEvalMultivariate:
+    """func_eval.rs:4-41 (f, g; the optional Hessian is not used on this path)."""
+
+    def __init__(self, f, g):
+        self._f, self._g = float(f), np.asarray(g, dtype=np.float64)
+
+    def f(self):
+        return self._f
+
+    def g(self):
+        return self._g
+
+    def __iter__(self):
+        return iter((self._f, self._g))
+
+
+class Context:
+    """One GPU (+ optionally one rank of a row-sharded group)."""
+
+    def __init__(self, device=0, rank=0, world=1, unique_id=None, host_allgather=None):
+        L = A.lib()
+        self.h = C.c_void_p()
+        self._keep = None
+        if world == 1:
+            _check(L.qn_context_create(device, C.byref(self.h)))
+        elif host_allgather is not None:
+            def tramp(_u, send, recv, count):
+                s = np.ctypeslib.as_array(send, shape=(count,))
+                r = np.ctypeslib.as_array(recv, shape=(count * world,))
+                try:
+                    host_allgather(s, r)
+                    return 0
+                except Exception:  # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._keep = A.HOST_ALLGATHER_FN(tramp)
+            _check(L.qn_context_create_sharded_host_exchange(device, rank, world, C.cast(self._keep, C.c_void_p), None, C.byref(self.h)))
+        else:
+            buf = C.create_string_buffer(bytes(unique_id), A.UNIQUE_ID_BYTES)
+            _check(L.qn_context_create_sharded(device, rank, world, buf, C.byref(self.h)))
+        self.rank, self.world, self.device = rank, world, device
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(A.UNIQUE_ID_BYTES)
+        _check(A.lib().qn_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def synchronize(self):
+        _check(A.lib().qn_context_synchronize(self.h))
+
+    def close(self):
+        if self.h:
+            A.lib().qn_context_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class MoreThuente:
+    """morethuente.rs:6-62"""
+
+    def __init__(self):
+        self.s = A.LineSearchStruct()
+        A.lib().qn_morethuente_default(C.byref(self.s))
+
+    @classmethod
+    def default(cls):
+        return cls()
+
+    def with_deltas(self, delta_min, delta, delta_max):
+        _check(A.lib().qn_morethuente_with_deltas(C.byref(self.s), delta_min, delta, delta_max))
+        return self
+
+    def with_t_min(self, t_min):
+        _check(A.lib().qn_morethuente_with_t_min(C.byref(self.s), t_min))
+        return self
+
+    def with_t_max(self, t_max):
+        _check(A.lib().qn_morethuente_with_t_max(C.byref(self.s), t_max))
+        return self
+
+    def with_c1(self, c1):
+        _check(A.lib().qn_morethuente_with_c1(C.byref(self.s), c1))
+        return self
+
+    def with_c2(self, c2):
+        _check(A.lib().qn_morethuente_with_c2(C.byref(self.s), c2))
+        return self
+
+
+class BackTracking:
+    """backtracking.rs:3-11"""
+
+    def __init__(self, c1, beta):
+        self.s = A.LineSearchStruct()
+        A.lib().qn_backtracking_new(C.byref(self.s), c1, beta)
+
+    @classmethod
+    def new(cls, c1, beta):
+        return cls(c1, beta)
+
+
+class Objective:
+    """A device-resident objective owned by the library."""
+
+    def __init__(self, ctx, handle, n):
+        self.ctx, self.h, self.n = ctx, handle, n
+
+    def __call__(self, x):
+        x = _f64(x)
+        g = np.empty(self.n)
+        f = C.c_double()
+        _check(A.lib().qn_objective_eval(self.h, _dp(x), C.byref(f), _dp(g)))
+        return FuncEvalMultivariate(f.value, g)
+
+    def rows(self, row0, nrows):
+        out = np.empty((nrows, self.n))
+        _check(A.lib().qn_objective_get_rows(self.h, row0, nrows, _dp(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            A.lib().qn_objective_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Quadratic(Objective):
+    """f = 1/2 x'Qx - b'x on the device."""
+
+    def __init__(self, q, b, ctx=None):
+        ctx = ctx or default_context()
+        q, b = _f64(q), _f64(b)
+        h = C.c_void_p()
+        _check(A.lib().qn_quadratic_create(ctx.h, b.size, _dp(q), _dp(b), C.byref(h)))
+        super().__init__(ctx, h, b.size)
+
+    @classmethod
+    def synthetic(cls, n, seed, diag, b, ctx=None):
+        ctx = ctx or default_context()
+        diag, b = _f64(diag), _f64(b)
+        h = C.c_void_p()
+        _check(A.lib().qn_quadratic_create_synthetic(ctx.h, n, seed, _dp(diag), _dp(b), C.byref(h)))
+        self = cls.__new__(cls)
+        Objective.__init__(self, ctx, h, n)
+        return self
+
+
+class _SolverBase:
+    METHOD = None
+
+    def __init__(self, tol, x0, ctx=None):
+        self.ctx = ctx or default_context()
+        x0 = _f64(x0)
+        self.n = x0.size
+        self.h = C.c_void_p()
+        _check(A.lib().qn_solver_create(self.ctx.h, self.METHOD, tol, _dp(x0), x0.size, C.byref(self.h)))
+        self.memoize = None  # None: 1 for device objectives, 0 for host closures
+        self._trace_cap = 0
+
+    @classmethod
+    def new(cls, tol, x0, ctx=None):
+        return cls(tol, x0, ctx)
+
+    def close(self):
+        if getattr(self, "h", None):
+            A.lib().qn_solver_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ---- LineSearchSolver::minimize (ls_solver.rs:66-111) ----
+    def minimize(self, line_search, oracle, max_iter_solver, max_iter_line_search, callback=None):
+        L = A.lib()
+        o = A.OracleStruct()
+        keep = []
+        if isinstance(oracle, Objective):
+            o.kind = A.ORACLE_OBJECTIVE
+            o.objective = oracle.h
+            o.memoize = 1 if self.memoize is None else int(self.memoize)
+        else:
+            n = self.n
+            err = []
+
+            def tramp(_u, xp, nn, fp, gp):
+                try:
+                    x = np.ctypeslib.as_array(xp, shape=(nn,)).copy()
+                    res = oracle(x)
+                    f, g = (res.f(), res.g()) if isinstance(res, FuncEvalMultivariate) else res
+                    fp[0] = float(f)
+                    np.ctypeslib.as_array(gp, shape=(nn,))[:] = np.asarray(g, dtype=np.float64)
+                    return 0
+                except Exception as e:  # noqa: BLE001 -- a panicking closure aborts the run
+                    err.append(e)
+                    return 1
+            cfn = A.HOST_ORACLE_FN(tramp)
+            keep.append(cfn)
+            o.kind = A.ORACLE_HOST
+            o.host_fn = C.cast(cfn, C.c_void_p)
+            o.memoize = 0 if self.memoize is None else int(self.memoize)
+        cb = None
+        if callback is not None:
+            cb = A.CALLBACK_FN(lambda _u, _s: callback(self))
+            keep.append(cb)
+        status = L.qn_minimize(self.h, C.byref(line_search.s), C.byref(o), max_iter_solver, max_iter_line_search,
+                               C.cast(cb, C.c_void_p) if cb else None, None)
+        if not isinstance(oracle, Objective) and err:
+            raise err[0]
+        _check(status)
+
+    # ---- getters (derive_getters, bfgs.rs:3-12 ; LineSearchSolver::xk/k, bfgs.rs:52-63) ----
+    def x(self):
+        out = np.empty(self.n)
+        _check(A.lib().qn_solver_get_x(self.h, _dp(out)))
+        return out
+
+    xk = x
+
+    def set_x(self, x):
+        x = _f64(x)
+        _check(A.lib().qn_solver_set_x(self.h, _dp(x)))
+
+    def k(self):
+        return A.lib().qn_solver_k(self.h)
+
+    def tol(self):
+        return A.lib().qn_solver_tol(self.h)
+
+    def _opt(self, fn):
+        v, some = C.c_double(), C.c_int()
+        _check(fn(self.h, C.byref(v), C.byref(some)))
+        return v.value if some.value else None
+
+    def s_norm(self):
+        return self._opt(A.lib().qn_solver_s_norm)
+
+    def y_norm(self):
+        return self._opt(A.lib().qn_solver_y_norm)
+
+    def next_iterate_too_close(self):
+        v = C.c_int()
+        _check(A.lib().qn_solver_next_iterate_too_close(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def gradient_next_iterate_too_close(self):
+        v = C.c_int()
+        _check(A.lib().qn_solver_gradient_next_iterate_too_close(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def has_converged(self, eval_x_k):
+        """bfgs.rs:64-76 evaluated on a host FuncEval (used by the reference's tests after minimize)."""
+        if self.next_iterate_too_close() or self.gradient_next_iterate_too_close():
+            return True
+        g = eval_x_k.g() if isinstance(eval_x_k, FuncEvalMultivariate) else eval_x_k[1]
+        return float(np.sqrt(np.dot(g, g))) < self.tol()
+
+    def approx_inv_hessian(self, all_ranks=True):
+        out = np.zeros((self.n, self.n), order="F")
+        _check(A.lib().qn_solver_get_inv_hessian(self.h, out.ctypes.data_as(A.dp), 1 if all_ranks else 0))
+        return np.ascontiguousarray(out)
+
+    def set_approx_inv_hessian(self, h):
+        a = np.asfortranarray(h, dtype=np.float64)
+        _check(A.lib().qn_solver_set_inv_hessian(self.h, a.ctypes.data_as(A.dp)))
+
+    # ---- instrumentation ----
+    def set_trace(self, cap, with_x=False):
+        self._trace_cap = cap
+        self._trace_x = with_x
+        _check(A.lib().qn_solver_set_trace(self.h, cap, 1 if with_x else 0))
+
+    def trace(self):
+        cap = self._trace_cap
+        recs = (A.TraceRec * max(cap, 1))()
+        ln = C.c_size_t()
+        xs = np.zeros((max(cap, 1), self.n)) if getattr(self, "_trace_x", False) else None
+        _check(A.lib().qn_solver_get_trace(self.h, recs, cap, C.byref(ln), _dp(xs) if xs is not None else None))
+        out = [dict(f=r.f, gnorm=r.gnorm, t=r.t, s_norm=r.s_norm, y_norm=r.y_norm, n_evals=r.n_evals, ls_iters=r.ls_iters,
+                    ls_cases=r.ls_cases, updated=r.updated) for r in recs[:ln.value]]
+        return out, (xs[:ln.value] if xs is not None else None)
+
+    def stats(self):
+        st = A.Stats()
+        _check(A.lib().qn_solver_get_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in A.Stats._fields_}
+
+    def set_profiling(self, on):
+        _check(A.lib().qn_solver_set_profiling(self.h, 1 if on else 0))
+
+    def set_sync_mode(self, sync):
+        _check(A.lib().qn_solver_set_sync_mode(self.h, int(sync)))
+
+    def set_tiling(self, rows_per_block=0, col_splits=0):
+        _check(A.lib().qn_solver_set_tiling(self.h, rows_per_block, col_splits))
+
+
+class BFGS(_SolverBase):
+    """quasi_newton/bfgs.rs"""
+    METHOD = A.BFGS
+
+
+class DFP(_SolverBase):
+    """quasi_newton/dfp.rs"""
+    METHOD = A.DFP
+
+
+class GradientDescent(_SolverBase):
+    """steepest_descent/gradient_descent.rs (config-1 plumbing)"""
+    METHOD = A.GRADIENT_DESCENT
+
+    def has_converged(self, eval_x_k):
+        g = eval_x_k.g() if isinstance(eval_x_k, FuncEvalMultivariate) else eval_x_k[1]
+        return float(np.max(np.abs(g))) < self.tol()
+
+
+# ---- kernel-level FFI helpers (tests of the individual primitives) ----
+class DeviceBuffer:
+    def __init__(self, ctx, host_array):
+        a = _f64(host_array)
+        self.ctx, self.shape, self.nbytes = ctx, a.shape, a.nbytes
+        self.p = C.c_void_p()
+        _check(A.lib().qn_dev_alloc(ctx.h, max(a.nbytes, 8), C.byref(self.p)))
+        if a.nbytes:
+            _check(A.lib().qn_h2d(ctx.h, self.p, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def get(self):
+        out = np.empty(self.shape)
+        if self.nbytes:
+            _check(A.lib().qn_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.p, self.nbytes))
+        return out
+
+    def free(self):
+        if self.p:
+            A.lib().qn_dev_free(self.ctx.h, self.p)
+            self.p = None
+
+
+def gemv(ctx, a_dev, ld, nrows, ncols, x_dev, y_dev):
+    _check(A.lib().qn_gemv(ctx.h, a_dev.p, ld, nrows, ncols, x_dev.p, y_dev.p))
+
+
+def rank2_update(ctx, h_dev, ld, row0, nrows, n, s_dev, u_dev, c_ss, c_su, c_uu):
+    _check(A.lib().qn_rank2_update(ctx.h, h_dev.p, ld, row0, nrows, n, s_dev.p, u_dev.p, c_ss, c_su, c_uu))
+
+
+def axpy(ctx, n, x_dev, t, d_dev, out_dev):
+    _check(A.lib().qn_axpy(ctx.h, n, x_dev.p, t, d_dev.p, out_dev.p))
+
+
+def dot(ctx, n, a_dev, b_dev):
+    v = C.c_double()
+    _check(A.lib().qn_dot(ctx.h, n, a_dev.p, b_dev.p, C.byref(v)))
+    return v.value
+
+
+def nrm2(ctx, n, a_dev):
+    v = C.c_double()
+    _check(A.lib().qn_nrm2(ctx.h, n, a_dev.p, C.byref(v)))
+    return v.value

@@ -1,0 +1,435 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full
+size -- through size-independent properties.
+
+Tolerances, over the pre-convergence window (||g_k|| >= 1e-6 ||g_0||, first 50 iterations):
+same More-Thuente case sequence and oracle-call count per iteration; |t - t_ref| <= 1e-9 |t_ref|;
+||x_k - x_k_ref|| <= 1e-9 max(1, ||x_k_ref||); |f - f_ref| <= 1e-10 max(1, |f_ref|).
+"ref" is the oracle restatement in as-written (O(n^3)) mode unless stated -- parity unpinned beyond the
+reference's own KATs (oracle/qn_oracle.h).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+T_TOL, X_TOL, F_TOL = 1e-9, 1e-9, 1e-10
+
+
+def _window(ref_trace):
+    g0 = ref_trace[0]["gnorm"]
+    w = 0
+    for r in ref_trace[:50]:
+        if r["gnorm"] < 1e-6 * g0:
+            break
+        w += 1
+    return w
+
+
+def _compare(tr, xs, ref, ref_xs, exact_counts=True):
+    w = min(_window(ref), len(tr))
+    assert w >= min(len(ref), 3)
+    for k in range(w):
+        a, b = tr[k], ref[k]
+        if exact_counts:
+            assert a["ls_cases"] == b["ls_cases"], (k, a, b)
+            assert a["n_evals"] == b["n_evals"], (k, a, b)
+            assert a["ls_iters"] == b["ls_iters"], (k, a, b)
+        assert abs(a["t"] - b["t"]) <= T_TOL * abs(b["t"]), (k, a["t"], b["t"])
+        assert abs(a["f"] - b["f"]) <= F_TOL * max(1.0, abs(b["f"])), (k, a["f"], b["f"])
+        assert np.linalg.norm(xs[k] - ref_xs[k]) <= X_TOL * max(1.0, np.linalg.norm(ref_xs[k])), k
+    return w
+
+
+def _ls(mod, name):
+    if name == "mt":
+        return mod.MoreThuente() if hasattr(mod, "MoreThuente") else mod.morethuente()
+    return mod.BackTracking(1e-4, 0.5) if hasattr(mod, "BackTracking") else mod.backtracking(1e-4, 0.5)
+
+
+def _run_ref(qo, method, lsname, q, b, x0, iters, tol=1e-10, mode=None):
+    s = qo.Solver(qo.BFGS if method == "bfgs" else qo.DFP, tol, x0, qo.UPDATE_AS_WRITTEN if mode is None else mode)
+    o = qo.QuadraticOracle(q, b)
+    st = s.minimize(_ls(qo, lsname), o, iters, 20, trace_cap=iters, trace_x=True)
+    return s, o, st
+
+
+def _run_gpu(qn, method, lsname, obj_or_fn, x0, iters, tol=1e-10, sync=None, memoize=None, tiling=None):
+    s = (qn.BFGS if method == "bfgs" else qn.DFP)(tol, x0)
+    s.set_trace(iters, with_x=True)
+    if sync is not None:
+        s.set_sync_mode(sync)
+    if memoize is not None:
+        s.memoize = memoize
+    if tiling:
+        s.set_tiling(*tiling)
+    status = 0
+    try:
+        s.minimize(_ls(qn, lsname), obj_or_fn, iters, 20)
+    except qn.MaxIterReached:
+        status = 1
+    except qn.OutOfDomain:
+        status = 2
+    return s, status
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own tests and examples, written as the reference writes them
+# ---------------------------------------------------------------------------------------------
+
+def test_examples_quadratic_rs(qn, qo):
+    """examples/quadratic.rs:10-43 (BFGS + MoreThuente::default, host closure)."""
+    prob = P.g1_quadratic_rs()
+    calls = []
+
+    def f_and_g(x):
+        calls.append(x.copy())
+        f, g = prob["fn"](x)
+        return qn.FuncEvalMultivariate(f, g)
+
+    ls = qn.MoreThuente.default()
+    solver = qn.BFGS.new(prob["tol"], prob["x0"])
+    solver.minimize(ls, f_and_g, 100, 10, None)  # .unwrap()
+    x = solver.x()
+    ev = prob["fn"](x)
+    assert abs(ev[0]) < 1e-6
+    # the oracle restatement predicts x = (0,0) exactly, k = 2, 9 oracle calls
+    assert solver.k() == 2 and len(calls) == 9
+    assert ev[0] == 0.0, f"examples/quadratic.rs:43 assert_eq!(f, 0.0) -- got {ev[0]!r} at x={x!r}"
+
+
+@pytest.mark.parametrize("lsname", ["mt", "bt"])
+def test_bfgs_rs_unit_tests(qn, lsname):
+    """bfgs.rs:141-239 bfgs_morethuente / bfgs_backtracking."""
+    prob = P.g2_bfgs_rs()
+    gd = qn.BFGS.new(1e-12, prob["x0"])
+    n_calls = [0]
+
+    def f_and_g(x):
+        n_calls[0] += 1
+        return prob["fn"](x)
+
+    gd.minimize(_ls(qn, lsname), f_and_g, 1000, 100000, None)
+    ev = qn.FuncEvalMultivariate(*prob["fn"](gd.xk()))
+    assert gd.has_converged(ev)
+    assert abs(ev.f() - 0.0) < 1e-6
+    assert gd.k() == 1 and n_calls[0] == 4
+    assert list(gd.xk()) == [-1.0, 1.0]
+
+
+@pytest.mark.parametrize("lsname", ["mt", "bt"])
+def test_dfp_rs_unit_tests(qn, lsname):
+    """dfp.rs:136-235."""
+    prob = P.g2_bfgs_rs()
+    gd = qn.DFP.new(1e-12, prob["x0"])
+    gd.minimize(_ls(qn, lsname), prob["fn"], 1000, 100000, None)
+    assert abs(prob["fn"](gd.xk())[0]) < 1e-6
+
+
+def test_examples_bfgs_example_rs(qn, qo):
+    prob = P.g4_bfgs_example_rs()
+    n_calls = [0]
+
+    def f_and_g(x):
+        n_calls[0] += 1
+        return prob["fn"](x)
+
+    s = qn.BFGS.new(prob["tol"], prob["x0"])
+    s.minimize(qn.MoreThuente.default(), f_and_g, 50, 20, None)
+    assert s.k() == 4 and n_calls[0] == 17
+    assert prob["fn"](s.x())[0] < 1e-18
+
+
+def test_examples_dfp_example_rs(qn):
+    prob = P.g7_dfp_example_rs()
+    n_calls = [0]
+
+    def f_and_g(x):
+        n_calls[0] += 1
+        return prob["fn"](x)
+
+    s = qn.DFP.new(prob["tol"], prob["x0"])
+    s.minimize(qn.MoreThuente.default(), f_and_g, 100, 20, None)
+    assert abs(prob["fn"](s.x())[0]) < 1e-6
+    assert s.k() == 3 and n_calls[0] == 12
+
+
+@pytest.mark.parametrize("lsname", ["mt", "bt"])
+def test_gradient_descent_rs_unit_tests(qn, qo, lsname):
+    """gradient_descent.rs:85-180 (config-1 plumbing) -- same behaviour as the oracle, see test_oracle_kat.py."""
+    g5 = P.g5_ill_conditioned()
+    s = qn.GradientDescent.new(1e-12, g5["x0"])
+    ref = qo.Solver(qo.GRADIENT_DESCENT, 1e-12, g5["x0"])
+    st_ref = ref.minimize(_ls(qo, lsname), qo.PyOracle(g5["fn"]), 1000, 100)
+    try:
+        s.minimize(_ls(qn, lsname), g5["fn"], 1000, 100, None)
+        st = 0
+    except qn.MaxIterReached:
+        st = 1
+    assert st == st_ref and s.k() == ref.k
+    assert abs(g5["fn"](s.x())[0]) < 1e-6
+    assert np.allclose(s.x(), ref.x, rtol=0, atol=1e-12)
+
+
+def test_solver_errors(qn):
+    """ls_solver.rs:10-20,37-40,109-110."""
+    prob = P.g2_bfgs_rs()
+    s = qn.BFGS.new(1e-12, prob["x0"])
+    with pytest.raises(qn.MaxIterReached, match="Max iter reached"):
+        s.minimize(qn.MoreThuente(), prob["fn"], 1, 10)  # converged after 1 iteration but only checked at loop top
+    assert s.k() == 1
+    s.minimize(qn.MoreThuente(), prob["fn"], 5, 10)  # warm restart: k reset, state kept -> Ok at loop top
+    assert s.k() == 0
+    s2 = qn.BFGS.new(1e-6, [1.0, 1.0])
+    with pytest.raises(qn.OutOfDomain, match="Out of domain"):
+        s2.minimize(qn.MoreThuente(), lambda x: (float("nan"), np.zeros(2)), 10, 10)
+    with pytest.raises(qn.ErrorInputParams):
+        qn.MoreThuente().with_c1(2.0)  # assert!(c1 < c2), morethuente.rs:52
+    with pytest.raises(qn.ErrorInputParams):
+        qn.MoreThuente().with_c2(1.5)  # morethuente.rs:58
+
+
+def test_callback_sees_state_after_each_iteration(qn, qo):
+    prob = P.g4_bfgs_example_rs()
+    seen = []
+    s = qn.BFGS.new(prob["tol"], prob["x0"])
+    s.minimize(qn.MoreThuente(), prob["fn"], 50, 20, lambda sv: seen.append((sv.k(), sv.x())))
+    ref_seen = []
+    r = qo.Solver(qo.BFGS, prob["tol"], prob["x0"])
+    r.minimize(qo.morethuente(), qo.PyOracle(prob["fn"]), 50, 20, callback=lambda sv: ref_seen.append((sv.k, sv.x)))
+    assert [k for k, _ in seen] == [k for k, _ in ref_seen] == [1, 2, 3, 4]
+    for (_, xa), (_, xb) in zip(seen, ref_seen):
+        assert np.allclose(xa, xb, rtol=0, atol=1e-12)
+
+
+def test_host_closure_call_sequence_matches_reference_order(qn, qo):
+    """memoize = 0: every oracle call of ls_solver.rs:79 / morethuente.rs:182,217,276 / bfgs.rs:98 is made, at the same points."""
+    n = 17
+    q, b, x0, _ = P.synth_problem(qo, n, 1e3)
+    fn = lambda x: (0.5 * x @ (q @ x) - b @ x, q @ x - b)  # noqa: E731
+    pts = []
+
+    def rec(x):
+        pts.append(x.copy())
+        return fn(x)
+
+    s = qn.BFGS.new(1e-10, x0)
+    try:
+        s.minimize(qn.MoreThuente(), rec, 12, 20)
+    except qn.MaxIterReached:
+        pass
+    o = qo.PyOracle(fn)
+    r = qo.Solver(qo.BFGS, 1e-10, x0)
+    r.minimize(qo.morethuente(), o, 12, 20)
+    assert len(pts) == o.calls
+    for a, c in zip(pts, o.points):
+        assert np.linalg.norm(a - c) <= 1e-9 * max(1.0, np.linalg.norm(c))
+
+
+# ---------------------------------------------------------------------------------------------
+# iterate-level parity on the seeded SPD family, every mode of the HIP path
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("method", ["bfgs", "dfp"])
+@pytest.mark.parametrize("lsname", ["mt", "bt"])
+@pytest.mark.parametrize("n,kappa", [(2, 10.0), (3, 100.0), (8, 100.0), (17, 1e3), (64, 1e3), (200, 1e3), (515, 1e3)])
+def test_device_objective_pipelined_vs_oracle(qn, qo, method, lsname, n, kappa):
+    q, b, x0, diag = P.synth_problem(qo, n, kappa)
+    iters = 40
+    ref, o, st_ref = _run_ref(qo, method, lsname, q, b, x0, iters)
+    obj = qn.Quadratic(q, b)
+    s, st = _run_gpu(qn, method, lsname, obj, x0, iters)
+    tr, xs = s.trace()
+    w = _compare(tr, xs, ref.trace, ref.trace_x)
+    if w == len(ref.trace):
+        assert st == st_ref and s.k() == ref.k
+    stats = s.stats()
+    assert stats["oracle_calls"] >= stats["oracle_evals"]
+    if lsname == "mt" and method == "bfgs" and n >= 8:
+        # 5 calls of the reference's sequence per iteration, 2 distinct points
+        full = [r for r in tr[:w] if r["n_evals"] == 5]
+        assert len(full) >= w - 2
+
+
+@pytest.mark.parametrize("mode", ["sync_memo", "sync_nomemo"])
+@pytest.mark.parametrize("method,lsname", [("bfgs", "mt"), ("bfgs", "bt"), ("dfp", "mt")])
+def test_device_objective_sync_modes_vs_oracle(qn, qo, mode, method, lsname):
+    n = 96
+    q, b, x0, diag = P.synth_problem(qo, n, 1e3)
+    iters = 30
+    ref, o, _ = _run_ref(qo, method, lsname, q, b, x0, iters)
+    obj = qn.Quadratic(q, b)
+    s, _ = _run_gpu(qn, method, lsname, obj, x0, iters, sync=1, memoize=(mode == "sync_memo"))
+    tr, xs = s.trace()
+    _compare(tr, xs, ref.trace, ref.trace_x)
+    st = s.stats()
+    if mode == "sync_nomemo":
+        assert st["oracle_evals"] == st["oracle_calls"] == o.calls
+    else:
+        assert st["oracle_evals"] < st["oracle_calls"] == o.calls
+
+
+def test_pipelined_equals_sync_bitwise(qn, qo):
+    """The request pump must not change a single bit: pipelined and synchronous runs are the same kernels."""
+    n = 300
+    q, b, x0, diag = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+    a, _ = _run_gpu(qn, "bfgs", "mt", obj, x0, 30, sync=0)
+    c, _ = _run_gpu(qn, "bfgs", "mt", obj, x0, 30, sync=1)
+    ta, xa = a.trace()
+    tc, xc = c.trace()
+    assert ta == tc and np.array_equal(xa, xc)
+    assert np.array_equal(a.approx_inv_hessian(), c.approx_inv_hessian())
+
+
+@pytest.mark.parametrize("tiling", [(4, 1), (8, 2), (16, 1), (8, 3)])
+def test_tilings_agree_with_oracle(qn, qo, tiling):
+    n = 1100  # three column chunks, ragged tail
+    q, b, x0, diag = P.synth_problem(qo, n)
+    ref, _, _ = _run_ref(qo, "bfgs", "mt", q, b, x0, 12, mode=qo.UPDATE_RANK2)
+    obj = qn.Quadratic(q, b)
+    s, _ = _run_gpu(qn, "bfgs", "mt", obj, x0, 12, tiling=tiling)
+    tr, xs = s.trace()
+    _compare(tr, xs, ref.trace, ref.trace_x)
+
+
+def test_golden_fixtures(qn, qo):
+    """tests/golden/traces.json (build-generated from the oracle, see make_golden.py)."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traces.json")) as fh:
+        cases = json.load(fh)["cases"]
+    unhx = lambda v: np.array([float.fromhex(x) for x in v])  # noqa: E731
+    for c in cases:
+        n = c["n"]
+        diag, b, x0 = unhx(c["diag"]), unhx(c["b"]), unhx(c["x0"])
+        obj = qn.Quadratic.synthetic(n, c["seed"], diag, b)
+        s, st = _run_gpu(qn, c["method"], c["ls"], obj, x0, c["max_iter"], tol=c["tol"])
+        tr, xs = s.trace()
+        ref = [dict(t=t, f=f, gnorm=g, ls_cases=lc, n_evals=ne, ls_iters=0) for t, f, g, lc, ne in
+               zip(unhx(c["t"]), unhx(c["f"]), unhx(c["gnorm"]), c["ls_cases"], c["n_evals"])]
+        ref_xs = np.array([unhx(r) for r in c["x_trace"]])
+        w = min(_window(ref), len(tr))
+        for k in range(w):
+            assert tr[k]["ls_cases"] == ref[k]["ls_cases"] and tr[k]["n_evals"] == ref[k]["n_evals"], (n, c["method"], c["ls"], k)
+            assert abs(tr[k]["t"] - ref[k]["t"]) <= T_TOL * abs(ref[k]["t"])
+            assert abs(tr[k]["f"] - ref[k]["f"]) <= F_TOL * max(1.0, abs(ref[k]["f"]))
+            assert np.linalg.norm(xs[k] - ref_xs[k]) <= X_TOL * max(1.0, np.linalg.norm(ref_xs[k]))
+
+
+# ---------------------------------------------------------------------------------------------
+# kernels one at a time (the kernel-level FFI) and the generator
+# ---------------------------------------------------------------------------------------------
+
+def test_synthetic_generator_bitwise(qn, qo):
+    for n in (5, 64, 777):
+        q, b, x0, diag = P.synth_problem(qo, n)
+        obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
+        assert np.array_equal(obj.rows(0, n), q)
+        ev = obj(x0)
+        f_ref, g_ref = qo.QuadraticOracle(q, b)(x0)
+        assert abs(ev.f() - f_ref) <= 1e-12 * max(1.0, abs(f_ref))
+        assert np.linalg.norm(ev.g() - g_ref) <= 1e-12 * np.linalg.norm(g_ref)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 513, 2049])
+def test_primitives_vs_oracle(qn, qo, n):
+    ctx = qn.default_context()
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n, n))
+    x, d = rng.standard_normal(n), rng.standard_normal(n)
+    A, X, D, Y = (qn.DeviceBuffer(ctx, v) for v in (a, x, d, np.zeros(n)))
+    # gemv: row sums of the same products, different order (wave tree vs column sweep)
+    qn.gemv(ctx, A, n, n, n, X, Y)
+    y_ref = qo.gemv_colsweep(a, x)
+    scale = np.abs(a) @ np.abs(x)
+    assert np.all(np.abs(Y.get() - y_ref) <= 4 * n * np.finfo(float).eps * scale + 1e-300)
+    # axpy: bit-exact (two roundings per element, ls_solver.rs:60)
+    t = 0.49995
+    qn.axpy(ctx, n, X, t, D, Y)
+    assert np.array_equal(Y.get(), qo.axpy_new(x, t, d))
+    # dot / norm
+    assert abs(qn.dot(ctx, n, X, D) - qo.dot(x, d)) <= 4 * n * np.finfo(float).eps * (np.abs(x) @ np.abs(d))
+    assert abs(qn.nrm2(ctx, n, X) - qo.norm(x)) <= 4 * n * np.finfo(float).eps * qo.norm(x)
+    # rank-2 update: bit-exact against the same formula on the host, symmetric output
+    h = rng.standard_normal((n, n))
+    h = 0.5 * (h + h.T)
+    H = qn.DeviceBuffer(ctx, h)
+    c_ss, c_su = 0.37, -0.21
+    qn.rank2_update(ctx, H, n, 0, n, n, X, D, c_ss, c_su, 0.0)
+    t1 = np.multiply.outer(x, d) + np.multiply.outer(d, x)
+    expect = (h + c_su * t1) + c_ss * np.multiply.outer(x, x)
+    got = H.get()
+    assert np.array_equal(got, expect) and np.array_equal(got, got.T)
+    for buf in (A, X, D, Y, H):
+        buf.free()
+
+
+def test_inverse_hessian_getter_setter_and_secant(qn, qo):
+    n = 130
+    q, b, x0, diag = P.synth_problem(qo, n, 100.0)
+    obj = qn.Quadratic(q, b)
+    s = qn.BFGS(1e-12, x0)
+    assert np.array_equal(s.approx_inv_hessian(), np.eye(n))  # BFGS::new: H = I
+    s.set_trace(8, with_x=True)
+    with pytest.raises(qn.MaxIterReached):
+        s.minimize(qn.MoreThuente(), obj, 8, 20)
+    h = s.approx_inv_hessian()  # flushes the pending rank-2 update
+    assert np.array_equal(h, h.T)  # commutative inner sums keep H bitwise symmetric
+    _, xs = s.trace()
+    sk = xs[-1] - xs[-2]
+    yk = q @ sk
+    assert np.linalg.norm(h @ yk - sk) <= 1e-9 * np.linalg.norm(sk)  # secant equation H+ y = s
+    ref = qo.Solver(qo.BFGS, 1e-12, x0)
+    ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b), 8, 20)
+    assert np.linalg.norm(h - ref.approx_inv_hessian) <= 1e-9 * np.linalg.norm(h)
+    # setter round trip + warm restart from a given H
+    s2 = qn.BFGS(1e-12, s.x())
+    s2.set_approx_inv_hessian(h)
+    assert np.array_equal(s2.approx_inv_hessian(), h)
+    ref2 = qo.Solver(qo.BFGS, 1e-12, s.x())
+    ref2.set_inv_hessian(h)
+    ref2.minimize(qo.morethuente(), qo.QuadraticOracle(q, b), 5, 20, trace_cap=5, trace_x=True)
+    s2.set_trace(5, with_x=True)
+    with pytest.raises(qn.MaxIterReached):
+        s2.minimize(qn.MoreThuente(), obj, 5, 20)
+    tr, xs2 = s2.trace()
+    _compare(tr, xs2, ref2.trace, ref2.trace_x)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full size (config 2: n = 4096): size-independent properties
+# ---------------------------------------------------------------------------------------------
+
+def test_full_size_properties_n4096(qn, qo):
+    n, iters = 4096, 30
+    diag = P.synth_diag(n)
+    b, x0 = P.synth_vectors(n)
+    obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
+    s = qn.BFGS(1e-10, x0)
+    s.set_trace(iters, with_x=True)
+    with pytest.raises(qn.MaxIterReached):
+        s.minimize(qn.MoreThuente(), obj, iters, 20)
+    tr, xs = s.trace()
+    assert len(tr) == iters
+    f = np.array([r["f"] for r in tr])
+    assert np.all(np.diff(f) < 0)  # Armijo: strictly decreasing objective
+    assert all(r["n_evals"] in (3, 5) for r in tr)
+    st = s.stats()
+    assert st["oracle_evals"] <= 2 * iters + 1  # E <= 2 distinct points per iteration
+    h = s.approx_inv_hessian()
+    assert np.array_equal(h, h.T)
+    # secant equation with y recomputed by the device objective: y = g(x_k+1) - g(x_k)
+    sk = xs[-1] - xs[-2]
+    yk = obj(xs[-1]).g() - obj(xs[-2]).g()
+    assert np.linalg.norm(h @ yk - sk) <= 1e-8 * np.linalg.norm(sk)
+    # curvature: H stays positive definite along the path (y.s > 0 under strong Wolfe)
+    assert yk @ sk > 0
+    # the rank-2 CPU restatement follows the same path at this size (threads only split rows)
+    q = qo.synth_rows(n, 0, n, P.SEED, diag, nthreads=qo.max_threads())
+    ref = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
+    ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b, nthreads=qo.max_threads()), 12, 20, trace_cap=12, trace_x=True)
+    _compare(tr[:12], xs[:12], ref.trace, ref.trace_x)
