@@ -52,7 +52,8 @@ struct QnCtl {
     double mt_c1, mt_c2, mt_tmin, mt_tmax, mt_delta;
     double bt_c1, bt_beta;
     int64_t trace_cap;
-    int32_t trace_x, _pad0;
+    int32_t trace_x;
+    int32_t small_n; // n <= 5 on one GPU: solver arithmetic in the reference's exact operation order (thread 0)
 
     // ---- solver state ----
     int32_t phase, state, status, after_state;

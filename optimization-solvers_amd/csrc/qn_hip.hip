@@ -489,6 +489,7 @@ extern "C" int qn_solver_create(qn_context* ctx, int method, double tol, const d
     s->V.x = p; s->V.g = p + np; s->V.d = p + 2 * np; s->V.xt = p + 3 * np; s->V.gt = p + 4 * np;
     s->V.s = p + 5 * np; s->V.y = p + 6 * np; s->V.sp = p + 7 * np; s->V.up = p + 8 * np;
     s->V.n = (int)n; s->V.n_pad = (int)np; s->V.rpr = s->T.rpr; s->V.world = ctx->world;
+    s->V.H = s->H;
     QNCHK(solver_alloc_hp(s));
     QNCHK(dev_alloc_zero(&s->f_dev, 2, st));
     s->V.f_dev = s->f_dev;
@@ -810,6 +811,8 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
     h->bt_c1 = ls->bt_c1; h->bt_beta = ls->bt_beta;
     h->trace_cap = (int64_t)s->trace_cap;
     h->trace_x = s->trace_x;
+    h->small_n = (s->n <= QN_SMALL_N && c->world == 1) ? 1 : 0;
+    if (h->small_n && h->pending) QNCHK(flush_pending(s));
     h->phase = QN_PH_IDLE;
     h->status = -1;
     QNCHK(poke_ctl(s));

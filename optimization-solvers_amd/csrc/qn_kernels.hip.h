@@ -47,6 +47,7 @@ struct QnVecs {
     double* f_dev;    // generic oracles: f at xt
     QnTraceRec* trace;
     double* xtrace;
+    double* H; // this rank's rows (used directly only by the n <= 5 reference-order path)
     int n, n_pad, rpr, world, hcs, qcs;
 };
 
@@ -455,6 +456,84 @@ __device__ __forceinline__ void req_eval_t(QnCtl& c, double t, int after_state, 
     c.phase = QN_PH_REQ_EVAL;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Reference-order arithmetic for n <= 5 (single thread).  For these sizes nalgebra does not hand products to
+// matrixmultiply, so the reference's operation order is fully determined and the HIP
+// path reproduces the reference bit for bit -- this is what keeps `assert_eq!(eval.f(), &0.0)` of
+// examples/quadratic.rs:43 true.  Larger n use the O(n^2) rank-2 form (tolerance-level parity).
+// ------------------------------------------------------------------------------------------------
+#define QN_SMALL_N 5
+
+__device__ __forceinline__ double ref_dot(const double* a, const double* b, int n) { // [nalgebra] 8-accumulator dot
+    double res = 0.0, a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    int i = 0;
+    while (n - i >= 8) {
+        a0 += a[i] * b[i]; a1 += a[i + 1] * b[i + 1]; a2 += a[i + 2] * b[i + 2]; a3 += a[i + 3] * b[i + 3];
+        a4 += a[i + 4] * b[i + 4]; a5 += a[i + 5] * b[i + 5]; a6 += a[i + 6] * b[i + 6]; a7 += a[i + 7] * b[i + 7];
+        i += 8;
+    }
+    res += a0 + a4; res += a1 + a5; res += a2 + a6; res += a3 + a7;
+    for (; i < n; ++i) res += a[i] * b[i];
+    return res;
+}
+
+// d = -(H g), column sweep (bfgs.rs:47); H is row-major with leading dimension ld
+__device__ __forceinline__ void small_direction(const double* H, int ld, int n, const double* g, double* d) {
+    double y[QN_SMALL_N];
+    for (int i = 0; i < n; ++i) y[i] = H[i * ld] * g[0];
+    for (int j = 1; j < n; ++j)
+        for (int i = 0; i < n; ++i) y[i] = H[i * ld + j] * g[j] + y[i];
+    for (int i = 0; i < n; ++i) d[i] = -y[i];
+}
+
+// C = A*B through per-column gemv, all QN_SMALL_N-strided local arrays indexed [i + j*QN_SMALL_N]
+__device__ __forceinline__ void small_matmul(const double* a, const double* b, double* c, int n) {
+    for (int j = 0; j < n; ++j) {
+        for (int i = 0; i < n; ++i) c[i + j * QN_SMALL_N] = a[i] * b[j * QN_SMALL_N];
+        for (int k = 1; k < n; ++k)
+            for (int i = 0; i < n; ++i) c[i + j * QN_SMALL_N] = a[i + k * QN_SMALL_N] * b[k + j * QN_SMALL_N] + c[i + j * QN_SMALL_N];
+    }
+}
+
+// bfgs.rs:115-124 / dfp.rs:115-120 exactly as written
+__device__ __forceinline__ void small_update(double* H, int ld, int n, const double* s, const double* y, int method) {
+    double h[QN_SMALL_N * QN_SMALL_N], m0[QN_SMALL_N * QN_SMALL_N], m1[QN_SMALL_N * QN_SMALL_N], m2[QN_SMALL_N * QN_SMALL_N],
+        m3[QN_SMALL_N * QN_SMALL_N];
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) h[i + j * QN_SMALL_N] = H[i * ld + j];
+    if (method == 0) {
+        const double ys = ref_dot(y, s, n);
+        const double rho = 1.0 / ys;
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) {
+                const double w_a = s[i] * y[j], w_b = s[j] * y[i];
+                const double id = (i == j) ? 1.0 : 0.0;
+                m0[i + j * QN_SMALL_N] = id - (w_a * rho);
+                m1[i + j * QN_SMALL_N] = id - (w_b * rho);
+            }
+        small_matmul(m0, h, m2, n);
+        small_matmul(m2, m1, m3, n);
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) H[i * ld + j] = m3[i + j * QN_SMALL_N] + (s[i] * s[j]) * rho;
+    } else {
+        const double sy = ref_dot(s, y, n);
+        double u[QN_SMALL_N];
+        for (int i = 0; i < n; ++i) u[i] = h[i] * y[0];
+        for (int j = 1; j < n; ++j)
+            for (int i = 0; i < n; ++i) u[i] = h[i + j * QN_SMALL_N] * y[j] + u[i];
+        const double yhy = ref_dot(y, u, n);
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) m0[i + j * QN_SMALL_N] = y[i] * y[j];
+        small_matmul(h, m0, m1, n);
+        small_matmul(m1, h, m2, n);
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) {
+                const double delta = (s[i] * s[j]) / sy - m2[i + j * QN_SMALL_N] / yhy;
+                H[i * ld + j] = h[i + j * QN_SMALL_N] + delta;
+            }
+    }
+}
+
 #define QN_PH_RUNNING 5
 #define QN_ORACLE_GENERIC 0
 #define QN_ORACLE_QUAD 1
@@ -502,6 +581,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
         }
         __syncthreads();
         if (tid == 0) {
+            if (c.small_n && kind == QN_REQ_T) gd[0] = ref_dot(V.gt, V.d, n);
             c.f_e = f_e;
             c.gd_e = gd[0];
             c.n_oracle_evals++;
@@ -581,6 +661,18 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                 ctl_block_sum<2>(p, lds);
                 gnorm = sqrt(p[0]);
             }
+            if (c.small_n) { // reference order, thread 0 (uniform branch)
+                __syncthreads();
+                if (tid == 0) {
+                    if (!gd_method) {
+                        gnorm = sqrt(ref_dot(V.g, V.g, n));
+                        small_direction(V.H, n_pad, n, V.g, V.d);
+                    }
+                    p[0] = ref_dot(V.g, V.d, n);
+                    p[1] = 0.0;
+                    for (int i = 0; i < n; ++i) p[1] += isfinite(V.d[i]) ? 0.0 : 1.0;
+                }
+            }
             if (tid == 0) {
                 c.gnorm = gnorm; c.tr_f = c.f_k; c.tr_gnorm = gnorm;
                 const double f = c.f_k;
@@ -593,6 +685,9 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                     if (conv) {
                         c.status = 0; c.phase = QN_PH_DONE;
                     } else if (gd_method) {
+                        c.gd0 = p[0]; c.d_finite = p[1] == 0.0; c.last_valid = 0;
+                        c.state = QN_ST_LS_BEGIN;
+                    } else if (c.small_n) {
                         c.gd0 = p[0]; c.d_finite = p[1] == 0.0; c.last_valid = 0;
                         c.state = QN_ST_LS_BEGIN;
                     } else if (c.have_dir) {
@@ -770,6 +865,11 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                 p[2] = __builtin_fma(yi, si, p[2]);
             }
             ctl_block_sum<3>(p, lds);
+            if (c.small_n) {
+                __threadfence_block();
+                __syncthreads();
+                if (tid == 0) { p[0] = ref_dot(V.s, V.s, n); p[1] = ref_dot(V.y, V.y, n); p[2] = ref_dot(V.y, V.s, n); }
+            }
             if (tid == 0) {
                 c.s_norm = sqrt(p[0]); c.has_s_norm = 1;
                 c.y_norm = sqrt(p[1]); c.has_y_norm = 1;
@@ -779,6 +879,10 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                 c.have_dir = 0;
                 c.last_valid = 0;
                 if (c.s_norm < c.tol || c.y_norm < c.tol) { // bfgs.rs:106-112: H is not updated
+                    c.state = QN_ST_ITER_END;
+                } else if (c.small_n) {
+                    small_update(V.H, n_pad, n, V.s, V.y, c.method);
+                    c.tr_updated = 1;
                     c.state = QN_ST_ITER_END;
                 } else {
                     c.hp_lazy = c.memoize;
