@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- BFGS iterations/sec on the synthetic n-dim convex quadratic (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one BFGS iteration (direction, More-Thuente line search, rank-2 inverse-Hessian update) on the
+device-resident objective f = 1/2 x'Qx - b'x; Q, H, and every vector are in HBM before the timed region.
+N = 1 runs BASELINE.json configs[1] (n = 4096); N > 1 runs configs[2]'s problem (n = 32768) with H and Q
+row-sharded over the N ranks and one RCCL all-gather per mat-vec pass ("scaling": "strong" over N = 2,4,8).
+Prints ONE JSON line on rank 0.  The product path is libqn_hip.so (hand-written gfx950 kernels); the CPU
+oracle is used only for the `cpu_baseline` leg.  No GPU => hard failure, never a fallback.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SEED = 0x5EED0001
+KAPPA = 1.0e3
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md:36); 6290 GB/s measured-achievable
+METRIC = "BFGS iterations/sec on n-dim convex quadratic (f64) at 1/2/4/8 MI355X"
+
+
+def synth_inputs(n):
+    diag = KAPPA ** (np.arange(n, dtype=np.float64) / max(n - 1, 1))
+    rng = np.random.Generator(np.random.Philox(key=SEED))
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    return diag, b, x0
+
+
+def run_iterations(qn, solver, ls, obj, x0, iters):
+    """Exactly `iters` BFGS iterations; if the run converges first, restart from (x0, H = I) and keep counting
+    (SURVEY.md 8(d)).  Returns the number of restarts."""
+    done, restarts = 0, 0
+    while done < iters:
+        try:
+            solver.minimize(ls, obj, iters - done, 20)
+            done += solver.k()
+            if done < iters:  # Ok(()) before the cap: converged
+                solver.reset(x0)
+                restarts += 1
+        except qn.MaxIterReached:
+            done += solver.k()
+    return restarts
+
+
+def cpu_baseline(n, iters):
+    """CPU port timed on the host cores: the oracle restatement with the O(n^2) rank-2 update (the reference's
+    literal update is O(n^3): 2.7e11 flop per iteration at n = 4096), reference call sequence (5 oracle calls per
+    iteration), OpenMP over all cores."""
+    from oracle import qn_oracle as qo
+    threads = qo.max_threads()
+    diag, b, x0 = synth_inputs(n)
+    q = qo.synth_rows(n, 0, n, SEED, diag, nthreads=threads)
+    s = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=threads)
+    o = qo.QuadraticOracle(q, b, nthreads=threads)
+    s.minimize(qo.morethuente(), o, 2, 20)  # warm the caches / thread pool
+    t0 = time.perf_counter()
+    s.minimize(qo.morethuente(), o, iters, 20)
+    dt = time.perf_counter() - t0
+    k = s.k
+    out = {"value": k / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
+           "sample": f"{k} BFGS+MoreThuente iterations at n={n} (same Q, b, x0 as the GPU run), rank-2 O(n^2) update, "
+                     f"reference oracle-call sequence, OpenMP x{threads}"}
+    # the reference's own formulation (dense n x n products, single thread as matrixmultiply is built) at a size it finishes
+    n_small = 384
+    d2, b2, x2 = synth_inputs(n_small)
+    q2 = qo.synth_rows(n_small, 0, n_small, SEED, d2)
+    s2 = qo.Solver(qo.BFGS, 1e-10, x2, qo.UPDATE_AS_WRITTEN, nthreads=1)
+    o2 = qo.QuadraticOracle(q2, b2, nthreads=1)
+    t0 = time.perf_counter()
+    s2.minimize(qo.morethuente(), o2, 4, 20)
+    dt2 = time.perf_counter() - t0
+    per_iter = dt2 / max(s2.k, 1)
+    out["as_written_1thread"] = {"n": n_small, "s_per_iteration": per_iter,
+                                 "extrapolated_s_per_iteration_at_n": per_iter * (n / n_small) ** 3,
+                                 "note": "bfgs.rs:115-124 literally (O(n^3)), naive loops, 1 thread; extrapolated with n^3"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=None, help="override the problem dimension")
+    ap.add_argument("--ls", default="mt", choices=["mt", "bt"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--tiling", default=None, help="rows_per_block,col_splits")
+    ap.add_argument("--sync-mode", type=int, default=None)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        if world > 1:
+            sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import torch  # device plumbing + torch.distributed rendezvous only
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device is visible and there is no CPU fallback")
+
+    import __graft_entry__ as ge
+    qn = ge.load_package()
+
+    n = args.n or (4096 if world == 1 else 32768)
+    steps = args.steps if args.steps is not None else (200 if n <= 8192 else 50)
+    warmup = args.warmup
+
+    ctx = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # control plane; the data plane is RCCL inside libqn_hip
+        ids = [qn.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx = qn.Context(device=local_rank, rank=rank, world=world, unique_id=ids[0])
+    else:
+        ctx = qn.Context(device=local_rank)
+
+    diag, b, x0 = synth_inputs(n)
+    obj = qn.Quadratic.synthetic(n, SEED, diag, b, ctx=ctx)  # Q is generated shard-locally on the device
+    solver = qn.BFGS(1e-10, x0, ctx=ctx)
+    if args.tiling:
+        r, c = (int(v) for v in args.tiling.split(","))
+        solver.set_tiling(r, c)
+    if args.sync_mode is not None:
+        solver.set_sync_mode(args.sync_mode)
+    ls = qn.MoreThuente() if args.ls == "mt" else qn.BackTracking(1e-4, 0.5)
+
+    def barrier():
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # warm-up iterations (untimed), then exactly `steps` timed iterations of the same solve
+    if warmup > 0:
+        run_iterations(qn, solver, ls, obj, x0, warmup)
+    barrier()
+    st0 = solver.stats()
+    t0 = time.perf_counter()
+    restarts = run_iterations(qn, solver, ls, obj, x0, steps)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    st1 = solver.stats()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    barrier()
+
+    evals = st1["oracle_evals"] - st0["oracle_evals"]
+    calls = st1["oracle_calls"] - st0["oracle_calls"]
+    h_bytes = st1["h_bytes"] - st0["h_bytes"]
+    obj_bytes = st1["obj_bytes"] - st0["obj_bytes"]
+    its = steps / elapsed
+
+    # kernel-level roofline: same workload again with every launch bracketed by HIP events on the solver's stream
+    roofline = None
+    if not args.no_profile_pass:
+        prof_steps = min(steps, 50)
+        solver.set_profiling(True)
+        solver.set_sync_mode(1)  # only real work is launched: no predicated-off launches dilute the averages
+        p0 = solver.stats()
+        run_iterations(qn, solver, ls, obj, x0, prof_steps)
+        p1 = solver.stats()
+        solver.set_profiling(False)
+        solver.set_sync_mode(args.sync_mode if args.sync_mode is not None else -1)
+        n_h = p1["n_hpass_timed"] - p0["n_hpass_timed"]
+        t_h = p1["t_hpass_ms"] - p0["t_hpass_ms"]
+        n_e = p1["n_eval_timed"] - p0["n_eval_timed"]
+        t_e = p1["t_eval_ms"] - p0["t_eval_ms"]
+        n_c = p1["n_ctl_timed"] - p0["n_ctl_timed"]
+        t_c = p1["t_ctl_ms"] - p0["t_ctl_ms"]
+        # algorithmic bytes of one h_pass launch on this rank: read + write of the rank's n/P x n f64 shard
+        alg_h = 16.0 * n * n / world
+        alg_q = 8.0 * n * n / world
+        # launches that were predicated off (pipelined mode) finish in ~2 us; keep them out of the average
+        h_launch_ms = t_h / max(n_h, 1)
+        ach = alg_h / (h_launch_ms * 1e-3) / 1e9 if n_h else None
+        roofline = {"bound": "hbm", "kernel": "h_pass_kernel (fused rank-2 update + 2-RHS mat-vec over H)",
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
+                    "traffic": None,
+                    "algorithmic_bytes_per_launch": alg_h, "avg_launch_ms": h_launch_ms, "launches_timed": n_h,
+                    "quad_matvec": {"algorithmic_bytes_per_launch": alg_q, "avg_launch_ms": t_e / max(n_e, 1), "launches_timed": n_e,
+                                    "achieved": (alg_q / (t_e / max(n_e, 1) * 1e-3) / 1e9) if n_e else None},
+                    "ctl_step": {"avg_launch_ms": t_c / max(n_c, 1), "launches_timed": n_c},
+                    "note": "HIP events on the solver stream around every launch of a synchronous-mode pass over the same workload"}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                roofline["traffic"] = json.load(open(pmc)).get(f"n{n}_p{world}", {}).get("h_pass_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                pass
+
+    if rank == 0:
+        b_iter = 16.0 * n * n + 8.0 * n * n * (evals / steps)
+        out = {
+            "metric": METRIC, "value": its, "unit": "iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BFGS + MoreThuente::default (max_iter_line_search 20), n={n} convex quadratic "
+                                   f"(random SPD Q, kappa=1e3, seed 0x5EED0001), f64, {world}xMI355X"
+                                   + (", H and Q row-sharded, RCCL all-gather per pass" if world > 1 else ""),
+                       "n": n, "line_search": args.ls, "tol": 1e-10, "parallelism": f"row-shard x{world}"},
+            "iteration_accounting": {"oracle_calls_reference_sequence": calls, "oracle_evaluations_distinct": evals,
+                                     "restarts_after_convergence": restarts,
+                                     "algorithmic_bytes_per_iteration": b_iter,
+                                     "whole_iteration_hbm_frac": b_iter * its / (world * HBM_PEAK_GBS * 1e9),
+                                     "h_bytes_counted": h_bytes, "objective_bytes_counted": obj_bytes,
+                                     "launches": st1["launches"] - st0["launches"], "host_syncs": st1["host_syncs"] - st0["host_syncs"]},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, 30 if n <= 4096 else 4)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

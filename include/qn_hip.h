@@ -141,6 +141,8 @@ typedef struct qn_solver qn_solver;
 /* BFGS::new(tol, x0) / DFP::new / GradientDescent::new(grad_tol, x0): H = I (no identity copy is kept) */
 int qn_solver_create(qn_context* ctx, int method, double tol, const double* x0_host, size_t n, qn_solver** out);
 void qn_solver_destroy(qn_solver* s);
+/* back to the state right after BFGS::new(tol, x0): x = x0, H = I, k = 0, s_norm = y_norm = None */
+int qn_solver_reset(qn_solver* s, const double* x0_host);
 
 /* callback: Option<&mut dyn FnMut(&Self)> (ls_solver.rs:72,105-107); called after k += 1 */
 typedef void (*qn_callback_fn)(void* user, qn_solver* solver);

@@ -78,6 +78,7 @@ SYMBOLS = [
     ("qn_objective_get_rows", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, dp]),
     ("qn_solver_create", C.c_int, [C.c_void_p, C.c_int, C.c_double, dp, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("qn_solver_destroy", None, [C.c_void_p]),
+    ("qn_solver_reset", C.c_int, [C.c_void_p, dp]),
     ("qn_minimize", C.c_int, [C.c_void_p, C.POINTER(LineSearchStruct), C.POINTER(OracleStruct), C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("qn_solver_n", C.c_size_t, [C.c_void_p]),
     ("qn_solver_k", C.c_size_t, [C.c_void_p]),

@@ -575,6 +575,20 @@ static int peek_ctl(qn_solver* s) { // device -> host mirror
     return QN_OK;
 }
 
+extern "C" int qn_solver_reset(qn_solver* s, const double* x0_host) {
+    if (!s || !x0_host) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    hipStream_t st = s->ctx->stream;
+    if (s->H) {
+        hipLaunchKernelGGL(identity_fill_kernel, dim3(2048), dim3(256), 0, st, s->H, s->T);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemsetAsync(s->vec_block, 0, 9 * (size_t)s->T.n_pad * sizeof(double), st));
+    HIPCHK(hipMemcpyAsync(s->V.x, x0_host, s->n * sizeof(double), hipMemcpyHostToDevice, st));
+    memset(s->hctl, 0, sizeof(QnCtl));
+    return poke_ctl(s);
+}
+
 extern "C" int qn_solver_set_x(qn_solver* s, const double* x_host) {
     HIPCHK(hipSetDevice(s->ctx->device));
     HIPCHK(hipMemcpyAsync(s->V.x, x_host, s->n * sizeof(double), hipMemcpyHostToDevice, s->ctx->stream));

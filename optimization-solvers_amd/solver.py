@@ -250,6 +250,11 @@ class _SolverBase:
     def new(cls, tol, x0, ctx=None):
         return cls(tol, x0, ctx)
 
+    def reset(self, x0):
+        """Back to the state right after `new(tol, x0)`."""
+        x0 = _f64(x0)
+        _check(A.lib().qn_solver_reset(self.h, _dp(x0)))
+
     def close(self):
         if getattr(self, "h", None):
             A.lib().qn_solver_destroy(self.h)
