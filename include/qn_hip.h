@@ -63,6 +63,11 @@ typedef int (*qn_host_allgather_fn)(void* user, const double* sendbuf, double* r
 int qn_context_create_sharded_host_exchange(int device, int rank, int world, qn_host_allgather_fn fn, void* user,
                                             qn_context** out);
 void qn_context_destroy(qn_context* ctx);
+/* the row partition used for H and the objective's matrix: rows per rank (a multiple of 16) and padded dimension */
+int qn_partition(size_t n, int world, size_t* rows_per_rank, size_t* n_pad);
+/* diagnostics: create a 1-rank RCCL communicator on this context's GPU, all-gather a small buffer in place on the
+ * context's stream and verify it (checks that librccl loads and that the calling convention matches) */
+int qn_comm_selftest(qn_context* ctx);
 int qn_context_synchronize(qn_context* ctx);
 int qn_context_rank(const qn_context* ctx);
 int qn_context_world(const qn_context* ctx);

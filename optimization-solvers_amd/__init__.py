@@ -1,7 +1,7 @@
 """optimization-solvers_amd: MI355X-native quasi-Newton / line-search inner loop behind the reference's
 Solver::minimize() surface.  The directory name is not a Python identifier; load it with
 `__graft_entry__.load_package()` (registers it as `optimization_solvers_amd`)."""
-from . import _abi  # noqa: F401
+from . import _abi, dist  # noqa: F401
 from .solver import (BFGS, DFP, AbnormalTermination, BackTracking, Context, DeviceBuffer, ErrorInputParams,  # noqa: F401
                      FuncEvalMultivariate, GradientDescent, MaxIterReached, MoreThuente, Objective, OutOfDomain, Quadratic,
-                     SolverError, axpy, default_context, dot, gemv, nrm2, rank2_update)
+                     SolverError, axpy, default_context, dot, gemv, nrm2, partition, rank2_update)

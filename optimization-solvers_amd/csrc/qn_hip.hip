@@ -223,6 +223,36 @@ static QnTile make_tile(size_t n, const qn_context* c, int cs) {
     return T;
 }
 
+extern "C" int qn_partition(size_t n, int world, size_t* rows_per_rank, size_t* n_pad) {
+    if (world < 1 || n == 0) return fail(QN_ERROR_INPUT_PARAMS, "bad n/world");
+    const int rpr = part_rpr(n, world);
+    if (rows_per_rank) *rows_per_rank = (size_t)rpr;
+    if (n_pad) *n_pad = (size_t)rpr * (size_t)world;
+    return QN_OK;
+}
+
+extern "C" int qn_comm_selftest(qn_context* c) {
+    HIPCHK(hipSetDevice(c->device));
+    QNCHK(rccl_load());
+    RcclUniqueId id;
+    RCCLCHK(g_rccl.GetUniqueId(&id));
+    RcclComm comm = nullptr;
+    RCCLCHK(g_rccl.CommInitRank(&comm, 1, id, 0));
+    const size_t count = 1024;
+    double* buf = nullptr;
+    HIPCHK(hipMalloc((void**)&buf, count * sizeof(double)));
+    std::vector<double> h(count), back(count, 0.0);
+    for (size_t i = 0; i < count; ++i) h[i] = 0.5 * (double)i - 3.0;
+    HIPCHK(hipMemcpyAsync(buf, h.data(), count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RCCLCHK(g_rccl.AllGather(buf, buf, count, kRcclDouble, comm, c->stream)); // in place, rank 0 of 1
+    HIPCHK(hipMemcpyAsync(back.data(), buf, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    g_rccl.CommDestroy(comm);
+    HIPCHK(hipFree(buf));
+    if (memcmp(h.data(), back.data(), count * sizeof(double)) != 0) return fail(QN_ABNORMAL_TERMINATION, "RCCL self-test: data mismatch");
+    return QN_OK;
+}
+
 static int dev_alloc_zero(double** p, size_t count, hipStream_t st) {
     HIPCHK(hipMalloc((void**)p, count * sizeof(double)));
     HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(double), st));

@@ -117,6 +117,9 @@ class Context:
     def synchronize(self):
         _check(A.lib().qn_context_synchronize(self.h))
 
+    def comm_selftest(self):
+        _check(A.lib().qn_comm_selftest(self.h))
+
     def close(self):
         if self.h:
             A.lib().qn_context_destroy(self.h)
@@ -127,6 +130,13 @@ class Context:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+def partition(n, world):
+    """(rows_per_rank, n_pad) of the row partition used for H and the objective's matrix."""
+    rpr, npad = C.c_size_t(), C.c_size_t()
+    _check(A.lib().qn_partition(n, world, C.byref(rpr), C.byref(npad)))
+    return rpr.value, npad.value
 
 
 _default_ctx = None

@@ -1,0 +1,129 @@
+"""Worker for the world_size-2 tests; launched by test_dist_gloo.py / test_gpu_sharded.py through
+`python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 ... tests/dist_worker.py MODE OUT`."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    mode, out_path = sys.argv[1], sys.argv[2]
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import __graft_entry__ as ge
+    qn = ge.load_package()
+    from oracle import qn_oracle as qo
+    import problems as P
+
+    result = {"rank": rank, "world": world}
+    if mode == "cpu":
+        # (1) the host all-gather helper
+        ag = qn.dist.gloo_allgather()
+        send = np.arange(5, dtype=np.float64) + 10.0 * rank
+        recv = np.zeros(5 * world)
+        ag(send, recv)
+        result["allgather_ok"] = bool(np.array_equal(recv, np.concatenate([np.arange(5) + 10.0 * r for r in range(world)])))
+
+        # (2) N > 1 semantics on the CPU: row partition + all-gather of mat-vec slices + replicated scalar work
+        n = 203
+        rpr, n_pad = qn.partition(n, world)
+        lo, hi = qn.dist.row_range(n, rank, world, rpr)
+        diag = P.synth_diag(n)
+        b, x0 = P.synth_vectors(n)
+        q_rows = qo.synth_rows(n, lo, hi - lo, P.SEED, diag)  # shard-local generation
+        calls = [0]
+
+        def sharded_oracle(x):
+            calls[0] += 1
+            sl = np.zeros(rpr)
+            for r in range(hi - lo):  # row sums left to right, as the oracle's quadratic does
+                acc = 0.0
+                row = q_rows[r]
+                for j in range(n):
+                    acc += row[j] * x[j]
+                sl[r] = acc
+            full = np.zeros(rpr * world)
+            ag(sl, full)
+            qx = full[:n]
+            f = 0.5 * qo.dot(x, qx) - qo.dot(b, x)
+            return f, qx - b
+
+        s = qo.Solver(qo.BFGS, 1e-10, x0)
+        st = s.minimize(qo.morethuente(), sharded_oracle, 6, 20, trace_cap=6, trace_x=True)
+        # unsharded run of the same thing on every rank
+        q = qo.synth_rows(n, 0, n, P.SEED, diag)
+        ref = qo.Solver(qo.BFGS, 1e-10, x0)
+        st_ref = ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b), 6, 20, trace_cap=6, trace_x=True)
+        result["sharded_equals_unsharded_bitwise"] = bool(st == st_ref and np.array_equal(s.trace_x, ref.trace_x)
+                                                          and np.array_equal(s.approx_inv_hessian, ref.approx_inv_hessian))
+        result["x_hex"] = [float(v).hex() for v in s.x]
+        result["partition"] = [rpr, n_pad, lo, hi]
+    elif mode == "gpu":
+        # two ranks share the one GPU of the dev box; slices are exchanged through host memory with gloo.
+        n, iters = 700, 25
+        diag = P.synth_diag(n)
+        b, x0 = P.synth_vectors(n)
+        ctx = qn.dist.sharded_context(0, host_exchange=True)
+        obj = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx)
+        s = qn.BFGS(1e-10, x0, ctx=ctx)
+        s.set_trace(iters, with_x=True)
+        try:
+            s.minimize(qn.MoreThuente(), obj, iters, 20)
+        except qn.MaxIterReached:
+            pass
+        tr, xs = s.trace()
+        h = s.approx_inv_hessian(all_ranks=True)
+        # the same solve on a private single-rank context
+        ctx1 = qn.Context(0)
+        obj1 = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx1)
+        s1 = qn.BFGS(1e-10, x0, ctx=ctx1)
+        s1.set_trace(iters, with_x=True)
+        s1.set_sync_mode(1)
+        try:
+            s1.minimize(qn.MoreThuente(), obj1, iters, 20)
+        except qn.MaxIterReached:
+            pass
+        tr1, xs1 = s1.trace()
+        h1 = s1.approx_inv_hessian()
+        result["iters"] = len(tr)
+        result["trace_equal"] = bool(tr == tr1)
+        result["x_equal"] = bool(np.array_equal(xs, xs1))
+        result["h_equal"] = bool(np.array_equal(h, h1))
+        result["objective_rows_ok"] = bool(np.array_equal(
+            obj.rows(*[(lambda lo, hi: (lo, hi - lo))(*qn.dist.row_range(n, rank, world, qn.partition(n, world)[0]))][0]),
+            qo.synth_rows(n, *[(lambda lo, hi: (lo, hi - lo))(*qn.dist.row_range(n, rank, world, qn.partition(n, world)[0]))][0], P.SEED, diag)))
+        ev = obj(x0)
+        ev1 = obj1(x0)
+        result["eval_equal"] = bool(ev.f() == ev1.f() and np.array_equal(ev.g(), ev1.g()))
+        # DFP + backtracking on the sharded context too
+        s2 = qn.DFP(1e-10, x0, ctx=ctx)
+        s2.set_trace(10, with_x=True)
+        try:
+            s2.minimize(qn.BackTracking(1e-4, 0.5), obj, 10, 20)
+        except qn.MaxIterReached:
+            pass
+        s3 = qn.DFP(1e-10, x0, ctx=ctx1)
+        s3.set_trace(10, with_x=True)
+        s3.set_sync_mode(1)
+        try:
+            s3.minimize(qn.BackTracking(1e-4, 0.5), obj1, 10, 20)
+        except qn.MaxIterReached:
+            pass
+        result["dfp_bt_equal"] = bool(np.array_equal(s2.trace()[1], s3.trace()[1]))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, result)
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            json.dump(gathered, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
