@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=None, help="override the problem dimension")
+    ap.add_argument("--dim", type=int, default=None, help="override the problem dimension n")
     ap.add_argument("--ls", default="mt", choices=["mt", "bt"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -117,17 +117,18 @@ def main():
     import __graft_entry__ as ge
     qn = ge.load_package()
 
-    n = args.n or (4096 if world == 1 else 32768)
+    n = args.dim or (4096 if world == 1 else 32768)
     steps = args.steps if args.steps is not None else (200 if n <= 8192 else 50)
     warmup = args.warmup
 
     ctx = None
+    host_exchange = os.environ.get("QN_BENCH_EXCHANGE", "rccl") == "host"  # harness rehearsal on a 1-GPU box only
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # control plane; the data plane is RCCL inside libqn_hip
-        ids = [qn.Context.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx = qn.Context(device=local_rank, rank=rank, world=world, unique_id=ids[0])
+        # control plane: gloo (unique-id broadcast, barriers, max over ranks); data plane: RCCL inside libqn_hip.so
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        ndev = torch.cuda.device_count()
+        ctx = qn.dist.sharded_context(local_rank % max(ndev, 1), host_exchange=host_exchange)
     else:
         ctx = qn.Context(device=local_rank)
 
@@ -215,7 +216,8 @@ def main():
             "config": {"workload": f"BFGS + MoreThuente::default (max_iter_line_search 20), n={n} convex quadratic "
                                    f"(random SPD Q, kappa=1e3, seed 0x5EED0001), f64, {world}xMI355X"
                                    + (", H and Q row-sharded, RCCL all-gather per pass" if world > 1 else ""),
-                       "n": n, "line_search": args.ls, "tol": 1e-10, "parallelism": f"row-shard x{world}"},
+                       "n": n, "line_search": args.ls, "tol": 1e-10, "parallelism": f"row-shard x{world}",
+                       "exchange": "none" if world == 1 else ("host-staged gloo (rehearsal)" if host_exchange else "rccl all-gather")},
             "iteration_accounting": {"oracle_calls_reference_sequence": calls, "oracle_evaluations_distinct": evals,
                                      "restarts_after_convergence": restarts,
                                      "algorithmic_bytes_per_iteration": b_iter,

@@ -63,8 +63,16 @@ struct QnCtl {
     double f_k;   // f(x_k)
     double gd0;   // g_k . d_k
     double gnorm; // ||g_k||
+    double gg;    // ||g(x_k)||^2 when gg_valid (computed in the sweep that produced g)
+    int32_t gg_valid, xtrace_done;
     int32_t have_cur_eval; // g / f_k hold the evaluation at the current x (memoised loop-top call)
     int32_t have_dir;      // d / gd0 already hold the direction for the current x (lazy H+ g+)
+
+    // ---- fused fast path (qn_fused.hip.h): buffer toggles, on-the-fly direction, staged sums of the last evaluation ----
+    int32_t fused, xc, sc, dir_mode, gd0_valid, _padf;
+    double dir_ug, dir_sg;
+    double st_gd0, st_yy, st_ys, st_gg, st_ss, st_dnf;
+    double hp_yu, hp_ug, hp_sg;
 
     // ---- request ----
     int32_t req_kind, req_need_vectors;

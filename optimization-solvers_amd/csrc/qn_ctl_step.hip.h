@@ -1,0 +1,683 @@
+// qn_ctl_step.hip.h -- the solver state machine (included by qn_kernels.hip.h).
+//
+// One workgroup of 1024 threads.  The kernel is latency-bound, so it is organised around two rules:
+//   * every vector phase issues ALL its loads before the first use (4 elements per thread per trip, pointers
+//     marked __restrict__, invalid lanes clamped to index 0 instead of branching), and phases that can share a
+//     sweep are fused (evaluation epilogue + g.d; s, y, norms, y.s and ||g+||^2 in one sweep);
+//   * consecutive scalar states run back to back in thread 0 without workgroup barriers; the workgroup only
+//     meets at a barrier when the next state needs all threads.
+// Thread t always touches elements t, t+1024, ..., so it only ever re-reads its own writes.
+#pragma once
+
+#ifdef QN_CTL_STAMPS
+#define QN_STAMP(id) do { if (tid == 0 && V.dbg) V.dbg[stamp_base + (id)] = wall_clock64(); } while (0)
+#else
+#define QN_STAMP(id) do { } while (0)
+#endif
+
+#define QN_TILE_IDX(base)                                        \
+    int idx[4];                                                  \
+    bool ok[4];                                                  \
+    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {           \
+        const int i_ = (base) + u_ * QN_CTL_TPB + tid;           \
+        ok[u_] = i_ < n_pad;                                     \
+        idx[u_] = ok[u_] ? i_ : 0;                               \
+    }
+
+// Sum K per-thread values over the workgroup; only thread 0 receives the totals (one barrier).
+template <int K>
+__device__ __forceinline__ void ctl_block_sum_t0(double (&v)[K], double* lds /* 16*K */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[k] = v[k] + __shfl_xor(v[k], off, 64);
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double t = (lane < QN_CTL_TPB / 64) ? lds[lane * K + k] : 0.0;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+            v[k] = t;
+        }
+    }
+}
+
+// fused path: sum the per-workgroup partials [world][NP][nblk] in global tile order (rank-major = row order)
+template <int NP>
+__device__ __forceinline__ void ctl_sum_partials(const double* __restrict__ part, int world, int nblk, double (&p)[NP], double* lds) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) p[k] = 0.0;
+    const int E = world * nblk;
+    for (int e = threadIdx.x; e < E; e += QN_CTL_TPB) {
+        const int r = e / nblk, b = e - r * nblk;
+        const double* base = part + (size_t)r * NP * nblk + b;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) p[k] = p[k] + base[(size_t)k * nblk];
+    }
+    ctl_block_sum_t0<NP>(p, lds);
+}
+
+__device__ __forceinline__ void qn_keepalive(double v) { asm volatile("" ::"v"(v)); }
+
+// ------------------------------------------------------------------------------------------------
+// scalar states (thread 0 only).  Runs until the machine yields or reaches a state that needs all threads.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool qn_check_is_scalar(const QnCtl& c) {
+    return c.method != 2 && (c.small_n || c.gg_valid);
+}
+
+__device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double* small_scratch) {
+    const int n = V.n, n_pad = V.n_pad;
+    for (int guard = 0; guard < (1 << 22); ++guard) {
+        if (c.phase != QN_PH_RUNNING) return;
+        switch (c.state) {
+        case QN_ST_BEGIN: { // ls_solver.rs:74-76: only k is reset
+            c.k = 0;
+            c.have_cur_eval = 0; c.have_dir = 0; c.last_valid = 0; c.gg_valid = 0;
+            c.n_oracle_calls = 0; c.n_oracle_evals = 0; c.n_hpasses = 0; c.n_hpass_rw = 0; c.n_iterations = 0;
+            c.status = -1;
+            c.state = QN_ST_LOOP_TOP;
+        } break;
+
+        case QN_ST_LOOP_TOP: { // ls_solver.rs:78-79
+            if (!(c.max_iter > c.k)) {
+                c.status = 1; // MaxIterReached, ls_solver.rs:109-110
+                c.phase = QN_PH_DONE;
+            } else {
+                c.tr_n_evals = 0; c.tr_ls_iters = 0; c.tr_ls_cases = 0; c.tr_ndigits = 0; c.tr_updated = 0;
+                c.ls_result = NAN;
+                c.n_oracle_calls++;
+                c.tr_n_evals++;
+                if (c.memoize && c.have_cur_eval) {
+                    c.state = QN_ST_CHECK;
+                } else {
+                    c.req_kind = QN_REQ_X; c.req_t = 0.0; c.req_need_vectors = 1;
+                    c.after_state = QN_ST_AFTER_EVALX;
+                    c.phase = QN_PH_REQ_EVAL;
+                }
+            }
+        } break;
+
+        case QN_ST_AFTER_EVALX: {
+            if (!c.fused) return;
+            c.f_k = c.f_e; // g <- gt is committed by the direction pass (h_pass row-block 0)
+            c.gg = c.st_gg; c.gg_valid = 1;
+            c.have_cur_eval = c.memoize;
+            c.have_dir = 0;
+            c.state = QN_ST_CHECK;
+        } break;
+
+        case QN_ST_AFTER_DIR: {
+            if (!c.fused) return;
+            c.n_hpasses++;
+            if (c.pending) c.n_hpass_rw++;
+            c.pending = 0;
+            c.dir_mode = 0; // d = -v
+            c.gd0_valid = 0; c.d_finite = 0; c.last_valid = 0;
+            c.state = QN_ST_LS_BEGIN;
+        } break;
+
+        case QN_ST_AFTER_NEXT: { // bfgs.rs:94-102 from the sums staged by the accepted evaluation
+            if (!c.fused) return;
+            c.s_norm = sqrt(c.st_ss); c.has_s_norm = 1;
+            c.y_norm = sqrt(c.st_yy); c.has_y_norm = 1;
+            c.ys = c.st_ys;
+            c.gg = c.st_gg; c.gg_valid = 1;
+            c.f_k = c.f_e;
+            c.xc ^= 1; // x <- x+ : the trial half of the double buffer becomes x
+            c.have_cur_eval = c.memoize;
+            c.have_dir = 0;
+            c.last_valid = 0;
+            if (c.s_norm < c.tol || c.y_norm < c.tol) { // bfgs.rs:106-112: H is not updated
+                c.state = QN_ST_ITER_END;
+            } else {
+                c.hp_lazy = 1; c.hp_nrhs = 2;
+                c.after_state = QN_ST_AFTER_U;
+                c.phase = QN_PH_REQ_HPASS;
+            }
+        } break;
+
+        case QN_ST_AFTER_U: { // coefficients of bfgs.rs:115-124 / dfp.rs:115-120 in rank-2 form
+            if (!c.fused) return;
+            const double yu = c.hp_yu;
+            if (c.method == 0) { const double rho = 1.0 / c.ys; c.c_su = -rho; c.c_ss = rho * rho * yu + rho; c.c_uu = 0.0; }
+            else { c.c_ss = 1.0 / c.ys; c.c_su = 0.0; c.c_uu = -1.0 / yu; }
+            c.n_hpasses++;
+            if (c.pending) c.n_hpass_rw++;
+            c.pending = 1;
+            c.sc ^= 1; // the staged s becomes the pending s; the new u is already in UN
+            c.dir_mode = 1; c.dir_ug = c.hp_ug; c.dir_sg = c.hp_sg; // next direction formed on the fly by the evaluations
+            c.gd0_valid = 0; c.d_finite = 0;
+            c.have_dir = 1;
+            c.tr_updated = 1;
+            c.state = QN_ST_ITER_END;
+        } break;
+
+        case QN_ST_CHECK: { // ls_solver.rs:37-40 (OutOfDomain), has_converged (bfgs.rs:64-76)
+            if (!qn_check_is_scalar(c)) return; // gradient descent / unknown ||g||: all threads needed
+            double gnorm, gd0 = c.gd0;
+            int d_finite = c.d_finite;
+            if (c.small_n) { // reference order: norm = sqrt(dot), direction by column sweep (bfgs.rs:47)
+                gnorm = sqrt(ref_dot(V.g, V.g, n));
+                small_direction(V.H, n_pad, n, V.g, V.d, small_scratch);
+                gd0 = ref_dot(V.g, V.d, n);
+                d_finite = 1;
+                for (int i = 0; i < n; ++i) d_finite &= isfinite(V.d[i]) ? 1 : 0;
+            } else {
+                gnorm = sqrt(c.gg);
+            }
+            c.gnorm = gnorm; c.tr_f = c.f_k; c.tr_gnorm = gnorm;
+            const double f = c.f_k;
+            if (isnan(f) || isinf(f)) {
+                c.status = 2; c.phase = QN_PH_DONE; // OutOfDomain
+            } else if ((c.has_s_norm && c.s_norm < c.tol) || (c.has_y_norm && c.y_norm < c.tol) || (gnorm < c.tol)) {
+                c.status = 0; c.phase = QN_PH_DONE;
+            } else if (c.small_n) {
+                c.gd0 = gd0; c.d_finite = d_finite; c.last_valid = 0;
+                c.state = QN_ST_LS_BEGIN;
+            } else if (c.have_dir) {
+                c.state = QN_ST_LS_BEGIN;
+            } else { // bfgs.rs:47 d = -(H g): one pass over H (applies a pending update on the way)
+                c.hp_nrhs = 1; c.hp_lazy = 0;
+                c.after_state = QN_ST_AFTER_DIR;
+                c.phase = QN_PH_REQ_HPASS;
+            }
+        } break;
+
+        case QN_ST_LS_BEGIN: {
+            c.ls_i = 0;
+            if (c.ls_kind == 0) { // morethuente.rs:173-178
+                c.use_mod = 0; c.conv = 0;
+                c.t = fmin(fmax(1.0, c.mt_tmin), c.mt_tmax);
+                c.tl = c.mt_tmin; c.tu = c.mt_tmax;
+                c.state = QN_ST_MT_LOOP;
+            } else { // backtracking.rs:28-29
+                c.t = 1.0;
+                c.state = QN_ST_BT_LOOP;
+            }
+        } break;
+
+        case QN_ST_MT_LOOP: { // morethuente.rs:181-182
+            if (!(c.ls_i < c.max_iter_ls)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :295-296
+            else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_MT_AFTER_T, 0); }
+        } break;
+
+        case QN_ST_MT_AFTER_T: { // morethuente.rs:184-217
+            const double f_et = c.f_e, gd_t = c.gd_e, t = c.t;
+            const bool wolfe = (f_et - c.f_k <= c.mt_c1 * t * c.gd0) && (fabs(gd_t) <= c.mt_c2 * fabs(c.gd0));
+            if (wolfe || c.conv || t == c.tl || t == c.tu) {
+                tr_push_case(c, 0);
+                c.ls_result = t; c.state = QN_ST_AFTER_LS;
+            } else {
+                c.phi_t_f = f_et; c.phi_t_g = gd_t;
+                c.psi_t_f = f_et - c.f_k - c.mt_c1 * t * c.gd0; // psi, :140-149
+                c.psi_t_g = gd_t - c.mt_c1 * c.gd0;
+                if (!c.use_mod && c.psi_t_f <= 0. && c.phi_t_g > 0.) c.use_mod = 1; // :212-215
+                req_eval_t(c, c.tl, QN_ST_MT_AFTER_TL, 0); // :217
+            }
+        } break;
+
+        case QN_ST_MT_AFTER_TL: { // morethuente.rs:218-287
+            const double phi_tl_f = c.f_e, phi_tl_g = c.gd_e;
+            double f_tl, g_tl, f_t, g_t;
+            if (c.use_mod) { f_tl = phi_tl_f; g_tl = phi_tl_g; f_t = c.phi_t_f; g_t = c.phi_t_g; }
+            else {
+                f_tl = phi_tl_f - c.f_k - c.mt_c1 * c.tl * c.gd0;
+                g_tl = phi_tl_g - c.mt_c1 * c.gd0;
+                f_t = c.psi_t_f; g_t = c.psi_t_g;
+            }
+            c.sel_f_tl = f_tl; c.sel_g_tl = g_tl; c.sel_f_t = f_t; c.sel_g_t = g_t;
+            const double t = c.t, tl = c.tl, tu = c.tu;
+            if (f_t > f_tl) { // case 1
+                const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
+                const double tq = mt_quad1(tl, t, f_tl, f_t, g_tl);
+                tr_push_case(c, 1);
+                c.t = (fabs(tc - tl) < fabs(tq - tl)) ? tc : 0.5 * (tq + tc);
+                c.state = QN_ST_MT_FINISH;
+            } else if (g_t * g_tl < 0.) { // case 2
+                const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
+                const double ts = mt_quad2(tl, t, g_tl, g_t);
+                tr_push_case(c, 2);
+                c.t = (fabs(tc - t) >= fabs(ts - t)) ? tc : ts;
+                c.state = QN_ST_MT_FINISH;
+            } else if (fabs(g_t) <= fabs(g_tl)) { // case 3
+                const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
+                const double ts = mt_quad2(tl, t, g_tl, g_t);
+                tr_push_case(c, 3);
+                const double t_plus = (fabs(tc - t) < fabs(ts - t)) ? tc : ts;
+                if (t > tl) c.t = fmin(t_plus, t + c.mt_delta * (tu - t));
+                else c.t = fmax(t_plus, t + c.mt_delta * (tu - t));
+                c.state = QN_ST_MT_FINISH;
+            } else { // case 4: evaluates at tu (possibly +inf), :274-287
+                req_eval_t(c, c.tu, QN_ST_MT_AFTER_TU, 0);
+            }
+        } break;
+
+        case QN_ST_MT_AFTER_TU: {
+            double f_tu, g_tu;
+            if (c.use_mod) { f_tu = c.f_e; g_tu = c.gd_e; }
+            else { f_tu = c.f_e - c.f_k - c.mt_c1 * c.tu * c.gd0; g_tu = c.gd_e - c.mt_c1 * c.gd0; }
+            tr_push_case(c, 4);
+            c.t = mt_cubic(c.tu, c.t, c.sel_f_t, f_tu, c.sel_g_t, g_tu); // :286, argument order as written
+            c.state = QN_ST_MT_FINISH;
+        } break;
+
+        case QN_ST_MT_FINISH: { // morethuente.rs:290-293: the NEW t with the OLD trial's f_t, g_t
+            c.t = fmin(fmax(c.t, c.mt_tmin), c.mt_tmax);
+            double tl = c.tl, tu = c.tu;
+            c.conv = mt_update_interval(c.sel_f_tl, c.sel_f_t, c.sel_g_t, &tl, c.t, &tu);
+            c.tl = tl; c.tu = tu;
+            c.ls_i++;
+            c.state = QN_ST_MT_LOOP;
+        } break;
+
+        case QN_ST_BT_LOOP: { // backtracking.rs:31-34
+            if (!(c.max_iter_ls > c.ls_i)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :54
+            else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_BT_AFTER, 0); }
+        } break;
+
+        case QN_ST_BT_AFTER: { // backtracking.rs:37-51
+            const double f1 = c.f_e;
+            if (isnan(f1) || isinf(f1)) { c.t *= c.bt_beta; c.state = QN_ST_BT_LOOP; } // shrink, iteration not counted
+            else if (f1 - c.f_k <= c.bt_c1 * c.t * c.gd0) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; }
+            else { c.t *= c.bt_beta; c.ls_i++; c.state = QN_ST_BT_LOOP; }
+        } break;
+
+        case QN_ST_AFTER_LS: {
+            if (c.method == 2) return; // gradient descent: x += step*d needs all threads
+            req_eval_t(c, c.ls_result, QN_ST_AFTER_NEXT, 1); // bfgs.rs:94,98: oracle(x + step*d)
+        } break;
+
+        case QN_ST_ITER_END: { // ls_solver.rs:104-107
+            const bool rec = c.k < c.trace_cap;
+            if (rec && c.trace_x && !c.xtrace_done) return; // the iterate has to be copied by all threads first
+            if (rec) {
+                QnTraceRec r;
+                r.f = c.tr_f; r.gnorm = c.tr_gnorm; r.t = c.ls_result;
+                r.s_norm = c.has_s_norm ? c.s_norm : NAN;
+                r.y_norm = c.has_y_norm ? c.y_norm : NAN;
+                r.n_evals = c.tr_n_evals; r.ls_iters = c.tr_ls_iters; r.ls_cases = c.tr_ls_cases; r.updated = c.tr_updated;
+                V.trace[c.k] = r;
+            }
+            c.xtrace_done = 0;
+            c.k += 1;
+            c.n_iterations++;
+            c.state = QN_ST_LOOP_TOP;
+            if (c.callback_mode) c.phase = QN_PH_ITER_DONE;
+        } break;
+
+        default:
+            return; // a vector state
+        }
+    }
+    c.status = 4; // guard tripped
+    c.phase = QN_PH_DONE;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------
+template <int ORACLE>
+__global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict__ gctl, const QnVecs V, const int expect_phase) {
+    __shared__ QnCtl c;
+    __shared__ double lds[16 * QN_NEVP];
+    __shared__ double small_scratch[5 * QN_SMALL_N * QN_SMALL_N + QN_SMALL_N];
+    if (gctl->phase != expect_phase) return;
+    const int tid = threadIdx.x;
+    const int n = V.n, n_pad = V.n_pad;
+#ifdef QN_CTL_STAMPS
+    const long stamp_base = V.dbg ? (long)(V.dbg[0] & 0xffff) * 16 + 16 : 0;
+    if (tid == 0 && V.dbg) { V.dbg[0] = V.dbg[0] + 1; V.dbg[stamp_base + 15] = expect_phase; }
+#endif
+    QN_STAMP(0);
+    double* __restrict__ const vx = V.x;
+    double* __restrict__ const vg = V.g;
+    double* __restrict__ const vd = V.d;
+    double* __restrict__ const vxt = V.xt;
+    double* __restrict__ const vgt = V.gt;
+    double* __restrict__ const vs = V.s;
+    double* __restrict__ const vy = V.y;
+    double* __restrict__ const vsp = V.sp;
+    double* __restrict__ const vup = V.up;
+    const double* __restrict__ const vb = V.b;
+
+    const int fused = gctl->fused;
+    double fp[QN_NEVP];
+#pragma unroll
+    for (int k = 0; k < QN_NEVP; ++k) fp[k] = 0.0;
+    if (fused) { // nothing but per-workgroup partial sums to read
+        if (expect_phase == QN_PH_REQ_EVAL) {
+            ctl_sum_partials<QN_NEVP>(V.F.evp, V.world, V.F.nblk, fp, lds);
+        } else if (expect_phase == QN_PH_REQ_HPASS) {
+            double hp3[QN_NHPP];
+            ctl_sum_partials<QN_NHPP>(V.F.hpp, V.world, V.F.nblk, hp3, lds);
+            fp[0] = hp3[0]; fp[1] = hp3[1]; fp[2] = hp3[2];
+        }
+    }
+
+    // ---- consume the serviced evaluation: f, g at xt, and g.d, in one sweep; warm x and g for AFTER_NEXT ----
+    double cons_f = 0.0, cons_gd = 0.0;
+    if (!fused && expect_phase == QN_PH_REQ_EVAL) {
+        double p[3] = {0.0, 0.0, 0.0};
+        for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+            QN_TILE_IDX(base)
+            double qv[4], xv[4], bv[4], dv[4], px[4], pg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ORACLE == QN_ORACLE_QUAD) { qv[u] = q_val(V, idx[u]); xv[u] = vxt[idx[u]]; bv[u] = vb[idx[u]]; }
+                else { qv[u] = vgt[idx[u]]; xv[u] = 0.0; bv[u] = 0.0; }
+                dv[u] = vd[idx[u]];
+                px[u] = vx[idx[u]];
+                pg[u] = vg[idx[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ok[u]) {
+                    double gt = qv[u];
+                    if (ORACLE == QN_ORACLE_QUAD) { // f = 1/2 xt'(Q xt) - b'xt ; g = Q xt - b
+                        gt = qv[u] - bv[u];
+                        vgt[idx[u]] = gt;
+                        p[0] = __builtin_fma(xv[u], qv[u], p[0]);
+                        p[1] = __builtin_fma(bv[u], xv[u], p[1]);
+                    }
+                    p[2] = __builtin_fma(gt, dv[u], p[2]);
+                }
+                qn_keepalive(px[u]);
+                qn_keepalive(pg[u]);
+            }
+        }
+        QN_STAMP(1);
+        ctl_block_sum<3>(p, lds);
+        cons_f = (ORACLE == QN_ORACLE_QUAD) ? (0.5 * p[0] - p[1]) : *V.f_dev;
+        cons_gd = p[2];
+    }
+    {
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(gctl);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(&c);
+        for (int i = tid; i < (int)(sizeof(QnCtl) / 8); i += QN_CTL_TPB) dst[i] = src[i];
+    }
+    __syncthreads();
+    QN_STAMP(2);
+    if (tid == 0) {
+        if (fused && expect_phase == QN_PH_REQ_EVAL) {
+            cons_f = 0.5 * fp[0] - fp[1]; // f = 1/2 x+'(Q x+) - b'x+
+            cons_gd = fp[2];
+            c.st_gd0 = fp[3]; c.st_yy = fp[4]; c.st_ys = fp[5]; c.st_gg = fp[6]; c.st_ss = fp[7]; c.st_dnf = fp[8];
+            if (c.req_kind == QN_REQ_T && !c.gd0_valid) { c.gd0 = fp[3]; c.d_finite = fp[8] == 0.0; c.gd0_valid = 1; }
+        }
+        if (fused && expect_phase == QN_PH_REQ_HPASS) { c.hp_yu = fp[0]; c.hp_ug = fp[1]; c.hp_sg = fp[2]; }
+        if (expect_phase == QN_PH_REQ_EVAL) {
+            const int kind = c.req_kind;
+            if (c.small_n && kind == QN_REQ_T) cons_gd = ref_dot(V.gt, V.d, n);
+            c.f_e = cons_f;
+            c.gd_e = cons_gd;
+            c.n_oracle_evals++;
+            if (kind == QN_REQ_T) { c.last_valid = 1; c.last_t = c.req_t; c.f_last = cons_f; c.gd_last = cons_gd; }
+            else c.last_valid = 0;
+        }
+        if (expect_phase == QN_PH_IDLE) c.state = QN_ST_BEGIN;
+        else if (expect_phase == QN_PH_REQ_EVAL || expect_phase == QN_PH_REQ_HPASS) c.state = c.after_state;
+        c.phase = QN_PH_RUNNING;
+        ctl_scalar_run(c, V, small_scratch);
+    }
+    QN_STAMP(3);
+
+    for (int guard = 0; guard < (1 << 20); ++guard) {
+        __syncthreads();
+        if (c.phase != QN_PH_RUNNING) break;
+        const int st = c.state;
+        QN_STAMP(4 + 3 * (guard < 3 ? guard : 2));
+        switch (st) {
+        case QN_ST_AFTER_EVALX: { // g <- gt, ||g||^2
+            double p[1] = {0.0};
+            for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+                QN_TILE_IDX(base)
+                double gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gv[u] = vgt[idx[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u]) { vg[idx[u]] = gv[u]; p[0] = __builtin_fma(gv[u], gv[u], p[0]); }
+            }
+            ctl_block_sum<1>(p, lds);
+            if (tid == 0) {
+                c.f_k = c.f_e;
+                c.gg = p[0]; c.gg_valid = 1;
+                c.have_cur_eval = c.memoize;
+                c.have_dir = 0;
+                c.state = QN_ST_CHECK;
+            }
+        } break;
+
+        case QN_ST_CHECK: { // vector variant: gradient descent (inf-norm, d = -g), or ||g|| not known yet
+            const bool gd_method = c.method == 2;
+            double gnorm, p[2] = {0.0, 0.0};
+            if (gd_method) {
+                double m = -INFINITY; // fold(NEG_INFINITY, |acc, x| x.abs().max(acc)): NaN entries are ignored
+                for (int i = tid; i < n; i += QN_CTL_TPB) {
+                    const double gi = vg[i];
+                    m = fmax(fabs(gi), m);
+                    const double di = -gi; // gradient_descent.rs:29
+                    vd[i] = di;
+                    p[0] = __builtin_fma(gi, di, p[0]);
+                    p[1] += isfinite(di) ? 0.0 : 1.0;
+                }
+                gnorm = ctl_block_fmax(m, lds);
+                ctl_block_sum<2>(p, lds);
+                if (c.small_n) {
+                    __syncthreads();
+                    if (tid == 0) p[0] = ref_dot(V.g, V.d, n);
+                }
+            } else {
+                for (int i = tid; i < n_pad; i += QN_CTL_TPB) { const double gi = vg[i]; p[0] = __builtin_fma(gi, gi, p[0]); }
+                ctl_block_sum<2>(p, lds);
+                gnorm = sqrt(p[0]);
+            }
+            if (tid == 0) {
+                if (!gd_method) { // now ||g||^2 is known: the scalar variant finishes the state
+                    c.gg = p[0]; c.gg_valid = 1;
+                } else {
+                    c.gnorm = gnorm; c.tr_f = c.f_k; c.tr_gnorm = gnorm;
+                    const double f = c.f_k;
+                    if (isnan(f) || isinf(f)) { c.status = 2; c.phase = QN_PH_DONE; }
+                    else if (gnorm < c.tol) { c.status = 0; c.phase = QN_PH_DONE; } // gradient_descent.rs:46-53
+                    else { c.gd0 = p[0]; c.d_finite = p[1] == 0.0; c.last_valid = 0; c.state = QN_ST_LS_BEGIN; }
+                }
+            }
+        } break;
+
+        case QN_ST_AFTER_DIR: { // d = -(H g) from the gathered h_pass output, g.d
+            double p[2] = {0.0, 0.0};
+            for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+                QN_TILE_IDX(base)
+                double hv[4], gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { hv[u] = hp_val(V, 1, 0, idx[u]); gv[u] = vg[idx[u]]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u]) {
+                        const double di = -hv[u];
+                        vd[idx[u]] = di;
+                        p[0] = __builtin_fma(gv[u], di, p[0]);
+                        p[1] += isfinite(di) ? 0.0 : 1.0;
+                    }
+            }
+            ctl_block_sum<2>(p, lds);
+            if (tid == 0) {
+                c.n_hpasses++;
+                if (c.pending) c.n_hpass_rw++;
+                c.pending = 0;
+                c.gd0 = p[0]; c.d_finite = p[1] == 0.0; c.last_valid = 0;
+                c.state = QN_ST_LS_BEGIN;
+            }
+        } break;
+
+        case QN_ST_AFTER_LS: { // gradient descent only (ls_solver.rs:44-64 / gradient_descent.rs:55-82): x += step*d
+            const double step = c.ls_result;
+            const bool hit = c.last_valid && c.last_t == step;
+            const bool memo = c.memoize != 0;
+            double p[1] = {0.0};
+            for (int i = tid; i < n_pad; i += QN_CTL_TPB) {
+                if (hit) {
+                    vx[i] = vxt[i];
+                    if (memo) { const double gi = vgt[i]; vg[i] = gi; p[0] = __builtin_fma(gi, gi, p[0]); }
+                } else {
+                    const double td = step * vd[i];
+                    vx[i] = vx[i] + td;
+                }
+            }
+            ctl_block_sum<1>(p, lds);
+            if (tid == 0) {
+                if (hit && memo) { c.f_k = c.f_last; c.have_cur_eval = 1; } else c.have_cur_eval = 0;
+                c.gg_valid = 0;
+                c.last_valid = 0;
+                c.state = QN_ST_ITER_END;
+            }
+        } break;
+
+        case QN_ST_AFTER_NEXT: { // bfgs.rs:94-102 in one sweep: s, y, ||s||, ||y||, y.s, x <- x+, g <- g+, ||g+||^2
+            double p[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+                QN_TILE_IDX(base)
+                double xn[4], gn[4], xo[4], go[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { xn[u] = vxt[idx[u]]; gn[u] = vgt[idx[u]]; xo[u] = vx[idx[u]]; go[u] = vg[idx[u]]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u]) {
+                        const double si = xn[u] - xo[u]; // s = x+ - x (not t*d), :96
+                        const double yi = gn[u] - go[u]; // :98
+                        vs[idx[u]] = si; vy[idx[u]] = yi; vx[idx[u]] = xn[u]; vg[idx[u]] = gn[u];
+                        p[0] = __builtin_fma(si, si, p[0]);
+                        p[1] = __builtin_fma(yi, yi, p[1]);
+                        p[2] = __builtin_fma(yi, si, p[2]);
+                        p[3] = __builtin_fma(gn[u], gn[u], p[3]);
+                    }
+            }
+            ctl_block_sum<4>(p, lds);
+            if (c.small_n) {
+                __threadfence_block();
+                __syncthreads();
+                if (tid == 0) { p[0] = ref_dot(V.s, V.s, n); p[1] = ref_dot(V.y, V.y, n); p[2] = ref_dot(V.y, V.s, n); }
+            }
+            if (tid == 0) {
+                c.s_norm = sqrt(p[0]); c.has_s_norm = 1;
+                c.y_norm = sqrt(p[1]); c.has_y_norm = 1;
+                c.ys = p[2];
+                c.gg = p[3]; c.gg_valid = 1;
+                c.f_k = c.f_e;
+                c.have_cur_eval = c.memoize;
+                c.have_dir = 0;
+                c.last_valid = 0;
+                if (c.s_norm < c.tol || c.y_norm < c.tol) { // bfgs.rs:106-112: H is not updated
+                    c.state = QN_ST_ITER_END;
+                } else if (c.small_n) {
+                    small_update(V.H, n_pad, n, V.s, V.y, c.method, small_scratch);
+                    c.tr_updated = 1;
+                    c.state = QN_ST_ITER_END;
+                } else {
+                    c.hp_lazy = c.memoize;
+                    c.hp_nrhs = c.memoize ? 2 : 1; // u = H y (and v = H g+ when the next direction may be formed lazily)
+                    c.after_state = QN_ST_AFTER_U;
+                    c.phase = QN_PH_REQ_HPASS;
+                }
+            }
+        } break;
+
+        case QN_ST_AFTER_U: { // bfgs.rs:115-124 / dfp.rs:115-120 in rank-2 form; the update itself is applied by the next h_pass
+            const int nrhs = c.hp_nrhs;
+            const bool lazy = c.hp_lazy != 0;
+            const int method = c.method;
+            const double ys = c.ys;
+            double p[3] = {0.0, 0.0, 0.0};
+            for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+                QN_TILE_IDX(base)
+                double uv[4], sv[4], yv[4], gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uv[u] = hp_val(V, nrhs, 0, idx[u]); sv[u] = vs[idx[u]]; yv[u] = vy[idx[u]]; gv[u] = vg[idx[u]];
+                    if (lazy) qn_keepalive(hp_val(V, nrhs, 1, idx[u])); // warm v for the second sweep
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u]) {
+                        vup[idx[u]] = uv[u]; vsp[idx[u]] = sv[u];
+                        p[0] = __builtin_fma(yv[u], uv[u], p[0]);
+                        p[1] = __builtin_fma(uv[u], gv[u], p[1]);
+                        p[2] = __builtin_fma(sv[u], gv[u], p[2]);
+                    }
+            }
+            ctl_block_sum<3>(p, lds);
+            const double yu = p[0], ug = p[1], sg = p[2];
+            double c_ss, c_su, c_uu;
+            if (method == 0) { const double rho = 1.0 / ys; c_su = -rho; c_ss = rho * rho * yu + rho; c_uu = 0.0; }
+            else { c_ss = 1.0 / ys; c_su = 0.0; c_uu = -1.0 / yu; }
+            double q[2] = {0.0, 0.0};
+            if (lazy) { // d+ = -(H+ g+) = -(v + c_su (s (u.g) + u (s.g)) + c_ss s (s.g) + c_uu u (u.g)),  v = H g+
+                for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+                    QN_TILE_IDX(base)
+                    double uv[4], sv[4], vv[4], gv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { uv[u] = vup[idx[u]]; sv[u] = vsp[idx[u]]; vv[u] = hp_val(V, nrhs, 1, idx[u]); gv[u] = vg[idx[u]]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (ok[u]) {
+                            double w = vv[u];
+                            if (c_su != 0.0) w = w + c_su * (sv[u] * ug + uv[u] * sg);
+                            w = w + c_ss * (sv[u] * sg);
+                            if (c_uu != 0.0) w = w + c_uu * (uv[u] * ug);
+                            const double di = -w;
+                            vd[idx[u]] = di;
+                            q[0] = __builtin_fma(gv[u], di, q[0]);
+                            q[1] += isfinite(di) ? 0.0 : 1.0;
+                        }
+                }
+                ctl_block_sum<2>(q, lds);
+            }
+            if (tid == 0) {
+                c.n_hpasses++;
+                if (c.pending) c.n_hpass_rw++;
+                c.c_ss = c_ss; c.c_su = c_su; c.c_uu = c_uu;
+                c.pending = 1;
+                c.tr_updated = 1;
+                if (lazy) { c.gd0 = q[0]; c.d_finite = q[1] == 0.0; c.have_dir = 1; }
+                c.state = QN_ST_ITER_END;
+            }
+        } break;
+
+        case QN_ST_ITER_END: { // only reached here when the iterate has to be recorded (trace with x)
+            double* row = V.xtrace + (size_t)c.k * (size_t)n;
+            const double* xs = c.fused ? V.F.X0 + (size_t)c.xc * (size_t)n_pad : vx;
+            for (int i = tid; i < n; i += QN_CTL_TPB) row[i] = xs[i];
+            if (tid == 0) {
+                c.xtrace_done = 1;
+            }
+        } break;
+
+        default: { // a scalar state left over (cannot happen: ctl_scalar_run consumes them) -> abort instead of spinning
+            if (tid == 0) { c.status = 4; c.phase = QN_PH_DONE; }
+        } break;
+        }
+        QN_STAMP(5 + 3 * (guard < 3 ? guard : 2));
+        if (tid == 0) ctl_scalar_run(c, V, small_scratch); // chain the scalar states that follow without further barriers
+        QN_STAMP(6 + 3 * (guard < 3 ? guard : 2));
+    }
+    QN_STAMP(13);
+    __syncthreads();
+    if (tid == 0 && c.phase == QN_PH_RUNNING) { c.status = 4; c.phase = QN_PH_DONE; } // guard tripped
+    __syncthreads();
+    {
+        uint64_t* dst = reinterpret_cast<uint64_t*>(gctl);
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(&c);
+        for (int i = tid; i < (int)(sizeof(QnCtl) / 8); i += QN_CTL_TPB) dst[i] = src[i];
+    }
+    QN_STAMP(14);
+}

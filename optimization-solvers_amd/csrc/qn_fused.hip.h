@@ -1,0 +1,274 @@
+// qn_fused.hip.h -- the fused fast path (device objective, memoised oracle, BFGS / DFP).
+//
+// Measured on MI355X (profiles/r01_a_*): a single workgroup moves ~50 GB/s, so sweeping n-vectors in the
+// control workgroup cost 10-18 us per step at n = 4096 and would cost ~100 us at n = 32768.  In the fused
+// path NO kernel other than the two streaming kernels ever touches an n-vector:
+//
+//   quad_eval_fused_kernel  q = Q_rows (x + t d) with the direction formed on the fly
+//                           d_j = -(v_j + c_su (s_j (u.g) + u_j (s.g)) + c_ss s_j (s.g) + c_uu u_j (u.g)),
+//       epilogue per row i: gt_i = q_i - b_i, y_i = gt_i - g_i, and nine per-workgroup partial sums
+//                           (x+.q, b.x+, gt.d, g.d, y.y, y.s, gt.gt, s.s, #non-finite d);
+//       row-block 0 also stores the trial point x+ (into the other half of the x double buffer), the staged
+//       step s = x+ - x, and refreshes the pending-u copy.
+//   h_pass_fused_kernel     the H pass of qn_kernels.hip.h with an epilogue: u_i, v_i stored as vectors,
+//                           three partial sums (y.u, u.g+, s.g+); row-block 0 commits g <- g+.
+//   ctl_step (fused states) sums P*nblk partials per quantity and runs the scalar state machine.
+//
+// Accepting a line-search point is a pointer toggle (x double buffer, s double buffer) -- no copies.
+// Buffers whose slices are all-gathered across ranks (gt, y, u, v, partials) are fixed, so the host can issue
+// the collectives without knowing any device-side decision.
+#pragma once
+
+// d_j on the fly; `mode` 0: d = -v (direction pass), 1: lazy H+ g+ formula
+__device__ __forceinline__ double qn_dir1(int mode, double v, double s, double u, double c_ss, double c_su, double c_uu, double ug,
+                                          double sg) {
+    double w = v;
+    if (mode) {
+        if (c_su != 0.0) w = w + c_su * (s * ug + u * sg);
+        w = w + c_ss * (s * sg);
+        if (c_uu != 0.0) w = w + c_uu * (u * ug);
+    }
+    return -w;
+}
+
+// reduce NP values over the first R lanes of wave 0 (R a power of two <= 16); lane 0 gets the totals
+template <int R, int NP>
+__device__ __forceinline__ void qn_rows_reduce(double (&p)[NP]) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+#pragma unroll
+        for (int off = R / 2; off >= 1; off >>= 1) p[k] = p[k] + __shfl_xor(p[k], off, 64);
+    }
+}
+
+struct QnEvalFusedArgs {
+    const double* Q;
+    QnTile T;
+    QnFused F;
+    const QnCtl* ctl;
+    int expect_phase;
+};
+
+template <int R>
+__global__ __launch_bounds__(QN_TPB) void quad_eval_fused_kernel(const QnEvalFusedArgs a) {
+    __shared__ double red[4 * R];
+    const QnCtl* __restrict__ ctl = a.ctl;
+    if (ctl->phase != a.expect_phase) return;
+    const int kind = ctl->req_kind;
+    const double t = ctl->req_t;
+    const int mode = ctl->dir_mode;
+    const double c_ss = ctl->c_ss, c_su = ctl->c_su, c_uu = ctl->c_uu, ug = ctl->dir_ug, sg = ctl->dir_sg;
+    const QnTile T = a.T;
+    const size_t np = (size_t)T.n_pad;
+    const int xc = ctl->xc, sc = ctl->sc;
+    const double* __restrict__ x = a.F.X0 + (size_t)xc * np;
+    double* __restrict__ xt = a.F.X0 + (size_t)(1 - xc) * np;
+    const double* __restrict__ sp = a.F.S0 + (size_t)sc * np;
+    double* __restrict__ sstage = a.F.S0 + (size_t)(1 - sc) * np;
+    const double* __restrict__ un = a.F.UN;
+    const double* __restrict__ vv = a.F.VV;
+    const int tid = threadIdx.x;
+    const int rb = blockIdx.x * R;
+    const int nchunks = (T.n_pad + QN_CHUNK - 1) / QN_CHUNK;
+    const bool lead = blockIdx.x == 0;
+
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int j = c * QN_CHUNK + 2 * tid;
+        if (j < T.n_pad) {
+            const double* qbase = a.Q + (size_t)rb * np + j;
+            v2d h[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) h[r] = ld2(qbase + (size_t)r * np);
+            const v2d xj = ld2(x + j);
+            v2d xtj = xj;
+            v2d uj = {0.0, 0.0};
+            if (kind == QN_REQ_T) {
+                const v2d vj = ld2(vv + j);
+                v2d sj = {0.0, 0.0};
+                if (mode) { sj = ld2(sp + j); uj = ld2(un + j); }
+                const double d0 = qn_dir1(mode, vj.x, sj.x, uj.x, c_ss, c_su, c_uu, ug, sg);
+                const double d1 = qn_dir1(mode, vj.y, sj.y, uj.y, c_ss, c_su, c_uu, ug, sg);
+                const double td0 = t * d0, td1 = t * d1; // `step * direction` rounds first (bfgs.rs:94)
+                xtj.x = xj.x + td0;
+                xtj.y = xj.y + td1;
+            }
+            if (lead) {
+                st2(xt + j, xtj);
+                v2d sj2;
+                sj2.x = xtj.x - xj.x; // s = x+ - x (bfgs.rs:96)
+                sj2.y = xtj.y - xj.y;
+                st2(sstage + j, sj2);
+                st2(a.F.UP + j, (kind == QN_REQ_T && mode) ? uj : ld2(un + j)); // refresh the pending-u copy read by the next H pass
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r] = __builtin_fma(h[r].x, xtj.x, acc[r]);
+                acc[r] = __builtin_fma(h[r].y, xtj.y, acc[r]);
+            }
+        }
+    }
+    const double qi = qn_block_fold<R>(acc, red);
+    if (tid < R) {
+        const int gi = T.row_off + rb + tid;
+        const double xi = x[gi];
+        double di = 0.0;
+        if (kind == QN_REQ_T) {
+            const double si0 = mode ? sp[gi] : 0.0, ui0 = mode ? un[gi] : 0.0;
+            di = qn_dir1(mode, vv[gi], si0, ui0, c_ss, c_su, c_uu, ug, sg);
+        }
+        double xti = xi;
+        if (kind == QN_REQ_T) { const double td = t * di; xti = xi + td; }
+        const double bi = a.F.b[gi], go = a.F.G[gi];
+        const double gti = qi - bi;
+        const double yi = gti - go;
+        const double si = xti - xi;
+        a.F.GT[gi] = gti;
+        a.F.Y[gi] = yi;
+        double p[QN_NEVP];
+        p[0] = xti * qi;
+        p[1] = bi * xti;
+        p[2] = gti * di;
+        p[3] = go * di;
+        p[4] = yi * yi;
+        p[5] = yi * si;
+        p[6] = gti * gti;
+        p[7] = si * si;
+        p[8] = isfinite(di) ? 0.0 : 1.0;
+        qn_rows_reduce<R, QN_NEVP>(p);
+        if (tid == 0) {
+            double* out = a.F.evp + (size_t)T.rank * QN_NEVP * a.F.nblk + blockIdx.x;
+#pragma unroll
+            for (int k = 0; k < QN_NEVP; ++k) out[(size_t)k * a.F.nblk] = p[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// H pass with the fused epilogue.  Column work is h_pass_body's; this kernel adds the vector outputs.
+// ------------------------------------------------------------------------------------------------
+struct QnHPassFusedArgs {
+    double* H;
+    QnTile T;
+    QnFused F;
+    const QnCtl* ctl;
+    int expect_phase;
+};
+
+template <int R, int NRHS, bool PENDING>
+__device__ __forceinline__ void h_pass_fused_body(double* __restrict__ H, const QnTile T, const QnFused& F, const double* __restrict__ sp,
+                                                  const double* __restrict__ sstage, const double c_ss, const double c_su,
+                                                  const double c_uu, const bool dir_pass, double* red) {
+    const int tid = threadIdx.x;
+    const int rb = blockIdx.x * R;
+    const size_t np = (size_t)T.n_pad;
+    const int nchunks = (T.n_pad + QN_CHUNK - 1) / QN_CHUNK;
+    const bool use_su = c_su != 0.0, use_uu = c_uu != 0.0;
+    const bool lead = blockIdx.x == 0;
+    const double* __restrict__ up = F.UP;
+    const double* __restrict__ gt = F.GT;
+    const double* __restrict__ yv = F.Y;
+
+    double si[R], ui[R];
+    bool rowok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int gi = T.row_off + rb + r;
+        rowok[r] = gi < T.n;
+        si[r] = PENDING ? sp[gi] : 0.0;
+        ui[r] = PENDING ? up[gi] : 0.0;
+    }
+    constexpr int NV = NRHS * R;
+    double acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int j = c * QN_CHUNK + 2 * tid;
+        if (j < T.n_pad) {
+            double* hbase = H + (size_t)rb * np + j;
+            v2d h[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) h[r] = ld2(hbase + (size_t)r * np);
+            v2d sj = {0.0, 0.0}, uj = {0.0, 0.0};
+            if (PENDING) { sj = ld2(sp + j); uj = ld2(up + j); }
+            const v2d gj = ld2(gt + j);                 // g at the accepted point (g+), or g_0 for a direction pass
+            const v2d r0 = (NRHS == 2) ? ld2(yv + j) : gj; // update pass: rhs0 = y, rhs1 = g+ ; direction pass: rhs0 = g
+            if (lead) st2(F.G + j, gj);                 // commit g <- g+
+            const bool c0ok = j < T.n, c1ok = (j + 1) < T.n;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                v2d hn = h[r];
+                if (PENDING) {
+                    if (use_su) {
+                        hn.x = hn.x + c_su * (si[r] * uj.x + ui[r] * sj.x);
+                        hn.y = hn.y + c_su * (si[r] * uj.y + ui[r] * sj.y);
+                    }
+                    hn.x = hn.x + c_ss * (si[r] * sj.x);
+                    hn.y = hn.y + c_ss * (si[r] * sj.y);
+                    if (use_uu) {
+                        hn.x = hn.x + c_uu * (ui[r] * uj.x);
+                        hn.y = hn.y + c_uu * (ui[r] * uj.y);
+                    }
+                    hn.x = (rowok[r] && c0ok) ? hn.x : 0.0;
+                    hn.y = (rowok[r] && c1ok) ? hn.y : 0.0;
+                    st2(hbase + (size_t)r * np, hn);
+                }
+                acc[r] = __builtin_fma(hn.x, r0.x, acc[r]);
+                acc[r] = __builtin_fma(hn.y, r0.y, acc[r]);
+                if (NRHS == 2) {
+                    acc[R + r] = __builtin_fma(hn.x, gj.x, acc[R + r]);
+                    acc[R + r] = __builtin_fma(hn.y, gj.y, acc[R + r]);
+                }
+            }
+        }
+    }
+    const double tot = qn_block_fold<NV>(acc, red);
+    if (tid < NV) {
+        const int rhs = tid / R, r = tid % R;
+        const int gi = T.row_off + rb + r;
+        if (NRHS == 2) {
+            if (rhs == 0) F.UN[gi] = tot; else F.VV[gi] = tot;
+        } else {
+            F.VV[gi] = tot; // direction pass: v = H g
+        }
+    }
+    if (NRHS == 2 && tid < R) { // y.u, u.g+, s.g+ over this tile's rows (tid < R holds u_i)
+        const int gi = T.row_off + rb + tid;
+        const double gpi = gt[gi];
+        double p[QN_NHPP];
+        p[0] = yv[gi] * tot;
+        p[1] = tot * gpi;
+        p[2] = sstage[gi] * gpi;
+        qn_rows_reduce<R, QN_NHPP>(p);
+        if (tid == 0) {
+            double* out = F.hpp + (size_t)T.rank * QN_NHPP * F.nblk + blockIdx.x;
+#pragma unroll
+            for (int k = 0; k < QN_NHPP; ++k) out[(size_t)k * F.nblk] = p[k];
+        }
+    }
+    (void)dir_pass;
+}
+
+template <int R>
+__global__ __launch_bounds__(QN_TPB) void h_pass_fused_kernel(const QnHPassFusedArgs a) {
+    __shared__ double red[4 * 2 * R];
+    const QnCtl* __restrict__ ctl = a.ctl;
+    if (ctl->phase != a.expect_phase) return;
+    const int nrhs = ctl->hp_nrhs;
+    const int pending = ctl->pending;
+    const double c_ss = ctl->c_ss, c_su = ctl->c_su, c_uu = ctl->c_uu;
+    const size_t np = (size_t)a.T.n_pad;
+    const int sc = ctl->sc;
+    const double* sp = a.F.S0 + (size_t)sc * np;
+    const double* sstage = a.F.S0 + (size_t)(1 - sc) * np;
+    if (pending) {
+        if (nrhs == 2) h_pass_fused_body<R, 2, true>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, false, red);
+        else h_pass_fused_body<R, 1, true>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, true, red);
+    } else {
+        if (nrhs == 2) h_pass_fused_body<R, 2, false>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, false, red);
+        else h_pass_fused_body<R, 1, false>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, true, red);
+    }
+}

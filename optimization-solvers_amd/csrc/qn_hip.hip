@@ -60,6 +60,8 @@ struct RcclApi {
     int (*CommDestroy)(RcclComm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
 };
 static RcclApi g_rccl;
 static const int kRcclDouble = 8; // ncclFloat64 / ncclDouble (rccl.h)
@@ -78,6 +80,8 @@ static int rccl_load() {
     g_rccl.CommDestroy = (int (*)(RcclComm))dlsym(h, "ncclCommDestroy");
     g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t))dlsym(h, "ncclAllGather");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather)
         return fail(QN_ABNORMAL_TERMINATION, "librccl is missing a required symbol");
     g_rccl.handle = h;
@@ -200,6 +204,22 @@ static int exchange(qn_context* c, double* buf, size_t count) {
         return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed");
     HIPCHK(hipMemcpyAsync(buf, c->xchg_recv.data(), count * (size_t)c->world * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return QN_OK;
+}
+
+// Several in-place all-gathers issued as ONE RCCL group (one fused collective launch).
+struct XchgItem { double* buf; size_t count; };
+static int exchange_group(qn_context* c, const XchgItem* items, int nitems) {
+    if (c->world == 1) return QN_OK;
+    if (c->comm && g_rccl.GroupStart && g_rccl.GroupEnd) {
+        c->n_comm++;
+        RCCLCHK(g_rccl.GroupStart());
+        for (int i = 0; i < nitems; ++i)
+            RCCLCHK(g_rccl.AllGather(items[i].buf + (size_t)c->rank * items[i].count, items[i].buf, items[i].count, kRcclDouble, c->comm, c->stream));
+        RCCLCHK(g_rccl.GroupEnd());
+        return QN_OK;
+    }
+    for (int i = 0; i < nitems; ++i) QNCHK(exchange(c, items[i].buf, items[i].count));
     return QN_OK;
 }
 
@@ -444,12 +464,16 @@ struct qn_solver {
     double* vec_block = nullptr; // one allocation holding all n_pad vectors
     QnVecs V{};
     double* f_dev = nullptr;
+    double* fused_block = nullptr; // X0[2], S0[2], G, GT, Y, UN, UP, VV (10 n_pad vectors)
+    double *fused_evp = nullptr, *fused_hpp = nullptr;
+    int fused_nblk = 0;
     QnCtl* ctl = nullptr;  // device
     QnCtl* hctl = nullptr; // pinned host mirror
     double *hx = nullptr, *hg = nullptr; // pinned staging for host oracles
     size_t trace_cap = 0;
     int trace_x = 0;
     int sync_mode = -1; // -1 auto
+    int no_fused = 0;   // diagnostics: force the generic (non-fused) path
     int profiling = 0;
     std::vector<TimedEvent> events;
     std::vector<hipEvent_t> event_pool;
@@ -486,6 +510,28 @@ static void prof_collect(qn_solver* s) {
         s->event_pool.push_back(e.b);
     }
     s->events.clear();
+}
+
+// buffers of the fused fast path (allocated on first use; partial buffers depend on the row tile R)
+static int solver_alloc_fused(qn_solver* s) {
+    const size_t np = s->T.n_pad;
+    hipStream_t st = s->ctx->stream;
+    if (!s->fused_block) QNCHK(dev_alloc_zero(&s->fused_block, 10 * np, st));
+    const int nblk = s->T.rpr / s->R;
+    if (nblk != s->fused_nblk) {
+        if (s->fused_evp) { HIPCHK(hipFree(s->fused_evp)); s->fused_evp = nullptr; }
+        if (s->fused_hpp) { HIPCHK(hipFree(s->fused_hpp)); s->fused_hpp = nullptr; }
+        QNCHK(dev_alloc_zero(&s->fused_evp, (size_t)s->ctx->world * QN_NEVP * nblk, st));
+        QNCHK(dev_alloc_zero(&s->fused_hpp, (size_t)s->ctx->world * QN_NHPP * nblk, st));
+        s->fused_nblk = nblk;
+    }
+    double* p = s->fused_block;
+    QnFused& F = s->V.F;
+    F.X0 = p; F.S0 = p + 2 * np; F.G = p + 4 * np; F.GT = p + 5 * np; F.Y = p + 6 * np;
+    F.UN = p + 7 * np; F.UP = p + 8 * np; F.VV = p + 9 * np;
+    F.evp = s->fused_evp; F.hpp = s->fused_hpp;
+    F.nblk = nblk;
+    return QN_OK;
 }
 
 static int solver_alloc_hp(qn_solver* s) {
@@ -541,6 +587,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     for (auto& e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
+    (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
     delete s;
@@ -570,15 +617,31 @@ extern "C" int qn_solver_get_trace(qn_solver* s, qn_trace_rec* out_host, size_t 
     return QN_OK;
 }
 
+#ifdef QN_CTL_STAMPS
+extern "C" int qn_debug_stamps(qn_solver* s, unsigned long long* out, size_t count) { // diagnostic build only
+    HIPCHK(hipSetDevice(s->ctx->device));
+    if (!s->V.dbg) {
+        HIPCHK(hipMalloc((void**)&s->V.dbg, (1 << 20) * 8));
+        HIPCHK(hipMemset(s->V.dbg, 0, (1 << 20) * 8));
+        return QN_OK;
+    }
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    HIPCHK(hipMemcpy(out, s->V.dbg, count * 8, hipMemcpyDeviceToHost));
+    return QN_OK;
+}
+#endif
+
 extern "C" int qn_solver_set_profiling(qn_solver* s, int on) { s->profiling = on; return QN_OK; }
 extern "C" int qn_solver_set_sync_mode(qn_solver* s, int sync) { s->sync_mode = sync; return QN_OK; }
 extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits) {
+    if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; } // diagnostics: -1 selects the generic (non-fused) kernels
     if (rows_per_block != 0 && rows_per_block != 4 && rows_per_block != 8 && rows_per_block != 16)
         return fail(QN_ERROR_INPUT_PARAMS, "rows_per_block must be 4, 8 or 16");
     if (col_splits < 0 || col_splits > 64) return fail(QN_ERROR_INPUT_PARAMS, "col_splits out of range");
     HIPCHK(hipSetDevice(s->ctx->device));
     if (rows_per_block) s->R = rows_per_block;
     if (col_splits) { s->hcs = col_splits; s->qcs = col_splits; }
+    if (rows_per_block < 0) s->no_fused = 1;
     return solver_alloc_hp(s);
 }
 
@@ -751,6 +814,7 @@ struct Run {
     const qn_oracle* o;
     qn_objective* obj;
     int oracle_tpl; // QN_ORACLE_GENERIC / QN_ORACLE_QUAD
+    bool fused;
 };
 
 static int launch_ctl(Run& r, int expect_phase) {
@@ -765,10 +829,66 @@ static int launch_ctl(Run& r, int expect_phase) {
     return QN_OK;
 }
 
+template <int R>
+static void launch_eval_fused(hipStream_t st, const QnEvalFusedArgs& a) {
+    hipLaunchKernelGGL(quad_eval_fused_kernel<R>, dim3(a.T.rpr / R), dim3(QN_TPB), 0, st, a);
+}
+template <int R>
+static void launch_hpass_fused(hipStream_t st, const QnHPassFusedArgs& a) {
+    hipLaunchKernelGGL(h_pass_fused_kernel<R>, dim3(a.T.rpr / R), dim3(QN_TPB), 0, st, a);
+}
+
+static int enqueue_eval_fused(Run& r) {
+    qn_solver* s = r.s;
+    qn_context* c = s->ctx;
+    QnEvalFusedArgs a{};
+    a.Q = r.obj->Q; a.T = s->T; a.T.cs = 1; a.F = s->V.F; a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_EVAL;
+    {
+        ProfScope ps(s, KC_EVAL);
+        switch (s->R) {
+        case 4: launch_eval_fused<4>(c->stream, a); break;
+        case 16: launch_eval_fused<16>(c->stream, a); break;
+        default: launch_eval_fused<8>(c->stream, a); break;
+        }
+        s->stats.launches++;
+        HIPCHK(hipGetLastError());
+    }
+    if (c->world > 1) {
+        ProfScope ps(s, KC_COMM);
+        const XchgItem items[3] = {{s->V.F.GT, (size_t)s->T.rpr}, {s->V.F.Y, (size_t)s->T.rpr}, {s->V.F.evp, (size_t)QN_NEVP * s->V.F.nblk}};
+        QNCHK(exchange_group(c, items, 3));
+    }
+    return QN_OK;
+}
+
+static int enqueue_hpass_fused(Run& r) {
+    qn_solver* s = r.s;
+    qn_context* c = s->ctx;
+    QnHPassFusedArgs a{};
+    a.H = s->H; a.T = s->T; a.T.cs = 1; a.F = s->V.F; a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_HPASS;
+    {
+        ProfScope ps(s, KC_HPASS);
+        switch (s->R) {
+        case 4: launch_hpass_fused<4>(c->stream, a); break;
+        case 16: launch_hpass_fused<16>(c->stream, a); break;
+        default: launch_hpass_fused<8>(c->stream, a); break;
+        }
+        s->stats.launches++;
+        HIPCHK(hipGetLastError());
+    }
+    if (c->world > 1) {
+        ProfScope ps(s, KC_COMM);
+        const XchgItem items[3] = {{s->V.F.UN, (size_t)s->T.rpr}, {s->V.F.VV, (size_t)s->T.rpr}, {s->V.F.hpp, (size_t)QN_NHPP * s->V.F.nblk}};
+        QNCHK(exchange_group(c, items, 3));
+    }
+    return QN_OK;
+}
+
 // enqueue the evaluation of the oracle at the requested point (predicated on phase == REQ_EVAL)
 static int enqueue_eval(Run& r) {
     qn_solver* s = r.s;
     qn_context* c = s->ctx;
+    if (r.fused) return enqueue_eval_fused(r);
     if (r.oracle_tpl == QN_ORACLE_QUAD) {
         QnQuadArgs a{};
         a.Q = r.obj->Q; a.T = s->T; a.T.cs = s->qcs;
@@ -811,6 +931,7 @@ static int enqueue_eval(Run& r) {
 static int enqueue_hpass_req(Run& r) {
     qn_solver* s = r.s;
     qn_context* c = s->ctx;
+    if (r.fused) return enqueue_hpass_fused(r);
     QnHPassArgs a = hpass_args(s, QN_PH_REQ_HPASS);
     {
         ProfScope ps(s, KC_HPASS);
@@ -828,7 +949,7 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
     if (!s || !ls || !o) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
     qn_context* c = s->ctx;
     HIPCHK(hipSetDevice(c->device));
-    Run r{s, o, nullptr, QN_ORACLE_GENERIC};
+    Run r{s, o, nullptr, QN_ORACLE_GENERIC, false};
     if (o->kind == QN_ORACLE_OBJECTIVE) {
         if (!o->objective) return fail(QN_ERROR_INPUT_PARAMS, "objective is null");
         if (o->objective->ctx != c || o->objective->n != s->n) return fail(QN_ERROR_INPUT_PARAMS, "objective does not match the solver");
@@ -857,6 +978,21 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
     h->trace_x = s->trace_x;
     h->small_n = (s->n <= QN_SMALL_N && c->world == 1) ? 1 : 0;
     if (h->small_n && h->pending) QNCHK(flush_pending(s));
+    // fused fast path: device quadratic, memoised, BFGS/DFP, no callback, one column split, n > 5
+    r.fused = r.oracle_tpl == QN_ORACLE_QUAD && h->memoize && s->method != QN_GRADIENT_DESCENT && !callback && s->hcs == 1 &&
+              s->qcs == 1 && !h->small_n && !s->no_fused;
+    h->fused = r.fused ? 1 : 0;
+    if (r.fused) { // import the canonical state (x, pending s and u) into the fused buffers
+        QNCHK(solver_alloc_fused(s));
+        s->V.F.b = r.obj->b;
+        const size_t vb = (size_t)s->T.n_pad * sizeof(double);
+        HIPCHK(hipMemcpyAsync(s->V.F.X0, s->V.x, vb, hipMemcpyDeviceToDevice, c->stream));
+        if (h->pending) {
+            HIPCHK(hipMemcpyAsync(s->V.F.S0, s->V.sp, vb, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(s->V.F.UN, s->V.up, vb, hipMemcpyDeviceToDevice, c->stream));
+        }
+        h->xc = 0; h->sc = 0; h->dir_mode = 0; h->gd0_valid = 0;
+    }
     h->phase = QN_PH_IDLE;
     h->status = -1;
     QNCHK(poke_ctl(s));
@@ -892,6 +1028,15 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
                 if (!gd) { QNCHK(enqueue_hpass_req(r)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS)); }
             }
         }
+    }
+    if (r.fused) { // export back to the canonical buffers
+        const size_t np = s->T.n_pad, vb = np * sizeof(double);
+        HIPCHK(hipMemcpyAsync(s->V.x, s->V.F.X0 + (size_t)h->xc * np, vb, hipMemcpyDeviceToDevice, c->stream));
+        if (h->pending) {
+            HIPCHK(hipMemcpyAsync(s->V.sp, s->V.F.S0 + (size_t)h->sc * np, vb, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(s->V.up, s->V.F.UN, vb, hipMemcpyDeviceToDevice, c->stream));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
     }
     s->stats.iterations = h->n_iterations;
     s->stats.oracle_calls = h->n_oracle_calls;

@@ -39,6 +39,25 @@ struct QnTile {
     int rank;
 };
 
+#define QN_NEVP 9 // partial sums per workgroup of an evaluation (fused path)
+#define QN_NHPP 3 // partial sums per workgroup of an update pass (fused path)
+
+// buffers of the fused fast path (qn_fused.hip.h)
+struct QnFused {
+    double* X0;   // [2][n_pad]: x = X0 + xc*n_pad, trial point in the other half
+    double* S0;   // [2][n_pad]: pending s = S0 + sc*n_pad, staged s in the other half
+    double* G;    // gradient at x_k (committed by h_pass row-block 0)
+    double* GT;   // gradient at the last evaluated point (gathered)
+    double* Y;    // gt - g at the last evaluated point (gathered)
+    double* UN;   // u = H y of the last update pass (gathered)
+    double* UP;   // copy of UN read by the next update pass as the pending u
+    double* VV;   // v = H g+ (gathered)
+    double* evp;  // [world][QN_NEVP][nblk]
+    double* hpp;  // [world][QN_NHPP][nblk]
+    const double* b;
+    int nblk;     // row tiles per rank
+};
+
 struct QnVecs {
     double *x, *g, *d, *xt, *gt, *s, *y, *sp, *up;
     double* q;        // quadratic objective: Q (x + t d), gathered layout [world][qcs][rpr]
@@ -48,6 +67,8 @@ struct QnVecs {
     QnTraceRec* trace;
     double* xtrace;
     double* H; // this rank's rows (used directly only by the n <= 5 reference-order path)
+    unsigned long long* dbg; // diagnostic builds only (QN_CTL_STAMPS): in-kernel time stamps
+    QnFused F; // fused fast path buffers (valid when ctl->fused)
     int n, n_pad, rpr, world, hcs, qcs;
 };
 
@@ -478,8 +499,7 @@ __device__ __forceinline__ double ref_dot(const double* a, const double* b, int 
 }
 
 // d = -(H g), column sweep (bfgs.rs:47); H is row-major with leading dimension ld
-__device__ __forceinline__ void small_direction(const double* H, int ld, int n, const double* g, double* d) {
-    double y[QN_SMALL_N];
+__device__ __forceinline__ void small_direction(const double* H, int ld, int n, const double* g, double* d, double* y /* LDS, >= 5 */) {
     for (int i = 0; i < n; ++i) y[i] = H[i * ld] * g[0];
     for (int j = 1; j < n; ++j)
         for (int i = 0; i < n; ++i) y[i] = H[i * ld + j] * g[j] + y[i];
@@ -496,9 +516,10 @@ __device__ __forceinline__ void small_matmul(const double* a, const double* b, d
 }
 
 // bfgs.rs:115-124 / dfp.rs:115-120 exactly as written
-__device__ __forceinline__ void small_update(double* H, int ld, int n, const double* s, const double* y, int method) {
-    double h[QN_SMALL_N * QN_SMALL_N], m0[QN_SMALL_N * QN_SMALL_N], m1[QN_SMALL_N * QN_SMALL_N], m2[QN_SMALL_N * QN_SMALL_N],
-        m3[QN_SMALL_N * QN_SMALL_N];
+__device__ __forceinline__ void small_update(double* H, int ld, int n, const double* s, const double* y, int method,
+                                             double* scratch /* LDS, >= 5*25 + 5 doubles */) {
+    constexpr int MM = QN_SMALL_N * QN_SMALL_N;
+    double *h = scratch, *m0 = scratch + MM, *m1 = scratch + 2 * MM, *m2 = scratch + 3 * MM, *m3 = scratch + 4 * MM;
     for (int j = 0; j < n; ++j)
         for (int i = 0; i < n; ++i) h[i + j * QN_SMALL_N] = H[i * ld + j];
     if (method == 0) {
@@ -517,7 +538,7 @@ __device__ __forceinline__ void small_update(double* H, int ld, int n, const dou
             for (int i = 0; i < n; ++i) H[i * ld + j] = m3[i + j * QN_SMALL_N] + (s[i] * s[j]) * rho;
     } else {
         const double sy = ref_dot(s, y, n);
-        double u[QN_SMALL_N];
+        double* u = scratch + 5 * MM;
         for (int i = 0; i < n; ++i) u[i] = h[i] * y[0];
         for (int j = 1; j < n; ++j)
             for (int i = 0; i < n; ++i) u[i] = h[i + j * QN_SMALL_N] * y[j] + u[i];
@@ -538,443 +559,8 @@ __device__ __forceinline__ void small_update(double* H, int ld, int n, const dou
 #define QN_ORACLE_GENERIC 0
 #define QN_ORACLE_QUAD 1
 
-// ------------------------------------------------------------------------------------------------
-// ctl_step: the solver state machine.  One workgroup of 1024 threads; vector work is strided over the
-// workgroup (thread t always touches elements t, t+1024, ... so it only re-reads its own writes), scalar
-// decisions are taken by thread 0 on the LDS copy of the control block.
-// ------------------------------------------------------------------------------------------------
-template <int ORACLE>
-__global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict__ gctl, const QnVecs V, const int expect_phase) {
-    __shared__ QnCtl c;
-    __shared__ double lds[16 * 4];
-    if (gctl->phase != expect_phase) return;
-    const int tid = threadIdx.x;
-    {
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(gctl);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(&c);
-        for (int i = tid; i < (int)(sizeof(QnCtl) / 8); i += QN_CTL_TPB) dst[i] = src[i];
-    }
-    __syncthreads();
-    const int n = V.n, n_pad = V.n_pad;
-
-    // ---- consume the serviced request ----
-    if (expect_phase == QN_PH_REQ_EVAL) {
-        double f_e;
-        if (ORACLE == QN_ORACLE_QUAD) { // f = 1/2 xt'(Q xt) - b'xt ; g = Q xt - b
-            double p[2] = {0.0, 0.0};
-            for (int i = tid; i < n_pad; i += QN_CTL_TPB) {
-                const double qi = q_val(V, i), xi = V.xt[i], bi = V.b[i];
-                p[0] = __builtin_fma(xi, qi, p[0]);
-                p[1] = __builtin_fma(bi, xi, p[1]);
-                V.gt[i] = qi - bi;
-            }
-            ctl_block_sum<2>(p, lds);
-            f_e = 0.5 * p[0] - p[1];
-        } else {
-            f_e = *V.f_dev;
-        }
-        double gd[1] = {0.0};
-        const int kind = c.req_kind;
-        if (kind == QN_REQ_T) {
-            for (int i = tid; i < n_pad; i += QN_CTL_TPB) gd[0] = __builtin_fma(V.gt[i], V.d[i], gd[0]);
-            ctl_block_sum<1>(gd, lds);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            if (c.small_n && kind == QN_REQ_T) gd[0] = ref_dot(V.gt, V.d, n);
-            c.f_e = f_e;
-            c.gd_e = gd[0];
-            c.n_oracle_evals++;
-            if (kind == QN_REQ_T) { c.last_valid = 1; c.last_t = c.req_t; c.f_last = f_e; c.gd_last = gd[0]; }
-            else c.last_valid = 0;
-        }
-    }
-    if (tid == 0) {
-        if (expect_phase == QN_PH_IDLE) c.state = QN_ST_BEGIN;
-        else if (expect_phase == QN_PH_REQ_EVAL || expect_phase == QN_PH_REQ_HPASS) c.state = c.after_state;
-        c.phase = QN_PH_RUNNING;
-    }
-
-    for (int guard = 0; guard < (1 << 24); ++guard) {
-        __syncthreads();
-        if (c.phase != QN_PH_RUNNING) break;
-        const int st = c.state;
-        switch (st) {
-        case QN_ST_BEGIN: { // ls_solver.rs:74-76: only k is reset
-            if (tid == 0) {
-                c.k = 0;
-                c.have_cur_eval = 0; c.have_dir = 0; c.last_valid = 0;
-                c.n_oracle_calls = 0; c.n_oracle_evals = 0; c.n_hpasses = 0; c.n_hpass_rw = 0; c.n_iterations = 0;
-                c.status = -1;
-                c.state = QN_ST_LOOP_TOP;
-            }
-        } break;
-
-        case QN_ST_LOOP_TOP: { // ls_solver.rs:78-79
-            if (tid == 0) {
-                if (!(c.max_iter > c.k)) {
-                    c.status = 1; // MaxIterReached, ls_solver.rs:109-110
-                    c.phase = QN_PH_DONE;
-                } else {
-                    c.tr_n_evals = 0; c.tr_ls_iters = 0; c.tr_ls_cases = 0; c.tr_ndigits = 0; c.tr_updated = 0;
-                    c.ls_result = NAN;
-                    c.n_oracle_calls++;
-                    c.tr_n_evals++;
-                    if (c.memoize && c.have_cur_eval) {
-                        c.state = QN_ST_CHECK;
-                    } else {
-                        c.req_kind = QN_REQ_X; c.req_t = 0.0; c.req_need_vectors = 1;
-                        c.after_state = QN_ST_AFTER_EVALX;
-                        c.phase = QN_PH_REQ_EVAL;
-                    }
-                }
-            }
-        } break;
-
-        case QN_ST_AFTER_EVALX: {
-            for (int i = tid; i < n_pad; i += QN_CTL_TPB) V.g[i] = V.gt[i];
-            if (tid == 0) {
-                c.f_k = c.f_e;
-                c.have_cur_eval = c.memoize;
-                c.have_dir = 0;
-                c.state = QN_ST_CHECK;
-            }
-        } break;
-
-        case QN_ST_CHECK: { // ls_solver.rs:37-40 (OutOfDomain), has_converged (bfgs.rs:64-76 / gradient_descent.rs:46-53)
-            const bool gd_method = c.method == 2;
-            double gnorm, p[2] = {0.0, 0.0};
-            if (gd_method) {
-                double m = -INFINITY; // fold(NEG_INFINITY, |acc, x| x.abs().max(acc)): NaN entries are ignored
-                for (int i = tid; i < n; i += QN_CTL_TPB) {
-                    const double gi = V.g[i];
-                    m = fmax(fabs(gi), m);
-                    const double di = -gi; // gradient_descent.rs:29
-                    V.d[i] = di;
-                    p[0] = __builtin_fma(gi, di, p[0]);
-                    p[1] += isfinite(di) ? 0.0 : 1.0;
-                }
-                gnorm = ctl_block_fmax(m, lds);
-                ctl_block_sum<2>(p, lds);
-            } else {
-                for (int i = tid; i < n_pad; i += QN_CTL_TPB) { const double gi = V.g[i]; p[0] = __builtin_fma(gi, gi, p[0]); }
-                ctl_block_sum<2>(p, lds);
-                gnorm = sqrt(p[0]);
-            }
-            if (c.small_n) { // reference order, thread 0 (uniform branch)
-                __syncthreads();
-                if (tid == 0) {
-                    if (!gd_method) {
-                        gnorm = sqrt(ref_dot(V.g, V.g, n));
-                        small_direction(V.H, n_pad, n, V.g, V.d);
-                    }
-                    p[0] = ref_dot(V.g, V.d, n);
-                    p[1] = 0.0;
-                    for (int i = 0; i < n; ++i) p[1] += isfinite(V.d[i]) ? 0.0 : 1.0;
-                }
-            }
-            if (tid == 0) {
-                c.gnorm = gnorm; c.tr_f = c.f_k; c.tr_gnorm = gnorm;
-                const double f = c.f_k;
-                if (isnan(f) || isinf(f)) {
-                    c.status = 2; c.phase = QN_PH_DONE; // OutOfDomain
-                } else {
-                    bool conv;
-                    if (gd_method) conv = gnorm < c.tol;
-                    else conv = (c.has_s_norm && c.s_norm < c.tol) || (c.has_y_norm && c.y_norm < c.tol) || (gnorm < c.tol);
-                    if (conv) {
-                        c.status = 0; c.phase = QN_PH_DONE;
-                    } else if (gd_method) {
-                        c.gd0 = p[0]; c.d_finite = p[1] == 0.0; c.last_valid = 0;
-                        c.state = QN_ST_LS_BEGIN;
-                    } else if (c.small_n) {
-                        c.gd0 = p[0]; c.d_finite = p[1] == 0.0; c.last_valid = 0;
-                        c.state = QN_ST_LS_BEGIN;
-                    } else if (c.have_dir) {
-                        c.state = QN_ST_LS_BEGIN;
-                    } else { // bfgs.rs:47 d = -(H g): one pass over H (applies a pending update on the way)
-                        c.hp_nrhs = 1; c.hp_lazy = 0;
-                        c.after_state = QN_ST_AFTER_DIR;
-                        c.phase = QN_PH_REQ_HPASS;
-                    }
-                }
-            }
-        } break;
-
-        case QN_ST_AFTER_DIR: {
-            double p[2] = {0.0, 0.0};
-            for (int i = tid; i < n_pad; i += QN_CTL_TPB) {
-                const double di = -hp_val(V, 1, 0, i);
-                V.d[i] = di;
-                p[0] = __builtin_fma(V.g[i], di, p[0]);
-                p[1] += isfinite(di) ? 0.0 : 1.0;
-            }
-            ctl_block_sum<2>(p, lds);
-            if (tid == 0) {
-                c.n_hpasses++;
-                if (c.pending) c.n_hpass_rw++;
-                c.pending = 0;
-                c.gd0 = p[0]; c.d_finite = p[1] == 0.0; c.last_valid = 0;
-                c.state = QN_ST_LS_BEGIN;
-            }
-        } break;
-
-        case QN_ST_LS_BEGIN: {
-            if (tid == 0) {
-                c.ls_i = 0;
-                if (c.ls_kind == 0) { // morethuente.rs:173-178
-                    c.use_mod = 0; c.conv = 0;
-                    c.t = fmin(fmax(1.0, c.mt_tmin), c.mt_tmax);
-                    c.tl = c.mt_tmin; c.tu = c.mt_tmax;
-                    c.state = QN_ST_MT_LOOP;
-                } else { // backtracking.rs:28-29
-                    c.t = 1.0;
-                    c.state = QN_ST_BT_LOOP;
-                }
-            }
-        } break;
-
-        case QN_ST_MT_LOOP: { // morethuente.rs:181-182
-            if (tid == 0) {
-                if (!(c.ls_i < c.max_iter_ls)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :295-296
-                else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_MT_AFTER_T, 0); }
-            }
-        } break;
-
-        case QN_ST_MT_AFTER_T: { // morethuente.rs:184-217
-            if (tid == 0) {
-                const double f_et = c.f_e, gd_t = c.gd_e, t = c.t;
-                const bool wolfe = (f_et - c.f_k <= c.mt_c1 * t * c.gd0) && (fabs(gd_t) <= c.mt_c2 * fabs(c.gd0));
-                if (wolfe || c.conv || t == c.tl || t == c.tu) {
-                    tr_push_case(c, 0);
-                    c.ls_result = t; c.state = QN_ST_AFTER_LS;
-                } else {
-                    c.phi_t_f = f_et; c.phi_t_g = gd_t;
-                    c.psi_t_f = f_et - c.f_k - c.mt_c1 * t * c.gd0; // psi, :140-149
-                    c.psi_t_g = gd_t - c.mt_c1 * c.gd0;
-                    if (!c.use_mod && c.psi_t_f <= 0. && c.phi_t_g > 0.) c.use_mod = 1; // :212-215
-                    req_eval_t(c, c.tl, QN_ST_MT_AFTER_TL, 0); // :217
-                }
-            }
-        } break;
-
-        case QN_ST_MT_AFTER_TL: { // morethuente.rs:218-287
-            if (tid == 0) {
-                const double phi_tl_f = c.f_e, phi_tl_g = c.gd_e;
-                double f_tl, g_tl, f_t, g_t;
-                if (c.use_mod) { f_tl = phi_tl_f; g_tl = phi_tl_g; f_t = c.phi_t_f; g_t = c.phi_t_g; }
-                else {
-                    f_tl = phi_tl_f - c.f_k - c.mt_c1 * c.tl * c.gd0;
-                    g_tl = phi_tl_g - c.mt_c1 * c.gd0;
-                    f_t = c.psi_t_f; g_t = c.psi_t_g;
-                }
-                c.sel_f_tl = f_tl; c.sel_g_tl = g_tl; c.sel_f_t = f_t; c.sel_g_t = g_t;
-                const double t = c.t, tl = c.tl, tu = c.tu;
-                if (f_t > f_tl) { // case 1
-                    const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
-                    const double tq = mt_quad1(tl, t, f_tl, f_t, g_tl);
-                    tr_push_case(c, 1);
-                    c.t = (fabs(tc - tl) < fabs(tq - tl)) ? tc : 0.5 * (tq + tc);
-                    c.state = QN_ST_MT_FINISH;
-                } else if (g_t * g_tl < 0.) { // case 2
-                    const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
-                    const double ts = mt_quad2(tl, t, g_tl, g_t);
-                    tr_push_case(c, 2);
-                    c.t = (fabs(tc - t) >= fabs(ts - t)) ? tc : ts;
-                    c.state = QN_ST_MT_FINISH;
-                } else if (fabs(g_t) <= fabs(g_tl)) { // case 3
-                    const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
-                    const double ts = mt_quad2(tl, t, g_tl, g_t);
-                    tr_push_case(c, 3);
-                    const double t_plus = (fabs(tc - t) < fabs(ts - t)) ? tc : ts;
-                    if (t > tl) c.t = fmin(t_plus, t + c.mt_delta * (tu - t));
-                    else c.t = fmax(t_plus, t + c.mt_delta * (tu - t));
-                    c.state = QN_ST_MT_FINISH;
-                } else { // case 4: evaluates at tu (possibly +inf), :274-287
-                    req_eval_t(c, c.tu, QN_ST_MT_AFTER_TU, 0);
-                }
-            }
-        } break;
-
-        case QN_ST_MT_AFTER_TU: {
-            if (tid == 0) {
-                double f_tu, g_tu;
-                if (c.use_mod) { f_tu = c.f_e; g_tu = c.gd_e; }
-                else { f_tu = c.f_e - c.f_k - c.mt_c1 * c.tu * c.gd0; g_tu = c.gd_e - c.mt_c1 * c.gd0; }
-                tr_push_case(c, 4);
-                c.t = mt_cubic(c.tu, c.t, c.sel_f_t, f_tu, c.sel_g_t, g_tu); // :286, argument order as written
-                c.state = QN_ST_MT_FINISH;
-            }
-        } break;
-
-        case QN_ST_MT_FINISH: { // morethuente.rs:290-293: the NEW t with the OLD trial's f_t, g_t
-            if (tid == 0) {
-                c.t = fmin(fmax(c.t, c.mt_tmin), c.mt_tmax);
-                double tl = c.tl, tu = c.tu;
-                c.conv = mt_update_interval(c.sel_f_tl, c.sel_f_t, c.sel_g_t, &tl, c.t, &tu);
-                c.tl = tl; c.tu = tu;
-                c.ls_i++;
-                c.state = QN_ST_MT_LOOP;
-            }
-        } break;
-
-        case QN_ST_BT_LOOP: { // backtracking.rs:31-34
-            if (tid == 0) {
-                if (!(c.max_iter_ls > c.ls_i)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :54
-                else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_BT_AFTER, 0); }
-            }
-        } break;
-
-        case QN_ST_BT_AFTER: { // backtracking.rs:37-51
-            if (tid == 0) {
-                const double f1 = c.f_e;
-                if (isnan(f1) || isinf(f1)) { c.t *= c.bt_beta; c.state = QN_ST_BT_LOOP; } // shrink, iteration not counted
-                else if (f1 - c.f_k <= c.bt_c1 * c.t * c.gd0) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; }
-                else { c.t *= c.bt_beta; c.ls_i++; c.state = QN_ST_BT_LOOP; }
-            }
-        } break;
-
-        case QN_ST_AFTER_LS: {
-            if (c.method == 2) { // default hook ls_solver.rs:44-64 / gradient_descent.rs:55-82: x += step*d, no re-evaluation
-                const double step = c.ls_result;
-                const bool hit = c.last_valid && c.last_t == step;
-                for (int i = tid; i < n_pad; i += QN_CTL_TPB) {
-                    if (hit) { V.x[i] = V.xt[i]; if (c.memoize) V.g[i] = V.gt[i]; }
-                    else { const double td = step * V.d[i]; V.x[i] = V.x[i] + td; }
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    if (hit && c.memoize) { c.f_k = c.f_last; c.have_cur_eval = 1; } else c.have_cur_eval = 0;
-                    c.last_valid = 0;
-                    c.state = QN_ST_ITER_END;
-                }
-            } else {
-                if (tid == 0) req_eval_t(c, c.ls_result, QN_ST_AFTER_NEXT, 1); // bfgs.rs:94,98: oracle(x + step*d)
-            }
-        } break;
-
-        case QN_ST_AFTER_NEXT: { // bfgs.rs:94-102
-            double p[3] = {0.0, 0.0, 0.0};
-            for (int i = tid; i < n_pad; i += QN_CTL_TPB) {
-                const double xn = V.xt[i], gn = V.gt[i];
-                const double si = xn - V.x[i]; // s = x+ - x (not t*d), :96
-                const double yi = gn - V.g[i]; // :98
-                V.s[i] = si; V.y[i] = yi; V.x[i] = xn; V.g[i] = gn;
-                p[0] = __builtin_fma(si, si, p[0]);
-                p[1] = __builtin_fma(yi, yi, p[1]);
-                p[2] = __builtin_fma(yi, si, p[2]);
-            }
-            ctl_block_sum<3>(p, lds);
-            if (c.small_n) {
-                __threadfence_block();
-                __syncthreads();
-                if (tid == 0) { p[0] = ref_dot(V.s, V.s, n); p[1] = ref_dot(V.y, V.y, n); p[2] = ref_dot(V.y, V.s, n); }
-            }
-            if (tid == 0) {
-                c.s_norm = sqrt(p[0]); c.has_s_norm = 1;
-                c.y_norm = sqrt(p[1]); c.has_y_norm = 1;
-                c.ys = p[2];
-                c.f_k = c.f_e;
-                c.have_cur_eval = c.memoize;
-                c.have_dir = 0;
-                c.last_valid = 0;
-                if (c.s_norm < c.tol || c.y_norm < c.tol) { // bfgs.rs:106-112: H is not updated
-                    c.state = QN_ST_ITER_END;
-                } else if (c.small_n) {
-                    small_update(V.H, n_pad, n, V.s, V.y, c.method);
-                    c.tr_updated = 1;
-                    c.state = QN_ST_ITER_END;
-                } else {
-                    c.hp_lazy = c.memoize;
-                    c.hp_nrhs = c.memoize ? 2 : 1; // u = H y (and v = H g+ when the next direction may be formed lazily)
-                    c.after_state = QN_ST_AFTER_U;
-                    c.phase = QN_PH_REQ_HPASS;
-                }
-            }
-        } break;
-
-        case QN_ST_AFTER_U: { // bfgs.rs:115-124 / dfp.rs:115-120 in rank-2 form; the update itself is applied by the next h_pass
-            const int nrhs = c.hp_nrhs;
-            const bool lazy = c.hp_lazy != 0;
-            double p[3] = {0.0, 0.0, 0.0};
-            for (int i = tid; i < n_pad; i += QN_CTL_TPB) {
-                const double ui = hp_val(V, nrhs, 0, i);
-                const double si = V.s[i];
-                V.up[i] = ui; V.sp[i] = si;
-                p[0] = __builtin_fma(V.y[i], ui, p[0]);
-                if (lazy) {
-                    const double gi = V.g[i];
-                    p[1] = __builtin_fma(ui, gi, p[1]);
-                    p[2] = __builtin_fma(si, gi, p[2]);
-                }
-            }
-            ctl_block_sum<3>(p, lds);
-            const double yu = p[0], ug = p[1], sg = p[2];
-            double c_ss, c_su, c_uu;
-            if (c.method == 0) { const double rho = 1.0 / c.ys; c_su = -rho; c_ss = rho * rho * yu + rho; c_uu = 0.0; }
-            else { c_ss = 1.0 / c.ys; c_su = 0.0; c_uu = -1.0 / yu; }
-            double q[2] = {0.0, 0.0};
-            if (lazy) { // d+ = -(H+ g+) = -(v + c_su (s (u.g) + u (s.g)) + c_ss s (s.g) + c_uu u (u.g)),  v = H g+
-                for (int i = tid; i < n_pad; i += QN_CTL_TPB) {
-                    const double si = V.sp[i], ui = V.up[i];
-                    double w = hp_val(V, nrhs, 1, i);
-                    if (c_su != 0.0) w = w + c_su * (si * ug + ui * sg);
-                    w = w + c_ss * (si * sg);
-                    if (c_uu != 0.0) w = w + c_uu * (ui * ug);
-                    const double di = -w;
-                    V.d[i] = di;
-                    q[0] = __builtin_fma(V.g[i], di, q[0]);
-                    q[1] += isfinite(di) ? 0.0 : 1.0;
-                }
-                ctl_block_sum<2>(q, lds);
-            }
-            if (tid == 0) {
-                c.n_hpasses++;
-                if (c.pending) c.n_hpass_rw++;
-                c.c_ss = c_ss; c.c_su = c_su; c.c_uu = c_uu;
-                c.pending = 1;
-                c.tr_updated = 1;
-                if (lazy) { c.gd0 = q[0]; c.d_finite = q[1] == 0.0; c.have_dir = 1; }
-                c.state = QN_ST_ITER_END;
-            }
-        } break;
-
-        case QN_ST_ITER_END: { // ls_solver.rs:104-107
-            const bool rec = c.k < c.trace_cap;
-            if (rec && c.trace_x) {
-                double* row = V.xtrace + (size_t)c.k * (size_t)n;
-                for (int i = tid; i < n; i += QN_CTL_TPB) row[i] = V.x[i];
-            }
-            if (tid == 0) {
-                if (rec) {
-                    QnTraceRec r;
-                    r.f = c.tr_f; r.gnorm = c.tr_gnorm; r.t = c.ls_result;
-                    r.s_norm = c.has_s_norm ? c.s_norm : NAN;
-                    r.y_norm = c.has_y_norm ? c.y_norm : NAN;
-                    r.n_evals = c.tr_n_evals; r.ls_iters = c.tr_ls_iters; r.ls_cases = c.tr_ls_cases; r.updated = c.tr_updated;
-                    V.trace[c.k] = r;
-                }
-                c.k += 1;
-                c.n_iterations++;
-                c.state = QN_ST_LOOP_TOP;
-                if (c.callback_mode) c.phase = QN_PH_ITER_DONE;
-            }
-        } break;
-
-        default: {
-            if (tid == 0) { c.status = 4; c.phase = QN_PH_DONE; }
-        } break;
-        }
-    }
-    __syncthreads();
-    if (tid == 0 && c.phase == QN_PH_RUNNING) { c.status = 4; c.phase = QN_PH_DONE; } // guard tripped
-    __syncthreads();
-    {
-        uint64_t* dst = reinterpret_cast<uint64_t*>(gctl);
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(&c);
-        for (int i = tid; i < (int)(sizeof(QnCtl) / 8); i += QN_CTL_TPB) dst[i] = src[i];
-    }
-}
+#include "qn_fused.hip.h"
+#include "qn_ctl_step.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // plain primitives for the kernel-level FFI (include/qn_hip.h, last section).  No layout assumptions.

@@ -433,3 +433,38 @@ def test_full_size_properties_n4096(qn, qo):
     ref = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
     ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b, nthreads=qo.max_threads()), 12, 20, trace_cap=12, trace_x=True)
     _compare(tr[:12], xs[:12], ref.trace, ref.trace_x)
+
+
+def test_fused_path_matches_generic_path_and_oracle(qn, qo):
+    """The fused fast path (vector work in the streaming kernels' epilogues, pointer toggles) against the generic
+    path (vector work in the control workgroup) and the oracle."""
+    n = 777
+    q, b, x0, diag = P.synth_problem(qo, n)
+    ref, _, _ = _run_ref(qo, "bfgs", "mt", q, b, x0, 30)
+    obj = qn.Quadratic(q, b)
+    fused, _ = _run_gpu(qn, "bfgs", "mt", obj, x0, 30)
+    generic, _ = _run_gpu(qn, "bfgs", "mt", obj, x0, 30, tiling=(-1, 0))
+    tf, xf = fused.trace()
+    tg, xg = generic.trace()
+    _compare(tf, xf, ref.trace, ref.trace_x)
+    _compare(tg, xg, ref.trace, ref.trace_x)
+    _compare(tf, xf, tg, xg)
+    assert fused.stats()["oracle_evals"] == generic.stats()["oracle_evals"]
+    hf, hg = fused.approx_inv_hessian(), generic.approx_inv_hessian()
+    assert np.array_equal(hf, hf.T)
+    assert np.linalg.norm(hf - hg) <= 1e-9 * np.linalg.norm(hg)
+    # warm restart across paths: continue the fused run on the generic path and vice versa
+    for a, bpath in ((fused, (-1, 0)), (generic, (8, 1))):
+        a.set_tiling(*bpath) if bpath[0] > 0 else a.set_tiling(-1, 0)
+    cont_ref = qo.Solver(qo.BFGS, 1e-10, ref.x)
+    cont_ref.set_inv_hessian(ref.approx_inv_hessian)
+    cont_ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b), 10, 20, trace_cap=10, trace_x=True)
+    fused.set_trace(10, with_x=True)
+    try:
+        fused.minimize(qn.MoreThuente(), obj, 10, 20)
+    except qn.MaxIterReached:
+        pass
+    tc, xc = fused.trace()
+    w = min(len(tc), _window(cont_ref.trace))
+    for k in range(w):
+        assert np.linalg.norm(xc[k] - cont_ref.trace_x[k]) <= 1e-7 * max(1.0, np.linalg.norm(cont_ref.trace_x[k]))
