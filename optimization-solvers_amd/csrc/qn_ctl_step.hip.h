@@ -19,50 +19,38 @@
     int idx[4];                                                  \
     bool ok[4];                                                  \
     _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {           \
-        const int i_ = (base) + u_ * QN_CTL_TPB + tid;           \
+        const int i_ = (base) + u_ * tpb + tid;                  \
         ok[u_] = i_ < n_pad;                                     \
         idx[u_] = ok[u_] ? i_ : 0;                               \
     }
 
-// Sum K per-thread values over the workgroup; only thread 0 receives the totals (one barrier).
-template <int K>
-__device__ __forceinline__ void ctl_block_sum_t0(double (&v)[K], double* lds /* 16*K */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v[k] = v[k] + __shfl_xor(v[k], off, 64);
-    }
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double t = (lane < QN_CTL_TPB / 64) ? lds[lane * K + k] : 0.0;
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
-            v[k] = t;
-        }
-    }
-}
-
-// fused path: sum the per-workgroup partials [world][NP][nblk] in global tile order (rank-major = row order)
+// fused path: sum the per-workgroup partials [world][NP][nblk] in global tile order (rank-major = row order).
+// Column k is owned by wave (k mod nwaves): its 64 lanes stride the entries with all loads in flight, one
+// shuffle tree per column, lane 0 parks the total in LDS.  After the caller's barrier lds[k] holds column k.
 template <int NP>
-__device__ __forceinline__ void ctl_sum_partials(const double* __restrict__ part, int world, int nblk, double (&p)[NP], double* lds) {
-#pragma unroll
-    for (int k = 0; k < NP; ++k) p[k] = 0.0;
+__device__ __forceinline__ void ctl_sum_partials(const double* __restrict__ part, int world, int nblk, double* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int E = world * nblk;
-    for (int e = threadIdx.x; e < E; e += QN_CTL_TPB) {
-        const int r = e / nblk, b = e - r * nblk;
-        const double* base = part + (size_t)r * NP * nblk + b;
+    for (int k = wave; k < NP; k += nw) {
+        double acc = 0.0;
+        for (int e0 = 0; e0 < E; e0 += 8 * 64) {
+            double v[8];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) p[k] = p[k] + base[(size_t)k * nblk];
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 64 + lane;
+                const bool ok = e < E;
+                const int ee = ok ? e : 0;
+                const int r = ee / nblk, b = ee - r * nblk;
+                const double x = part[((size_t)r * NP + k) * nblk + b];
+                v[u] = ok ? x : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = acc + v[u];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
+        if (lane == 0) lds[k] = acc;
     }
-    ctl_block_sum_t0<NP>(p, lds);
 }
 
 __device__ __forceinline__ void qn_keepalive(double v) { asm volatile("" ::"v"(v)); }
@@ -332,6 +320,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
     __shared__ double small_scratch[5 * QN_SMALL_N * QN_SMALL_N + QN_SMALL_N];
     if (gctl->phase != expect_phase) return;
     const int tid = threadIdx.x;
+    const int tpb = blockDim.x;
     const int n = V.n, n_pad = V.n_pad;
 #ifdef QN_CTL_STAMPS
     const long stamp_base = V.dbg ? (long)(V.dbg[0] & 0xffff) * 16 + 16 : 0;
@@ -350,24 +339,16 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
     const double* __restrict__ const vb = V.b;
 
     const int fused = gctl->fused;
-    double fp[QN_NEVP];
-#pragma unroll
-    for (int k = 0; k < QN_NEVP; ++k) fp[k] = 0.0;
-    if (fused) { // nothing but per-workgroup partial sums to read
-        if (expect_phase == QN_PH_REQ_EVAL) {
-            ctl_sum_partials<QN_NEVP>(V.F.evp, V.world, V.F.nblk, fp, lds);
-        } else if (expect_phase == QN_PH_REQ_HPASS) {
-            double hp3[QN_NHPP];
-            ctl_sum_partials<QN_NHPP>(V.F.hpp, V.world, V.F.nblk, hp3, lds);
-            fp[0] = hp3[0]; fp[1] = hp3[1]; fp[2] = hp3[2];
-        }
+    if (fused) { // nothing but per-workgroup partial sums to read; column totals land in lds[0..NP)
+        if (expect_phase == QN_PH_REQ_EVAL) ctl_sum_partials<QN_NEVP>(V.F.evp, V.world, V.F.nblk, lds);
+        else if (expect_phase == QN_PH_REQ_HPASS) ctl_sum_partials<QN_NHPP>(V.F.hpp, V.world, V.F.nblk, lds);
     }
 
     // ---- consume the serviced evaluation: f, g at xt, and g.d, in one sweep; warm x and g for AFTER_NEXT ----
     double cons_f = 0.0, cons_gd = 0.0;
     if (!fused && expect_phase == QN_PH_REQ_EVAL) {
         double p[3] = {0.0, 0.0, 0.0};
-        for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+        for (int base = 0; base < n_pad; base += 4 * tpb) {
             QN_TILE_IDX(base)
             double qv[4], xv[4], bv[4], dv[4], px[4], pg[4];
 #pragma unroll
@@ -402,18 +383,18 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
     {
         const uint64_t* src = reinterpret_cast<const uint64_t*>(gctl);
         uint64_t* dst = reinterpret_cast<uint64_t*>(&c);
-        for (int i = tid; i < (int)(sizeof(QnCtl) / 8); i += QN_CTL_TPB) dst[i] = src[i];
+        for (int i = tid; i < (int)(sizeof(QnCtl) / 8); i += tpb) dst[i] = src[i];
     }
     __syncthreads();
     QN_STAMP(2);
     if (tid == 0) {
         if (fused && expect_phase == QN_PH_REQ_EVAL) {
-            cons_f = 0.5 * fp[0] - fp[1]; // f = 1/2 x+'(Q x+) - b'x+
-            cons_gd = fp[2];
-            c.st_gd0 = fp[3]; c.st_yy = fp[4]; c.st_ys = fp[5]; c.st_gg = fp[6]; c.st_ss = fp[7]; c.st_dnf = fp[8];
-            if (c.req_kind == QN_REQ_T && !c.gd0_valid) { c.gd0 = fp[3]; c.d_finite = fp[8] == 0.0; c.gd0_valid = 1; }
+            cons_f = 0.5 * lds[0] - lds[1]; // f = 1/2 x+'(Q x+) - b'x+
+            cons_gd = lds[2];
+            c.st_gd0 = lds[3]; c.st_yy = lds[4]; c.st_ys = lds[5]; c.st_gg = lds[6]; c.st_ss = lds[7]; c.st_dnf = lds[8];
+            if (c.req_kind == QN_REQ_T && !c.gd0_valid) { c.gd0 = lds[3]; c.d_finite = lds[8] == 0.0; c.gd0_valid = 1; }
         }
-        if (fused && expect_phase == QN_PH_REQ_HPASS) { c.hp_yu = fp[0]; c.hp_ug = fp[1]; c.hp_sg = fp[2]; }
+        if (fused && expect_phase == QN_PH_REQ_HPASS) { c.hp_yu = lds[0]; c.hp_ug = lds[1]; c.hp_sg = lds[2]; }
         if (expect_phase == QN_PH_REQ_EVAL) {
             const int kind = c.req_kind;
             if (c.small_n && kind == QN_REQ_T) cons_gd = ref_dot(V.gt, V.d, n);
@@ -438,7 +419,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
         switch (st) {
         case QN_ST_AFTER_EVALX: { // g <- gt, ||g||^2
             double p[1] = {0.0};
-            for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+            for (int base = 0; base < n_pad; base += 4 * tpb) {
                 QN_TILE_IDX(base)
                 double gv[4];
 #pragma unroll
@@ -462,7 +443,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
             double gnorm, p[2] = {0.0, 0.0};
             if (gd_method) {
                 double m = -INFINITY; // fold(NEG_INFINITY, |acc, x| x.abs().max(acc)): NaN entries are ignored
-                for (int i = tid; i < n; i += QN_CTL_TPB) {
+                for (int i = tid; i < n; i += tpb) {
                     const double gi = vg[i];
                     m = fmax(fabs(gi), m);
                     const double di = -gi; // gradient_descent.rs:29
@@ -477,7 +458,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                     if (tid == 0) p[0] = ref_dot(V.g, V.d, n);
                 }
             } else {
-                for (int i = tid; i < n_pad; i += QN_CTL_TPB) { const double gi = vg[i]; p[0] = __builtin_fma(gi, gi, p[0]); }
+                for (int i = tid; i < n_pad; i += tpb) { const double gi = vg[i]; p[0] = __builtin_fma(gi, gi, p[0]); }
                 ctl_block_sum<2>(p, lds);
                 gnorm = sqrt(p[0]);
             }
@@ -496,7 +477,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
 
         case QN_ST_AFTER_DIR: { // d = -(H g) from the gathered h_pass output, g.d
             double p[2] = {0.0, 0.0};
-            for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+            for (int base = 0; base < n_pad; base += 4 * tpb) {
                 QN_TILE_IDX(base)
                 double hv[4], gv[4];
 #pragma unroll
@@ -525,7 +506,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
             const bool hit = c.last_valid && c.last_t == step;
             const bool memo = c.memoize != 0;
             double p[1] = {0.0};
-            for (int i = tid; i < n_pad; i += QN_CTL_TPB) {
+            for (int i = tid; i < n_pad; i += tpb) {
                 if (hit) {
                     vx[i] = vxt[i];
                     if (memo) { const double gi = vgt[i]; vg[i] = gi; p[0] = __builtin_fma(gi, gi, p[0]); }
@@ -545,7 +526,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
 
         case QN_ST_AFTER_NEXT: { // bfgs.rs:94-102 in one sweep: s, y, ||s||, ||y||, y.s, x <- x+, g <- g+, ||g+||^2
             double p[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+            for (int base = 0; base < n_pad; base += 4 * tpb) {
                 QN_TILE_IDX(base)
                 double xn[4], gn[4], xo[4], go[4];
 #pragma unroll
@@ -598,7 +579,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
             const int method = c.method;
             const double ys = c.ys;
             double p[3] = {0.0, 0.0, 0.0};
-            for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+            for (int base = 0; base < n_pad; base += 4 * tpb) {
                 QN_TILE_IDX(base)
                 double uv[4], sv[4], yv[4], gv[4];
 #pragma unroll
@@ -622,7 +603,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
             else { c_ss = 1.0 / ys; c_su = 0.0; c_uu = -1.0 / yu; }
             double q[2] = {0.0, 0.0};
             if (lazy) { // d+ = -(H+ g+) = -(v + c_su (s (u.g) + u (s.g)) + c_ss s (s.g) + c_uu u (u.g)),  v = H g+
-                for (int base = 0; base < n_pad; base += 4 * QN_CTL_TPB) {
+                for (int base = 0; base < n_pad; base += 4 * tpb) {
                     QN_TILE_IDX(base)
                     double uv[4], sv[4], vv[4], gv[4];
 #pragma unroll
@@ -656,7 +637,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
         case QN_ST_ITER_END: { // only reached here when the iterate has to be recorded (trace with x)
             double* row = V.xtrace + (size_t)c.k * (size_t)n;
             const double* xs = c.fused ? V.F.X0 + (size_t)c.xc * (size_t)n_pad : vx;
-            for (int i = tid; i < n; i += QN_CTL_TPB) row[i] = xs[i];
+            for (int i = tid; i < n; i += tpb) row[i] = xs[i];
             if (tid == 0) {
                 c.xtrace_done = 1;
             }
@@ -677,7 +658,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
     {
         uint64_t* dst = reinterpret_cast<uint64_t*>(gctl);
         const uint64_t* src = reinterpret_cast<const uint64_t*>(&c);
-        for (int i = tid; i < (int)(sizeof(QnCtl) / 8); i += QN_CTL_TPB) dst[i] = src[i];
+        for (int i = tid; i < (int)(sizeof(QnCtl) / 8); i += tpb) dst[i] = src[i];
     }
     QN_STAMP(14);
 }

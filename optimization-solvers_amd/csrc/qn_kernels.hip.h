@@ -28,7 +28,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define QN_TPB 256        // threads per workgroup of the streaming kernels
 #define QN_CHUNK 512      // columns per chunk (2 per thread)
-#define QN_CTL_TPB 1024   // threads of the control workgroup
+#define QN_CTL_TPB 1024   // max threads of the control workgroup (generic path); the fused path launches 256
 
 struct QnTile {
     int n;       // logical dimension
@@ -392,7 +392,7 @@ __device__ __forceinline__ void ctl_block_sum(double (&v)[K], double* lds /* 16*
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         double t = 0.0;
-        for (int w = 0; w < QN_CTL_TPB / 64; ++w) t = t + lds[w * K + k];
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t = t + lds[w * K + k];
         v[k] = t;
     }
 }
@@ -405,7 +405,7 @@ __device__ __forceinline__ double ctl_block_fmax(double v, double* lds) {
     if (lane == 0) lds[wave] = v;
     __syncthreads();
     double t = -INFINITY;
-    for (int w = 0; w < QN_CTL_TPB / 64; ++w) t = fmax(t, lds[w]);
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, lds[w]);
     return t;
 }
 
