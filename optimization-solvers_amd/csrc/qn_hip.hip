@@ -820,8 +820,8 @@ struct Run {
 static int launch_ctl(Run& r, int expect_phase) {
     qn_solver* s = r.s;
     ProfScope ps(s, KC_CTL);
-    // the fused path only sums partials: 256 threads; the generic path sweeps n-vectors: 1024 threads
-    const dim3 blk(r.fused ? 256 : QN_CTL_TPB);
+    // the fused path only sums partials: 576 threads (one wave per column); the generic path sweeps n-vectors: 1024 threads
+    const dim3 blk(r.fused ? 576 : QN_CTL_TPB); // 9 waves: one per partial-sum column
     if (r.oracle_tpl == QN_ORACLE_QUAD)
         hipLaunchKernelGGL(ctl_step_kernel<QN_ORACLE_QUAD>, dim3(1), blk, 0, s->ctx->stream, s->ctl, s->V, expect_phase);
     else
