@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqn_hip.so")
+LIB_PATH = os.environ.get("QN_HIP_LIB") or os.path.join(_HERE, "lib", "libqn_hip.so")  # QN_HIP_LIB: diagnostic builds
 
 OK, MAX_ITER_REACHED, OUT_OF_DOMAIN, ERROR_INPUT_PARAMS, ABNORMAL_TERMINATION = range(5)
 LS_MORETHUENTE, LS_BACKTRACKING = 0, 1

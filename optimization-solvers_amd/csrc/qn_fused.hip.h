@@ -49,17 +49,44 @@ struct QnEvalFusedArgs {
     int expect_phase;
 };
 
-template <int R>
+// experiment switches (cache policy of the streamed matrices)
+#ifdef QN_NT_H
+#define QN_ST2_STREAM(p, v) __builtin_nontemporal_store((v), reinterpret_cast<v2d*>(p))
+#define QN_LD2_H(p) __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p))
+#else
+#define QN_ST2_STREAM(p, v) st2((p), (v))
+#define QN_LD2_H(p) ld2(p)
+#endif
+#ifdef QN_NT_Q
+#define QN_LD2_Q(p) __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p))
+#else
+#define QN_LD2_Q(p) ld2(p)
+#endif
+
+template <int R, int U>
 __global__ __launch_bounds__(QN_TPB) void quad_eval_fused_kernel(const QnEvalFusedArgs a) {
     __shared__ double red[4 * R];
+    const QnTile T = a.T;
+    const size_t np = (size_t)T.n_pad;
+    const int tid = threadIdx.x;
+    const int rb = blockIdx.x * R;
+    const int nchunks = (T.n_pad + QN_CHUNK - 1) / QN_CHUNK;
+    // The matrix addresses do not depend on the control block: issue the first tile's loads before reading it, so
+    // the (remote) control-block read and the first HBM round trip overlap.  A predicated-off launch wastes them.
+    v2d h[U][R];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = u * QN_CHUNK + 2 * tid;
+        const double* qbase = a.Q + (size_t)rb * np + (j < T.n_pad ? j : 0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) h[u][r] = QN_LD2_Q(qbase + (size_t)r * np);
+    }
     const QnCtl* __restrict__ ctl = a.ctl;
     if (ctl->phase != a.expect_phase) return;
     const int kind = ctl->req_kind;
     const double t = ctl->req_t;
     const int mode = ctl->dir_mode;
     const double c_ss = ctl->c_ss, c_su = ctl->c_su, c_uu = ctl->c_uu, ug = ctl->dir_ug, sg = ctl->dir_sg;
-    const QnTile T = a.T;
-    const size_t np = (size_t)T.n_pad;
     const int xc = ctl->xc, sc = ctl->sc;
     const double* __restrict__ x = a.F.X0 + (size_t)xc * np;
     double* __restrict__ xt = a.F.X0 + (size_t)(1 - xc) * np;
@@ -67,61 +94,68 @@ __global__ __launch_bounds__(QN_TPB) void quad_eval_fused_kernel(const QnEvalFus
     double* __restrict__ sstage = a.F.S0 + (size_t)(1 - sc) * np;
     const double* __restrict__ un = a.F.UN;
     const double* __restrict__ vv = a.F.VV;
-    const int tid = threadIdx.x;
-    const int rb = blockIdx.x * R;
-    const int nchunks = (T.n_pad + QN_CHUNK - 1) / QN_CHUNK;
     const bool lead = blockIdx.x == 0;
+    const bool is_t = kind == QN_REQ_T;
+
+    // row-side inputs of the epilogue, fetched now so that their latency is hidden behind the streaming loop
+    const int gi = T.row_off + rb + (tid < R ? tid : 0);
+    const double e_x = x[gi], e_b = a.F.b[gi], e_g = a.F.G[gi];
+    const double e_v = is_t ? vv[gi] : 0.0;
+    const double e_s = (is_t && mode) ? sp[gi] : 0.0, e_u = (is_t && mode) ? un[gi] : 0.0;
 
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
-    for (int c = 0; c < nchunks; ++c) {
-        const int j = c * QN_CHUNK + 2 * tid;
-        if (j < T.n_pad) {
-            const double* qbase = a.Q + (size_t)rb * np + j;
-            v2d h[R];
+    for (int c = 0; c < nchunks; c += U) {
+        if (c > 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) h[r] = ld2(qbase + (size_t)r * np);
-            const v2d xj = ld2(x + j);
-            v2d xtj = xj;
-            v2d uj = {0.0, 0.0};
-            if (kind == QN_REQ_T) {
-                const v2d vj = ld2(vv + j);
-                v2d sj = {0.0, 0.0};
-                if (mode) { sj = ld2(sp + j); uj = ld2(un + j); }
-                const double d0 = qn_dir1(mode, vj.x, sj.x, uj.x, c_ss, c_su, c_uu, ug, sg);
-                const double d1 = qn_dir1(mode, vj.y, sj.y, uj.y, c_ss, c_su, c_uu, ug, sg);
-                const double td0 = t * d0, td1 = t * d1; // `step * direction` rounds first (bfgs.rs:94)
-                xtj.x = xj.x + td0;
-                xtj.y = xj.y + td1;
-            }
-            if (lead) {
-                st2(xt + j, xtj);
-                v2d sj2;
-                sj2.x = xtj.x - xj.x; // s = x+ - x (bfgs.rs:96)
-                sj2.y = xtj.y - xj.y;
-                st2(sstage + j, sj2);
-                st2(a.F.UP + j, (kind == QN_REQ_T && mode) ? uj : ld2(un + j)); // refresh the pending-u copy read by the next H pass
-            }
+            for (int u = 0; u < U; ++u) {
+                const int j = (c + u) * QN_CHUNK + 2 * tid;
+                const double* qbase = a.Q + (size_t)rb * np + (j < T.n_pad ? j : 0);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                acc[r] = __builtin_fma(h[r].x, xtj.x, acc[r]);
-                acc[r] = __builtin_fma(h[r].y, xtj.y, acc[r]);
+                for (int r = 0; r < R; ++r) h[u][r] = QN_LD2_Q(qbase + (size_t)r * np);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = (c + u) * QN_CHUNK + 2 * tid;
+            if (j < T.n_pad) {
+                const v2d xj = ld2(x + j);
+                v2d xtj = xj;
+                v2d uj = {0.0, 0.0};
+                if (is_t) {
+                    const v2d vj = ld2(vv + j);
+                    v2d sj = {0.0, 0.0};
+                    if (mode) { sj = ld2(sp + j); uj = ld2(un + j); }
+                    const double d0 = qn_dir1(mode, vj.x, sj.x, uj.x, c_ss, c_su, c_uu, ug, sg);
+                    const double d1 = qn_dir1(mode, vj.y, sj.y, uj.y, c_ss, c_su, c_uu, ug, sg);
+                    const double td0 = t * d0, td1 = t * d1; // `step * direction` rounds first (bfgs.rs:94)
+                    xtj.x = xj.x + td0;
+                    xtj.y = xj.y + td1;
+                }
+                if (lead) {
+                    st2(xt + j, xtj);
+                    v2d sj2;
+                    sj2.x = xtj.x - xj.x; // s = x+ - x (bfgs.rs:96)
+                    sj2.y = xtj.y - xj.y;
+                    st2(sstage + j, sj2);
+                    st2(a.F.UP + j, (is_t && mode) ? uj : ld2(un + j)); // refresh the pending-u copy read by the next H pass
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    acc[r] = __builtin_fma(h[u][r].x, xtj.x, acc[r]);
+                    acc[r] = __builtin_fma(h[u][r].y, xtj.y, acc[r]);
+                }
             }
         }
     }
     const double qi = qn_block_fold<R>(acc, red);
     if (tid < R) {
-        const int gi = T.row_off + rb + tid;
-        const double xi = x[gi];
-        double di = 0.0;
-        if (kind == QN_REQ_T) {
-            const double si0 = mode ? sp[gi] : 0.0, ui0 = mode ? un[gi] : 0.0;
-            di = qn_dir1(mode, vv[gi], si0, ui0, c_ss, c_su, c_uu, ug, sg);
-        }
+        const double xi = e_x;
+        const double di = is_t ? qn_dir1(mode, e_v, e_s, e_u, c_ss, c_su, c_uu, ug, sg) : 0.0;
         double xti = xi;
-        if (kind == QN_REQ_T) { const double td = t * di; xti = xi + td; }
-        const double bi = a.F.b[gi], go = a.F.G[gi];
+        if (is_t) { const double td = t * di; xti = xi + td; }
+        const double bi = e_b, go = e_g;
         const double gti = qi - bi;
         const double yi = gti - go;
         const double si = xti - xi;
@@ -157,10 +191,10 @@ struct QnHPassFusedArgs {
     int expect_phase;
 };
 
-template <int R, int NRHS, bool PENDING>
+template <int R, int U, int NRHS, bool PENDING>
 __device__ __forceinline__ void h_pass_fused_body(double* __restrict__ H, const QnTile T, const QnFused& F, const double* __restrict__ sp,
                                                   const double* __restrict__ sstage, const double c_ss, const double c_su,
-                                                  const double c_uu, const bool dir_pass, double* red) {
+                                                  const double c_uu, v2d (&h)[U][R], double* red) {
     const int tid = threadIdx.x;
     const int rb = blockIdx.x * R;
     const size_t np = (size_t)T.n_pad;
@@ -180,47 +214,61 @@ __device__ __forceinline__ void h_pass_fused_body(double* __restrict__ H, const 
         si[r] = PENDING ? sp[gi] : 0.0;
         ui[r] = PENDING ? up[gi] : 0.0;
     }
+    // row-side inputs of the epilogue (fetched early)
+    const int egi = T.row_off + rb + (tid < R ? tid : 0);
+    const double e_gp = gt[egi];
+    const double e_y = (NRHS == 2) ? yv[egi] : 0.0, e_s = (NRHS == 2) ? sstage[egi] : 0.0;
+
     constexpr int NV = NRHS * R;
     double acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.0;
 
-    for (int c = 0; c < nchunks; ++c) {
-        const int j = c * QN_CHUNK + 2 * tid;
-        if (j < T.n_pad) {
-            double* hbase = H + (size_t)rb * np + j;
-            v2d h[R];
+    for (int c = 0; c < nchunks; c += U) {
+        if (c > 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) h[r] = ld2(hbase + (size_t)r * np);
-            v2d sj = {0.0, 0.0}, uj = {0.0, 0.0};
-            if (PENDING) { sj = ld2(sp + j); uj = ld2(up + j); }
-            const v2d gj = ld2(gt + j);                 // g at the accepted point (g+), or g_0 for a direction pass
-            const v2d r0 = (NRHS == 2) ? ld2(yv + j) : gj; // update pass: rhs0 = y, rhs1 = g+ ; direction pass: rhs0 = g
-            if (lead) st2(F.G + j, gj);                 // commit g <- g+
-            const bool c0ok = j < T.n, c1ok = (j + 1) < T.n;
+            for (int u = 0; u < U; ++u) {
+                const int j = (c + u) * QN_CHUNK + 2 * tid;
+                const double* hbase = H + (size_t)rb * np + (j < T.n_pad ? j : 0);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                v2d hn = h[r];
-                if (PENDING) {
-                    if (use_su) {
-                        hn.x = hn.x + c_su * (si[r] * uj.x + ui[r] * sj.x);
-                        hn.y = hn.y + c_su * (si[r] * uj.y + ui[r] * sj.y);
+                for (int r = 0; r < R; ++r) h[u][r] = QN_LD2_H(hbase + (size_t)r * np);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = (c + u) * QN_CHUNK + 2 * tid;
+            if (j < T.n_pad) {
+                double* hbase = H + (size_t)rb * np + j;
+                v2d sj = {0.0, 0.0}, uj = {0.0, 0.0};
+                if (PENDING) { sj = ld2(sp + j); uj = ld2(up + j); }
+                const v2d gj = ld2(gt + j);                    // g at the accepted point (g+), or g_0 for a direction pass
+                const v2d r0 = (NRHS == 2) ? ld2(yv + j) : gj; // update pass: rhs0 = y, rhs1 = g+ ; direction pass: rhs0 = g
+                if (lead) st2(F.G + j, gj);                    // commit g <- g+
+                const bool c0ok = j < T.n, c1ok = (j + 1) < T.n;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    v2d hn = h[u][r];
+                    if (PENDING) {
+                        if (use_su) {
+                            hn.x = hn.x + c_su * (si[r] * uj.x + ui[r] * sj.x);
+                            hn.y = hn.y + c_su * (si[r] * uj.y + ui[r] * sj.y);
+                        }
+                        hn.x = hn.x + c_ss * (si[r] * sj.x);
+                        hn.y = hn.y + c_ss * (si[r] * sj.y);
+                        if (use_uu) {
+                            hn.x = hn.x + c_uu * (ui[r] * uj.x);
+                            hn.y = hn.y + c_uu * (ui[r] * uj.y);
+                        }
+                        hn.x = (rowok[r] && c0ok) ? hn.x : 0.0;
+                        hn.y = (rowok[r] && c1ok) ? hn.y : 0.0;
+                        QN_ST2_STREAM(hbase + (size_t)r * np, hn);
                     }
-                    hn.x = hn.x + c_ss * (si[r] * sj.x);
-                    hn.y = hn.y + c_ss * (si[r] * sj.y);
-                    if (use_uu) {
-                        hn.x = hn.x + c_uu * (ui[r] * uj.x);
-                        hn.y = hn.y + c_uu * (ui[r] * uj.y);
+                    acc[r] = __builtin_fma(hn.x, r0.x, acc[r]);
+                    acc[r] = __builtin_fma(hn.y, r0.y, acc[r]);
+                    if (NRHS == 2) {
+                        acc[R + r] = __builtin_fma(hn.x, gj.x, acc[R + r]);
+                        acc[R + r] = __builtin_fma(hn.y, gj.y, acc[R + r]);
                     }
-                    hn.x = (rowok[r] && c0ok) ? hn.x : 0.0;
-                    hn.y = (rowok[r] && c1ok) ? hn.y : 0.0;
-                    st2(hbase + (size_t)r * np, hn);
-                }
-                acc[r] = __builtin_fma(hn.x, r0.x, acc[r]);
-                acc[r] = __builtin_fma(hn.y, r0.y, acc[r]);
-                if (NRHS == 2) {
-                    acc[R + r] = __builtin_fma(hn.x, gj.x, acc[R + r]);
-                    acc[R + r] = __builtin_fma(hn.y, gj.y, acc[R + r]);
                 }
             }
         }
@@ -236,12 +284,10 @@ __device__ __forceinline__ void h_pass_fused_body(double* __restrict__ H, const 
         }
     }
     if (NRHS == 2 && tid < R) { // y.u, u.g+, s.g+ over this tile's rows (tid < R holds u_i)
-        const int gi = T.row_off + rb + tid;
-        const double gpi = gt[gi];
         double p[QN_NHPP];
-        p[0] = yv[gi] * tot;
-        p[1] = tot * gpi;
-        p[2] = sstage[gi] * gpi;
+        p[0] = e_y * tot;
+        p[1] = tot * e_gp;
+        p[2] = e_s * e_gp;
         qn_rows_reduce<R, QN_NHPP>(p);
         if (tid == 0) {
             double* out = F.hpp + (size_t)T.rank * QN_NHPP * F.nblk + blockIdx.x;
@@ -249,26 +295,33 @@ __device__ __forceinline__ void h_pass_fused_body(double* __restrict__ H, const 
             for (int k = 0; k < QN_NHPP; ++k) out[(size_t)k * F.nblk] = p[k];
         }
     }
-    (void)dir_pass;
 }
 
-template <int R>
+template <int R, int U>
 __global__ __launch_bounds__(QN_TPB) void h_pass_fused_kernel(const QnHPassFusedArgs a) {
     __shared__ double red[4 * 2 * R];
+    const size_t np = (size_t)a.T.n_pad;
+    v2d h[U][R]; // first tile: issued before the control block is read (see quad_eval_fused_kernel)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = u * QN_CHUNK + 2 * (int)threadIdx.x;
+        const double* hbase = a.H + (size_t)(blockIdx.x * R) * np + (j < a.T.n_pad ? j : 0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) h[u][r] = QN_LD2_H(hbase + (size_t)r * np);
+    }
     const QnCtl* __restrict__ ctl = a.ctl;
     if (ctl->phase != a.expect_phase) return;
     const int nrhs = ctl->hp_nrhs;
     const int pending = ctl->pending;
     const double c_ss = ctl->c_ss, c_su = ctl->c_su, c_uu = ctl->c_uu;
-    const size_t np = (size_t)a.T.n_pad;
     const int sc = ctl->sc;
     const double* sp = a.F.S0 + (size_t)sc * np;
     const double* sstage = a.F.S0 + (size_t)(1 - sc) * np;
     if (pending) {
-        if (nrhs == 2) h_pass_fused_body<R, 2, true>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, false, red);
-        else h_pass_fused_body<R, 1, true>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, true, red);
+        if (nrhs == 2) h_pass_fused_body<R, U, 2, true>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, h, red);
+        else h_pass_fused_body<R, U, 1, true>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, h, red);
     } else {
-        if (nrhs == 2) h_pass_fused_body<R, 2, false>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, false, red);
-        else h_pass_fused_body<R, 1, false>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, true, red);
+        if (nrhs == 2) h_pass_fused_body<R, U, 2, false>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, h, red);
+        else h_pass_fused_body<R, U, 1, false>(a.H, a.T, a.F, sp, sstage, c_ss, c_su, c_uu, h, red);
     }
 }

@@ -459,7 +459,7 @@ struct qn_solver {
     size_t n = 0;
     double tol = 0.0;
     QnTile T{};
-    int R = 8, hcs = 1, qcs = 1;
+    int R = 4, U = 1, hcs = 1, qcs = 1; // row tile, chunks per trip (fused kernels), column splits
     double* H = nullptr;
     double* vec_block = nullptr; // one allocation holding all n_pad vectors
     QnVecs V{};
@@ -553,6 +553,9 @@ extern "C" int qn_solver_create(qn_context* ctx, int method, double tol, const d
     *out = s;
     s->ctx = ctx; s->method = method; s->n = n; s->tol = tol;
     s->T = make_tile(n, ctx, 1);
+    // row tile: 4 rows per workgroup keeps 4 workgroups per CU busy at n = 4096; at large n the per-workgroup partial
+    // sums read by the control step dominate its latency, so use 8 (measured: profiles/r01_c_tiling_sweep.txt)
+    s->R = (s->T.rpr >= 16384 / ctx->world && n >= 16384) ? 8 : 4;
     const size_t np = s->T.n_pad;
     hipStream_t st = ctx->stream;
     if (method != QN_GRADIENT_DESCENT) {
@@ -635,8 +638,14 @@ extern "C" int qn_solver_set_profiling(qn_solver* s, int on) { s->profiling = on
 extern "C" int qn_solver_set_sync_mode(qn_solver* s, int sync) { s->sync_mode = sync; return QN_OK; }
 extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits) {
     if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; } // diagnostics: -1 selects the generic (non-fused) kernels
-    if (rows_per_block != 0 && rows_per_block != 4 && rows_per_block != 8 && rows_per_block != 16)
-        return fail(QN_ERROR_INPUT_PARAMS, "rows_per_block must be 4, 8 or 16");
+    if (rows_per_block != 0 && rows_per_block != 2 && rows_per_block != 4 && rows_per_block != 8 && rows_per_block != 16)
+        return fail(QN_ERROR_INPUT_PARAMS, "rows_per_block must be 2, 4, 8 or 16");
+    if (col_splits >= 100) { // tuning: 100 + U selects U column chunks per loop trip of the fused kernels (one column split)
+        const int u = col_splits - 100;
+        if (u != 1 && u != 2 && u != 4) return fail(QN_ERROR_INPUT_PARAMS, "chunks per trip must be 1, 2 or 4");
+        s->U = u;
+        col_splits = 1;
+    }
     if (col_splits < 0 || col_splits > 64) return fail(QN_ERROR_INPUT_PARAMS, "col_splits out of range");
     HIPCHK(hipSetDevice(s->ctx->device));
     if (rows_per_block) s->R = rows_per_block;
@@ -831,14 +840,29 @@ static int launch_ctl(Run& r, int expect_phase) {
     return QN_OK;
 }
 
-template <int R>
+template <int R, int U>
 static void launch_eval_fused(hipStream_t st, const QnEvalFusedArgs& a) {
-    hipLaunchKernelGGL(quad_eval_fused_kernel<R>, dim3(a.T.rpr / R), dim3(QN_TPB), 0, st, a);
+    hipLaunchKernelGGL((quad_eval_fused_kernel<R, U>), dim3(a.T.rpr / R), dim3(QN_TPB), 0, st, a);
 }
-template <int R>
+template <int R, int U>
 static void launch_hpass_fused(hipStream_t st, const QnHPassFusedArgs& a) {
-    hipLaunchKernelGGL(h_pass_fused_kernel<R>, dim3(a.T.rpr / R), dim3(QN_TPB), 0, st, a);
+    hipLaunchKernelGGL((h_pass_fused_kernel<R, U>), dim3(a.T.rpr / R), dim3(QN_TPB), 0, st, a);
 }
+#define QN_DISPATCH_RU(fn, R_, U_, ...)                                             \
+    do {                                                                            \
+        const int key_ = (R_) * 10 + (U_);                                          \
+        switch (key_) {                                                             \
+        case 21: fn<2, 1>(__VA_ARGS__); break;                                      \
+        case 22: fn<2, 2>(__VA_ARGS__); break;                                      \
+        case 24: fn<2, 4>(__VA_ARGS__); break;                                      \
+        case 41: fn<4, 1>(__VA_ARGS__); break;                                      \
+        case 42: fn<4, 2>(__VA_ARGS__); break;                                      \
+        case 44: fn<4, 4>(__VA_ARGS__); break;                                      \
+        case 82: fn<8, 2>(__VA_ARGS__); break;                                      \
+        case 161: fn<16, 1>(__VA_ARGS__); break;                                    \
+        default: fn<8, 1>(__VA_ARGS__); break;                                      \
+        }                                                                           \
+    } while (0)
 
 static int enqueue_eval_fused(Run& r) {
     qn_solver* s = r.s;
@@ -847,11 +871,7 @@ static int enqueue_eval_fused(Run& r) {
     a.Q = r.obj->Q; a.T = s->T; a.T.cs = 1; a.F = s->V.F; a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_EVAL;
     {
         ProfScope ps(s, KC_EVAL);
-        switch (s->R) {
-        case 4: launch_eval_fused<4>(c->stream, a); break;
-        case 16: launch_eval_fused<16>(c->stream, a); break;
-        default: launch_eval_fused<8>(c->stream, a); break;
-        }
+        QN_DISPATCH_RU(launch_eval_fused, s->R, s->U, c->stream, a);
         s->stats.launches++;
         HIPCHK(hipGetLastError());
     }
@@ -870,11 +890,7 @@ static int enqueue_hpass_fused(Run& r) {
     a.H = s->H; a.T = s->T; a.T.cs = 1; a.F = s->V.F; a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_HPASS;
     {
         ProfScope ps(s, KC_HPASS);
-        switch (s->R) {
-        case 4: launch_hpass_fused<4>(c->stream, a); break;
-        case 16: launch_hpass_fused<16>(c->stream, a); break;
-        default: launch_hpass_fused<8>(c->stream, a); break;
-        }
+        QN_DISPATCH_RU(launch_hpass_fused, s->R, s->U, c->stream, a);
         s->stats.launches++;
         HIPCHK(hipGetLastError());
     }
