@@ -323,6 +323,12 @@ struct qn_objective {
     double* b = nullptr; // n_pad
     // scratch for qn_objective_eval
     double *ex = nullptr, *eq = nullptr, *eg = nullptr, *ef = nullptr;
+    // log-sum-exp: A rows are in Q ([mrpr][n_pad]), c in b (m_pad)
+    size_t m = 0;
+    QnTile TA{}; // row partition of A (m rows)
+    double mu = 0.0;
+    int lse_rs = 1;
+    double *lz = nullptr, *lw = nullptr, *lgpart = nullptr, *lgall = nullptr, *lscal = nullptr;
 };
 
 static int objective_base(qn_context* ctx, size_t n, const double* b_host, qn_objective** out) {
@@ -370,8 +376,67 @@ extern "C" int qn_quadratic_create_synthetic(qn_context* ctx, size_t n, uint64_t
     return QN_OK;
 }
 
-extern "C" int qn_logsumexp_create(qn_context*, size_t, size_t, const double*, const double*, double, qn_objective**) {
-    return fail(QN_ERROR_INPUT_PARAMS, "log-sum-exp objective: not built yet (SURVEY.md 8(f) row f1)");
+extern "C" int qn_logsumexp_create(qn_context* ctx, size_t m, size_t n, const double* a_host, const double* c_host, double mu,
+                                   qn_objective** out) {
+    if (!ctx || !out || !a_host || !c_host || n == 0 || m == 0) return fail(QN_ERROR_INPUT_PARAMS, "null argument or empty shape");
+    if (n > (size_t)1 << 30 || m > (size_t)1 << 30) return fail(QN_ERROR_INPUT_PARAMS, "shape too large");
+    HIPCHK(hipSetDevice(ctx->device));
+    qn_objective* o = new qn_objective();
+    *out = o;
+    o->ctx = ctx; o->kind = OBJ_LOGSUMEXP; o->n = n; o->m = m; o->mu = mu;
+    o->T = make_tile(n, ctx, 1);  // column padding follows the solver's vectors
+    o->TA = make_tile(m, ctx, 1); // rows of A are sharded
+    const size_t np = o->T.n_pad, mp = o->TA.n_pad, mrpr = o->TA.rpr;
+    hipStream_t st = ctx->stream;
+    QNCHK(dev_alloc_zero(&o->Q, mrpr * np, st));
+    QNCHK(dev_alloc_zero(&o->b, mp, st));
+    HIPCHK(hipMemcpyAsync(o->b, c_host, m * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st)); // the zero-fill above must land before the (null-stream) 2-D upload below
+    const size_t r0 = (size_t)o->TA.row_off;
+    if (r0 < m) {
+        const size_t nr = std::min(mrpr, m - r0);
+        HIPCHK(hipMemcpy2D(o->Q, np * sizeof(double), a_host + r0 * n, n * sizeof(double), n * sizeof(double), nr, hipMemcpyHostToDevice));
+    }
+    o->lse_rs = (int)std::max<size_t>(1, std::min<size_t>(64, mrpr / 64));
+    QNCHK(dev_alloc_zero(&o->lz, (size_t)ctx->world * 2 * mrpr, st));
+    QNCHK(dev_alloc_zero(&o->lw, mp, st));
+    QNCHK(dev_alloc_zero(&o->lgpart, (size_t)o->lse_rs * np, st));
+    QNCHK(dev_alloc_zero(&o->lgall, (size_t)ctx->world * np, st));
+    QNCHK(dev_alloc_zero(&o->lscal, 2, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return QN_OK;
+}
+
+template <int R>
+static void launch_hpass(hipStream_t st, const QnHPassArgs& a);
+
+// enqueue one evaluation of the log-sum-exp objective at x_dev (n_pad entries): f -> f_dev, g -> g_dev
+static int lse_enqueue_eval(qn_objective* o, const double* x_dev, double* f_dev, double* g_dev) {
+    qn_context* c = o->ctx;
+    hipStream_t st = c->stream;
+    // pass 1: z = A_rows x (the H-pass kernel in plain mat-vec mode)
+    QnHPassArgs h{};
+    h.H = o->Q; h.T = o->TA; h.T.n_pad = o->T.n_pad; h.T.n = (int)o->n; h.T.cs = 1;
+    h.T.rpr = o->TA.rpr; h.T.row_off = 0; // row guards are not needed for a read-only pass
+    h.hp = o->lz; h.expect_phase = -1; h.force_nrhs = 1; h.force_pending = 0; h.r0 = x_dev; h.r1 = x_dev;
+    h.sp = x_dev; h.up = x_dev;
+    launch_hpass<8>(st, h);
+    HIPCHK(hipGetLastError());
+    QNCHK(exchange(c, o->lz, 2 * (size_t)o->TA.rpr));
+    QnLseArgs a{};
+    a.A = o->Q; a.c = o->b; a.z = o->lz; a.w = o->lw; a.gpart = o->lgpart; a.gall = o->lgall; a.x = x_dev;
+    a.f_out = f_dev; a.g_out = g_dev; a.scal = o->lscal; a.mu = o->mu;
+    a.m = (int)o->m; a.m_pad = o->TA.n_pad; a.mrpr = o->TA.rpr; a.n = (int)o->n; a.n_pad = o->T.n_pad;
+    a.world = c->world; a.rank = c->rank; a.rs = o->lse_rs;
+    hipLaunchKernelGGL(lse_softmax_kernel, dim3(1), dim3(1024), 0, st, a);
+    // pass 2: column sums A'w over this rank's rows
+    hipLaunchKernelGGL(lse_colsum_kernel, dim3((a.n_pad + QN_CHUNK - 1) / QN_CHUNK, a.rs), dim3(QN_TPB), 0, st, a);
+    hipLaunchKernelGGL(lse_reduce_splits_kernel, dim3(std::min(1024, (a.n_pad + 255) / 256)), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    QNCHK(exchange(c, o->lgall, (size_t)a.n_pad));
+    hipLaunchKernelGGL(lse_finish_kernel, dim3(std::min(1024, (a.n_pad + 255) / 256)), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return QN_OK;
 }
 
 extern "C" void qn_objective_destroy(qn_objective* o) {
@@ -379,11 +444,14 @@ extern "C" void qn_objective_destroy(qn_objective* o) {
     (void)hipSetDevice(o->ctx->device);
     (void)hipFree(o->Q); (void)hipFree(o->b);
     (void)hipFree(o->ex); (void)hipFree(o->eq); (void)hipFree(o->eg); (void)hipFree(o->ef);
+    (void)hipFree(o->lz); (void)hipFree(o->lw); (void)hipFree(o->lgpart); (void)hipFree(o->lgall); (void)hipFree(o->lscal);
     delete o;
 }
 
 extern "C" int qn_objective_get_rows(qn_objective* o, size_t row0, size_t nrows, double* out_host) {
-    const size_t lo = (size_t)o->T.row_off, hi = std::min(o->n, lo + (size_t)o->T.rpr);
+    const bool lse = o->kind == OBJ_LOGSUMEXP;
+    const size_t lo = lse ? (size_t)o->TA.row_off : (size_t)o->T.row_off;
+    const size_t hi = lse ? std::min(o->m, lo + (size_t)o->TA.rpr) : std::min(o->n, lo + (size_t)o->T.rpr);
     if (row0 < lo || row0 + nrows > hi) return fail(QN_ERROR_INPUT_PARAMS, "rows outside this rank's shard");
     HIPCHK(hipSetDevice(o->ctx->device));
     HIPCHK(hipMemcpy2D(out_host, o->n * sizeof(double), o->Q + (row0 - lo) * (size_t)o->T.n_pad, (size_t)o->T.n_pad * sizeof(double),
@@ -422,8 +490,21 @@ __global__ __launch_bounds__(QN_CTL_TPB) void quad_finish_kernel(const QnVecs V,
 extern "C" int qn_objective_eval(qn_objective* o, const double* x_host, double* f, double* g_host) {
     qn_context* c = o->ctx;
     HIPCHK(hipSetDevice(c->device));
-    if (o->kind != OBJ_QUADRATIC) return fail(QN_ERROR_INPUT_PARAMS, "unsupported objective");
     const size_t np = o->T.n_pad;
+    if (o->kind == OBJ_LOGSUMEXP) {
+        if (!o->ex) {
+            QNCHK(dev_alloc_zero(&o->ex, 2 * np, c->stream));
+            QNCHK(dev_alloc_zero(&o->eg, np, c->stream));
+            QNCHK(dev_alloc_zero(&o->ef, 2, c->stream));
+        }
+        HIPCHK(hipMemcpyAsync(o->ex, x_host, o->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        QNCHK(lse_enqueue_eval(o, o->ex, o->ef, o->eg));
+        HIPCHK(hipMemcpyAsync(f, o->ef, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(g_host, o->eg, o->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return QN_OK;
+    }
+    if (o->kind != OBJ_QUADRATIC) return fail(QN_ERROR_INPUT_PARAMS, "unsupported objective");
     if (!o->ex) {
         QNCHK(dev_alloc_zero(&o->ex, 2 * np, c->stream)); // x and xt
         QNCHK(dev_alloc_zero(&o->eq, np, c->stream));
@@ -940,6 +1021,7 @@ static int enqueue_eval(Run& r) {
         HIPCHK(hipStreamSynchronize(c->stream));
         return QN_OK;
     }
+    if (r.o->kind == QN_ORACLE_OBJECTIVE) return lse_enqueue_eval(r.obj, s->V.xt, s->f_dev, s->V.gt); // log-sum-exp
     // device closure
     if (r.o->device_fn(r.o->device_user, (void*)c->stream, s->V.xt, s->n, s->f_dev, s->V.gt) != 0)
         return fail(QN_ABNORMAL_TERMINATION, "device oracle returned non-zero");
@@ -973,6 +1055,7 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
         if (o->objective->ctx != c || o->objective->n != s->n) return fail(QN_ERROR_INPUT_PARAMS, "objective does not match the solver");
         r.obj = o->objective;
         if (r.obj->kind == OBJ_QUADRATIC) { r.oracle_tpl = QN_ORACLE_QUAD; s->V.b = r.obj->b; }
+        else if (r.obj->kind == OBJ_LOGSUMEXP) r.oracle_tpl = QN_ORACLE_GENERIC; // evaluated by its own kernels into (f_dev, gt)
         else return fail(QN_ERROR_INPUT_PARAMS, "unsupported objective");
     } else if (o->kind == QN_ORACLE_HOST) {
         if (!o->host_fn) return fail(QN_ERROR_INPUT_PARAMS, "host oracle is null");
@@ -1015,7 +1098,8 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
     h->status = -1;
     QNCHK(poke_ctl(s));
 
-    const bool can_pipeline = (o->kind != QN_ORACLE_HOST) && !callback && !(c->world > 1 && !c->comm);
+    // only the quadratic objective's kernels are predicated on the control block; everything else is serviced synchronously
+    const bool can_pipeline = (r.oracle_tpl == QN_ORACLE_QUAD) && !callback && !(c->world > 1 && !c->comm);
     const bool sync = s->sync_mode == 1 || (s->sync_mode == -1 && !(can_pipeline && o->memoize)) || !can_pipeline;
 
     QNCHK(launch_ctl(r, QN_PH_IDLE));

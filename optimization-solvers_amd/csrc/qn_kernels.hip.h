@@ -559,6 +559,98 @@ __device__ __forceinline__ void small_update(double* H, int ld, int n, const dou
 #define QN_ORACLE_GENERIC 0
 #define QN_ORACLE_QUAD 1
 
+// ------------------------------------------------------------------------------------------------
+// log-sum-exp objective: f = log sum_i exp(a_i'x + c_i) + mu/2 ||x||^2,
+// g = A' softmax(Ax + c) + mu x.  Two passes over this rank's rows of A per evaluation (16*m*n/P bytes):
+// z = A x (h_pass_kernel in mat-vec mode), then the column sums A'w.  Max-shifted for stability.
+// ------------------------------------------------------------------------------------------------
+struct QnLseArgs {
+    const double* A;   // this rank's rows, [mrpr][n_pad]
+    const double* c;   // m_pad
+    double* z;         // gathered A x: rank block p at z + p*2*mrpr (h_pass layout, one rhs)
+    double* w;         // m_pad softmax weights
+    double* gpart;     // [rs][n_pad] column-sum partials of this rank
+    double* gall;      // gathered per-rank gradients [world][n_pad]
+    const double* x;   // evaluation point (n_pad)
+    double* f_out;     // scalar
+    double* g_out;     // n_pad
+    double* scal;      // [0] = zmax + log(sum), [1] = ||x||^2
+    double mu;
+    int m, m_pad, mrpr, n, n_pad, world, rank, rs;
+};
+
+__device__ __forceinline__ double lse_z(const QnLseArgs& a, int i) { // gathered layout of h_pass output, one rhs, one column split
+    const int p = i / a.mrpr, il = i - p * a.mrpr;
+    return a.z[(size_t)p * 2 * a.mrpr + il];
+}
+
+// single workgroup: softmax weights of all m rows (+ ||x||^2)
+__global__ __launch_bounds__(1024) void lse_softmax_kernel(const QnLseArgs a) {
+    __shared__ double lds[32];
+    const int tid = threadIdx.x, tpb = blockDim.x;
+    double mx = -INFINITY;
+    for (int i = tid; i < a.m; i += tpb) mx = fmax(mx, lse_z(a, i) + a.c[i]);
+    mx = ctl_block_fmax(mx, lds);
+    double p[2] = {0.0, 0.0};
+    for (int i = tid; i < a.m; i += tpb) {
+        const double e = exp(lse_z(a, i) + a.c[i] - mx);
+        a.w[i] = e;
+        p[0] += e;
+    }
+    for (int j = tid; j < a.n; j += tpb) p[1] = __builtin_fma(a.x[j], a.x[j], p[1]);
+    ctl_block_sum<2>(p, lds);
+    for (int i = tid; i < a.m_pad; i += tpb) a.w[i] = (i < a.m) ? a.w[i] / p[0] : 0.0;
+    if (tid == 0) { a.scal[0] = mx + log(p[0]); a.scal[1] = p[1]; }
+}
+
+// column sums over this rank's rows: gpart[rs][j] = sum_{i in split rs} w_i A[i][j]; grid (n_pad/512, rs)
+__global__ __launch_bounds__(QN_TPB) void lse_colsum_kernel(const QnLseArgs a) {
+    const int j = blockIdx.x * QN_CHUNK + 2 * threadIdx.x;
+    if (j >= a.n_pad) return;
+    const int rows_per = (a.mrpr + a.rs - 1) / a.rs;
+    const int i0 = blockIdx.y * rows_per, i1 = min(a.mrpr, i0 + rows_per);
+    const double* wl = a.w + (size_t)a.rank * a.mrpr;
+    v2d acc = {0.0, 0.0};
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {
+        v2d h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = ld2(a.A + (size_t)(i + r) * a.n_pad + j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double wi = wl[i + r];
+            acc.x = __builtin_fma(wi, h[r].x, acc.x);
+            acc.y = __builtin_fma(wi, h[r].y, acc.y);
+        }
+    }
+    for (; i < i1; ++i) {
+        const v2d h = ld2(a.A + (size_t)i * a.n_pad + j);
+        const double wi = wl[i];
+        acc.x = __builtin_fma(wi, h.x, acc.x);
+        acc.y = __builtin_fma(wi, h.y, acc.y);
+    }
+    st2(a.gpart + (size_t)blockIdx.y * a.n_pad + j, acc);
+}
+
+// this rank's gradient contribution: sum of the row splits (fixed order)
+__global__ void lse_reduce_splits_kernel(const QnLseArgs a) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n_pad; j += gridDim.x * blockDim.x) {
+        double t = a.gpart[j];
+        for (int s = 1; s < a.rs; ++s) t = t + a.gpart[(size_t)s * a.n_pad + j];
+        a.gall[(size_t)a.rank * a.n_pad + j] = t;
+    }
+}
+
+// g = sum over ranks (fixed order) + mu x ; f = zmax + log(sum) + mu/2 ||x||^2
+__global__ void lse_finish_kernel(const QnLseArgs a) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n_pad; j += gridDim.x * blockDim.x) {
+        double t = a.gall[j];
+        for (int p = 1; p < a.world; ++p) t = t + a.gall[(size_t)p * a.n_pad + j];
+        a.g_out[j] = (j < a.n) ? t + a.mu * a.x[j] : 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.f_out = a.scal[0] + 0.5 * a.mu * a.scal[1];
+}
+
 #include "qn_fused.hip.h"
 #include "qn_ctl_step.hip.h"
 

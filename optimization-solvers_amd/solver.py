@@ -244,6 +244,19 @@ class Quadratic(Objective):
         return self
 
 
+class LogSumExp(Objective):
+    """f = log sum_i exp(a_i'x + c_i) + mu/2 ||x||^2 on the device (A is m x n row-major, rows sharded over ranks)."""
+
+    def __init__(self, a, c, mu, ctx=None):
+        ctx = ctx or default_context()
+        a, c = _f64(a), _f64(c)
+        m, n = a.shape
+        h = C.c_void_p()
+        _check(A.lib().qn_logsumexp_create(ctx.h, m, n, _dp(a), _dp(c), float(mu), C.byref(h)))
+        super().__init__(ctx, h, n)
+        self.m = m
+
+
 class _SolverBase:
     METHOD = None
 

@@ -116,6 +116,29 @@ def main():
         except qn.MaxIterReached:
             pass
         result["dfp_bt_equal"] = bool(np.array_equal(s2.trace()[1], s3.trace()[1]))
+        # log-sum-exp objective (rows of A sharded, gradient summed over ranks in fixed order): sharded vs single rank
+        rng = np.random.default_rng(5)
+        m2, n2 = 333, 150
+        a = rng.standard_normal((m2, n2)) * (3.0 / np.sqrt(n2))
+        cvec = rng.standard_normal(m2)
+        xs0 = rng.standard_normal(n2)
+        lse = qn.LogSumExp(a, cvec, 0.1, ctx=ctx)
+        lse1 = qn.LogSumExp(a, cvec, 0.1, ctx=ctx1)
+        e, e1 = lse(xs0), lse1(xs0)
+        result["lse_eval_close"] = bool(abs(e.f() - e1.f()) <= 1e-13 * max(1.0, abs(e1.f()))
+                                        and np.linalg.norm(e.g() - e1.g()) <= 1e-13 * np.linalg.norm(e1.g()))
+        s4 = qn.DFP(1e-10, xs0, ctx=ctx)
+        s4.set_trace(12, with_x=True)
+        s5 = qn.DFP(1e-10, xs0, ctx=ctx1)
+        s5.set_trace(12, with_x=True)
+        for sv, ob in ((s4, lse), (s5, lse1)):
+            try:
+                sv.minimize(qn.MoreThuente(), ob, 12, 20)
+            except qn.MaxIterReached:
+                pass
+        (t4, x4), (t5, x5) = s4.trace(), s5.trace()
+        result["lse_dfp_close"] = bool(len(t4) == len(t5) and [r["ls_cases"] for r in t4] == [r["ls_cases"] for r in t5]
+                                       and np.linalg.norm(x4 - x5) <= 1e-9 * np.linalg.norm(x5))
     gathered = [None] * world
     dist.all_gather_object(gathered, result)
     if rank == 0:

@@ -1,0 +1,91 @@
+"""GPU tests of row f1: DFP / BFGS + More-Thuente on the log-sum-exp objective
+f = log sum_i exp(a_i'x + c_i) + mu/2 ||x||^2 -- a non-quadratic objective that drives the line search through
+its other cases -- against the CPU oracle, and BASELINE.json config 5's size through size-independent properties."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import _compare, _ls
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(m, n, seed=3, scale=1.0):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((m, n)) * scale / np.sqrt(n)
+    c = rng.standard_normal(m)
+    x0 = rng.standard_normal(n)
+    return a, c, x0
+
+
+@pytest.mark.parametrize("m,n", [(7, 5), (40, 13), (300, 200), (1030, 515)])
+def test_logsumexp_evaluation_vs_oracle(qn, qo, m, n):
+    a, c, x0 = _problem(m, n)
+    mu = 0.05
+    obj = qn.LogSumExp(a, c, mu)
+    ev = obj(x0)
+    f_ref, g_ref = qo.LogSumExpOracle(a, c, mu)(x0)
+    assert abs(ev.f() - f_ref) <= 1e-12 * max(1.0, abs(f_ref))
+    assert np.linalg.norm(ev.g() - g_ref) <= 1e-12 * max(1.0, np.linalg.norm(g_ref))
+    assert np.array_equal(obj.rows(0, m), a)
+
+
+@pytest.mark.parametrize("method", ["dfp", "bfgs"])
+@pytest.mark.parametrize("lsname", ["mt", "bt"])
+def test_quasi_newton_on_logsumexp_vs_oracle(qn, qo, method, lsname):
+    m, n = 600, 384
+    a, c, x0 = _problem(m, n, scale=3.0)
+    mu, iters = 0.1, 30
+    ref = qo.Solver(qo.DFP if method == "dfp" else qo.BFGS, 1e-10, x0, qo.UPDATE_AS_WRITTEN)
+    o = qo.LogSumExpOracle(a, c, mu, nthreads=4)
+    st_ref = ref.minimize(_ls(qo, lsname), o, iters, 20, trace_cap=iters, trace_x=True)
+    obj = qn.LogSumExp(a, c, mu)
+    s = (qn.DFP if method == "dfp" else qn.BFGS)(1e-10, x0)
+    s.set_trace(iters, with_x=True)
+    try:
+        s.minimize(_ls(qn, lsname), obj, iters, 20)
+        st = 0
+    except qn.MaxIterReached:
+        st = 1
+    tr, xs = s.trace()
+    w = _compare(tr, xs, ref.trace, ref.trace_x)
+    if w == len(ref.trace):
+        assert st == st_ref
+    # the non-quadratic objective takes the cheap path most of the time: t = 1 accepted => 3 calls per iteration
+    if lsname == "mt":
+        assert sum(1 for r in tr[:w] if r["n_evals"] == 3) >= 1
+    st_ = s.stats()
+    assert st_["oracle_evals"] < st_["oracle_calls"]  # memoised: loop-top and bfgs.rs:98 calls are not re-evaluated
+
+
+def test_config5_size_properties_dfp_morethuente_n16384(qn, qo):
+    """BASELINE.json config 5: DFP + More-Thuente, n = 16384 log-sum-exp, f64 (one GPU here; rows shard across ranks)."""
+    n = m = 16384
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((m, n)) * (2.0 / np.sqrt(n))
+    c = rng.standard_normal(m)
+    x0 = rng.standard_normal(n)
+    mu, iters = 0.1, 6
+    obj = qn.LogSumExp(a, c, mu)
+    s = qn.DFP(1e-10, x0)
+    s.set_trace(iters, with_x=True)
+    with pytest.raises(qn.MaxIterReached):
+        s.minimize(qn.MoreThuente(), obj, iters, 20)
+    tr, xs = s.trace()
+    f = np.array([r["f"] for r in tr])
+    assert len(tr) == iters and np.all(np.diff(f) < 0)  # sufficient decrease every iteration
+    # f and g at the last iterate agree with the threaded CPU oracle at full size
+    o = qo.LogSumExpOracle(a, c, mu, nthreads=qo.max_threads())
+    f_ref, g_ref = o(xs[-1])
+    ev = obj(xs[-1])
+    assert abs(ev.f() - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
+    assert np.linalg.norm(ev.g() - g_ref) <= 1e-11 * np.linalg.norm(g_ref)
+    # secant equation of the DFP update on the last pair: H+ y = s
+    sk = xs[-1] - xs[-2]
+    yk = ev.g() - obj(xs[-2]).g()
+    h = s.approx_inv_hessian()
+    assert np.array_equal(h, h.T)
+    assert np.linalg.norm(h @ yk - sk) <= 1e-8 * np.linalg.norm(sk)
+    # first iterations against the threaded rank-2 CPU restatement
+    ref = qo.Solver(qo.DFP, 1e-10, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
+    ref.minimize(qo.morethuente(), o, 3, 20, trace_cap=3, trace_x=True)
+    _compare(tr[:3], xs[:3], ref.trace, ref.trace_x)

@@ -18,3 +18,4 @@ def test_two_ranks_on_one_gpu_equal_single_rank_bitwise(tmp_path):
         assert r["iters"] == 25
         assert r["trace_equal"] and r["x_equal"] and r["h_equal"], r
         assert r["objective_rows_ok"] and r["eval_equal"] and r["dfp_bt_equal"], r
+        assert r["lse_eval_close"] and r["lse_dfp_close"], r
