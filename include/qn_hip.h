@@ -102,6 +102,8 @@ void qn_backtracking_new(qn_linesearch* ls, double c1, double beta); /* BackTrac
 typedef int (*qn_host_oracle_fn)(void* user, const double* x_host, size_t n, double* f, double* g_host);
 /* device closure: enqueue work on `stream` that reads x_dev[0..n) and writes *f_dev and g_dev[0..n). */
 typedef int (*qn_device_oracle_fn)(void* user, void* stream, const double* x_dev, size_t n, double* f_dev, double* g_dev);
+/* Newton only: the Hessian part of the FuncEval (func_eval.rs:8,27-33) at x, column-major n x n (like DMatrix). */
+typedef int (*qn_host_hessian_fn)(void* user, const double* x_host, size_t n, double* h_colmajor_host);
 
 typedef struct qn_objective qn_objective; /* a device-resident objective owned by the library */
 
@@ -119,6 +121,7 @@ typedef struct {
     qn_device_oracle_fn device_fn;
     void* device_user;
     qn_objective* objective;
+    qn_host_hessian_fn host_hessian_fn; /* Newton with a host closure; device objectives supply their own Hessian */
 } qn_oracle;
 
 /* Built-in benchmark objective (build-defined): f = 1/2 x'Qx - b'x, g = Qx - b.
@@ -138,9 +141,9 @@ int qn_objective_eval(qn_objective* obj, const double* x_host, double* f, double
 int qn_objective_get_rows(qn_objective* obj, size_t row0, size_t nrows, double* out_host);
 
 /* ---------------------------------------------------------------------------------------------
- * Solvers: BFGS (bfgs.rs:4-127), DFP (dfp.rs), GradientDescent (gradient_descent.rs:7-82).
+ * Solvers: BFGS (bfgs.rs:4-127), DFP (dfp.rs), GradientDescent (gradient_descent.rs:7-82), Newton (newton/mod.rs).
  * ------------------------------------------------------------------------------------------- */
-enum { QN_BFGS = 0, QN_DFP = 1, QN_GRADIENT_DESCENT = 2 };
+enum { QN_BFGS = 0, QN_DFP = 1, QN_GRADIENT_DESCENT = 2, QN_NEWTON = 3 /* newton/mod.rs:8-69, SURVEY.md 8(f) row f2 */ };
 typedef struct qn_solver qn_solver;
 
 /* BFGS::new(tol, x0) / DFP::new / GradientDescent::new(grad_tol, x0): H = I (no identity copy is kept) */
@@ -166,6 +169,7 @@ int qn_solver_s_norm(qn_solver* s, double* out, int* is_some); /* s_norm(): Opti
 int qn_solver_y_norm(qn_solver* s, double* out, int* is_some); /* y_norm(): Option<f64> */
 int qn_solver_next_iterate_too_close(qn_solver* s, int* out);          /* bfgs.rs:15-20 */
 int qn_solver_gradient_next_iterate_too_close(qn_solver* s, int* out); /* bfgs.rs:21-26 */
+int qn_solver_decrement_squared(qn_solver* s, double* out, int* is_some); /* Newton: decrement_squared(): Option<f64>, newton/mod.rs:10 */
 /* approx_inv_hessian(): column-major n x n.  Lazy: applies the pending rank-2 update and gathers this rank's
  * rows; rows of other ranks are left untouched unless `all_ranks` (then an all-gather fills everything). */
 int qn_solver_get_inv_hessian(qn_solver* s, double* out_colmajor_host, int all_ranks);

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("QN_HIP_LIB") or os.path.join(_HERE, "lib", "libqn_hip
 OK, MAX_ITER_REACHED, OUT_OF_DOMAIN, ERROR_INPUT_PARAMS, ABNORMAL_TERMINATION = range(5)
 LS_MORETHUENTE, LS_BACKTRACKING = 0, 1
 ORACLE_HOST, ORACLE_DEVICE_FN, ORACLE_OBJECTIVE = 0, 1, 2
-BFGS, DFP, GRADIENT_DESCENT = 0, 1, 2
+BFGS, DFP, GRADIENT_DESCENT, NEWTON = 0, 1, 2, 3
 UNIQUE_ID_BYTES = 128
 
 dp = C.POINTER(C.c_double)
@@ -25,6 +25,7 @@ class LineSearchStruct(C.Structure):
 HOST_ORACLE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, C.c_size_t, dp, dp)
 DEVICE_ORACLE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
 CALLBACK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+HOST_HESSIAN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, C.c_size_t, dp)
 HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp, C.c_size_t)
 
 
@@ -32,7 +33,7 @@ class OracleStruct(C.Structure):
     _fields_ = [("kind", C.c_int32), ("memoize", C.c_int32),
                 ("host_fn", C.c_void_p), ("host_user", C.c_void_p),
                 ("device_fn", C.c_void_p), ("device_user", C.c_void_p),
-                ("objective", C.c_void_p)]
+                ("objective", C.c_void_p), ("host_hessian_fn", C.c_void_p)]
 
 
 class TraceRec(C.Structure):
@@ -91,6 +92,7 @@ SYMBOLS = [
     ("qn_solver_y_norm", C.c_int, [C.c_void_p, dp, C.POINTER(C.c_int)]),
     ("qn_solver_next_iterate_too_close", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     ("qn_solver_gradient_next_iterate_too_close", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    ("qn_solver_decrement_squared", C.c_int, [C.c_void_p, dp, C.POINTER(C.c_int)]),
     ("qn_solver_get_inv_hessian", C.c_int, [C.c_void_p, dp, C.c_int]),
     ("qn_solver_set_inv_hessian", C.c_int, [C.c_void_p, dp]),
     ("qn_solver_set_trace", C.c_int, [C.c_void_p, C.c_size_t, C.c_int]),

@@ -14,7 +14,8 @@ enum QnPhase : int32_t {
     QN_PH_REQ_EVAL = 1,  // evaluate the oracle at (req_kind, req_t)
     QN_PH_REQ_HPASS = 2, // run h_pass with hp_nrhs right-hand sides
     QN_PH_ITER_DONE = 3, // host callback wanted (ls_solver.rs:105-107)
-    QN_PH_DONE = 4       // finished: status holds the SolverError code
+    QN_PH_DONE = 4,      // finished: status holds the SolverError code
+    QN_PH_REQ_NEWTON = 6 // Newton: factorise the Hessian at x_k and solve for d and H^-1 d (5 is the in-kernel RUNNING marker)
 };
 
 enum QnReqKind : int32_t { QN_REQ_X = 0 /* at x_k itself */, QN_REQ_T = 1 /* at x_k + t d_k */ };
@@ -36,7 +37,8 @@ enum QnState : int32_t {
     QN_ST_AFTER_LS,
     QN_ST_AFTER_NEXT,
     QN_ST_AFTER_U,
-    QN_ST_ITER_END
+    QN_ST_ITER_END,
+    QN_ST_AFTER_NEWTON
 };
 
 struct QnTraceRec { // == qn_trace_rec (include/qn_hip.h)
@@ -73,6 +75,10 @@ struct QnCtl {
     double dir_ug, dir_sg;
     double st_gd0, st_yy, st_ys, st_gg, st_ss, st_dnf;
     double hp_yu, hp_ug, hp_sg;
+
+    // ---- Newton (newton/mod.rs:8-13) ----
+    int32_t has_dec, _padn;
+    double dec; // decrement_squared: Option<f64>
 
     // ---- request ----
     int32_t req_kind, req_need_vectors;

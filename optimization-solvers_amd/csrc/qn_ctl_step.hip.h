@@ -59,7 +59,7 @@ __device__ __forceinline__ void qn_keepalive(double v) { asm volatile("" ::"v"(v
 // scalar states (thread 0 only).  Runs until the machine yields or reaches a state that needs all threads.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool qn_check_is_scalar(const QnCtl& c) {
-    return c.method != 2 && (c.small_n || c.gg_valid);
+    return c.method != 2 && (c.small_n || c.gg_valid || c.method == 3);
 }
 
 __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double* small_scratch) {
@@ -151,6 +151,14 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
 
         case QN_ST_CHECK: { // ls_solver.rs:37-40 (OutOfDomain), has_converged (bfgs.rs:64-76)
             if (!qn_check_is_scalar(c)) return; // gradient descent / unknown ||g||: all threads needed
+            if (c.method == 3) { // Newton: has_converged is the decrement test (newton/mod.rs:64-69)
+                c.gnorm = c.gg_valid ? sqrt(c.gg) : NAN; c.tr_f = c.f_k; c.tr_gnorm = c.gnorm;
+                const double f = c.f_k;
+                if (isnan(f) || isinf(f)) { c.status = 2; c.phase = QN_PH_DONE; }
+                else if (c.has_dec && c.dec * 0.5 < c.tol) { c.status = 0; c.phase = QN_PH_DONE; }
+                else { c.after_state = QN_ST_AFTER_NEWTON; c.phase = QN_PH_REQ_NEWTON; } // compute_direction, newton/mod.rs:26-49
+                break;
+            }
             double gnorm, gd0 = c.gd0;
             int d_finite = c.d_finite;
             if (c.small_n) { // reference order: norm = sqrt(dot), direction by column sweep (bfgs.rs:47)
@@ -280,7 +288,7 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
         } break;
 
         case QN_ST_AFTER_LS: {
-            if (c.method == 2) return; // gradient descent: x += step*d needs all threads
+            if (c.method >= 2) return; // gradient descent / Newton: the default hook x += step*d needs all threads
             req_eval_t(c, c.ls_result, QN_ST_AFTER_NEXT, 1); // bfgs.rs:94,98: oracle(x + step*d)
         } break;
 
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
             else c.last_valid = 0;
         }
         if (expect_phase == QN_PH_IDLE) c.state = QN_ST_BEGIN;
-        else if (expect_phase == QN_PH_REQ_EVAL || expect_phase == QN_PH_REQ_HPASS) c.state = c.after_state;
+        else if (expect_phase == QN_PH_REQ_EVAL || expect_phase == QN_PH_REQ_HPASS || expect_phase == QN_PH_REQ_NEWTON) c.state = c.after_state;
         c.phase = QN_PH_RUNNING;
         ctl_scalar_run(c, V, small_scratch);
     }
@@ -501,7 +509,32 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
             }
         } break;
 
-        case QN_ST_AFTER_LS: { // gradient descent only (ls_solver.rs:44-64 / gradient_descent.rs:55-82): x += step*d
+        case QN_ST_AFTER_NEWTON: { // d and z = H^-1 d were left in V.d / V.s by the factorisation + solves
+            const bool failed = *V.nfail != 0;
+            double p[3] = {0.0, 0.0, 0.0};
+            for (int i = tid; i < n_pad; i += tpb) {
+                const double gi = vg[i];
+                double di;
+                if (failed) { di = -gi; vd[i] = di; } // singular Hessian: gradient-descent direction (newton/mod.rs:43-46)
+                else di = vd[i];
+                p[0] = __builtin_fma(gi, di, p[0]);
+                p[1] += isfinite(di) ? 0.0 : 1.0;
+                if (!failed) p[2] = __builtin_fma(vs[i], di, p[2]); // (hessian_inv * direction).dot(direction)
+            }
+            ctl_block_sum<3>(p, lds);
+            if (c.small_n) {
+                __threadfence_block();
+                __syncthreads();
+                if (tid == 0) { p[0] = ref_dot(V.g, V.d, n); if (!failed) p[2] = ref_dot(V.s, V.d, n); }
+            }
+            if (tid == 0) {
+                if (!failed) { c.dec = p[2]; c.has_dec = 1; }
+                c.gd0 = p[0]; c.d_finite = p[1] == 0.0; c.last_valid = 0;
+                c.state = QN_ST_LS_BEGIN;
+            }
+        } break;
+
+        case QN_ST_AFTER_LS: { // gradient descent / Newton (ls_solver.rs:44-64 / gradient_descent.rs:55-82): x += step*d
             const double step = c.ls_result;
             const bool hit = c.last_valid && c.last_t == step;
             const bool memo = c.memoize != 0;

@@ -545,6 +545,11 @@ struct qn_solver {
     double* vec_block = nullptr; // one allocation holding all n_pad vectors
     QnVecs V{};
     double* f_dev = nullptr;
+    // Newton: Hessian work matrix (row-major, ld = nw), right-hand sides, staging for host Hessians, failure flag
+    double *newton_w = nullptr, *newton_x = nullptr, *newton_hsrc = nullptr;
+    int* newton_fail = nullptr;
+    size_t newton_n64 = 0;
+    std::vector<double> newton_hhost;
     double* fused_block = nullptr; // X0[2], S0[2], G, GT, Y, UN, UP, VV (10 n_pad vectors)
     double *fused_evp = nullptr, *fused_hpp = nullptr;
     int fused_nblk = 0;
@@ -627,7 +632,8 @@ static int solver_alloc_hp(qn_solver* s) {
 
 extern "C" int qn_solver_create(qn_context* ctx, int method, double tol, const double* x0_host, size_t n, qn_solver** out) {
     if (!ctx || !x0_host || !out || n == 0) return fail(QN_ERROR_INPUT_PARAMS, "null argument or n == 0");
-    if (method != QN_BFGS && method != QN_DFP && method != QN_GRADIENT_DESCENT) return fail(QN_ERROR_INPUT_PARAMS, "unknown method");
+    if (method != QN_BFGS && method != QN_DFP && method != QN_GRADIENT_DESCENT && method != QN_NEWTON)
+        return fail(QN_ERROR_INPUT_PARAMS, "unknown method");
     if (n > (size_t)1 << 30) return fail(QN_ERROR_INPUT_PARAMS, "n too large");
     HIPCHK(hipSetDevice(ctx->device));
     qn_solver* s = new qn_solver();
@@ -639,7 +645,7 @@ extern "C" int qn_solver_create(qn_context* ctx, int method, double tol, const d
     s->R = (s->T.rpr >= 16384 / ctx->world && n >= 16384) ? 8 : 4;
     const size_t np = s->T.n_pad;
     hipStream_t st = ctx->stream;
-    if (method != QN_GRADIENT_DESCENT) {
+    if (method == QN_BFGS || method == QN_DFP) {
         QNCHK(dev_alloc_zero(&s->H, (size_t)s->T.rpr * np, st));
         hipLaunchKernelGGL(identity_fill_kernel, dim3(2048), dim3(256), 0, st, s->H, s->T); // bfgs.rs:27-39: H = I
         HIPCHK(hipGetLastError());
@@ -671,6 +677,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     for (auto& e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
+    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
@@ -788,6 +795,11 @@ extern "C" int qn_solver_y_norm(qn_solver* s, double* out, int* is_some) {
     if (out) *out = s->hctl->y_norm;
     return QN_OK;
 }
+extern "C" int qn_solver_decrement_squared(qn_solver* s, double* out, int* is_some) { // newton/mod.rs:10
+    if (is_some) *is_some = s->hctl->has_dec;
+    if (out) *out = s->hctl->dec;
+    return QN_OK;
+}
 extern "C" int qn_solver_next_iterate_too_close(qn_solver* s, int* out) { // bfgs.rs:15-20
     *out = s->hctl->has_s_norm && s->hctl->s_norm < s->tol;
     return QN_OK;
@@ -897,6 +909,40 @@ extern "C" int qn_solver_get_stats(qn_solver* s, qn_stats* out) {
     *out = s->stats;
     return QN_OK;
 }
+
+// ---- Newton direction (newton/mod.rs:26-49): Cholesky factorisation + four triangular solves, or the n <= 5 kernel ----
+static int newton_alloc(qn_solver* s) {
+    if (s->newton_w) return QN_OK;
+    const size_t n64 = (s->n + QN_NB - 1) / QN_NB * QN_NB;
+    s->newton_n64 = n64;
+    hipStream_t st = s->ctx->stream;
+    QNCHK(dev_alloc_zero(&s->newton_w, n64 * n64, st));
+    QNCHK(dev_alloc_zero(&s->newton_x, 2 * n64, st));
+    HIPCHK(hipMalloc((void**)&s->newton_fail, sizeof(int)));
+    HIPCHK(hipMemsetAsync(s->newton_fail, 0, sizeof(int), st));
+    s->V.nfail = s->newton_fail;
+    return QN_OK;
+}
+
+static int newton_tri_solve(qn_solver* s, double* x) { // x <- (L L')^-1 x
+    hipStream_t st = s->ctx->stream;
+    const int n64 = (int)s->newton_n64;
+    const size_t ld = s->newton_n64;
+    for (int k0 = 0; k0 < n64; k0 += QN_NB) {
+        hipLaunchKernelGGL(tri_fwd_diag_kernel, dim3(1), dim3(64), 0, st, s->newton_w, ld, k0, x);
+        const int below = n64 - k0 - QN_NB;
+        if (below > 0) hipLaunchKernelGGL(tri_fwd_update_kernel, dim3(std::min(1024, (below + 3) / 4)), dim3(256), 0, st, s->newton_w, ld, k0, n64, x);
+    }
+    for (int k0 = n64 - QN_NB; k0 >= 0; k0 -= QN_NB) {
+        hipLaunchKernelGGL(tri_bwd_diag_kernel, dim3(1), dim3(64), 0, st, s->newton_w, ld, k0, x);
+        if (k0 > 0) hipLaunchKernelGGL(tri_bwd_update_kernel, dim3(std::min(1024, (k0 + 255) / 256)), dim3(256), 0, st, s->newton_w, ld, k0, x);
+    }
+    HIPCHK(hipGetLastError());
+    return QN_OK;
+}
+
+struct Run;
+static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj);
 
 // ---- the pump ----
 struct Run {
@@ -1044,6 +1090,60 @@ static int enqueue_hpass_req(Run& r) {
     return QN_OK;
 }
 
+static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
+    qn_context* c = s->ctx;
+    hipStream_t st = c->stream;
+    QNCHK(newton_alloc(s));
+    const int n = (int)s->n, n64 = (int)s->newton_n64;
+    const size_t ld = s->newton_n64;
+    // the Hessian at x_k: a device objective's own matrix, or the host closure's (uploaded)
+    const double* hsrc = nullptr;
+    size_t ld_src = 0;
+    if (obj) { hsrc = obj->Q; ld_src = (size_t)obj->T.n_pad; }
+    else {
+        if (!s->newton_hsrc) HIPCHK(hipMalloc((void**)&s->newton_hsrc, (size_t)n * n * sizeof(double)));
+        s->newton_hhost.resize((size_t)n * n * 2);
+        HIPCHK(hipMemcpyAsync(s->hx, s->V.x, s->n * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double* hc = s->newton_hhost.data();           // column-major from the closure (DMatrix)
+        double* hr = s->newton_hhost.data() + (size_t)n * n; // row-major for the device
+        if (o->host_hessian_fn(o->host_user, s->hx, s->n, hc) != 0) return fail(QN_ABNORMAL_TERMINATION, "host Hessian callback failed");
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) hr[(size_t)i * n + j] = hc[i + (size_t)j * n];
+        HIPCHK(hipMemcpyAsync(s->newton_hsrc, hr, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, st));
+        hsrc = s->newton_hsrc; ld_src = (size_t)n;
+    }
+    HIPCHK(hipMemsetAsync(s->newton_fail, 0, sizeof(int), st));
+    if (s->hctl->small_n) { // reference-order arithmetic, one thread
+        hipLaunchKernelGGL(newton_small_kernel, dim3(1), dim3(64), 0, st, hsrc, ld_src, n, s->V.g, s->V.d, s->V.s, s->newton_fail);
+        HIPCHK(hipGetLastError());
+        return QN_OK;
+    }
+    hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, s->newton_w, ld, n, n64, hsrc, ld_src);
+    for (int k0 = 0; k0 < n64; k0 += QN_NB) { // blocked right-looking Cholesky, lower triangle in place
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, s->newton_w, ld, k0, s->newton_fail);
+        const int nt = (n64 - k0 - QN_NB) / QN_NB;
+        if (nt > 0) {
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3(nt), dim3(64), 0, st, s->newton_w, ld, k0, n64, s->newton_fail);
+            hipLaunchKernelGGL(chol_syrk_kernel, dim3(nt, nt), dim3(256), 0, st, s->newton_w, ld, k0, s->newton_fail);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    // d = -(H^-1 g) ; z = H^-1 d
+    double* x1 = s->newton_x;
+    double* x2 = s->newton_x + n64;
+    const dim3 vg(std::min(1024, (n64 + 255) / 256)), vb(256);
+    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, x1, s->V.g, n, n64, -1.0);
+    QNCHK(newton_tri_solve(s, x1));
+    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.d, x1, n, s->T.n_pad, 1.0);
+    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, x2, x1, n, n64, 1.0);
+    QNCHK(newton_tri_solve(s, x2));
+    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.s, x2, n, s->T.n_pad, 1.0);
+    HIPCHK(hipGetLastError());
+    s->stats.launches += 6 + 3 * (uint64_t)(n64 / QN_NB) + 8 * (uint64_t)(n64 / QN_NB);
+    return QN_OK;
+}
+
 extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracle* o, size_t max_iter_solver,
                            size_t max_iter_line_search, qn_callback_fn callback, void* callback_user) {
     if (!s || !ls || !o) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
@@ -1063,6 +1163,12 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
         if (!o->device_fn) return fail(QN_ERROR_INPUT_PARAMS, "device oracle is null");
     } else return fail(QN_ERROR_INPUT_PARAMS, "unknown oracle kind");
     if (ls->kind != QN_LS_MORETHUENTE && ls->kind != QN_LS_BACKTRACKING) return fail(QN_ERROR_INPUT_PARAMS, "unknown line search");
+    if (s->method == QN_NEWTON) {
+        if (c->world > 1) return fail(QN_ERROR_INPUT_PARAMS, "Newton is single-GPU (SURVEY.md 8(f) row f2)");
+        if (!(r.obj && r.obj->kind == OBJ_QUADRATIC) && !(o->kind == QN_ORACLE_HOST && o->host_hessian_fn))
+            return fail(QN_ERROR_INPUT_PARAMS, "Hessian not available in the oracle"); // newton/mod.rs:34 .expect(...)
+        QNCHK(newton_alloc(s));
+    }
 
     // configuration -> control block (state carried over from earlier runs: x, H, pending update, s_norm, y_norm)
     QnCtl* h = s->hctl;
@@ -1080,7 +1186,7 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
     h->small_n = (s->n <= QN_SMALL_N && c->world == 1) ? 1 : 0;
     if (h->small_n && h->pending) QNCHK(flush_pending(s));
     // fused fast path: device quadratic, memoised, BFGS/DFP, no callback, one column split, n > 5
-    r.fused = r.oracle_tpl == QN_ORACLE_QUAD && h->memoize && s->method != QN_GRADIENT_DESCENT && !callback && s->hcs == 1 &&
+    r.fused = r.oracle_tpl == QN_ORACLE_QUAD && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP) && !callback && s->hcs == 1 &&
               s->qcs == 1 && !h->small_n && !s->no_fused;
     h->fused = r.fused ? 1 : 0;
     if (r.fused) { // import the canonical state (x, pending s and u) into the fused buffers
@@ -1100,7 +1206,7 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
 
     // only the quadratic objective's kernels are predicated on the control block; everything else is serviced synchronously
     const bool can_pipeline = (r.oracle_tpl == QN_ORACLE_QUAD) && !callback && !(c->world > 1 && !c->comm);
-    const bool sync = s->sync_mode == 1 || (s->sync_mode == -1 && !(can_pipeline && o->memoize)) || !can_pipeline;
+    const bool sync = s->method == QN_NEWTON || s->sync_mode == 1 || (s->sync_mode == -1 && !(can_pipeline && o->memoize)) || !can_pipeline;
 
     QNCHK(launch_ctl(r, QN_PH_IDLE));
     int status = QN_ABNORMAL_TERMINATION;
@@ -1111,6 +1217,7 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
             if (ph == QN_PH_DONE) { status = h->status; break; }
             if (ph == QN_PH_REQ_EVAL) { QNCHK(enqueue_eval(r)); QNCHK(launch_ctl(r, QN_PH_REQ_EVAL)); }
             else if (ph == QN_PH_REQ_HPASS) { QNCHK(enqueue_hpass_req(r)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS)); }
+            else if (ph == QN_PH_REQ_NEWTON) { QNCHK(enqueue_newton(s, o, r.obj)); QNCHK(launch_ctl(r, QN_PH_REQ_NEWTON)); }
             else if (ph == QN_PH_ITER_DONE) { callback(callback_user, s); QNCHK(launch_ctl(r, QN_PH_ITER_DONE)); }
             else return fail(QN_ABNORMAL_TERMINATION, "control block in an unexpected phase");
         }

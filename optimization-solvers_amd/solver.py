@@ -68,8 +68,20 @@ def _dp(a):
 class FuncEvalMultivariate:
     """func_eval.rs:4-41 (f, g; the optional Hessian is not used on this path)."""
 
-    def __init__(self, f, g):
+    def __init__(self, f, g, hessian=None):
         self._f, self._g = float(f), np.asarray(g, dtype=np.float64)
+        self._h = hessian
+
+    @classmethod
+    def new(cls, f, g):
+        return cls(f, g)
+
+    def with_hessian(self, hessian):  # func_eval.rs:27-30
+        self._h = np.asarray(hessian, dtype=np.float64)
+        return self
+
+    def hessian(self):
+        return self._h
 
     def f(self):
         return self._f
@@ -306,17 +318,33 @@ class _SolverBase:
                 try:
                     x = np.ctypeslib.as_array(xp, shape=(nn,)).copy()
                     res = oracle(x)
-                    f, g = (res.f(), res.g()) if isinstance(res, FuncEvalMultivariate) else res
+                    f, g = (res.f(), res.g()) if isinstance(res, FuncEvalMultivariate) else res[:2]
                     fp[0] = float(f)
                     np.ctypeslib.as_array(gp, shape=(nn,))[:] = np.asarray(g, dtype=np.float64)
                     return 0
                 except Exception as e:  # noqa: BLE001 -- a panicking closure aborts the run
                     err.append(e)
                     return 1
+            def htramp(_u, xp, nn, hp):  # Newton: the Hessian part of the closure's FuncEval (newton/mod.rs:31-35)
+                try:
+                    x = np.ctypeslib.as_array(xp, shape=(nn,)).copy()
+                    res = oracle(x)
+                    hm = res.hessian() if isinstance(res, FuncEvalMultivariate) else (res[2] if len(res) > 2 else None)
+                    if hm is None:
+                        raise RuntimeError("Hessian not available in the oracle")
+                    np.ctypeslib.as_array(hp, shape=(nn * nn,))[:] = np.asfortranarray(hm, dtype=np.float64).ravel(order="F")
+                    return 0
+                except Exception as e:  # noqa: BLE001
+                    err.append(e)
+                    return 1
             cfn = A.HOST_ORACLE_FN(tramp)
             keep.append(cfn)
             o.kind = A.ORACLE_HOST
             o.host_fn = C.cast(cfn, C.c_void_p)
+            if self.METHOD == A.NEWTON:
+                hfn = A.HOST_HESSIAN_FN(htramp)
+                keep.append(hfn)
+                o.host_hessian_fn = C.cast(hfn, C.c_void_p)
             o.memoize = 0 if self.memoize is None else int(self.memoize)
         cb = None
         if callback is not None:
@@ -431,6 +459,18 @@ class GradientDescent(_SolverBase):
     def has_converged(self, eval_x_k):
         g = eval_x_k.g() if isinstance(eval_x_k, FuncEvalMultivariate) else eval_x_k[1]
         return float(np.max(np.abs(g))) < self.tol()
+
+
+class Newton(_SolverBase):
+    """newton/mod.rs: direction from a dense factorisation of the Hessian on the GPU."""
+    METHOD = A.NEWTON
+
+    def decrement_squared(self):
+        return self._opt(A.lib().qn_solver_decrement_squared)
+
+    def has_converged(self, eval_x_k=None):  # newton/mod.rs:64-69
+        d = self.decrement_squared()
+        return d is not None and d * 0.5 < self.tol()
 
 
 # ---- kernel-level FFI helpers (tests of the individual primitives) ----

@@ -367,7 +367,15 @@ struct qo_solver {
     /* scratch */
     double *g, *d, *xn, *gn, *s, *y, *u, *work;
     double *m0, *m1, *m2, *m3, *m4; /* n x n temporaries for the as-written update */
+    /* Newton (newton/mod.rs:8-13) */
+    qo_hessian_fn hess_fn;
+    void* hess_user;
+    int has_decrement;
+    double decrement_squared;
 };
+
+void qo_solver_set_hessian_fn(qo_solver* s, qo_hessian_fn fn, void* user) { s->hess_fn = fn; s->hess_user = user; }
+int qo_solver_decrement_squared(const qo_solver* s, double* out) { if (s->has_decrement && out) *out = s->decrement_squared; return s->has_decrement; }
 
 qo_solver* qo_solver_create(int method, double tol, const double* x0, size_t n, int update_mode, int nthreads) {
     qo_solver* s = (qo_solver*)calloc(1, sizeof(*s));
@@ -382,7 +390,7 @@ qo_solver* qo_solver_create(int method, double tol, const double* x0, size_t n, 
     double** vecs[] = {&s->g, &s->d, &s->xn, &s->gn, &s->s, &s->y, &s->u};
     for (size_t i = 0; i < sizeof(vecs) / sizeof(vecs[0]); ++i) *vecs[i] = (double*)calloc(nn, sizeof(double));
     s->work = (double*)calloc(4 * nn, sizeof(double));
-    if (method != QO_GRADIENT_DESCENT) {
+    if (method == QO_BFGS || method == QO_DFP) {
         /* bfgs.rs:27-39: H = I (the reference also keeps a second identity matrix; not needed here) */
         s->h = (double*)calloc(nn * nn, sizeof(double));
         for (size_t i = 0; i < n; ++i) s->h[i + i * n] = 1.0;
@@ -408,6 +416,8 @@ void qo_solver_set_inv_hessian(qo_solver* s, const double* h) { if (s->h) memcpy
 
 /* has_converged: bfgs.rs:64-76 (dfp.rs identical) ; gradient_descent.rs:46-53 */
 static int has_converged(const qo_solver* s, const double* g) {
+    if (s->method == QO_NEWTON) /* newton/mod.rs:64-69 */
+        return s->has_decrement ? (s->decrement_squared * 0.5 < s->tol) : 0;
     if (s->method == QO_GRADIENT_DESCENT) {
         double acc = -INFINITY; /* fold(NEG_INFINITY, |acc, x| x.abs().max(acc)) */
         for (size_t i = 0; i < s->n; ++i) acc = fmax(fabs(g[i]), acc);
@@ -515,6 +525,70 @@ static void rank2_update(qo_solver* so, const double* s, const double* y) {
     }
 }
 
+/* [nalgebra] Matrix::try_inverse on a dynamic square matrix: closed forms for n <= 2 (restated: 1x1 reciprocal, 2x2 by
+ * the determinant), LU with partial pivoting otherwise (nalgebra also has closed forms for 3x3 / 4x4 and its LU order
+ * is not reproduced: tolerance-level).  Returns 0 when singular (determinant / pivot exactly zero).  Column-major. */
+static int try_inverse(const double* a, double* inv, size_t n) {
+    if (n == 1) {
+        if (a[0] == 0.0) return 0;
+        inv[0] = 1.0 / a[0];
+        return 1;
+    }
+    if (n == 2) {
+        const double m11 = a[0], m21 = a[1], m12 = a[2], m22 = a[3];
+        const double det = m11 * m22 - m21 * m12;
+        if (det == 0.0) return 0;
+        inv[0] = m22 / det; inv[2] = -m12 / det; inv[1] = -m21 / det; inv[3] = m11 / det;
+        return 1;
+    }
+    double* lu = (double*)malloc(sizeof(double) * n * n);
+    size_t* piv = (size_t*)malloc(sizeof(size_t) * n);
+    memcpy(lu, a, sizeof(double) * n * n);
+    int ok = 1;
+    for (size_t k = 0; k < n && ok; ++k) {
+        size_t p = k;
+        double best = fabs(lu[k + k * n]);
+        for (size_t i = k + 1; i < n; ++i) if (fabs(lu[i + k * n]) > best) { best = fabs(lu[i + k * n]); p = i; }
+        piv[k] = p;
+        if (best == 0.0) { ok = 0; break; }
+        if (p != k) for (size_t j = 0; j < n; ++j) { double t = lu[k + j * n]; lu[k + j * n] = lu[p + j * n]; lu[p + j * n] = t; }
+        const double d = lu[k + k * n];
+        for (size_t i = k + 1; i < n; ++i) lu[i + k * n] /= d;
+        for (size_t j = k + 1; j < n; ++j) {
+            const double ukj = lu[k + j * n];
+            for (size_t i = k + 1; i < n; ++i) lu[i + j * n] -= lu[i + k * n] * ukj;
+        }
+    }
+    if (ok) {
+        for (size_t c = 0; c < n; ++c) {
+            double* x = inv + c * n;
+            for (size_t i = 0; i < n; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+            for (size_t k = 0; k < n; ++k) if (piv[k] != k) { double t = x[k]; x[k] = x[piv[k]]; x[piv[k]] = t; }
+            for (size_t k = 0; k < n; ++k) for (size_t i = k + 1; i < n; ++i) x[i] -= lu[i + k * n] * x[k];
+            for (size_t kk = n; kk-- > 0;) { x[kk] /= lu[kk + kk * n]; for (size_t i = 0; i < kk; ++i) x[i] -= lu[i + kk * n] * x[kk]; }
+        }
+    }
+    free(lu); free(piv);
+    return ok;
+}
+
+/* Newton::compute_direction, newton/mod.rs:26-49 */
+static void newton_direction(qo_solver* so) {
+    const size_t n = so->n;
+    ensure_mats(so);
+    double *hess = so->m0, *inv = so->m1;
+    so->hess_fn(so->hess_user, so->x, n, hess); /* eval.hessian().clone().expect(...) */
+    if (try_inverse(hess, inv, n)) {
+        qo_gemv_colsweep(inv, so->g, so->d, n); /* -&hessian_inv * eval.g() */
+        for (size_t i = 0; i < n; ++i) so->d[i] = -so->d[i];
+        qo_gemv_colsweep(inv, so->d, so->u, n); /* (hessian_inv * &direction).dot(&direction) -- reproduce, do not 'fix' */
+        so->decrement_squared = qo_dot(so->u, so->d, n);
+        so->has_decrement = 1;
+    } else {
+        for (size_t i = 0; i < n; ++i) so->d[i] = -so->g[i]; /* singular: gradient-descent direction */
+    }
+}
+
 /* LineSearchSolver::minimize, ls_solver.rs:66-111, with BFGS::update_next_iterate (bfgs.rs:78-127),
  * DFP (dfp.rs:78-123) or the default hook (ls_solver.rs:44-64 / gradient_descent.rs:55-82). */
 int qo_minimize(qo_solver* so, const qo_linesearch* ls, qo_oracle_fn oracle, void* oracle_user,
@@ -536,6 +610,8 @@ int qo_minimize(qo_solver* so, const qo_linesearch* ls, qo_oracle_fn oracle, voi
         /* compute_direction */
         if (so->method == QO_GRADIENT_DESCENT) {
             for (size_t i = 0; i < n; ++i) so->d[i] = -so->g[i]; /* gradient_descent.rs:29 */
+        } else if (so->method == QO_NEWTON) {
+            newton_direction(so);
         } else {
             /* bfgs.rs:47: (-&H) * g.  Negating every H_ij first gives bit-for-bit -(H g). */
             gemv_colmajor_mt(so->h, so->g, so->d, n, so->nthreads);
@@ -547,8 +623,8 @@ int qo_minimize(qo_solver* so, const qo_linesearch* ls, qo_oracle_fn oracle, voi
         qo_axpy_new(so->x, step, so->d, so->xn, n); /* bfgs.rs:94 / ls_solver.rs:60 */
 
         int updated = 0;
-        if (so->method == QO_GRADIENT_DESCENT) {
-            memcpy(so->x, so->xn, sizeof(double) * n); /* gradient_descent.rs:79 */
+        if (so->method == QO_GRADIENT_DESCENT || so->method == QO_NEWTON) {
+            memcpy(so->x, so->xn, sizeof(double) * n); /* gradient_descent.rs:79 ; Newton keeps the default hook ls_solver.rs:44-64 */
         } else {
             for (size_t i = 0; i < n; ++i) so->s[i] = so->xn[i] - so->x[i]; /* bfgs.rs:96 s = x+ - x (not t*d) */
             so->s_norm = qo_norm(so->s, n); so->has_s_norm = 1;             /* :97 */
@@ -591,6 +667,14 @@ done:
 /* ------------------------------------------------------------------------------------------ */
 /* benchmark objectives (build-defined; the reference only has user closures)                   */
 /* ------------------------------------------------------------------------------------------ */
+
+int qo_quadratic_hessian(void* user, const double* x, size_t n, double* h) {
+    (void)x;
+    qo_quadratic* p = (qo_quadratic*)user;
+    for (size_t j = 0; j < n; ++j)
+        for (size_t i = 0; i < n; ++i) h[i + j * n] = p->q[i * n + j];
+    return 0;
+}
 
 /* f = 1/2 x'(Qx) - b'x ; g = Qx - b.  Row sums run left to right over j. */
 int qo_quadratic_eval(void* user, const double* x, size_t n, double* f, double* g) {

@@ -32,7 +32,7 @@ enum {
 };
 
 /* solver families on the path (src/quasi_newton/bfgs.rs, dfp.rs, src/steepest_descent/gradient_descent.rs) */
-enum { QO_BFGS = 0, QO_DFP = 1, QO_GRADIENT_DESCENT = 2 };
+enum { QO_BFGS = 0, QO_DFP = 1, QO_GRADIENT_DESCENT = 2, QO_NEWTON = 3 /* src/newton/mod.rs */ };
 
 /* how the inverse-Hessian update is evaluated */
 enum {
@@ -59,6 +59,12 @@ void qo_backtracking_new(qo_linesearch* ls, double c1, double beta); /* backtrac
 typedef int (*qo_oracle_fn)(void* user, const double* x, size_t n, double* f, double* g);
 
 typedef struct qo_solver qo_solver;
+
+/* Newton only: the Hessian part of FuncEvalMultivariate (func_eval.rs:8,27-33), column-major n x n, evaluated at the
+ * loop-top point right after the oracle call (newton/mod.rs:31-35 `.expect("Hessian not available in the oracle")`). */
+typedef int (*qo_hessian_fn)(void* user, const double* x, size_t n, double* h_colmajor);
+void qo_solver_set_hessian_fn(qo_solver* s, qo_hessian_fn fn, void* user);
+int qo_solver_decrement_squared(const qo_solver* s, double* out); /* Option<f64>, newton/mod.rs:10 */
 
 /* callback: Option<&mut dyn FnMut(&Self)> (ls_solver.rs:72,105-107) */
 typedef void (*qo_callback_fn)(void* user, const qo_solver* solver);
@@ -121,6 +127,7 @@ typedef struct {
     size_t calls;
 } qo_quadratic;
 int qo_quadratic_eval(void* user /* qo_quadratic* */, const double* x, size_t n, double* f, double* g);
+int qo_quadratic_hessian(void* user /* qo_quadratic* */, const double* x, size_t n, double* h_colmajor); /* = Q */
 
 /* synthetic SPD generator: off-diagonal Q_ij = Q_ji = u(seed, min(i,j), max(i,j)) * inv_n with u in [-1,1),
  * diagonal supplied by the caller.  Fills rows [row0, row0+nrows) of a row-major block with leading dim n. */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libqn_oracle.so")
 
 OK, MAX_ITER_REACHED, OUT_OF_DOMAIN, ERROR_INPUT_PARAMS, ABNORMAL_TERMINATION = range(5)
-BFGS, DFP, GRADIENT_DESCENT = 0, 1, 2
+BFGS, DFP, GRADIENT_DESCENT, NEWTON = 0, 1, 2, 3
 UPDATE_AS_WRITTEN, UPDATE_RANK2 = 0, 1
 LS_MORETHUENTE, LS_BACKTRACKING = 0, 1
 
@@ -59,6 +59,7 @@ class LogSumExp(C.Structure):
 
 ORACLE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double))
 CALLBACK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+HESSIAN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double))
 
 _lib = None
 
@@ -91,6 +92,10 @@ def lib():
     L.qo_solver_y_norm.restype = C.c_int
     L.qo_solver_y_norm.argtypes = [C.c_void_p, dp]
     L.qo_solver_set_inv_hessian.argtypes = [C.c_void_p, dp]
+    L.qo_solver_set_hessian_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qo_solver_decrement_squared.restype = C.c_int
+    L.qo_solver_decrement_squared.argtypes = [C.c_void_p, dp]
+    L.qo_quadratic_hessian.restype = C.c_int
     L.qo_dot.restype = C.c_double
     L.qo_dot.argtypes = [dp, dp, C.c_size_t]
     L.qo_norm.restype = C.c_double
@@ -278,6 +283,28 @@ class Solver:
             self.trace_x = xs[:tr.len].copy() if trace_x else None
             self.n_oracle_calls = tr.n_oracle_calls
         return status
+
+    def set_hessian(self, fn_or_quadratic):
+        """Newton: where the Hessian part of the FuncEval comes from (a Python x -> H closure, or a QuadraticOracle)."""
+        if isinstance(fn_or_quadratic, QuadraticOracle):
+            self._hess_keep = fn_or_quadratic
+            lib().qo_solver_set_hessian_fn(self.h, C.cast(lib().qo_quadratic_hessian, C.c_void_p),
+                                           C.cast(C.pointer(fn_or_quadratic.st), C.c_void_p))
+            return
+        n = self.n
+
+        def tramp(_u, xp, nn, hp):
+            x = np.ctypeslib.as_array(xp, shape=(nn,)).copy()
+            h = np.asfortranarray(fn_or_quadratic(x), dtype=np.float64)
+            np.ctypeslib.as_array(hp, shape=(nn * nn,))[:] = h.ravel(order="F")
+            return 0
+        self._hess_keep = HESSIAN_FN(tramp)
+        lib().qo_solver_set_hessian_fn(self.h, C.cast(self._hess_keep, C.c_void_p), None)
+
+    @property
+    def decrement_squared(self):
+        v = C.c_double()
+        return v.value if lib().qo_solver_decrement_squared(self.h, C.byref(v)) else None
 
     @property
     def x(self):

@@ -54,7 +54,7 @@ def test_struct_sizes_match_header(qn):
     A = qn._abi
     assert C.sizeof(A.LineSearchStruct) == 8 + 9 * 8
     assert C.sizeof(A.TraceRec) == 5 * 8 + 4 * 4
-    assert C.sizeof(A.OracleStruct) == 8 + 5 * 8
+    assert C.sizeof(A.OracleStruct) == 8 + 6 * 8
     assert C.sizeof(A.Stats) == 16 * 8
 
 
