@@ -643,6 +643,7 @@ extern "C" int qn_solver_create(qn_context* ctx, int method, double tol, const d
     // row tile: 4 rows per workgroup keeps 4 workgroups per CU busy at n = 4096; at large n the per-workgroup partial
     // sums read by the control step dominate its latency, so use 8 (measured: profiles/r01_c_tiling_sweep.txt)
     s->R = (s->T.rpr >= 16384 / ctx->world && n >= 16384) ? 8 : 4;
+    s->U = (n >= 16384) ? 2 : 1; // column chunks per loop trip of the fused kernels
     const size_t np = s->T.n_pad;
     hipStream_t st = ctx->stream;
     if (method == QN_BFGS || method == QN_DFP) {

@@ -1,7 +1,7 @@
-"""Diagnostic: in-kernel time stamps of ctl_step (build with -DQN_CTL_STAMPS into lib/libqn_hip_stamps.so)."""
+"""Diagnostic: in-kernel time stamps of ctl_step (build csrc/qn_hip.hip with -DQN_CTL_STAMPS into optimization-solvers_amd/lib/libqn_hip_stamps.so)."""
 import ctypes as C, os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as ge
 qn = ge.load_package()
