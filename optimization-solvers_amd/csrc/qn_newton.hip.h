@@ -18,14 +18,27 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// 64 x 64 tile  global -> LDS (row stride QN_NB + 1), T threads, 8 independent loads in flight per thread
+template <int T, bool TRANSPOSE>
+__device__ __forceinline__ void qn_tile_to_lds(double (*dst)[QN_NB + 1], const double* __restrict__ src, size_t ld) {
+    const int tid = threadIdx.x;
+    for (int e0 = 0; e0 < QN_NB * QN_NB; e0 += 8 * T) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * T + tid; v[u] = src[(size_t)(e / QN_NB) * ld + (e % QN_NB)]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * T + tid;
+            if (TRANSPOSE) dst[e % QN_NB][e / QN_NB] = v[u]; else dst[e / QN_NB][e % QN_NB] = v[u];
+        }
+    }
+}
+
 // ---- diagonal block: W[k0:k0+NB, k0:k0+NB] = L L' (lower), in place; rows/cols >= n_valid are identity padding ----
 __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ W, size_t ld, int k0, int* __restrict__ fail) {
     __shared__ double a[QN_NB][QN_NB + 1];
     const int tid = threadIdx.x;
-    for (int e = tid; e < QN_NB * QN_NB; e += 256) {
-        const int i = e / QN_NB, j = e % QN_NB;
-        a[i][j] = W[(size_t)(k0 + i) * ld + k0 + j];
-    }
+    qn_tile_to_lds<256, false>(a, W + (size_t)k0 * ld + k0, ld);
     __syncthreads();
     for (int j = 0; j < QN_NB; ++j) {
         const double piv = a[j][j];
@@ -59,12 +72,8 @@ __global__ __launch_bounds__(64) void chol_trsm_kernel(double* __restrict__ W, s
     __shared__ double xt[QN_NB][QN_NB + 1]; // xt[j][r]: column j of the panel tile, row r
     const int tid = threadIdx.x;
     const int r0 = k0 + QN_NB + blockIdx.x * QN_NB;
-    for (int e = tid; e < QN_NB * QN_NB; e += 64) {
-        const int i = e / QN_NB, j = e % QN_NB;
-        L[i][j] = W[(size_t)(k0 + i) * ld + k0 + j];
-        const int r = r0 + i;
-        xt[j][i] = (r < nrows_total) ? W[(size_t)r * ld + k0 + j] : 0.0;
-    }
+    qn_tile_to_lds<64, false>(L, W + (size_t)k0 * ld + k0, ld);
+    qn_tile_to_lds<64, true>(xt, W + (size_t)r0 * ld + k0, ld); // r0 + 63 < nrows_total: the padded dimension is a multiple of 64
     __syncthreads();
     // thread = row: forward substitution against L' (x L' = a  <=>  x_j = (a_j - sum_{p<j} x_p L[j][p]) / L[j][j])
     for (int j = 0; j < QN_NB; ++j) {
@@ -86,15 +95,12 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, 
     const int ti = blockIdx.y, tj = blockIdx.x;
     if (tj > ti) return;
     if (*fail) return;
-    __shared__ double PI[QN_NB][QN_NB]; // PI[k][i] = P[i0 + i][k0 + k]  (k-major: lanes read consecutive i)
-    __shared__ double PJ[QN_NB][QN_NB];
+    __shared__ double PI[QN_NB][QN_NB + 1]; // PI[k][i] = P[i0 + i][k0 + k]  (k-major: lanes read consecutive i; +1 pad for the transposing stores)
+    __shared__ double PJ[QN_NB][QN_NB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = k0 + QN_NB + ti * QN_NB, j0 = k0 + QN_NB + tj * QN_NB;
-    for (int e = tid; e < QN_NB * QN_NB; e += 256) {
-        const int r = e / QN_NB, k = e % QN_NB; // coalesced along k in global memory
-        PI[k][r] = W[(size_t)(i0 + r) * ld + k0 + k];
-        PJ[k][r] = W[(size_t)(j0 + r) * ld + k0 + k];
-    }
+    qn_tile_to_lds<256, true>(PI, W + (size_t)i0 * ld + k0, ld); // coalesced along k in global memory
+    qn_tile_to_lds<256, true>(PJ, W + (size_t)j0 * ld + k0, ld);
     __syncthreads();
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
     v4d acc[2][2];
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(64) void tri_fwd_diag_kernel(const double* __restri
     __shared__ double L[QN_NB][QN_NB + 1];
     __shared__ double xs[QN_NB];
     const int tid = threadIdx.x;
-    for (int e = tid; e < QN_NB * QN_NB; e += 64) L[e / QN_NB][e % QN_NB] = W[(size_t)(k0 + e / QN_NB) * ld + k0 + e % QN_NB];
+    qn_tile_to_lds<64, false>(L, W + (size_t)k0 * ld + k0, ld);
     xs[tid] = x[k0 + tid];
     __syncthreads();
     for (int j = 0; j < QN_NB; ++j) {
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(64) void tri_bwd_diag_kernel(const double* __restri
     __shared__ double L[QN_NB][QN_NB + 1];
     __shared__ double xs[QN_NB];
     const int tid = threadIdx.x;
-    for (int e = tid; e < QN_NB * QN_NB; e += 64) L[e / QN_NB][e % QN_NB] = W[(size_t)(k0 + e / QN_NB) * ld + k0 + e % QN_NB];
+    qn_tile_to_lds<64, false>(L, W + (size_t)k0 * ld + k0, ld);
     xs[tid] = x[k0 + tid];
     __syncthreads();
     for (int j = QN_NB - 1; j >= 0; --j) {
