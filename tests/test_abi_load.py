@@ -75,3 +75,36 @@ def test_product_does_not_reference_the_oracle():
                 text = open(os.path.join(dirpath, fn), errors="ignore").read()
                 for needle in ("libqn_oracle", "qn_oracle.h", "qn_oracle.c", "qn_oracle.py", "oracle/", "from oracle", "import oracle"):
                     assert needle not in text, (needle, os.path.join(dirpath, fn))
+
+
+def test_rust_shim_in_integration_md_matches_the_header():
+    """Row f3 (source-only deliverable): every `pub fn qn_*` of the Rust extern block exists in include/qn_hip.h with the
+    same number of parameters, and the #[repr(C)] structs have as many fields as the C structs."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "qn_hip.h")).read(), flags=re.S)
+    rust_fns = re.findall(r"pub fn (qn_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", md, flags=re.S)
+    assert len(rust_fns) >= 12
+    for name, params in rust_fns:
+        m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", hdr, flags=re.S)
+        assert m, name
+        c_params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
+        r_params = [p for p in params.split(",") if p.strip()]
+        assert len(c_params) == len(r_params), (name, c_params, r_params)
+
+    def c_fields(struct_name):
+        end = re.search(r"\}\s*" + struct_name + r"\s*;", hdr).start()
+        body = hdr[hdr.rfind("typedef struct {", 0, end) + len("typedef struct {"):end]
+        n = 0
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                n += decl.count(",") + 1
+        return n
+
+    def rust_fields(struct_name):
+        body = re.search(r"pub struct " + struct_name + r"\s*\{(.*?)\n\}", md, flags=re.S).group(1)
+        body = re.sub(r"//.*", "", body)
+        return len(re.findall(r"\bpub\s+\w+\s*:", body))
+
+    assert c_fields("qn_linesearch") == rust_fields("QnLineSearch") == 11
+    assert c_fields("qn_oracle") == rust_fields("QnOracle") == 8
