@@ -33,10 +33,10 @@ __device__ __forceinline__ void ctl_sum_partials(const double* __restrict__ part
     const int E = world * nblk;
     for (int k = wave; k < NP; k += nw) {
         double acc = 0.0;
-        for (int e0 = 0; e0 < E; e0 += 8 * 64) {
-            double v[8];
+        for (int e0 = 0; e0 < E; e0 += 16 * 64) { // 16 independent loads in flight per lane (the sweep is latency-bound)
+            double v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int e = e0 + u * 64 + lane;
                 const bool ok = e < E;
                 const int ee = ok ? e : 0;
@@ -45,7 +45,7 @@ __device__ __forceinline__ void ctl_sum_partials(const double* __restrict__ part
                 v[u] = ok ? x : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = acc + v[u];
+            for (int u = 0; u < 16; ++u) acc = acc + v[u];
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
