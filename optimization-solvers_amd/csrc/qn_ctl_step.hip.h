@@ -326,10 +326,24 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
     __shared__ QnCtl c;
     __shared__ double lds[16 * QN_NEVP];
     __shared__ double small_scratch[5 * QN_SMALL_N * QN_SMALL_N + QN_SMALL_N];
-    if (gctl->phase != expect_phase) return;
     const int tid = threadIdx.x;
     const int tpb = blockDim.x;
     const int n = V.n, n_pad = V.n_pad;
+    const bool fused = V.fused_hint != 0; // host-known: lets the fused step start its loads before the control block arrives
+    if (fused) {
+        // the control block and the partial sums are fetched together (one memory round trip instead of two); a
+        // predicated-off launch wastes the partial loads, nothing else
+        constexpr int NW = (int)(sizeof(QnCtl) / 8);
+        uint64_t cw = 0;
+        if (tid < NW) cw = reinterpret_cast<const uint64_t*>(gctl)[tid];
+        if (expect_phase == QN_PH_REQ_EVAL) ctl_sum_partials<QN_NEVP>(V.F.evp, V.world, V.F.nblk, lds);
+        else if (expect_phase == QN_PH_REQ_HPASS) ctl_sum_partials<QN_NHPP>(V.F.hpp, V.world, V.F.nblk, lds);
+        if (tid < NW) reinterpret_cast<uint64_t*>(&c)[tid] = cw;
+        __syncthreads();
+        if (c.phase != expect_phase) return;
+    } else {
+        if (gctl->phase != expect_phase) return;
+    }
 #ifdef QN_CTL_STAMPS
     const long stamp_base = V.dbg ? (long)(V.dbg[0] & 0xffff) * 16 + 16 : 0;
     if (tid == 0 && V.dbg) { V.dbg[0] = V.dbg[0] + 1; V.dbg[stamp_base + 15] = expect_phase; }
@@ -345,12 +359,6 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
     double* __restrict__ const vsp = V.sp;
     double* __restrict__ const vup = V.up;
     const double* __restrict__ const vb = V.b;
-
-    const int fused = gctl->fused;
-    if (fused) { // nothing but per-workgroup partial sums to read; column totals land in lds[0..NP)
-        if (expect_phase == QN_PH_REQ_EVAL) ctl_sum_partials<QN_NEVP>(V.F.evp, V.world, V.F.nblk, lds);
-        else if (expect_phase == QN_PH_REQ_HPASS) ctl_sum_partials<QN_NHPP>(V.F.hpp, V.world, V.F.nblk, lds);
-    }
 
     // ---- consume the serviced evaluation: f, g at xt, and g.d, in one sweep; warm x and g for AFTER_NEXT ----
     double cons_f = 0.0, cons_gd = 0.0;
@@ -388,12 +396,12 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
         cons_f = (ORACLE == QN_ORACLE_QUAD) ? (0.5 * p[0] - p[1]) : *V.f_dev;
         cons_gd = p[2];
     }
-    {
+    if (!fused) {
         const uint64_t* src = reinterpret_cast<const uint64_t*>(gctl);
         uint64_t* dst = reinterpret_cast<uint64_t*>(&c);
         for (int i = tid; i < (int)(sizeof(QnCtl) / 8); i += tpb) dst[i] = src[i];
+        __syncthreads();
     }
-    __syncthreads();
     QN_STAMP(2);
     if (tid == 0) {
         if (fused && expect_phase == QN_PH_REQ_EVAL) {

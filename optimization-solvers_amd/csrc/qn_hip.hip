@@ -1190,6 +1190,7 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
     r.fused = r.oracle_tpl == QN_ORACLE_QUAD && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP) && !callback && s->hcs == 1 &&
               s->qcs == 1 && !h->small_n && !s->no_fused;
     h->fused = r.fused ? 1 : 0;
+    s->V.fused_hint = h->fused;
     if (r.fused) { // import the canonical state (x, pending s and u) into the fused buffers
         QNCHK(solver_alloc_fused(s));
         s->V.F.b = r.obj->b;

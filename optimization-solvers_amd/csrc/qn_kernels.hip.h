@@ -69,6 +69,7 @@ struct QnVecs {
     double* H; // this rank's rows (used directly only by the n <= 5 reference-order path)
     unsigned long long* dbg; // diagnostic builds only (QN_CTL_STAMPS): in-kernel time stamps
     QnFused F; // fused fast path buffers (valid when ctl->fused)
+    int fused_hint;   // set by the host for runs on the fused path (== ctl->fused)
     const int* nfail; // Newton: set by the factorisation when the Hessian is not positive definite
     int n, n_pad, rpr, world, hcs, qcs;
 };
