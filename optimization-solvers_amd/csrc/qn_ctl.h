@@ -15,6 +15,8 @@ enum QnPhase : int32_t {
     QN_PH_REQ_HPASS = 2, // run h_pass with hp_nrhs right-hand sides
     QN_PH_ITER_DONE = 3, // host callback wanted (ls_solver.rs:105-107)
     QN_PH_DONE = 4,      // finished: status holds the SolverError code
+    QN_PH_REQ_HPASS_EVAL = 7, // fused path: run h_pass, then the evaluation at (req_kind, req_t) whose direction uses the
+                              // coefficients of the update this pass completes (derived from the pass's partial sums)
     QN_PH_REQ_NEWTON = 6 // Newton: factorise the Hessian at x_k and solve for d and H^-1 d (5 is the in-kernel RUNNING marker)
 };
 
@@ -71,7 +73,9 @@ struct QnCtl {
     int32_t have_dir;      // d / gd0 already hold the direction for the current x (lazy H+ g+)
 
     // ---- fused fast path (qn_fused.hip.h): buffer toggles, on-the-fly direction, staged sums of the last evaluation ----
-    int32_t fused, xc, sc, dir_mode, gd0_valid, _padf;
+    int32_t fused, xc, sc, dir_mode, gd0_valid;
+    int32_t no_defer, _padd; // diagnostics: disable the deferred update
+    int32_t defer_u; // the coefficients of the update in flight are not committed yet (QN_PH_REQ_HPASS_EVAL)
     double dir_ug, dir_sg;
     double st_gd0, st_yy, st_ys, st_gg, st_ss, st_dnf;
     double hp_yu, hp_ug, hp_sg;

@@ -28,27 +28,11 @@
 // Column k is owned by wave (k mod nwaves): its 64 lanes stride the entries with all loads in flight, one
 // shuffle tree per column, lane 0 parks the total in LDS.  After the caller's barrier lds[k] holds column k.
 template <int NP>
-__device__ __forceinline__ void ctl_sum_partials(const double* __restrict__ part, int world, int nblk, double* lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int E = world * nblk;
+__device__ __forceinline__ void ctl_sum_partials(const double* __restrict__ part, int world, int nblk, double* lds, int wave0 = 0) {
+    const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) - wave0, nw = (int)(blockDim.x >> 6) - wave0;
+    if (wave < 0) return;
     for (int k = wave; k < NP; k += nw) {
-        double acc = 0.0;
-        for (int e0 = 0; e0 < E; e0 += 16 * 64) { // 16 independent loads in flight per lane (the sweep is latency-bound)
-            double v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = e0 + u * 64 + lane;
-                const bool ok = e < E;
-                const int ee = ok ? e : 0;
-                const int r = ee / nblk, b = ee - r * nblk;
-                const double x = part[((size_t)r * NP + k) * nblk + b];
-                v[u] = ok ? x : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc = acc + v[u];
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
+        const double acc = qn_partial_col_sum(part, world, nblk, NP, k, lane);
         if (lane == 0) lds[k] = acc;
     }
 }
@@ -128,16 +112,28 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
                 c.state = QN_ST_ITER_END;
             } else {
                 c.hp_lazy = 1; c.hp_nrhs = 2;
-                c.after_state = QN_ST_AFTER_U;
-                c.phase = QN_PH_REQ_HPASS;
+                const double fk = c.f_k;
+                const bool will_continue = (c.k + 1 < c.max_iter) && !(isnan(fk) || isinf(fk)) && !(sqrt(c.gg) < c.tol);
+                if (will_continue && !c.callback_mode && !c.no_defer) {
+                    // Deferred update: everything the step after the H pass would decide is already known except the
+                    // update's coefficients (they need y.u, u.g+, s.g+ from the pass).  Run the rest of the iteration
+                    // bookkeeping now; the next evaluation request becomes QN_PH_REQ_HPASS_EVAL, its kernel derives the
+                    // coefficients from the pass's partial sums, and the following step commits them.  One launch less.
+                    c.defer_u = 1;
+                    c.tr_updated = 1;
+                    c.have_dir = 1; c.gd0_valid = 0; c.d_finite = 0;
+                    c.state = QN_ST_ITER_END;
+                } else {
+                    c.after_state = QN_ST_AFTER_U;
+                    c.phase = QN_PH_REQ_HPASS;
+                }
             }
         } break;
 
         case QN_ST_AFTER_U: { // coefficients of bfgs.rs:115-124 / dfp.rs:115-120 in rank-2 form
             if (!c.fused) return;
             const double yu = c.hp_yu;
-            if (c.method == 0) { const double rho = 1.0 / c.ys; c.c_su = -rho; c.c_ss = rho * rho * yu + rho; c.c_uu = 0.0; }
-            else { c.c_ss = 1.0 / c.ys; c.c_su = 0.0; c.c_uu = -1.0 / yu; }
+            qn_update_coeffs(c.method, c.ys, yu, c.c_ss, c.c_su, c.c_uu);
             c.n_hpasses++;
             if (c.pending) c.n_hpass_rw++;
             c.pending = 1;
@@ -322,9 +318,9 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
 // the kernel
 // ------------------------------------------------------------------------------------------------
 template <int ORACLE>
-__global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict__ gctl, const QnVecs V, const int expect_phase) {
+__global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict__ gctl, const QnVecs V, const int expect_mask) {
     __shared__ QnCtl c;
-    __shared__ double lds[16 * QN_NEVP];
+    __shared__ double lds[16 * QN_NEVP]; // block sums; fused path: [0, 9) evaluation totals, [9, 12) update-pass totals
     __shared__ double small_scratch[5 * QN_SMALL_N * QN_SMALL_N + QN_SMALL_N];
     const int tid = threadIdx.x;
     const int tpb = blockDim.x;
@@ -336,14 +332,17 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
         constexpr int NW = (int)(sizeof(QnCtl) / 8);
         uint64_t cw = 0;
         if (tid < NW) cw = reinterpret_cast<const uint64_t*>(gctl)[tid];
-        if (expect_phase == QN_PH_REQ_EVAL) ctl_sum_partials<QN_NEVP>(V.F.evp, V.world, V.F.nblk, lds);
-        else if (expect_phase == QN_PH_REQ_HPASS) ctl_sum_partials<QN_NHPP>(V.F.hpp, V.world, V.F.nblk, lds);
+        const bool want_ev = (expect_mask & ((1 << QN_PH_REQ_EVAL) | (1 << QN_PH_REQ_HPASS_EVAL))) != 0;
+        const bool want_hp = (expect_mask & ((1 << QN_PH_REQ_HPASS) | (1 << QN_PH_REQ_HPASS_EVAL))) != 0;
+        if (want_ev) ctl_sum_partials<QN_NEVP>(V.F.evp, V.world, V.F.nblk, lds);                                   // waves 0..8
+        if (want_hp) ctl_sum_partials<QN_NHPP>(V.F.hpp, V.world, V.F.nblk, lds + QN_NEVP, want_ev ? QN_NEVP : 0); // waves 9..11
         if (tid < NW) reinterpret_cast<uint64_t*>(&c)[tid] = cw;
         __syncthreads();
-        if (c.phase != expect_phase) return;
+        if (!((1 << c.phase) & expect_mask)) return;
     } else {
-        if (gctl->phase != expect_phase) return;
+        if (!((1 << gctl->phase) & expect_mask)) return;
     }
+    int expect_phase = fused ? c.phase : gctl->phase; // the request actually being consumed
 #ifdef QN_CTL_STAMPS
     const long stamp_base = V.dbg ? (long)(V.dbg[0] & 0xffff) * 16 + 16 : 0;
     if (tid == 0 && V.dbg) { V.dbg[0] = V.dbg[0] + 1; V.dbg[stamp_base + 15] = expect_phase; }
@@ -404,13 +403,24 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
     }
     QN_STAMP(2);
     if (tid == 0) {
+        if (fused && expect_phase == QN_PH_REQ_HPASS_EVAL) { // commit the update the evaluation kernel already used
+            const double yu = lds[QN_NEVP + 0];
+            qn_update_coeffs(c.method, c.ys, yu, c.c_ss, c.c_su, c.c_uu);
+            c.n_hpasses++;
+            if (c.pending) c.n_hpass_rw++;
+            c.pending = 1;
+            c.sc ^= 1; // the staged s becomes the pending s; the new u is already in UN
+            c.dir_mode = 1; c.dir_ug = lds[QN_NEVP + 1]; c.dir_sg = lds[QN_NEVP + 2];
+            c.defer_u = 0;
+            expect_phase = QN_PH_REQ_EVAL; // from here on: an ordinary evaluation result
+        }
         if (fused && expect_phase == QN_PH_REQ_EVAL) {
             cons_f = 0.5 * lds[0] - lds[1]; // f = 1/2 x+'(Q x+) - b'x+
             cons_gd = lds[2];
             c.st_gd0 = lds[3]; c.st_yy = lds[4]; c.st_ys = lds[5]; c.st_gg = lds[6]; c.st_ss = lds[7]; c.st_dnf = lds[8];
             if (c.req_kind == QN_REQ_T && !c.gd0_valid) { c.gd0 = lds[3]; c.d_finite = lds[8] == 0.0; c.gd0_valid = 1; }
         }
-        if (fused && expect_phase == QN_PH_REQ_HPASS) { c.hp_yu = lds[0]; c.hp_ug = lds[1]; c.hp_sg = lds[2]; }
+        if (fused && expect_phase == QN_PH_REQ_HPASS) { c.hp_yu = lds[QN_NEVP + 0]; c.hp_ug = lds[QN_NEVP + 1]; c.hp_sg = lds[QN_NEVP + 2]; }
         if (expect_phase == QN_PH_REQ_EVAL) {
             const int kind = c.req_kind;
             if (c.small_n && kind == QN_REQ_T) cons_gd = ref_dot(V.gt, V.d, n);
@@ -422,6 +432,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
         }
         if (expect_phase == QN_PH_IDLE) c.state = QN_ST_BEGIN;
         else if (expect_phase == QN_PH_REQ_EVAL || expect_phase == QN_PH_REQ_HPASS || expect_phase == QN_PH_REQ_NEWTON) c.state = c.after_state;
+        // (QN_PH_REQ_HPASS_EVAL was turned into QN_PH_REQ_EVAL by the commit above)
         c.phase = QN_PH_RUNNING;
         ctl_scalar_run(c, V, small_scratch);
     }

@@ -31,6 +31,38 @@ __device__ __forceinline__ double qn_dir1(int mode, double v, double s, double u
     return -w;
 }
 
+// Sum of column k of a per-workgroup partial buffer [world][NP][nblk] by ONE wave: lanes stride the tiles in global
+// order (rank-major = row order) with 16 loads in flight, then a shuffle tree.  Every lane returns the total.  Used by
+// the control step and, for the deferred update, by every workgroup of the evaluation kernel: the same code, so the
+// same bits everywhere.
+__device__ __forceinline__ double qn_partial_col_sum(const double* __restrict__ part, int world, int nblk, int NP, int k, int lane) {
+    const int E = world * nblk;
+    double acc = 0.0;
+    for (int e0 = 0; e0 < E; e0 += 16 * 64) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = e0 + u * 64 + lane;
+            const bool ok = e < E;
+            const int ee = ok ? e : 0;
+            const int r = ee / nblk, b = ee - r * nblk;
+            const double x = part[((size_t)r * NP + k) * nblk + b];
+            v[u] = ok ? x : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = acc + v[u];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
+    return acc;
+}
+
+// coefficients of the symmetric rank-2 form of bfgs.rs:115-124 (method 0) / dfp.rs:115-120 (method 1)
+__device__ __forceinline__ void qn_update_coeffs(int method, double ys, double yu, double& c_ss, double& c_su, double& c_uu) {
+    if (method == 0) { const double rho = 1.0 / ys; c_su = -rho; c_ss = rho * rho * yu + rho; c_uu = 0.0; }
+    else { c_ss = 1.0 / ys; c_su = 0.0; c_uu = -1.0 / yu; }
+}
+
 // reduce NP values over the first R lanes of wave 0 (R a power of two <= 16); lane 0 gets the totals
 template <int R, int NP>
 __device__ __forceinline__ void qn_rows_reduce(double (&p)[NP]) {
@@ -47,6 +79,8 @@ struct QnEvalFusedArgs {
     QnFused F;
     const QnCtl* ctl;
     int expect_phase;
+    int after_h; // this launch directly follows an h_pass launch: it may service QN_PH_REQ_HPASS_EVAL
+    int world;
 };
 
 // experiment switches (cache policy of the streamed matrices)
@@ -82,12 +116,27 @@ __global__ __launch_bounds__(QN_TPB) void quad_eval_fused_kernel(const QnEvalFus
         for (int r = 0; r < R; ++r) h[u][r] = QN_LD2_Q(qbase + (size_t)r * np);
     }
     const QnCtl* __restrict__ ctl = a.ctl;
-    if (ctl->phase != a.expect_phase) return;
+    const int phase = ctl->phase;
+    const bool post_h = a.after_h && phase == QN_PH_REQ_HPASS_EVAL;
+    if (phase != a.expect_phase && !post_h) return;
     const int kind = ctl->req_kind;
     const double t = ctl->req_t;
-    const int mode = ctl->dir_mode;
-    const double c_ss = ctl->c_ss, c_su = ctl->c_su, c_uu = ctl->c_uu, ug = ctl->dir_ug, sg = ctl->dir_sg;
-    const int xc = ctl->xc, sc = ctl->sc;
+    int mode = ctl->dir_mode;
+    double c_ss = ctl->c_ss, c_su = ctl->c_su, c_uu = ctl->c_uu, ug = ctl->dir_ug, sg = ctl->dir_sg;
+    const int xc = ctl->xc;
+    int sc = ctl->sc;
+    if (post_h) { // the update that h_pass just completed is not committed yet: derive its coefficients here (the control
+                  // step after this launch commits the very same values: qn_partial_col_sum is order-identical)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (wave < QN_NHPP) { const double v = qn_partial_col_sum(a.F.hpp, a.world, a.F.nblk, QN_NHPP, wave, lane); if (lane == 0) red[wave] = v; }
+        __syncthreads();
+        const double yu = red[0];
+        ug = red[1]; sg = red[2];
+        __syncthreads();
+        qn_update_coeffs(ctl->method, ctl->ys, yu, c_ss, c_su, c_uu);
+        mode = 1;
+        sc ^= 1; // the staged s became the pending s
+    }
     const double* __restrict__ x = a.F.X0 + (size_t)xc * np;
     double* __restrict__ xt = a.F.X0 + (size_t)(1 - xc) * np;
     const double* __restrict__ sp = a.F.S0 + (size_t)sc * np;
@@ -310,7 +359,8 @@ __global__ __launch_bounds__(QN_TPB) void h_pass_fused_kernel(const QnHPassFused
         for (int r = 0; r < R; ++r) h[u][r] = QN_LD2_H(hbase + (size_t)r * np);
     }
     const QnCtl* __restrict__ ctl = a.ctl;
-    if (ctl->phase != a.expect_phase) return;
+    const int phase = ctl->phase;
+    if (phase != a.expect_phase && phase != QN_PH_REQ_HPASS_EVAL) return;
     const int nrhs = ctl->hp_nrhs;
     const int pending = ctl->pending;
     const double c_ss = ctl->c_ss, c_su = ctl->c_su, c_uu = ctl->c_uu;

@@ -560,6 +560,7 @@ struct qn_solver {
     int trace_x = 0;
     int sync_mode = -1; // -1 auto
     int no_fused = 0;   // diagnostics: force the generic (non-fused) path
+    int no_defer = 0;   // diagnostics: fused path without the deferred update step
     int profiling = 0;
     std::vector<TimedEvent> events;
     std::vector<hipEvent_t> event_pool;
@@ -726,7 +727,8 @@ extern "C" int qn_debug_stamps(qn_solver* s, unsigned long long* out, size_t cou
 extern "C" int qn_solver_set_profiling(qn_solver* s, int on) { s->profiling = on; return QN_OK; }
 extern "C" int qn_solver_set_sync_mode(qn_solver* s, int sync) { s->sync_mode = sync; return QN_OK; }
 extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits) {
-    if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; } // diagnostics: -1 selects the generic (non-fused) kernels
+    if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; }
+    if (rows_per_block == -2) { s->no_defer = 1; rows_per_block = 0; } // diagnostics: fused kernels, update step not deferred // diagnostics: -1 selects the generic (non-fused) kernels
     if (rows_per_block != 0 && rows_per_block != 2 && rows_per_block != 4 && rows_per_block != 8 && rows_per_block != 16)
         return fail(QN_ERROR_INPUT_PARAMS, "rows_per_block must be 2, 4, 8 or 16");
     if (col_splits >= 100) { // tuning: 100 + U selects U column chunks per loop trip of the fused kernels (one column split)
@@ -954,19 +956,23 @@ struct Run {
     bool fused;
 };
 
-static int launch_ctl(Run& r, int expect_phase) {
+static int launch_ctl_mask(Run& r, int expect_mask) {
     qn_solver* s = r.s;
     ProfScope ps(s, KC_CTL);
-    // the fused path only sums partials: 576 threads (one wave per column); the generic path sweeps n-vectors: 1024 threads
-    const dim3 blk(r.fused ? 576 : QN_CTL_TPB); // 9 waves: one per partial-sum column
+    // fused path: the step only sums per-workgroup partials, one wave per column (9 evaluation + 3 update-pass columns);
+    // generic path: it sweeps n-vectors with 1024 threads
+    const bool hp = (expect_mask & ((1 << QN_PH_REQ_HPASS) | (1 << QN_PH_REQ_HPASS_EVAL))) != 0;
+    const bool ev = (expect_mask & ((1 << QN_PH_REQ_EVAL) | (1 << QN_PH_REQ_HPASS_EVAL))) != 0;
+    const dim3 blk(r.fused ? ((hp && ev) ? 768 : 576) : QN_CTL_TPB);
     if (r.oracle_tpl == QN_ORACLE_QUAD)
-        hipLaunchKernelGGL(ctl_step_kernel<QN_ORACLE_QUAD>, dim3(1), blk, 0, s->ctx->stream, s->ctl, s->V, expect_phase);
+        hipLaunchKernelGGL(ctl_step_kernel<QN_ORACLE_QUAD>, dim3(1), blk, 0, s->ctx->stream, s->ctl, s->V, expect_mask);
     else
-        hipLaunchKernelGGL(ctl_step_kernel<QN_ORACLE_GENERIC>, dim3(1), blk, 0, s->ctx->stream, s->ctl, s->V, expect_phase);
+        hipLaunchKernelGGL(ctl_step_kernel<QN_ORACLE_GENERIC>, dim3(1), blk, 0, s->ctx->stream, s->ctl, s->V, expect_mask);
     s->stats.launches++;
     HIPCHK(hipGetLastError());
     return QN_OK;
 }
+static int launch_ctl(Run& r, int expect_phase) { return launch_ctl_mask(r, 1 << expect_phase); }
 
 template <int R, int U>
 static void launch_eval_fused(hipStream_t st, const QnEvalFusedArgs& a) {
@@ -992,11 +998,12 @@ static void launch_hpass_fused(hipStream_t st, const QnHPassFusedArgs& a) {
         }                                                                           \
     } while (0)
 
-static int enqueue_eval_fused(Run& r) {
+static int enqueue_eval_fused(Run& r, int after_h) {
     qn_solver* s = r.s;
     qn_context* c = s->ctx;
     QnEvalFusedArgs a{};
     a.Q = r.obj->Q; a.T = s->T; a.T.cs = 1; a.F = s->V.F; a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_EVAL;
+    a.after_h = after_h; a.world = c->world;
     {
         ProfScope ps(s, KC_EVAL);
         QN_DISPATCH_RU(launch_eval_fused, s->R, s->U, c->stream, a);
@@ -1031,10 +1038,10 @@ static int enqueue_hpass_fused(Run& r) {
 }
 
 // enqueue the evaluation of the oracle at the requested point (predicated on phase == REQ_EVAL)
-static int enqueue_eval(Run& r) {
+static int enqueue_eval(Run& r, int after_h = 0) {
     qn_solver* s = r.s;
     qn_context* c = s->ctx;
-    if (r.fused) return enqueue_eval_fused(r);
+    if (r.fused) return enqueue_eval_fused(r, after_h);
     if (r.oracle_tpl == QN_ORACLE_QUAD) {
         QnQuadArgs a{};
         a.Q = r.obj->Q; a.T = s->T; a.T.cs = s->qcs;
@@ -1191,6 +1198,8 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
               s->qcs == 1 && !h->small_n && !s->no_fused;
     h->fused = r.fused ? 1 : 0;
     s->V.fused_hint = h->fused;
+    h->defer_u = 0;
+    h->no_defer = s->no_defer;
     if (r.fused) { // import the canonical state (x, pending s and u) into the fused buffers
         QNCHK(solver_alloc_fused(s));
         s->V.F.b = r.obj->b;
@@ -1219,6 +1228,9 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
             if (ph == QN_PH_DONE) { status = h->status; break; }
             if (ph == QN_PH_REQ_EVAL) { QNCHK(enqueue_eval(r)); QNCHK(launch_ctl(r, QN_PH_REQ_EVAL)); }
             else if (ph == QN_PH_REQ_HPASS) { QNCHK(enqueue_hpass_req(r)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS)); }
+            else if (ph == QN_PH_REQ_HPASS_EVAL) { // fused path: update pass, then the evaluation that derives the update's coefficients itself
+                QNCHK(enqueue_hpass_req(r)); QNCHK(enqueue_eval(r, 1)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS_EVAL));
+            }
             else if (ph == QN_PH_REQ_NEWTON) { QNCHK(enqueue_newton(s, o, r.obj)); QNCHK(launch_ctl(r, QN_PH_REQ_NEWTON)); }
             else if (ph == QN_PH_ITER_DONE) { callback(callback_user, s); QNCHK(launch_ctl(r, QN_PH_ITER_DONE)); }
             else return fail(QN_ABNORMAL_TERMINATION, "control block in an unexpected phase");
@@ -1234,9 +1246,18 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
             int64_t remaining = h->max_iter - h->k;
             if (remaining < 1) remaining = 1;
             const int64_t periods = std::min<int64_t>(remaining, 256);
+            const int first_mask = (1 << QN_PH_REQ_EVAL) | (1 << QN_PH_REQ_HPASS) | (1 << QN_PH_REQ_HPASS_EVAL);
             for (int64_t p = 0; p < periods; ++p) {
-                for (int e = 0; e < slots; ++e) { QNCHK(enqueue_eval(r)); QNCHK(launch_ctl(r, QN_PH_REQ_EVAL)); }
-                if (!gd) { QNCHK(enqueue_hpass_req(r)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS)); }
+                if (r.fused) {
+                    // [eval*, step*] [eval, step] x (slots-1) [h_pass]: the first evaluation of a period directly follows the
+                    // previous period's h_pass and may service QN_PH_REQ_HPASS_EVAL; its step also consumes a plain h_pass
+                    QNCHK(enqueue_eval(r, 1)); QNCHK(launch_ctl_mask(r, first_mask));
+                    for (int e = 1; e < slots; ++e) { QNCHK(enqueue_eval(r, 0)); QNCHK(launch_ctl(r, QN_PH_REQ_EVAL)); }
+                    QNCHK(enqueue_hpass_req(r));
+                } else {
+                    for (int e = 0; e < slots; ++e) { QNCHK(enqueue_eval(r)); QNCHK(launch_ctl(r, QN_PH_REQ_EVAL)); }
+                    if (!gd) { QNCHK(enqueue_hpass_req(r)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS)); }
+                }
             }
         }
     }

@@ -476,7 +476,7 @@ __device__ __forceinline__ void req_eval_t(QnCtl& c, double t, int after_state, 
     c.req_t = t;
     c.req_need_vectors = need_vectors;
     c.after_state = after_state;
-    c.phase = QN_PH_REQ_EVAL;
+    c.phase = c.defer_u ? QN_PH_REQ_HPASS_EVAL : QN_PH_REQ_EVAL;
 }
 
 // ------------------------------------------------------------------------------------------------

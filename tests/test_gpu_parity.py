@@ -612,3 +612,24 @@ def test_config3_size_properties_n32768_single_gpu(qn, qo):
     sk = xs[-1] - xs[-2]
     yk = g - obj(xs[-2]).g()
     assert yk @ sk > 0
+
+
+def test_deferred_update_step_is_bitwise_neutral(qn, qo):
+    """Fused path: with the deferred update the step after the H pass disappears (its coefficients are derived by the next
+    evaluation kernel from the same partial sums).  Nothing numeric may change: same bits with and without, in pipelined and
+    synchronous mode, for both methods and both line searches."""
+    n = 640
+    q, b, x0, diag = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+    for method, lsname in (("bfgs", "mt"), ("dfp", "mt"), ("bfgs", "bt")):
+        runs = []
+        for tiling, sync in (((0, 0), 0), ((-2, 0), 0), ((0, 0), 1), ((-2, 0), 1)):
+            s, st = _run_gpu(qn, method, lsname, obj, x0, 35, sync=sync, tiling=tiling if tiling != (0, 0) else None)
+            tr, xs = s.trace()
+            runs.append((st, tr, xs, s.approx_inv_hessian(), s.stats()))
+        for other in runs[1:]:
+            assert other[0] == runs[0][0] and other[1] == runs[0][1]
+            assert np.array_equal(other[2], runs[0][2]) and np.array_equal(other[3], runs[0][3])
+        # the deferred variant saves one launch per iteration in the steady state
+        assert runs[0][4]["launches"] < runs[1][4]["launches"]
+        assert runs[0][4]["h_passes"] == runs[1][4]["h_passes"] and runs[0][4]["oracle_evals"] == runs[1][4]["oracle_evals"]
