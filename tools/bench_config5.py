@@ -1,0 +1,44 @@
+"""Row f1 measurement (BASELINE.json config 5): DFP + More-Thuente on the n = m = 16384 log-sum-exp objective, one GPU.
+Prints one JSON line: iterations/s, oracle evaluations, and the achieved HBM rate of the objective's two passes over A
+(16*m*n bytes per evaluation) and of the H pass (16 n^2), measured with HIP events in synchronous mode."""
+import json, sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+import __graft_entry__ as ge
+qn = ge.load_package()
+n = m = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+rng = np.random.default_rng(11)
+a = rng.standard_normal((m, n)) * (2.0 / np.sqrt(n))
+c = rng.standard_normal(m)
+x0 = rng.standard_normal(n)
+obj = qn.LogSumExp(a, c, 0.1)
+s = qn.DFP(1e-10, x0)
+def run(k):
+    try:
+        s.minimize(qn.MoreThuente(), obj, k, 20)
+    except qn.MaxIterReached:
+        pass
+run(3)  # warm-up
+qn.default_context().synchronize()
+st0 = s.stats(); t0 = time.perf_counter()
+run(iters)
+qn.default_context().synchronize()
+dt = time.perf_counter() - t0; st1 = s.stats()
+s.set_profiling(True); p0 = s.stats(); run(8); p1 = s.stats(); s.set_profiling(False)
+n_h = p1["n_hpass_timed"] - p0["n_hpass_timed"]; t_h = p1["t_hpass_ms"] - p0["t_hpass_ms"]
+evals = st1["oracle_evals"] - st0["oracle_evals"]
+h_ms = t_h / max(n_h, 1)
+# time of one evaluation (two passes over A + softmax + reductions), events around a direct call
+import ctypes as C
+ev_ms = []
+for _ in range(5):
+    qn.default_context().synchronize(); t1 = time.perf_counter(); obj(x0); qn.default_context().synchronize(); ev_ms.append((time.perf_counter() - t1) * 1e3)
+ev = sorted(ev_ms)[len(ev_ms) // 2]
+out = {"config": f"DFP + MoreThuente, n=m={n} log-sum-exp (mu=0.1), f64, 1xMI355X (BASELINE.json config 5 runs it on 4)",
+       "iterations_per_s": iters / dt, "ms_per_iteration": 1e3 * dt / iters, "oracle_evals_per_iteration": evals / iters,
+       "h_pass": {"avg_launch_ms": h_ms, "algorithmic_bytes": 16.0 * n * n, "achieved_GBs": 16.0 * n * n / (h_ms * 1e-3) / 1e9 if n_h else None},
+       "objective_eval": {"wall_ms_incl_host_copies": ev, "algorithmic_bytes": 16.0 * m * n,
+                          "achieved_GBs_lower_bound": 16.0 * m * n / (ev * 1e-3) / 1e9},
+       "peak_GBs": 8000.0}
+print(json.dumps(out))
