@@ -78,12 +78,17 @@ void* qn_context_stream(qn_context* ctx); /* hipStream_t */
  *   QN_LS_MORETHUENTE : MoreThuente        (morethuente.rs:6-62, compute_step_len :165-297)
  *   QN_LS_BACKTRACKING: BackTracking       (backtracking.rs:3-58)
  * ------------------------------------------------------------------------------------------- */
-enum { QN_LS_MORETHUENTE = 0, QN_LS_BACKTRACKING = 1 };
+enum { QN_LS_MORETHUENTE = 0, QN_LS_BACKTRACKING = 1,
+       QN_LS_MORETHUENTE_B = 2 /* MoreThuenteB, morethuente_b.rs */, QN_LS_BACKTRACKING_B = 3 /* BackTrackingB, backtracking_b.rs */ };
 typedef struct {
     int32_t kind;
     int32_t _pad;
     double c1, c2, t_min, t_max, delta_min, delta, delta_max; /* More-Thuente fields, morethuente.rs:6-14 */
     double bt_c1, bt_beta;                                    /* BackTracking{c1, beta}, backtracking.rs:3-6 */
+    /* the *_B variants hold their own box (morethuente_b.rs:14-15, backtracking_b.rs:7-8): host vectors of length n,
+     * read by qn_minimize; NULL = unbounded side */
+    const double* lower_bound_host;
+    const double* upper_bound_host;
 } qn_linesearch;
 
 void qn_morethuente_default(qn_linesearch* ls);                      /* MoreThuente::default, morethuente.rs:16-28 */
@@ -93,6 +98,10 @@ int qn_morethuente_with_t_max(qn_linesearch* ls, double t_max);      /* :46-49 *
 int qn_morethuente_with_c1(qn_linesearch* ls, double c1);            /* :50-55; the assert!s become QN_ERROR_INPUT_PARAMS */
 int qn_morethuente_with_c2(qn_linesearch* ls, double c2);            /* :56-62 */
 void qn_backtracking_new(qn_linesearch* ls, double c1, double beta); /* BackTracking::new, backtracking.rs:8-10 */
+void qn_morethuente_b_new(qn_linesearch* ls);                          /* MoreThuenteB::new(n): defaults, bounds -inf/+inf, morethuente_b.rs:18-31 */
+void qn_backtracking_b_new(qn_linesearch* ls, double c1, double beta, const double* lower_bound_host, const double* upper_bound_host); /* backtracking_b.rs:10-23 */
+void qn_linesearch_with_lower_bound(qn_linesearch* ls, const double* lower_bound_host); /* morethuente_b.rs:32-35 */
+void qn_linesearch_with_upper_bound(qn_linesearch* ls, const double* upper_bound_host); /* morethuente_b.rs:36-39 */
 
 /* ---------------------------------------------------------------------------------------------
  * Oracle: `impl FnMut(&DVector<f64>) -> FuncEvalMultivariate` (ls_solver.rs:69, func_eval.rs:4-41).
@@ -143,12 +152,16 @@ int qn_objective_get_rows(qn_objective* obj, size_t row0, size_t nrows, double* 
 /* ---------------------------------------------------------------------------------------------
  * Solvers: BFGS (bfgs.rs:4-127), DFP (dfp.rs), GradientDescent (gradient_descent.rs:7-82), Newton (newton/mod.rs).
  * ------------------------------------------------------------------------------------------- */
-enum { QN_BFGS = 0, QN_DFP = 1, QN_GRADIENT_DESCENT = 2, QN_NEWTON = 3 /* newton/mod.rs:8-69, SURVEY.md 8(f) row f2 */ };
+enum { QN_BFGS = 0, QN_DFP = 1, QN_GRADIENT_DESCENT = 2, QN_NEWTON = 3 /* newton/mod.rs:8-69, SURVEY.md 8(f) row f2 */,
+       QN_SR1 = 4 /* sr1_b.rs (row f4; SR1B once qn_solver_set_bounds is called) */ };
 typedef struct qn_solver qn_solver;
 
 /* BFGS::new(tol, x0) / DFP::new / GradientDescent::new(grad_tol, x0): H = I (no identity copy is kept) */
 int qn_solver_create(qn_context* ctx, int method, double tol, const double* x0_host, size_t n, qn_solver** out);
 void qn_solver_destroy(qn_solver* s);
+/* Row f4: BFGSB / DFPB / SR1B (bfgs_b.rs:43-77, dfp_b.rs, sr1_b.rs): box bounds on a BFGS / DFP / SR1 solver.  The current x
+ * is projected (bfgs_b.rs:49) and every direction becomes P(x - H g) - x (bfgs_b.rs:72-75). */
+int qn_solver_set_bounds(qn_solver* s, const double* lower_bound_host, const double* upper_bound_host);
 /* back to the state right after BFGS::new(tol, x0): x = x0, H = I, k = 0, s_norm = y_norm = None */
 int qn_solver_reset(qn_solver* s, const double* x0_host);
 
@@ -156,7 +169,8 @@ int qn_solver_reset(qn_solver* s, const double* x0_host);
 typedef void (*qn_callback_fn)(void* user, qn_solver* solver);
 
 /* LineSearchSolver::minimize (ls_solver.rs:66-111).  Resets k only (warm restart keeps x, H, s_norm, y_norm). */
-int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracle* oracle, size_t max_iter_solver,
+/* `ls` is not const: MoreThuenteB clips its t_max to the box and keeps it clipped (morethuente_b.rs:201 `self.t_max = ...`). */
+int qn_minimize(qn_solver* s, qn_linesearch* ls, const qn_oracle* oracle, size_t max_iter_solver,
                 size_t max_iter_line_search, qn_callback_fn callback, void* callback_user);
 
 /* getters generated by derive_getters on bfgs.rs:3-12, plus LineSearchSolver::xk/k (bfgs.rs:52-63) */

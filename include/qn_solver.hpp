@@ -93,7 +93,8 @@ class MoreThuente {
     MoreThuente with_c2(Floating v) && { check(qn_morethuente_with_c2(&s_, v)); return *this; }
     Floating c1() const { return s_.c1; }
     Floating c2() const { return s_.c2; }
-    const qn_linesearch& ffi() const { return s_; }
+    Floating t_max() const { return s_.t_max; }
+    qn_linesearch& ffi() { return s_; }
 };
 
 // backtracking.rs:3-11
@@ -102,7 +103,7 @@ class BackTracking {
   public:
     BackTracking(Floating c1, Floating beta) { qn_backtracking_new(&s_, c1, beta); }
     static BackTracking new_(Floating c1, Floating beta) { return BackTracking(c1, beta); }
-    const qn_linesearch& ffi() const { return s_; }
+    qn_linesearch& ffi() { return s_; }
 };
 
 // a device-resident objective (built-in quadratic f = 1/2 x'Qx - b'x)

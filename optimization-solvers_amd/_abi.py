@@ -7,9 +7,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QN_HIP_LIB") or os.path.join(_HERE, "lib", "libqn_hip.so")  # QN_HIP_LIB: diagnostic builds
 
 OK, MAX_ITER_REACHED, OUT_OF_DOMAIN, ERROR_INPUT_PARAMS, ABNORMAL_TERMINATION = range(5)
-LS_MORETHUENTE, LS_BACKTRACKING = 0, 1
+LS_MORETHUENTE, LS_BACKTRACKING, LS_MORETHUENTE_B, LS_BACKTRACKING_B = 0, 1, 2, 3
 ORACLE_HOST, ORACLE_DEVICE_FN, ORACLE_OBJECTIVE = 0, 1, 2
-BFGS, DFP, GRADIENT_DESCENT, NEWTON = 0, 1, 2, 3
+BFGS, DFP, GRADIENT_DESCENT, NEWTON, SR1 = 0, 1, 2, 3, 4
 UNIQUE_ID_BYTES = 128
 
 dp = C.POINTER(C.c_double)
@@ -19,7 +19,8 @@ class LineSearchStruct(C.Structure):
     _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32),
                 ("c1", C.c_double), ("c2", C.c_double), ("t_min", C.c_double), ("t_max", C.c_double),
                 ("delta_min", C.c_double), ("delta", C.c_double), ("delta_max", C.c_double),
-                ("bt_c1", C.c_double), ("bt_beta", C.c_double)]
+                ("bt_c1", C.c_double), ("bt_beta", C.c_double),
+                ("lower_bound_host", C.c_void_p), ("upper_bound_host", C.c_void_p)]
 
 
 HOST_ORACLE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, C.c_size_t, dp, dp)
@@ -73,6 +74,10 @@ SYMBOLS = [
     ("qn_morethuente_with_c1", C.c_int, [C.POINTER(LineSearchStruct), C.c_double]),
     ("qn_morethuente_with_c2", C.c_int, [C.POINTER(LineSearchStruct), C.c_double]),
     ("qn_backtracking_new", None, [C.POINTER(LineSearchStruct), C.c_double, C.c_double]),
+    ("qn_morethuente_b_new", None, [C.POINTER(LineSearchStruct)]),
+    ("qn_backtracking_b_new", None, [C.POINTER(LineSearchStruct), C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    ("qn_linesearch_with_lower_bound", None, [C.POINTER(LineSearchStruct), C.c_void_p]),
+    ("qn_linesearch_with_upper_bound", None, [C.POINTER(LineSearchStruct), C.c_void_p]),
     ("qn_quadratic_create", C.c_int, [C.c_void_p, C.c_size_t, dp, dp, C.POINTER(C.c_void_p)]),
     ("qn_quadratic_create_synthetic", C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, dp, dp, C.POINTER(C.c_void_p)]),
     ("qn_logsumexp_create", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, dp, dp, C.c_double, C.POINTER(C.c_void_p)]),
@@ -82,6 +87,7 @@ SYMBOLS = [
     ("qn_solver_create", C.c_int, [C.c_void_p, C.c_int, C.c_double, dp, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("qn_solver_destroy", None, [C.c_void_p]),
     ("qn_solver_reset", C.c_int, [C.c_void_p, dp]),
+    ("qn_solver_set_bounds", C.c_int, [C.c_void_p, dp, dp]),
     ("qn_minimize", C.c_int, [C.c_void_p, C.POINTER(LineSearchStruct), C.POINTER(OracleStruct), C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("qn_solver_n", C.c_size_t, [C.c_void_p]),
     ("qn_solver_k", C.c_size_t, [C.c_void_p]),

@@ -80,6 +80,11 @@ struct QnCtl {
     double st_gd0, st_yy, st_ys, st_gg, st_ss, st_dnf;
     double hp_yu, hp_ug, hp_sg;
 
+    // ---- bounded variants (row f4) ----
+    int32_t bounded, req_project, last_projected, _padb;
+    double mtb_cand; // min over i of the step to the box along d (morethuente_b.rs:185-198)
+    double bt_diff2; // ||P(x + t d) - x||^2 of the last projected trial (backtracking_b.rs:33-34)
+
     // ---- Newton (newton/mod.rs:8-13) ----
     int32_t has_dec, _padn;
     double dec; // decrement_squared: Option<f64>

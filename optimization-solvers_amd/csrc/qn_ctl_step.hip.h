@@ -159,7 +159,17 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
             int d_finite = c.d_finite;
             if (c.small_n) { // reference order: norm = sqrt(dot), direction by column sweep (bfgs.rs:47)
                 gnorm = sqrt(ref_dot(V.g, V.g, n));
-                small_direction(V.H, n_pad, n, V.g, V.d, small_scratch);
+                small_direction(V.H, n_pad, n, V.g, V.d, small_scratch, V.x, c.bounded ? V.lb : nullptr, c.bounded ? V.ub : nullptr);
+                if (c.ls_kind == 2) { // morethuente_b.rs:185-198
+                    double cand = INFINITY;
+                    for (int i = 0; i < n; ++i) {
+                        const double di = V.d[i];
+                        double v = INFINITY;
+                        if (di > 0.0) v = (V.lub[i] - V.x[i]) / di; else if (di < 0.0) v = (V.llb[i] - V.x[i]) / di;
+                        cand = fmin(v, cand);
+                    }
+                    c.mtb_cand = cand;
+                }
                 gd0 = ref_dot(V.g, V.d, n);
                 d_finite = 1;
                 for (int i = 0; i < n; ++i) d_finite &= isfinite(V.d[i]) ? 1 : 0;
@@ -186,7 +196,8 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
 
         case QN_ST_LS_BEGIN: {
             c.ls_i = 0;
-            if (c.ls_kind == 0) { // morethuente.rs:173-178
+            if (c.ls_kind == 2) c.mt_tmax = fmin(c.mt_tmax, c.mtb_cand); // morethuente_b.rs:201: self.t_max = self.t_max.min(candidate) -- persists
+            if (c.ls_kind == 0 || c.ls_kind == 2) { // morethuente.rs:173-178
                 c.use_mod = 0; c.conv = 0;
                 c.t = fmin(fmax(1.0, c.mt_tmin), c.mt_tmax);
                 c.tl = c.mt_tmin; c.tu = c.mt_tmax;
@@ -273,18 +284,19 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
 
         case QN_ST_BT_LOOP: { // backtracking.rs:31-34
             if (!(c.max_iter_ls > c.ls_i)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :54
-            else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_BT_AFTER, 0); }
+            else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_BT_AFTER, 0, c.ls_kind == 3 ? 1 : 0); }
         } break;
 
         case QN_ST_BT_AFTER: { // backtracking.rs:37-51
             const double f1 = c.f_e;
             if (isnan(f1) || isinf(f1)) { c.t *= c.bt_beta; c.state = QN_ST_BT_LOOP; } // shrink, iteration not counted
-            else if (f1 - c.f_k <= c.bt_c1 * c.t * c.gd0) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; }
+            else if (c.ls_kind == 3 ? (f1 - c.f_k <= (-c.bt_c1 / c.t) * c.bt_diff2) // backtracking_b.rs:24-34
+                                    : (f1 - c.f_k <= c.bt_c1 * c.t * c.gd0)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; }
             else { c.t *= c.bt_beta; c.ls_i++; c.state = QN_ST_BT_LOOP; }
         } break;
 
         case QN_ST_AFTER_LS: {
-            if (c.method >= 2) return; // gradient descent / Newton: the default hook x += step*d needs all threads
+            if (c.method == 2 || c.method == 3) return; // gradient descent / Newton: the default hook x += step*d needs all threads
             req_eval_t(c, c.ls_result, QN_ST_AFTER_NEXT, 1); // bfgs.rs:94,98: oracle(x + step*d)
         } break;
 
@@ -401,8 +413,20 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
         for (int i = tid; i < (int)(sizeof(QnCtl) / 8); i += tpb) dst[i] = src[i];
         __syncthreads();
     }
+    double cons_diff2 = 0.0;
+    if (!fused && expect_phase == QN_PH_REQ_EVAL && c.req_project) { // BackTrackingB: ||P(x + t d) - x||^2
+        double p[1] = {0.0};
+        for (int i = tid; i < n_pad; i += tpb) { const double df = vxt[i] - vx[i]; p[0] = __builtin_fma(df, df, p[0]); }
+        ctl_block_sum<1>(p, lds);
+        if (c.small_n) {
+            __syncthreads();
+            if (tid == 0) { double acc8[QN_SMALL_N]; for (int i = 0; i < n; ++i) acc8[i] = V.xt[i] - V.x[i]; p[0] = ref_dot(acc8, acc8, n); }
+        }
+        cons_diff2 = p[0];
+    }
     QN_STAMP(2);
     if (tid == 0) {
+        if (expect_phase == QN_PH_REQ_EVAL) { c.bt_diff2 = cons_diff2; c.last_projected = c.req_project; }
         if (fused && expect_phase == QN_PH_REQ_HPASS_EVAL) { // commit the update the evaluation kernel already used
             const double yu = lds[QN_NEVP + 0];
             qn_update_coeffs(c.method, c.ys, yu, c.c_ss, c.c_su, c.c_uu);
@@ -502,8 +526,10 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
             }
         } break;
 
-        case QN_ST_AFTER_DIR: { // d = -(H g) from the gathered h_pass output, g.d
+        case QN_ST_AFTER_DIR: { // d = -(H g) from the gathered h_pass output (bounded: P(x - H g) - x), g.d
             double p[2] = {0.0, 0.0};
+            const bool bounded = c.bounded != 0, want_cand = c.ls_kind == 2;
+            double cand = INFINITY;
             for (int base = 0; base < n_pad; base += 4 * tpb) {
                 QN_TILE_IDX(base)
                 double hv[4], gv[4];
@@ -512,14 +538,23 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (ok[u]) {
-                        const double di = -hv[u];
+                        double di = -hv[u];
+                        if (bounded) { const double xi = vx[idx[u]]; double t = xi - hv[u]; t = fmin(fmax(t, V.lb[idx[u]]), V.ub[idx[u]]); di = t - xi; } // bfgs_b.rs:72-75
                         vd[idx[u]] = di;
                         p[0] = __builtin_fma(gv[u], di, p[0]);
                         p[1] += isfinite(di) ? 0.0 : 1.0;
+                        if (want_cand) { // morethuente_b.rs:185-198
+                            const double xi = vx[idx[u]];
+                            double v = INFINITY;
+                            if (di > 0.0) v = (V.lub[idx[u]] - xi) / di; else if (di < 0.0) v = (V.llb[idx[u]] - xi) / di;
+                            cand = fmin(v, cand);
+                        }
                     }
             }
             ctl_block_sum<2>(p, lds);
+            if (want_cand) cand = -ctl_block_fmax(-cand, lds);
             if (tid == 0) {
+                c.mtb_cand = cand;
                 c.n_hpasses++;
                 if (c.pending) c.n_hpass_rw++;
                 c.pending = 0;
@@ -630,7 +665,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
             const bool lazy = c.hp_lazy != 0;
             const int method = c.method;
             const double ys = c.ys;
-            double p[3] = {0.0, 0.0, 0.0};
+            double p[4] = {0.0, 0.0, 0.0, 0.0};
             for (int base = 0; base < n_pad; base += 4 * tpb) {
                 QN_TILE_IDX(base)
                 double uv[4], sv[4], yv[4], gv[4];
@@ -646,14 +681,17 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                         p[0] = __builtin_fma(yv[u], uv[u], p[0]);
                         p[1] = __builtin_fma(uv[u], gv[u], p[1]);
                         p[2] = __builtin_fma(sv[u], gv[u], p[2]);
+                        p[3] = __builtin_fma(sv[u] - uv[u], yv[u], p[3]); // SR1: (s - H y).y, sr1_b.rs:145
                     }
             }
-            ctl_block_sum<3>(p, lds);
+            ctl_block_sum<4>(p, lds);
             const double yu = p[0], ug = p[1], sg = p[2];
             double c_ss, c_su, c_uu;
             if (method == 0) { const double rho = 1.0 / ys; c_su = -rho; c_ss = rho * rho * yu + rho; c_uu = 0.0; }
+            else if (method == 4) { c_ss = 1.0 / p[3]; c_su = -c_ss; c_uu = c_ss; } // (s-u)(s-u)'/((s-u).y) = c (ss' - (su' + us') + uu')
             else { c_ss = 1.0 / ys; c_su = 0.0; c_uu = -1.0 / yu; }
             double q[2] = {0.0, 0.0};
+            double lazy_cand = INFINITY;
             if (lazy) { // d+ = -(H+ g+) = -(v + c_su (s (u.g) + u (s.g)) + c_ss s (s.g) + c_uu u (u.g)),  v = H g+
                 for (int base = 0; base < n_pad; base += 4 * tpb) {
                     QN_TILE_IDX(base)
@@ -667,13 +705,21 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                             if (c_su != 0.0) w = w + c_su * (sv[u] * ug + uv[u] * sg);
                             w = w + c_ss * (sv[u] * sg);
                             if (c_uu != 0.0) w = w + c_uu * (uv[u] * ug);
-                            const double di = -w;
+                            double di = -w;
+                            if (c.bounded) { const double xi = vx[idx[u]]; double t = xi - w; t = fmin(fmax(t, V.lb[idx[u]]), V.ub[idx[u]]); di = t - xi; }
                             vd[idx[u]] = di;
                             q[0] = __builtin_fma(gv[u], di, q[0]);
                             q[1] += isfinite(di) ? 0.0 : 1.0;
+                            if (c.ls_kind == 2) {
+                                const double xi = vx[idx[u]];
+                                double v = INFINITY;
+                                if (di > 0.0) v = (V.lub[idx[u]] - xi) / di; else if (di < 0.0) v = (V.llb[idx[u]] - xi) / di;
+                                lazy_cand = fmin(v, lazy_cand);
+                            }
                         }
                 }
                 ctl_block_sum<2>(q, lds);
+                if (c.ls_kind == 2) lazy_cand = -ctl_block_fmax(-lazy_cand, lds);
             }
             if (tid == 0) {
                 c.n_hpasses++;
@@ -681,7 +727,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                 c.c_ss = c_ss; c.c_su = c_su; c.c_uu = c_uu;
                 c.pending = 1;
                 c.tr_updated = 1;
-                if (lazy) { c.gd0 = q[0]; c.d_finite = q[1] == 0.0; c.have_dir = 1; }
+                if (lazy) { c.gd0 = q[0]; c.d_finite = q[1] == 0.0; c.have_dir = 1; c.mtb_cand = lazy_cand; }
                 c.state = QN_ST_ITER_END;
             }
         } break;

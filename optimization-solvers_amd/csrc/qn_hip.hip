@@ -304,6 +304,18 @@ extern "C" int qn_morethuente_with_c2(qn_linesearch* ls, double c2) { // asserts
     if (!(c2 > ls->c1)) return fail(QN_ERROR_INPUT_PARAMS, "c2 must be greater than c1");
     ls->c2 = c2; return QN_OK;
 }
+extern "C" void qn_morethuente_b_new(qn_linesearch* ls) { // MoreThuenteB::new(n), morethuente_b.rs:18-31
+    qn_morethuente_default(ls);
+    ls->kind = QN_LS_MORETHUENTE_B;
+}
+extern "C" void qn_backtracking_b_new(qn_linesearch* ls, double c1, double beta, const double* lb, const double* ub) { // backtracking_b.rs:10-23
+    memset(ls, 0, sizeof(*ls));
+    ls->kind = QN_LS_BACKTRACKING_B;
+    ls->bt_c1 = c1; ls->bt_beta = beta;
+    ls->lower_bound_host = lb; ls->upper_bound_host = ub;
+}
+extern "C" void qn_linesearch_with_lower_bound(qn_linesearch* ls, const double* lb) { ls->lower_bound_host = lb; }
+extern "C" void qn_linesearch_with_upper_bound(qn_linesearch* ls, const double* ub) { ls->upper_bound_host = ub; }
 extern "C" void qn_backtracking_new(qn_linesearch* ls, double c1, double beta) { // backtracking.rs:8-10
     memset(ls, 0, sizeof(*ls));
     ls->kind = QN_LS_BACKTRACKING;
@@ -550,6 +562,8 @@ struct qn_solver {
     int* newton_fail = nullptr;
     size_t newton_n64 = 0;
     std::vector<double> newton_hhost;
+    double* bounds_block = nullptr; // lb, ub (solver), llb, lub (bounded line search): 4 n_pad vectors
+    int bounded = 0;
     double* fused_block = nullptr; // X0[2], S0[2], G, GT, Y, UN, UP, VV (10 n_pad vectors)
     double *fused_evp = nullptr, *fused_hpp = nullptr;
     int fused_nblk = 0;
@@ -633,7 +647,7 @@ static int solver_alloc_hp(qn_solver* s) {
 
 extern "C" int qn_solver_create(qn_context* ctx, int method, double tol, const double* x0_host, size_t n, qn_solver** out) {
     if (!ctx || !x0_host || !out || n == 0) return fail(QN_ERROR_INPUT_PARAMS, "null argument or n == 0");
-    if (method != QN_BFGS && method != QN_DFP && method != QN_GRADIENT_DESCENT && method != QN_NEWTON)
+    if (method != QN_BFGS && method != QN_DFP && method != QN_GRADIENT_DESCENT && method != QN_NEWTON && method != QN_SR1)
         return fail(QN_ERROR_INPUT_PARAMS, "unknown method");
     if (n > (size_t)1 << 30) return fail(QN_ERROR_INPUT_PARAMS, "n too large");
     HIPCHK(hipSetDevice(ctx->device));
@@ -647,7 +661,7 @@ extern "C" int qn_solver_create(qn_context* ctx, int method, double tol, const d
     s->U = (n >= 16384) ? 2 : 1; // column chunks per loop trip of the fused kernels
     const size_t np = s->T.n_pad;
     hipStream_t st = ctx->stream;
-    if (method == QN_BFGS || method == QN_DFP) {
+    if (method == QN_BFGS || method == QN_DFP || method == QN_SR1) {
         QNCHK(dev_alloc_zero(&s->H, (size_t)s->T.rpr * np, st));
         hipLaunchKernelGGL(identity_fill_kernel, dim3(2048), dim3(256), 0, st, s->H, s->T); // bfgs.rs:27-39: H = I
         HIPCHK(hipGetLastError());
@@ -680,6 +694,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     for (auto& e : s->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
     (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail);
+    (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
@@ -766,6 +781,38 @@ static int peek_ctl(qn_solver* s) { // device -> host mirror
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
     s->stats.host_syncs++;
     return QN_OK;
+}
+
+// box vectors live in one allocation: [lb | ub | llb | lub], padding -inf / +inf so padded entries never move
+static int bounds_alloc(qn_solver* s) {
+    if (s->bounds_block) return QN_OK;
+    const size_t np = s->T.n_pad;
+    HIPCHK(hipMalloc((void**)&s->bounds_block, 4 * np * sizeof(double)));
+    std::vector<double> init(4 * np);
+    for (size_t i = 0; i < np; ++i) { init[i] = -INFINITY; init[np + i] = INFINITY; init[2 * np + i] = -INFINITY; init[3 * np + i] = INFINITY; }
+    HIPCHK(hipMemcpy(s->bounds_block, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice));
+    s->V.lb = s->bounds_block; s->V.ub = s->bounds_block + np; s->V.llb = s->bounds_block + 2 * np; s->V.lub = s->bounds_block + 3 * np;
+    return QN_OK;
+}
+static int bounds_upload(qn_solver* s, double* dst, const double* src_host, double fill) {
+    std::vector<double> v(s->T.n_pad, fill);
+    if (src_host) memcpy(v.data(), src_host, s->n * sizeof(double));
+    HIPCHK(hipMemcpy(dst, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    return QN_OK;
+}
+
+extern "C" int qn_solver_set_bounds(qn_solver* s, const double* lb_host, const double* ub_host) { // BFGSB::new, bfgs_b.rs:43-63
+    if (!s || !lb_host || !ub_host) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
+    if (s->method != QN_BFGS && s->method != QN_DFP && s->method != QN_SR1) return fail(QN_ERROR_INPUT_PARAMS, "bounds need a BFGS / DFP / SR1 solver");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    QNCHK(bounds_alloc(s));
+    QNCHK(bounds_upload(s, s->bounds_block, lb_host, -INFINITY));
+    QNCHK(bounds_upload(s, s->bounds_block + s->T.n_pad, ub_host, INFINITY));
+    std::vector<double> x(s->n);
+    QNCHK(qn_solver_get_x(s, x.data()));
+    for (size_t i = 0; i < s->n; ++i) x[i] = std::fmin(std::fmax(x[i], lb_host[i]), ub_host[i]); // x0.box_projection(&lower, &upper), :49
+    s->bounded = 1;
+    return qn_solver_set_x(s, x.data());
 }
 
 extern "C" int qn_solver_reset(qn_solver* s, const double* x0_host) {
@@ -1046,6 +1093,7 @@ static int enqueue_eval(Run& r, int after_h = 0) {
         QnQuadArgs a{};
         a.Q = r.obj->Q; a.T = s->T; a.T.cs = s->qcs;
         a.x = s->V.x; a.d = s->V.d; a.xt = s->V.xt;
+        a.llb = s->V.llb; a.lub = s->V.lub;
         a.out = s->V.q + (size_t)c->rank * s->qcs * s->T.rpr;
         a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_EVAL;
         {
@@ -1060,7 +1108,7 @@ static int enqueue_eval(Run& r, int after_h = 0) {
         return QN_OK;
     }
     hipLaunchKernelGGL(trial_point_kernel, dim3(std::min(1024, (s->T.n_pad + 255) / 256)), dim3(256), 0, c->stream, s->V.x, s->V.d,
-                       s->V.xt, s->T.n_pad, s->ctl, (int)QN_PH_REQ_EVAL);
+                       s->V.xt, s->T.n_pad, s->ctl, (int)QN_PH_REQ_EVAL, s->V.llb, s->V.lub);
     s->stats.launches++;
     HIPCHK(hipGetLastError());
     if (r.o->kind == QN_ORACLE_HOST) {
@@ -1152,7 +1200,7 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
     return QN_OK;
 }
 
-extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracle* o, size_t max_iter_solver,
+extern "C" int qn_minimize(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, size_t max_iter_solver,
                            size_t max_iter_line_search, qn_callback_fn callback, void* callback_user) {
     if (!s || !ls || !o) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
     qn_context* c = s->ctx;
@@ -1170,7 +1218,15 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
     } else if (o->kind == QN_ORACLE_DEVICE_FN) {
         if (!o->device_fn) return fail(QN_ERROR_INPUT_PARAMS, "device oracle is null");
     } else return fail(QN_ERROR_INPUT_PARAMS, "unknown oracle kind");
-    if (ls->kind != QN_LS_MORETHUENTE && ls->kind != QN_LS_BACKTRACKING) return fail(QN_ERROR_INPUT_PARAMS, "unknown line search");
+    if (ls->kind < QN_LS_MORETHUENTE || ls->kind > QN_LS_BACKTRACKING_B) return fail(QN_ERROR_INPUT_PARAMS, "unknown line search");
+    const bool ls_bounded = ls->kind == QN_LS_MORETHUENTE_B || ls->kind == QN_LS_BACKTRACKING_B;
+    if (ls_bounded || s->bounded) {
+        QNCHK(bounds_alloc(s));
+        if (ls_bounded) {
+            QNCHK(bounds_upload(s, s->bounds_block + 2 * (size_t)s->T.n_pad, ls->lower_bound_host, -INFINITY));
+            QNCHK(bounds_upload(s, s->bounds_block + 3 * (size_t)s->T.n_pad, ls->upper_bound_host, INFINITY));
+        }
+    }
     if (s->method == QN_NEWTON) {
         if (c->world > 1) return fail(QN_ERROR_INPUT_PARAMS, "Newton is single-GPU (SURVEY.md 8(f) row f2)");
         if (!(r.obj && r.obj->kind == OBJ_QUADRATIC) && !(o->kind == QN_ORACLE_HOST && o->host_hessian_fn))
@@ -1191,11 +1247,13 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
     h->bt_c1 = ls->bt_c1; h->bt_beta = ls->bt_beta;
     h->trace_cap = (int64_t)s->trace_cap;
     h->trace_x = s->trace_x;
+    h->bounded = s->bounded;
+    h->req_project = 0; h->last_projected = 0; h->mtb_cand = INFINITY;
     h->small_n = (s->n <= QN_SMALL_N && c->world == 1) ? 1 : 0;
     if (h->small_n && h->pending) QNCHK(flush_pending(s));
     // fused fast path: device quadratic, memoised, BFGS/DFP, no callback, one column split, n > 5
     r.fused = r.oracle_tpl == QN_ORACLE_QUAD && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP) && !callback && s->hcs == 1 &&
-              s->qcs == 1 && !h->small_n && !s->no_fused;
+              s->qcs == 1 && !h->small_n && !s->no_fused && !s->bounded && !ls_bounded; // bounded variants (row f4): generic path
     h->fused = r.fused ? 1 : 0;
     s->V.fused_hint = h->fused;
     h->defer_u = 0;
@@ -1238,7 +1296,7 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
     } else {
         // pipelined: every kernel is predicated on the control block, so a fixed pattern can be enqueued ahead
         // of the decisions; one period = [eval, step] x slots, [h_pass, step], and advances at most one iteration.
-        const int slots = (ls->kind == QN_LS_MORETHUENTE) ? 2 : 4;
+        const int slots = (ls->kind == QN_LS_MORETHUENTE || ls->kind == QN_LS_MORETHUENTE_B) ? 2 : 4;
         const int gd = s->method == QN_GRADIENT_DESCENT;
         for (;;) {
             QNCHK(peek_ctl(s));
@@ -1270,6 +1328,7 @@ extern "C" int qn_minimize(qn_solver* s, const qn_linesearch* ls, const qn_oracl
         }
         HIPCHK(hipStreamSynchronize(c->stream));
     }
+    if (ls->kind == QN_LS_MORETHUENTE_B) ls->t_max = h->mt_tmax; // morethuente_b.rs:201: the clipped t_max stays in the line search
     s->stats.iterations = h->n_iterations;
     s->stats.oracle_calls = h->n_oracle_calls;
     s->stats.oracle_evals = h->n_oracle_evals;

@@ -70,6 +70,8 @@ struct QnVecs {
     unsigned long long* dbg; // diagnostic builds only (QN_CTL_STAMPS): in-kernel time stamps
     QnFused F; // fused fast path buffers (valid when ctl->fused)
     int fused_hint;   // set by the host for runs on the fused path (== ctl->fused)
+    const double *lb, *ub;   // solver bounds (BFGSB / DFPB / SR1B), n_pad entries, padding -inf / +inf
+    const double *llb, *lub; // the bounded line search's own box
     const int* nfail; // Newton: set by the factorisation when the Hessian is not positive definite
     int n, n_pad, rpr, world, hcs, qcs;
 };
@@ -261,6 +263,7 @@ struct QnQuadArgs {
     const double *x, *d;
     double* xt;
     double* out; // this rank's block of the gathered q buffer [qcs][rpr]
+    const double *llb, *lub; // bounded backtracking: the trial point is projected onto the line search's box
     const QnCtl* ctl;
     int expect_phase; // < 0: unconditional with force_kind / force_t
     int force_kind;
@@ -272,10 +275,12 @@ __global__ __launch_bounds__(QN_TPB) void quad_matvec_kernel(const QnQuadArgs a)
     __shared__ double red[4 * R];
     int kind;
     double t;
+    bool project = false;
     if (a.expect_phase >= 0) {
         if (a.ctl->phase != a.expect_phase) return;
         kind = a.ctl->req_kind;
         t = a.ctl->req_t;
+        project = a.ctl->req_project != 0;
     } else {
         kind = a.force_kind;
         t = a.force_t;
@@ -300,6 +305,11 @@ __global__ __launch_bounds__(QN_TPB) void quad_matvec_kernel(const QnQuadArgs a)
                 const double td0 = t * dj.x, td1 = t * dj.y; // `step * direction` rounds first
                 xj.x = xj.x + td0;
                 xj.y = xj.y + td1;
+                if (project) {
+                    const v2d lo = ld2(a.llb + j), hi = ld2(a.lub + j);
+                    xj.x = fmin(fmax(xj.x, lo.x), hi.x);
+                    xj.y = fmin(fmax(xj.y, lo.y), hi.y);
+                }
             }
             if (blockIdx.x == 0) st2(a.xt + j, xj);
             const double* qbase = a.Q + (size_t)rb * (size_t)T.n_pad + j;
@@ -319,15 +329,18 @@ __global__ __launch_bounds__(QN_TPB) void quad_matvec_kernel(const QnQuadArgs a)
 
 // xt = x or x + t*d for oracles that are not fused with the trial point
 __global__ void trial_point_kernel(const double* __restrict__ x, const double* __restrict__ d, double* __restrict__ xt,
-                                   int n_pad, const QnCtl* ctl, int expect_phase) {
+                                   int n_pad, const QnCtl* ctl, int expect_phase, const double* __restrict__ llb,
+                                   const double* __restrict__ lub) {
     if (ctl->phase != expect_phase) return;
     const int kind = ctl->req_kind;
     const double t = ctl->req_t;
+    const bool project = ctl->req_project != 0; // BackTrackingB projects its trial points (backtracking_b.rs:67)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
         double v = x[i];
         if (kind == QN_REQ_T) {
             const double td = t * d[i];
             v = v + td;
+            if (project) v = fmin(fmax(v, llb[i]), lub[i]);
         }
         xt[i] = v;
     }
@@ -459,10 +472,10 @@ __device__ __forceinline__ void tr_push_case(QnCtl& c, int digit) {
 
 // One oracle call of the reference's sequence at x + t d.  With memoisation a call whose point was already
 // evaluated is answered from the memo (the values are identical; see include/qn_hip.h qn_oracle.memoize).
-__device__ __forceinline__ void req_eval_t(QnCtl& c, double t, int after_state, int need_vectors) {
+__device__ __forceinline__ void req_eval_t(QnCtl& c, double t, int after_state, int need_vectors, int project = 0) {
     c.n_oracle_calls++;
     c.tr_n_evals++;
-    if (c.memoize) {
+    if (c.memoize && !project && !c.last_projected) {
         if (!need_vectors && t == 0.0 && c.d_finite) { // x + 0*d == x: phi(0) = (f_k, g_k.d)
             c.f_e = c.f_k; c.gd_e = c.gd0; c.state = after_state;
             return;
@@ -474,6 +487,7 @@ __device__ __forceinline__ void req_eval_t(QnCtl& c, double t, int after_state, 
     }
     c.req_kind = QN_REQ_T;
     c.req_t = t;
+    c.req_project = project;
     c.req_need_vectors = need_vectors;
     c.after_state = after_state;
     c.phase = c.defer_u ? QN_PH_REQ_HPASS_EVAL : QN_PH_REQ_EVAL;
@@ -501,11 +515,16 @@ __device__ __forceinline__ double ref_dot(const double* a, const double* b, int 
 }
 
 // d = -(H g), column sweep (bfgs.rs:47); H is row-major with leading dimension ld
-__device__ __forceinline__ void small_direction(const double* H, int ld, int n, const double* g, double* d, double* y /* LDS, >= 5 */) {
+__device__ __forceinline__ void small_direction(const double* H, int ld, int n, const double* g, double* d, double* y /* LDS, >= 5 */,
+                                                const double* x = nullptr, const double* lb = nullptr, const double* ub = nullptr) {
     for (int i = 0; i < n; ++i) y[i] = H[i * ld] * g[0];
     for (int j = 1; j < n; ++j)
         for (int i = 0; i < n; ++i) y[i] = H[i * ld + j] * g[j] + y[i];
-    for (int i = 0; i < n; ++i) d[i] = -y[i];
+    if (lb) { // bfgs_b.rs:72-75: P(x - H g) - x
+        for (int i = 0; i < n; ++i) { double t = x[i] - y[i]; t = fmin(fmax(t, lb[i]), ub[i]); d[i] = t - x[i]; }
+    } else {
+        for (int i = 0; i < n; ++i) d[i] = -y[i];
+    }
 }
 
 // C = A*B through per-column gemv, all QN_SMALL_N-strided local arrays indexed [i + j*QN_SMALL_N]
@@ -538,6 +557,15 @@ __device__ __forceinline__ void small_update(double* H, int ld, int n, const dou
         small_matmul(m2, m1, m3, n);
         for (int j = 0; j < n; ++j)
             for (int i = 0; i < n; ++i) H[i * ld + j] = m3[i + j * QN_SMALL_N] + (s[i] * s[j]) * rho;
+    } else if (method == 4) { // sr1_b.rs:143-146: hy = H y ; shy = s - hy ; H += shy shy' / shy.dot(y)
+        double* w = scratch + 5 * MM;
+        for (int i = 0; i < n; ++i) w[i] = h[i] * y[0];
+        for (int j = 1; j < n; ++j)
+            for (int i = 0; i < n; ++i) w[i] = h[i + j * QN_SMALL_N] * y[j] + w[i];
+        for (int i = 0; i < n; ++i) w[i] = s[i] - w[i];
+        const double den = ref_dot(w, y, n);
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) H[i * ld + j] = h[i + j * QN_SMALL_N] + (w[i] * w[j]) / den;
     } else {
         const double sy = ref_dot(s, y, n);
         double* u = scratch + 5 * MM;

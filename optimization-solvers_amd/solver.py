@@ -205,6 +205,46 @@ class BackTracking:
         return cls(c1, beta)
 
 
+class MoreThuenteB(MoreThuente):
+    """morethuente_b.rs: More-Thuente whose t_max is clipped to the box (and stays clipped)."""
+
+    def __init__(self, n):
+        self.s = A.LineSearchStruct()
+        A.lib().qn_morethuente_b_new(C.byref(self.s))
+        self.n = n
+        self._lb = self._ub = None
+
+    @classmethod
+    def new(cls, n):
+        return cls(n)
+
+    def with_lower_bound(self, lb):
+        self._lb = _f64(lb)
+        A.lib().qn_linesearch_with_lower_bound(C.byref(self.s), self._lb.ctypes.data)
+        return self
+
+    def with_upper_bound(self, ub):
+        self._ub = _f64(ub)
+        A.lib().qn_linesearch_with_upper_bound(C.byref(self.s), self._ub.ctypes.data)
+        return self
+
+    def t_max(self):
+        return self.s.t_max
+
+
+class BackTrackingB:
+    """backtracking_b.rs: projected trial points, modified Armijo rule."""
+
+    def __init__(self, c1, beta, lower_bound, upper_bound):
+        self.s = A.LineSearchStruct()
+        self._lb, self._ub = _f64(lower_bound), _f64(upper_bound)
+        A.lib().qn_backtracking_b_new(C.byref(self.s), c1, beta, self._lb.ctypes.data, self._ub.ctypes.data)
+
+    @classmethod
+    def new(cls, c1, beta, lower_bound, upper_bound):
+        return cls(c1, beta, lower_bound, upper_bound)
+
+
 class Objective:
     """A device-resident objective owned by the library."""
 
@@ -459,6 +499,43 @@ class GradientDescent(_SolverBase):
     def has_converged(self, eval_x_k):
         g = eval_x_k.g() if isinstance(eval_x_k, FuncEvalMultivariate) else eval_x_k[1]
         return float(np.max(np.abs(g))) < self.tol()
+
+
+class _BoundedBase(_SolverBase):
+    """bfgs_b.rs / dfp_b.rs / sr1_b.rs: `new(tol, x0, lower_bound, upper_bound)`; x0 is projected, directions are P(x - Hg) - x."""
+
+    def __init__(self, tol, x0, lower_bound, upper_bound, ctx=None):
+        super().__init__(tol, x0, ctx)
+        self._lb, self._ub = _f64(lower_bound), _f64(upper_bound)
+        _check(A.lib().qn_solver_set_bounds(self.h, _dp(self._lb), _dp(self._ub)))
+
+    @classmethod
+    def new(cls, tol, x0, lower_bound, upper_bound, ctx=None):
+        return cls(tol, x0, lower_bound, upper_bound, ctx)
+
+    def lower_bound(self):
+        return self._lb
+
+    def upper_bound(self):
+        return self._ub
+
+    def projected_gradient(self, eval_x_k):  # ls_solver.rs:121-133
+        g = np.array(eval_x_k.g() if isinstance(eval_x_k, FuncEvalMultivariate) else eval_x_k[1], dtype=np.float64)
+        x = self.x()
+        g[((x == self._lb) & (g > 0)) | ((x == self._ub) & (g < 0))] = 0.0
+        return g
+
+
+class BFGSB(_BoundedBase):
+    METHOD = A.BFGS
+
+
+class DFPB(_BoundedBase):
+    METHOD = A.DFP
+
+
+class SR1B(_BoundedBase):
+    METHOD = A.SR1
 
 
 class Newton(_SolverBase):

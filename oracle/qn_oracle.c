@@ -335,11 +335,44 @@ static double morethuente_step(const qo_linesearch* ls, const double* x, double 
     return t; /* :295-296 */
 }
 
+/* BackTrackingB::compute_step_len, backtracking_b.rs:52-88 (the trial point is projected; modified Armijo rule :24-34) */
+static double backtracking_b_step(const qo_linesearch* ls, const double* x, double f0, const double* d, size_t n, oracle_t* o,
+                                  size_t max_iter, ls_stats* st, double* xt, double* gt) {
+    double t = 1.0;
+    size_t i = 0;
+    while (max_iter > i) {
+        if (st) st->iters++;
+        qo_axpy_new(x, t, d, xt, n);
+        for (size_t j = 0; j < n; ++j) xt[j] = fmin(fmax(xt[j], ls->lower_bound[j]), ls->upper_bound[j]); /* :67 */
+        double ft;
+        call_oracle(o, xt, n, &ft, gt);
+        if (isnan(ft) || isinf(ft)) { t *= ls->bt_beta; continue; }
+        /* sufficient_decrease_with_bounds: f - f0 <= (-c1 / t) * diff.dot(&diff) */
+        for (size_t j = 0; j < n; ++j) gt[j] = xt[j] - x[j]; /* gt reused as diff */
+        if (ft - f0 <= (-ls->bt_c1 / t) * qo_dot(gt, gt, n)) return t;
+        t *= ls->bt_beta;
+        i += 1;
+    }
+    return t;
+}
+
 static double compute_step_len(const qo_linesearch* ls, const double* x, double f0, const double* g0,
                                const double* d, size_t n, oracle_t* o, size_t max_iter, ls_stats* st,
                                double* work /* 4n */) {
     if (ls->kind == QO_LS_BACKTRACKING)
         return backtracking_step(ls, x, f0, g0, d, n, o, max_iter, st, work, work + n);
+    if (ls->kind == QO_LS_BACKTRACKING_B)
+        return backtracking_b_step(ls, x, f0, d, n, o, max_iter, st, work, work + n);
+    if (ls->kind == QO_LS_MORETHUENTE_B) { /* morethuente_b.rs:185-201: t_max is clipped to the box -- and STAYS clipped (self.t_max) */
+        double cand = INFINITY;
+        for (size_t i = 0; i < n; ++i) {
+            double v = INFINITY;
+            if (d[i] > 0.0) v = (ls->upper_bound[i] - x[i]) / d[i];
+            else if (d[i] < 0.0) v = (ls->lower_bound[i] - x[i]) / d[i];
+            cand = fmin(v, cand); /* fold(INFINITY, |acc, x| x.min(acc)) */
+        }
+        ((qo_linesearch*)ls)->t_max = fmin(ls->t_max, cand);
+    }
     return morethuente_step(ls, x, f0, g0, d, n, o, max_iter, st, work, work + n, work + 2 * n, work + 3 * n);
 }
 
@@ -367,12 +400,24 @@ struct qo_solver {
     /* scratch */
     double *g, *d, *xn, *gn, *s, *y, *u, *work;
     double *m0, *m1, *m2, *m3, *m4; /* n x n temporaries for the as-written update */
+    double *lb, *ub; /* BFGSB / DFPB / SR1B bounds (NULL: unbounded solver) */
     /* Newton (newton/mod.rs:8-13) */
     qo_hessian_fn hess_fn;
     void* hess_user;
     int has_decrement;
     double decrement_squared;
 };
+
+/* BoxProjection::box_projection, number.rs:19: sup(lower).inf(upper) */
+static double box1(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+void qo_solver_set_bounds(qo_solver* s, const double* lb, const double* ub) { /* bfgs_b.rs:43-63 */
+    const size_t n = s->n;
+    if (!s->lb) { s->lb = (double*)malloc(sizeof(double) * (n ? n : 1)); s->ub = (double*)malloc(sizeof(double) * (n ? n : 1)); }
+    memcpy(s->lb, lb, sizeof(double) * n);
+    memcpy(s->ub, ub, sizeof(double) * n);
+    for (size_t i = 0; i < n; ++i) s->x[i] = box1(s->x[i], lb[i], ub[i]); /* :49 x0.box_projection(..) */
+}
 
 void qo_solver_set_hessian_fn(qo_solver* s, qo_hessian_fn fn, void* user) { s->hess_fn = fn; s->hess_user = user; }
 int qo_solver_decrement_squared(const qo_solver* s, double* out) { if (s->has_decrement && out) *out = s->decrement_squared; return s->has_decrement; }
@@ -390,7 +435,7 @@ qo_solver* qo_solver_create(int method, double tol, const double* x0, size_t n, 
     double** vecs[] = {&s->g, &s->d, &s->xn, &s->gn, &s->s, &s->y, &s->u};
     for (size_t i = 0; i < sizeof(vecs) / sizeof(vecs[0]); ++i) *vecs[i] = (double*)calloc(nn, sizeof(double));
     s->work = (double*)calloc(4 * nn, sizeof(double));
-    if (method == QO_BFGS || method == QO_DFP) {
+    if (method == QO_BFGS || method == QO_DFP || method == QO_SR1) {
         /* bfgs.rs:27-39: H = I (the reference also keeps a second identity matrix; not needed here) */
         s->h = (double*)calloc(nn * nn, sizeof(double));
         for (size_t i = 0; i < n; ++i) s->h[i + i * n] = 1.0;
@@ -403,6 +448,7 @@ void qo_solver_destroy(qo_solver* s) {
     free(s->x); free(s->h); free(s->g); free(s->d); free(s->xn); free(s->gn);
     free(s->s); free(s->y); free(s->u); free(s->work);
     free(s->m0); free(s->m1); free(s->m2); free(s->m3); free(s->m4);
+    free(s->lb); free(s->ub);
     free(s);
 }
 
@@ -483,6 +529,17 @@ static void dfp_update_as_written(qo_solver* so, const double* s, const double* 
         }
 }
 
+/* sr1_b.rs:143-146 literally: hy = H y ; shy = s - hy ; H += shy shy' / shy.dot(y) */
+static void sr1_update_as_written(qo_solver* so, const double* s, const double* y) {
+    const size_t n = so->n;
+    double* shy = so->u;
+    gemv_colmajor_mt(so->h, y, shy, n, so->nthreads);
+    for (size_t i = 0; i < n; ++i) shy[i] = s[i] - shy[i];
+    const double den = qo_dot(shy, y, n);
+    for (size_t j = 0; j < n; ++j)
+        for (size_t i = 0; i < n; ++i) so->h[i + j * n] += (shy[i] * shy[j]) / den;
+}
+
 /* The algebraically identical symmetric rank-2 form:
  *   BFGS: H + c_su (s u' + u s') + c_ss s s',  u = H y, c_su = -rho, c_ss = rho^2 (y.u) + rho
  *   DFP : H + c_ss s s' + c_uu u u',           c_ss = 1/(s.y), c_uu = -1/(y.u)
@@ -500,6 +557,11 @@ static void rank2_update(qo_solver* so, const double* s, const double* y) {
         c_su = -rho;
         c_ss = rho * rho * yu + rho;
         c_uu = 0.0;
+    } else if (so->method == QO_SR1) { /* (s-u)(s-u)'/((s-u).y) = c (s s' - (s u' + u s') + u u') */
+        double den = 0.0;
+        for (size_t i = 0; i < n; ++i) den += (s[i] - u[i]) * y[i];
+        c_ss = 1.0 / den; c_su = -c_ss; c_uu = c_ss;
+        (void)ys; (void)yu;
     } else {
         c_ss = 1.0 / ys;
         c_su = 0.0;
@@ -515,6 +577,13 @@ static void rank2_update(qo_solver* so, const double* s, const double* y) {
                 double t1 = s[i] * uj + u[i] * sj;
                 double hn = hj[i] + c_su * t1;
                 hj[i] = hn + c_ss * (s[i] * sj);
+            }
+        } else if (so->method == QO_SR1) {
+            for (size_t i = 0; i < n; ++i) {
+                double t1 = s[i] * uj + u[i] * sj;
+                double hn = hj[i] + c_su * t1;
+                hn = hn + c_ss * (s[i] * sj);
+                hj[i] = hn + c_uu * (u[i] * uj);
             }
         } else {
             for (size_t i = 0; i < n; ++i) {
@@ -615,7 +684,15 @@ int qo_minimize(qo_solver* so, const qo_linesearch* ls, qo_oracle_fn oracle, voi
         } else {
             /* bfgs.rs:47: (-&H) * g.  Negating every H_ij first gives bit-for-bit -(H g). */
             gemv_colmajor_mt(so->h, so->g, so->d, n, so->nthreads);
-            for (size_t i = 0; i < n; ++i) so->d[i] = -so->d[i];
+            if (so->lb) { /* bfgs_b.rs:72-75: P(x - H g) - x */
+                for (size_t i = 0; i < n; ++i) {
+                    double t = so->x[i] - so->d[i];
+                    t = box1(t, so->lb[i], so->ub[i]);
+                    so->d[i] = t - so->x[i];
+                }
+            } else {
+                for (size_t i = 0; i < n; ++i) so->d[i] = -so->d[i];
+            }
         }
 
         ls_stats st = {0, 0, 0};
@@ -635,6 +712,7 @@ int qo_minimize(qo_solver* so, const qo_linesearch* ls, qo_oracle_fn oracle, voi
             memcpy(so->x, so->xn, sizeof(double) * n);                      /* :102 */
             if (!(so->s_norm < so->tol) && !(so->y_norm < so->tol)) {       /* :106-112 */
                 if (so->update_mode == QO_UPDATE_RANK2) rank2_update(so, so->s, so->y);
+                else if (so->method == QO_SR1) sr1_update_as_written(so, so->s, so->y);
                 else if (so->method == QO_BFGS) bfgs_update_as_written(so, so->s, so->y);
                 else dfp_update_as_written(so, so->s, so->y);
                 updated = 1;

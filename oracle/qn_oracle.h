@@ -32,7 +32,8 @@ enum {
 };
 
 /* solver families on the path (src/quasi_newton/bfgs.rs, dfp.rs, src/steepest_descent/gradient_descent.rs) */
-enum { QO_BFGS = 0, QO_DFP = 1, QO_GRADIENT_DESCENT = 2, QO_NEWTON = 3 /* src/newton/mod.rs */ };
+enum { QO_BFGS = 0, QO_DFP = 1, QO_GRADIENT_DESCENT = 2, QO_NEWTON = 3 /* src/newton/mod.rs */,
+       QO_SR1 = 4 /* src/quasi_newton/sr1_b.rs (with bounds: SR1B) */ };
 
 /* how the inverse-Hessian update is evaluated */
 enum {
@@ -40,7 +41,8 @@ enum {
     QO_UPDATE_RANK2 = 1       /* algebraically identical symmetric rank-2 form, O(n^2) (what the GPU path computes) */
 };
 
-enum { QO_LS_MORETHUENTE = 0, QO_LS_BACKTRACKING = 1 };
+enum { QO_LS_MORETHUENTE = 0, QO_LS_BACKTRACKING = 1,
+       QO_LS_MORETHUENTE_B = 2 /* morethuente_b.rs */, QO_LS_BACKTRACKING_B = 3 /* backtracking_b.rs */ };
 
 /* MoreThuente, src/line_search/morethuente.rs:6-28 ; BackTracking, src/line_search/backtracking.rs:3-11 */
 typedef struct {
@@ -49,6 +51,8 @@ typedef struct {
     double c1, c2, t_min, t_max, delta_min, delta, delta_max;
     /* Backtracking */
     double bt_c1, bt_beta;
+    /* the *_B variants: box bounds held by the line search itself (morethuente_b.rs:14-15, backtracking_b.rs:7-8) */
+    const double *lower_bound, *upper_bound;
 } qo_linesearch;
 
 void qo_morethuente_default(qo_linesearch* ls);                 /* morethuente.rs:16-28 */
@@ -92,6 +96,9 @@ typedef struct {
 /* BFGS::new / DFP::new / GradientDescent::new (bfgs.rs:27-39, dfp.rs, gradient_descent.rs:14-21) */
 qo_solver* qo_solver_create(int method, double tol, const double* x0, size_t n, int update_mode, int nthreads);
 void qo_solver_destroy(qo_solver* s);
+/* BFGSB / DFPB / SR1B (bfgs_b.rs:43-63): box bounds; the current x is projected onto them, directions become
+ * P(x - H g) - x (bfgs_b.rs:66-77) */
+void qo_solver_set_bounds(qo_solver* s, const double* lower_bound, const double* upper_bound);
 
 /* LineSearchSolver::minimize (ls_solver.rs:66-111) */
 int qo_minimize(qo_solver* s, const qo_linesearch* ls, qo_oracle_fn oracle, void* oracle_user,

@@ -14,9 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libqn_oracle.so")
 
 OK, MAX_ITER_REACHED, OUT_OF_DOMAIN, ERROR_INPUT_PARAMS, ABNORMAL_TERMINATION = range(5)
-BFGS, DFP, GRADIENT_DESCENT, NEWTON = 0, 1, 2, 3
+BFGS, DFP, GRADIENT_DESCENT, NEWTON, SR1 = 0, 1, 2, 3, 4
 UPDATE_AS_WRITTEN, UPDATE_RANK2 = 0, 1
-LS_MORETHUENTE, LS_BACKTRACKING = 0, 1
+LS_MORETHUENTE, LS_BACKTRACKING, LS_MORETHUENTE_B, LS_BACKTRACKING_B = 0, 1, 2, 3
 
 
 def build(force=False):
@@ -34,7 +34,8 @@ class LineSearch(C.Structure):
     _fields_ = [("kind", C.c_int),
                 ("c1", C.c_double), ("c2", C.c_double), ("t_min", C.c_double), ("t_max", C.c_double),
                 ("delta_min", C.c_double), ("delta", C.c_double), ("delta_max", C.c_double),
-                ("bt_c1", C.c_double), ("bt_beta", C.c_double)]
+                ("bt_c1", C.c_double), ("bt_beta", C.c_double),
+                ("lower_bound", C.c_void_p), ("upper_bound", C.c_void_p)]
 
 
 class TraceRec(C.Structure):
@@ -92,6 +93,7 @@ def lib():
     L.qo_solver_y_norm.restype = C.c_int
     L.qo_solver_y_norm.argtypes = [C.c_void_p, dp]
     L.qo_solver_set_inv_hessian.argtypes = [C.c_void_p, dp]
+    L.qo_solver_set_bounds.argtypes = [C.c_void_p, dp, dp]
     L.qo_solver_set_hessian_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.qo_solver_decrement_squared.restype = C.c_int
     L.qo_solver_decrement_squared.argtypes = [C.c_void_p, dp]
@@ -136,6 +138,27 @@ def backtracking(c1, beta):
     ls = LineSearch()
     lib().qo_backtracking_new(C.byref(ls), c1, beta)
     return ls
+
+
+def _with_bounds(ls, n, lb, ub):
+    ls._lb = _f64(np.full(n, -np.inf) if lb is None else lb)
+    ls._ub = _f64(np.full(n, np.inf) if ub is None else ub)
+    ls.lower_bound, ls.upper_bound = ls._lb.ctypes.data, ls._ub.ctypes.data
+    return ls
+
+
+def morethuente_b(n, lb=None, ub=None, **kw):
+    """MoreThuenteB::new(n).with_lower_bound(..).with_upper_bound(..) (morethuente_b.rs:18-39)"""
+    ls = morethuente(**kw)
+    ls.kind = LS_MORETHUENTE_B
+    return _with_bounds(ls, n, lb, ub)
+
+
+def backtracking_b(c1, beta, lb, ub):
+    """BackTrackingB::new(c1, beta, lower, upper) (backtracking_b.rs:10-23)"""
+    ls = backtracking(c1, beta)
+    ls.kind = LS_BACKTRACKING_B
+    return _with_bounds(ls, len(lb), lb, ub)
 
 
 def dot(a, b):
@@ -283,6 +306,11 @@ class Solver:
             self.trace_x = xs[:tr.len].copy() if trace_x else None
             self.n_oracle_calls = tr.n_oracle_calls
         return status
+
+    def set_bounds(self, lb, ub):
+        """BFGSB / DFPB / SR1B::new(tol, x0, lower, upper): projects x and makes the directions P(x - Hg) - x."""
+        lb, ub = _f64(lb), _f64(ub)
+        lib().qo_solver_set_bounds(self.h, _dp(lb), _dp(ub))
 
     def set_hessian(self, fn_or_quadratic):
         """Newton: where the Hessian part of the FuncEval comes from (a Python x -> H closure, or a QuadraticOracle)."""

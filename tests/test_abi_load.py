@@ -52,7 +52,7 @@ def test_line_search_structs_and_builder_asserts(qn):
 
 def test_struct_sizes_match_header(qn):
     A = qn._abi
-    assert C.sizeof(A.LineSearchStruct) == 8 + 9 * 8
+    assert C.sizeof(A.LineSearchStruct) == 8 + 9 * 8 + 2 * 8
     assert C.sizeof(A.TraceRec) == 5 * 8 + 4 * 4
     assert C.sizeof(A.OracleStruct) == 8 + 6 * 8
     assert C.sizeof(A.Stats) == 16 * 8
@@ -106,5 +106,5 @@ def test_rust_shim_in_integration_md_matches_the_header():
         body = re.sub(r"//.*", "", body)
         return len(re.findall(r"\bpub\s+\w+\s*:", body))
 
-    assert c_fields("qn_linesearch") == rust_fields("QnLineSearch") == 11
+    assert c_fields("qn_linesearch") == rust_fields("QnLineSearch") == 13
     assert c_fields("qn_oracle") == rust_fields("QnOracle") == 8

@@ -1,0 +1,119 @@
+"""GPU tests of row f4: the bounded quasi-Newton solvers BFGSB / DFPB / SR1B (bfgs_b.rs, dfp_b.rs, sr1_b.rs)
+and the bounded line searches MoreThuenteB / BackTrackingB, against the oracle's restatement."""
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+INF = float("inf")
+
+
+def _box(qo, n, kappa=50.0):
+    q, b, x0, _ = P.synth_problem(qo, n, kappa)
+    xs = np.linalg.solve(q, b)
+    lb = xs - 0.3 * np.abs(xs) - 0.05
+    ub = xs + 0.1
+    k = max(1, n // 4)
+    lb[:k] = xs[:k] + 0.2  # these bounds are active at the constrained optimum
+    ub[:k] = xs[:k] + 1.0
+    return q, b, x0, lb, ub
+
+
+def _make_ls(mod, name, n, lb, ub):
+    oracle = not hasattr(mod, "MoreThuenteB")
+    if name == "mt":
+        return mod.morethuente() if oracle else mod.MoreThuente()
+    if name == "mtb":
+        return mod.morethuente_b(n, lb, ub) if oracle else mod.MoreThuenteB.new(n).with_lower_bound(lb).with_upper_bound(ub)
+    return mod.backtracking_b(1e-4, 0.5, lb, ub) if oracle else mod.BackTrackingB.new(1e-4, 0.5, lb, ub)
+
+
+def test_bfgs_b_rs_unit_test(qn, qo):
+    """bfgs_b.rs:160-212 constrained_grad_desc_backtracking: gamma = 999, infinite bounds, BackTrackingB, caps 10000/1000."""
+    gamma = 999.0
+    fn = lambda x: (0.5 * (x[0] ** 2 + gamma * x[1] ** 2), np.array([x[0], gamma * x[1]]))  # noqa: E731
+    lower, upper = [-INF, -INF], [INF, INF]
+    ls = qn.BackTrackingB.new(1e-4, 0.5, lower, upper)
+    gd = qn.BFGSB.new(1e-12, [180.0, 152.0], lower, upper)
+    gd.minimize(ls, fn, 10000, 1000, None)  # .unwrap()
+    ev = qn.FuncEvalMultivariate(*fn(gd.xk()))
+    assert gd.has_converged(ev)
+    assert np.max(np.abs(gd.projected_gradient(ev))) < 1e-6
+    ref = qo.Solver(qo.BFGS, 1e-12, [180.0, 152.0])
+    ref.set_bounds(lower, upper)
+    assert ref.minimize(qo.backtracking_b(1e-4, 0.5, lower, upper), qo.PyOracle(fn), 10000, 1000) == qo.OK
+    assert gd.k() == ref.k and np.array_equal(gd.xk(), ref.x)  # n = 2: reference order, bit for bit
+
+
+@pytest.mark.parametrize("method", ["bfgsb", "dfpb", "sr1b"])
+@pytest.mark.parametrize("lsname", ["mt", "mtb", "btb"])
+@pytest.mark.parametrize("n", [3, 40, 300])
+def test_bounded_solvers_vs_oracle(qn, qo, method, lsname, n):
+    q, b, x0, lb, ub = _box(qo, n)
+    iters = 40
+    ref = qo.Solver({"bfgsb": qo.BFGS, "dfpb": qo.DFP, "sr1b": qo.SR1}[method], 1e-9, x0)
+    ref.set_bounds(lb, ub)
+    ls_ref = _make_ls(qo, lsname, n, lb, ub)
+    st_ref = ref.minimize(ls_ref, qo.QuadraticOracle(q, b), iters, 30, trace_cap=iters, trace_x=True)
+    cls = {"bfgsb": qn.BFGSB, "dfpb": qn.DFPB, "sr1b": qn.SR1B}[method]
+    if n <= 5:  # reference-order path + host closure: every bit must agree with the restatement
+        fn = lambda x: qo.QuadraticOracle(q, b)(x)  # noqa: E731
+        s = cls.new(1e-9, x0, lb, ub)
+        s.set_trace(iters, with_x=True)
+        try:
+            s.minimize(_make_ls(qn, lsname, n, lb, ub), fn, iters, 30)
+        except qn.MaxIterReached:
+            pass
+        tr, xs = s.trace()
+        assert len(tr) == len(ref.trace)
+        assert [r["n_evals"] for r in tr] == [r["n_evals"] for r in ref.trace]
+        assert np.array_equal(xs, ref.trace_x)
+        return
+    for memo in (1, 0):
+        s = cls.new(1e-9, x0, lb, ub)
+        s.memoize = memo
+        s.set_trace(iters, with_x=True)
+        ls = _make_ls(qn, lsname, n, lb, ub)
+        st = 0
+        try:
+            s.minimize(ls, qn.Quadratic(q, b), iters, 30)
+        except qn.MaxIterReached:
+            st = 1
+        tr, xs = s.trace()
+        x = s.x()
+        assert np.all(x >= lb - 1e-12) and np.all(x <= ub + 1e-12)  # projected directions keep every iterate feasible (to rounding)
+        w = min(len(tr), len(ref.trace), 12)
+        assert w >= min(3, len(ref.trace))
+        for k in range(w):
+            assert tr[k]["n_evals"] == ref.trace[k]["n_evals"], (k, memo)
+            assert abs(tr[k]["t"] - ref.trace[k]["t"]) <= 1e-8 * abs(ref.trace[k]["t"]), (k, memo)
+            assert np.linalg.norm(xs[k] - ref.trace_x[k]) <= 1e-8 * max(1.0, np.linalg.norm(ref.trace_x[k])), (k, memo)
+        if len(tr) == len(ref.trace) and w == len(tr):
+            assert st == st_ref
+        if lsname == "mtb":  # morethuente_b.rs:201: the clipped t_max is kept by the line search object
+            assert ls.t_max() <= 1e300 and abs(ls.t_max() - ls_ref.t_max) <= 1e-8 * max(1.0, abs(ls_ref.t_max))
+
+
+@pytest.mark.parametrize("method", ["bfgsb", "dfpb", "sr1b"])
+def test_bounded_run_to_termination_matches_oracle(qn, qo, method):
+    """Full runs (the reference stops on ||s|| / ||y|| < tol, not on optimality): same exit, same point, same active set."""
+    n = 64
+    q, b, x0, lb, ub = _box(qo, n)
+    ref = qo.Solver({"bfgsb": qo.BFGS, "dfpb": qo.DFP, "sr1b": qo.SR1}[method], 1e-9, x0)
+    ref.set_bounds(lb, ub)
+    oq = qo.QuadraticOracle(q, b)
+    st_ref = ref.minimize(qo.morethuente(), oq, 300, 30)
+    s = {"bfgsb": qn.BFGSB, "dfpb": qn.DFPB, "sr1b": qn.SR1B}[method].new(1e-9, x0, lb, ub)
+    st = 0
+    try:
+        s.minimize(qn.MoreThuente(), qn.Quadratic(q, b), 300, 30)
+    except qn.MaxIterReached:
+        st = 1
+    x = s.x()
+    assert st == st_ref and abs(s.k() - ref.k) <= 2
+    assert np.all(x >= lb - 1e-12) and np.all(x <= ub + 1e-12)
+    assert abs(oq(x)[0] - oq(ref.x)[0]) <= 1e-6 * max(1.0, abs(oq(ref.x)[0]))
+    active = np.isclose(x, lb) | np.isclose(x, ub)
+    active_ref = np.isclose(ref.x, lb) | np.isclose(ref.x, ub)
+    assert active.sum() >= n // 4 and np.array_equal(active, active_ref)
