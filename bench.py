@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--ls", default="mt", choices=["mt", "bt"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--no-scaling-ref", action="store_true",
+                    help="N > 1: skip the single-GPU run of the same workload on rank 0 (strong-scaling denominator)")
     ap.add_argument("--tiling", default=None, help="rows_per_block,col_splits")
     ap.add_argument("--sync-mode", type=int, default=None)
     args = ap.parse_args()
@@ -125,13 +127,31 @@ def main():
     warmup = args.warmup
 
     ctx = None
+    rccl_error = None
     host_exchange = os.environ.get("QN_BENCH_EXCHANGE", "rccl") == "host"  # harness rehearsal on a 1-GPU box only
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane: gloo (unique-id broadcast, barriers, max over ranks); data plane: RCCL inside libqn_hip.so
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         ndev = torch.cuda.device_count()
-        ctx = qn.dist.sharded_context(local_rank % max(ndev, 1), host_exchange=host_exchange)
+        dev = local_rank % max(ndev, 1)
+        err = None
+        try:
+            ctx = qn.dist.sharded_context(dev, host_exchange=host_exchange)
+            ctx.comm_check()  # one verified all-gather before any solver state depends on the communicator
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        okf = torch.tensor([0 if err else 1], dtype=torch.int32)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) == 0:
+            if host_exchange:
+                sys.exit(f"rank {rank}: host-staged exchange failed: {err}")
+            # RCCL could not be brought up on some rank: keep the run alive on the host-staged exchange and SAY SO in the line
+            print(f"[bench rank {rank}] RCCL exchange unavailable ({err}); falling back to host-staged gloo exchange", file=sys.stderr)
+            rccl_error = err or "failed on another rank"
+            host_exchange = True
+            ctx = qn.dist.sharded_context(dev, host_exchange=True)
+            ctx.comm_check()
     else:
         ctx = qn.Context(device=local_rank)
 
@@ -220,9 +240,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BFGS + MoreThuente::default (max_iter_line_search 20), n={n} convex quadratic "
                                    f"(random SPD Q, kappa=1e3, seed 0x5EED0001), f64, {world}xMI355X"
-                                   + (", H and Q row-sharded, RCCL all-gather per pass" if world > 1 else ""),
+                                   + ((", H and Q row-sharded, " + ("host-staged" if host_exchange else "RCCL") + " all-gather per pass") if world > 1 else ""),
                        "n": n, "line_search": args.ls, "tol": 1e-10, "parallelism": f"row-shard x{world}",
-                       "exchange": "none" if world == 1 else ("host-staged gloo (rehearsal)" if host_exchange else "rccl all-gather")},
+                       "exchange": "none" if world == 1 else ("host-staged gloo (rehearsal)" if host_exchange else "rccl all-gather"),
+                       **({"rccl_error": rccl_error} if rccl_error else {})},
             "iteration_accounting": {"oracle_calls_reference_sequence": calls, "oracle_evaluations_distinct": evals,
                                      "restarts_after_convergence": restarts,
                                      "algorithmic_bytes_per_iteration": b_iter,
@@ -233,6 +254,25 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, 30 if n <= 4096 else 4)
+        if world > 1 and not args.no_scaling_ref:
+            # strong-scaling denominator: the SAME workload unsharded on rank 0's GPU alone (N = 1 of the default run
+            # is configs[1], a different problem size, so value(N)/value(1) across default runs is not an efficiency)
+            try:
+                ctx1 = qn.Context(device=local_rank % max(torch.cuda.device_count(), 1))
+                obj1 = qn.Quadratic.synthetic(n, SEED, diag, b, ctx=ctx1)
+                s1 = qn.BFGS(1e-10, x0, ctx=ctx1)
+                ref_steps = min(steps, 50)
+                run_iterations(qn, s1, ls, obj1, x0, min(warmup, 5))
+                ctx1.synchronize()
+                t1 = time.perf_counter()
+                run_iterations(qn, s1, ls, obj1, x0, ref_steps)
+                ctx1.synchronize()
+                dt1 = time.perf_counter() - t1
+                out["strong_scaling_ref"] = {"n_gpus": 1, "value": ref_steps / dt1, "unit": "iterations/s", "steps": ref_steps,
+                                             "note": f"same n={n} workload, unsharded, on rank 0's GPU after the timed region"}
+                del s1, obj1, ctx1
+            except Exception as e:  # noqa: BLE001 -- the reference leg must never lose the bench line
+                out["strong_scaling_ref"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

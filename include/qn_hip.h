@@ -68,6 +68,8 @@ int qn_partition(size_t n, int world, size_t* rows_per_rank, size_t* n_pad);
 /* diagnostics: create a 1-rank RCCL communicator on this context's GPU, all-gather a small buffer in place on the
  * context's stream and verify it (checks that librccl loads and that the calling convention matches) */
 int qn_comm_selftest(qn_context* ctx);
+/* collective (every rank calls it): one rank-tagged all-gather through the context's own exchange, verified on every rank */
+int qn_context_comm_check(qn_context* ctx);
 int qn_context_synchronize(qn_context* ctx);
 int qn_context_rank(const qn_context* ctx);
 int qn_context_world(const qn_context* ctx);

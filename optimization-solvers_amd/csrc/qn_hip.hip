@@ -273,6 +273,34 @@ extern "C" int qn_comm_selftest(qn_context* c) {
     return QN_OK;
 }
 
+// Cross-rank check of the context's own exchange (RCCL communicator or host callback): every rank contributes a
+// rank-tagged slice to one in-place all-gather and verifies all of them.  Collective: call on every rank.
+extern "C" int qn_context_comm_check(qn_context* c) {
+    if (!c) return fail(QN_ERROR_INPUT_PARAMS, "context is null");
+    if (c->world == 1) return QN_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t count = 4096, total = count * (size_t)c->world;
+    double* buf = nullptr;
+    HIPCHK(hipMalloc((void**)&buf, total * sizeof(double)));
+    std::vector<double> h(total, -1.0);
+    for (size_t i = 0; i < count; ++i) h[(size_t)c->rank * count + i] = 1000.0 * (double)c->rank + 0.25 * (double)i;
+    HIPCHK(hipMemcpyAsync(buf, h.data(), total * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int st = exchange(c, buf, count);
+    if (st == QN_OK) {
+        hipError_t e = hipMemcpyAsync(h.data(), buf, total * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, std::string("comm check: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(buf);
+    if (st != QN_OK) return st;
+    for (int r = 0; r < c->world; ++r)
+        for (size_t i = 0; i < count; ++i)
+            if (h[(size_t)r * count + i] != 1000.0 * (double)r + 0.25 * (double)i)
+                return fail(QN_ABNORMAL_TERMINATION, "comm check: all-gather returned wrong data");
+    return QN_OK;
+}
+
 static int dev_alloc_zero(double** p, size_t count, hipStream_t st) {
     HIPCHK(hipMalloc((void**)p, count * sizeof(double)));
     HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(double), st));

@@ -19,8 +19,15 @@ def sharded_context(device, group=None, host_exchange=False):
         return Context(device)
     if host_exchange:
         return Context(device, rank=rank, world=world, host_allgather=gloo_allgather(group))
-    ids = [Context.unique_id() if rank == 0 else None]
+    ids = [None]
+    if rank == 0:
+        try:
+            ids = [Context.unique_id()]
+        except Exception as e:  # noqa: BLE001 -- tell the other ranks instead of leaving them in the broadcast
+            ids = [e]
     dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if isinstance(ids[0], Exception):
+        raise ids[0]
     return Context(device, rank=rank, world=world, unique_id=ids[0])
 
 

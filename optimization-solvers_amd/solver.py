@@ -132,6 +132,10 @@ class Context:
     def comm_selftest(self):
         _check(A.lib().qn_comm_selftest(self.h))
 
+    def comm_check(self):
+        """Collective: one verified rank-tagged all-gather through this context's exchange (RCCL or host-staged)."""
+        _check(A.lib().qn_context_comm_check(self.h))
+
     def close(self):
         if self.h:
             A.lib().qn_context_destroy(self.h)

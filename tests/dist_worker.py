@@ -70,6 +70,7 @@ def main():
         diag = P.synth_diag(n)
         b, x0 = P.synth_vectors(n)
         ctx = qn.dist.sharded_context(0, host_exchange=True)
+        ctx.comm_check()  # one verified rank-tagged all-gather through the context's exchange
         obj = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx)
         s = qn.BFGS(1e-10, x0, ctx=ctx)
         s.set_trace(iters, with_x=True)
