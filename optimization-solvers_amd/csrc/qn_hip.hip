@@ -586,7 +586,7 @@ struct qn_solver {
     QnVecs V{};
     double* f_dev = nullptr;
     // Newton: Hessian work matrix (row-major, ld = nw), right-hand sides, staging for host Hessians, failure flag
-    double *newton_w = nullptr, *newton_x = nullptr, *newton_hsrc = nullptr;
+    double *newton_w = nullptr, *newton_x = nullptr, *newton_hsrc = nullptr, *newton_invl = nullptr;
     int* newton_fail = nullptr;
     size_t newton_n64 = 0;
     std::vector<double> newton_hhost;
@@ -721,7 +721,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     for (auto& e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
-    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail);
+    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
@@ -996,24 +996,27 @@ static int newton_alloc(qn_solver* s) {
     hipStream_t st = s->ctx->stream;
     QNCHK(dev_alloc_zero(&s->newton_w, n64 * n64, st));
     QNCHK(dev_alloc_zero(&s->newton_x, 2 * n64, st));
+    QNCHK(dev_alloc_zero(&s->newton_invl, (n64 / QN_NB) * QN_NB * QN_NB, st));
     HIPCHK(hipMalloc((void**)&s->newton_fail, sizeof(int)));
     HIPCHK(hipMemsetAsync(s->newton_fail, 0, sizeof(int), st));
     s->V.nfail = s->newton_fail;
     return QN_OK;
 }
 
-static int newton_tri_solve(qn_solver* s, double* x) { // x <- (L L')^-1 x
+static int newton_tri_solve(qn_solver* s, double* x, double* tmp) { // x <- (L L')^-1 x ; tmp: n64 scratch
     hipStream_t st = s->ctx->stream;
     const int n64 = (int)s->newton_n64;
     const size_t ld = s->newton_n64;
-    for (int k0 = 0; k0 < n64; k0 += QN_NB) {
-        hipLaunchKernelGGL(tri_fwd_diag_kernel, dim3(1), dim3(64), 0, st, s->newton_w, ld, k0, x);
+    for (int k0 = 0; k0 < n64; k0 += QN_NB) { // L y = x : rhs x (consumed), solution tmp
         const int below = n64 - k0 - QN_NB;
-        if (below > 0) hipLaunchKernelGGL(tri_fwd_update_kernel, dim3(std::min(1024, (below + 3) / 4)), dim3(256), 0, st, s->newton_w, ld, k0, n64, x);
+        const int grid = std::max(1, std::min(256, (below + 3) / 4));
+        hipLaunchKernelGGL(tri_fwd_step_kernel, dim3(grid), dim3(256), 0, st, s->newton_w, ld, k0, n64,
+                           s->newton_invl + (size_t)(k0 / QN_NB) * QN_NB * QN_NB, x, tmp);
     }
-    for (int k0 = n64 - QN_NB; k0 >= 0; k0 -= QN_NB) {
-        hipLaunchKernelGGL(tri_bwd_diag_kernel, dim3(1), dim3(64), 0, st, s->newton_w, ld, k0, x);
-        if (k0 > 0) hipLaunchKernelGGL(tri_bwd_update_kernel, dim3(std::min(1024, (k0 + 255) / 256)), dim3(256), 0, st, s->newton_w, ld, k0, x);
+    for (int k0 = n64 - QN_NB; k0 >= 0; k0 -= QN_NB) { // L' z = y : rhs tmp (consumed), solution x
+        const int grid = std::max(1, std::min(256, (k0 + 255) / 256));
+        hipLaunchKernelGGL(tri_bwd_step_kernel, dim3(grid), dim3(256), 0, st, s->newton_w, ld, k0,
+                           s->newton_invl + (size_t)(k0 / QN_NB) * QN_NB * QN_NB, tmp, x);
     }
     HIPCHK(hipGetLastError());
     return QN_OK;
@@ -1204,12 +1207,25 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
         return QN_OK;
     }
     hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, s->newton_w, ld, n, n64, hsrc, ld_src);
-    for (int k0 = 0; k0 < n64; k0 += QN_NB) { // blocked right-looking Cholesky, lower triangle in place
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, s->newton_w, ld, k0, s->newton_fail);
-        const int nt = (n64 - k0 - QN_NB) / QN_NB;
+    // blocked right-looking Cholesky, lower triangle in place.  Outer blocks of 256 columns: each 64-column panel is
+    // factorised and applied to the REST OF ITS OUTER BLOCK only; the trailing matrix then takes one depth-256 update.
+    const int KB = 4 * QN_NB;
+    for (int K0 = 0; K0 < n64; K0 += KB) {
+        const int Kend = std::min(K0 + KB, n64);
+        for (int k0 = K0; k0 < Kend; k0 += QN_NB) {
+            double* invl = s->newton_invl + (size_t)(k0 / QN_NB) * QN_NB * QN_NB;
+            hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(256), 0, st, s->newton_w, ld, k0, invl, s->newton_fail);
+            const int nrt = (n64 - k0 - QN_NB) / QN_NB; // row tiles below the diagonal block
+            if (nrt > 0) hipLaunchKernelGGL(chol_panel_kernel, dim3(nrt), dim3(256), 0, st, s->newton_w, ld, k0, invl, s->newton_fail);
+            const int nct = (Kend - k0 - QN_NB) / QN_NB; // column tiles left in this outer block
+            if (nrt > 0 && nct > 0)
+                hipLaunchKernelGGL(chol_syrk_kernel, dim3(nct, nrt), dim3(256), 0, st, s->newton_w, ld, k0, QN_NB, k0 + QN_NB, s->newton_fail);
+            s->stats.launches += 3;
+        }
+        const int nt = (n64 - Kend) / QN_NB;
         if (nt > 0) {
-            hipLaunchKernelGGL(chol_trsm_kernel, dim3(nt), dim3(64), 0, st, s->newton_w, ld, k0, n64, s->newton_fail);
-            hipLaunchKernelGGL(chol_syrk_kernel, dim3(nt, nt), dim3(256), 0, st, s->newton_w, ld, k0, s->newton_fail);
+            hipLaunchKernelGGL(chol_syrk_kernel, dim3(nt, nt), dim3(256), 0, st, s->newton_w, ld, K0, Kend - K0, Kend, s->newton_fail);
+            s->stats.launches++;
         }
     }
     HIPCHK(hipGetLastError());
@@ -1218,13 +1234,12 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
     double* x2 = s->newton_x + n64;
     const dim3 vg(std::min(1024, (n64 + 255) / 256)), vb(256);
     hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, x1, s->V.g, n, n64, -1.0);
-    QNCHK(newton_tri_solve(s, x1));
+    QNCHK(newton_tri_solve(s, x1, x2));
     hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.d, x1, n, s->T.n_pad, 1.0);
-    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, x2, x1, n, n64, 1.0);
-    QNCHK(newton_tri_solve(s, x2));
-    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.s, x2, n, s->T.n_pad, 1.0);
+    QNCHK(newton_tri_solve(s, x1, x2)); // the first solve's result is the second's right-hand side
+    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.s, x1, n, s->T.n_pad, 1.0);
     HIPCHK(hipGetLastError());
-    s->stats.launches += 6 + 3 * (uint64_t)(n64 / QN_NB) + 8 * (uint64_t)(n64 / QN_NB);
+    s->stats.launches += 4 + 4 * (uint64_t)(n64 / QN_NB);
     return QN_OK;
 }
 

@@ -3,11 +3,13 @@
 // The reference inverts the Hessian (`try_inverse`, LU) and multiplies: d = -H^-1 g, decrement^2 = (H^-1 d).d.
 // Here the (symmetric positive definite) Hessian is factorised once per iteration, H = L L', by a blocked
 // right-looking Cholesky in f64 and both quantities come from triangular solves:
-//   chol_diag_kernel   64 x 64 diagonal block, one workgroup, in LDS
-//   chol_trsm_kernel   panel below the diagonal block: rows * L_kk^-T, 64 rows per workgroup through LDS
-//   chol_syrk_kernel   trailing update C -= P P' on the lower triangle with v_mfma_f64_16x16x4_f64
-//                      (64 x 64 tile per workgroup, both panels staged k-major in LDS: conflict-free fragment reads)
-//   tri_*_kernel       blocked forward / backward substitution for the vector right-hand sides
+//   chol_diag_inv_kernel  64 x 64 diagonal block L_kk and its inverse, one wave, rows in registers
+//   chol_panel_kernel     panel below the diagonal block: rows * L_kk^-T as a product with the stored inverse (f64 MFMA)
+//   chol_syrk_kernel      C -= P P' on the lower triangle with v_mfma_f64_16x16x4_f64: after every 64-column panel only
+//                         the rest of its 256-column outer block, then ONE depth-256 update of the trailing matrix
+//                         (64 x 64 tile per workgroup, both panels staged k-major in LDS: conflict-free fragment reads)
+//   tri_*_step_kernel     blocked forward / backward substitution for the vector right-hand sides, one launch per
+//                         block: the block solve is a product with the stored inverse, the rest a row update
 // A non-positive or non-finite pivot marks the factorisation failed; the solver then falls back to d = -g
 // exactly as the reference does for a singular Hessian (newton/mod.rs:43-46).  An indefinite but invertible
 // Hessian is treated as singular here (the reference's LU would still invert it): convex problems only.
@@ -34,84 +36,97 @@ __device__ __forceinline__ void qn_tile_to_lds(double (*dst)[QN_NB + 1], const d
     }
 }
 
-// ---- diagonal block: W[k0:k0+NB, k0:k0+NB] = L L' (lower), in place; rows/cols >= n_valid are identity padding ----
-__global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ W, size_t ld, int k0, int* __restrict__ fail) {
+__device__ __forceinline__ double qn_readlane_d(double v, int l) { // wave-uniform broadcast of lane l's value (l uniform)
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// ---- diagonal block: W[k0:k0+NB, k0:k0+NB] = L L' (lower, in place) and invL = L^-1 (dense 64 x 64, zeros above the
+// diagonal) for the panel product and the triangular solves.  4 waves; for L: lane = row, wave w keeps columns
+// 16w..16w+15 of that row in registers; for X = L^-1 (forward elimination of the identity, sharing the sweep): lane =
+// column, wave w keeps rows 16w..16w+15.  Step j: the owning wave broadcasts the pivot with v_readlane and publishes
+// column j of L (zeroed up to the diagonal) and the finished row j of X through double-buffered LDS vectors, ONE barrier,
+// then every wave applies both rank-1 updates with plain FMAs.  Measured on the way here: a fully unrolled one-wave
+// version 86 us (121 KB of cold instruction fetch), a predicated update 96 us (16 branches per step, serialised LDS
+// waits), selects instead of zeroed multipliers 57 us, separate L and X sweeps 36 us.  Rows/cols past n are identity padding.
+#ifdef QN_DIAG_STAMPS
+#define QN_DSTAMP(i) do { if (threadIdx.x == 0) qn_diag_stamps[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define QN_DSTAMP(i)
+#endif
+__global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__ W, size_t ld, int k0, double* __restrict__ invL,
+                                                            int* __restrict__ fail) {
     __shared__ double a[QN_NB][QN_NB + 1];
-    const int tid = threadIdx.x;
+    __shared__ double col[2][QN_NB];
+    __shared__ double xrow[2][QN_NB];
+    __shared__ int bad_s;
+    QN_DSTAMP(0);
+    if (*fail) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     qn_tile_to_lds<256, false>(a, W + (size_t)k0 * ld + k0, ld);
+    if (tid == 0) bad_s = 0;
     __syncthreads();
-    for (int j = 0; j < QN_NB; ++j) {
-        const double piv = a[j][j];
-        if (!(piv > 0.0) || !isfinite(piv)) { // uniform: every thread reads the same LDS word
-            if (tid == 0) *fail = 1;
-            return;
+    QN_DSTAMP(1);
+    double r[16], x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { r[c] = a[lane][16 * wave + c]; x[c] = (16 * wave + c == lane) ? 1.0 : 0.0; }
+    for (int w0 = 0; w0 < 4; ++w0) {
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * w0 + jj;
+            if (wave == w0) {
+                const double piv = qn_readlane_d(r[jj], j);
+                if (!(piv > 0.0) || !isfinite(piv)) { if (lane == 0) bad_s = 1; }
+                const double di = rsqrt(piv); // one reciprocal square root instead of sqrt -> divide on the sweep's critical path
+                double l = r[jj] * di;
+                if (lane == j) l = piv * di;
+                r[jj] = l;
+                const double xv = x[jj] * di; // row j of X is complete: X[j][:] = (e_j - sum_{p<j} L[j][p] X[p][:]) / L[j][j]
+                x[jj] = xv;
+                col[j & 1][lane] = (lane > j) ? l : 0.0; // zeros up to the diagonal: rows <= j and columns <= j drop out of the updates
+                xrow[j & 1][lane] = xv;
+            }
+            __syncthreads();
+            const double l = col[j & 1][lane], xp = xrow[j & 1][lane];
+            double lc[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lc[c] = col[j & 1][16 * wave + c]; // broadcast reads, all in flight together
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                r[c] = __builtin_fma(-l, lc[c], r[c]);  // A[lane][16w+c] -= L[lane][j] L[16w+c][j]
+                x[c] = __builtin_fma(-lc[c], xp, x[c]); // X[16w+c][lane] -= L[16w+c][j] X[j][lane]
+            }
         }
-        const double d = sqrt(piv);
-        __syncthreads();
-        if (tid == 0) a[j][j] = d;
-        for (int i = j + 1 + tid; i < QN_NB; i += 256) a[i][j] = a[i][j] / d;
-        __syncthreads();
-        // rank-1 update of the remaining lower triangle: a[i][c] -= a[i][j] * a[c][j], j < c <= i
-        const int m = QN_NB - j - 1;
-        for (int e = tid; e < m * m; e += 256) {
-            const int i = j + 1 + e / m, c = j + 1 + e % m;
-            if (c <= i) a[i][c] = a[i][c] - a[i][j] * a[c][j];
-        }
-        __syncthreads();
     }
+    __syncthreads();
+    QN_DSTAMP(2);
+    if (bad_s) { // a non-positive pivot poisons everything after it: nothing is stored
+        if (tid == 0) *fail = 1;
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { const int cc = 16 * wave + c; a[lane][cc] = (cc <= lane) ? r[c] : 0.0; }
+    __syncthreads();
     for (int e = tid; e < QN_NB * QN_NB; e += 256) {
         const int i = e / QN_NB, j = e % QN_NB;
         if (j <= i) W[(size_t)(k0 + i) * ld + k0 + j] = a[i][j];
     }
+    QN_DSTAMP(3);
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) { const int i = 16 * wave + ii; invL[i * QN_NB + lane] = (lane <= i) ? x[ii] : 0.0; }
+    QN_DSTAMP(4);
+    QN_DSTAMP(5);
 }
 
-// ---- panel: rows r >= k0+NB: W[r, k0:k0+NB] <- W[r, k0:k0+NB] * L_kk^-T ; 64 rows per workgroup (64 threads) ----
-__global__ __launch_bounds__(64) void chol_trsm_kernel(double* __restrict__ W, size_t ld, int k0, int nrows_total, const int* __restrict__ fail) {
-    if (*fail) return;
-    __shared__ double L[QN_NB][QN_NB + 1];
-    __shared__ double xt[QN_NB][QN_NB + 1]; // xt[j][r]: column j of the panel tile, row r
-    const int tid = threadIdx.x;
-    const int r0 = k0 + QN_NB + blockIdx.x * QN_NB;
-    qn_tile_to_lds<64, false>(L, W + (size_t)k0 * ld + k0, ld);
-    qn_tile_to_lds<64, true>(xt, W + (size_t)r0 * ld + k0, ld); // r0 + 63 < nrows_total: the padded dimension is a multiple of 64
-    __syncthreads();
-    // thread = row: forward substitution against L' (x L' = a  <=>  x_j = (a_j - sum_{p<j} x_p L[j][p]) / L[j][j])
-    for (int j = 0; j < QN_NB; ++j) {
-        double acc = xt[j][tid];
-        for (int p = 0; p < j; ++p) acc = acc - xt[p][tid] * L[j][p];
-        xt[j][tid] = acc / L[j][j];
-    }
-    __syncthreads();
-    for (int e = tid; e < QN_NB * QN_NB; e += 64) {
-        const int i = e / QN_NB, j = e % QN_NB;
-        const int r = r0 + i;
-        if (r < nrows_total) W[(size_t)r * ld + k0 + j] = xt[j][i];
-    }
-}
-
-// ---- trailing update on the lower triangle: C[ti, tj] -= P_ti * P_tj'  (tiles of 64, ti >= tj), f64 MFMA ----
-// grid (nt, nt); 256 threads = 4 waves, wave w owns the 32 x 32 quadrant (w >> 1, w & 1): 2 x 2 MFMA tiles of 16 x 16.
-__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, size_t ld, int k0, const int* __restrict__ fail) {
-    const int ti = blockIdx.y, tj = blockIdx.x;
-    if (tj > ti) return;
-    if (*fail) return;
-    __shared__ double PI[QN_NB][QN_NB + 1]; // PI[k][i] = P[i0 + i][k0 + k]  (k-major: lanes read consecutive i; +1 pad for the transposing stores)
-    __shared__ double PJ[QN_NB][QN_NB + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = k0 + QN_NB + ti * QN_NB, j0 = k0 + QN_NB + tj * QN_NB;
-    qn_tile_to_lds<256, true>(PI, W + (size_t)i0 * ld + k0, ld); // coalesced along k in global memory
-    qn_tile_to_lds<256, true>(PJ, W + (size_t)j0 * ld + k0, ld);
-    __syncthreads();
-    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
-    v4d acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+// 64 x 64 x 64 product on the f64 matrix cores from two k-major LDS panels: acc[a][b] += PI[:, wi+16a ..]' PJ[:, wj+16b ..]
+__device__ __forceinline__ void qn_mfma_64(const double (*PI)[QN_NB + 1], const double (*PJ)[QN_NB + 1], int kdepth, int wi, int wj, int lane,
+                                           v4d (&acc)[2][2]) {
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll 4
-    for (int kk = 0; kk < QN_NB; kk += 4) {
-        // A operand: A[i = lane&15][k = lane>>4] ; B operand: B[k = lane>>4][j = lane&15] = P_j[j][k]
+    for (int kk = 0; kk < kdepth; kk += 4) {
+        // A operand: A[i = lane&15][k = lane>>4] ; B operand: B[k = lane>>4][j = lane&15]
         const double a0 = PI[kk + l4][wi + l15], a1 = PI[kk + l4][wi + 16 + l15];
         const double b0 = PJ[kk + l4][wj + l15], b1 = PJ[kk + l4][wj + 16 + l15];
         acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
@@ -119,71 +134,142 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, 
         acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
-    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+}
+
+// ---- panel: rows r >= k0+NB: W[r, k0:k0+NB] <- W[r, k0:k0+NB] * invL'   (64 rows per workgroup, f64 MFMA) ----
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ W, size_t ld, int k0, const double* __restrict__ invL,
+                                                         const int* __restrict__ fail) {
+    if (*fail) return;
+    __shared__ double PI[QN_NB][QN_NB + 1]; // PI[k][i] = W[r0 + i][k0 + k]
+    __shared__ double PJ[QN_NB][QN_NB + 1]; // PJ[k][j] = invL[j][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = k0 + QN_NB + blockIdx.x * QN_NB;
+    qn_tile_to_lds<256, true>(PI, W + (size_t)r0 * ld + k0, ld);
+    qn_tile_to_lds<256, true>(PJ, invL, QN_NB);
+    __syncthreads();
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    qn_mfma_64(PI, PJ, QN_NB, wi, wj, lane, acc);
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+                W[(size_t)(r0 + wi + a * 16 + l4 + 4 * reg) * ld + k0 + wj + b * 16 + l15] = acc[a][b][reg];
+}
+
+// ---- symmetric update on the lower triangle: C[ti, tj] -= P_ti P_tj' over the panel columns [kb, kb + klen) ----
+// Tiles of 64 with origin c0 (rows c0 + 64 ti, columns c0 + 64 tj, tj <= ti); grid (column tiles, row tiles).  klen = 64
+// inside a 256-column outer block (only the block's remaining columns), klen = 256 for the trailing matrix, which
+// quarters the read-modify-write traffic of the big update.  256 threads = 4 waves, wave w owns the 32 x 32 quadrant
+// (w >> 1, w & 1): 2 x 2 MFMA tiles of 16 x 16; the panels are staged k-major in LDS 32 columns at a time.
+#define QN_KC 32
+__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, size_t ld, int kb, int klen, int c0, const int* __restrict__ fail) {
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    if (*fail) return;
+    __shared__ double PI[QN_KC][QN_NB + 1];
+    __shared__ double PJ[QN_KC][QN_NB + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = c0 + ti * QN_NB, j0 = c0 + tj * QN_NB;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    // thread t stages rows (t >> 5) + 8 u, u = 0..7, column (t & 31) of each 64 x 32 panel chunk (coalesced along k)
+    const int sr = tid >> 5, sk = tid & 31;
+    const double* pi = W + (size_t)(i0 + sr) * ld + kb + sk;
+    const double* pj = W + (size_t)(j0 + sr) * ld + kb + sk;
+    double vi[8], vj[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { vi[u] = pi[(size_t)(8 * u) * ld]; vj[u] = pj[(size_t)(8 * u) * ld]; }
+    for (int kc = 0; kc < klen; kc += QN_KC) {
+        if (kc) __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { PI[sk][sr + 8 * u] = vi[u]; PJ[sk][sr + 8 * u] = vj[u]; }
+        __syncthreads();
+        if (kc + QN_KC < klen) { // next chunk's loads fly while this one is multiplied
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { vi[u] = pi[(size_t)(8 * u) * ld + kc + QN_KC]; vj[u] = pj[(size_t)(8 * u) * ld + kc + QN_KC]; }
+        }
+        const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < QN_KC; kk += 4) {
+            const double a0 = PI[kk + l4][wi + l15], a1 = PI[kk + l4][wi + 16 + l15];
+            const double b0 = PJ[kk + l4][wj + l15], b1 = PJ[kk + l4][wj + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int row = i0 + wi + a * 16 + l4 + 4 * reg;
-                const int col = j0 + wj + b * 16 + l15;
-                double* p = W + (size_t)row * ld + col;
+                double* p = W + (size_t)(i0 + wi + a * 16 + l4 + 4 * reg) * ld + j0 + wj + b * 16 + l15;
                 *p = *p - acc[a][b][reg];
             }
 }
 
-// ---- triangular solves with vector right-hand sides (in place on x, length n_pad) ----
-// forward, block k: x_k <- L_kk^-1 x_k (one wave), then x_i -= L[i, k-block] x_k for the rows below (one wave per row)
-__global__ __launch_bounds__(64) void tri_fwd_diag_kernel(const double* __restrict__ W, size_t ld, int k0, double* __restrict__ x) {
-    __shared__ double L[QN_NB][QN_NB + 1];
-    __shared__ double xs[QN_NB];
-    const int tid = threadIdx.x;
-    qn_tile_to_lds<64, false>(L, W + (size_t)k0 * ld + k0, ld);
-    xs[tid] = x[k0 + tid];
+// ---- triangular solves with a vector right-hand side, one launch per 64-block ----
+// Every workgroup first forms the block's solution from the stored inverse (a 64 x 64 product: cheaper than waiting for
+// a separate launch), workgroup 0 stores it into `sol`, then all update their rows of the running right-hand side `rhs`.
+__device__ __forceinline__ void qn_block_solve(const double* __restrict__ invL, const double* __restrict__ rk, bool transpose, double* xk /*LDS[64]*/,
+                                               double* rs /*LDS[64]*/) {
+    const int tid = threadIdx.x; // 256 threads: thread = (row tid >> 2, quarter tid & 3)
+    if (tid < QN_NB) rs[tid] = rk[tid];
     __syncthreads();
-    for (int j = 0; j < QN_NB; ++j) {
-        if (tid == j) xs[j] = xs[j] / L[j][j];
-        __syncthreads();
-        if (tid > j) xs[tid] = xs[tid] - L[tid][j] * xs[j];
-        __syncthreads();
+    const int row = tid >> 2, q = tid & 3;
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int k = q * 16 + c;
+        const double m = transpose ? invL[k * QN_NB + row] : invL[row * QN_NB + k];
+        acc = __builtin_fma(m, rs[k], acc);
     }
-    x[k0 + tid] = xs[tid];
+    acc = acc + __shfl_xor(acc, 1, 64);
+    acc = acc + __shfl_xor(acc, 2, 64);
+    if (q == 0) xk[row] = acc;
+    __syncthreads();
 }
-__global__ __launch_bounds__(256) void tri_fwd_update_kernel(const double* __restrict__ W, size_t ld, int k0, int n_pad, double* __restrict__ x) {
+// forward (L y = b), block k: y_k = invL_k rhs_k ; rhs_i -= L[i, k-block] y_k for the rows below (one wave per row)
+__global__ __launch_bounds__(256) void tri_fwd_step_kernel(const double* __restrict__ W, size_t ld, int k0, int n_pad, const double* __restrict__ invL,
+                                                           double* __restrict__ rhs, double* __restrict__ sol) {
+    __shared__ double xk[QN_NB], rs[QN_NB];
+    qn_block_solve(invL, rhs + k0, false, xk, rs);
+    if (blockIdx.x == 0 && threadIdx.x < QN_NB) sol[k0 + threadIdx.x] = xk[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double xk = x[k0 + lane];
+    const double xl = xk[lane];
     for (int r = k0 + QN_NB + blockIdx.x * 4 + wave; r < n_pad; r += gridDim.x * 4) {
-        double p = W[(size_t)r * ld + k0 + lane] * xk;
+        double p = W[(size_t)r * ld + k0 + lane] * xl;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
-        if (lane == 0) x[r] = x[r] - p;
+        if (lane == 0) rhs[r] = rhs[r] - p;
     }
 }
-// backward (L' z = x), block k from the end: z_k <- L_kk^-T x_k, then x_j -= sum_{i in block k} L[i][j] z_i for j < k0
-__global__ __launch_bounds__(64) void tri_bwd_diag_kernel(const double* __restrict__ W, size_t ld, int k0, double* __restrict__ x) {
-    __shared__ double L[QN_NB][QN_NB + 1];
-    __shared__ double xs[QN_NB];
-    const int tid = threadIdx.x;
-    qn_tile_to_lds<64, false>(L, W + (size_t)k0 * ld + k0, ld);
-    xs[tid] = x[k0 + tid];
-    __syncthreads();
-    for (int j = QN_NB - 1; j >= 0; --j) {
-        if (tid == j) xs[j] = xs[j] / L[j][j];
-        __syncthreads();
-        if (tid < j) xs[tid] = xs[tid] - L[j][tid] * xs[j]; // (L')[tid][j] = L[j][tid]
-        __syncthreads();
-    }
-    x[k0 + tid] = xs[tid];
-}
-__global__ __launch_bounds__(256) void tri_bwd_update_kernel(const double* __restrict__ W, size_t ld, int k0, double* __restrict__ x) {
-    __shared__ double zk[QN_NB];
-    if (threadIdx.x < QN_NB) zk[threadIdx.x] = x[k0 + threadIdx.x];
-    __syncthreads();
+// backward (L' z = y), block k from the end: z_k = invL_k' rhs_k ; rhs_j -= sum_{i in block k} L[i][j] z_i for j < k0
+__global__ __launch_bounds__(256) void tri_bwd_step_kernel(const double* __restrict__ W, size_t ld, int k0, const double* __restrict__ invL,
+                                                           double* __restrict__ rhs, double* __restrict__ sol) {
+    __shared__ double zk[QN_NB], rs[QN_NB];
+    qn_block_solve(invL, rhs + k0, true, zk, rs);
+    if (blockIdx.x == 0 && threadIdx.x < QN_NB) sol[k0 + threadIdx.x] = zk[threadIdx.x];
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k0; j += gridDim.x * blockDim.x) {
         double acc = 0.0;
+#pragma unroll 16
         for (int i = 0; i < QN_NB; ++i) acc = __builtin_fma(W[(size_t)(k0 + i) * ld + j], zk[i], acc);
-        x[j] = x[j] - acc;
+        rhs[j] = rhs[j] - acc;
     }
 }
 
