@@ -586,7 +586,8 @@ struct qn_solver {
     QnVecs V{};
     double* f_dev = nullptr;
     // Newton: Hessian work matrix (row-major, ld = nw), right-hand sides, staging for host Hessians, failure flag
-    double *newton_w = nullptr, *newton_x = nullptr, *newton_hsrc = nullptr, *newton_invl = nullptr;
+    double *newton_w = nullptr, *newton_x = nullptr, *newton_hsrc = nullptr, *newton_invl = nullptr, *newton_inv2 = nullptr;
+    bool newton_big = false;
     int* newton_fail = nullptr;
     size_t newton_n64 = 0;
     std::vector<double> newton_hhost;
@@ -721,7 +722,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     for (auto& e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
-    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail);
+    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
@@ -991,15 +992,47 @@ extern "C" int qn_solver_get_stats(qn_solver* s, qn_stats* out) {
 // ---- Newton direction (newton/mod.rs:26-49): Cholesky factorisation + four triangular solves, or the n <= 5 kernel ----
 static int newton_alloc(qn_solver* s) {
     if (s->newton_w) return QN_OK;
-    const size_t n64 = (s->n + QN_NB - 1) / QN_NB * QN_NB;
+    size_t n64 = (s->n + QN_NB - 1) / QN_NB * QN_NB;
+    s->newton_big = n64 > QN_TS; // 512-wide triangular blocks (inverses doubled up from the 64-wide ones)
+    if (s->newton_big) n64 = (s->n + QN_TS - 1) / QN_TS * QN_TS;
     s->newton_n64 = n64;
     hipStream_t st = s->ctx->stream;
     QNCHK(dev_alloc_zero(&s->newton_w, n64 * n64, st));
     QNCHK(dev_alloc_zero(&s->newton_x, 2 * n64, st));
-    QNCHK(dev_alloc_zero(&s->newton_invl, (n64 / QN_NB) * QN_NB * QN_NB, st));
+    QNCHK(dev_alloc_zero(&s->newton_invl, n64 * QN_NB, st));
+    if (s->newton_big) { // inverse blocks of width 128, 256, 512, the transposed 512 ones, and the product scratch
+        QNCHK(dev_alloc_zero(&s->newton_inv2, n64 * (128 + 256 + 512 + 512 + 256), st));
+    }
     HIPCHK(hipMalloc((void**)&s->newton_fail, sizeof(int)));
     HIPCHK(hipMemsetAsync(s->newton_fail, 0, sizeof(int), st));
     s->V.nfail = s->newton_fail;
+    return QN_OK;
+}
+
+static inline int rowdot_grid(int nrows) { return std::max(1, std::min(1024, nrows <= 4096 ? (nrows + 3) / 4 : (nrows + 15) / 16)); }
+
+// inverses of the 512-wide diagonal blocks of L from the 64-wide ones: inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1, C^-1]
+static int newton_build_block_inverses(qn_solver* s) {
+    hipStream_t st = s->ctx->stream;
+    const size_t n64 = s->newton_n64, ld = n64;
+    double* lvl[4] = {s->newton_invl, s->newton_inv2, s->newton_inv2 + n64 * 128, s->newton_inv2 + n64 * (128 + 256)};
+    double* invT = s->newton_inv2 + n64 * (128 + 256 + 512);
+    double* T = s->newton_inv2 + n64 * (128 + 256 + 512 + 512);
+    for (int l = 0; l < 3; ++l) {
+        const int sz = QN_NB << l;
+        const int npairs = (int)(n64 / (2 * (size_t)sz));
+        const size_t ss = (size_t)sz * sz;
+        const dim3 grid(sz / QN_NB, sz / QN_NB, npairs);
+        QnBatchGemm g1{s->newton_w + (size_t)sz * ld, ld, 2 * (size_t)sz * ld + 2 * (size_t)sz, lvl[l], (size_t)sz, 2 * ss, T, (size_t)sz, ss, sz, 1.0};
+        hipLaunchKernelGGL(tri_batch_gemm_kernel, grid, dim3(256), 0, st, g1); // T = B A^-1
+        QnBatchGemm g2{lvl[l] + ss, (size_t)sz, 2 * ss, T, (size_t)sz, ss, lvl[l + 1] + (size_t)sz * 2 * sz, 2 * (size_t)sz, 4 * ss, sz, -1.0};
+        hipLaunchKernelGGL(tri_batch_gemm_kernel, grid, dim3(256), 0, st, g2); // lower-left = -C^-1 T
+        hipLaunchKernelGGL(tri_inv_assemble_kernel, dim3(1024), dim3(256), 0, st, lvl[l], lvl[l + 1], sz, npairs);
+    }
+    const int nb = (int)(n64 / QN_TS);
+    hipLaunchKernelGGL(tri_transpose_blocks_kernel, dim3(QN_TS / 32, QN_TS / 32, nb), dim3(256), 0, st, lvl[3], invT, (int)QN_TS, nb);
+    s->stats.launches += 10;
+    HIPCHK(hipGetLastError());
     return QN_OK;
 }
 
@@ -1007,6 +1040,28 @@ static int newton_tri_solve(qn_solver* s, double* x, double* tmp) { // x <- (L L
     hipStream_t st = s->ctx->stream;
     const int n64 = (int)s->newton_n64;
     const size_t ld = s->newton_n64;
+    if (s->newton_big) {
+        const double* inv = s->newton_inv2 + (size_t)n64 * (128 + 256);
+        const double* invT = s->newton_inv2 + (size_t)n64 * (128 + 256 + 512);
+        const size_t bb = (size_t)QN_TS * QN_TS;
+        const int nb = n64 / QN_TS;
+        for (int K = 0; K < nb; ++K) { // L y = x : rhs x (consumed), solution tmp
+            const int K0 = K * QN_TS, below = n64 - K0 - QN_TS;
+            hipLaunchKernelGGL(tri_rowdot512_kernel, dim3(rowdot_grid(QN_TS)), dim3(256), 0, st, inv + K * bb, (size_t)QN_TS, (int)QN_TS, x + K0, tmp + K0, 0);
+            if (below > 0)
+                hipLaunchKernelGGL(tri_rowdot512_kernel, dim3(rowdot_grid(below)), dim3(256), 0, st, s->newton_w + (size_t)(K0 + QN_TS) * ld + K0, ld,
+                                   below, tmp + K0, x + K0 + QN_TS, 1);
+        }
+        for (int K = nb - 1; K >= 0; --K) { // L' z = y : rhs tmp (consumed), solution x
+            const int K0 = K * QN_TS;
+            hipLaunchKernelGGL(tri_rowdot512_kernel, dim3(rowdot_grid(QN_TS)), dim3(256), 0, st, invT + K * bb, (size_t)QN_TS, (int)QN_TS, tmp + K0, x + K0, 0);
+            if (K0 > 0)
+                hipLaunchKernelGGL(tri_coldot512_kernel, dim3((K0 + 63) / 64), dim3(256), 0, st, s->newton_w + (size_t)K0 * ld, ld, K0, x + K0, tmp);
+        }
+        s->stats.launches += 4 * (uint64_t)nb;
+        HIPCHK(hipGetLastError());
+        return QN_OK;
+    }
     for (int k0 = 0; k0 < n64; k0 += QN_NB) { // L y = x : rhs x (consumed), solution tmp
         const int below = n64 - k0 - QN_NB;
         const int grid = std::max(1, std::min(256, (below + 3) / 4));
@@ -1209,6 +1264,9 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
     hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, s->newton_w, ld, n, n64, hsrc, ld_src);
     // blocked right-looking Cholesky, lower triangle in place.  Outer blocks of 256 columns: each 64-column panel is
     // factorised and applied to the REST OF ITS OUTER BLOCK only; the trailing matrix then takes one depth-256 update.
+    // (Look-ahead -- the next block's diag/panel chain on this stream beside the bulk update on a second, low-priority
+    // stream -- was measured and dropped: the chain's single-workgroup kernels sat behind the bulk kernel's ~10^4
+    // workgroups until it drained, 21 us -> 240-280 us each, and the iteration got 7 % slower.)
     const int KB = 4 * QN_NB;
     for (int K0 = 0; K0 < n64; K0 += KB) {
         const int Kend = std::min(K0 + KB, n64);
@@ -1229,6 +1287,7 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
         }
     }
     HIPCHK(hipGetLastError());
+    if (s->newton_big) QNCHK(newton_build_block_inverses(s));
     // d = -(H^-1 g) ; z = H^-1 d
     double* x1 = s->newton_x;
     double* x2 = s->newton_x + n64;
@@ -1239,7 +1298,7 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
     QNCHK(newton_tri_solve(s, x1, x2)); // the first solve's result is the second's right-hand side
     hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.s, x1, n, s->T.n_pad, 1.0);
     HIPCHK(hipGetLastError());
-    s->stats.launches += 4 + 4 * (uint64_t)(n64 / QN_NB);
+    s->stats.launches += 4 + (s->newton_big ? 0 : 4 * (uint64_t)(n64 / QN_NB));
     return QN_OK;
 }
 

@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ W,
 // Tiles of 64 with origin c0 (rows c0 + 64 ti, columns c0 + 64 tj, tj <= ti); grid (column tiles, row tiles).  klen = 64
 // inside a 256-column outer block (only the block's remaining columns), klen = 256 for the trailing matrix, which
 // quarters the read-modify-write traffic of the big update.  256 threads = 4 waves, wave w owns the 32 x 32 quadrant
-// (w >> 1, w & 1): 2 x 2 MFMA tiles of 16 x 16; the panels are staged k-major in LDS 32 columns at a time.
+// (w >> 1, w & 1): 2 x 2 MFMA tiles of 16 x 16; the panels are staged k-major in LDS 32 columns at a time.  Measured at
+// n = 8192: 39.5 TFLOP/s on the depth-256 updates (50 % of the 78.6 TFLOP/s f64 MFMA peak); a 128 x 128-tile variant
+// (4 x 4 MFMA tiles per wave, 2 waves per SIMD) was slower (5.7 ms vs 4.3 ms per factorisation) and was dropped.
 #define QN_KC 32
 __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, size_t ld, int kb, int klen, int c0, const int* __restrict__ fail) {
     const int ti = blockIdx.y, tj = blockIdx.x;
@@ -271,6 +273,138 @@ __global__ __launch_bounds__(256) void tri_bwd_step_kernel(const double* __restr
         for (int i = 0; i < QN_NB; ++i) acc = __builtin_fma(W[(size_t)(k0 + i) * ld + j], zk[i], acc);
         rhs[j] = rhs[j] - acc;
     }
+}
+
+// ---- triangular solves for large n: 512-wide blocks whose inverses are assembled from the 64-wide ones ----
+// inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1, C^-1]: three doubling levels (64 -> 128 -> 256 -> 512), each two batched MFMA
+// products and a copy; a sweep is then 16 steps of (block product, panel update) instead of 128 dependent launches.
+#define QN_TS 512
+
+// batched 64 x 64 tile of  OUT = sign * A B  (row-major operands, depth `depth`, a multiple of 64); z = batch index
+struct QnBatchGemm {
+    const double* A; size_t lda; size_t a_batch; // A + z * a_batch : rows x depth
+    const double* B; size_t ldb; size_t b_batch; // B + z * b_batch : depth x cols
+    double* C; size_t ldc; size_t c_batch;
+    int depth;
+    double sign;
+};
+__global__ __launch_bounds__(256) void tri_batch_gemm_kernel(const QnBatchGemm g) {
+    __shared__ double PI[QN_NB][QN_NB + 1]; // PI[k][i] = A[i0 + i][k]
+    __shared__ double PJ[QN_NB][QN_NB + 1]; // PJ[k][j] = B[k][j0 + j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.y * QN_NB, j0 = blockIdx.x * QN_NB;
+    const double* A = g.A + (size_t)blockIdx.z * g.a_batch + (size_t)i0 * g.lda;
+    const double* B = g.B + (size_t)blockIdx.z * g.b_batch + j0;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int kc = 0; kc < g.depth; kc += QN_NB) {
+        if (kc) __syncthreads();
+        qn_tile_to_lds<256, true>(PI, A + kc, g.lda);
+        qn_tile_to_lds<256, false>(PJ, B + (size_t)kc * g.ldb, g.ldb);
+        __syncthreads();
+        qn_mfma_64(PI, PJ, QN_NB, wi, wj, lane, acc);
+    }
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double* C = g.C + (size_t)blockIdx.z * g.c_batch;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                C[(size_t)(i0 + wi + a * 16 + l4 + 4 * reg) * g.ldc + j0 + wj + b * 16 + l15] = g.sign * acc[a][b][reg];
+}
+// out block p (2s x 2s) <- [in[2p] 0; (left to the product) in[2p+1]]
+__global__ void tri_inv_assemble_kernel(const double* __restrict__ in, double* __restrict__ out, int s, int npairs) {
+    const size_t per = (size_t)4 * s * s, total = per * npairs;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = e / per, w = e % per;
+        const int i = (int)(w / (2 * s)), j = (int)(w % (2 * s));
+        if (i < s && j < s) out[e] = in[(2 * p) * (size_t)s * s + (size_t)i * s + j];
+        else if (i >= s && j >= s) out[e] = in[(2 * p + 1) * (size_t)s * s + (size_t)(i - s) * s + (j - s)];
+        else if (i < s) out[e] = 0.0;
+    }
+}
+__global__ void tri_transpose_blocks_kernel(const double* __restrict__ in, double* __restrict__ out, int s, int nblocks) {
+    __shared__ double t[32][33];
+    const int tiles = s / 32;
+    const int blk = blockIdx.z, ti = blockIdx.y, tj = blockIdx.x;
+    if (ti >= tiles || tj >= tiles || blk >= nblocks) return;
+    const double* src = in + (size_t)blk * s * s;
+    double* dst = out + (size_t)blk * s * s;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 256 threads: 32 x 8
+    for (int r = ty; r < 32; r += 8) t[r][tx] = src[(size_t)(ti * 32 + r) * s + tj * 32 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) dst[(size_t)(tj * 32 + r) * s + ti * 32 + tx] = t[tx][r];
+}
+
+// y[i] (= or -=) M[i][0:512] . v[0:512], one wave per row, 4 rows in flight per wave for latency overlap
+__global__ __launch_bounds__(256) void tri_rowdot512_kernel(const double* __restrict__ M, size_t ldm, int nrows, const double* __restrict__ v,
+                                                            double* __restrict__ y, int subtract) {
+    __shared__ double vs[QN_TS];
+    for (int k = threadIdx.x; k < QN_TS; k += 256) vs[k] = v[k];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double vl[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { vl[2 * u] = vs[128 * u + 2 * lane]; vl[2 * u + 1] = vs[128 * u + 2 * lane + 1]; }
+    const int stride = gridDim.x * 4;
+    for (int r0 = blockIdx.x * 4 + wave; r0 < nrows; r0 += 4 * stride) {
+        double p[4];
+        v2d m[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + q * stride;
+            const double* row = M + (size_t)(r < nrows ? r : r0) * ldm + 2 * lane;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m[q][u] = *reinterpret_cast<const v2d*>(row + 128 * u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double a = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a = __builtin_fma(m[q][u].x, vl[2 * u], a); a = __builtin_fma(m[q][u].y, vl[2 * u + 1], a); }
+            p[q] = a;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p[q] = p[q] + __shfl_xor(p[q], off, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + q * stride;
+                if (r < nrows) y[r] = subtract ? (y[r] - p[q]) : p[q];
+            }
+        }
+    }
+}
+// backward panel update: y[j] -= sum_{i < 512} M[i][j] z[i] for j < ncols; workgroup = 64 columns x 4 waves of 128 rows each
+__global__ __launch_bounds__(256) void tri_coldot512_kernel(const double* __restrict__ M, size_t ldm, int ncols, const double* __restrict__ z,
+                                                            double* __restrict__ y) {
+    __shared__ double zs[QN_TS];
+    __shared__ double part[4][64];
+    for (int k = threadIdx.x; k < QN_TS; k += 256) zs[k] = z[k];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const double* col = M + (size_t)(wave * 128) * ldm + (j < ncols ? j : 0);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = 0; i0 < 128; i0 += 16) {
+        double m[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) m[u] = col[(size_t)(i0 + u) * ldm];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u & 3] = __builtin_fma(m[u], zs[wave * 128 + i0 + u], acc[u & 3]);
+    }
+    part[wave][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (wave == 0 && j < ncols) y[j] = y[j] - (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
 }
 
 // Hessian staging: W (row-major, ld = n_pad64) <- src rows (ld_src), identity on the padding diagonal

@@ -6,6 +6,7 @@
 #include <cmath>
 #define QN_SMALL_N 5
 __device__ long long qn_diag_stamps[16];
+typedef double v2d __attribute__((ext_vector_type(2)));
 #include "../optimization-solvers_amd/csrc/qn_newton.hip.h"
 int main() {
     const int n = 64;
