@@ -633,3 +633,36 @@ def test_deferred_update_step_is_bitwise_neutral(qn, qo):
         # the deferred variant saves one launch per iteration in the steady state
         assert runs[0][4]["launches"] < runs[1][4]["launches"]
         assert runs[0][4]["h_passes"] == runs[1][4]["h_passes"] and runs[0][4]["oracle_evals"] == runs[1][4]["oracle_evals"]
+
+
+def test_element_offsets_beyond_int32_n49152(qn, qo):
+    """n = 49152: n^2 = 2.4e9 elements per matrix (H + Q = 36 GiB), so every row offset past row 43690 exceeds 2^31.
+    The fused and the generic path are different kernels with their own index arithmetic: they must agree to rounding,
+    the objective must match a host evaluation of rows near the end of the matrix, and f must decrease monotonically."""
+    n, iters = 49152, 4
+    diag = P.synth_diag(n)
+    b, x0 = P.synth_vectors(n)
+    obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
+    runs = []
+    for tiling in (None, (-1, 0)):
+        s = qn.BFGS(1e-10, x0)
+        if tiling:
+            s.set_tiling(*tiling)
+        s.set_trace(iters, with_x=True)
+        with pytest.raises(qn.MaxIterReached):
+            s.minimize(qn.MoreThuente(), obj, iters, 20)
+        runs.append(s.trace())
+        del s
+    (tr, xs), (tr_g, xs_g) = runs
+    f = np.array([r["f"] for r in tr])
+    assert len(tr) == iters and np.all(np.diff(f) < 0)
+    assert [r["n_evals"] for r in tr] == [r["n_evals"] for r in tr_g]
+    assert np.allclose([r["t"] for r in tr], [r["t"] for r in tr_g], rtol=1e-9, atol=0)
+    assert np.linalg.norm(xs[-1] - xs_g[-1]) <= 1e-9 * np.linalg.norm(xs[-1])
+    for row0 in (0, 43689, n - 3):  # rows on both sides of the 2^31-element boundary
+        rows = obj.rows(row0, 3)
+        assert np.array_equal(rows, qo.synth_rows(n, row0, 3, P.SEED, diag))
+        g = obj(xs[-1]).g()
+        assert np.allclose(g[row0:row0 + 3], rows @ xs[-1] - b[row0:row0 + 3], rtol=1e-12, atol=1e-12)
+    # the last iterate moved in the tail coordinates too (the update and both mat-vecs reached the last rows)
+    assert np.all(xs[-1][-64:] != x0[-64:])
