@@ -108,3 +108,12 @@ def test_rust_shim_in_integration_md_matches_the_header():
 
     assert c_fields("qn_linesearch") == rust_fields("QnLineSearch") == 13
     assert c_fields("qn_oracle") == rust_fields("QnOracle") == 8
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/qn_hip.h is what bindgen / a hand-written `extern "C"` block binds: it must compile as C, not only as C++."""
+    import subprocess
+    src = tmp_path / "c_check.c"
+    src.write_text('#include "qn_hip.h"\nint main(void) { qn_linesearch ls; qn_morethuente_default(&ls); return (int)sizeof(qn_oracle) == 0; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"), str(src)])
