@@ -1277,12 +1277,12 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
             if (nrt > 0) hipLaunchKernelGGL(chol_panel_kernel, dim3(nrt), dim3(256), 0, st, s->newton_w, ld, k0, invl, s->newton_fail);
             const int nct = (Kend - k0 - QN_NB) / QN_NB; // column tiles left in this outer block
             if (nrt > 0 && nct > 0)
-                hipLaunchKernelGGL(chol_syrk_kernel, dim3(nct, nrt), dim3(256), 0, st, s->newton_w, ld, k0, QN_NB, k0 + QN_NB, s->newton_fail);
+                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nrt, nct)), dim3(256), 0, st, s->newton_w, ld, k0, QN_NB, k0 + QN_NB, nct, s->newton_fail);
             s->stats.launches += 3;
         }
         const int nt = (n64 - Kend) / QN_NB;
         if (nt > 0) {
-            hipLaunchKernelGGL(chol_syrk_kernel, dim3(nt, nt), dim3(256), 0, st, s->newton_w, ld, K0, Kend - K0, Kend, s->newton_fail);
+            hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt, nt)), dim3(256), 0, st, s->newton_w, ld, K0, Kend - K0, Kend, nt, s->newton_fail);
             s->stats.launches++;
         }
     }

@@ -165,27 +165,36 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ W,
 }
 
 // ---- symmetric update on the lower triangle: C[ti, tj] -= P_ti P_tj' over the panel columns [kb, kb + klen) ----
-// Tiles of 64 with origin c0 (rows c0 + 64 ti, columns c0 + 64 tj, tj <= ti); grid (column tiles, row tiles).  klen = 64
+// Tiles of 64 with origin c0 (rows c0 + 64 ti, columns c0 + 64 tj, tj <= ti); a linear grid over exactly those tiles.  klen = 64
 // inside a 256-column outer block (only the block's remaining columns), klen = 256 for the trailing matrix, which
 // quarters the read-modify-write traffic of the big update.  256 threads = 4 waves, wave w owns the 32 x 32 quadrant
 // (w >> 1, w & 1): 2 x 2 MFMA tiles of 16 x 16; the panels are staged k-major in LDS 32 columns at a time.  Measured at
 // n = 8192: 39.5 TFLOP/s on the depth-256 updates (50 % of the 78.6 TFLOP/s f64 MFMA peak); a 128 x 128-tile variant
 // (4 x 4 MFMA tiles per wave, 2 waves per SIMD) was slower (5.7 ms vs 4.3 ms per factorisation) and was dropped.
 #define QN_KC 32
-__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, size_t ld, int kb, int klen, int c0, const int* __restrict__ fail) {
-    const int ti = blockIdx.y, tj = blockIdx.x;
-    if (tj > ti) return;
+// tile (ti, tj) of launch-linear index t in a grid of `ncols` column tiles (tj < ncols, tj <= ti): the first `ncols` tile
+// rows are triangular, the rest are full -- no workgroup is launched for the upper triangle
+__device__ __forceinline__ void qn_tri_tile(int t, int ncols, int& ti, int& tj) {
+    const int tri = ncols * (ncols + 1) / 2;
+    if (t >= tri) { const int r = t - tri; ti = ncols + r / ncols; tj = r % ncols; return; }
+    int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    while (i * (i + 1) / 2 > t) --i;
+    ti = i; tj = t - i * (i + 1) / 2;
+}
+static inline int qn_tri_tiles(int nrows_t, int ncols_t) { // number of tiles with tj < ncols_t, tj <= ti < nrows_t (ncols_t <= nrows_t)
+    return ncols_t * (ncols_t + 1) / 2 + (nrows_t - ncols_t) * ncols_t;
+}
+__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, size_t ld, int kb, int klen, int c0, int ncols, const int* __restrict__ fail) {
+    int ti, tj;
+    qn_tri_tile(blockIdx.x, ncols, ti, tj);
     if (*fail) return;
     __shared__ double PI[QN_KC][QN_NB + 1];
     __shared__ double PJ[QN_KC][QN_NB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = c0 + ti * QN_NB, j0 = c0 + tj * QN_NB;
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
-    v4d acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int l15 = lane & 15, l4 = lane >> 4;
     // thread t stages rows (t >> 5) + 8 u, u = 0..7, column (t & 31) of each 64 x 32 panel chunk (coalesced along k)
     const int sr = tid >> 5, sk = tid & 31;
     const double* pi = W + (size_t)(i0 + sr) * ld + kb + sk;
@@ -193,6 +202,15 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, 
     double vi[8], vj[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) { vi[u] = pi[(size_t)(8 * u) * ld]; vj[u] = pj[(size_t)(8 * u) * ld]; }
+    // the accumulators start at -C (its loads overlap the first panel chunk): the result is -(acc) = C - P_i P_j'
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+                acc[a][b][reg] = -W[(size_t)(i0 + wi + a * 16 + l4 + 4 * reg) * ld + j0 + wj + b * 16 + l15];
     for (int kc = 0; kc < klen; kc += QN_KC) {
         if (kc) __syncthreads();
 #pragma unroll
@@ -202,7 +220,6 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, 
 #pragma unroll
             for (int u = 0; u < 8; ++u) { vi[u] = pi[(size_t)(8 * u) * ld + kc + QN_KC]; vj[u] = pj[(size_t)(8 * u) * ld + kc + QN_KC]; }
         }
-        const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
         for (int kk = 0; kk < QN_KC; kk += 4) {
             const double a0 = PI[kk + l4][wi + l15], a1 = PI[kk + l4][wi + 16 + l15];
@@ -213,16 +230,13 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, 
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
-    const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                double* p = W + (size_t)(i0 + wi + a * 16 + l4 + 4 * reg) * ld + j0 + wj + b * 16 + l15;
-                *p = *p - acc[a][b][reg];
-            }
+            for (int reg = 0; reg < 4; ++reg)
+                W[(size_t)(i0 + wi + a * 16 + l4 + 4 * reg) * ld + j0 + wj + b * 16 + l15] = -acc[a][b][reg];
 }
 
 // ---- triangular solves with a vector right-hand side, one launch per 64-block ----
