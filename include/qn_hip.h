@@ -70,6 +70,9 @@ int qn_partition(size_t n, int world, size_t* rows_per_rank, size_t* n_pad);
 int qn_comm_selftest(qn_context* ctx);
 /* collective (every rank calls it): one rank-tagged all-gather through the context's own exchange, verified on every rank */
 int qn_context_comm_check(qn_context* ctx);
+/* measurement aid: the fixed part (ms) of what a hipEventRecord / launch / hipEventRecord bracket on the idle context stream
+ * reports beyond the bracketed kernel's own duration: 2 * bracket(one empty kernel) - bracket(two empty kernels) */
+int qn_context_event_bracket_overhead(qn_context* ctx, int reps, double* out_ms);
 int qn_context_synchronize(qn_context* ctx);
 int qn_context_rank(const qn_context* ctx);
 int qn_context_world(const qn_context* ctx);

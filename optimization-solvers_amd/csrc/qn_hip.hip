@@ -301,6 +301,35 @@ extern "C" int qn_context_comm_check(qn_context* c) {
     return QN_OK;
 }
 
+__global__ void qn_empty_kernel() {}
+extern "C" int qn_context_event_bracket_overhead(qn_context* c, int reps, double* out_ms) {
+    if (!c || !out_ms || reps < 1) return fail(QN_ERROR_INPUT_PARAMS, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    hipEvent_t a = nullptr, b = nullptr;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    // A bracket around k empty kernels reports fixed + k * (one empty dispatch).  The fixed part -- what a bracket adds to the
+    // duration of the single kernel inside it -- is 2 * bracket(1) - bracket(2).
+    double total[2] = {0.0, 0.0};
+    for (int k = 1; k <= 2; ++k) {
+        for (int i = 0; i < reps + 5; ++i) {
+            HIPCHK(hipStreamSynchronize(c->stream)); // the launch meets an idle stream, as in synchronous mode
+            HIPCHK(hipEventRecord(a, c->stream));
+            for (int j = 0; j < k; ++j) hipLaunchKernelGGL(qn_empty_kernel, dim3(1), dim3(64), 0, c->stream);
+            HIPCHK(hipEventRecord(b, c->stream));
+            HIPCHK(hipEventSynchronize(b));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, a, b));
+            if (i >= 5) total[k - 1] += ms; // the first few carry one-off costs
+        }
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    const double b1 = total[0] / reps, b2 = total[1] / reps;
+    *out_ms = std::max(0.0, 2.0 * b1 - b2);
+    return QN_OK;
+}
+
 static int dev_alloc_zero(double** p, size_t count, hipStream_t st) {
     HIPCHK(hipMalloc((void**)p, count * sizeof(double)));
     HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(double), st));

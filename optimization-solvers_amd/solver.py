@@ -136,6 +136,12 @@ class Context:
         """Collective: one verified rank-tagged all-gather through this context's exchange (RCCL or host-staged)."""
         _check(A.lib().qn_context_comm_check(self.h))
 
+    def event_bracket_overhead_ms(self, reps=200):
+        """Mean elapsed time an event / launch / event bracket reports for an empty kernel on the idle stream."""
+        out = C.c_double(0.0)
+        _check(A.lib().qn_context_event_bracket_overhead(self.h, int(reps), C.byref(out)))
+        return out.value
+
     def close(self):
         if self.h:
             A.lib().qn_context_destroy(self.h)
