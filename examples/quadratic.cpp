@@ -49,6 +49,26 @@ int main() {
     bool threw = false;
     try { auto bad = MoreThuente::default_().with_c1(2.0); (void)bad; } catch (const SolverError& e) { threw = e.kind == SolverError::ErrorInputParams; }
     if (!threw) { std::printf("builder assert FAILED\n"); return 1; }
+    // backtracking.rs:65-113: LineSearch::compute_step_len on its own inside a hand-rolled gradient descent (gamma = 90)
+    {
+        const Floating g90 = 90.0;
+        auto fg3 = [&](const DVector& v) { return FuncEvalMultivariate(0.5 * (v[0] * v[0] + g90 * v[1] * v[1]), {v[0], g90 * v[1]}); };
+        DVector it{180.0, 152.0};
+        auto ls = BackTracking::new_(1e-4, 0.5);
+        const size_t max_iter = 1000;
+        size_t k3 = 1;
+        while (max_iter > k3) {
+            FuncEvalMultivariate ev = fg3(it);
+            if (ev.g()[0] * ev.g()[0] + ev.g()[1] * ev.g()[1] < 1e-12) break;
+            DVector dir{-ev.g()[0], -ev.g()[1]};
+            const Floating t = ls.compute_step_len(it, ev, dir, fg3, max_iter);
+            it[0] += t * dir[0];
+            it[1] += t * dir[1];
+            ++k3;
+        }
+        if (!(std::fabs(it[0]) < 1e-6)) { std::printf("backtracking compute_step_len FAILED\n"); return 1; } // backtracking.rs:111
+        std::printf("line search alone: %zu steps\n", k3);
+    }
     std::printf("ok\n");
     return 0;
 }

@@ -178,6 +178,13 @@ typedef void (*qn_callback_fn)(void* user, qn_solver* solver);
 int qn_minimize(qn_solver* s, qn_linesearch* ls, const qn_oracle* oracle, size_t max_iter_solver,
                 size_t max_iter_line_search, qn_callback_fn callback, void* callback_user);
 
+/* LineSearch::compute_step_len (line_search/mod.rs:14-23) on its own, as the reference's line-search tests call it
+ * (backtracking.rs:65-113, morethuente.rs:303-352, morethuente_b.rs:330-385): step length along `direction` from `x_k`, where
+ * (f_k, g_k) is the evaluation at x_k.  Runs the device state machine from the line search's first statement to its return;
+ * `ls` is updated as by qn_minimize (MoreThuenteB keeps its clipped t_max). */
+int qn_compute_step_len(qn_context* ctx, qn_linesearch* ls, const double* x_k_host, double f_k, const double* g_k_host,
+                        const double* direction_host, size_t n, const qn_oracle* oracle, size_t max_iter, double* step_out);
+
 /* getters generated by derive_getters on bfgs.rs:3-12, plus LineSearchSolver::xk/k (bfgs.rs:52-63) */
 size_t qn_solver_n(const qn_solver* s);
 size_t qn_solver_k(const qn_solver* s);                    /* k() */

@@ -80,10 +80,37 @@ class Context {
     static Context& default_context() { static Context c(0); return c; }
 };
 
+// LineSearch::compute_step_len (line_search/mod.rs:14-23) for a line-search mirror `LS` and a host closure
+template <class LS, class Oracle>
+inline Floating compute_step_len(LS& ls, const DVector& x_k, const FuncEvalMultivariate& eval_x_k, const DVector& direction_k, Oracle&& oracle,
+                                 size_t max_iter, Context& ctx = Context::default_context()) {
+    using OracleT = std::remove_reference_t<Oracle>;
+    OracleT* op = &oracle;
+    auto tramp = [](void* user, const double* x, size_t n, double* f, double* g) -> int {
+        DVector xv(x, x + n);
+        FuncEvalMultivariate ev = (*static_cast<OracleT*>(user))(xv);
+        *f = ev.f();
+        for (size_t i = 0; i < n; ++i) g[i] = ev.g()[i];
+        return 0;
+    };
+    qn_oracle o{};
+    o.kind = QN_ORACLE_HOST;
+    o.memoize = 0;
+    o.host_fn = tramp;
+    o.host_user = op;
+    Floating t = 0;
+    check(qn_compute_step_len(ctx.handle(), &ls.ffi(), x_k.data(), eval_x_k.f(), eval_x_k.g().data(), direction_k.data(), x_k.size(), &o, max_iter, &t));
+    return t;
+}
+
 // morethuente.rs:6-62
 class MoreThuente {
     qn_linesearch s_;
   public:
+    template <class Oracle>
+    Floating compute_step_len(const DVector& x_k, const FuncEvalMultivariate& eval_x_k, const DVector& direction_k, Oracle&& oracle, size_t max_iter) {
+        return optimization_solvers::compute_step_len(*this, x_k, eval_x_k, direction_k, oracle, max_iter);
+    }
     MoreThuente() { qn_morethuente_default(&s_); }
     static MoreThuente default_() { return MoreThuente(); }
     MoreThuente with_deltas(Floating dmin, Floating d, Floating dmax) && { check(qn_morethuente_with_deltas(&s_, dmin, d, dmax)); return *this; }
@@ -101,6 +128,10 @@ class MoreThuente {
 class BackTracking {
     qn_linesearch s_;
   public:
+    template <class Oracle>
+    Floating compute_step_len(const DVector& x_k, const FuncEvalMultivariate& eval_x_k, const DVector& direction_k, Oracle&& oracle, size_t max_iter) {
+        return optimization_solvers::compute_step_len(*this, x_k, eval_x_k, direction_k, oracle, max_iter);
+    }
     BackTracking(Floating c1, Floating beta) { qn_backtracking_new(&s_, c1, beta); }
     static BackTracking new_(Floating c1, Floating beta) { return BackTracking(c1, beta); }
     qn_linesearch& ffi() { return s_; }

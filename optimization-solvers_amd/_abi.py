@@ -91,6 +91,8 @@ SYMBOLS = [
     ("qn_solver_reset", C.c_int, [C.c_void_p, dp]),
     ("qn_solver_set_bounds", C.c_int, [C.c_void_p, dp, dp]),
     ("qn_minimize", C.c_int, [C.c_void_p, C.POINTER(LineSearchStruct), C.POINTER(OracleStruct), C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+    ("qn_compute_step_len", C.c_int, [C.c_void_p, C.POINTER(LineSearchStruct), dp, C.c_double, dp, dp, C.c_size_t, C.POINTER(OracleStruct), C.c_size_t,
+                             C.POINTER(C.c_double)]),
     ("qn_solver_n", C.c_size_t, [C.c_void_p]),
     ("qn_solver_k", C.c_size_t, [C.c_void_p]),
     ("qn_solver_tol", C.c_double, [C.c_void_p]),

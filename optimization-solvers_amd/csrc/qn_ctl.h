@@ -40,7 +40,8 @@ enum QnState : int32_t {
     QN_ST_AFTER_NEXT,
     QN_ST_AFTER_U,
     QN_ST_ITER_END,
-    QN_ST_AFTER_NEWTON
+    QN_ST_AFTER_NEWTON,
+    QN_ST_LS_ONLY // qn_compute_step_len: g.d for the caller's direction, then the line search alone
 };
 
 struct QnTraceRec { // == qn_trace_rec (include/qn_hip.h)
@@ -81,7 +82,8 @@ struct QnCtl {
     double hp_yu, hp_ug, hp_sg;
 
     // ---- bounded variants (row f4) ----
-    int32_t bounded, req_project, last_projected, _padb;
+    int32_t bounded, req_project, last_projected;
+    int32_t ls_only; // LineSearch::compute_step_len on its own (line_search/mod.rs:14-23): stop when the line search returns
     double mtb_cand; // min over i of the step to the box along d (morethuente_b.rs:185-198)
     double bt_diff2; // ||P(x + t d) - x||^2 of the last projected trial (backtracking_b.rs:33-34)
 

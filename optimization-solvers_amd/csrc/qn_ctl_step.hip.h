@@ -295,7 +295,10 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
             else { c.t *= c.bt_beta; c.ls_i++; c.state = QN_ST_BT_LOOP; }
         } break;
 
+        case QN_ST_LS_ONLY: return; // g.d needs all threads
+
         case QN_ST_AFTER_LS: {
+            if (c.ls_only) { c.status = 0; c.phase = QN_PH_DONE; break; } // compute_step_len returns the step, nothing else
             if (c.method == 2 || c.method == 3) return; // gradient descent / Newton: the default hook x += step*d needs all threads
             req_eval_t(c, c.ls_result, QN_ST_AFTER_NEXT, 1); // bfgs.rs:94,98: oracle(x + step*d)
         } break;
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
             if (kind == QN_REQ_T) { c.last_valid = 1; c.last_t = c.req_t; c.f_last = cons_f; c.gd_last = cons_gd; }
             else c.last_valid = 0;
         }
-        if (expect_phase == QN_PH_IDLE) c.state = QN_ST_BEGIN;
+        if (expect_phase == QN_PH_IDLE) c.state = c.ls_only ? QN_ST_LS_ONLY : QN_ST_BEGIN;
         else if (expect_phase == QN_PH_REQ_EVAL || expect_phase == QN_PH_REQ_HPASS || expect_phase == QN_PH_REQ_NEWTON) c.state = c.after_state;
         // (QN_PH_REQ_HPASS_EVAL was turned into QN_PH_REQ_EVAL by the commit above)
         c.phase = QN_PH_RUNNING;
@@ -559,6 +562,39 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                 if (c.pending) c.n_hpass_rw++;
                 c.pending = 0;
                 c.gd0 = p[0]; c.d_finite = p[1] == 0.0; c.last_valid = 0;
+                c.state = QN_ST_LS_BEGIN;
+            }
+        } break;
+
+        case QN_ST_LS_ONLY: { // x, g = g(x), d uploaded by the host; phi'(0) = g.d (morethuente.rs:137 / backtracking.rs:32)
+            double p[2] = {0.0, 0.0};
+            const bool want_cand = c.ls_kind == 2;
+            double cand = INFINITY;
+            for (int i = tid; i < n_pad; i += tpb) {
+                const double gi = vg[i], di = vd[i];
+                p[0] = __builtin_fma(gi, di, p[0]);
+                p[1] += isfinite(di) ? 0.0 : 1.0;
+                if (want_cand && i < n) { // morethuente_b.rs:185-198
+                    const double xi = vx[i];
+                    double v = INFINITY;
+                    if (di > 0.0) v = (V.lub[i] - xi) / di; else if (di < 0.0) v = (V.llb[i] - xi) / di;
+                    cand = fmin(v, cand);
+                }
+            }
+            ctl_block_sum<2>(p, lds);
+            if (want_cand) cand = -ctl_block_fmax(-cand, lds);
+            if (c.small_n) {
+                __threadfence_block();
+                __syncthreads();
+                if (tid == 0) p[0] = ref_dot(V.g, V.d, n);
+            }
+            if (tid == 0) {
+                c.k = 0; c.status = -1;
+                c.n_oracle_calls = 0; c.n_oracle_evals = 0;
+                c.tr_n_evals = 0; c.tr_ls_iters = 0; c.tr_ls_cases = 0; c.tr_ndigits = 0; c.tr_updated = 0;
+                c.mtb_cand = cand;
+                c.gd0 = p[0]; c.d_finite = p[1] == 0.0; c.last_valid = 0;
+                c.ls_result = NAN;
                 c.state = QN_ST_LS_BEGIN;
             }
         } break;

@@ -1331,8 +1331,33 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
     return QN_OK;
 }
 
+static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, size_t max_iter_solver, size_t max_iter_line_search,
+                         qn_callback_fn callback, void* callback_user, int ls_only, double ls_f0);
+
 extern "C" int qn_minimize(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, size_t max_iter_solver,
                            size_t max_iter_line_search, qn_callback_fn callback, void* callback_user) {
+    return minimize_impl(s, ls, o, max_iter_solver, max_iter_line_search, callback, callback_user, 0, 0.0);
+}
+
+// LineSearch::compute_step_len (line_search/mod.rs:14-23) on its own: the same device state machine entered at the line search
+extern "C" int qn_compute_step_len(qn_context* ctx, qn_linesearch* ls, const double* x_k_host, double f_k, const double* g_k_host,
+                                   const double* direction_host, size_t n, const qn_oracle* oracle, size_t max_iter, double* step_out) {
+    if (!ctx || !ls || !x_k_host || !g_k_host || !direction_host || !oracle || !step_out || n == 0)
+        return fail(QN_ERROR_INPUT_PARAMS, "null argument");
+    qn_solver* s = nullptr;
+    QNCHK(qn_solver_create(ctx, QN_GRADIENT_DESCENT, 0.0, x_k_host, n, &s)); // owns x and the work vectors; no inverse Hessian
+    int st = QN_OK;
+    hipError_t e = hipMemcpyAsync(s->V.g, g_k_host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->V.d, direction_host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, std::string("compute_step_len upload: ") + hipGetErrorString(e));
+    if (st == QN_OK) st = minimize_impl(s, ls, oracle, 1, max_iter, nullptr, nullptr, 1, f_k);
+    if (st == QN_OK) *step_out = s->hctl->ls_result;
+    qn_solver_destroy(s);
+    return st;
+}
+
+static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, size_t max_iter_solver, size_t max_iter_line_search,
+                         qn_callback_fn callback, void* callback_user, int ls_only, double ls_f0) {
     if (!s || !ls || !o) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
     qn_context* c = s->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -1380,6 +1405,8 @@ extern "C" int qn_minimize(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, 
     h->trace_x = s->trace_x;
     h->bounded = s->bounded;
     h->req_project = 0; h->last_projected = 0; h->mtb_cand = INFINITY;
+    h->ls_only = ls_only;
+    if (ls_only) { h->f_k = ls_f0; h->have_cur_eval = 0; h->have_dir = 0; h->last_valid = 0; }
     h->small_n = (s->n <= QN_SMALL_N && c->world == 1) ? 1 : 0;
     if (h->small_n && h->pending) QNCHK(flush_pending(s));
     // fused fast path: device quadratic, memoised, BFGS/DFP, no callback, one column split, n > 5

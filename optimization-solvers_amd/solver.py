@@ -171,7 +171,45 @@ def default_context():
     return _default_ctx
 
 
-class MoreThuente:
+class _LineSearch:
+    """LineSearch (line_search/mod.rs:14-23): `compute_step_len` on its own, as the reference's line-search tests call it."""
+
+    def compute_step_len(self, x_k, eval_x_k, direction_k, oracle, max_iter, ctx=None, memoize=None):
+        ctx = ctx or (oracle.ctx if isinstance(oracle, Objective) else default_context())
+        x, d = _f64(x_k), _f64(direction_k)
+        f0, g0 = (eval_x_k.f(), _f64(eval_x_k.g())) if isinstance(eval_x_k, FuncEvalMultivariate) else (float(eval_x_k[0]), _f64(eval_x_k[1]))
+        o = A.OracleStruct()
+        keep, err = [], []
+        if isinstance(oracle, Objective):
+            o.kind = A.ORACLE_OBJECTIVE
+            o.objective = oracle.h
+            o.memoize = 1 if memoize is None else int(memoize)
+        else:
+            def tramp(_u, xp, nn, fp, gp):
+                try:
+                    res = oracle(np.ctypeslib.as_array(xp, shape=(nn,)).copy())
+                    f, g = (res.f(), res.g()) if isinstance(res, FuncEvalMultivariate) else res[:2]
+                    fp[0] = float(f)
+                    np.ctypeslib.as_array(gp, shape=(nn,))[:] = np.asarray(g, dtype=np.float64)
+                    return 0
+                except Exception as e:  # noqa: BLE001 -- a panicking closure aborts the run
+                    err.append(e)
+                    return 1
+            cfn = A.HOST_ORACLE_FN(tramp)
+            keep.append(cfn)
+            o.kind = A.ORACLE_HOST
+            o.host_fn = C.cast(cfn, C.c_void_p)
+            o.memoize = 0 if memoize is None else int(memoize)
+        t = C.c_double(0.0)
+        status = A.lib().qn_compute_step_len(ctx.h, C.byref(self.s), x.ctypes.data_as(A.dp), float(f0), g0.ctypes.data_as(A.dp),
+                                             d.ctypes.data_as(A.dp), x.size, C.byref(o), int(max_iter), C.byref(t))
+        if err:
+            raise err[0]
+        _check(status)
+        return t.value
+
+
+class MoreThuente(_LineSearch):
     """morethuente.rs:6-62"""
 
     def __init__(self):
@@ -203,7 +241,7 @@ class MoreThuente:
         return self
 
 
-class BackTracking:
+class BackTracking(_LineSearch):
     """backtracking.rs:3-11"""
 
     def __init__(self, c1, beta):
@@ -242,7 +280,7 @@ class MoreThuenteB(MoreThuente):
         return self.s.t_max
 
 
-class BackTrackingB:
+class BackTrackingB(_LineSearch):
     """backtracking_b.rs: projected trial points, modified Armijo rule."""
 
     def __init__(self, c1, beta, lower_bound, upper_bound):
