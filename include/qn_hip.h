@@ -188,6 +188,7 @@ int qn_compute_step_len(qn_context* ctx, qn_linesearch* ls, const double* x_k_ho
 /* getters generated by derive_getters on bfgs.rs:3-12, plus LineSearchSolver::xk/k (bfgs.rs:52-63) */
 size_t qn_solver_n(const qn_solver* s);
 size_t qn_solver_k(const qn_solver* s);                    /* k() */
+int qn_solver_set_k(qn_solver* s, size_t k);               /* k_mut() (bfgs.rs:58-63) */
 double qn_solver_tol(const qn_solver* s);                  /* tol() */
 int qn_solver_get_x(qn_solver* s, double* out_host);       /* x() / xk() */
 int qn_solver_set_x(qn_solver* s, const double* x_host);   /* xk_mut() */

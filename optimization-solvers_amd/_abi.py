@@ -95,6 +95,7 @@ SYMBOLS = [
                              C.POINTER(C.c_double)]),
     ("qn_solver_n", C.c_size_t, [C.c_void_p]),
     ("qn_solver_k", C.c_size_t, [C.c_void_p]),
+    ("qn_solver_set_k", C.c_int, [C.c_void_p, C.c_size_t]),
     ("qn_solver_tol", C.c_double, [C.c_void_p]),
     ("qn_solver_get_x", C.c_int, [C.c_void_p, dp]),
     ("qn_solver_set_x", C.c_int, [C.c_void_p, dp]),

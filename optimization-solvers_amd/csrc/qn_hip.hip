@@ -887,6 +887,11 @@ extern "C" int qn_solver_reset(qn_solver* s, const double* x0_host) {
     return poke_ctl(s);
 }
 
+extern "C" int qn_solver_set_k(qn_solver* s, size_t k) { // k_mut() (bfgs.rs:58-63); minimize() resets it to 0 itself (ls_solver.rs:74-76)
+    if (!s) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
+    s->hctl->k = (int64_t)k;
+    return poke_ctl(s);
+}
 extern "C" int qn_solver_set_x(qn_solver* s, const double* x_host) {
     HIPCHK(hipSetDevice(s->ctx->device));
     HIPCHK(hipMemcpyAsync(s->V.x, x_host, s->n * sizeof(double), hipMemcpyHostToDevice, s->ctx->stream));

@@ -459,6 +459,12 @@ class _SolverBase:
     def k(self):
         return A.lib().qn_solver_k(self.h)
 
+    def set_k(self, k):  # k_mut(), bfgs.rs:58-63
+        _check(A.lib().qn_solver_set_k(self.h, int(k)))
+
+    def identity(self):  # derive_getters on bfgs.rs:9 `identity: DMatrix<Floating>`; the GPU solver keeps no copy of it
+        return np.eye(self.n)
+
     def tol(self):
         return A.lib().qn_solver_tol(self.h)
 
