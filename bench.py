@@ -6,8 +6,9 @@
 
 One "step" = one BFGS iteration (direction, More-Thuente line search, rank-2 inverse-Hessian update) on the
 device-resident objective f = 1/2 x'Qx - b'x; Q, H, and every vector are in HBM before the timed region.
-N = 1 runs BASELINE.json configs[1] (n = 4096); N > 1 runs configs[2]'s problem (n = 32768) with H and Q
-row-sharded over the N ranks and one RCCL all-gather per mat-vec pass ("scaling": "strong" over N = 2,4,8).
+N = 1 runs BASELINE.json configs[1] (n = 4096; one rank streams only the upper block triangle of the symmetric H and Q);
+N > 1 runs configs[2]'s problem (n = 32768) with H and Q row-sharded over the N ranks and one RCCL all-gather per mat-vec
+pass ("scaling": "strong" over N = 2,4,8).
 Prints ONE JSON line on rank 0.  The product path is libqn_hip.so (hand-written gfx950 kernels); the CPU
 oracle is used only for the `cpu_baseline` leg.  No GPU => hard failure, never a fallback.
 """
@@ -209,9 +210,11 @@ def main():
         t_e = p1["t_eval_ms"] - p0["t_eval_ms"]
         n_c = p1["n_ctl_timed"] - p0["n_ctl_timed"]
         t_c = p1["t_ctl_ms"] - p0["t_ctl_ms"]
-        # algorithmic bytes of one h_pass launch on this rank: read + write of the rank's n/P x n f64 shard
-        alg_h = 16.0 * n * n / world
-        alg_q = 8.0 * n * n / world
+        # algorithmic bytes of one h_pass launch on this rank: read + write of what the pass streams -- the rank's n/P x n f64
+        # shard, or (one rank, symmetric-storage path) the upper block triangle's 128 x 128 tiles of the symmetric H
+        mat = float(p1["matrix_bytes_per_pass"])
+        alg_h = 2.0 * mat
+        alg_q = mat
         # launches that were predicated off (pipelined mode) finish in ~2 us; keep them out of the average
         # An event / launch / event bracket reports the kernel plus a fixed launch / event cost.  It is NOT subtracted: measured
         # against rocprofv3 on the same run the raw bracket is 2-3 us (4 %) above the profiler's kernel duration, so `achieved`
@@ -219,7 +222,9 @@ def main():
         h_launch_ms = t_h / max(n_h, 1)
         bracket_ms = ctx.event_bracket_overhead_ms(200)
         ach = alg_h / (h_launch_ms * 1e-3) / 1e9 if n_h else None
-        roofline = {"bound": "hbm", "kernel": "h_pass_kernel (fused rank-2 update + 2-RHS mat-vec over H)",
+        sym_pass = world == 1 and mat < 8.0 * n * n
+        roofline = {"bound": "hbm", "kernel": ("sym_hpass_tile_kernel (rank-2 update + row and column dots of [y, g+] over the upper block triangle of H)"
+                                               if sym_pass else "h_pass_fused_kernel (fused rank-2 update + 2-RHS mat-vec over the rank's rows of H)"),
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                     "traffic": None,
                     "achievable_note": "plain read+write streams reach 4.9-5.4 TB/s on this device (hipMemcpy D2D 5.0 TB/s; "
@@ -234,25 +239,30 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                roofline["traffic"] = json.load(open(pmc)).get(f"n{n}_p{world}", {}).get("h_pass_bytes_per_launch")
+                roofline["traffic"] = json.load(open(pmc)).get(f"n{n}_p{world}" + ("_sym" if sym_pass else ""), {}).get("h_pass_bytes_per_launch")
             except Exception:  # noqa: BLE001
                 pass
 
     if rank == 0:
-        b_iter = 16.0 * n * n + 8.0 * n * n * (evals / steps)
+        mat_bytes = float(st1["matrix_bytes_per_pass"])  # per rank: the row shard, or the upper block triangle (symmetric storage)
+        symmetric = world == 1 and mat_bytes < 8.0 * n * n
+        b_iter = world * (2.0 * mat_bytes + mat_bytes * (evals / steps))
         out = {
             "metric": METRIC, "value": its, "unit": "iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BFGS + MoreThuente::default (max_iter_line_search 20), n={n} convex quadratic "
                                    f"(random SPD Q, kappa=1e3, seed 0x5EED0001), f64, {world}xMI355X"
-                                   + ((", H and Q row-sharded, " + ("host-staged" if host_exchange else "RCCL") + " all-gather per pass") if world > 1 else ""),
+                                   + ((", H and Q row-sharded, " + ("host-staged" if host_exchange else "RCCL") + " all-gather per pass") if world > 1 else "")
+                                   + (", symmetric storage: only the upper block triangle of H and Q is streamed" if symmetric else ""),
+                       "matrix_layout": "upper block triangle (128 x 128 tiles) of the symmetric H and Q" if symmetric else "full row-major, row-sharded",
                        "n": n, "line_search": args.ls, "tol": 1e-10, "parallelism": f"row-shard x{world}",
                        "exchange": "none" if world == 1 else ("host-staged gloo (rehearsal)" if host_exchange else "rccl all-gather"),
                        **({"rccl_error": rccl_error} if rccl_error else {})},
             "iteration_accounting": {"oracle_calls_reference_sequence": calls, "oracle_evaluations_distinct": evals,
                                      "restarts_after_convergence": restarts,
                                      "algorithmic_bytes_per_iteration": b_iter,
+                                     "full_matrix_bytes_per_iteration_survey_8d": 16.0 * n * n + 8.0 * n * n * (evals / steps),
                                      "whole_iteration_hbm_frac": b_iter * its / (world * HBM_PEAK_GBS * 1e9),
                                      "h_bytes_counted": h_bytes, "objective_bytes_counted": obj_bytes,
                                      "launches": st1["launches"] - st0["launches"], "host_syncs": st1["host_syncs"] - st0["host_syncs"]},
@@ -267,6 +277,7 @@ def main():
                 ctx1 = qn.Context(device=local_rank % max(torch.cuda.device_count(), 1))
                 obj1 = qn.Quadratic.synthetic(n, SEED, diag, b, ctx=ctx1)
                 s1 = qn.BFGS(1e-10, x0, ctx=ctx1)
+                s1.set_tiling(-3, 0)  # the same algorithm as the N-rank run: fused row kernels on the full matrices
                 ref_steps = min(steps, 50)
                 run_iterations(qn, s1, ls, obj1, x0, min(warmup, 5))
                 ctx1.synchronize()
@@ -275,8 +286,17 @@ def main():
                 ctx1.synchronize()
                 dt1 = time.perf_counter() - t1
                 out["strong_scaling_ref"] = {"n_gpus": 1, "value": ref_steps / dt1, "unit": "iterations/s", "steps": ref_steps,
-                                             "note": f"same n={n} workload, unsharded, on rank 0's GPU after the timed region"}
-                del s1, obj1, ctx1
+                                             "note": f"same n={n} workload and the same kernels (full row-major matrices), unsharded, on rank 0's GPU "
+                                                     "after the timed region"}
+                # for the record: one GPU with the symmetric-storage path (half the bytes; not available row-sharded yet)
+                s2 = qn.BFGS(1e-10, x0, ctx=ctx1)
+                run_iterations(qn, s2, ls, obj1, x0, min(warmup, 5))
+                ctx1.synchronize()
+                t2 = time.perf_counter()
+                run_iterations(qn, s2, ls, obj1, x0, ref_steps)
+                ctx1.synchronize()
+                out["strong_scaling_ref"]["single_gpu_symmetric_storage_value"] = ref_steps / (time.perf_counter() - t2)
+                del s1, s2, obj1, ctx1
             except Exception as e:  # noqa: BLE001 -- the reference leg must never lose the bench line
                 out["strong_scaling_ref"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

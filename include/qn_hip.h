@@ -225,6 +225,8 @@ typedef struct {
     uint64_t host_syncs;       /* stream synchronisations */
     double   t_hpass_ms, t_eval_ms, t_ctl_ms, t_comm_ms; /* HIP-event time per kernel class (profiling mode) */
     uint64_t n_hpass_timed, n_eval_timed, n_ctl_timed, n_comm_timed;
+    uint64_t matrix_bytes_per_pass; /* bytes of H (or Q) one pass of the last run streams on this rank: the rank's rows, or -- on the
+                                       symmetric-storage path of a single rank -- the upper block triangle's 128 x 128 tiles */
 } qn_stats;
 int qn_solver_get_stats(qn_solver* s, qn_stats* out);
 /* profiling != 0: bracket every launch with HIP events on the solver's stream (slower; for roofline reports) */
@@ -232,7 +234,9 @@ int qn_solver_set_profiling(qn_solver* s, int on);
 /* 0 = pipelined (device-resident control, no host sync per decision; default for memoised device objectives),
  * 1 = synchronous (host reads the control block after every step; always used with host oracles / callbacks) */
 int qn_solver_set_sync_mode(qn_solver* s, int sync);
-/* tuning: rows per workgroup tile (4, 8 or 16), column splits (>= 1); 0 keeps the default */
+/* tuning: rows per workgroup tile (4, 8 or 16), column splits (>= 1); 0 keeps the default.  Diagnostics: rows = -1 selects the
+ * generic (non-fused) kernels, -2 the fused kernels without the deferred update step, -3 the fused ROW kernels on the full
+ * matrices instead of the symmetric-storage tiles; col_splits = 100 + U selects U column chunks per loop trip */
 int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits);
 
 /* ---------------------------------------------------------------------------------------------

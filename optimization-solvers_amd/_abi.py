@@ -47,7 +47,8 @@ class Stats(C.Structure):
                 ("h_passes", C.c_uint64), ("h_bytes", C.c_uint64), ("obj_bytes", C.c_uint64),
                 ("launches", C.c_uint64), ("host_syncs", C.c_uint64),
                 ("t_hpass_ms", C.c_double), ("t_eval_ms", C.c_double), ("t_ctl_ms", C.c_double), ("t_comm_ms", C.c_double),
-                ("n_hpass_timed", C.c_uint64), ("n_eval_timed", C.c_uint64), ("n_ctl_timed", C.c_uint64), ("n_comm_timed", C.c_uint64)]
+                ("n_hpass_timed", C.c_uint64), ("n_eval_timed", C.c_uint64), ("n_ctl_timed", C.c_uint64), ("n_comm_timed", C.c_uint64),
+                ("matrix_bytes_per_pass", C.c_uint64)]
 
 
 # every symbol include/qn_hip.h declares: (name, restype, argtypes)

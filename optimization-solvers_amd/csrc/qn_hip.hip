@@ -617,6 +617,10 @@ struct qn_solver {
     // Newton: Hessian work matrix (row-major, ld = nw), right-hand sides, staging for host Hessians, failure flag
     double *newton_w = nullptr, *newton_x = nullptr, *newton_hsrc = nullptr, *newton_invl = nullptr, *newton_inv2 = nullptr;
     bool newton_big = false;
+    // symmetric-storage fast path (qn_sym.hip.h): slot buffer, tile count per side, opt-out, "user installed a non-symmetric H"
+    double* sym_part = nullptr;
+    int sym_nb = 0;
+    bool no_sym = false, h_nonsym = false;
     int* newton_fail = nullptr;
     size_t newton_n64 = 0;
     std::vector<double> newton_hhost;
@@ -672,11 +676,16 @@ static void prof_collect(qn_solver* s) {
 }
 
 // buffers of the fused fast path (allocated on first use; partial buffers depend on the row tile R)
-static int solver_alloc_fused(qn_solver* s) {
+static int solver_alloc_fused(qn_solver* s, bool sym) {
     const size_t np = s->T.n_pad;
     hipStream_t st = s->ctx->stream;
     if (!s->fused_block) QNCHK(dev_alloc_zero(&s->fused_block, 10 * np, st));
-    const int nblk = s->T.rpr / s->R;
+    const int nblk = sym ? (int)(np / QN_TB) : s->T.rpr / s->R; // partial-sum rows: 128-row blocks or R-row workgroups
+    if (sym && s->sym_nb != nblk) {
+        if (s->sym_part) { HIPCHK(hipFree(s->sym_part)); s->sym_part = nullptr; }
+        QNCHK(dev_alloc_zero(&s->sym_part, (size_t)nblk * nblk * 2 * QN_TB, st));
+        s->sym_nb = nblk;
+    }
     if (nblk != s->fused_nblk) {
         if (s->fused_evp) { HIPCHK(hipFree(s->fused_evp)); s->fused_evp = nullptr; }
         if (s->fused_hpp) { HIPCHK(hipFree(s->fused_hpp)); s->fused_hpp = nullptr; }
@@ -751,7 +760,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     for (auto& e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
-    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail);
+    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
@@ -801,6 +810,7 @@ extern "C" int qn_solver_set_profiling(qn_solver* s, int on) { s->profiling = on
 extern "C" int qn_solver_set_sync_mode(qn_solver* s, int sync) { s->sync_mode = sync; return QN_OK; }
 extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits) {
     if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; }
+    if (rows_per_block == -3) { s->no_sym = 1; rows_per_block = 0; }   // diagnostics: fused row kernels on the full matrices
     if (rows_per_block == -2) { s->no_defer = 1; rows_per_block = 0; } // diagnostics: fused kernels, update step not deferred // diagnostics: -1 selects the generic (non-fused) kernels
     if (rows_per_block != 0 && rows_per_block != 2 && rows_per_block != 4 && rows_per_block != 8 && rows_per_block != 16)
         return fail(QN_ERROR_INPUT_PARAMS, "rows_per_block must be 2, 4, 8 or 16");
@@ -1012,6 +1022,10 @@ extern "C" int qn_solver_set_inv_hessian(qn_solver* s, const double* h) {
         for (size_t j = 0; j < n; ++j) rows[r * np + j] = h[i + j * n];
     }
     HIPCHK(hipMemcpy(s->H, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
+    s->h_nonsym = false; // the symmetric-storage path needs H == H' bit for bit (BFGS / DFP keep it so from a symmetric start)
+    for (size_t i = 0; i < n && !s->h_nonsym; ++i)
+        for (size_t j = i + 1; j < n; ++j)
+            if (h[i + j * n] != h[j + i * n]) { s->h_nonsym = true; break; }
     s->hctl->pending = 0; s->hctl->have_dir = 0;
     return poke_ctl(s);
 }
@@ -1121,6 +1135,7 @@ struct Run {
     qn_objective* obj;
     int oracle_tpl; // QN_ORACLE_GENERIC / QN_ORACLE_QUAD
     bool fused;
+    bool sym = false; // fused path on the upper block triangle of H and Q (qn_sym.hip.h)
 };
 
 static int launch_ctl_mask(Run& r, int expect_mask) {
@@ -1171,6 +1186,21 @@ static int enqueue_eval_fused(Run& r, int after_h) {
     QnEvalFusedArgs a{};
     a.Q = r.obj->Q; a.T = s->T; a.T.cs = 1; a.F = s->V.F; a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_EVAL;
     a.after_h = after_h; a.world = c->world;
+    if (r.sym) {
+        QnSymEvalArgs y{};
+        y.Q = r.obj->Q; y.T = a.T; y.F = a.F; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_EVAL; y.after_h = after_h; y.nb = s->sym_nb; y.part = s->sym_part;
+        {
+            ProfScope ps(s, KC_EVAL);
+            hipLaunchKernelGGL(sym_eval_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(256), 0, c->stream, y);
+        }
+        {
+            ProfScope ps(s, KC_CTL);
+            hipLaunchKernelGGL(sym_eval_reduce_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
+        }
+        s->stats.launches += 2;
+        HIPCHK(hipGetLastError());
+        return QN_OK;
+    }
     {
         ProfScope ps(s, KC_EVAL);
         QN_DISPATCH_RU(launch_eval_fused, s->R, s->U, c->stream, a);
@@ -1190,6 +1220,21 @@ static int enqueue_hpass_fused(Run& r) {
     qn_context* c = s->ctx;
     QnHPassFusedArgs a{};
     a.H = s->H; a.T = s->T; a.T.cs = 1; a.F = s->V.F; a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_HPASS;
+    if (r.sym) {
+        QnSymHPassArgs y{};
+        y.H = s->H; y.T = a.T; y.F = a.F; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_HPASS; y.nb = s->sym_nb; y.part = s->sym_part;
+        {
+            ProfScope ps(s, KC_HPASS);
+            hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(256), 0, c->stream, y);
+        }
+        {
+            ProfScope ps(s, KC_CTL);
+            hipLaunchKernelGGL(sym_hpass_reduce_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
+        }
+        s->stats.launches += 2;
+        HIPCHK(hipGetLastError());
+        return QN_OK;
+    }
     {
         ProfScope ps(s, KC_HPASS);
         QN_DISPATCH_RU(launch_hpass_fused, s->R, s->U, c->stream, a);
@@ -1419,10 +1464,12 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
               s->qcs == 1 && !h->small_n && !s->no_fused && !s->bounded && !ls_bounded; // bounded variants (row f4): generic path
     h->fused = r.fused ? 1 : 0;
     s->V.fused_hint = h->fused;
+    // ... and on the upper block triangle only (half the bytes) when H and Q are whole 128-tiles on one rank
+    r.sym = r.fused && c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
     h->defer_u = 0;
     h->no_defer = s->no_defer;
     if (r.fused) { // import the canonical state (x, pending s and u) into the fused buffers
-        QNCHK(solver_alloc_fused(s));
+        QNCHK(solver_alloc_fused(s, r.sym));
         s->V.F.b = r.obj->b;
         const size_t vb = (size_t)s->T.n_pad * sizeof(double);
         HIPCHK(hipMemcpyAsync(s->V.F.X0, s->V.x, vb, hipMemcpyDeviceToDevice, c->stream));
@@ -1482,6 +1529,11 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             }
         }
     }
+    if (r.sym) { // the run maintained the upper block triangle of H only: restore the lower one
+        const int b32 = s->T.n_pad / 32;
+        hipLaunchKernelGGL(sym_mirror_kernel, dim3(b32, b32), dim3(256), 0, c->stream, s->H, s->T.n_pad);
+        HIPCHK(hipGetLastError());
+    }
     if (r.fused) { // export back to the canonical buffers
         const size_t np = s->T.n_pad, vb = np * sizeof(double);
         HIPCHK(hipMemcpyAsync(s->V.x, s->V.F.X0 + (size_t)h->xc * np, vb, hipMemcpyDeviceToDevice, c->stream));
@@ -1496,9 +1548,11 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     s->stats.oracle_calls = h->n_oracle_calls;
     s->stats.oracle_evals = h->n_oracle_evals;
     s->stats.h_passes = h->n_hpasses;
-    const uint64_t shard = (uint64_t)s->T.rpr * (uint64_t)s->T.n_pad * 8ull;
+    uint64_t shard = (uint64_t)s->T.rpr * (uint64_t)s->T.n_pad * 8ull;
+    if (r.sym) shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb + 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull; // the streamed tiles
     s->stats.h_bytes = (h->n_hpasses + h->n_hpass_rw) * shard;
     s->stats.obj_bytes = (r.oracle_tpl == QN_ORACLE_QUAD) ? h->n_oracle_evals * shard : 0;
+    s->stats.matrix_bytes_per_pass = shard;
     if (status == QN_ABNORMAL_TERMINATION) return fail(status, "solver state machine aborted");
     return status;
 }

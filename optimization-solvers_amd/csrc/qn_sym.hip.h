@@ -1,0 +1,385 @@
+// qn_sym.hip.h -- the fused fast path on the UPPER BLOCK TRIANGLE of the two symmetric matrices (single rank).
+//
+// The inverse Hessian approximation is symmetric bit for bit (the rank-2 update's inner sums commute) and so is the
+// benchmark objective's Q, so only the 128 x 128 tiles (I, J >= I) are streamed: half the bytes of the row kernels of
+// qn_fused.hip.h.  Tile (I, J) contributes
+//     row part     r_i += sum_{j in J} M_ij v_j      (i in I)        -> slot J of block-row I
+//     column part  r_j += sum_{i in I} M_ij v_i      (j in J, J > I) -> slot I of block-row J     (M_ji = M_ij)
+// into part[R][k][rhs][128]: block-row R receives exactly nb slots, each written by exactly one tile.  A second, small
+// kernel per pass sums the slots of its block-row in slot order (fixed order: bitwise reproducible) and runs the very
+// epilogue the row kernels run (g+, y, u, v, the per-block partial sums for the control step, the vector commits).
+// The lower block triangle of H is NOT maintained during a run; qn_minimize mirrors it back before it returns.
+// Measured (tools/sym_probe.hip): update pass 27.6 us + 5 us reduce at n = 4096 (row kernel 47.6 us); 1.9x at n = 16384.
+#pragma once
+
+#define QN_TB 128
+// cache policy of the streamed tiles: at n = 4096 the two half matrices (2 x 64 MiB) fit the 256 MiB Infinity Cache
+#ifdef QN_SYM_NT
+#define QN_SYM_LD_H(p) QN_LD2_H(p)
+#define QN_SYM_ST_H(p, v) QN_ST2_STREAM(p, v)
+#else
+#define QN_SYM_LD_H(p) ld2(p)
+#define QN_SYM_ST_H(p, v) st2((p), (v))
+#endif
+
+struct QnSymEvalArgs {
+    const double* Q;
+    QnTile T;
+    QnFused F;
+    const QnCtl* ctl;
+    int expect_phase;
+    int after_h;
+    int nb;
+    double* part; // [nb][nb][2][QN_TB]
+};
+struct QnSymHPassArgs {
+    double* H;
+    QnTile T;
+    QnFused F;
+    const QnCtl* ctl;
+    int expect_phase;
+    int nb;
+    double* part;
+};
+
+// launch-linear index t -> upper-triangle tile (I, J >= I), row-major over I
+__device__ __forceinline__ void qn_sym_tile(int t, int nb, int& I, int& J) {
+    const double b = 2.0 * nb + 1.0;
+    int i = (int)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+    if (i < 0) i = 0;
+    if (i > nb - 1) i = nb - 1;
+    while (i > 0 && i * nb - i * (i - 1) / 2 > t) --i;
+    while ((i + 1) * nb - (i + 1) * i / 2 <= t) ++i;
+    I = i;
+    J = i + (t - (i * nb - i * (i - 1) / 2));
+}
+
+// the evaluation request, decoded exactly as quad_eval_fused_kernel decodes it (incl. the deferred update's coefficients)
+struct QnEvalReq {
+    double t, c_ss, c_su, c_uu, ug, sg;
+    int mode, xc, sc;
+    bool is_t;
+};
+// returns false when the launch is predicated off; contains barriers: call from uniform control flow, 256 threads
+__device__ __forceinline__ bool qn_eval_request(const QnCtl* __restrict__ ctl, const QnFused& F, int expect_phase, int after_h, double* red4,
+                                                QnEvalReq& q) {
+    const int phase = ctl->phase;
+    const bool post_h = after_h && phase == QN_PH_REQ_HPASS_EVAL;
+    if (phase != expect_phase && !post_h) return false;
+    q.is_t = ctl->req_kind == QN_REQ_T;
+    q.t = ctl->req_t;
+    q.mode = ctl->dir_mode;
+    q.c_ss = ctl->c_ss; q.c_su = ctl->c_su; q.c_uu = ctl->c_uu; q.ug = ctl->dir_ug; q.sg = ctl->dir_sg;
+    q.xc = ctl->xc;
+    q.sc = ctl->sc;
+    if (post_h) { // same derivation as quad_eval_fused_kernel: the control step commits the very same values afterwards
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (wave < QN_NHPP) { const double v = qn_partial_col_sum(F.hpp, 1, F.nblk, QN_NHPP, wave, lane); if (lane == 0) red4[wave] = v; }
+        __syncthreads();
+        const double yu = red4[0];
+        q.ug = red4[1]; q.sg = red4[2];
+        __syncthreads();
+        qn_update_coeffs(ctl->method, ctl->ys, yu, q.c_ss, q.c_su, q.c_uu);
+        q.mode = 1;
+        q.sc ^= 1;
+    }
+    return true;
+}
+__device__ __forceinline__ double qn_trial_entry(const QnEvalReq& q, const double* __restrict__ x, const double* __restrict__ vv,
+                                                 const double* __restrict__ sp, const double* __restrict__ un, int idx, double* d_out = nullptr) {
+    const double xi = x[idx];
+    if (!q.is_t) { if (d_out) *d_out = 0.0; return xi; }
+    const double d = qn_dir1(q.mode, vv[idx], q.mode ? sp[idx] : 0.0, q.mode ? un[idx] : 0.0, q.c_ss, q.c_su, q.c_uu, q.ug, q.sg);
+    if (d_out) *d_out = d;
+    const double td = q.t * d; // `step * direction` rounds first (bfgs.rs:94)
+    return xi + td;
+}
+
+// sum of the nb slots of (block-row R, rhs) for row `i` of the block, in slot order
+__device__ __forceinline__ double qn_sym_slot_sum(const double* __restrict__ part, int nb, int R, int rhs, int i) {
+    const double* p = part + (((size_t)R * nb) * 2 + rhs) * QN_TB + i;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < nb; k0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (k0 + q < nb) ? p[(size_t)(k0 + q) * 2 * QN_TB] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = acc + v[q];
+    }
+    return acc;
+}
+// per-block totals of NP values held by threads 0..127 (threads >= 128 pass zeros): fixed order; thread k < NP gets total k
+template <int NP>
+__device__ __forceinline__ double qn_sym_block_totals(double (&p)[16], double (*red)[16]) {
+    static_assert(NP <= 16, "at most 16 partial sums");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    QnWaveFold<16, 32>::run(p, lane); // lanes with (lane & 3) == 0 hold value index lane >> 2
+    if ((lane & 3) == 0) red[wave][lane >> 2] = p[0];
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < NP) tot = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    return tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// evaluation: q = Q (x + t d) from the upper block triangle
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sym_eval_tile_kernel(const QnSymEvalArgs a) {
+    __shared__ double red4[4];
+    __shared__ double rowx[QN_TB];
+    __shared__ double colred[4][QN_TB];
+    int I, J;
+    qn_sym_tile(blockIdx.x, a.nb, I, J);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t np = (size_t)a.T.n_pad;
+    const int i0 = I * QN_TB, j0 = J * QN_TB, jc = j0 + 2 * lane;
+    const double* qbase = a.Q + (size_t)(i0 + wave * 32) * np + jc;
+    v2d h[8]; // the first rows are requested before the control block is read
+#pragma unroll
+    for (int r = 0; r < 8; ++r) h[r] = QN_LD2_Q(qbase + (size_t)r * np);
+    QnEvalReq q;
+    if (!qn_eval_request(a.ctl, a.F, a.expect_phase, a.after_h, red4, q)) return;
+    const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
+    const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
+    if (tid < QN_TB) rowx[tid] = qn_trial_entry(q, x, a.F.VV, sp, a.F.UN, i0 + tid);
+    v2d xtj;
+    xtj.x = qn_trial_entry(q, x, a.F.VV, sp, a.F.UN, jc);
+    xtj.y = qn_trial_entry(q, x, a.F.VV, sp, a.F.UN, jc + 1);
+    __syncthreads();
+    double cx = 0.0, cy = 0.0;
+    for (int rc = 0; rc < 32; rc += 8) {
+        if (rc) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) h[r] = QN_LD2_Q(qbase + (size_t)(rc + r) * np);
+        }
+        double racc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            double t0 = h[r].x * xtj.x;
+            t0 = __builtin_fma(h[r].y, xtj.y, t0);
+            racc[r] = t0;
+            const double xi = rowx[wave * 32 + rc + r];
+            cx = __builtin_fma(h[r].x, xi, cx);
+            cy = __builtin_fma(h[r].y, xi, cy);
+        }
+        QnWaveFold<8, 32>::run(racc, lane); // lanes with (lane & 7) == 0 hold row lane >> 3
+        if ((lane & 7) == 0) a.part[(((size_t)I * a.nb + J) * 2 + 0) * QN_TB + wave * 32 + rc + (lane >> 3)] = racc[0];
+    }
+    if (J > I) {
+        colred[wave][2 * lane] = cx;
+        colred[wave][2 * lane + 1] = cy;
+        __syncthreads();
+        if (tid < QN_TB) a.part[(((size_t)J * a.nb + I) * 2 + 0) * QN_TB + tid] = ((colred[0][tid] + colred[1][tid]) + colred[2][tid]) + colred[3][tid];
+    }
+}
+
+// block-row R: q_i = sum of its slots, then the epilogue of quad_eval_fused_kernel for these 128 rows
+__global__ __launch_bounds__(256) void sym_eval_reduce_kernel(const QnSymEvalArgs a) {
+    __shared__ double red4[4];
+    __shared__ double red[4][16];
+    const int R = blockIdx.x, tid = threadIdx.x;
+    const size_t np = (size_t)a.T.n_pad;
+    QnEvalReq q;
+    if (!qn_eval_request(a.ctl, a.F, a.expect_phase, a.after_h, red4, q)) return;
+    const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
+    double* __restrict__ xt = a.F.X0 + (size_t)(1 - q.xc) * np;
+    const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
+    double* __restrict__ sstage = a.F.S0 + (size_t)(1 - q.sc) * np;
+    double p[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[k] = 0.0;
+    if (tid < QN_TB) {
+        const int gi = R * QN_TB + tid;
+        const double qi = qn_sym_slot_sum(a.part, a.nb, R, 0, tid);
+        double di;
+        const double xi = x[gi];
+        const double xti = qn_trial_entry(q, x, a.F.VV, sp, a.F.UN, gi, &di);
+        const double bi = a.F.b[gi], go = a.F.G[gi];
+        const double gti = qi - bi;
+        const double yi = gti - go;
+        const double si = xti - xi; // s = x+ - x (bfgs.rs:96)
+        a.F.GT[gi] = gti;
+        a.F.Y[gi] = yi;
+        xt[gi] = xti;
+        sstage[gi] = si;
+        a.F.UP[gi] = a.F.UN[gi]; // refresh the pending-u copy read by the next H pass
+        p[0] = xti * qi;
+        p[1] = bi * xti;
+        p[2] = gti * di;
+        p[3] = go * di;
+        p[4] = yi * yi;
+        p[5] = yi * si;
+        p[6] = gti * gti;
+        p[7] = si * si;
+        p[8] = isfinite(di) ? 0.0 : 1.0;
+    }
+    const double tot = qn_sym_block_totals<QN_NEVP>(p, red);
+    if (tid < QN_NEVP) a.F.evp[(size_t)tid * a.F.nblk + R] = tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// H pass: pending rank-2 update of the tile, row and column dots with [y, g+] (update pass) or [g] (direction pass)
+// ------------------------------------------------------------------------------------------------
+template <int NRHS, bool PENDING>
+__device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int I, int J, const double* __restrict__ sp, double c_ss, double c_su,
+                                                    double c_uu, v2d (&h)[8], double (*rowv)[QN_TB], double (*colred)[2][QN_TB]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t np = (size_t)a.T.n_pad;
+    const int n = a.T.n;
+    const int i0 = I * QN_TB, j0 = J * QN_TB, jc = j0 + 2 * lane;
+    const double* __restrict__ up = a.F.UP;
+    const double* __restrict__ gt = a.F.GT;
+    const double* __restrict__ r0v = (NRHS == 2) ? a.F.Y : a.F.GT; // update pass: rhs0 = y, rhs1 = g+ ; direction pass: rhs0 = g
+    if (tid < QN_TB) {
+        rowv[0][tid] = PENDING ? sp[i0 + tid] : 0.0;
+        rowv[1][tid] = PENDING ? up[i0 + tid] : 0.0;
+        rowv[2][tid] = r0v[i0 + tid];
+        rowv[3][tid] = (NRHS == 2) ? gt[i0 + tid] : 0.0;
+    }
+    v2d sj = {0.0, 0.0}, uj = {0.0, 0.0};
+    if (PENDING) { sj = ld2(sp + jc); uj = ld2(up + jc); }
+    const v2d a0 = ld2(r0v + jc);
+    const v2d a1 = (NRHS == 2) ? ld2(gt + jc) : (v2d){0.0, 0.0};
+    const bool use_su = c_su != 0.0, use_uu = c_uu != 0.0;
+    const bool c0ok = jc < n, c1ok = (jc + 1) < n;
+    __syncthreads();
+    double c0x = 0.0, c0y = 0.0, c1x = 0.0, c1y = 0.0;
+    double* hbase = a.H + (size_t)(i0 + wave * 32) * np + jc;
+    for (int rc = 0; rc < 32; rc += 8) {
+        if (rc) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) h[r] = QN_SYM_LD_H(hbase + (size_t)(rc + r) * np);
+        }
+        double racc[8 * NRHS];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int ri = wave * 32 + rc + r;
+            v2d hn = h[r];
+            if (PENDING) {
+                const double si = rowv[0][ri], ui = rowv[1][ri];
+                if (use_su) {
+                    hn.x = hn.x + c_su * (si * uj.x + ui * sj.x);
+                    hn.y = hn.y + c_su * (si * uj.y + ui * sj.y);
+                }
+                hn.x = hn.x + c_ss * (si * sj.x);
+                hn.y = hn.y + c_ss * (si * sj.y);
+                if (use_uu) {
+                    hn.x = hn.x + c_uu * (ui * uj.x);
+                    hn.y = hn.y + c_uu * (ui * uj.y);
+                }
+                const bool rowok = (i0 + ri) < n;
+                hn.x = (rowok && c0ok) ? hn.x : 0.0;
+                hn.y = (rowok && c1ok) ? hn.y : 0.0;
+                QN_SYM_ST_H(hbase + (size_t)(rc + r) * np, hn);
+            }
+            double t0 = hn.x * a0.x;
+            t0 = __builtin_fma(hn.y, a0.y, t0);
+            racc[r] = t0;
+            const double y0 = rowv[2][ri];
+            c0x = __builtin_fma(hn.x, y0, c0x);
+            c0y = __builtin_fma(hn.y, y0, c0y);
+            if (NRHS == 2) {
+                double t1 = hn.x * a1.x;
+                t1 = __builtin_fma(hn.y, a1.y, t1);
+                racc[8 + r] = t1;
+                const double y1 = rowv[3][ri];
+                c1x = __builtin_fma(hn.x, y1, c1x);
+                c1y = __builtin_fma(hn.y, y1, c1y);
+            }
+        }
+        QnWaveFold<8 * NRHS, 32>::run(racc, lane);
+        constexpr int SH = (NRHS == 2) ? 2 : 3; // 16 values -> index lane >> 2 ; 8 values -> index lane >> 3
+        if ((lane & ((1 << SH) - 1)) == 0) {
+            const int idx = lane >> SH, rhs = idx >> 3, r = idx & 7;
+            a.part[(((size_t)I * a.nb + J) * 2 + rhs) * QN_TB + wave * 32 + rc + r] = racc[0];
+        }
+    }
+    if (J > I) {
+        colred[wave][0][2 * lane] = c0x;
+        colred[wave][0][2 * lane + 1] = c0y;
+        if (NRHS == 2) { colred[wave][1][2 * lane] = c1x; colred[wave][1][2 * lane + 1] = c1y; }
+        __syncthreads();
+        for (int e = tid; e < NRHS * QN_TB; e += 256) {
+            const int rhs = e / QN_TB, c = e % QN_TB;
+            a.part[(((size_t)J * a.nb + I) * 2 + rhs) * QN_TB + c] =
+                ((colred[0][rhs][c] + colred[1][rhs][c]) + colred[2][rhs][c]) + colred[3][rhs][c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sym_hpass_tile_kernel(const QnSymHPassArgs a) {
+    __shared__ double rowv[4][QN_TB];
+    __shared__ double colred[4][2][QN_TB];
+    int I, J;
+    qn_sym_tile(blockIdx.x, a.nb, I, J);
+    const size_t np = (size_t)a.T.n_pad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v2d h[8];
+    {
+        const double* hbase = a.H + (size_t)(I * QN_TB + wave * 32) * np + J * QN_TB + 2 * lane;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) h[r] = QN_SYM_LD_H(hbase + (size_t)r * np);
+    }
+    const QnCtl* __restrict__ ctl = a.ctl;
+    const int phase = ctl->phase;
+    if (phase != a.expect_phase && phase != QN_PH_REQ_HPASS_EVAL) return;
+    const int nrhs = ctl->hp_nrhs;
+    const int pending = ctl->pending;
+    const double c_ss = ctl->c_ss, c_su = ctl->c_su, c_uu = ctl->c_uu;
+    const double* sp = a.F.S0 + (size_t)ctl->sc * np;
+    if (pending) {
+        if (nrhs == 2) sym_hpass_tile_body<2, true>(a, I, J, sp, c_ss, c_su, c_uu, h, rowv, colred);
+        else sym_hpass_tile_body<1, true>(a, I, J, sp, c_ss, c_su, c_uu, h, rowv, colred);
+    } else {
+        if (nrhs == 2) sym_hpass_tile_body<2, false>(a, I, J, sp, c_ss, c_su, c_uu, h, rowv, colred);
+        else sym_hpass_tile_body<1, false>(a, I, J, sp, c_ss, c_su, c_uu, h, rowv, colred);
+    }
+}
+
+// block-row R: u_i, v_i = sums of the slots; the epilogue of h_pass_fused_kernel for these 128 rows
+__global__ __launch_bounds__(256) void sym_hpass_reduce_kernel(const QnSymHPassArgs a) {
+    __shared__ double red[4][16];
+    const int R = blockIdx.x, tid = threadIdx.x;
+    const size_t np = (size_t)a.T.n_pad;
+    const QnCtl* __restrict__ ctl = a.ctl;
+    const int phase = ctl->phase;
+    if (phase != a.expect_phase && phase != QN_PH_REQ_HPASS_EVAL) return;
+    const int nrhs = ctl->hp_nrhs;
+    const double* sstage = a.F.S0 + (size_t)(1 - ctl->sc) * np;
+    double p[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[k] = 0.0;
+    if (tid < QN_TB) {
+        const int gi = R * QN_TB + tid;
+        const double gp = a.F.GT[gi];
+        const double tot0 = qn_sym_slot_sum(a.part, a.nb, R, 0, tid);
+        if (nrhs == 2) {
+            const double tot1 = qn_sym_slot_sum(a.part, a.nb, R, 1, tid);
+            a.F.UN[gi] = tot0;
+            a.F.VV[gi] = tot1;
+            p[0] = a.F.Y[gi] * tot0; // y.u
+            p[1] = tot0 * gp;        // u.g+
+            p[2] = sstage[gi] * gp;  // s.g+
+        } else {
+            a.F.VV[gi] = tot0; // direction pass: v = H g
+        }
+        a.F.G[gi] = gp; // commit g <- g+
+    }
+    if (nrhs == 2) {
+        const double tot = qn_sym_block_totals<QN_NHPP>(p, red);
+        if (tid < QN_NHPP) a.F.hpp[(size_t)tid * a.F.nblk + R] = tot;
+    }
+}
+
+// after a run: lower tile (J, I) <- transpose of the maintained upper tile (I, J), I < J; 32 x 32 sub-tiles through LDS
+__global__ __launch_bounds__(256) void sym_mirror_kernel(double* __restrict__ H, int n_pad) {
+    __shared__ double t[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x; // 32-blocks
+    if (bj <= bi) return;
+    if ((bi * 32) / QN_TB == (bj * 32) / QN_TB) return; // inside a diagonal 128-tile: both halves are maintained
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t np = (size_t)n_pad;
+    for (int r = ty; r < 32; r += 8) t[r][tx] = H[(size_t)(bi * 32 + r) * np + bj * 32 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) H[(size_t)(bj * 32 + r) * np + bi * 32 + tx] = t[tx][r];
+}

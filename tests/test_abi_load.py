@@ -55,7 +55,7 @@ def test_struct_sizes_match_header(qn):
     assert C.sizeof(A.LineSearchStruct) == 8 + 9 * 8 + 2 * 8
     assert C.sizeof(A.TraceRec) == 5 * 8 + 4 * 4
     assert C.sizeof(A.OracleStruct) == 8 + 6 * 8
-    assert C.sizeof(A.Stats) == 16 * 8
+    assert C.sizeof(A.Stats) == 17 * 8
 
 
 def test_no_gpu_means_loud_failure_not_fallback(qn):

@@ -1,0 +1,119 @@
+"""GPU tests of the symmetric-storage fast path (csrc/qn_sym.hip.h: only the upper block triangle of H and Q is streamed).
+It must agree with the fused ROW kernels on the full matrices (tiling -3) and with the oracle to the stated tolerance, be
+bit-identical between pipelined and synchronous mode and with / without the deferred update step, leave a complete,
+bitwise symmetric H behind (the lower triangle is mirrored back when minimize returns), and step aside for a
+non-symmetric user-installed H."""
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(qn, method, lsname, obj, x0, iters, tiling=None, sync=None):
+    s = (qn.BFGS if method == "bfgs" else qn.DFP)(1e-10, x0)
+    s.set_trace(iters, with_x=True)
+    if tiling:
+        s.set_tiling(*tiling)
+    if sync is not None:
+        s.set_sync_mode(sync)
+    ls = qn.MoreThuente() if lsname == "mt" else qn.BackTracking(1e-4, 0.5)
+    st = 0
+    try:
+        s.minimize(ls, obj, iters, 20)
+    except qn.MaxIterReached:
+        st = 1
+    return s, st
+
+
+@pytest.mark.parametrize("n", [1024, 1152, 2048])
+@pytest.mark.parametrize("method,lsname", [("bfgs", "mt"), ("dfp", "mt"), ("bfgs", "bt")])
+def test_symmetric_path_vs_row_kernels_and_oracle(qn, qo, n, method, lsname):
+    q, b, x0, diag = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+    iters = 30
+    s, st = _run(qn, method, lsname, obj, x0, iters)
+    assert s.stats()["matrix_bytes_per_pass"] == (n // 128) * (n // 128 + 1) // 2 * 128 * 128 * 8  # the path under test did run
+    r, st_r = _run(qn, method, lsname, obj, x0, iters, tiling=(-3, 0))
+    assert r.stats()["matrix_bytes_per_pass"] == n * n * 8
+    (tr, xs), (tr_r, xs_r) = s.trace(), r.trace()
+    assert st == st_r and len(tr) == len(tr_r)
+    assert [(a["n_evals"], a["ls_cases"]) for a in tr] == [(a["n_evals"], a["ls_cases"]) for a in tr_r]
+    assert np.allclose([a["t"] for a in tr], [a["t"] for a in tr_r], rtol=1e-9, atol=0)
+    assert np.linalg.norm(xs[-1] - xs_r[-1]) <= 1e-9 * max(1.0, np.linalg.norm(xs_r[-1]))
+    # the inverse Hessian left behind: complete, bitwise symmetric, equal to the row kernels' to rounding
+    h, h_r = s.approx_inv_hessian(), r.approx_inv_hessian()
+    assert np.array_equal(h, h.T)
+    assert np.abs(h - h_r).max() <= 1e-9 * np.abs(h_r).max()
+    # and the oracle (rank-2 restatement), same tolerance as the parity sweep
+    ref = qo.Solver(qo.BFGS if method == "bfgs" else qo.DFP, 1e-10, x0, qo.UPDATE_RANK2)
+    ls = qo.morethuente() if lsname == "mt" else qo.backtracking(1e-4, 0.5)
+    ref.minimize(ls, qo.QuadraticOracle(q, b), iters, 20, trace_cap=iters, trace_x=True)
+    k = min(len(tr), len(ref.trace))
+    assert k >= 10
+    for a, c in zip(tr[:k], ref.trace[:k]):
+        assert a["n_evals"] == c["n_evals"] and abs(a["t"] - c["t"]) <= 1e-9 * abs(c["t"])
+    assert np.linalg.norm(xs[k - 1] - ref.trace_x[k - 1]) <= 1e-9 * max(1.0, np.linalg.norm(ref.trace_x[k - 1]))
+
+
+def test_symmetric_path_is_bitwise_reproducible_across_modes(qn, qo):
+    n = 1280
+    q, b, x0, _ = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+    runs = []
+    for tiling, sync in ((None, 0), (None, 1), ((-2, 0), 0), ((-2, 0), 1)):  # pipelined / synchronous, with / without the deferred step
+        s, st = _run(qn, "bfgs", "mt", obj, x0, 35, tiling=tiling, sync=sync)
+        tr, xs = s.trace()
+        runs.append((st, tr, xs, s.approx_inv_hessian()))
+    for other in runs[1:]:
+        assert other[0] == runs[0][0] and other[1] == runs[0][1]
+        assert np.array_equal(other[2], runs[0][2]) and np.array_equal(other[3], runs[0][3])
+
+
+def test_warm_restart_continues_on_the_mirrored_hessian(qn, qo):
+    """Two minimize calls of 10 iterations follow one of 20: the lower triangle restored between the calls is the right one
+    (the second call's first pass applies the pending update to it)."""
+    n = 1024
+    q, b, x0, _ = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+    one, _ = _run(qn, "bfgs", "mt", obj, x0, 20)
+    two = qn.BFGS(1e-10, x0)
+    for _ in range(2):
+        with pytest.raises(qn.MaxIterReached):
+            two.minimize(qn.MoreThuente(), obj, 10, 20)
+    # (to rounding, not bit for bit: a fresh call forms its first direction with a pass over H, a running one with the lazy formula)
+    assert np.linalg.norm(one.x() - two.x()) <= 1e-9 * np.linalg.norm(one.x())
+    h1, h2 = one.approx_inv_hessian(), two.approx_inv_hessian()
+    assert np.array_equal(h2, h2.T) and np.abs(h1 - h2).max() <= 1e-9 * np.abs(h1).max()
+    # ... and the generic path can take over from the mirrored matrix (it reads every entry)
+    three = qn.BFGS(1e-10, x0)
+    with pytest.raises(qn.MaxIterReached):
+        three.minimize(qn.MoreThuente(), obj, 10, 20)
+    three.set_tiling(-1, 0)
+    with pytest.raises(qn.MaxIterReached):
+        three.minimize(qn.MoreThuente(), obj, 10, 20)
+    assert np.linalg.norm(three.x() - one.x()) <= 1e-9 * np.linalg.norm(one.x())
+
+
+def test_non_symmetric_user_hessian_uses_the_full_matrix(qn, qo):
+    n = 1024
+    q, b, x0, _ = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+    rng = np.random.default_rng(11)
+    h0 = np.eye(n) + 1e-3 * rng.standard_normal((n, n))  # not symmetric: the reference would use it as it is
+    s = qn.BFGS(1e-10, x0)
+    s.set_approx_inv_hessian(h0)
+    with pytest.raises(qn.MaxIterReached):
+        s.minimize(qn.MoreThuente(), obj, 5, 20)
+    assert s.stats()["matrix_bytes_per_pass"] == n * n * 8
+    ref = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2)
+    ref.set_inv_hessian(h0)
+    ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b), 5, 20)
+    assert np.linalg.norm(s.x() - ref.x) <= 1e-9 * np.linalg.norm(ref.x)
+    # a symmetric one re-enables the tiles
+    s2 = qn.BFGS(1e-10, x0)
+    s2.set_approx_inv_hessian(0.5 * (h0 + h0.T))
+    with pytest.raises(qn.MaxIterReached):
+        s2.minimize(qn.MoreThuente(), obj, 5, 20)
+    assert s2.stats()["matrix_bytes_per_pass"] < n * n * 8
