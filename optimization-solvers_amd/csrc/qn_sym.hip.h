@@ -10,6 +10,11 @@
 // epilogue the row kernels run (g+, y, u, v, the per-block partial sums for the control step, the vector commits).
 // The lower block triangle of H is NOT maintained during a run; qn_minimize mirrors it back before it returns.
 // Measured (tools/sym_probe.hip): update pass 27.6 us + 5 us reduce at n = 4096 (row kernel 47.6 us); 1.9x at n = 16384.
+// Measured and dropped: summing the slots inside the tile kernel (the last tile to arrive at a block-row, told by an
+// agent-scope arrival counter, reads the slots with sc1 loads and runs the epilogue) instead of the second launch.  Bitwise
+// identical results, but every tile then ends in `s_waitcnt vmcnt(0)` + barrier + one or two returning atomics, and the
+// grid at n = 4096 is a single wave of workgroups, so all of it is exposed: tile kernels +8-9 us against ~6 us for the
+// launch saved (9.1 k vs 9.5 k it/s at n = 4096; 211 vs 286 it/s at n = 32768).
 #pragma once
 
 #define QN_TB 128
