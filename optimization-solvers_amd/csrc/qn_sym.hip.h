@@ -14,7 +14,8 @@
 // agent-scope arrival counter, reads the slots with sc1 loads and runs the epilogue) instead of the second launch.  Bitwise
 // identical results, but every tile then ends in `s_waitcnt vmcnt(0)` + barrier + one or two returning atomics, and the
 // grid at n = 4096 is a single wave of workgroups, so all of it is exposed: tile kernels +8-9 us against ~6 us for the
-// launch saved (9.1 k vs 9.5 k it/s at n = 4096; 211 vs 286 it/s at n = 32768).
+// launch saved (9.1 k vs 9.5 k it/s at n = 4096; 211 vs 286 it/s at n = 32768).  Likewise dropped: the evaluation's slot
+// reduction and the control step in one launch (last of the nb reduce workgroups runs the step): 9.1 k vs 9.9 k it/s.
 #pragma once
 
 #define QN_TB 128
@@ -100,18 +101,27 @@ __device__ __forceinline__ double qn_trial_entry(const QnEvalReq& q, const doubl
     return xi + td;
 }
 
-// sum of the nb slots of (block-row R, rhs) for row `i` of the block, in slot order
-__device__ __forceinline__ double qn_sym_slot_sum(const double* __restrict__ part, int nb, int R, int rhs, int i) {
+// Sum of the nb slots of (block-row R, rhs) for row `i` of the block: the two halves of the workgroup (threads 0..127 and
+// 128..255) each add one half of the slot range in slot order, 16 loads in flight, and the halves are combined through LDS
+// -- a fixed order.  All 256 threads call it; threads 0..127 get the total of their row (i = tid & 127).
+__device__ __forceinline__ double qn_sym_slot_sum(const double* __restrict__ part, int nb, int R, int rhs, double* halfbuf /* LDS[128] */) {
+    const int i = threadIdx.x & (QN_TB - 1), half = threadIdx.x >> 7;
+    const int nh = (nb + 1) / 2;
+    const int k_lo = half * nh, k_hi = (half == 0) ? nh : nb;
     const double* p = part + (((size_t)R * nb) * 2 + rhs) * QN_TB + i;
     double acc = 0.0;
-    for (int k0 = 0; k0 < nb; k0 += 8) {
-        double v[8];
+    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+        double v[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (k0 + q < nb) ? p[(size_t)(k0 + q) * 2 * QN_TB] : 0.0;
+        for (int q = 0; q < 16; ++q) v[q] = (k0 + q < k_hi) ? p[(size_t)(k0 + q) * 2 * QN_TB] : 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc = acc + v[q];
+        for (int q = 0; q < 16; ++q) acc = acc + v[q];
     }
-    return acc;
+    if (half == 1) halfbuf[i] = acc;
+    __syncthreads();
+    const double tot = (half == 0) ? acc + halfbuf[i] : 0.0;
+    __syncthreads(); // halfbuf is reused by the next call
+    return tot;
 }
 // per-block totals of NP values held by threads 0..127 (threads >= 128 pass zeros): fixed order; thread k < NP gets total k
 template <int NP>
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(256) void sym_eval_tile_kernel(const QnSymEvalArgs 
 __global__ __launch_bounds__(256) void sym_eval_reduce_kernel(const QnSymEvalArgs a) {
     __shared__ double red4[4];
     __shared__ double red[4][16];
+    __shared__ double halfbuf[QN_TB];
     const int R = blockIdx.x, tid = threadIdx.x;
     const size_t np = (size_t)a.T.n_pad;
     QnEvalReq q;
@@ -193,9 +204,9 @@ __global__ __launch_bounds__(256) void sym_eval_reduce_kernel(const QnSymEvalArg
     double p[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) p[k] = 0.0;
+    const double qi = qn_sym_slot_sum(a.part, a.nb, R, 0, halfbuf);
     if (tid < QN_TB) {
         const int gi = R * QN_TB + tid;
-        const double qi = qn_sym_slot_sum(a.part, a.nb, R, 0, tid);
         double di;
         const double xi = x[gi];
         const double xti = qn_trial_entry(q, x, a.F.VV, sp, a.F.UN, gi, &di);
@@ -344,6 +355,7 @@ __global__ __launch_bounds__(256) void sym_hpass_tile_kernel(const QnSymHPassArg
 // block-row R: u_i, v_i = sums of the slots; the epilogue of h_pass_fused_kernel for these 128 rows
 __global__ __launch_bounds__(256) void sym_hpass_reduce_kernel(const QnSymHPassArgs a) {
     __shared__ double red[4][16];
+    __shared__ double halfbuf[QN_TB];
     const int R = blockIdx.x, tid = threadIdx.x;
     const size_t np = (size_t)a.T.n_pad;
     const QnCtl* __restrict__ ctl = a.ctl;
@@ -354,12 +366,12 @@ __global__ __launch_bounds__(256) void sym_hpass_reduce_kernel(const QnSymHPassA
     double p[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) p[k] = 0.0;
+    const double tot0 = qn_sym_slot_sum(a.part, a.nb, R, 0, halfbuf);
+    const double tot1 = (nrhs == 2) ? qn_sym_slot_sum(a.part, a.nb, R, 1, halfbuf) : 0.0; // nrhs is uniform
     if (tid < QN_TB) {
         const int gi = R * QN_TB + tid;
         const double gp = a.F.GT[gi];
-        const double tot0 = qn_sym_slot_sum(a.part, a.nb, R, 0, tid);
         if (nrhs == 2) {
-            const double tot1 = qn_sym_slot_sum(a.part, a.nb, R, 1, tid);
             a.F.UN[gi] = tot0;
             a.F.VV[gi] = tot1;
             p[0] = a.F.Y[gi] * tot0; // y.u
