@@ -230,6 +230,9 @@ def main():
                     "achievable_note": "plain read+write streams reach 4.9-5.4 TB/s on this device (hipMemcpy D2D 5.0 TB/s; "
                                        "profiles/r01_c_bw_probe.txt); peak is the 8 TB/s HBM3E spec",
                     "algorithmic_bytes_per_launch": alg_h, "avg_launch_ms": h_launch_ms, "launches_timed": n_h,
+                    # SURVEY.md 8(d) counts 16 n^2 / P bytes per H pass (full matrix read + written); the symmetric-storage path does
+                    # the same pass on half of them, so its rate in full-matrix terms is higher than the bytes it really moves
+                    "full_matrix_equivalent_GBs": (16.0 * n * n / world) / (h_launch_ms * 1e-3) / 1e9 if n_h else None,
                     "event_bracket_fixed_overhead_ms_not_subtracted": bracket_ms,
                     "quad_matvec": {"algorithmic_bytes_per_launch": alg_q, "avg_launch_ms": t_e / max(n_e, 1), "launches_timed": n_e,
                                     "achieved": (alg_q / (t_e / max(n_e, 1) * 1e-3) / 1e9) if n_e else None},

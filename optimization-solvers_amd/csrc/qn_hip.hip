@@ -1191,7 +1191,7 @@ static int enqueue_eval_fused(Run& r, int after_h) {
         y.Q = r.obj->Q; y.T = a.T; y.F = a.F; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_EVAL; y.after_h = after_h; y.nb = s->sym_nb; y.part = s->sym_part;
         {
             ProfScope ps(s, KC_EVAL);
-            hipLaunchKernelGGL(sym_eval_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(256), 0, c->stream, y);
+            hipLaunchKernelGGL(sym_eval_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
         }
         {
             ProfScope ps(s, KC_CTL);
@@ -1225,7 +1225,7 @@ static int enqueue_hpass_fused(Run& r) {
         y.H = s->H; y.T = a.T; y.F = a.F; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_HPASS; y.nb = s->sym_nb; y.part = s->sym_part;
         {
             ProfScope ps(s, KC_HPASS);
-            hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(256), 0, c->stream, y);
+            hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
         }
         {
             ProfScope ps(s, KC_CTL);

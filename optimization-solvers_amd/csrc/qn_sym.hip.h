@@ -19,6 +19,9 @@
 #pragma once
 
 #define QN_TB 128
+#define QN_SYM_WAVES 8                       // waves per tile workgroup (512 threads)
+#define QN_SYM_RPW (QN_TB / QN_SYM_WAVES)     // rows of the tile per wave
+#define QN_SYM_TPB (64 * QN_SYM_WAVES)
 // cache policy of the streamed tiles: at n = 4096 the two half matrices (2 x 64 MiB) fit the 256 MiB Infinity Cache
 #ifdef QN_SYM_NT
 #define QN_SYM_LD_H(p) QN_LD2_H(p)
@@ -139,19 +142,20 @@ __device__ __forceinline__ double qn_sym_block_totals(double (&p)[16], double (*
 // ------------------------------------------------------------------------------------------------
 // evaluation: q = Q (x + t d) from the upper block triangle
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sym_eval_tile_kernel(const QnSymEvalArgs a) {
+__global__ __launch_bounds__(QN_SYM_TPB) void sym_eval_tile_kernel(const QnSymEvalArgs a) {
     __shared__ double red4[4];
     __shared__ double rowx[QN_TB];
-    __shared__ double colred[4][QN_TB];
+    __shared__ double colred[QN_SYM_WAVES][QN_TB];
     int I, J;
     qn_sym_tile(blockIdx.x, a.nb, I, J);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.T.n_pad;
     const int i0 = I * QN_TB, j0 = J * QN_TB, jc = j0 + 2 * lane;
-    const double* qbase = a.Q + (size_t)(i0 + wave * 32) * np + jc;
-    v2d h[8]; // the first rows are requested before the control block is read
+    const double* qbase = a.Q + (size_t)(i0 + wave * QN_SYM_RPW) * np + jc;
+    v2d h[QN_SYM_RPW]; // the wave's whole share of the tile is requested before the control block is read: the grid is a single
+                       // wave of workgroups at n = 4096, so nothing else would hide the prologue's two dependent round trips
 #pragma unroll
-    for (int r = 0; r < 8; ++r) h[r] = QN_LD2_Q(qbase + (size_t)r * np);
+    for (int r = 0; r < QN_SYM_RPW; ++r) h[r] = QN_LD2_Q(qbase + (size_t)r * np);
     QnEvalReq q;
     if (!qn_eval_request(a.ctl, a.F, a.expect_phase, a.after_h, red4, q)) return;
     const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
@@ -162,29 +166,32 @@ __global__ __launch_bounds__(256) void sym_eval_tile_kernel(const QnSymEvalArgs 
     xtj.y = qn_trial_entry(q, x, a.F.VV, sp, a.F.UN, jc + 1);
     __syncthreads();
     double cx = 0.0, cy = 0.0;
-    for (int rc = 0; rc < 32; rc += 8) {
-        if (rc) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) h[r] = QN_LD2_Q(qbase + (size_t)(rc + r) * np);
-        }
+    for (int rc = 0; rc < QN_SYM_RPW; rc += 8) {
         double racc[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            double t0 = h[r].x * xtj.x;
-            t0 = __builtin_fma(h[r].y, xtj.y, t0);
+            const v2d hv = h[rc + r];
+            double t0 = hv.x * xtj.x;
+            t0 = __builtin_fma(hv.y, xtj.y, t0);
             racc[r] = t0;
-            const double xi = rowx[wave * 32 + rc + r];
-            cx = __builtin_fma(h[r].x, xi, cx);
-            cy = __builtin_fma(h[r].y, xi, cy);
+            const double xi = rowx[wave * QN_SYM_RPW + rc + r];
+            cx = __builtin_fma(hv.x, xi, cx);
+            cy = __builtin_fma(hv.y, xi, cy);
         }
         QnWaveFold<8, 32>::run(racc, lane); // lanes with (lane & 7) == 0 hold row lane >> 3
-        if ((lane & 7) == 0) a.part[(((size_t)I * a.nb + J) * 2 + 0) * QN_TB + wave * 32 + rc + (lane >> 3)] = racc[0];
+        if ((lane & 7) == 0) a.part[(((size_t)I * a.nb + J) * 2 + 0) * QN_TB + wave * QN_SYM_RPW + rc + (lane >> 3)] = racc[0];
     }
     if (J > I) {
         colred[wave][2 * lane] = cx;
         colred[wave][2 * lane + 1] = cy;
         __syncthreads();
-        if (tid < QN_TB) a.part[(((size_t)J * a.nb + I) * 2 + 0) * QN_TB + tid] = ((colred[0][tid] + colred[1][tid]) + colred[2][tid]) + colred[3][tid];
+        if (tid < QN_TB) {
+            double acc = colred[0][tid];
+#pragma unroll
+            for (int w = 1; w < QN_SYM_WAVES; ++w) acc = acc + colred[w][tid];
+            a.part[(((size_t)J * a.nb + I) * 2 + 0) * QN_TB + tid] = acc;
+        }
     }
 }
 
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256) void sym_eval_reduce_kernel(const QnSymEvalArg
 // ------------------------------------------------------------------------------------------------
 template <int NRHS, bool PENDING>
 __device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int I, int J, const double* __restrict__ sp, double c_ss, double c_su,
-                                                    double c_uu, v2d (&h)[8], double (*rowv)[QN_TB], double (*colred)[2][QN_TB]) {
+                                                    double c_uu, v2d (&h)[8], double (*rowv)[QN_TB], double (*colred)[2][QN_TB]) { // colred[QN_SYM_WAVES][2][QN_TB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.T.n_pad;
     const int n = a.T.n;
@@ -260,8 +267,8 @@ __device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int
     const bool c0ok = jc < n, c1ok = (jc + 1) < n;
     __syncthreads();
     double c0x = 0.0, c0y = 0.0, c1x = 0.0, c1y = 0.0;
-    double* hbase = a.H + (size_t)(i0 + wave * 32) * np + jc;
-    for (int rc = 0; rc < 32; rc += 8) {
+    double* hbase = a.H + (size_t)(i0 + wave * QN_SYM_RPW) * np + jc;
+    for (int rc = 0; rc < QN_SYM_RPW; rc += 8) {
         if (rc) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) h[r] = QN_SYM_LD_H(hbase + (size_t)(rc + r) * np);
@@ -269,7 +276,7 @@ __device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int
         double racc[8 * NRHS];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int ri = wave * 32 + rc + r;
+            const int ri = wave * QN_SYM_RPW + rc + r;
             v2d hn = h[r];
             if (PENDING) {
                 const double si = rowv[0][ri], ui = rowv[1][ri];
@@ -307,7 +314,7 @@ __device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int
         constexpr int SH = (NRHS == 2) ? 2 : 3; // 16 values -> index lane >> 2 ; 8 values -> index lane >> 3
         if ((lane & ((1 << SH) - 1)) == 0) {
             const int idx = lane >> SH, rhs = idx >> 3, r = idx & 7;
-            a.part[(((size_t)I * a.nb + J) * 2 + rhs) * QN_TB + wave * 32 + rc + r] = racc[0];
+            a.part[(((size_t)I * a.nb + J) * 2 + rhs) * QN_TB + wave * QN_SYM_RPW + rc + r] = racc[0];
         }
     }
     if (J > I) {
@@ -315,24 +322,27 @@ __device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int
         colred[wave][0][2 * lane + 1] = c0y;
         if (NRHS == 2) { colred[wave][1][2 * lane] = c1x; colred[wave][1][2 * lane + 1] = c1y; }
         __syncthreads();
-        for (int e = tid; e < NRHS * QN_TB; e += 256) {
-            const int rhs = e / QN_TB, c = e % QN_TB;
-            a.part[(((size_t)J * a.nb + I) * 2 + rhs) * QN_TB + c] =
-                ((colred[0][rhs][c] + colred[1][rhs][c]) + colred[2][rhs][c]) + colred[3][rhs][c];
+        if (tid < NRHS * QN_TB) {
+            const int rhs = tid / QN_TB, c = tid % QN_TB;
+            double acc = colred[0][rhs][c];
+#pragma unroll
+            for (int w = 1; w < QN_SYM_WAVES; ++w) acc = acc + colred[w][rhs][c];
+            a.part[(((size_t)J * a.nb + I) * 2 + rhs) * QN_TB + c] = acc;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void sym_hpass_tile_kernel(const QnSymHPassArgs a) {
+__global__ __launch_bounds__(QN_SYM_TPB) void sym_hpass_tile_kernel(const QnSymHPassArgs a) {
     __shared__ double rowv[4][QN_TB];
-    __shared__ double colred[4][2][QN_TB];
+    __shared__ double colred[QN_SYM_WAVES][2][QN_TB];
     int I, J;
     qn_sym_tile(blockIdx.x, a.nb, I, J);
     const size_t np = (size_t)a.T.n_pad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    v2d h[8];
+    v2d h[8]; // the first rows are requested before the control block is read (all 32, as in the evaluation kernel, costs the
+              // update kernel its second workgroup per CU: 256 VGPRs, 42 us instead of 34 at n = 4096)
     {
-        const double* hbase = a.H + (size_t)(I * QN_TB + wave * 32) * np + J * QN_TB + 2 * lane;
+        const double* hbase = a.H + (size_t)(I * QN_TB + wave * QN_SYM_RPW) * np + J * QN_TB + 2 * lane;
 #pragma unroll
         for (int r = 0; r < 8; ++r) h[r] = QN_SYM_LD_H(hbase + (size_t)r * np);
     }
