@@ -1136,6 +1136,7 @@ struct Run {
     int oracle_tpl; // QN_ORACLE_GENERIC / QN_ORACLE_QUAD
     bool fused;
     bool sym = false; // fused path on the upper block triangle of H and Q (qn_sym.hip.h)
+    bool sym_generic = false; // generic path: the H pass alone on the upper block triangle
 };
 
 static int launch_ctl_mask(Run& r, int expect_mask) {
@@ -1299,6 +1300,22 @@ static int enqueue_hpass_req(Run& r) {
     qn_solver* s = r.s;
     qn_context* c = s->ctx;
     if (r.fused) return enqueue_hpass_fused(r);
+    if (r.sym_generic) {
+        QnSymHPassArgs y{};
+        y.H = s->H; y.T = s->T; y.T.cs = 1; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_HPASS; y.nb = s->sym_nb; y.part = s->sym_part;
+        y.generic = 1; y.gsp = s->V.sp; y.gup = s->V.up; y.gvy = s->V.y; y.gvg = s->V.g; y.ghp = s->V.hp;
+        {
+            ProfScope ps(s, KC_HPASS);
+            hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
+        }
+        {
+            ProfScope ps(s, KC_CTL);
+            hipLaunchKernelGGL(sym_hpass_reduce_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
+        }
+        s->stats.launches += 2;
+        HIPCHK(hipGetLastError());
+        return QN_OK;
+    }
     QnHPassArgs a = hpass_args(s, QN_PH_REQ_HPASS);
     {
         ProfScope ps(s, KC_HPASS);
@@ -1465,7 +1482,18 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     h->fused = r.fused ? 1 : 0;
     s->V.fused_hint = h->fused;
     // ... and on the upper block triangle only (half the bytes) when H and Q are whole 128-tiles on one rank
-    r.sym = r.fused && c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
+    const bool sym_ok = c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
+    r.sym = r.fused && sym_ok;
+    // the generic path's H pass alone (closures, log-sum-exp objective, SR1, bounded variants): same tiles, sums into V.hp
+    r.sym_generic = !r.fused && sym_ok && s->H && s->hcs == 1 && (s->method == QN_BFGS || s->method == QN_DFP || s->method == QN_SR1);
+    if (r.sym_generic) {
+        const int nb = s->T.n_pad / QN_TB;
+        if (s->sym_nb != nb) {
+            if (s->sym_part) { HIPCHK(hipFree(s->sym_part)); s->sym_part = nullptr; }
+            QNCHK(dev_alloc_zero(&s->sym_part, (size_t)nb * nb * 2 * QN_TB, c->stream));
+            s->sym_nb = nb;
+        }
+    }
     h->defer_u = 0;
     h->no_defer = s->no_defer;
     if (r.fused) { // import the canonical state (x, pending s and u) into the fused buffers
@@ -1529,7 +1557,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             }
         }
     }
-    if (r.sym) { // the run maintained the upper block triangle of H only: restore the lower one
+    if (r.sym || r.sym_generic) { // the run maintained the upper block triangle of H only: restore the lower one
         const int b32 = s->T.n_pad / 32;
         hipLaunchKernelGGL(sym_mirror_kernel, dim3(b32, b32), dim3(256), 0, c->stream, s->H, s->T.n_pad);
         HIPCHK(hipGetLastError());
@@ -1549,9 +1577,10 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     s->stats.oracle_evals = h->n_oracle_evals;
     s->stats.h_passes = h->n_hpasses;
     uint64_t shard = (uint64_t)s->T.rpr * (uint64_t)s->T.n_pad * 8ull;
-    if (r.sym) shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb + 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull; // the streamed tiles
+    const uint64_t full_shard = shard;
+    if (r.sym || r.sym_generic) shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb + 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull; // the streamed tiles
     s->stats.h_bytes = (h->n_hpasses + h->n_hpass_rw) * shard;
-    s->stats.obj_bytes = (r.oracle_tpl == QN_ORACLE_QUAD) ? h->n_oracle_evals * shard : 0;
+    s->stats.obj_bytes = (r.oracle_tpl == QN_ORACLE_QUAD) ? h->n_oracle_evals * (r.sym ? shard : full_shard) : 0;
     s->stats.matrix_bytes_per_pass = shard;
     if (status == QN_ABNORMAL_TERMINATION) return fail(status, "solver state machine aborted");
     return status;

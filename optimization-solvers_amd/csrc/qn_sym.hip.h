@@ -49,6 +49,11 @@ struct QnSymHPassArgs {
     int expect_phase;
     int nb;
     double* part;
+    // generic path (host / device closures, log-sum-exp objective, SR1, bounded variants): fixed vector buffers, the sums go to the
+    // gathered h_pass output the control step reads (qn_kernels.hip.h h_pass_kernel), no epilogue
+    int generic;
+    const double *gsp, *gup, *gvy, *gvg;
+    double* ghp;
 };
 
 // launch-linear index t -> upper-triangle tile (I, J >= I), row-major over I
@@ -244,15 +249,14 @@ __global__ __launch_bounds__(256) void sym_eval_reduce_kernel(const QnSymEvalArg
 // H pass: pending rank-2 update of the tile, row and column dots with [y, g+] (update pass) or [g] (direction pass)
 // ------------------------------------------------------------------------------------------------
 template <int NRHS, bool PENDING>
-__device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int I, int J, const double* __restrict__ sp, double c_ss, double c_su,
+__device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int I, int J, const double* __restrict__ sp, const double* __restrict__ up,
+                                                    const double* __restrict__ r0v, const double* __restrict__ gt, double c_ss, double c_su,
                                                     double c_uu, v2d (&h)[8], double (*rowv)[QN_TB], double (*colred)[2][QN_TB]) { // colred[QN_SYM_WAVES][2][QN_TB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.T.n_pad;
     const int n = a.T.n;
     const int i0 = I * QN_TB, j0 = J * QN_TB, jc = j0 + 2 * lane;
-    const double* __restrict__ up = a.F.UP;
-    const double* __restrict__ gt = a.F.GT;
-    const double* __restrict__ r0v = (NRHS == 2) ? a.F.Y : a.F.GT; // update pass: rhs0 = y, rhs1 = g+ ; direction pass: rhs0 = g
+    // r0v: update pass rhs0 = y (rhs1 = gt = g+); direction pass rhs0 = g
     if (tid < QN_TB) {
         rowv[0][tid] = PENDING ? sp[i0 + tid] : 0.0;
         rowv[1][tid] = PENDING ? up[i0 + tid] : 0.0;
@@ -348,17 +352,24 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_hpass_tile_kernel(const QnSymH
     }
     const QnCtl* __restrict__ ctl = a.ctl;
     const int phase = ctl->phase;
-    if (phase != a.expect_phase && phase != QN_PH_REQ_HPASS_EVAL) return;
-    const int nrhs = ctl->hp_nrhs;
+    if (phase != a.expect_phase && !(phase == QN_PH_REQ_HPASS_EVAL && !a.generic)) return;
+    const int nrhs = ctl->hp_nrhs; // generic path: 0 = apply the pending update only (the sums are then not used)
     const int pending = ctl->pending;
     const double c_ss = ctl->c_ss, c_su = ctl->c_su, c_uu = ctl->c_uu;
-    const double* sp = a.F.S0 + (size_t)ctl->sc * np;
-    if (pending) {
-        if (nrhs == 2) sym_hpass_tile_body<2, true>(a, I, J, sp, c_ss, c_su, c_uu, h, rowv, colred);
-        else sym_hpass_tile_body<1, true>(a, I, J, sp, c_ss, c_su, c_uu, h, rowv, colred);
+    const double *sp, *up, *r0v, *gt;
+    if (a.generic) {
+        sp = a.gsp; up = a.gup; gt = a.gvg;
+        r0v = (ctl->after_state == QN_ST_AFTER_DIR) ? a.gvg : a.gvy; // as h_pass_kernel: rhs0 = g for a direction pass, y for an update pass (1 or 2 rhs)
     } else {
-        if (nrhs == 2) sym_hpass_tile_body<2, false>(a, I, J, sp, c_ss, c_su, c_uu, h, rowv, colred);
-        else sym_hpass_tile_body<1, false>(a, I, J, sp, c_ss, c_su, c_uu, h, rowv, colred);
+        sp = a.F.S0 + (size_t)ctl->sc * np; up = a.F.UP; gt = a.F.GT;
+        r0v = (nrhs == 2) ? a.F.Y : a.F.GT;
+    }
+    if (pending) {
+        if (nrhs == 2) sym_hpass_tile_body<2, true>(a, I, J, sp, up, r0v, gt, c_ss, c_su, c_uu, h, rowv, colred);
+        else sym_hpass_tile_body<1, true>(a, I, J, sp, up, r0v, gt, c_ss, c_su, c_uu, h, rowv, colred);
+    } else {
+        if (nrhs == 2) sym_hpass_tile_body<2, false>(a, I, J, sp, up, r0v, gt, c_ss, c_su, c_uu, h, rowv, colred);
+        else sym_hpass_tile_body<1, false>(a, I, J, sp, up, r0v, gt, c_ss, c_su, c_uu, h, rowv, colred);
     }
 }
 
@@ -370,8 +381,18 @@ __global__ __launch_bounds__(256) void sym_hpass_reduce_kernel(const QnSymHPassA
     const size_t np = (size_t)a.T.n_pad;
     const QnCtl* __restrict__ ctl = a.ctl;
     const int phase = ctl->phase;
-    if (phase != a.expect_phase && phase != QN_PH_REQ_HPASS_EVAL) return;
+    if (phase != a.expect_phase && !(phase == QN_PH_REQ_HPASS_EVAL && !a.generic)) return;
     const int nrhs = ctl->hp_nrhs;
+    if (a.generic) { // the control step does the rest (qn_ctl_step.hip.h, states AFTER_DIR / AFTER_U)
+        if (nrhs == 0) return;
+        const double t0 = qn_sym_slot_sum(a.part, a.nb, R, 0, halfbuf);
+        const double t1 = (nrhs == 2) ? qn_sym_slot_sum(a.part, a.nb, R, 1, halfbuf) : 0.0;
+        if (tid < QN_TB) {
+            a.ghp[(size_t)R * QN_TB + tid] = t0;
+            if (nrhs == 2) a.ghp[(size_t)a.T.rpr + (size_t)R * QN_TB + tid] = t1;
+        }
+        return;
+    }
     const double* sstage = a.F.S0 + (size_t)(1 - ctl->sc) * np;
     double p[16];
 #pragma unroll

@@ -117,3 +117,87 @@ def test_non_symmetric_user_hessian_uses_the_full_matrix(qn, qo):
     with pytest.raises(qn.MaxIterReached):
         s2.minimize(qn.MoreThuente(), obj, 5, 20)
     assert s2.stats()["matrix_bytes_per_pass"] < n * n * 8
+
+
+# ---------------------------------------------------------------------------------------------
+# the generic path's H pass on the same tiles (closures, log-sum-exp objective, SR1, bounded variants)
+# ---------------------------------------------------------------------------------------------
+
+def _generic_pair(make_solver, minimize):
+    out = []
+    for full in (False, True):
+        s = make_solver()
+        if full:
+            s.set_tiling(-3, 0)  # H pass on the full row-major matrix
+        s.set_trace(40, with_x=True)
+        st = 0
+        try:
+            minimize(s)
+        except Exception as e:  # noqa: BLE001
+            st = type(e).__name__
+        out.append((s, st))
+    return out
+
+
+def _assert_same_run(a, b, n, half_expected=True):
+    (s, st), (r, st_r) = a, b
+    assert st == st_r
+    if half_expected:
+        assert s.stats()["matrix_bytes_per_pass"] == (n // 128) * (n // 128 + 1) // 2 * 128 * 128 * 8
+    assert r.stats()["matrix_bytes_per_pass"] == n * n * 8
+    (tr, xs), (tr_r, xs_r) = s.trace(), r.trace()
+    assert len(tr) == len(tr_r) and len(tr) >= 5
+    assert [x["n_evals"] for x in tr] == [x["n_evals"] for x in tr_r]
+    assert np.linalg.norm(xs[-1] - xs_r[-1]) <= 1e-9 * max(1.0, np.linalg.norm(xs_r[-1]))
+    h, h_r = s.approx_inv_hessian(), r.approx_inv_hessian()
+    assert np.array_equal(h, h.T) and np.abs(h - h_r).max() <= 1e-9 * np.abs(h_r).max()
+
+
+@pytest.mark.parametrize("method", ["bfgs", "dfp"])
+def test_generic_path_device_objective_on_tiles(qn, qo, method):
+    n = 1024
+    q, b, x0, _ = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+
+    def make():
+        s = (qn.BFGS if method == "bfgs" else qn.DFP)(1e-10, x0)
+        s.set_tiling(-1, 0)  # generic kernels (the control step does the vector work)
+        return s
+    a, b_ = _generic_pair(make, lambda s: s.minimize(qn.MoreThuente(), obj, 25, 20))
+    _assert_same_run(a, b_, n)
+
+
+def test_generic_path_host_closure_on_tiles(qn, qo):
+    n = 1024
+    q, b, x0, _ = P.synth_problem(qo, n)
+    fn = lambda x: (0.5 * x @ (q @ x) - b @ x, q @ x - b)  # noqa: E731
+    a, b_ = _generic_pair(lambda: qn.BFGS(1e-10, x0), lambda s: s.minimize(qn.MoreThuente(), fn, 12, 20))
+    _assert_same_run(a, b_, n)
+    ref = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2)
+    ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b), 12, 20)
+    assert np.linalg.norm(a[0].x() - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
+
+
+def test_generic_path_logsumexp_dfp_on_tiles(qn, qo):
+    rng = np.random.default_rng(21)
+    m = n = 1024
+    amat = rng.standard_normal((m, n)) * (3.0 / np.sqrt(n))
+    c = rng.standard_normal(m)
+    x0 = rng.standard_normal(n)
+    obj = qn.LogSumExp(amat, c, 0.1)
+    a, b_ = _generic_pair(lambda: qn.DFP(1e-10, x0), lambda s: s.minimize(qn.MoreThuente(), obj, 15, 20))
+    _assert_same_run(a, b_, n)
+
+
+def test_generic_path_sr1b_bounded_on_tiles(qn, qo):
+    n = 1024
+    q, b, x0, _ = P.synth_problem(qo, n)
+    rng = np.random.default_rng(5)
+    xs = np.linalg.solve(q, b)
+    lb = np.where(rng.random(n) < 0.3, xs + 0.05, -np.inf)
+    ub = np.where(rng.random(n) < 0.3, np.maximum(xs - 0.05, lb + 0.1), np.inf)
+    obj = qn.Quadratic(q, b)
+    a, b_ = _generic_pair(lambda: qn.SR1B.new(1e-10, x0, lb, ub), lambda s: s.minimize(qn.MoreThuente(), obj, 20, 20))
+    _assert_same_run(a, b_, n)
+    x = a[0].x()
+    assert np.all(x >= lb - 1e-12) and np.all(x <= ub + 1e-12)
