@@ -621,6 +621,7 @@ struct qn_solver {
     double* sym_part = nullptr;
     int sym_nb = 0;
     bool no_sym = false, h_nonsym = false;
+    bool h_lower_stale = false; // a symmetric-storage run is (or was) updating the upper block triangle only
     int* newton_fail = nullptr;
     size_t newton_n64 = 0;
     std::vector<double> newton_hhost;
@@ -890,6 +891,8 @@ extern "C" int qn_solver_reset(qn_solver* s, const double* x0_host) {
     if (s->H) {
         hipLaunchKernelGGL(identity_fill_kernel, dim3(2048), dim3(256), 0, st, s->H, s->T);
         HIPCHK(hipGetLastError());
+        s->h_lower_stale = false;
+        s->h_nonsym = false;
     }
     HIPCHK(hipMemsetAsync(s->vec_block, 0, 9 * (size_t)s->T.n_pad * sizeof(double), st));
     HIPCHK(hipMemcpyAsync(s->V.x, x0_host, s->n * sizeof(double), hipMemcpyHostToDevice, st));
@@ -963,7 +966,18 @@ static QnHPassArgs hpass_args(qn_solver* s, int expect_phase) {
     return a;
 }
 
+// the symmetric-storage paths maintain the upper block triangle only: restore the lower one before anything reads whole rows
+static int ensure_full_h(qn_solver* s) {
+    if (!s->H || !s->h_lower_stale) return QN_OK;
+    const int b32 = s->T.n_pad / 32;
+    hipLaunchKernelGGL(sym_mirror_kernel, dim3(b32, b32), dim3(256), 0, s->ctx->stream, s->H, s->T.n_pad);
+    HIPCHK(hipGetLastError());
+    s->h_lower_stale = false;
+    return QN_OK;
+}
+
 static int flush_pending(qn_solver* s) { // H_stored <- H_true
+    QNCHK(ensure_full_h(s)); // (also from a callback in the middle of a symmetric-storage run)
     if (!s->H || !s->hctl->pending) return QN_OK;
     QnHPassArgs a = hpass_args(s, -1);
     a.force_nrhs = 0; a.force_pending = 1;
@@ -1022,6 +1036,7 @@ extern "C" int qn_solver_set_inv_hessian(qn_solver* s, const double* h) {
         for (size_t j = 0; j < n; ++j) rows[r * np + j] = h[i + j * n];
     }
     HIPCHK(hipMemcpy(s->H, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
+    s->h_lower_stale = false; // every entry was just replaced
     s->h_nonsym = false; // the symmetric-storage path needs H == H' bit for bit (BFGS / DFP keep it so from a symmetric start)
     for (size_t i = 0; i < n && !s->h_nonsym; ++i)
         for (size_t j = i + 1; j < n; ++j)
@@ -1224,6 +1239,7 @@ static int enqueue_hpass_fused(Run& r) {
     if (r.sym) {
         QnSymHPassArgs y{};
         y.H = s->H; y.T = a.T; y.F = a.F; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_HPASS; y.nb = s->sym_nb; y.part = s->sym_part;
+        s->h_lower_stale = true;
         {
             ProfScope ps(s, KC_HPASS);
             hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
@@ -1304,6 +1320,7 @@ static int enqueue_hpass_req(Run& r) {
         QnSymHPassArgs y{};
         y.H = s->H; y.T = s->T; y.T.cs = 1; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_HPASS; y.nb = s->sym_nb; y.part = s->sym_part;
         y.generic = 1; y.gsp = s->V.sp; y.gup = s->V.up; y.gvy = s->V.y; y.gvg = s->V.g; y.ghp = s->V.hp;
+        s->h_lower_stale = true;
         {
             ProfScope ps(s, KC_HPASS);
             hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
@@ -1557,11 +1574,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             }
         }
     }
-    if (r.sym || r.sym_generic) { // the run maintained the upper block triangle of H only: restore the lower one
-        const int b32 = s->T.n_pad / 32;
-        hipLaunchKernelGGL(sym_mirror_kernel, dim3(b32, b32), dim3(256), 0, c->stream, s->H, s->T.n_pad);
-        HIPCHK(hipGetLastError());
-    }
+    QNCHK(ensure_full_h(s)); // a symmetric-storage run maintained the upper block triangle of H only: restore the lower one
     if (r.fused) { // export back to the canonical buffers
         const size_t np = s->T.n_pad, vb = np * sizeof(double);
         HIPCHK(hipMemcpyAsync(s->V.x, s->V.F.X0 + (size_t)h->xc * np, vb, hipMemcpyDeviceToDevice, c->stream));

@@ -201,3 +201,26 @@ def test_generic_path_sr1b_bounded_on_tiles(qn, qo):
     _assert_same_run(a, b_, n)
     x = a[0].x()
     assert np.all(x >= lb - 1e-12) and np.all(x <= ub + 1e-12)
+
+
+def test_callback_sees_a_complete_hessian_mid_run(qn, qo):
+    """ls_solver.rs:105-107: the callback gets `&Self`; approx_inv_hessian() called from it must be the whole matrix although
+    the run itself only maintains the upper block triangle."""
+    n = 1024
+    q, b, x0, _ = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+    seen = []
+
+    def cb(solver):
+        h = solver.approx_inv_hessian()
+        seen.append((solver.k(), bool(np.array_equal(h, h.T)), h))
+
+    s = qn.BFGS(1e-10, x0)
+    with pytest.raises(qn.MaxIterReached):
+        s.minimize(qn.MoreThuente(), obj, 6, 20, cb)
+    assert [k for k, _, _ in seen] == [1, 2, 3, 4, 5, 6] and all(sym for _, sym, _ in seen)
+    ref = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2)
+    hs = []
+    ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b), 6, 20, callback=lambda r: hs.append(r.approx_inv_hessian))
+    for (_, _, h), h_ref in zip(seen, hs):
+        assert np.abs(h - h_ref).max() <= 1e-8 * np.abs(h_ref).max()
