@@ -139,7 +139,8 @@ typedef struct {
 } qn_oracle;
 
 /* Built-in benchmark objective (build-defined): f = 1/2 x'Qx - b'x, g = Qx - b.
- * `q_rowmajor_host` is the full symmetric n x n matrix; each rank uploads only its own rows. */
+ * `q_rowmajor_host` is the full symmetric n x n matrix; each rank uploads only its own rows.  (A matrix that is not symmetric
+ * bit for bit is multiplied as given -- the symmetric-storage evaluation is then not used.) */
 int qn_quadratic_create(qn_context* ctx, size_t n, const double* q_rowmajor_host, const double* b_host, qn_objective** out);
 /* Same objective with Q generated on the device, shard-locally: off-diagonal Q_ij = u(seed,min,max)/n,
  * u in [-1,1) from a counter-based splitmix64 hash; diagonal given (SPD if diag_i >= 1). */

@@ -390,6 +390,7 @@ struct qn_objective {
     QnTile T{};
     double* Q = nullptr; // this rank's rows, [rpr][n_pad]
     double* b = nullptr; // n_pad
+    bool q_symmetric = true; // quadratic: Q == Q' bit for bit (checked at creation); the symmetric-storage evaluation needs it
     // scratch for qn_objective_eval
     double *ex = nullptr, *eq = nullptr, *eg = nullptr, *ef = nullptr;
     // log-sum-exp: A rows are in Q ([mrpr][n_pad]), c in b (m_pad)
@@ -427,6 +428,11 @@ extern "C" int qn_quadratic_create(qn_context* ctx, size_t n, const double* q_ho
         HIPCHK(hipMemcpy2D(o->Q, (size_t)o->T.n_pad * sizeof(double), q_host + r0 * n, n * sizeof(double), n * sizeof(double), nr,
                            hipMemcpyHostToDevice));
     }
+    // g = Q x - b is the gradient of f only for a symmetric Q, but nothing stops a caller from passing another matrix: the row
+    // kernels multiply by what was given, so the symmetric-storage evaluation is used only when Q is symmetric bit for bit
+    for (size_t i = 0; i < n && o->q_symmetric; ++i)
+        for (size_t j = i + 1; j < n; ++j)
+            if (q_host[i * n + j] != q_host[j * n + i]) { o->q_symmetric = false; break; }
     return QN_OK;
 }
 
@@ -1500,7 +1506,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     s->V.fused_hint = h->fused;
     // ... and on the upper block triangle only (half the bytes) when H and Q are whole 128-tiles on one rank
     const bool sym_ok = c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
-    r.sym = r.fused && sym_ok;
+    r.sym = r.fused && sym_ok && r.obj && r.obj->q_symmetric;
     // the generic path's H pass alone (closures, log-sum-exp objective, SR1, bounded variants): same tiles, sums into V.hp
     r.sym_generic = !r.fused && sym_ok && s->H && s->hcs == 1 && (s->method == QN_BFGS || s->method == QN_DFP || s->method == QN_SR1);
     if (r.sym_generic) {

@@ -224,3 +224,21 @@ def test_callback_sees_a_complete_hessian_mid_run(qn, qo):
     ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b), 6, 20, callback=lambda r: hs.append(r.approx_inv_hessian))
     for (_, _, h), h_ref in zip(seen, hs):
         assert np.abs(h - h_ref).max() <= 1e-8 * np.abs(h_ref).max()
+
+
+def test_non_symmetric_objective_matrix_is_multiplied_as_given(qn, qo):
+    """A caller may hand qn_quadratic_create a Q that is not symmetric (g = Qx - b is then not the gradient of f, but that is the
+    caller's business): the evaluation must multiply by the matrix as given, i.e. stay on the row kernels."""
+    n = 1024
+    q, b, x0, _ = P.synth_problem(qo, n)
+    rng = np.random.default_rng(2)
+    qa = q + 1e-3 * np.triu(rng.standard_normal((n, n)), 1)  # upper triangle perturbed only
+    obj = qn.Quadratic(qa, b)
+    ev = obj(x0)
+    assert np.allclose(ev.g(), qa @ x0 - b, rtol=1e-12, atol=1e-12)
+    s = qn.BFGS(1e-10, x0)
+    try:
+        s.minimize(qn.MoreThuente(), obj, 3, 20)
+    except qn.SolverError:
+        pass
+    assert s.stats()["matrix_bytes_per_pass"] == n * n * 8
