@@ -1211,6 +1211,7 @@ static int enqueue_eval_fused(Run& r, int after_h) {
     if (r.sym) {
         QnSymEvalArgs y{};
         y.Q = r.obj->Q; y.T = a.T; y.F = a.F; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_EVAL; y.after_h = after_h; y.nb = s->sym_nb; y.part = s->sym_part;
+        y.nt = 0; // Q is only read: non-temporal loads measured no gain at n = 32768 and -4 % at n = 16384
         {
             ProfScope ps(s, KC_EVAL);
             hipLaunchKernelGGL(sym_eval_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
@@ -1245,6 +1246,7 @@ static int enqueue_hpass_fused(Run& r) {
     if (r.sym) {
         QnSymHPassArgs y{};
         y.H = s->H; y.T = a.T; y.F = a.F; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_HPASS; y.nb = s->sym_nb; y.part = s->sym_part;
+        y.nt = s->T.n_pad >= 8192; // past the Infinity Cache (same-box A/B: +7 % at n = 32768, +3 % at 8192, -1 % at 4096)
         s->h_lower_stale = true;
         {
             ProfScope ps(s, KC_HPASS);
@@ -1326,6 +1328,7 @@ static int enqueue_hpass_req(Run& r) {
         QnSymHPassArgs y{};
         y.H = s->H; y.T = s->T; y.T.cs = 1; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_HPASS; y.nb = s->sym_nb; y.part = s->sym_part;
         y.generic = 1; y.gsp = s->V.sp; y.gup = s->V.up; y.gvy = s->V.y; y.gvg = s->V.g; y.ghp = s->V.hp;
+        y.nt = s->T.n_pad >= 8192; // past the Infinity Cache (same-box A/B: +7 % at n = 32768, +3 % at 8192, -1 % at 4096)
         s->h_lower_stale = true;
         {
             ProfScope ps(s, KC_HPASS);

@@ -22,14 +22,15 @@
 #define QN_SYM_WAVES 8                       // waves per tile workgroup (512 threads)
 #define QN_SYM_RPW (QN_TB / QN_SYM_WAVES)     // rows of the tile per wave
 #define QN_SYM_TPB (64 * QN_SYM_WAVES)
-// cache policy of the streamed tiles: at n = 4096 the two half matrices (2 x 64 MiB) fit the 256 MiB Infinity Cache
-#ifdef QN_SYM_NT
-#define QN_SYM_LD_H(p) QN_LD2_H(p)
-#define QN_SYM_ST_H(p, v) QN_ST2_STREAM(p, v)
-#else
-#define QN_SYM_LD_H(p) ld2(p)
-#define QN_SYM_ST_H(p, v) st2((p), (v))
-#endif
+// Cache policy of the streamed tiles, chosen per run (`nt`): at n = 4096 the two half matrices (2 x 64 MiB) fit the 256 MiB
+// Infinity Cache and plain accesses win (+2 %); past it (n >= 8192) every byte is touched once per pass and non-temporal
+// loads / stores win (n = 32768: 285 -> 313 it/s).
+template <bool NT> __device__ __forceinline__ v2d qn_sym_ld(const double* p) {
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p)) : ld2(p);
+}
+template <bool NT> __device__ __forceinline__ void qn_sym_st(double* p, v2d v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(p)); else st2(p, v);
+}
 
 struct QnSymEvalArgs {
     const double* Q;
@@ -40,6 +41,7 @@ struct QnSymEvalArgs {
     int after_h;
     int nb;
     double* part; // [nb][nb][2][QN_TB]
+    int nt;       // non-temporal tile loads
 };
 struct QnSymHPassArgs {
     double* H;
@@ -54,6 +56,7 @@ struct QnSymHPassArgs {
     int generic;
     const double *gsp, *gup, *gvy, *gvg;
     double* ghp;
+    int nt; // non-temporal tile loads and stores
 };
 
 // launch-linear index t -> upper-triangle tile (I, J >= I), row-major over I
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_eval_tile_kernel(const QnSymEv
     v2d h[QN_SYM_RPW]; // the wave's whole share of the tile is requested before the control block is read: the grid is a single
                        // wave of workgroups at n = 4096, so nothing else would hide the prologue's two dependent round trips
 #pragma unroll
-    for (int r = 0; r < QN_SYM_RPW; ++r) h[r] = QN_LD2_Q(qbase + (size_t)r * np);
+    for (int r = 0; r < QN_SYM_RPW; ++r) h[r] = a.nt ? qn_sym_ld<true>(qbase + (size_t)r * np) : qn_sym_ld<false>(qbase + (size_t)r * np);
     QnEvalReq q;
     if (!qn_eval_request(a.ctl, a.F, a.expect_phase, a.after_h, red4, q)) return;
     const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void sym_eval_reduce_kernel(const QnSymEvalArg
 // ------------------------------------------------------------------------------------------------
 // H pass: pending rank-2 update of the tile, row and column dots with [y, g+] (update pass) or [g] (direction pass)
 // ------------------------------------------------------------------------------------------------
-template <int NRHS, bool PENDING>
+template <int NRHS, bool PENDING, bool NT>
 __device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int I, int J, const double* __restrict__ sp, const double* __restrict__ up,
                                                     const double* __restrict__ r0v, const double* __restrict__ gt, double c_ss, double c_su,
                                                     double c_uu, v2d (&h)[8], double (*rowv)[QN_TB], double (*colred)[2][QN_TB]) { // colred[QN_SYM_WAVES][2][QN_TB]
@@ -275,7 +278,7 @@ __device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int
     for (int rc = 0; rc < QN_SYM_RPW; rc += 8) {
         if (rc) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) h[r] = QN_SYM_LD_H(hbase + (size_t)(rc + r) * np);
+            for (int r = 0; r < 8; ++r) h[r] = qn_sym_ld<NT>(hbase + (size_t)(rc + r) * np);
         }
         double racc[8 * NRHS];
 #pragma unroll
@@ -297,7 +300,7 @@ __device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int
                 const bool rowok = (i0 + ri) < n;
                 hn.x = (rowok && c0ok) ? hn.x : 0.0;
                 hn.y = (rowok && c1ok) ? hn.y : 0.0;
-                QN_SYM_ST_H(hbase + (size_t)(rc + r) * np, hn);
+                qn_sym_st<NT>(hbase + (size_t)(rc + r) * np, hn);
             }
             double t0 = hn.x * a0.x;
             t0 = __builtin_fma(hn.y, a0.y, t0);
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_hpass_tile_kernel(const QnSymH
     {
         const double* hbase = a.H + (size_t)(I * QN_TB + wave * QN_SYM_RPW) * np + J * QN_TB + 2 * lane;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) h[r] = QN_SYM_LD_H(hbase + (size_t)r * np);
+        for (int r = 0; r < 8; ++r) h[r] = a.nt ? qn_sym_ld<true>(hbase + (size_t)r * np) : qn_sym_ld<false>(hbase + (size_t)r * np);
     }
     const QnCtl* __restrict__ ctl = a.ctl;
     const int phase = ctl->phase;
@@ -364,13 +367,15 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_hpass_tile_kernel(const QnSymH
         sp = a.F.S0 + (size_t)ctl->sc * np; up = a.F.UP; gt = a.F.GT;
         r0v = (nrhs == 2) ? a.F.Y : a.F.GT;
     }
-    if (pending) {
-        if (nrhs == 2) sym_hpass_tile_body<2, true>(a, I, J, sp, up, r0v, gt, c_ss, c_su, c_uu, h, rowv, colred);
-        else sym_hpass_tile_body<1, true>(a, I, J, sp, up, r0v, gt, c_ss, c_su, c_uu, h, rowv, colred);
+#define QN_SYM_BODY(NR, PE, NTF) sym_hpass_tile_body<NR, PE, NTF>(a, I, J, sp, up, r0v, gt, c_ss, c_su, c_uu, h, rowv, colred)
+    if (a.nt) {
+        if (pending) { if (nrhs == 2) QN_SYM_BODY(2, true, true); else QN_SYM_BODY(1, true, true); }
+        else { if (nrhs == 2) QN_SYM_BODY(2, false, true); else QN_SYM_BODY(1, false, true); }
     } else {
-        if (nrhs == 2) sym_hpass_tile_body<2, false>(a, I, J, sp, up, r0v, gt, c_ss, c_su, c_uu, h, rowv, colred);
-        else sym_hpass_tile_body<1, false>(a, I, J, sp, up, r0v, gt, c_ss, c_su, c_uu, h, rowv, colred);
+        if (pending) { if (nrhs == 2) QN_SYM_BODY(2, true, false); else QN_SYM_BODY(1, true, false); }
+        else { if (nrhs == 2) QN_SYM_BODY(2, false, false); else QN_SYM_BODY(1, false, false); }
     }
+#undef QN_SYM_BODY
 }
 
 // block-row R: u_i, v_i = sums of the slots; the epilogue of h_pass_fused_kernel for these 128 rows
