@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define QN_ABI_VERSION 1
+#define QN_ABI_VERSION 2
 
 /* SolverError (ls_solver.rs:10-20); 0 is Ok(()) */
 typedef enum {
@@ -204,11 +204,13 @@ int qn_solver_get_inv_hessian(qn_solver* s, double* out_colmajor_host, int all_r
 int qn_solver_set_inv_hessian(qn_solver* s, const double* h_colmajor_host);
 
 /* ---- build-side instrumentation (not in the reference) ---- */
+#define QN_TRACE_LS_MODIFIED (1 << 30)
 typedef struct {
     double f, gnorm, t, s_norm, y_norm; /* f(x_k), ||g_k|| (inf-norm for gradient descent), step, ||s||, ||y|| */
     int32_t n_evals;   /* oracle calls of the reference's sequence in this iteration (memoised ones included) */
     int32_t ls_iters;  /* line-search inner iterations started */
-    int32_t ls_cases;  /* More-Thuente: base-8 digits, one per inner iteration: 1..4 trial case, 0 returned */
+    int32_t ls_cases;  /* More-Thuente: base-8 digits, one per inner iteration: 1..4 trial case, 0 returned;
+                        * bit 30 (QN_TRACE_LS_MODIFIED): the modified-updating switch (morethuente.rs:212-215) was thrown */
     int32_t updated;   /* 1 if the inverse Hessian was updated */
 } qn_trace_rec;
 /* record up to `cap` iterations of the next qn_minimize calls; x_trace (optional) gets x_{k+1} rows */
@@ -227,8 +229,23 @@ typedef struct {
     double   t_hpass_ms, t_eval_ms, t_ctl_ms, t_comm_ms; /* HIP-event time per kernel class (profiling mode) */
     uint64_t n_hpass_timed, n_eval_timed, n_ctl_timed, n_comm_timed;
     uint64_t matrix_bytes_per_pass; /* bytes of H (or Q) one pass of the last run streams on this rank: the rank's rows, or -- on the
-                                       symmetric-storage path of a single rank -- the upper block triangle's 128 x 128 tiles */
+                                       symmetric-storage path -- the 128 x 128 tiles of the symmetric half this rank owns */
+    /* The counters above describe the LAST qn_minimize call (the device control block restarts them with k, ls_solver.rs:74).
+     * These accumulate over every qn_minimize call made on this solver, so a harness that makes several calls (warm-up,
+     * timed region, restarts after convergence) can difference them. */
+    uint64_t total_minimize_calls, total_iterations, total_oracle_calls, total_oracle_evals, total_h_passes, total_h_bytes,
+        total_obj_bytes;
+    uint32_t path; /* QN_PATH_* flags of the last call: which kernels serviced it */
+    uint32_t _pad;
+    /* profiling mode, symmetric-storage path: the small second launch of a pass (slot sums + epilogue), timed on its own;
+     * t_hpass_ms / t_eval_ms then hold the tile kernels alone */
+    double   t_hreduce_ms, t_ereduce_ms;
+    uint64_t n_hreduce_timed, n_ereduce_timed;
 } qn_stats;
+#define QN_PATH_FUSED 1u       /* fused fast path (device quadratic, memoised): no kernel but the streaming ones touches an n-vector */
+#define QN_PATH_SYM 2u         /* ... on the symmetric half of H and Q only */
+#define QN_PATH_SYM_GENERIC 4u /* generic path whose H pass runs on the symmetric half */
+#define QN_PATH_PIPELINED 8u   /* predicated kernels enqueued ahead of the device-side decisions (no host sync per step) */
 int qn_solver_get_stats(qn_solver* s, qn_stats* out);
 /* profiling != 0: bracket every launch with HIP events on the solver's stream (slower; for roofline reports) */
 int qn_solver_set_profiling(qn_solver* s, int on);

@@ -48,7 +48,14 @@ class Stats(C.Structure):
                 ("launches", C.c_uint64), ("host_syncs", C.c_uint64),
                 ("t_hpass_ms", C.c_double), ("t_eval_ms", C.c_double), ("t_ctl_ms", C.c_double), ("t_comm_ms", C.c_double),
                 ("n_hpass_timed", C.c_uint64), ("n_eval_timed", C.c_uint64), ("n_ctl_timed", C.c_uint64), ("n_comm_timed", C.c_uint64),
-                ("matrix_bytes_per_pass", C.c_uint64)]
+                ("matrix_bytes_per_pass", C.c_uint64),
+                ("total_minimize_calls", C.c_uint64), ("total_iterations", C.c_uint64), ("total_oracle_calls", C.c_uint64),
+                ("total_oracle_evals", C.c_uint64), ("total_h_passes", C.c_uint64), ("total_h_bytes", C.c_uint64),
+                ("total_obj_bytes", C.c_uint64), ("path", C.c_uint32), ("_pad", C.c_uint32),
+                ("t_hreduce_ms", C.c_double), ("t_ereduce_ms", C.c_double), ("n_hreduce_timed", C.c_uint64), ("n_ereduce_timed", C.c_uint64)]
+
+
+PATH_FUSED, PATH_SYM, PATH_SYM_GENERIC, PATH_PIPELINED = 1, 2, 4, 8
 
 
 # every symbol include/qn_hip.h declares: (name, restype, argtypes)

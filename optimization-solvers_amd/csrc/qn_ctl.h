@@ -44,6 +44,8 @@ enum QnState : int32_t {
     QN_ST_LS_ONLY // qn_compute_step_len: g.d for the caller's direction, then the line search alone
 };
 
+#define QN_LS_MODIFIED_BIT (1 << 30) // trace: ls_cases bit 30 = the modified-updating switch of morethuente.rs:212-215 was thrown
+
 struct QnTraceRec { // == qn_trace_rec (include/qn_hip.h)
     double f, gnorm, t, s_norm, y_norm;
     int32_t n_evals, ls_iters, ls_cases, updated;

@@ -223,7 +223,7 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
                 c.phi_t_f = f_et; c.phi_t_g = gd_t;
                 c.psi_t_f = f_et - c.f_k - c.mt_c1 * t * c.gd0; // psi, :140-149
                 c.psi_t_g = gd_t - c.mt_c1 * c.gd0;
-                if (!c.use_mod && c.psi_t_f <= 0. && c.phi_t_g > 0.) c.use_mod = 1; // :212-215
+                if (!c.use_mod && c.psi_t_f <= 0. && c.phi_t_g > 0.) { c.use_mod = 1; c.tr_ls_cases |= QN_LS_MODIFIED_BIT; } // :212-215 (sticky)
                 req_eval_t(c, c.tl, QN_ST_MT_AFTER_TL, 0); // :217
             }
         } break;

@@ -606,7 +606,7 @@ extern "C" int qn_objective_eval(qn_objective* o, const double* x_host, double* 
 // ------------------------------------------------------------------------------------------------
 // solver
 // ------------------------------------------------------------------------------------------------
-enum { KC_HPASS = 0, KC_EVAL = 1, KC_CTL = 2, KC_COMM = 3, KC_COUNT = 4 };
+enum { KC_HPASS = 0, KC_EVAL = 1, KC_CTL = 2, KC_COMM = 3, KC_HREDUCE = 4, KC_EREDUCE = 5 };
 struct TimedEvent { hipEvent_t a, b; int cls; };
 
 struct qn_solver {
@@ -673,6 +673,8 @@ static void prof_collect(qn_solver* s) {
             case KC_HPASS: s->stats.t_hpass_ms += ms; s->stats.n_hpass_timed++; break;
             case KC_EVAL: s->stats.t_eval_ms += ms; s->stats.n_eval_timed++; break;
             case KC_CTL: s->stats.t_ctl_ms += ms; s->stats.n_ctl_timed++; break;
+            case KC_HREDUCE: s->stats.t_hreduce_ms += ms; s->stats.n_hreduce_timed++; break;
+            case KC_EREDUCE: s->stats.t_ereduce_ms += ms; s->stats.n_ereduce_timed++; break;
             default: s->stats.t_comm_ms += ms; s->stats.n_comm_timed++; break;
             }
         }
@@ -1217,7 +1219,7 @@ static int enqueue_eval_fused(Run& r, int after_h) {
             hipLaunchKernelGGL(sym_eval_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
         }
         {
-            ProfScope ps(s, KC_CTL);
+            ProfScope ps(s, KC_EREDUCE);
             hipLaunchKernelGGL(sym_eval_reduce_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
         }
         s->stats.launches += 2;
@@ -1253,7 +1255,7 @@ static int enqueue_hpass_fused(Run& r) {
             hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
         }
         {
-            ProfScope ps(s, KC_CTL);
+            ProfScope ps(s, KC_HREDUCE);
             hipLaunchKernelGGL(sym_hpass_reduce_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
         }
         s->stats.launches += 2;
@@ -1335,7 +1337,7 @@ static int enqueue_hpass_req(Run& r) {
             hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
         }
         {
-            ProfScope ps(s, KC_CTL);
+            ProfScope ps(s, KC_HREDUCE);
             hipLaunchKernelGGL(sym_hpass_reduce_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
         }
         s->stats.launches += 2;
@@ -1604,6 +1606,15 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     s->stats.h_bytes = (h->n_hpasses + h->n_hpass_rw) * shard;
     s->stats.obj_bytes = (r.oracle_tpl == QN_ORACLE_QUAD) ? h->n_oracle_evals * (r.sym ? shard : full_shard) : 0;
     s->stats.matrix_bytes_per_pass = shard;
+    s->stats.total_minimize_calls++;
+    s->stats.total_iterations += s->stats.iterations;
+    s->stats.total_oracle_calls += s->stats.oracle_calls;
+    s->stats.total_oracle_evals += s->stats.oracle_evals;
+    s->stats.total_h_passes += s->stats.h_passes;
+    s->stats.total_h_bytes += s->stats.h_bytes;
+    s->stats.total_obj_bytes += s->stats.obj_bytes;
+    s->stats.path = (r.fused ? QN_PATH_FUSED : 0u) | (r.sym ? QN_PATH_SYM : 0u) | (r.sym_generic ? QN_PATH_SYM_GENERIC : 0u) |
+                    (sync ? 0u : QN_PATH_PIPELINED);
     if (status == QN_ABNORMAL_TERMINATION) return fail(status, "solver state machine aborted");
     return status;
 }

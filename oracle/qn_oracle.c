@@ -280,7 +280,10 @@ static double morethuente_step(const qo_linesearch* ls, const double* x, double 
         double psi_t_f = phi_t_f - phi_0_f - ls->c1 * t * phi_0_g;
         double psi_t_g = phi_t_g - ls->c1 * phi_0_g;
 
-        if (!use_modified_updating && psi_t_f <= 0. && phi_t_g > 0.) use_modified_updating = 1; /* :212-215 */
+        if (!use_modified_updating && psi_t_f <= 0. && phi_t_g > 0.) { /* :212-215 */
+            use_modified_updating = 1;
+            if (st) st->cases |= QO_LS_MODIFIED_BIT; /* instrumentation: the sticky switch was thrown in this line search */
+        }
 
         double f_etl;
         qo_axpy_new(x, tl, d, xw, n);

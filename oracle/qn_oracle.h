@@ -73,6 +73,7 @@ int qo_solver_decrement_squared(const qo_solver* s, double* out); /* Option<f64>
 /* callback: Option<&mut dyn FnMut(&Self)> (ls_solver.rs:72,105-107) */
 typedef void (*qo_callback_fn)(void* user, const qo_solver* solver);
 
+#define QO_LS_MODIFIED_BIT (1 << 30)
 /* per-outer-iteration trace record (build-side instrumentation, not in the reference) */
 typedef struct {
     double f;        /* f(x_k) at loop top */
@@ -81,7 +82,8 @@ typedef struct {
     double s_norm, y_norm;
     int32_t n_evals; /* oracle calls made during this outer iteration (loop-top call included) */
     int32_t ls_iters;/* line-search inner iterations started */
-    int32_t ls_cases;/* More-Thuente: base-8 digits, one per inner iteration: 1..4 = trial case, 0 = returned */
+    int32_t ls_cases;/* More-Thuente: base-8 digits, one per inner iteration: 1..4 = trial case, 0 = returned;
+                      * bit 30 (QO_LS_MODIFIED_BIT): the modified-updating switch (morethuente.rs:212-215) was thrown */
     int32_t updated; /* 1 if the inverse Hessian was updated */
 } qo_trace_rec;
 

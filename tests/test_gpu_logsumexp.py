@@ -1,6 +1,7 @@
 """GPU tests of row f1: DFP / BFGS + More-Thuente on the log-sum-exp objective
-f = log sum_i exp(a_i'x + c_i) + mu/2 ||x||^2 -- a non-quadratic objective that drives the line search through
-its other cases -- against the CPU oracle, and BASELINE.json config 5's size through size-independent properties."""
+f = log sum_i exp(a_i'x + c_i) + mu/2 ||x||^2 -- a non-quadratic objective, evaluated by its own kernels on the generic
+path -- against the CPU oracle, and BASELINE.json config 5's size through size-independent properties.  (On this family
+More-Thuente accepts t = 1 in almost every iteration; its cases 2-4 are driven by tests/test_gpu_mt_cases.py.)"""
 import numpy as np
 import pytest
 

@@ -307,12 +307,26 @@ def test_golden_fixtures(qn, qo):
         n = c["n"]
         diag, b, x0 = unhx(c["diag"]), unhx(c["b"]), unhx(c["x0"])
         obj = qn.Quadratic.synthetic(n, c["seed"], diag, b)
-        s, st = _run_gpu(qn, c["method"], c["ls"], obj, x0, c["max_iter"], tol=c["tol"])
+        if c.get("workload"):  # More-Thuente cases 2-4 (tests/mt_workloads.py): scaled H0 and / or a finite t_max
+            s = (qn.BFGS if c["method"] == "bfgs" else qn.DFP)(c["tol"], x0)
+            if c["h0"] is not None:
+                s.set_approx_inv_hessian(c["h0"] * np.eye(n))
+            s.set_trace(c["max_iter"], with_x=True)
+            ls = qn.MoreThuente() if c["t_max"] is None else qn.MoreThuente().with_t_max(c["t_max"])
+            try:
+                s.minimize(ls, obj, c["max_iter"], c["max_iter_ls"])
+                st = 0
+            except qn.MaxIterReached:
+                st = 1
+            assert st == c["status"] and s.k() == c["k"], (n, c["workload"], c["method"])
+        else:
+            s, st = _run_gpu(qn, c["method"], c["ls"], obj, x0, c["max_iter"], tol=c["tol"])
         tr, xs = s.trace()
         ref = [dict(t=t, f=f, gnorm=g, ls_cases=lc, n_evals=ne, ls_iters=0) for t, f, g, lc, ne in
                zip(unhx(c["t"]), unhx(c["f"]), unhx(c["gnorm"]), c["ls_cases"], c["n_evals"])]
         ref_xs = np.array([unhx(r) for r in c["x_trace"]])
-        w = min(_window(ref), len(tr))
+        w = len(ref) if c.get("workload") else min(_window(ref), len(tr))  # (a workload's max_iter is its comparison window)
+        assert len(tr) >= w
         for k in range(w):
             assert tr[k]["ls_cases"] == ref[k]["ls_cases"] and tr[k]["n_evals"] == ref[k]["n_evals"], (n, c["method"], c["ls"], k)
             assert abs(tr[k]["t"] - ref[k]["t"]) <= T_TOL * abs(ref[k]["t"])
