@@ -246,6 +246,7 @@ typedef struct {
 #define QN_PATH_SYM 2u         /* ... on the symmetric half of H and Q only */
 #define QN_PATH_SYM_GENERIC 4u /* generic path whose H pass runs on the symmetric half */
 #define QN_PATH_PIPELINED 8u   /* predicated kernels enqueued ahead of the device-side decisions (no host sync per step) */
+#define QN_PATH_SYM2 16u       /* QN_PATH_SYM with the solver's decisions taken in every kernel's prologue (5 launches per iteration) */
 int qn_solver_get_stats(qn_solver* s, qn_stats* out);
 /* profiling != 0: bracket every launch with HIP events on the solver's stream (slower; for roofline reports) */
 int qn_solver_set_profiling(qn_solver* s, int on);
@@ -254,7 +255,8 @@ int qn_solver_set_profiling(qn_solver* s, int on);
 int qn_solver_set_sync_mode(qn_solver* s, int sync);
 /* tuning: rows per workgroup tile (4, 8 or 16), column splits (>= 1); 0 keeps the default.  Diagnostics: rows = -1 selects the
  * generic (non-fused) kernels, -2 the fused kernels without the deferred update step, -3 the fused ROW kernels on the full
- * matrices instead of the symmetric-storage tiles; col_splits = 100 + U selects U column chunks per loop trip */
+ * matrices instead of the symmetric-storage tiles, -4 the first-generation symmetric tile kernels (separate control
+ * launches); col_splits = 100 + U selects U column chunks per loop trip */
 int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits);
 
 /* ---------------------------------------------------------------------------------------------

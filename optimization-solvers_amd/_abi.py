@@ -55,7 +55,7 @@ class Stats(C.Structure):
                 ("t_hreduce_ms", C.c_double), ("t_ereduce_ms", C.c_double), ("n_hreduce_timed", C.c_uint64), ("n_ereduce_timed", C.c_uint64)]
 
 
-PATH_FUSED, PATH_SYM, PATH_SYM_GENERIC, PATH_PIPELINED = 1, 2, 4, 8
+PATH_FUSED, PATH_SYM, PATH_SYM_GENERIC, PATH_PIPELINED, PATH_SYM2 = 1, 2, 4, 8, 16
 
 
 # every symbol include/qn_hip.h declares: (name, restype, argtypes)

@@ -17,6 +17,7 @@ enum QnPhase : int32_t {
     QN_PH_DONE = 4,      // finished: status holds the SolverError code
     QN_PH_REQ_HPASS_EVAL = 7, // fused path: run h_pass, then the evaluation at (req_kind, req_t) whose direction uses the
                               // coefficients of the update this pass completes (derived from the pass's partial sums)
+    QN_PH_REQ_VEC = 8,   // sym2: turn the slots of the last evaluation into vectors (g+, y, x+, s) and their sums
     QN_PH_REQ_NEWTON = 6 // Newton: factorise the Hessian at x_k and solve for d and H^-1 d (5 is the in-kernel RUNNING marker)
 };
 
@@ -79,6 +80,12 @@ struct QnCtl {
     int32_t fused, xc, sc, dir_mode, gd0_valid;
     int32_t no_defer, _padd; // diagnostics: disable the deferred update
     int32_t defer_u; // the coefficients of the update in flight are not committed yet (QN_PH_REQ_HPASS_EVAL)
+    // second-generation symmetric path (qn_sym2.hip.h): the machine runs in the prologue of every kernel
+    int32_t sym2;     // this run uses it
+    int32_t serviced; // 0: the request in `phase` is pending, 1: its tiles are done and wait for their reduce launch, 2: complete
+    int32_t ev_par;   // half of the per-workgroup evaluation scalars the next evaluation writes
+    int32_t ev_kind;  // req_kind of the last serviced evaluation ...
+    double ev_t;      // ... and its step: what the accept-reduce turns into vectors
     double dir_ug, dir_sg;
     double st_gd0, st_yy, st_ys, st_gg, st_ss, st_dnf;
     double hp_yu, hp_ug, hp_sg;

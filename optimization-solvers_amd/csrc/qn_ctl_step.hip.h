@@ -46,7 +46,8 @@ __device__ __forceinline__ bool qn_check_is_scalar(const QnCtl& c) {
     return c.method != 2 && (c.small_n || c.gg_valid || c.method == 3);
 }
 
-__device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double* small_scratch) {
+// `side_effects`: false in all but one of the workgroups that run the machine redundantly (qn_sym2.hip.h): no trace stores
+__device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double* small_scratch, const bool side_effects = true) {
     const int n = V.n, n_pad = V.n_pad;
     for (int guard = 0; guard < (1 << 22); ++guard) {
         if (c.phase != QN_PH_RUNNING) return;
@@ -114,7 +115,7 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
                 c.hp_lazy = 1; c.hp_nrhs = 2;
                 const double fk = c.f_k;
                 const bool will_continue = (c.k + 1 < c.max_iter) && !(isnan(fk) || isinf(fk)) && !(sqrt(c.gg) < c.tol);
-                if (will_continue && !c.callback_mode && !c.no_defer) {
+                if (will_continue && !c.callback_mode && !c.no_defer && !c.sym2) { // (sym2: every step is a prologue, nothing to save)
                     // Deferred update: everything the step after the H pass would decide is already known except the
                     // update's coefficients (they need y.u, u.g+, s.g+ from the pass).  Run the rest of the iteration
                     // bookkeeping now; the next evaluation request becomes QN_PH_REQ_HPASS_EVAL, its kernel derives the
@@ -312,7 +313,7 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
                 r.s_norm = c.has_s_norm ? c.s_norm : NAN;
                 r.y_norm = c.has_y_norm ? c.y_norm : NAN;
                 r.n_evals = c.tr_n_evals; r.ls_iters = c.tr_ls_iters; r.ls_cases = c.tr_ls_cases; r.updated = c.tr_updated;
-                V.trace[c.k] = r;
+                if (side_effects) V.trace[c.k] = r;
             }
             c.xtrace_done = 0;
             c.k += 1;

@@ -52,9 +52,7 @@ __device__ __forceinline__ double qn_partial_col_sum(const double* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc = acc + v[u];
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
-    return acc;
+    return qn_wave_sum(acc);
 }
 
 // coefficients of the symmetric rank-2 form of bfgs.rs:115-124 (method 0) / dfp.rs:115-120 (method 1)

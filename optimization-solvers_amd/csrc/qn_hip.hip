@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -628,6 +629,16 @@ struct qn_solver {
     int sym_nb = 0;
     bool no_sym = false, h_nonsym = false;
     bool h_lower_stale = false; // a symmetric-storage run is (or was) updating the upper block triangle only
+    bool h_diag_stale = false;  // ... and (second-generation kernels) only the upper triangle of 16 x 16 sub-blocks inside the diagonal tiles
+    // second-generation symmetric path (qn_sym2.hip.h): static work lists, per-workgroup scalars, double-buffered control block
+    int *s2_items = nullptr, *s2_first = nullptr;
+    int s2_G = 0, s2_nb = 0, s2_maxk = 0;
+    double *s2_wgE = nullptr, *s2_wgH = nullptr, *s2_rp = nullptr;
+    QnCtl* s2_ctl = nullptr;
+    bool no_sym2 = false; // diagnostics: the first-generation tile kernels (qn_sym.hip.h)
+    // After a fused run the iterate and the pending update's vectors stay where the fused kernels keep them (X0[xc], S0[sc], UN);
+    // they are copied back to the canonical buffers only when something other than the next fused run wants them.
+    bool fused_live = false;
     int* newton_fail = nullptr;
     size_t newton_n64 = 0;
     std::vector<double> newton_hhost;
@@ -711,6 +722,52 @@ static int solver_alloc_fused(qn_solver* s, bool sym) {
     return QN_OK;
 }
 
+// sym2: work items (off-diagonal tiles cost 1, diagonal tiles -- upper triangle only -- 0.5625), assigned to min(items, 512)
+// workgroups by longest-processing-time-first so that every workgroup streams the same number of bytes to within one tile
+static int solver_alloc_sym2(qn_solver* s) {
+    const int nb = s->T.n_pad / QN_TB;
+    hipStream_t st = s->ctx->stream;
+    if (s->s2_nb != nb) {
+        (void)hipFree(s->s2_items); (void)hipFree(s->s2_first); (void)hipFree(s->s2_wgE); (void)hipFree(s->s2_wgH); (void)hipFree(s->s2_rp);
+        s->s2_items = s->s2_first = nullptr; s->s2_wgE = s->s2_wgH = s->s2_rp = nullptr;
+        const int nitems = nb * (nb + 1) / 2;
+        const int G = std::min(nitems, QN_S2_MAXG);
+        std::vector<std::vector<int>> lists(G);
+        std::vector<std::pair<double, int>> heap; // (-load, workgroup): max-heap on the least loaded
+        for (int g = 0; g < G; ++g) heap.push_back({0.0, -g});
+        std::make_heap(heap.begin(), heap.end());
+        auto give = [&](int I, int J, double cost) {
+            std::pop_heap(heap.begin(), heap.end());
+            auto e = heap.back();
+            lists[-e.second].push_back((I << 16) | J);
+            e.first -= cost;
+            heap.back() = e;
+            std::push_heap(heap.begin(), heap.end());
+        };
+        for (int I = 0; I < nb; ++I)
+            for (int J = I + 1; J < nb; ++J) give(I, J, 1.0);
+        for (int I = 0; I < nb; ++I) give(I, I, 0.5625);
+        size_t maxk = 0;
+        for (int g = 0; g < G; ++g) maxk = std::max(maxk, lists[g].size());
+        std::vector<int> items(maxk * (size_t)G, -1); // [k][g]: the workgroup's k-th item; -1 ends its list
+        for (int g = 0; g < G; ++g)
+            for (size_t k = 0; k < lists[g].size(); ++k) items[k * (size_t)G + g] = lists[g][k];
+        HIPCHK(hipMalloc((void**)&s->s2_items, items.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(s->s2_items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
+        s->s2_maxk = (int)maxk;
+        QNCHK(dev_alloc_zero(&s->s2_wgE, (size_t)2 * G * QN_S2_ROW, st));
+        QNCHK(dev_alloc_zero(&s->s2_wgH, (size_t)nb * 2, st));
+        QNCHK(dev_alloc_zero(&s->s2_rp, (size_t)nb * QN_S2_ROW, st));
+        s->s2_G = G;
+        s->s2_nb = nb;
+    }
+    if (!s->s2_ctl) {
+        HIPCHK(hipMalloc((void**)&s->s2_ctl, 2 * sizeof(QnCtl)));
+        HIPCHK(hipMemsetAsync(s->s2_ctl, 0, 2 * sizeof(QnCtl), st));
+    }
+    return QN_OK;
+}
+
 static int solver_alloc_hp(qn_solver* s) {
     if (s->V.hp) { HIPCHK(hipFree(s->V.hp)); s->V.hp = nullptr; }
     if (s->V.q) { HIPCHK(hipFree(s->V.q)); s->V.q = nullptr; }
@@ -772,6 +829,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
+    (void)hipFree(s->s2_items); (void)hipFree(s->s2_first); (void)hipFree(s->s2_wgE); (void)hipFree(s->s2_wgH); (void)hipFree(s->s2_rp); (void)hipFree(s->s2_ctl);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
     delete s;
@@ -801,7 +859,7 @@ extern "C" int qn_solver_get_trace(qn_solver* s, qn_trace_rec* out_host, size_t 
     return QN_OK;
 }
 
-#ifdef QN_CTL_STAMPS
+#if defined(QN_CTL_STAMPS) || defined(QN_S2_STAMPS)
 extern "C" int qn_debug_stamps(qn_solver* s, unsigned long long* out, size_t count) { // diagnostic build only
     HIPCHK(hipSetDevice(s->ctx->device));
     if (!s->V.dbg) {
@@ -820,6 +878,7 @@ extern "C" int qn_solver_set_sync_mode(qn_solver* s, int sync) { s->sync_mode = 
 extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits) {
     if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; }
     if (rows_per_block == -3) { s->no_sym = 1; rows_per_block = 0; }   // diagnostics: fused row kernels on the full matrices
+    if (rows_per_block == -4) { s->no_sym2 = 1; rows_per_block = 0; }  // diagnostics: first-generation symmetric tile kernels (8 launches per iteration)
     if (rows_per_block == -2) { s->no_defer = 1; rows_per_block = 0; } // diagnostics: fused kernels, update step not deferred // diagnostics: -1 selects the generic (non-fused) kernels
     if (rows_per_block != 0 && rows_per_block != 2 && rows_per_block != 4 && rows_per_block != 8 && rows_per_block != 16)
         return fail(QN_ERROR_INPUT_PARAMS, "rows_per_block must be 2, 4, 8 or 16");
@@ -841,8 +900,25 @@ extern "C" size_t qn_solver_n(const qn_solver* s) { return s->n; }
 extern "C" size_t qn_solver_k(const qn_solver* s) { return (size_t)s->hctl->k; }
 extern "C" double qn_solver_tol(const qn_solver* s) { return s->tol; }
 
+// canonical buffers <- fused buffers (the lazy half of qn_minimize's export)
+static int fused_export(qn_solver* s) {
+    if (!s->fused_live) return QN_OK;
+    qn_context* c = s->ctx;
+    const QnCtl* h = s->hctl;
+    const size_t np = s->T.n_pad, vb = np * sizeof(double);
+    HIPCHK(hipMemcpyAsync(s->V.x, s->V.F.X0 + (size_t)h->xc * np, vb, hipMemcpyDeviceToDevice, c->stream));
+    if (h->pending) {
+        HIPCHK(hipMemcpyAsync(s->V.sp, s->V.F.S0 + (size_t)h->sc * np, vb, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(s->V.up, s->V.F.UN, vb, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    s->fused_live = false;
+    return QN_OK;
+}
+
 extern "C" int qn_solver_get_x(qn_solver* s, double* out) {
     HIPCHK(hipSetDevice(s->ctx->device));
+    QNCHK(fused_export(s));
     HIPCHK(hipMemcpyAsync(out, s->V.x, s->n * sizeof(double), hipMemcpyDeviceToHost, s->ctx->stream));
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
     return QN_OK;
@@ -899,9 +975,10 @@ extern "C" int qn_solver_reset(qn_solver* s, const double* x0_host) {
     if (s->H) {
         hipLaunchKernelGGL(identity_fill_kernel, dim3(2048), dim3(256), 0, st, s->H, s->T);
         HIPCHK(hipGetLastError());
-        s->h_lower_stale = false;
+        s->h_lower_stale = false; s->h_diag_stale = false;
         s->h_nonsym = false;
     }
+    s->fused_live = false; // (whatever the fused buffers hold is dropped with the rest of the state)
     HIPCHK(hipMemsetAsync(s->vec_block, 0, 9 * (size_t)s->T.n_pad * sizeof(double), st));
     HIPCHK(hipMemcpyAsync(s->V.x, x0_host, s->n * sizeof(double), hipMemcpyHostToDevice, st));
     memset(s->hctl, 0, sizeof(QnCtl));
@@ -915,6 +992,7 @@ extern "C" int qn_solver_set_k(qn_solver* s, size_t k) { // k_mut() (bfgs.rs:58-
 }
 extern "C" int qn_solver_set_x(qn_solver* s, const double* x_host) {
     HIPCHK(hipSetDevice(s->ctx->device));
+    QNCHK(fused_export(s));
     HIPCHK(hipMemcpyAsync(s->V.x, x_host, s->n * sizeof(double), hipMemcpyHostToDevice, s->ctx->stream));
     s->hctl->have_cur_eval = 0; s->hctl->have_dir = 0; s->hctl->last_valid = 0;
     return poke_ctl(s);
@@ -978,13 +1056,15 @@ static QnHPassArgs hpass_args(qn_solver* s, int expect_phase) {
 static int ensure_full_h(qn_solver* s) {
     if (!s->H || !s->h_lower_stale) return QN_OK;
     const int b32 = s->T.n_pad / 32;
-    hipLaunchKernelGGL(sym_mirror_kernel, dim3(b32, b32), dim3(256), 0, s->ctx->stream, s->H, s->T.n_pad);
+    hipLaunchKernelGGL(sym2_mirror_kernel, dim3(b32, b32), dim3(256), 0, s->ctx->stream, s->H, s->T.n_pad); // (also inside the diagonal tiles)
     HIPCHK(hipGetLastError());
     s->h_lower_stale = false;
+    s->h_diag_stale = false;
     return QN_OK;
 }
 
 static int flush_pending(qn_solver* s) { // H_stored <- H_true
+    QNCHK(fused_export(s));  // the pending update's vectors
     QNCHK(ensure_full_h(s)); // (also from a callback in the middle of a symmetric-storage run)
     if (!s->H || !s->hctl->pending) return QN_OK;
     QnHPassArgs a = hpass_args(s, -1);
@@ -1043,8 +1123,9 @@ extern "C" int qn_solver_set_inv_hessian(qn_solver* s, const double* h) {
         if (i >= n) break;
         for (size_t j = 0; j < n; ++j) rows[r * np + j] = h[i + j * n];
     }
+    QNCHK(fused_export(s));
     HIPCHK(hipMemcpy(s->H, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
-    s->h_lower_stale = false; // every entry was just replaced
+    s->h_lower_stale = false; s->h_diag_stale = false; // every entry was just replaced
     s->h_nonsym = false; // the symmetric-storage path needs H == H' bit for bit (BFGS / DFP keep it so from a symmetric start)
     for (size_t i = 0; i < n && !s->h_nonsym; ++i)
         for (size_t j = i + 1; j < n; ++j)
@@ -1160,7 +1241,49 @@ struct Run {
     bool fused;
     bool sym = false; // fused path on the upper block triangle of H and Q (qn_sym.hip.h)
     bool sym_generic = false; // generic path: the H pass alone on the upper block triangle
+    bool sym2 = false;        // second-generation symmetric path (qn_sym2.hip.h)
+    QnS2Args s2{};
+    uint64_t s2_launches = 0; // parity of the control-block double buffer = launches so far & 1
 };
+
+static int s2_launch(Run& r, int kind) {
+    qn_solver* s = r.s;
+    hipStream_t st = s->ctx->stream;
+    QnS2Args a = r.s2;
+    a.parity = (int)(r.s2_launches & 1);
+#ifdef QN_S2_STAMPS
+    a.dbg = s->V.dbg; a.slot = (int)r.s2_launches;
+#endif
+    r.s2_launches++;
+    const int cls = kind == QN_S2_EVAL ? KC_EVAL : kind == QN_S2_VEC ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS : kind == QN_S2_HREDUCE ? KC_HREDUCE : KC_CTL;
+    ProfScope ps(s, cls);
+    switch (kind) {
+    case QN_S2_EVAL: hipLaunchKernelGGL(s2_eval_kernel, dim3(a.G), dim3(QN_S2_TPB), 0, st, a); break;
+    case QN_S2_VEC: hipLaunchKernelGGL(s2_vec_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
+    case QN_S2_HTILE:
+        if (s->method == QN_BFGS) {
+            if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            else hipLaunchKernelGGL((s2_hpass_kernel<false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        } else {
+            if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            else hipLaunchKernelGGL((s2_hpass_kernel<false, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        }
+        s->h_lower_stale = true; s->h_diag_stale = true;
+        break;
+    case QN_S2_HREDUCE: hipLaunchKernelGGL(s2_hreduce_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
+    default: hipLaunchKernelGGL(s2_advance_kernel, dim3(1), dim3(QN_S2_TPB), 0, st, a); break;
+    }
+    s->stats.launches++;
+    HIPCHK(hipGetLastError());
+    return QN_OK;
+}
+static int s2_peek(Run& r) { // the control block the last enqueued launch writes -> host mirror
+    qn_solver* s = r.s;
+    HIPCHK(hipMemcpyAsync(s->hctl, s->s2_ctl + (r.s2_launches & 1), sizeof(QnCtl), hipMemcpyDeviceToHost, s->ctx->stream));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    s->stats.host_syncs++;
+    return QN_OK;
+}
 
 static int launch_ctl_mask(Run& r, int expect_mask) {
     qn_solver* s = r.s;
@@ -1522,29 +1645,87 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             s->sym_nb = nb;
         }
     }
+    r.sym2 = r.sym && !s->no_sym2 && (size_t)s->T.n_pad == s->n; // (the second-generation kernels keep no padding entries at zero)
+    h->sym2 = r.sym2 ? 1 : 0;
+    h->serviced = 0; h->ev_par = 0; h->ev_kind = QN_REQ_X; h->ev_t = 0.0;
     h->defer_u = 0;
     h->no_defer = s->no_defer;
-    if (r.fused) { // import the canonical state (x, pending s and u) into the fused buffers
+    if (!r.fused) QNCHK(fused_export(s)); // another path takes over: it works on the canonical buffers
+    if (!(r.sym || r.sym_generic) || (s->h_diag_stale && !r.sym2)) QNCHK(ensure_full_h(s)); // ... and on whole rows of H (or whole diagonal tiles)
+    if (r.fused) {
         QNCHK(solver_alloc_fused(s, r.sym));
         s->V.F.b = r.obj->b;
-        const size_t vb = (size_t)s->T.n_pad * sizeof(double);
-        HIPCHK(hipMemcpyAsync(s->V.F.X0, s->V.x, vb, hipMemcpyDeviceToDevice, c->stream));
-        if (h->pending) {
-            HIPCHK(hipMemcpyAsync(s->V.F.S0, s->V.sp, vb, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(s->V.F.UN, s->V.up, vb, hipMemcpyDeviceToDevice, c->stream));
-        }
-        h->xc = 0; h->sc = 0; h->dir_mode = 0; h->gd0_valid = 0;
+        if (!s->fused_live) { // import the canonical state (x, pending s and u) into the fused buffers
+            const size_t vb = (size_t)s->T.n_pad * sizeof(double);
+            HIPCHK(hipMemcpyAsync(s->V.F.X0, s->V.x, vb, hipMemcpyDeviceToDevice, c->stream));
+            if (h->pending) {
+                HIPCHK(hipMemcpyAsync(s->V.F.S0, s->V.sp, vb, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(hipMemcpyAsync(s->V.F.UN, s->V.up, vb, hipMemcpyDeviceToDevice, c->stream));
+            }
+            h->xc = 0; h->sc = 0;
+        } // (else: a fused run left them there; xc / sc in the control block say which halves are current)
+        h->dir_mode = 0; h->gd0_valid = 0;
     }
     h->phase = QN_PH_IDLE;
     h->status = -1;
-    QNCHK(poke_ctl(s));
+    if (r.sym2) {
+        QNCHK(solver_alloc_sym2(s));
+        QnS2Args& a = r.s2;
+        a.Q = r.obj->Q; a.H = s->H; a.n = (int)s->n; a.np = s->T.n_pad; a.nb = s->s2_nb; a.G = s->s2_G;
+        a.item_ij = s->s2_items; a.maxk = s->s2_maxk; a.F = s->V.F; a.part = s->sym_part;
+        a.wgE = s->s2_wgE; a.hrp = s->s2_wgH; a.rp = s->s2_rp; a.ctl2 = s->s2_ctl;
+        a.trace = s->V.trace; a.xtrace = s->V.xtrace;
+        a.nt = s->T.n_pad >= 8192; // H past the Infinity Cache: every byte is touched once per pass
+        HIPCHK(hipMemcpyAsync(s->s2_ctl, s->hctl, sizeof(QnCtl), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    } else {
+        QNCHK(poke_ctl(s));
+    }
 
     // only the quadratic objective's kernels are predicated on the control block; everything else is serviced synchronously
     const bool can_pipeline = (r.oracle_tpl == QN_ORACLE_QUAD) && !callback && !(c->world > 1 && !c->comm);
     const bool sync = s->method == QN_NEWTON || s->sync_mode == 1 || (s->sync_mode == -1 && !(can_pipeline && o->memoize)) || !can_pipeline;
 
-    QNCHK(launch_ctl(r, QN_PH_IDLE));
     int status = QN_ABNORMAL_TERMINATION;
+    if (r.sym2) {
+        if (sync) { // one request at a time: [service launch(es), advance], the host reads the control block in between
+            QNCHK(s2_launch(r, QN_S2_ADVANCE));
+            for (;;) {
+                QNCHK(s2_peek(r));
+                const int ph = h->phase;
+                if (ph == QN_PH_DONE) { status = h->status; break; }
+                if (h->serviced != 0) return fail(QN_ABNORMAL_TERMINATION, "sym2: request in an unexpected service state");
+                if (ph == QN_PH_REQ_EVAL) QNCHK(s2_launch(r, QN_S2_EVAL));
+                else if (ph == QN_PH_REQ_VEC) QNCHK(s2_launch(r, QN_S2_VEC));
+                else if (ph == QN_PH_REQ_HPASS) { QNCHK(s2_launch(r, QN_S2_HTILE)); QNCHK(s2_launch(r, QN_S2_HREDUCE)); }
+                else return fail(QN_ABNORMAL_TERMINATION, "sym2: control block in an unexpected phase");
+                QNCHK(s2_launch(r, QN_S2_ADVANCE));
+            }
+        } else { // pipelined: [eval x slots, accept-reduce, update tiles, update-reduce] per period, each launch predicated in its prologue
+            const int slots = (ls->kind == QN_LS_MORETHUENTE) ? 2 : 4;
+            bool first = true;
+            for (;;) {
+                if (!first) {
+                    QNCHK(s2_peek(r));
+                    if (h->phase == QN_PH_DONE) { status = h->status; break; }
+                }
+                int64_t remaining = h->max_iter - (first ? 0 : h->k);
+                if (remaining < 1) remaining = 1;
+                // one period per iteration, one more for a run that has no direction yet (evaluation at x, direction pass), and
+                // a last evaluation launch whose prologue finds the iteration cap reached and writes DONE
+                const int64_t periods = std::min<int64_t>(remaining + 1, 256);
+                first = false;
+                for (int64_t p = 0; p < periods; ++p) {
+                    for (int e = 0; e < slots; ++e) QNCHK(s2_launch(r, QN_S2_EVAL));
+                    QNCHK(s2_launch(r, QN_S2_VEC));
+                    QNCHK(s2_launch(r, QN_S2_HTILE));
+                    QNCHK(s2_launch(r, QN_S2_HREDUCE));
+                }
+                QNCHK(s2_launch(r, QN_S2_EVAL));
+            }
+        }
+    } else {
+    QNCHK(launch_ctl(r, QN_PH_IDLE));
     if (sync) {
         for (;;) {
             QNCHK(peek_ctl(s));
@@ -1585,16 +1766,11 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             }
         }
     }
-    QNCHK(ensure_full_h(s)); // a symmetric-storage run maintained the upper block triangle of H only: restore the lower one
-    if (r.fused) { // export back to the canonical buffers
-        const size_t np = s->T.n_pad, vb = np * sizeof(double);
-        HIPCHK(hipMemcpyAsync(s->V.x, s->V.F.X0 + (size_t)h->xc * np, vb, hipMemcpyDeviceToDevice, c->stream));
-        if (h->pending) {
-            HIPCHK(hipMemcpyAsync(s->V.sp, s->V.F.S0 + (size_t)h->sc * np, vb, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(s->V.up, s->V.F.UN, vb, hipMemcpyDeviceToDevice, c->stream));
-        }
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
+    } // (!r.sym2)
+    // Nothing is copied back here: the iterate and the pending vectors stay in the fused buffers (fused_export), the lower
+    // triangle of H stays stale (ensure_full_h) until a getter, a setter or a run on another path asks for them.  A solve made
+    // of several qn_minimize calls (warm restarts, a harness timing short calls) pays for neither.
+    if (r.fused) s->fused_live = true;
     if (ls->kind == QN_LS_MORETHUENTE_B) ls->t_max = h->mt_tmax; // morethuente_b.rs:201: the clipped t_max stays in the line search
     s->stats.iterations = h->n_iterations;
     s->stats.oracle_calls = h->n_oracle_calls;
@@ -1603,6 +1779,8 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     uint64_t shard = (uint64_t)s->T.rpr * (uint64_t)s->T.n_pad * 8ull;
     const uint64_t full_shard = shard;
     if (r.sym || r.sym_generic) shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb + 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull; // the streamed tiles
+    if (r.sym2) // diagonal tiles: wave w (rows 16 w ...) reads 64 - 8 w lanes of 16 bytes per row = 73 728 of the 131 072 bytes
+        shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb - 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull + (uint64_t)s->sym_nb * 73728ull;
     s->stats.h_bytes = (h->n_hpasses + h->n_hpass_rw) * shard;
     s->stats.obj_bytes = (r.oracle_tpl == QN_ORACLE_QUAD) ? h->n_oracle_evals * (r.sym ? shard : full_shard) : 0;
     s->stats.matrix_bytes_per_pass = shard;
@@ -1614,7 +1792,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     s->stats.total_h_bytes += s->stats.h_bytes;
     s->stats.total_obj_bytes += s->stats.obj_bytes;
     s->stats.path = (r.fused ? QN_PATH_FUSED : 0u) | (r.sym ? QN_PATH_SYM : 0u) | (r.sym_generic ? QN_PATH_SYM_GENERIC : 0u) |
-                    (sync ? 0u : QN_PATH_PIPELINED);
+                    (sync ? 0u : QN_PATH_PIPELINED) | (r.sym2 ? QN_PATH_SYM2 : 0u);
     if (status == QN_ABNORMAL_TERMINATION) return fail(status, "solver state machine aborted");
     return status;
 }

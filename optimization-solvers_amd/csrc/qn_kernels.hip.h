@@ -79,6 +79,39 @@ struct QnVecs {
 __device__ __forceinline__ v2d ld2(const double* p) { return *reinterpret_cast<const v2d*>(p); }
 __device__ __forceinline__ void st2(double* p, v2d v) { *reinterpret_cast<v2d*>(p) = v; }
 
+// ---- lane ^ OFF exchange of a double without the LDS crossbar: __shfl_xor compiles to two ds_bpermute_b32 (an LDS-pipeline
+// round trip each, ~100+ cycles, plus an address register); on gfx950 every power-of-two xor pattern is a VALU data-path
+// operation: quad_perm (1, 2), row_shl / row_shr 4 (4), row_ror 8 (8), v_permlane16_swap (16), v_permlane32_swap (32).
+// Checked lane for lane on the device by tools/xor_shuffle_probe.hip.
+template <int OFF>
+__device__ __forceinline__ int qn_xor_lanes_i(const int v) {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "power of two below the wave size");
+    if constexpr (OFF == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    else if constexpr (OFF == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); // quad_perm [2,3,0,1]
+    else if constexpr (OFF == 4) {
+        const int a = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0xf, false); // row_shl:4 : lane i <- lane i + 4
+        const int b = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false); // row_shr:4 : lane i <- lane i - 4
+        return (threadIdx.x & 4) ? b : a;
+    } else if constexpr (OFF == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false); // row_ror:8 within rows of 16
+    else if constexpr (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (threadIdx.x & 16) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+}
+template <int OFF>
+__device__ __forceinline__ double qn_xor_lanes(const double v) { // (block sizes are multiples of 64: threadIdx.x & OFF == lane & OFF)
+    return __hiloint2double(qn_xor_lanes_i<OFF>(__double2hiint(v)), qn_xor_lanes_i<OFF>(__double2loint(v)));
+}
+// sum over the wave, every lane gets the total (order: xor 32, 16, 8, 4, 2, 1 -- as the `for (off = 32; off; off >>= 1)` loops it replaces)
+__device__ __forceinline__ double qn_wave_sum(double v) {
+    v = v + qn_xor_lanes<32>(v); v = v + qn_xor_lanes<16>(v); v = v + qn_xor_lanes<8>(v);
+    v = v + qn_xor_lanes<4>(v); v = v + qn_xor_lanes<2>(v); v = v + qn_xor_lanes<1>(v);
+    return v;
+}
+
 // ---- halving butterfly: V values per lane -> lane l ends with the wave total of value (l >> (6 - log2 V)) in v[0]
 template <int CNT, int OFF>
 struct QnWaveFold {
@@ -92,12 +125,12 @@ struct QnWaveFold {
                 for (int i = 0; i < HALF; ++i) {
                     const double keep = up ? v[i + HALF] : v[i];
                     const double send = up ? v[i] : v[i + HALF];
-                    const double recv = __shfl_xor(send, OFF, 64);
+                    const double recv = qn_xor_lanes<OFF>(send);
                     v[i] = keep + recv;
                 }
                 QnWaveFold<HALF, OFF / 2>::run(v, lane);
             } else {
-                v[0] = v[0] + __shfl_xor(v[0], OFF, 64);
+                v[0] = v[0] + qn_xor_lanes<OFF>(v[0]);
                 QnWaveFold<1, OFF / 2>::run(v, lane);
             }
         }
@@ -395,8 +428,7 @@ __device__ __forceinline__ void ctl_block_sum(double (&v)[K], double* lds /* 16*
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v[k] = v[k] + __shfl_xor(v[k], off, 64);
+        v[k] = qn_wave_sum(v[k]);
     }
     __syncthreads();
     if (lane == 0) {
@@ -481,7 +513,13 @@ __device__ __forceinline__ void req_eval_t(QnCtl& c, double t, int after_state, 
             return;
         }
         if (c.last_valid && c.last_t == t) {
-            c.f_e = c.f_last; c.gd_e = c.gd_last; c.state = after_state;
+            c.f_e = c.f_last; c.gd_e = c.gd_last;
+            if (c.sym2 && need_vectors) { // the scalars are known; the vectors of that point are still slots (qn_sym2.hip.h)
+                c.after_state = after_state;
+                c.phase = QN_PH_REQ_VEC;
+                return;
+            }
+            c.state = after_state;
             return;
         }
     }
@@ -685,6 +723,7 @@ __global__ void lse_finish_kernel(const QnLseArgs a) {
 #include "qn_sym.hip.h"
 #include "qn_newton.hip.h"
 #include "qn_ctl_step.hip.h"
+#include "qn_sym2.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // plain primitives for the kernel-level FFI (include/qn_hip.h, last section).  No layout assumptions.
@@ -698,8 +737,7 @@ __global__ __launch_bounds__(256) void prim_gemv_kernel(const double* __restrict
     const double* a = A + (size_t)row * ld;
     double acc = 0.0;
     for (int j = lane; j < ncols; j += 64) acc = __builtin_fma(a[j], x[j], acc);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
+    acc = qn_wave_sum(acc);
     if (lane == 0) y[row] = acc;
 }
 

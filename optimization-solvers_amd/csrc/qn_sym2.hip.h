@@ -1,0 +1,734 @@
+// qn_sym2.hip.h -- the fused fast path on the symmetric half of H and Q, second generation (single rank).
+//
+// What round 1's profile showed at n = 4096 (profiles/r01_h_kernel_stats_n4096.csv): 8 dependent launches per BFGS
+// iteration, 34 us of the 101 us in three kinds of small serial kernels (slot reduction after EVERY evaluation, the
+// single-workgroup control step after every evaluation), an update-tile kernel at 202 VGPRs = ONE workgroup per CU, and a grid
+// of 528 tiles on 512 (256) resident slots.  This file removes those four things; the arithmetic of the iteration is unchanged.
+//
+//  1. The control step is no launch any more.  EVERY workgroup of EVERY kernel runs the solver's state machine
+//     (qn_ctl_step.hip.h ctl_scalar_run, the same device function the generic path's control kernel runs) in its prologue, from
+//     the same inputs, hence to the same bits; workgroup 0 alone performs the side effects (control block write-back, trace).
+//     The control block is double-buffered: kernel i reads ctl2[i & 1] and writes ctl2[(i + 1) & 1], so a late workgroup can
+//     never see the state its own launch produced.  The prologue costs ~2-3 us of one thread's dependent arithmetic, hidden
+//     behind the first tile's loads, which are issued before it.
+//  2. An evaluation hands the line search only what it needs: two scalars.  f(x + t d) = 1/2 xt'Q xt - b'xt and
+//     g(x + t d)'d = d'Q xt - b'd are sums of per-tile bilinear forms, so the tile kernel emits them per WORKGROUP (fixed
+//     order inside, fixed order across workgroups) and the next kernel's prologue sums <= 512 of them.  The row / column
+//     slots are still written, but they are reduced to VECTORS (g+, y, x+, s and their norms) only for the point the line
+//     search accepts: once per iteration instead of once per evaluation.  The same holds for the update pass:
+//     y'H+y and g+'H+y come out of the tiles as scalars.
+//  3. Work items, not tiles, are the launch unit: the grid is min(items, 256) workgroups = one per CU, each walking a static,
+//     cost-balanced list (longest-processing-time assignment on the host).  A diagonal tile is processed as its upper
+//     triangle only (waves skip the lanes left of their rows: 56 % of a tile's bytes), so n = 4096 is 496 + 32 x 0.56 = 514
+//     units, 2.0 per CU, instead of 528 tiles on 256 one-workgroup slots (three rounds).  The strictly lower part of H's
+//     diagonal tiles is restored with the rest of the lower triangle when a reader needs whole rows (sym2_mirror_kernel).
+//  4. Registers.  Two 8-wave workgroups per CU would need the tile kernels inside 128 VGPRs; with a load window, the column
+//     vectors and the accumulators of two right-hand sides the compiler (hipcc 7.2) could not hold the window in registers at
+//     that budget -- it parked every freshly loaded row in scratch memory and waited for it, which serialises exactly the loads
+//     the window exists to overlap.  So the kernels take the other road to the same bytes in flight: ONE workgroup per CU
+//     (__launch_bounds__(512, 2): 256 VGPRs), the wave's whole 16-row share of a tile in registers, and every register refilled
+//     with the same row of the workgroup's NEXT item the moment its row is consumed: 128 KB of loads in flight per CU across
+//     item boundaries, reductions and barriers.  Row-side inputs (x_i, d_i, s_i, u_i, y_i, g_i) live one row per lane and are
+//     broadcast into scalar registers as the unrolled row loop needs them: no LDS staging, no barrier before the loop.
+//
+// Launch pattern of one iteration (More-Thuente on the quadratic: two evaluations, the second one accepted):
+//     eval tiles | eval tiles | accept-reduce (nb workgroups) | update tiles | update-reduce (nb workgroups)
+// 5 launches instead of 8, every one of them predicated on the control block, so the host still enqueues a fixed pattern
+// hundreds of iterations ahead (pipelined mode) or services one request at a time (synchronous mode: the same kernels plus a
+// one-workgroup `advance` launch that runs the prologue alone -- bit-identical by construction).
+// Reference lines served: ls_solver.rs:66-111, bfgs.rs:42-127, dfp.rs:115-120, morethuente.rs:165-297, backtracking.rs:20-58.
+#pragma once
+
+#define QN_S2_TPB 512
+#define QN_S2_WAVES 8
+#define QN_S2_RPW 16   // rows of a tile per wave
+#define QN_S2_MAXG 256 // workgroups of a tile launch: one 8-wave workgroup per CU (see the note on registers below)
+#define QN_S2_NSE 6    // evaluation scalars per workgroup: xt'Q xt, b'xt, d'Q xt, b'd, g'd, #non-finite d
+#define QN_S2_NR 5     // accept-reduce partials per block-row: y'y, y's, g+'g+, s's, s'g+
+#define QN_S2_ROW 8    // doubles per partial row in memory (64 B: loaded as 16-byte pieces)
+
+enum { QN_S2_ADVANCE = 0, QN_S2_EVAL = 1, QN_S2_VEC = 2, QN_S2_HTILE = 3, QN_S2_HREDUCE = 4 };
+
+struct QnS2Args {
+    const double* Q;
+    double* H;
+    int n, np, nb, G;
+    const int* item_ij;  // [maxk][G]: k-th item of workgroup g = (I << 16) | J, J >= I (J == I: diagonal tile, upper triangle only);
+                         // -1 = the list has ended.  Transposed so that a workgroup's first item is ONE coalesced load away.
+    int maxk;            // longest list
+    QnFused F;           // X0, S0, G, GT, Y, UN, VV, b (UP is not used here: no kernel writes u while another reads it)
+    double* part;        // [nb][nb][2][128] row / column slots
+    double* wgE;         // [2][G][QN_S2_ROW] evaluation scalars, double-buffered on ctl.ev_par
+    double* hrp;         // [nb][2] update-reduce partials per block-row: y'u, u'g+
+    double* rp;          // [nb][QN_S2_ROW]
+    QnCtl* ctl2;         // [2]
+    QnTraceRec* trace;
+    double* xtrace;
+    int parity;          // this launch reads ctl2[parity] and writes ctl2[parity ^ 1]
+    int nt;              // non-temporal tile accesses on H (past the Infinity Cache)
+#ifdef QN_S2_STAMPS
+    unsigned long long* dbg; // diagnostic build: dbg[((slot % 64) * 256 + workgroup) * 16 + k] = wall clock (10 ns) at stamp k
+    int slot;
+#endif
+};
+#ifdef QN_S2_STAMPS
+#define QN_S2_STAMP(k) do { if (threadIdx.x == 0 && a.dbg && blockIdx.x < 256) a.dbg[(((size_t)(a.slot & 63)) * 256 + blockIdx.x) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define QN_S2_STAMP(k) do { } while (0)
+#endif
+
+struct QnS2Lds {
+    QnCtl c;
+    double red[QN_S2_WAVES][8];
+    double tot[8];
+};
+
+// ---- the state machine's view of a finished request: consume its sums, then run until the next request ----
+__device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const QnVecs& V, const bool leader, double* scratch, const bool resume) {
+    const int ph = c.phase;
+    if (resume) { ctl_scalar_run(c, V, scratch, leader); return; } // (the machine had stopped for the x-trace copy)
+    if (ph == QN_PH_DONE) return;
+    if (ph == QN_PH_IDLE) {
+        c.serviced = 0;
+        c.state = c.ls_only ? QN_ST_LS_ONLY : QN_ST_BEGIN;
+        c.phase = QN_PH_RUNNING;
+        ctl_scalar_run(c, V, scratch, leader);
+        return;
+    }
+    if (c.serviced != 2) return; // the request is still pending, or its tiles wait for their reduce launch
+    c.serviced = 0;
+    if (ph == QN_PH_REQ_EVAL) {
+        const double f = 0.5 * tot[0] - tot[1]; // f = 1/2 xt'(Q xt) - b'xt
+        const double gd = tot[2] - tot[3];      // g(xt)'d = d'(Q xt) - b'd
+        c.st_gd0 = tot[4]; c.st_dnf = tot[5];
+        if (c.req_kind == QN_REQ_T && !c.gd0_valid) { c.gd0 = tot[4]; c.d_finite = tot[5] == 0.0; c.gd0_valid = 1; }
+        c.f_e = f; c.gd_e = gd;
+        c.n_oracle_evals++;
+        c.ev_par ^= 1; c.ev_kind = c.req_kind; c.ev_t = c.req_t;
+        if (c.req_kind == QN_REQ_T) { c.last_valid = 1; c.last_t = c.req_t; c.f_last = f; c.gd_last = gd; }
+        else c.last_valid = 0;
+        if (c.req_need_vectors) { c.phase = QN_PH_REQ_VEC; return; } // the caller wants g+, y, s of this point too
+        c.state = c.after_state;
+    } else if (ph == QN_PH_REQ_VEC) {
+        c.st_yy = tot[0]; c.st_ys = tot[1]; c.st_gg = tot[2]; c.st_ss = tot[3]; c.hp_sg = tot[4];
+        c.state = c.after_state;
+    } else if (ph == QN_PH_REQ_HPASS) {
+        if (c.hp_nrhs == 2) { c.hp_yu = tot[0]; c.hp_ug = tot[1]; }
+        c.state = c.after_state;
+    } else {
+        return;
+    }
+    c.phase = QN_PH_RUNNING;
+    ctl_scalar_run(c, V, scratch, leader);
+}
+
+// Prologue of every sym2 kernel, in two parts so that a tile kernel can put its own loads in between.
+//   issue:  the control block and every partial sum the machine might want are requested FIRST (a wave's loads return in
+//           order: requested behind the 128 KB tile window they would wait for it).  Wave k < 6 takes column k of the three
+//           partial tables -- evaluation scalars per workgroup (both halves of the double buffer), accept-reduce and
+//           update-reduce partials per block-row -- 64 rows per load instruction.
+//   finish: the column the finished request produced is summed (fixed order: the lane's rows in row order, then a xor
+//           butterfly), the machine is advanced by thread 0 and workgroup 0 writes the new control block.
+//           Returns true when this launch is to service the pending request.
+#define QN_S2_PCH (QN_S2_MAXG / 64) // row chunks of 64 a wave loads per table at issue time
+struct QnS2Pro {
+    uint64_t cw;
+    double e0[QN_S2_PCH], e1[QN_S2_PCH], rr[QN_S2_PCH], hh[QN_S2_PCH];
+};
+
+template <int KIND>
+__device__ __forceinline__ void qn_s2_pro_issue(const QnS2Args& a, QnS2Pro& P) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = (int)(sizeof(QnCtl) / 8);
+    static_assert(NW <= 256, "control block too large for one sweep");
+    const uint64_t* cin = reinterpret_cast<const uint64_t*>(a.ctl2 + a.parity);
+    P.cw = 0;
+    if (tid < NW) P.cw = cin[tid];
+#pragma unroll
+    for (int j = 0; j < QN_S2_PCH; ++j) { P.e0[j] = 0.0; P.e1[j] = 0.0; P.rr[j] = 0.0; P.hh[j] = 0.0; }
+    if (KIND != QN_S2_HREDUCE && wave < QN_S2_NSE) {
+#pragma unroll
+        for (int j = 0; j < QN_S2_PCH; ++j) {
+            const int g = j * 64 + lane;
+            if (g < a.G) {
+                P.e0[j] = a.wgE[(size_t)g * QN_S2_ROW + wave];
+                P.e1[j] = a.wgE[((size_t)a.G + g) * QN_S2_ROW + wave];
+            }
+            if (g < a.nb) {
+                if (wave < QN_S2_NR) P.rr[j] = a.rp[(size_t)g * QN_S2_ROW + wave];
+                if (wave < 2) P.hh[j] = a.hrp[(size_t)g * 2 + wave];
+            }
+        }
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ bool qn_s2_pro_finish(const QnS2Args& a, QnS2Lds& L, const QnS2Pro& P) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const bool leader = blockIdx.x == 0;
+    constexpr int NW = (int)(sizeof(QnCtl) / 8);
+    uint64_t* cout = reinterpret_cast<uint64_t*>(a.ctl2 + (a.parity ^ 1));
+    if (tid < NW) reinterpret_cast<uint64_t*>(&L.c)[tid] = P.cw;
+    if (tid < 8) L.tot[tid] = 0.0;
+    __syncthreads();
+    QN_S2_STAMP(9);
+    QnCtl& c = L.c;
+    if (KIND == QN_S2_HREDUCE) { // no decision between the update tiles and their reduction: pass the control block on
+        const bool mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 1;
+        __syncthreads();
+        if (tid == 0 && mine) c.serviced = 2;
+        __syncthreads();
+        if (leader && tid < NW) cout[tid] = reinterpret_cast<const uint64_t*>(&L.c)[tid];
+        return mine;
+    }
+    const int ph = c.phase;
+    if (ph == QN_PH_DONE) { // launches enqueued past the end of the run: pass the control block on, nothing else
+        if (leader && tid < NW) cout[tid] = P.cw;
+        return false;
+    }
+    if (c.serviced == 2 && (ph == QN_PH_REQ_EVAL || ph == QN_PH_REQ_VEC || ph == QN_PH_REQ_HPASS)) { // uniform: c is in LDS
+        if (wave < QN_S2_NSE) {
+            double acc = 0.0;
+            if (ph == QN_PH_REQ_EVAL) {
+                const bool odd = c.ev_par != 0;
+#pragma unroll
+                for (int j = 0; j < QN_S2_PCH; ++j) acc = acc + (odd ? P.e1[j] : P.e0[j]);
+            } else {
+                const bool vec = ph == QN_PH_REQ_VEC;
+#pragma unroll
+                for (int j = 0; j < QN_S2_PCH; ++j) acc = acc + (vec ? P.rr[j] : P.hh[j]);
+                for (int b = QN_S2_MAXG + lane; b < a.nb; b += 64) { // (block-rows past 256: n > 32768)
+                    if (vec) { if (wave < QN_S2_NR) acc = acc + a.rp[(size_t)b * QN_S2_ROW + wave]; }
+                    else if (wave < 2) acc = acc + a.hrp[(size_t)b * 2 + wave];
+                }
+            }
+            acc = qn_wave_sum(acc);
+            if (lane == 0) L.tot[wave] = acc;
+        }
+        __syncthreads();
+    }
+    QN_S2_STAMP(10);
+    QnVecs V{};
+    V.n = a.n; V.n_pad = a.np; V.trace = a.trace;
+    for (int guard = 0; guard < 64; ++guard) { // (the n <= 5 reference-order code of the machine is never reached on this path: no scratch)
+        // (measured and dropped, as in round 1's control kernel: the machine on a register copy of the control block -- the
+        // compiler spills the copy to scratch memory, which is no faster than LDS)
+        if (tid == 0) qn_s2_advance(c, L.tot, V, leader, &L.red[0][0], guard > 0);
+        __syncthreads();
+        if (!(c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END)) break;
+        // the machine stopped because the iterate has to be recorded (trace with x): workgroup 0 copies it, all go on
+        if (leader) {
+            double* row = a.xtrace + (size_t)c.k * (size_t)a.n;
+            const double* xs = a.F.X0 + (size_t)c.xc * (size_t)a.np;
+            for (int i = tid; i < a.n; i += nthr) row[i] = xs[i];
+        }
+        __syncthreads();
+        if (tid == 0) c.xtrace_done = 1;
+        __syncthreads();
+    }
+    QN_S2_STAMP(11);
+    bool mine = false;
+    if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == 0;
+    if (KIND == QN_S2_VEC) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
+    if (KIND == QN_S2_HTILE) mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 0;
+    const bool stuck = c.phase == QN_PH_RUNNING; // a state this path cannot service: abort, never spin
+    __syncthreads();
+    if (tid == 0) {
+        if (stuck) { c.status = 4; c.phase = QN_PH_DONE; }
+        if (mine) c.serviced = (KIND == QN_S2_HTILE) ? 1 : 2; // as this launch leaves the request
+    }
+    __syncthreads();
+    if (leader && tid < NW) cout[tid] = reinterpret_cast<const uint64_t*>(&L.c)[tid];
+    return mine;
+}
+
+// the evaluation request as the tile and the accept-reduce kernels decode it
+__device__ __forceinline__ QnEvalReq qn_s2_eval_req(const QnCtl& c, bool last_eval) {
+    QnEvalReq q;
+    q.is_t = (last_eval ? c.ev_kind : c.req_kind) == QN_REQ_T;
+    q.t = last_eval ? c.ev_t : c.req_t;
+    q.mode = c.dir_mode;
+    q.c_ss = c.c_ss; q.c_su = c.c_su; q.c_uu = c.c_uu; q.ug = c.dir_ug; q.sg = c.dir_sg;
+    q.xc = c.xc; q.sc = c.sc;
+    return q;
+}
+
+// sum of `cnt` values held one per wave in red[w][k] by thread 0 (fixed order)
+__device__ __forceinline__ double qn_s2_wave_total(const double (*red)[8], int k) {
+    double t = red[0][k];
+#pragma unroll
+    for (int w = 1; w < QN_S2_WAVES; ++w) t = t + red[w][k];
+    return t;
+}
+
+// a wave-uniform double out of lane `l` (uniform) of a per-lane value: the row-side inputs of a tile (x_i, d_i, s_i, u_i, y_i,
+// g_i for the wave's 16 rows) live one row per lane and are broadcast into SGPRs as the row loop needs them -- no LDS staging,
+// no barrier, and no vector registers held across the loop for them
+__device__ __forceinline__ double qn_lane_bcast(const double v, const int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// Diagonal items without a single per-element test.  Wave w owns rows 16 w .. 16 w + 15 of the tile; lane l owns columns 2 l, 2 l + 1.
+//   * lanes left of the wave's 16 x 16 diagonal sub-block (l < 8 w) have nothing to do: they are CLONES of lane 8 w -- same
+//     load address (one request, no extra traffic), same column-side update vectors, hence the same stored values -- with
+//     their multiplier entries and column sums forced to zero;
+//   * the lanes of the diagonal sub-block (8 w <= l < 8 w + 8) use it WHOLE for the row part -- it is kept symmetric in memory,
+//     both triangles, by the symmetric update formula -- and contribute nothing to the column part (that would count it twice);
+//   * lanes right of it (l >= 8 w + 8) work as in an off-diagonal tile.
+// So a diagonal item differs from an off-diagonal one by three per-lane constants; the row loop is the same straight-line code.
+// (The sub-blocks below the diagonal ones are not maintained: sym2_mirror_kernel restores them with the lower block triangle.)
+__device__ __forceinline__ int qn_s2_col(bool diag, int lane, int wave) { return 2 * (diag ? max(lane, 8 * wave) : lane); }
+__device__ __forceinline__ bool qn_s2_row_on(bool diag, int lane, int wave) { return !diag || lane >= 8 * wave; }     // multiplier entries kept
+__device__ __forceinline__ bool qn_s2_col_on(bool diag, int lane, int wave) { return !diag || lane >= 8 * wave + 8; } // column sums kept
+
+// ------------------------------------------------------------------------------------------------
+// evaluation tiles: q-slots of Q (x + t d) and the scalars xt'Q xt, d'Q xt (+ on diagonal items the vector dots of block I)
+// ------------------------------------------------------------------------------------------------
+// x + t d at one index from loaded values: the arithmetic of qn_trial_entry (qn_sym.hip.h), which the accept-reduce uses
+__device__ __forceinline__ double qn_s2_trial(const QnEvalReq& q, const double xi, const double vi, const double si, const double ui, double& d) {
+    if (!q.is_t) { d = 0.0; return xi; }
+    d = qn_dir1(q.mode, vi, q.mode ? si : 0.0, q.mode ? ui : 0.0, q.c_ss, q.c_su, q.c_uu, q.ug, q.sg);
+    const double td = q.t * d; // `step * direction` rounds first (bfgs.rs:94)
+    return xi + td;
+}
+
+// the vector entries one item needs: row side (row 16 w + (lane & 15) of block I) and column side (this lane's two columns of J)
+struct QnS2EvalVec {
+    double x_r, v_r, s_r, u_r, b_r, g_r;
+    v2d x_c, v_c, s_c, u_c;
+};
+__device__ __forceinline__ void qn_s2_eval_vec_load(const QnS2Args& a, const double* x, const double* sp, const int ir, const int jc, QnS2EvalVec& v) {
+    v.x_r = x[ir]; v.v_r = a.F.VV[ir]; v.s_r = sp[ir]; v.u_r = a.F.UN[ir]; v.b_r = a.F.b[ir]; v.g_r = a.F.G[ir];
+    v.x_c = ld2(x + jc); v.v_c = ld2(a.F.VV + jc); v.s_c = ld2(sp + jc); v.u_c = ld2(a.F.UN + jc);
+}
+
+__global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a) {
+    __shared__ QnS2Lds L;
+    __shared__ double colsum[QN_TB];
+    __shared__ double colred[QN_S2_WAVES][QN_TB];
+    __shared__ double sred[QN_S2_WAVES][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t np = (size_t)a.np;
+    QN_S2_STAMP(0);
+    // A wave's loads return in order.  So: the first item (the window's addresses need it) is requested first, the control
+    // block and the partial sums next -- the prologue then never waits for the 128 KB window behind them -- and the window last.
+    int ij = a.item_ij[blockIdx.x];
+    QnS2Pro P;
+    qn_s2_pro_issue<QN_S2_EVAL>(a, P);
+    int I = ij >> 16, J = ij & 0xffff;
+    // The wave's 16 rows of the first item are requested before the control block has arrived (their addresses do not depend on
+    // it), and so are the first item's vector entries for BOTH settings of the two buffer toggles the control block holds
+    // (x / trial point, pending / staged s); every register of the window is refilled with the next item's row the moment its
+    // row is consumed: 128 KB in flight per workgroup across item boundaries, reductions and barriers.
+    v2d h[QN_S2_RPW];
+    const double* qb = a.Q + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
+#pragma unroll
+    for (int r = 0; r < QN_S2_RPW; ++r) h[r] = ld2(qb + (size_t)r * np);
+    QnS2EvalVec v0, v1; // v0: x = X0[0], s = S0[0]; v1 holds the other halves' x and s entries
+    {
+        const int ir = I * QN_TB + wave * QN_S2_RPW + (lane & 15), jc = J * QN_TB + 2 * lane;
+        qn_s2_eval_vec_load(a, a.F.X0, a.F.S0, ir, jc, v0);
+        v1.x_r = a.F.X0[np + ir]; v1.s_r = a.F.S0[np + ir];
+        v1.x_c = ld2(a.F.X0 + np + jc); v1.s_c = ld2(a.F.S0 + np + jc);
+    }
+    QN_S2_STAMP(1);
+    if (!qn_s2_pro_finish<QN_S2_EVAL>(a, L, P)) return;
+    QN_S2_STAMP(2);
+    int stamp_k = 3;
+    const QnEvalReq q = qn_s2_eval_req(L.c, false);
+    const int ev_par = L.c.ev_par;
+    const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
+    const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
+    if (q.xc) { v0.x_r = v1.x_r; v0.x_c = v1.x_c; }
+    if (q.sc) { v0.s_r = v1.s_r; v0.s_c = v1.s_c; }
+    double wg[QN_S2_NSE]; // thread 0: this workgroup's running totals (items in list order)
+#pragma unroll
+    for (int k = 0; k < QN_S2_NSE; ++k) wg[k] = 0.0;
+    for (int it = 0;; ++it) {
+        const bool diag = I == J; // (uniform)
+        // row side: lane l holds row 16 w + (l & 15) of the tile; column side: this lane's two columns
+        double dr;
+        const double xr = qn_s2_trial(q, v0.x_r, v0.v_r, v0.s_r, v0.u_r, dr);
+        double p1 = 0.0, p3 = 0.0, p4 = 0.0, p5 = 0.0; // diagonal items: b'xt, b'd, g'd, #non-finite d over block I (lanes 0..15 of every wave)
+        if (diag && lane < 16) { p1 = v0.b_r * xr; p3 = v0.b_r * dr; p4 = v0.g_r * dr; p5 = isfinite(dr) ? 0.0 : 1.0; }
+        v2d xtj, dj;
+        {
+            double d0, d1;
+            xtj.x = qn_s2_trial(q, v0.x_c.x, v0.v_c.x, v0.s_c.x, v0.u_c.x, d0);
+            xtj.y = qn_s2_trial(q, v0.x_c.y, v0.v_c.y, v0.s_c.y, v0.u_c.y, d1);
+            dj.x = d0; dj.y = d1;
+        }
+        // the next item: where the window is refilled from while this one is consumed
+        int ijn = -1;
+        if (it + 1 < a.maxk) ijn = a.item_ij[(size_t)(it + 1) * a.G + blockIdx.x];
+        const bool has_next = ijn >= 0; // (uniform)
+        const int In = has_next ? (ijn >> 16) : I, Jn = has_next ? (ijn & 0xffff) : J;
+        const double* qn = a.Q + (size_t)(In * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jn * QN_TB + qn_s2_col(In == Jn, lane, wave);
+        const size_t rstride = has_next ? np : 0; // (no next item: every lane re-reads one 16-byte word of this one, a single request per instruction)
+        if (!qn_s2_row_on(diag, lane, wave)) { xtj = (v2d){0.0, 0.0}; dj = (v2d){0.0, 0.0}; }
+        if (stamp_k < 13) QN_S2_STAMP(stamp_k); // vectors ready
+        ++stamp_k;
+        double cx = 0.0, cy = 0.0, pf = 0.0, pg = 0.0;
+        double racc[QN_S2_RPW];
+#pragma unroll
+        for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
+            const v2d hv = h[r];
+            h[r] = ld2(qn + (size_t)r * rstride); // the register this row frees takes the same row of the next item at once
+            const double xi = qn_lane_bcast(xr, r), di = qn_lane_bcast(dr, r);
+            double t0 = hv.x * xtj.x;
+            t0 = __builtin_fma(hv.y, xtj.y, t0);
+            racc[r] = t0;
+            cx = __builtin_fma(hv.x, xi, cx);
+            cy = __builtin_fma(hv.y, xi, cy);
+            pf = __builtin_fma(xi, t0, pf);
+            pg = __builtin_fma(di, t0, pg);
+        }
+        if (!qn_s2_col_on(diag, lane, wave)) { cx = 0.0; cy = 0.0; }
+        // the next item's vector entries go out now: they fly while this item's sums are folded, exchanged and stored
+        if (has_next) qn_s2_eval_vec_load(a, x, sp, In * QN_TB + wave * QN_S2_RPW + (lane & 15), Jn * QN_TB + 2 * lane, v0);
+        qn_keepalive(cx); qn_keepalive(pf);
+        if (stamp_k < 13) QN_S2_STAMP(stamp_k); // row loop done
+        ++stamp_k;
+        pf = __builtin_fma(xtj.x, cx, pf); pf = __builtin_fma(xtj.y, cy, pf); // xt_J'(column part): the mirrored half of xt'Q xt
+        pg = __builtin_fma(dj.x, cx, pg); pg = __builtin_fma(dj.y, cy, pg);   // d_J'(column part) = xt_I'Q_IJ d_J
+        colred[wave][2 * lane] = cx;
+        colred[wave][2 * lane + 1] = cy;
+        {
+            double sv[8] = {pf, pg, p1, p3, p4, p5, 0.0, 0.0};
+            QnWaveFold<8, 32>::run(sv, lane);
+            if ((lane & 7) == 0) sred[wave][lane >> 3] = sv[0];
+        }
+        QnWaveFold<QN_S2_RPW, 32>::run(racc, lane); // lanes with (lane & 3) == 0 hold the total of row lane >> 2
+        if (it == 0) { qn_keepalive(racc[0]); QN_S2_STAMP(12); }
+        __syncthreads();
+        if (it == 0) QN_S2_STAMP(13);
+        if (tid < QN_TB) {
+            double acc = colred[0][tid];
+#pragma unroll
+            for (int w = 1; w < QN_S2_WAVES; ++w) acc = acc + colred[w][tid];
+            if (diag) colsum[tid] = acc; // both parts of a diagonal tile belong to block-row I: one slot
+            else a.part[(((size_t)J * a.nb + I) * 2 + 0) * QN_TB + tid] = acc;
+        }
+        if (tid == 0) {
+            wg[0] = wg[0] + qn_s2_wave_total(sred, 0);
+            wg[2] = wg[2] + qn_s2_wave_total(sred, 1);
+            if (diag) {
+                wg[1] = wg[1] + qn_s2_wave_total(sred, 2);
+                wg[3] = wg[3] + qn_s2_wave_total(sred, 3);
+                wg[4] = wg[4] + qn_s2_wave_total(sred, 4);
+                wg[5] = wg[5] + qn_s2_wave_total(sred, 5);
+            }
+        }
+        if (it == 0) QN_S2_STAMP(14);
+        if (diag) __syncthreads(); // (uniform: I, J are the same in every thread)
+        if ((lane & 3) == 0) {
+            const int rl = wave * QN_S2_RPW + (lane >> 2);
+            double v = racc[0];
+            if (diag) v = v + colsum[rl];
+            a.part[(((size_t)I * a.nb + J) * 2 + 0) * QN_TB + rl] = v;
+        }
+        if (stamp_k < 13) QN_S2_STAMP(stamp_k); // item done
+        ++stamp_k;
+        if (!has_next) break;
+        I = In; J = Jn;
+        __syncthreads(); // colred / colsum / sred are rewritten by the next item
+    }
+    QN_S2_STAMP(15);
+    if (tid == 0) {
+        double* out = a.wgE + ((size_t)ev_par * a.G + blockIdx.x) * QN_S2_ROW;
+#pragma unroll
+        for (int k = 0; k < QN_S2_NSE; ++k) out[k] = wg[k];
+    }
+}
+
+// Slot sums of block-row R: 4 x 128 threads, each quarter adds a quarter of the row's nb slots in slot order and the quarters are
+// combined in order through LDS.  In two steps, so that the first 16 slots of every quarter (all of them up to n = 8192) are in
+// flight while the control block is still on its way: the addresses do not depend on it.
+struct QnS2Slots { double v[16]; };
+__device__ __forceinline__ void qn_s2_slot_issue(const double* __restrict__ part, int nb, int R, int rhs, QnS2Slots& S) {
+    const int i = threadIdx.x & (QN_TB - 1), qd = threadIdx.x >> 7;
+    const int per = (nb + 3) / 4;
+    const int k_lo = qd * per, k_hi = min(nb, k_lo + per);
+    const double* p = part + (((size_t)R * nb) * 2 + rhs) * QN_TB + i;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) S.v[u] = (k_lo + u < k_hi) ? p[(size_t)(k_lo + u) * 2 * QN_TB] : 0.0;
+}
+// threads 0..127 return the total of row (tid & 127); all 512 threads call it
+__device__ __forceinline__ double qn_s2_slot_sum(const double* __restrict__ part, int nb, int R, int rhs, const QnS2Slots& S, double (*qbuf)[QN_TB]) {
+    const int i = threadIdx.x & (QN_TB - 1), qd = threadIdx.x >> 7;
+    const int per = (nb + 3) / 4;
+    const int k_lo = qd * per, k_hi = min(nb, k_lo + per);
+    const double* p = part + (((size_t)R * nb) * 2 + rhs) * QN_TB + i;
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = acc + S.v[u];
+    for (int k0 = k_lo + 16; k0 < k_hi; k0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = (k0 + u < k_hi) ? p[(size_t)(k0 + u) * 2 * QN_TB] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = acc + v[u];
+    }
+    if (qd > 0) qbuf[qd - 1][i] = acc;
+    __syncthreads();
+    const double tot = (qd == 0) ? ((acc + qbuf[0][i]) + qbuf[1][i]) + qbuf[2][i] : 0.0;
+    __syncthreads(); // qbuf is reused by the next call
+    return tot;
+}
+
+// accept-reduce: block-row R of the LAST evaluation becomes vectors: q_i, g+ = q - b, y = g+ - g, x+ and s = x+ - x
+// (bfgs.rs:94-99), and the five sums the update needs
+__global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
+    __shared__ QnS2Lds L;
+    __shared__ double qbuf[3][QN_TB];
+    __shared__ double bred[2][8];
+    const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    QnS2Slots S0;
+    {
+        QnS2Pro P;
+        qn_s2_pro_issue<QN_S2_VEC>(a, P);
+        qn_s2_slot_issue(a.part, a.nb, R, 0, S0);
+        if (!qn_s2_pro_finish<QN_S2_VEC>(a, L, P)) return;
+    }
+    const size_t np = (size_t)a.np;
+    const QnEvalReq q = qn_s2_eval_req(L.c, true);
+    const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
+    double* __restrict__ xt = a.F.X0 + (size_t)(1 - q.xc) * np;
+    const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
+    double* __restrict__ sstage = a.F.S0 + (size_t)(1 - q.sc) * np;
+    const double qi = qn_s2_slot_sum(a.part, a.nb, R, 0, S0, qbuf);
+    double p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = 0.0;
+    if (tid < QN_TB) {
+        const int gi = R * QN_TB + tid;
+        double di;
+        const double xi = x[gi];
+        const double xti = qn_trial_entry(q, x, a.F.VV, sp, a.F.UN, gi, &di);
+        const double bi = a.F.b[gi], go = a.F.G[gi];
+        const double gti = qi - bi;
+        const double yi = gti - go;
+        const double si = xti - xi; // s = x+ - x, not t d (bfgs.rs:96)
+        a.F.GT[gi] = gti;
+        a.F.Y[gi] = yi;
+        xt[gi] = xti;
+        sstage[gi] = si;
+        p[0] = yi * yi; p[1] = yi * si; p[2] = gti * gti; p[3] = si * si; p[4] = si * gti;
+    }
+    if (wave < 2) { // threads 0..127 hold the rows
+        QnWaveFold<8, 32>::run(p, lane);
+        if ((lane & 7) == 0) bred[wave][lane >> 3] = p[0];
+    }
+    __syncthreads();
+    if (tid < QN_S2_NR) a.rp[(size_t)R * QN_S2_ROW + tid] = bred[0][tid] + bred[1][tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// update tiles: pending rank-2 update in place, row / column slots of [y, g+] (or [g, g]).
+// ONE branch-free body serves every request: no update pending = zero coefficients, a direction pass (one right-hand side,
+// once per qn_minimize call) = a two-right-hand-side pass with g in both places -- sixteen specialised copies of the row loop
+// cost more in registers (the compiler kept the load window in scratch memory across them) than the skipped flops were worth.
+// ------------------------------------------------------------------------------------------------
+struct QnS2HReq { // the update-pass request, decoded once per launch
+    const double *sp, *up, *r0v, *gt;
+    double c_ss, c_su, c_uu;
+    bool pending;
+};
+// the vector entries one item needs: row side (row 16 w + (lane & 15) of block I) and column side (this lane's two columns of J)
+struct QnS2HVec {
+    double s_r, u_r, y0_r, y1_r;
+    v2d s_c, u_c, a0, a1;
+};
+__device__ __forceinline__ void qn_s2_hvec_load(const QnS2HReq& q, const int ir, const int jc, QnS2HVec& v) {
+    v.s_r = q.sp[ir]; v.u_r = q.up[ir]; v.y0_r = q.r0v[ir]; v.y1_r = q.gt[ir];
+    v.s_c = ld2(q.sp + jc); v.u_c = ld2(q.up + jc); v.a0 = ld2(q.r0v + jc); v.a1 = ld2(q.gt + jc);
+}
+
+// BFGS: true -> the update has the (s u' + u s') and s s' terms (bfgs.rs:115-124); false -> DFP: s s' and u u' (dfp.rs:115-120)
+template <bool NT, bool BFGS>
+__global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a) {
+    __shared__ QnS2Lds L;
+    __shared__ double colsum[2][QN_TB]; // [rhs]: row part of a diagonal item, parked until its column part is summed
+    __shared__ double colred[QN_S2_WAVES][2][QN_TB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t np = (size_t)a.np;
+    int ij = a.item_ij[blockIdx.x]; // (load order: first item, control block and partial sums, window -- see s2_eval_kernel)
+    QnS2Pro P;
+    qn_s2_pro_issue<QN_S2_HTILE>(a, P);
+    int I = ij >> 16, J = ij & 0xffff;
+    v2d h[QN_S2_RPW]; // the wave's 16 rows of the first item go out before the control block has arrived ...
+    double* hbase = a.H + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
+#pragma unroll
+    for (int r = 0; r < QN_S2_RPW; ++r) h[r] = qn_sym_ld<NT>(hbase + (size_t)r * np);
+    // ... and so do the first item's vector entries, for both settings of what the control block decides: which half of the s
+    // double buffer is the pending one, and whether the first right-hand side is y (update pass) or g (direction pass)
+    QnS2HVec v0;
+    double s1_r, y_r;
+    v2d s1_c, y_c;
+    {
+        const int ir = I * QN_TB + wave * QN_S2_RPW + (lane & 15), jc = J * QN_TB + qn_s2_col(I == J, lane, wave);
+        QnS2HReq spec;
+        spec.sp = a.F.S0; spec.up = a.F.UN; spec.r0v = a.F.GT; spec.gt = a.F.GT;
+        qn_s2_hvec_load(spec, ir, jc, v0);
+        s1_r = a.F.S0[np + ir]; s1_c = ld2(a.F.S0 + np + jc);
+        y_r = a.F.Y[ir]; y_c = ld2(a.F.Y + jc);
+    }
+    if (!qn_s2_pro_finish<QN_S2_HTILE>(a, L, P)) return;
+    QnS2HReq q;
+    {
+        const QnCtl& c = L.c;
+        q.pending = c.pending != 0;
+        q.c_ss = c.c_ss; q.c_su = c.c_su; q.c_uu = c.c_uu;
+        q.sp = a.F.S0 + (size_t)c.sc * np;
+        q.up = a.F.UN;
+        q.gt = a.F.GT;
+        q.r0v = (c.hp_nrhs == 2) ? a.F.Y : a.F.GT; // a direction pass (bfgs.rs:47) multiplies g twice: slot 0 is what its reduce reads
+        if (c.sc) { v0.s_r = s1_r; v0.s_c = s1_c; }
+        if (c.hp_nrhs == 2) { v0.y0_r = y_r; v0.a0 = y_c; }
+    }
+    // The row loop below is branch-free.  No update pending (the first pass of a run) = an update with zero coefficients and
+    // zero vectors: H + 0 (0 0) = H.  (The path requires n = n_pad: no padding entries to keep at zero.)
+    const bool pend = q.pending;
+    const double c_ss = pend ? q.c_ss : 0.0, c_su = pend ? q.c_su : 0.0, c_uu = pend ? q.c_uu : 0.0;
+    const bool up = (lane & 32) != 0;
+    for (int it = 0;; ++it) {
+        const bool diag = I == J; // (uniform)
+        const double sr = pend ? v0.s_r : 0.0, ur = pend ? v0.u_r : 0.0;
+        const double y0r = v0.y0_r, y1r = v0.y1_r;
+        v2d sj = {0.0, 0.0}, uj = {0.0, 0.0};
+        if (pend) { sj = v0.s_c; uj = v0.u_c; } // (a diagonal item's clone lanes hold the clamped column's entries: identical stores)
+        v2d a0 = v0.a0, a1 = v0.a1; // update pass: y, g+ ; direction pass: g, g
+        if (!qn_s2_row_on(diag, lane, wave)) { a0 = (v2d){0.0, 0.0}; a1 = (v2d){0.0, 0.0}; }
+        // the next item: where the window is refilled from while this one is consumed
+        int ijn = -1;
+        if (it + 1 < a.maxk) ijn = a.item_ij[(size_t)(it + 1) * a.G + blockIdx.x];
+        const bool has_next = ijn >= 0; // (uniform)
+        const int In = has_next ? (ijn >> 16) : I, Jn = has_next ? (ijn & 0xffff) : J;
+        double* hnext = a.H + (size_t)(In * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jn * QN_TB + qn_s2_col(In == Jn, lane, wave);
+        const size_t rstride = has_next ? np : 0; // (none left: every lane re-reads one 16-byte word of this item)
+        double c0x = 0.0, c0y = 0.0, c1x = 0.0, c1y = 0.0;
+        double racc[QN_S2_RPW];
+#pragma unroll
+        for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
+            v2d hn = h[r];
+            h[r] = qn_sym_ld<NT>(hnext + (size_t)r * rstride); // the register this row frees takes the same row of the next item at once
+            const double si = qn_lane_bcast(sr, r), ui = qn_lane_bcast(ur, r);
+            if (BFGS) {
+                hn.x = hn.x + c_su * (si * uj.x + ui * sj.x);
+                hn.y = hn.y + c_su * (si * uj.y + ui * sj.y);
+            }
+            hn.x = hn.x + c_ss * (si * sj.x);
+            hn.y = hn.y + c_ss * (si * sj.y);
+            if (!BFGS) {
+                hn.x = hn.x + c_uu * (ui * uj.x);
+                hn.y = hn.y + c_uu * (ui * uj.y);
+            }
+            qn_sym_st<NT>(hbase + (size_t)r * np, hn);
+            const double y0 = qn_lane_bcast(y0r, r), y1 = qn_lane_bcast(y1r, r);
+            double t0 = hn.x * a0.x;
+            t0 = __builtin_fma(hn.y, a0.y, t0);
+            double t1 = hn.x * a1.x;
+            t1 = __builtin_fma(hn.y, a1.y, t1);
+            // first level of the 32-value butterfly (the row's sum for y against its sum for g+, lane against lane ^ 32) at
+            // once: two sums become one register; QnWaveFold<16, 16> finishes the same tree after the last row
+            racc[r] = (up ? t1 : t0) + qn_xor_lanes<32>(up ? t0 : t1);
+            c0x = __builtin_fma(hn.x, y0, c0x);
+            c0y = __builtin_fma(hn.y, y0, c0y);
+            c1x = __builtin_fma(hn.x, y1, c1x);
+            c1y = __builtin_fma(hn.y, y1, c1y);
+        }
+        if (!qn_s2_col_on(diag, lane, wave)) { c0x = 0.0; c0y = 0.0; c1x = 0.0; c1y = 0.0; }
+        // the next item's vector entries go out now: they fly while this item's sums are folded, exchanged and stored
+        if (has_next) qn_s2_hvec_load(q, In * QN_TB + wave * QN_S2_RPW + (lane & 15), Jn * QN_TB + qn_s2_col(In == Jn, lane, wave), v0);
+        QnWaveFold<QN_S2_RPW, 16>::run(racc, lane); // lanes with (lane & 1) == 0: total of row (lane >> 1) & 15 for rhs lane >> 5
+        colred[wave][0][2 * lane] = c0x;
+        colred[wave][0][2 * lane + 1] = c0y;
+        colred[wave][1][2 * lane] = c1x;
+        colred[wave][1][2 * lane + 1] = c1y;
+        if ((lane & 1) == 0) {
+            const int rhs = lane >> 5, rl = wave * QN_S2_RPW + ((lane >> 1) & 15);
+            if (diag) colsum[rhs][rl] = racc[0]; // the column part of a diagonal tile lands in the same slot: park the row part
+            else a.part[(((size_t)I * a.nb + J) * 2 + rhs) * QN_TB + rl] = racc[0];
+        }
+        __syncthreads();
+        if (tid < 2 * QN_TB) {
+            const int crhs = tid / QN_TB, c = tid % QN_TB;
+            double acc = colred[0][crhs][c];
+#pragma unroll
+            for (int w = 1; w < QN_S2_WAVES; ++w) acc = acc + colred[w][crhs][c];
+            if (diag) a.part[(((size_t)I * a.nb + I) * 2 + crhs) * QN_TB + c] = colsum[crhs][c] + acc; // row part + column part
+            else a.part[(((size_t)J * a.nb + I) * 2 + crhs) * QN_TB + c] = acc;
+        }
+        if (!has_next) break;
+        I = In; J = Jn; hbase = hnext;
+        __syncthreads(); // the LDS staging areas are rewritten by the next item
+    }
+}
+
+// update-reduce: u_i, v_i = sums of block-row R's slots, the partials of y'u and u'g+ (the update's coefficients and the next
+// direction need them); commits g <- g+ (the evaluation kernels read g for g'd)
+__global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a) {
+    __shared__ QnS2Lds L;
+    __shared__ double qbuf[3][QN_TB];
+    __shared__ double bred[2][8];
+    const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    QnS2Slots S0, S1;
+    {
+        QnS2Pro P;
+        qn_s2_pro_issue<QN_S2_HREDUCE>(a, P);
+        qn_s2_slot_issue(a.part, a.nb, R, 0, S0);
+        qn_s2_slot_issue(a.part, a.nb, R, 1, S1);
+        if (!qn_s2_pro_finish<QN_S2_HREDUCE>(a, L, P)) return;
+    }
+    const int nrhs = L.c.hp_nrhs;
+    const double tot0 = qn_s2_slot_sum(a.part, a.nb, R, 0, S0, qbuf);
+    const double tot1 = (nrhs == 2) ? qn_s2_slot_sum(a.part, a.nb, R, 1, S1, qbuf) : 0.0; // (uniform)
+    double p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = 0.0;
+    if (tid < QN_TB) {
+        const int gi = R * QN_TB + tid;
+        const double gp = a.F.GT[gi];
+        if (nrhs == 2) {
+            a.F.UN[gi] = tot0; a.F.VV[gi] = tot1;
+            p[0] = a.F.Y[gi] * tot0; // y'u = y'H+y
+            p[1] = tot0 * gp;        // u'g+
+        } else {
+            a.F.VV[gi] = tot0; // direction pass: v = H g (bfgs.rs:47)
+        }
+        a.F.G[gi] = gp; // commit g <- g+
+    }
+    if (wave < 2) { // threads 0..127 hold the rows
+        QnWaveFold<8, 32>::run(p, lane);
+        if ((lane & 7) == 0) bred[wave][lane >> 3] = p[0];
+    }
+    __syncthreads();
+    if (tid < 2) a.hrp[(size_t)R * 2 + tid] = bred[0][tid] + bred[1][tid];
+}
+
+// synchronous mode: the prologue alone (one workgroup)
+__global__ __launch_bounds__(QN_S2_TPB) void s2_advance_kernel(const QnS2Args a) {
+    __shared__ QnS2Lds L;
+    QnS2Pro P;
+    qn_s2_pro_issue<QN_S2_ADVANCE>(a, P);
+    (void)qn_s2_pro_finish<QN_S2_ADVANCE>(a, L, P);
+}
+
+// lower triangle <- transpose of the maintained upper one, 32 x 32 blocks through LDS; inside the diagonal blocks too
+__global__ __launch_bounds__(256) void sym2_mirror_kernel(double* __restrict__ H, int n_pad) {
+    __shared__ double t[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t np = (size_t)n_pad;
+    for (int r = ty; r < 32; r += 8) t[r][tx] = H[(size_t)(bi * 32 + r) * np + bj * 32 + tx];
+    __syncthreads();
+    if (bj > bi) {
+        for (int r = ty; r < 32; r += 8) H[(size_t)(bj * 32 + r) * np + bi * 32 + tx] = t[tx][r];
+    } else {
+        for (int r = ty; r < 32; r += 8)
+            if (tx < r) H[(size_t)(bi * 32 + r) * np + bi * 32 + tx] = t[tx][r];
+    }
+}

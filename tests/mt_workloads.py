@@ -12,10 +12,31 @@ Why these inputs (phi(t) = f(x + t d) is a parabola on a quadratic, t* its minim
     symmetric matrix).  It evaluates the oracle at x + tu d: with t_max = +inf that point is non-finite (f = NaN), the cubic
     returns NaN, Rust's max/min drop it, t = 0 and the run ends through `next iterate too close`; with a finite t_max the
     search goes on from the cubic through (t, tu).
-`iters` bounds each run to the stretch over which the as-written and rank-2 restatements agree to ~1e-15 (explored on CPU; a
-case-3 step extrapolates from [0, 1] to t ~ 20 and is ill-conditioned once rounding differences have accumulated, and the
-non-convex runs blow up), so the stated tolerance of the parity sweep applies unchanged.
+`iters` bounds each run to the stretch over which the as-written and rank-2 restatements agree to ~1e-15 (explored on CPU; the
+non-convex runs blow up afterwards), so the stated tolerance of the parity sweep applies unchanged -- with ONE exception,
+`t_tol` of "case3_inf": there the accepted step is the cubic / secant EXTRAPOLATION from [0, 1] to t* ~ 20 of a function that is
+a parabola.  For a parabola the cubic's discriminant z^2 - g_a g_b collapses to (g_a - g_b)^2 / 4 = O(g_a^2 / t*^2): the
+~1e-13 absolute difference that two summation orders leave in f(x + d) - f(x) ~ 1e2 comes out of that step as ~1e-11 relative in
+t at iteration 0, and iteration 1 -- whose gradient is the small remainder after that near-exact line minimisation -- amplifies
+it again to ~1e-8 (measured: 1.5e-8 between the HIP path and the oracle at n = 1024; the two restatements, which share their
+summation orders, agree to 1e-16).  That is the conditioning of morethuente.rs:256-272 at tu = +inf, not a property of the
+implementation, so this workload states 1e-6 for t (the iterates still meet 1e-9: the step error enters x scaled by |t d| / |x|).
+"case2_mod" has the milder form of the same thing: on Q ~ I every exact line minimisation shrinks the gradient ~50x (n = 1024),
+so g_k is the small difference of large terms and a relative perturbation eps of x_k shows up as eps ||g_0|| / ||g_k|| in
+phi'(t) and in the interpolated step; its step tolerance is therefore max(1e-9, 1e-10 ||g_0|| / ||g_k||) (measured: 2e-9 ... 8e-9
+at ||g_k|| / ||g_0|| = 3e-4, 3e-6 at 7e-6).  The benchmark family (kappa = 1e3) loses two orders of gradient in ~100
+iterations, not in one, which is why the parity sweep's flat 1e-9 holds there.
 """
+
+
+def t_tol(name, gnorm_k, gnorm_0, base=1e-9):
+    """step-length tolerance of workload `name` at an iteration whose loop-top gradient norm is gnorm_k"""
+    w = WORKLOADS[name]
+    tol = max(base, w.get("t_tol", 0.0))
+    if w.get("t_amp"):
+        tol = max(tol, w["t_amp"] * gnorm_0 / gnorm_k)
+    return tol
+
 import numpy as np
 
 import problems as P
@@ -46,8 +67,8 @@ def count_cases(trace):
 
 # name -> (kappa, fraction of negative diagonal entries, H0 = c I or None, t_max or None, iterations, digits it must produce)
 WORKLOADS = {
-    "case2_mod":      dict(kappa=1.0, neg=0.0, h0=1.95, t_max=None, iters=4, expect={2: 3}, expect_mod=3),
-    "case3_inf":      dict(kappa=1.0, neg=0.0, h0=0.05, t_max=None, iters=3, expect={3: 2}, expect_mod=0),
+    "case2_mod":      dict(kappa=1.0, neg=0.0, h0=1.95, t_max=None, iters=4, expect={2: 3}, expect_mod=3, t_amp=1e-10),
+    "case3_inf":      dict(kappa=1.0, neg=0.0, h0=0.05, t_max=None, iters=3, expect={3: 2}, expect_mod=0, t_tol=1e-6),
     "case3_tmax":     dict(kappa=1.0, neg=0.0, h0=0.05, t_max=4.0, iters=8, expect={3: 3}, expect_mod=0),
     "case4_inf":      dict(kappa=10.0, neg=0.1, h0=None, t_max=None, iters=8, expect={4: 1}, expect_mod=0),
     "case4_tmax4":    dict(kappa=10.0, neg=0.1, h0=None, t_max=4.0, iters=4, expect={4: 1}, expect_mod=0),

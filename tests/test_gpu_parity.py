@@ -14,6 +14,7 @@ import os
 import numpy as np
 import pytest
 
+import mt_workloads as W
 import problems as P
 
 pytestmark = pytest.mark.gpu
@@ -329,7 +330,8 @@ def test_golden_fixtures(qn, qo):
         assert len(tr) >= w
         for k in range(w):
             assert tr[k]["ls_cases"] == ref[k]["ls_cases"] and tr[k]["n_evals"] == ref[k]["n_evals"], (n, c["method"], c["ls"], k)
-            assert abs(tr[k]["t"] - ref[k]["t"]) <= T_TOL * abs(ref[k]["t"])
+            t_tol = W.t_tol(c["workload"], ref[k]["gnorm"], ref[0]["gnorm"], T_TOL) if c.get("workload") else T_TOL  # (conditioning: mt_workloads.py)
+            assert abs(tr[k]["t"] - ref[k]["t"]) <= t_tol * abs(ref[k]["t"]), (n, c.get("workload"), c["method"], k)
             assert abs(tr[k]["f"] - ref[k]["f"]) <= F_TOL * max(1.0, abs(ref[k]["f"]))
             assert np.linalg.norm(xs[k] - ref_xs[k]) <= X_TOL * max(1.0, np.linalg.norm(ref_xs[k]))
 
