@@ -6,9 +6,11 @@
 
 One "step" = one BFGS iteration (direction, More-Thuente line search, rank-2 inverse-Hessian update) on the
 device-resident objective f = 1/2 x'Qx - b'x; Q, H, and every vector are in HBM before the timed region.
-N = 1 runs BASELINE.json configs[1] (n = 4096; one rank streams only the upper block triangle of the symmetric H and Q);
+N = 1 runs BASELINE.json configs[1] (n = 4096; one rank streams only the symmetric half of H and Q);
 N > 1 runs configs[2]'s problem (n = 32768) with H and Q row-sharded over the N ranks and one RCCL all-gather per mat-vec
 pass ("scaling": "strong" over N = 2,4,8).
+Timing: 5 regions, each = reset to (x0, H = I), W untimed warm-up iterations, exactly K timed iterations
+between barrier + synchronize brackets, max over ranks; the MEDIAN region is reported (all five are in `timing.region_ms`).
 Prints ONE JSON line on rank 0.  The product path is libqn_hip.so (hand-written gfx950 kernels); the CPU
 oracle is used only for the `cpu_baseline` leg.  No GPU => hard failure, never a fallback.
 """
@@ -52,6 +54,13 @@ def run_iterations(qn, solver, ls, obj, x0, iters):
         except qn.MaxIterReached:
             done += solver.k()
     return restarts
+
+
+def totals(solver):
+    """Counters that accumulate over every qn_minimize call of the solver (the per-call ones restart with k)."""
+    st = solver.stats()
+    return {k: st[k] for k in ("total_minimize_calls", "total_iterations", "total_oracle_calls", "total_oracle_evals", "total_h_passes",
+                               "total_h_bytes", "total_obj_bytes", "launches", "host_syncs")}
 
 
 def cpu_baseline(n, iters):
@@ -171,32 +180,59 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # warm-up iterations (untimed), then exactly `steps` timed iterations of the same solve
-    if warmup > 0:
-        run_iterations(qn, solver, ls, obj, x0, warmup)
-    barrier()
-    st0 = solver.stats()
-    t0 = time.perf_counter()
-    restarts = run_iterations(qn, solver, ls, obj, x0, steps)
-    ctx.synchronize()
-    elapsed = time.perf_counter() - t0
-    st1 = solver.stats()
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    barrier()
-
-    evals = st1["oracle_evals"] - st0["oracle_evals"]
-    calls = st1["oracle_calls"] - st0["oracle_calls"]
-    h_bytes = st1["h_bytes"] - st0["h_bytes"]
-    obj_bytes = st1["obj_bytes"] - st0["obj_bytes"]
+    # median of 5 timed regions.  Each region is the same thing: back to (x0, H = I), `warmup` untimed iterations,
+    # then EXACTLY `steps` timed iterations of the same solve between barrier + synchronize brackets (max over ranks).
+    regions = 5
+    region_s, region_acc = [], []
+    for _ in range(regions):
+        solver.reset(x0)
+        if warmup > 0:
+            run_iterations(qn, solver, ls, obj, x0, warmup)
+        barrier()
+        t_before = totals(solver)
+        t0 = time.perf_counter()
+        restarts = run_iterations(qn, solver, ls, obj, x0, steps)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        t_after = totals(solver)
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        barrier()
+        acc = {k: t_after[k] - t_before[k] for k in t_after}
+        acc["restarts"] = restarts
+        region_s.append(dt)
+        region_acc.append(acc)
+    order = sorted(range(regions), key=lambda i: region_s[i])
+    mid = order[regions // 2]
+    elapsed = region_s[mid]
+    acc = region_acc[mid]
+    restarts = acc["restarts"]
+    evals, calls = acc["total_oracle_evals"], acc["total_oracle_calls"]
+    h_bytes, obj_bytes = acc["total_h_bytes"], acc["total_obj_bytes"]
     its = steps / elapsed
+
+    # fixed cost of one qn_minimize call (control-block round trips, enqueue of the launch pattern, any state hand-over): a call
+    # that is allowed zero iterations returns Err(MaxIterReached) from the first loop top (ls_solver.rs:78,109-110)
+    call_ms = []
+    for _ in range(7):
+        barrier()
+        t0 = time.perf_counter()
+        try:
+            solver.minimize(ls, obj, 0, 20)
+        except qn.MaxIterReached:
+            pass
+        ctx.synchronize()
+        call_ms.append(1e3 * (time.perf_counter() - t0))
+    call_ms.sort()
+    per_call_fixed_ms = call_ms[len(call_ms) // 2]
 
     # kernel-level roofline: same workload again with every launch bracketed by HIP events on the solver's stream
     roofline = None
     if not args.no_profile_pass:
         prof_steps = min(steps, 50)
+        solver.reset(x0)
         solver.set_profiling(True)
         solver.set_sync_mode(1)  # only real work is launched: no predicated-off launches dilute the averages
         p0 = solver.stats()
@@ -204,52 +240,68 @@ def main():
         p1 = solver.stats()
         solver.set_profiling(False)
         solver.set_sync_mode(args.sync_mode if args.sync_mode is not None else -1)
-        n_h = p1["n_hpass_timed"] - p0["n_hpass_timed"]
-        t_h = p1["t_hpass_ms"] - p0["t_hpass_ms"]
-        n_e = p1["n_eval_timed"] - p0["n_eval_timed"]
-        t_e = p1["t_eval_ms"] - p0["t_eval_ms"]
-        n_c = p1["n_ctl_timed"] - p0["n_ctl_timed"]
-        t_c = p1["t_ctl_ms"] - p0["t_ctl_ms"]
-        # algorithmic bytes of one h_pass launch on this rank: read + write of what the pass streams -- the rank's n/P x n f64
-        # shard, or (one rank, symmetric-storage path) the upper block triangle's 128 x 128 tiles of the symmetric H
+
+        def cls(name):
+            nn = p1[f"n_{name}_timed"] - p0[f"n_{name}_timed"]
+            tt = p1[f"t_{name}_ms"] - p0[f"t_{name}_ms"]
+            return nn, (tt / nn if nn else None)
+        (n_h, ms_h), (n_e, ms_e), (n_c, ms_c) = cls("hpass"), cls("eval"), cls("ctl")
+        (n_hr, ms_hr), (n_er, ms_er) = cls("hreduce"), cls("ereduce")
+        # algorithmic bytes of one update-pass launch on this rank: read + write of what the pass streams -- the rank's n/P x n f64
+        # shard, or (one rank, symmetric storage) the symmetric half: off-diagonal 128 x 128 tiles + the diagonal tiles' upper triangles
         mat = float(p1["matrix_bytes_per_pass"])
         alg_h = 2.0 * mat
         alg_q = mat
-        # launches that were predicated off (pipelined mode) finish in ~2 us; keep them out of the average
-        # An event / launch / event bracket reports the kernel plus a fixed launch / event cost.  It is NOT subtracted: measured
-        # against rocprofv3 on the same run the raw bracket is 2-3 us (4 %) above the profiler's kernel duration, so `achieved`
-        # below is slightly conservative; the empty-kernel calibration is reported next to it for the record.
-        h_launch_ms = t_h / max(n_h, 1)
+        # An event / launch / event bracket reports the kernel plus a fixed launch / event cost.  It is NOT subtracted: against
+        # rocprofv3 on the same run the raw bracket is 2-3 us above the profiler's kernel duration, so `achieved` below is slightly
+        # conservative; the empty-kernel calibration is reported next to it for the record.
         bracket_ms = ctx.event_bracket_overhead_ms(200)
-        ach = alg_h / (h_launch_ms * 1e-3) / 1e9 if n_h else None
+        ach = alg_h / (ms_h * 1e-3) / 1e9 if n_h else None
         sym_pass = world == 1 and mat < 8.0 * n * n
-        roofline = {"bound": "hbm", "kernel": ("sym_hpass_tile_kernel (rank-2 update + row and column dots of [y, g+] over the upper block triangle of H)"
-                                               if sym_pass else "h_pass_fused_kernel (fused rank-2 update + 2-RHS mat-vec over the rank's rows of H)"),
+        sym2 = bool(p1["path"] & 16)
+        kname = ("s2_hpass_kernel (pending rank-2 update in place + row and column sums of [y, g+] over the symmetric half of H; its "
+                 "prologue runs the solver's state machine)" if sym2 else
+                 "sym_hpass_tile_kernel (rank-2 update + row and column dots of [y, g+] over the upper block triangle of H)" if sym_pass else
+                 "h_pass_fused_kernel (fused rank-2 update + 2-RHS mat-vec over the rank's rows of H)")
+        roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                     "traffic": None,
+                    "traffic_source": None,
                     "achievable_note": "plain read+write streams reach 4.9-5.4 TB/s on this device (hipMemcpy D2D 5.0 TB/s; "
                                        "profiles/r01_c_bw_probe.txt); peak is the 8 TB/s HBM3E spec",
-                    "algorithmic_bytes_per_launch": alg_h, "avg_launch_ms": h_launch_ms, "launches_timed": n_h,
+                    "algorithmic_bytes_per_launch": alg_h, "avg_launch_ms": ms_h, "launches_timed": n_h,
+                    # the pass as the iteration pays for it: tile launch + its slot-reduction launch (symmetric storage only)
+                    "pass_with_reduce": ({"avg_ms": ms_h + ms_hr, "achieved": alg_h / ((ms_h + ms_hr) * 1e-3) / 1e9,
+                                          "frac": alg_h / ((ms_h + ms_hr) * 1e-3) / 1e9 / HBM_PEAK_GBS, "reduce_avg_launch_ms": ms_hr,
+                                          "reduce_launches_timed": n_hr} if (n_h and n_hr) else None),
                     # SURVEY.md 8(d) counts 16 n^2 / P bytes per H pass (full matrix read + written); the symmetric-storage path does
                     # the same pass on half of them, so its rate in full-matrix terms is higher than the bytes it really moves
-                    "full_matrix_equivalent_GBs": (16.0 * n * n / world) / (h_launch_ms * 1e-3) / 1e9 if n_h else None,
+                    "full_matrix_equivalent_GBs": (16.0 * n * n / world) / (ms_h * 1e-3) / 1e9 if n_h else None,
                     "event_bracket_fixed_overhead_ms_not_subtracted": bracket_ms,
-                    "quad_matvec": {"algorithmic_bytes_per_launch": alg_q, "avg_launch_ms": t_e / max(n_e, 1), "launches_timed": n_e,
-                                    "achieved": (alg_q / (t_e / max(n_e, 1) * 1e-3) / 1e9) if n_e else None},
-                    "ctl_step": {"avg_launch_ms": t_c / max(n_c, 1), "launches_timed": n_c},
+                    "quad_matvec": {"algorithmic_bytes_per_launch": alg_q, "avg_launch_ms": ms_e, "launches_timed": n_e,
+                                    "achieved": (alg_q / (ms_e * 1e-3) / 1e9) if n_e else None,
+                                    "accept_reduce_avg_launch_ms": ms_er, "accept_reduce_launches_timed": n_er},
+                    "ctl_step": {"avg_launch_ms": ms_c, "launches_timed": n_c,
+                                 "note": ("synchronous profiling pass only: in the timed (pipelined) region the state machine runs inside "
+                                          "the prologue of the streaming kernels, there is no control launch") if sym2 else None},
                     "note": "HIP events on the solver stream around every launch of a synchronous-mode pass over the same workload "
-                            "(raw brackets: 2-3 us above the rocprofv3 kernel durations of profiles/r01_g_kernel_stats_n4096.csv)"}
+                            "(raw brackets: 2-3 us above the rocprofv3 kernel durations; profiles/README.md names the CSV of this build)"}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                roofline["traffic"] = json.load(open(pmc)).get(f"n{n}_p{world}" + ("_sym" if sym_pass else ""), {}).get("h_pass_bytes_per_launch")
+                key = f"n{n}_p{world}" + ("_sym2" if sym2 else "_sym" if sym_pass else "")
+                roofline["traffic"] = json.load(open(pmc)).get(key, {}).get("h_pass_bytes_per_launch")
+                if roofline["traffic"] is not None:
+                    roofline["traffic_source"] = (f"profiles/pmc_traffic.json[{key}]: HBM bytes per launch from separate rocprofv3 --pmc "
+                                                  "FETCH_SIZE / WRITE_SIZE passes of this build (gfx950 x2 correction on FETCH_SIZE); an "
+                                                  "offline figure, not a counter read during this run")
             except Exception:  # noqa: BLE001
                 pass
 
     if rank == 0:
-        mat_bytes = float(st1["matrix_bytes_per_pass"])  # per rank: the row shard, or the upper block triangle (symmetric storage)
+        mat_bytes = float(solver.stats()["matrix_bytes_per_pass"])  # per rank: the row shard, or the symmetric half (symmetric storage)
         symmetric = world == 1 and mat_bytes < 8.0 * n * n
-        b_iter = world * (2.0 * mat_bytes + mat_bytes * (evals / steps))
+        b_iter = world * (h_bytes + obj_bytes) / steps  # counted: (passes + read-write passes) x bytes per pass + evaluations x bytes per pass
         out = {
             "metric": METRIC, "value": its, "unit": "iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -257,18 +309,28 @@ def main():
             "config": {"workload": f"BFGS + MoreThuente::default (max_iter_line_search 20), n={n} convex quadratic "
                                    f"(random SPD Q, kappa=1e3, seed 0x5EED0001), f64, {world}xMI355X"
                                    + ((", H and Q row-sharded, " + ("host-staged" if host_exchange else "RCCL") + " all-gather per pass") if world > 1 else "")
-                                   + (", symmetric storage: only the upper block triangle of H and Q is streamed" if symmetric else ""),
-                       "matrix_layout": "upper block triangle (128 x 128 tiles) of the symmetric H and Q" if symmetric else "full row-major, row-sharded",
+                                   + (", symmetric storage: only the symmetric half of H and Q is streamed" if symmetric else ""),
+                       "matrix_layout": ("symmetric half of H and Q: 128 x 128 tiles above the diagonal + the upper triangles of the diagonal tiles"
+                                         if symmetric else "full row-major, row-sharded"),
                        "n": n, "line_search": args.ls, "tol": 1e-10, "parallelism": f"row-shard x{world}",
                        "exchange": "none" if world == 1 else ("host-staged gloo (rehearsal)" if host_exchange else "rccl all-gather"),
                        **({"rccl_error": rccl_error} if rccl_error else {})},
+            "timing": {"regions": regions, "reported": "median region", "region_ms": [1e3 * t for t in region_s],
+                       "each_region": f"reset to (x0, H = I), {warmup} untimed iterations, then {steps} timed iterations",
+                       "qn_minimize_calls_in_region": acc["total_minimize_calls"],
+                       "per_call_fixed_ms": per_call_fixed_ms,
+                       "per_call_fixed_note": "median wall time of a qn_minimize call allowed 0 iterations (control block round trips + "
+                                              "launch pattern); it is inside every timed region once per call"},
             "iteration_accounting": {"oracle_calls_reference_sequence": calls, "oracle_evaluations_distinct": evals,
+                                     "evaluations_per_iteration": evals / steps, "oracle_calls_per_iteration": calls / steps,
+                                     "h_passes": acc["total_h_passes"],
                                      "restarts_after_convergence": restarts,
                                      "algorithmic_bytes_per_iteration": b_iter,
                                      "full_matrix_bytes_per_iteration_survey_8d": 16.0 * n * n + 8.0 * n * n * (evals / steps),
                                      "whole_iteration_hbm_frac": b_iter * its / (world * HBM_PEAK_GBS * 1e9),
                                      "h_bytes_counted": h_bytes, "objective_bytes_counted": obj_bytes,
-                                     "launches": st1["launches"] - st0["launches"], "host_syncs": st1["host_syncs"] - st0["host_syncs"]},
+                                     "launches": acc["launches"], "host_syncs": acc["host_syncs"],
+                                     "note": "counters are the solver's cumulative totals differenced around the median timed region"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

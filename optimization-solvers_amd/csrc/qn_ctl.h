@@ -78,7 +78,9 @@ struct QnCtl {
 
     // ---- fused fast path (qn_fused.hip.h): buffer toggles, on-the-fly direction, staged sums of the last evaluation ----
     int32_t fused, xc, sc, dir_mode, gd0_valid;
-    int32_t no_defer, _padd; // diagnostics: disable the deferred update
+    int32_t no_defer; // diagnostics: disable the deferred update
+    int32_t warm;     // this call continues the previous one on the same objective with nothing touched in between: the memo of the
+                      // evaluation at x_k and the lazily formed direction (have_cur_eval, have_dir) carry over (set by the host)
     int32_t defer_u; // the coefficients of the update in flight are not committed yet (QN_PH_REQ_HPASS_EVAL)
     // second-generation symmetric path (qn_sym2.hip.h): the machine runs in the prologue of every kernel
     int32_t sym2;     // this run uses it

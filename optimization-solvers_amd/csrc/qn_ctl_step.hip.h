@@ -54,7 +54,11 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
         switch (c.state) {
         case QN_ST_BEGIN: { // ls_solver.rs:74-76: only k is reset
             c.k = 0;
-            c.have_cur_eval = 0; c.have_dir = 0; c.last_valid = 0; c.gg_valid = 0;
+            // A fresh call evaluates the oracle at x_k and forms d = -H g from scratch (ls_solver.rs:79, bfgs.rs:47).  When it
+            // continues the previous call -- same immutable device objective, memoised oracle, state untouched -- both are already
+            // known: the last accepted evaluation IS f, g at x_k, and the direction is pending in its lazy form.
+            if (!c.warm) { c.have_cur_eval = 0; c.have_dir = 0; c.last_valid = 0; c.gg_valid = 0; }
+            else c.last_valid = 0;
             c.n_oracle_calls = 0; c.n_oracle_evals = 0; c.n_hpasses = 0; c.n_hpass_rw = 0; c.n_iterations = 0;
             c.status = -1;
             c.state = QN_ST_LOOP_TOP;

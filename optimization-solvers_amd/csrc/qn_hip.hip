@@ -639,6 +639,8 @@ struct qn_solver {
     // After a fused run the iterate and the pending update's vectors stay where the fused kernels keep them (X0[xc], S0[sc], UN);
     // they are copied back to the canonical buffers only when something other than the next fused run wants them.
     bool fused_live = false;
+    // the previous qn_minimize ended on the iteration cap of a fused, memoised run on `warm_obj`; nothing has touched the state since
+    const void* warm_obj = nullptr;
     int* newton_fail = nullptr;
     size_t newton_n64 = 0;
     std::vector<double> newton_hhost;
@@ -744,9 +746,22 @@ static int solver_alloc_sym2(qn_solver* s) {
             heap.back() = e;
             std::push_heap(heap.begin(), heap.end());
         };
+        // the first G items go to workgroups 0 .. G-1 in order (the kernels compute a workgroup's first item from its index:
+        // qn_s2_first_item); the rest to whoever has streamed least so far
+        int handed = 0;
+        auto hand = [&](int I, int J, double cost) {
+            if (handed < G) {
+                lists[handed].push_back((I << 16) | J);
+                for (auto& e : heap) if (-e.second == handed) e.first = -cost;
+                ++handed;
+                if (handed == G) std::make_heap(heap.begin(), heap.end());
+            } else {
+                give(I, J, cost);
+            }
+        };
         for (int I = 0; I < nb; ++I)
-            for (int J = I + 1; J < nb; ++J) give(I, J, 1.0);
-        for (int I = 0; I < nb; ++I) give(I, I, 0.5625);
+            for (int J = I + 1; J < nb; ++J) hand(I, J, 1.0);
+        for (int I = 0; I < nb; ++I) hand(I, I, 0.5625);
         size_t maxk = 0;
         for (int g = 0; g < G; ++g) maxk = std::max(maxk, lists[g].size());
         std::vector<int> items(maxk * (size_t)G, -1); // [k][g]: the workgroup's k-th item; -1 ends its list
@@ -902,6 +917,7 @@ extern "C" double qn_solver_tol(const qn_solver* s) { return s->tol; }
 
 // canonical buffers <- fused buffers (the lazy half of qn_minimize's export)
 static int fused_export(qn_solver* s) {
+    s->warm_obj = nullptr; // whoever asks for the canonical buffers may change them: the next call starts from scratch
     if (!s->fused_live) return QN_OK;
     qn_context* c = s->ctx;
     const QnCtl* h = s->hctl;
@@ -918,8 +934,9 @@ static int fused_export(qn_solver* s) {
 
 extern "C" int qn_solver_get_x(qn_solver* s, double* out) {
     HIPCHK(hipSetDevice(s->ctx->device));
-    QNCHK(fused_export(s));
-    HIPCHK(hipMemcpyAsync(out, s->V.x, s->n * sizeof(double), hipMemcpyDeviceToHost, s->ctx->stream));
+    // (a getter: read the iterate where it lives, do not disturb a run that may be continued)
+    const double* src = s->fused_live ? s->V.F.X0 + (size_t)s->hctl->xc * (size_t)s->T.n_pad : s->V.x;
+    HIPCHK(hipMemcpyAsync(out, src, s->n * sizeof(double), hipMemcpyDeviceToHost, s->ctx->stream));
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
     return QN_OK;
 }
@@ -978,7 +995,7 @@ extern "C" int qn_solver_reset(qn_solver* s, const double* x0_host) {
         s->h_lower_stale = false; s->h_diag_stale = false;
         s->h_nonsym = false;
     }
-    s->fused_live = false; // (whatever the fused buffers hold is dropped with the rest of the state)
+    s->fused_live = false; s->warm_obj = nullptr; // (whatever the fused buffers hold is dropped with the rest of the state)
     HIPCHK(hipMemsetAsync(s->vec_block, 0, 9 * (size_t)s->T.n_pad * sizeof(double), st));
     HIPCHK(hipMemcpyAsync(s->V.x, x0_host, s->n * sizeof(double), hipMemcpyHostToDevice, st));
     memset(s->hctl, 0, sizeof(QnCtl));
@@ -1664,7 +1681,10 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             }
             h->xc = 0; h->sc = 0;
         } // (else: a fused run left them there; xc / sc in the control block say which halves are current)
-        h->dir_mode = 0; h->gd0_valid = 0;
+        h->warm = (s->fused_live && s->warm_obj == (const void*)r.obj && h->memoize && h->pending && !ls_only) ? 1 : 0;
+        if (!h->warm) { h->dir_mode = 0; h->gd0_valid = 0; }
+    } else {
+        h->warm = 0;
     }
     h->phase = QN_PH_IDLE;
     h->status = -1;
@@ -1713,7 +1733,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 if (remaining < 1) remaining = 1;
                 // one period per iteration, one more for a run that has no direction yet (evaluation at x, direction pass), and
                 // a last evaluation launch whose prologue finds the iteration cap reached and writes DONE
-                const int64_t periods = std::min<int64_t>(remaining + 1, 256);
+                const int64_t periods = std::min<int64_t>(remaining + ((first && !h->warm) ? 1 : 0), 256);
                 first = false;
                 for (int64_t p = 0; p < periods; ++p) {
                     for (int e = 0; e < slots; ++e) QNCHK(s2_launch(r, QN_S2_EVAL));
@@ -1771,6 +1791,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     // triangle of H stays stale (ensure_full_h) until a getter, a setter or a run on another path asks for them.  A solve made
     // of several qn_minimize calls (warm restarts, a harness timing short calls) pays for neither.
     if (r.fused) s->fused_live = true;
+    s->warm_obj = (r.fused && status == QN_MAX_ITER_REACHED && h->memoize && h->have_cur_eval && h->have_dir) ? (const void*)r.obj : nullptr;
     if (ls->kind == QN_LS_MORETHUENTE_B) ls->t_max = h->mt_tmax; // morethuente_b.rs:201: the clipped t_max stays in the line search
     s->stats.iterations = h->n_iterations;
     s->stats.oracle_calls = h->n_oracle_calls;
@@ -1782,6 +1803,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     if (r.sym2) // diagonal tiles: wave w (rows 16 w ...) reads 64 - 8 w lanes of 16 bytes per row = 73 728 of the 131 072 bytes
         shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb - 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull + (uint64_t)s->sym_nb * 73728ull;
     s->stats.h_bytes = (h->n_hpasses + h->n_hpass_rw) * shard;
+    if (r.sym2) s->stats.h_bytes = 2 * h->n_hpasses * shard; // (its one branch-free body writes every pass back, pending update or not)
     s->stats.obj_bytes = (r.oracle_tpl == QN_ORACLE_QUAD) ? h->n_oracle_evals * (r.sym ? shard : full_shard) : 0;
     s->stats.matrix_bytes_per_pass = shard;
     s->stats.total_minimize_calls++;

@@ -84,6 +84,8 @@ struct QnS2Lds {
 };
 
 // ---- the state machine's view of a finished request: consume its sums, then run until the next request ----
+// (measured and dropped: the machine as ONE out-of-line function shared by the five kernels -- the calling convention costs the
+// tile kernels ~600 bytes of scratch per lane around the call: 10.9 k instead of 11.8 k it/s)
 __device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const QnVecs& V, const bool leader, double* scratch, const bool resume) {
     const int ph = c.phase;
     if (resume) { ctl_scalar_run(c, V, scratch, leader); return; } // (the machine had stopped for the x-trace copy)
@@ -270,6 +272,21 @@ __device__ __forceinline__ double qn_lane_bcast(const double v, const int l) {
     return __hiloint2double(hi, lo);
 }
 
+// The first item of workgroup g needs no load: the host hands the first G items out in order -- the off-diagonal tiles row-major
+// over (I, J > I), then the diagonal ones -- so it follows from g alone.
+__device__ __forceinline__ int qn_s2_first_item(int g, int nb) {
+    const int noff = nb * (nb - 1) / 2;
+    if (g >= noff) return ((g - noff) << 16) | (g - noff);
+    // row I starts at t(I) = I (nb - 1) - I (I - 1) / 2
+    const double bq = 2.0 * nb - 1.0;
+    int i = (int)((bq - sqrt(bq * bq - 8.0 * (double)g)) * 0.5);
+    if (i < 0) i = 0;
+    if (i > nb - 2) i = nb - 2;
+    while (i > 0 && i * (nb - 1) - i * (i - 1) / 2 > g) --i;
+    while ((i + 1) * (nb - 1) - (i + 1) * i / 2 <= g) ++i;
+    return (i << 16) | (i + 1 + (g - (i * (nb - 1) - i * (i - 1) / 2)));
+}
+
 // Diagonal items without a single per-element test.  Wave w owns rows 16 w .. 16 w + 15 of the tile; lane l owns columns 2 l, 2 l + 1.
 //   * lanes left of the wave's 16 x 16 diagonal sub-block (l < 8 w) have nothing to do: they are CLONES of lane 8 w -- same
 //     load address (one request, no extra traffic), same column-side update vectors, hence the same stored values -- with
@@ -312,9 +329,9 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
     QN_S2_STAMP(0);
-    // A wave's loads return in order.  So: the first item (the window's addresses need it) is requested first, the control
-    // block and the partial sums next -- the prologue then never waits for the 128 KB window behind them -- and the window last.
-    int ij = a.item_ij[blockIdx.x];
+    // A wave's loads return in order.  So: the control block and the partial sums are requested first -- the prologue then never
+    // waits for the 128 KB window behind them -- and the window last (its first item is a function of blockIdx: no load).
+    int ij = qn_s2_first_item(blockIdx.x, a.nb);
     QnS2Pro P;
     qn_s2_pro_issue<QN_S2_EVAL>(a, P);
     int I = ij >> 16, J = ij & 0xffff;
@@ -554,7 +571,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     __shared__ double colred[QN_S2_WAVES][2][QN_TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
-    int ij = a.item_ij[blockIdx.x]; // (load order: first item, control block and partial sums, window -- see s2_eval_kernel)
+    int ij = qn_s2_first_item(blockIdx.x, a.nb); // (load order: control block and partial sums, then the window -- see s2_eval_kernel)
     QnS2Pro P;
     qn_s2_pro_issue<QN_S2_HTILE>(a, P);
     int I = ij >> 16, J = ij & 0xffff;

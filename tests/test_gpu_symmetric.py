@@ -103,6 +103,50 @@ def test_warm_restart_continues_on_the_mirrored_hessian(qn, qo):
     assert np.linalg.norm(three.x() - one.x()) <= 1e-9 * np.linalg.norm(one.x())
 
 
+@pytest.mark.parametrize("tiling", [None, (-4, 0), (-3, 0)])
+def test_continued_calls_are_one_run_bit_for_bit(qn, qo, tiling):
+    """minimize resets only k (ls_solver.rs:74): a second call on the same device objective, with nothing touched in between,
+    continues the first one -- the memoised evaluation at x_k and the lazily formed direction carry over, so two calls of 10
+    iterations ARE one call of 20, bit for bit, and cost no extra evaluation or pass over H.  Touching the state (set_x) or
+    changing the objective makes the next call start from scratch: same iterates to rounding, one more evaluation."""
+    n = 1024
+    q, b, x0, _ = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+    one, _ = _run(qn, "bfgs", "mt", obj, x0, 20, tiling=tiling)
+    two = qn.BFGS(1e-10, x0)
+    if tiling:
+        two.set_tiling(*tiling)
+    evals = passes = 0
+    for _ in range(2):
+        with pytest.raises(qn.MaxIterReached):
+            two.minimize(qn.MoreThuente(), obj, 10, 20)
+        evals += two.stats()["oracle_evals"]
+        passes += two.stats()["h_passes"]
+    assert np.array_equal(one.x(), two.x())
+    assert (evals, passes) == (one.stats()["oracle_evals"], one.stats()["h_passes"])
+    assert np.array_equal(one.approx_inv_hessian(), two.approx_inv_hessian())
+    three = qn.BFGS(1e-10, x0)
+    if tiling:
+        three.set_tiling(*tiling)
+    with pytest.raises(qn.MaxIterReached):
+        three.minimize(qn.MoreThuente(), obj, 10, 20)
+    three.set_x(three.x())  # same values, but the solver cannot know that
+    with pytest.raises(qn.MaxIterReached):
+        three.minimize(qn.MoreThuente(), obj, 10, 20)
+    assert three.stats()["oracle_evals"] == two.stats()["oracle_evals"] + 1 and three.stats()["h_passes"] == two.stats()["h_passes"] + 1
+    assert np.linalg.norm(three.x() - one.x()) <= 1e-9 * np.linalg.norm(one.x())
+    four = qn.BFGS(1e-10, x0)
+    if tiling:
+        four.set_tiling(*tiling)
+    with pytest.raises(qn.MaxIterReached):
+        four.minimize(qn.MoreThuente(), obj, 10, 20)
+    obj2 = qn.Quadratic(q, b)  # an equal objective is still another oracle
+    with pytest.raises(qn.MaxIterReached):
+        four.minimize(qn.MoreThuente(), obj2, 10, 20)
+    assert four.stats()["oracle_evals"] == two.stats()["oracle_evals"] + 1
+    assert np.linalg.norm(four.x() - one.x()) <= 1e-9 * np.linalg.norm(one.x())
+
+
 def test_non_symmetric_user_hessian_uses_the_full_matrix(qn, qo):
     n = 1024
     q, b, x0, _ = P.synth_problem(qo, n)
