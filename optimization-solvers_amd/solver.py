@@ -184,6 +184,9 @@ class _LineSearch:
             o.kind = A.ORACLE_OBJECTIVE
             o.objective = oracle.h
             o.memoize = 1 if memoize is None else int(memoize)
+        elif isinstance(oracle, DeviceClosure):
+            o.kind, o.device_fn, o.device_user = A.ORACLE_DEVICE_FN, oracle.fn, oracle.user
+            o.memoize = 0 if memoize is None else int(memoize)
         else:
             def tramp(_u, xp, nn, fp, gp):
                 try:
@@ -323,6 +326,24 @@ class Objective:
             pass
 
 
+class DeviceClosure:
+    """`qn_oracle.kind = QN_ORACLE_DEVICE_FN` (include/qn_hip.h): the caller's own objective, already on the GPU.  `fn` is the
+    address of a `qn_device_oracle_fn` -- int fn(void* user, void* stream, const double* x_dev, size_t n, double* f_dev,
+    double* g_dev) -- that ENQUEUES its work on `stream`; the solver never copies x, f or g to the host on this path.  It stands
+    where the reference takes `impl FnMut(&DVector<f64>) -> FuncEvalMultivariate` (ls_solver.rs:69); like a host closure it is
+    called in the reference's order unless `solver.memoize = 1` declares it a pure function of x."""
+
+    def __init__(self, fn, user=None, keep=None):
+        self.fn = C.cast(fn, C.c_void_p)
+        self.user = C.c_void_p(user) if not isinstance(user, C.c_void_p) else user
+        self.keep = keep  # whatever owns `fn` / `user` (a ctypes.CDLL, a create/destroy pair): kept alive with the closure
+
+    @classmethod
+    def from_library(cls, path, symbol, user=None):
+        dll = C.CDLL(path)
+        return cls(getattr(dll, symbol), user, keep=dll)
+
+
 class Quadratic(Objective):
     """f = 1/2 x'Qx - b'x on the device."""
 
@@ -398,6 +419,9 @@ class _SolverBase:
             o.kind = A.ORACLE_OBJECTIVE
             o.objective = oracle.h
             o.memoize = 1 if self.memoize is None else int(self.memoize)
+        elif isinstance(oracle, DeviceClosure):
+            o.kind, o.device_fn, o.device_user = A.ORACLE_DEVICE_FN, oracle.fn, oracle.user
+            o.memoize = 0 if self.memoize is None else int(self.memoize)  # a closure: the reference's call sequence by default
         else:
             n = self.n
             err = []
@@ -440,7 +464,7 @@ class _SolverBase:
             keep.append(cb)
         status = L.qn_minimize(self.h, C.byref(line_search.s), C.byref(o), max_iter_solver, max_iter_line_search,
                                C.cast(cb, C.c_void_p) if cb else None, None)
-        if not isinstance(oracle, Objective) and err:
+        if not isinstance(oracle, (Objective, DeviceClosure)) and err:
             raise err[0]
         _check(status)
 
