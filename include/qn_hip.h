@@ -202,6 +202,13 @@ int qn_solver_decrement_squared(qn_solver* s, double* out, int* is_some); /* New
  * rows; rows of other ranks are left untouched unless `all_ranks` (then an all-gather fills everything). */
 int qn_solver_get_inv_hessian(qn_solver* s, double* out_colmajor_host, int all_ranks);
 int qn_solver_set_inv_hessian(qn_solver* s, const double* h_colmajor_host);
+/* ComputeDirection::compute_direction on its own (bfgs.rs:42-49, dfp.rs:42-49: -H g; gradient_descent.rs:24-30: -g), for a
+ * binding that implements the trait; qn_minimize computes its directions on the device and never calls this. */
+int qn_solver_compute_direction(qn_solver* s, const double* g_host, double* d_host);
+/* The inverse-Hessian half of the `update_next_iterate` hook on its own (bfgs.rs:92-130, dfp.rs:92-118), again for a binding
+ * that implements LineSearchSolver hook by hook: records s_norm / y_norm, skips the update when either is below tol
+ * (bfgs.rs:103-109), else applies the BFGS / DFP secant update to the device-resident matrix. */
+int qn_solver_secant_update(qn_solver* s, const double* s_host, const double* y_host);
 
 /* ---- build-side instrumentation (not in the reference) ---- */
 #define QN_TRACE_LS_MODIFIED (1 << 30)

@@ -114,6 +114,8 @@ SYMBOLS = [
     ("qn_solver_decrement_squared", C.c_int, [C.c_void_p, dp, C.POINTER(C.c_int)]),
     ("qn_solver_get_inv_hessian", C.c_int, [C.c_void_p, dp, C.c_int]),
     ("qn_solver_set_inv_hessian", C.c_int, [C.c_void_p, dp]),
+    ("qn_solver_compute_direction", C.c_int, [C.c_void_p, dp, dp]),
+    ("qn_solver_secant_update", C.c_int, [C.c_void_p, dp, dp]),
     ("qn_solver_set_trace", C.c_int, [C.c_void_p, C.c_size_t, C.c_int]),
     ("qn_solver_get_trace", C.c_int, [C.c_void_p, C.POINTER(TraceRec), C.c_size_t, C.POINTER(C.c_size_t), dp]),
     ("qn_solver_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),

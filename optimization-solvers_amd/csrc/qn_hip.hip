@@ -1130,6 +1130,84 @@ extern "C" int qn_solver_get_inv_hessian(qn_solver* s, double* out, int all_rank
     return QN_OK;
 }
 
+// ComputeDirection::compute_direction (bfgs.rs:42-49, dfp.rs:42-49: `-&self.approx_inv_hessian * eval.g()`;
+// gradient_descent.rs:24-30: `-eval.g()`) on its own, for a binding that implements the trait: g goes up, d comes down.
+extern "C" int qn_solver_compute_direction(qn_solver* s, const double* g_host, double* d_host) {
+    if (!s || !g_host || !d_host) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
+    if (s->method == QN_NEWTON) return fail(QN_ERROR_INPUT_PARAMS, "the Newton direction needs the oracle's Hessian: use qn_minimize");
+    const size_t n = s->n;
+    if (!s->H) { // gradient descent
+        for (size_t i = 0; i < n; ++i) d_host[i] = -g_host[i];
+        return QN_OK;
+    }
+    qn_context* c = s->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    QNCHK(flush_pending(s)); // the lazy update of the last iteration, and whole rows of H
+    const size_t np = s->T.n_pad, rpr = s->T.rpr;
+    double* buf = nullptr; // [g (np) | H g (np)]
+    HIPCHK(hipMalloc((void**)&buf, 2 * np * sizeof(double)));
+    HIPCHK(hipMemsetAsync(buf, 0, 2 * np * sizeof(double), c->stream));
+    HIPCHK(hipMemcpyAsync(buf, g_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int st = qn_gemv(c, s->H, np, rpr, n, buf, buf + np + (size_t)s->T.row_off);
+    if (st == QN_OK) st = exchange(c, buf + np, rpr);
+    if (st == QN_OK) {
+        hipError_t e = hipMemcpyAsync(d_host, buf + np, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, hipGetErrorString(e));
+    }
+    (void)hipFree(buf);
+    if (st != QN_OK) return st;
+    for (size_t i = 0; i < n; ++i) d_host[i] = -d_host[i];
+    return QN_OK;
+}
+
+// The second half of the `update_next_iterate` hook (bfgs.rs:92-130, dfp.rs:92-118) on its own, for a binding that implements
+// LineSearchSolver hook by hook: records ||s|| and ||y|| (s_norm / y_norm), returns early when either is below tol
+// (bfgs.rs:103-109), otherwise applies the secant update to the device-resident inverse Hessian as the rank-2 form of DESIGN.md 4
+// (u = H y; BFGS: rho = 1/y's, H += -rho (su' + us') + (rho^2 y'u + rho) ss'; DFP: H += ss'/y's - uu'/y'u).
+extern "C" int qn_solver_secant_update(qn_solver* s, const double* s_host, const double* y_host) {
+    if (!s || !s_host || !y_host) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
+    if ((s->method != QN_BFGS && s->method != QN_DFP) || s->bounded)
+        return fail(QN_ERROR_INPUT_PARAMS, "secant update: BFGS and DFP only");
+    qn_context* c = s->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    QNCHK(flush_pending(s));
+    const size_t n = s->n, np = s->T.n_pad, rpr = s->T.rpr;
+    double ss = 0.0, yy = 0.0, ys = 0.0;
+    for (size_t i = 0; i < n; ++i) { ss += s_host[i] * s_host[i]; yy += y_host[i] * y_host[i]; ys += y_host[i] * s_host[i]; }
+    QnCtl* h = s->hctl;
+    h->has_s_norm = 1; h->s_norm = std::sqrt(ss);
+    h->has_y_norm = 1; h->y_norm = std::sqrt(yy);
+    h->have_dir = 0; h->have_cur_eval = 0;
+    QNCHK(poke_ctl(s));
+    if (h->s_norm < s->tol || h->y_norm < s->tol) return QN_OK;
+    double* buf = nullptr; // [s | y | u = H y], n_pad each
+    HIPCHK(hipMalloc((void**)&buf, 3 * np * sizeof(double)));
+    std::vector<double> u(n);
+    int st = QN_OK;
+    auto hip_ok = [&](hipError_t e) { if (e != hipSuccess && st == QN_OK) st = fail(QN_ABNORMAL_TERMINATION, hipGetErrorString(e)); return e == hipSuccess; };
+    hip_ok(hipMemsetAsync(buf, 0, 3 * np * sizeof(double), c->stream));
+    hip_ok(hipMemcpyAsync(buf, s_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hip_ok(hipMemcpyAsync(buf + np, y_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (st == QN_OK) st = qn_gemv(c, s->H, np, rpr, n, buf + np, buf + 2 * np + (size_t)s->T.row_off);
+    if (st == QN_OK) st = exchange(c, buf + 2 * np, rpr);
+    if (st == QN_OK) {
+        hip_ok(hipMemcpyAsync(u.data(), buf + 2 * np, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        hip_ok(hipStreamSynchronize(c->stream));
+    }
+    if (st == QN_OK) {
+        double yu = 0.0;
+        for (size_t i = 0; i < n; ++i) yu += y_host[i] * u[i];
+        double c_ss, c_su, c_uu;
+        if (s->method == QN_BFGS) { const double rho = 1.0 / ys; c_su = -rho; c_ss = rho * rho * yu + rho; c_uu = 0.0; }
+        else { c_ss = 1.0 / ys; c_su = 0.0; c_uu = -1.0 / yu; }
+        st = qn_rank2_update(c, s->H, np, (size_t)s->T.row_off, rpr, n, buf, buf + 2 * np, c_ss, c_su, c_uu);
+        if (st == QN_OK) hip_ok(hipStreamSynchronize(c->stream));
+    }
+    (void)hipFree(buf);
+    return st;
+}
+
 extern "C" int qn_solver_set_inv_hessian(qn_solver* s, const double* h) {
     if (!s->H) return fail(QN_ERROR_INPUT_PARAMS, "gradient descent keeps no inverse Hessian");
     HIPCHK(hipSetDevice(s->ctx->device));

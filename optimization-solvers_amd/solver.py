@@ -525,6 +525,22 @@ class _SolverBase:
         _check(A.lib().qn_solver_get_inv_hessian(self.h, out.ctypes.data_as(A.dp), 1 if all_ranks else 0))
         return np.ascontiguousarray(out)
 
+    def compute_direction(self, eval_x_k):
+        """ComputeDirection::compute_direction (ls_solver.rs:3-8; bfgs.rs:42-49, dfp.rs:42-49, gradient_descent.rs:24-30)"""
+        g = _f64(eval_x_k.g() if isinstance(eval_x_k, FuncEvalMultivariate) else eval_x_k[1])
+        if g.size != self.n:
+            raise ErrorInputParams("gradient has the wrong dimension")
+        d = np.empty(self.n)
+        _check(A.lib().qn_solver_compute_direction(self.h, g.ctypes.data_as(A.dp), d.ctypes.data_as(A.dp)))
+        return d
+
+    def secant_update(self, s, y):
+        """the inverse-Hessian half of `update_next_iterate` (bfgs.rs:92-130, dfp.rs:92-118) on its own"""
+        s, y = _f64(s), _f64(y)
+        if s.size != self.n or y.size != self.n:
+            raise ErrorInputParams("s / y have the wrong dimension")
+        _check(A.lib().qn_solver_secant_update(self.h, s.ctypes.data_as(A.dp), y.ctypes.data_as(A.dp)))
+
     def set_approx_inv_hessian(self, h):
         a = np.asfortranarray(h, dtype=np.float64)
         _check(A.lib().qn_solver_set_inv_hessian(self.h, a.ctypes.data_as(A.dp)))
