@@ -641,7 +641,11 @@ struct qn_solver {
     bool fused_live = false;
     // the previous qn_minimize ended on the iteration cap of a fused, memoised run on `warm_obj`; nothing has touched the state since
     const void* warm_obj = nullptr;
-    int* newton_fail = nullptr;
+    int* newton_fail = nullptr; // [0]: the factorisation met a bad pivot, [1]: the staged Hessian is not symmetric bit for bit
+    int *newton_piv = nullptr, *newton_perm = nullptr; // LU fallback (qn_lu.hip.h): pivot rows, row permutation
+    std::vector<int> newton_piv_host;
+    uint64_t newton_lu_runs = 0, newton_chol_runs = 0;
+    int newton_force_lu = 0; // diagnostics (qn_solver_set_tiling rows = -5): skip the Cholesky attempt
     size_t newton_n64 = 0;
     std::vector<double> newton_hhost;
     double* bounds_block = nullptr; // lb, ub (solver), llb, lub (bounded line search): 4 n_pad vectors
@@ -841,7 +845,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     for (auto& e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
-    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail);
+    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->s2_items); (void)hipFree(s->s2_first); (void)hipFree(s->s2_wgE); (void)hipFree(s->s2_wgH); (void)hipFree(s->s2_rp); (void)hipFree(s->s2_ctl);
@@ -893,6 +897,7 @@ extern "C" int qn_solver_set_sync_mode(qn_solver* s, int sync) { s->sync_mode = 
 extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits) {
     if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; }
     if (rows_per_block == -3) { s->no_sym = 1; rows_per_block = 0; }   // diagnostics: fused row kernels on the full matrices
+    if (rows_per_block == -5) { s->newton_force_lu = 1; return QN_OK; } // diagnostics: Newton by pivoted LU even for an SPD Hessian
     if (rows_per_block == -4) { s->no_sym2 = 1; rows_per_block = 0; }  // diagnostics: first-generation symmetric tile kernels (8 launches per iteration)
     if (rows_per_block == -2) { s->no_defer = 1; rows_per_block = 0; } // diagnostics: fused kernels, update step not deferred // diagnostics: -1 selects the generic (non-fused) kernels
     if (rows_per_block != 0 && rows_per_block != 2 && rows_per_block != 4 && rows_per_block != 8 && rows_per_block != 16)
@@ -1250,8 +1255,11 @@ static int newton_alloc(qn_solver* s) {
     if (s->newton_big) { // inverse blocks of width 128, 256, 512, the transposed 512 ones, and the product scratch
         QNCHK(dev_alloc_zero(&s->newton_inv2, n64 * (128 + 256 + 512 + 512 + 256), st));
     }
-    HIPCHK(hipMalloc((void**)&s->newton_fail, sizeof(int)));
-    HIPCHK(hipMemsetAsync(s->newton_fail, 0, sizeof(int), st));
+    HIPCHK(hipMalloc((void**)&s->newton_fail, 2 * sizeof(int)));
+    HIPCHK(hipMemsetAsync(s->newton_fail, 0, 2 * sizeof(int), st));
+    HIPCHK(hipMalloc((void**)&s->newton_piv, n64 * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&s->newton_perm, n64 * sizeof(int)));
+    s->newton_piv_host.resize(n64);
     s->V.nfail = s->newton_fail;
     return QN_OK;
 }
@@ -1574,6 +1582,73 @@ static int enqueue_hpass_req(Run& r) {
     return QN_OK;
 }
 
+// Pivoted LU of the staged Hessian and the two solves (qn_lu.hip.h); leaves d in V.d, z = H^-1 d in V.s, and newton_fail[0] = 1
+// when a pivot column is exactly zero (then QN_ST_AFTER_NEWTON takes -g, newton/mod.rs:43-46).
+static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
+    hipStream_t st = s->ctx->stream;
+    const int n = (int)s->n, n64 = (int)s->newton_n64;
+    const int nlu = (n + QN_NB - 1) / QN_NB * QN_NB; // the factorisation works on whole 64-blocks; identity padding
+    const size_t ld = s->newton_n64;
+    double* W = s->newton_w;
+    int* flag = s->newton_fail;
+    s->newton_lu_runs++;
+    HIPCHK(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
+    hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, W, ld, n, n64, hsrc, ld_src); // both triangles
+    uint64_t launches = 1;
+    for (int p0 = 0; p0 < nlu; p0 += QN_NB) {
+        for (int k = p0; k < p0 + QN_NB; ++k) {
+            hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(1024), 0, st, W, ld, k, p0, nlu, s->newton_piv, flag);
+            const int below = nlu - k - 1;
+            if (below > 0)
+                hipLaunchKernelGGL(lu_col_step_kernel, dim3(std::min(1024, (below + 31) / 32)), dim3(256), 0, st, W, ld, k, p0, nlu, flag);
+            launches += 2;
+        }
+        const int right = nlu - p0 - QN_NB;
+        if (nlu > QN_NB)
+            hipLaunchKernelGGL(lu_swap_rows_kernel, dim3(std::min(256, (nlu + 255) / 256)), dim3(256), 0, st, W, ld, p0, nlu, s->newton_piv, flag);
+        if (right > 0) {
+            hipLaunchKernelGGL(lu_trsm_kernel, dim3((right + 255) / 256), dim3(256), 0, st, W, ld, p0, nlu, flag);
+            hipLaunchKernelGGL(lu_gemm_kernel, dim3(right / QN_NB, right / QN_NB), dim3(256), 0, st, W, ld, p0, flag);
+            launches += 2;
+        }
+        launches++;
+    }
+    HIPCHK(hipGetLastError());
+    // row permutation: the swaps replayed on the identity (host; this path synchronises per Newton iteration anyway)
+    int lu_failed = 0;
+    HIPCHK(hipMemcpyAsync(s->newton_piv_host.data(), s->newton_piv, (size_t)nlu * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&lu_failed, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    s->stats.host_syncs++;
+    s->stats.launches += launches;
+    if (lu_failed) return QN_OK; // singular: the control kernel falls back to -g
+    std::vector<int> perm((size_t)nlu);
+    for (int i = 0; i < nlu; ++i) perm[i] = i;
+    for (int k = 0; k < nlu; ++k) std::swap(perm[k], perm[s->newton_piv_host[k]]);
+    HIPCHK(hipMemcpyAsync(s->newton_perm, perm.data(), (size_t)nlu * sizeof(int), hipMemcpyHostToDevice, st));
+    double* x1 = s->newton_x;
+    double* x2 = s->newton_x + n64;
+    const dim3 vg(std::min(1024, (n64 + 255) / 256)), vb(256);
+    auto solve = [&](double* x, double* tmp) { // x <- U^-1 L^-1 x (x already permuted); tmp: scratch
+        for (int k0 = 0; k0 < nlu; k0 += QN_NB) {
+            const int below = nlu - k0 - QN_NB;
+            hipLaunchKernelGGL(lu_fwd_step_kernel, dim3(std::max(1, std::min(256, (below + 3) / 4))), dim3(256), 0, st, W, ld, k0, nlu, x, tmp);
+        }
+        for (int k0 = nlu - QN_NB; k0 >= 0; k0 -= QN_NB)
+            hipLaunchKernelGGL(lu_bwd_step_kernel, dim3(std::max(1, std::min(256, (k0 + 3) / 4))), dim3(256), 0, st, W, ld, k0, tmp, x);
+    };
+    hipLaunchKernelGGL(lu_vec_perm_kernel, vg, vb, 0, st, x1, s->V.g, s->newton_perm, n, nlu, -1.0); // P (-g)
+    solve(x1, x2);
+    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.d, x1, n, s->T.n_pad, 1.0); // d = -(H^-1 g)
+    hipLaunchKernelGGL(lu_vec_perm_kernel, vg, vb, 0, st, x2, s->V.d, s->newton_perm, n, nlu, 1.0); // P d
+    solve(x2, x1);
+    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.s, x2, n, s->T.n_pad, 1.0); // z = H^-1 d
+    HIPCHK(hipGetLastError());
+    s->stats.launches += 4 + 4 * (uint64_t)(nlu / QN_NB);
+    HIPCHK(hipStreamSynchronize(st)); // `perm` is a local
+    return QN_OK;
+}
+
 static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
     qn_context* c = s->ctx;
     hipStream_t st = c->stream;
@@ -1583,7 +1658,8 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
     // the Hessian at x_k: a device objective's own matrix, or the host closure's (uploaded)
     const double* hsrc = nullptr;
     size_t ld_src = 0;
-    if (obj) { hsrc = obj->Q; ld_src = (size_t)obj->T.n_pad; }
+    bool symmetric = true; // the Cholesky path reads the lower triangle only: it needs H == H' bit for bit
+    if (obj) { hsrc = obj->Q; ld_src = (size_t)obj->T.n_pad; symmetric = obj->q_symmetric; }
     else {
         if (!s->newton_hsrc) HIPCHK(hipMalloc((void**)&s->newton_hsrc, (size_t)n * n * sizeof(double)));
         s->newton_hhost.resize((size_t)n * n * 2);
@@ -1593,16 +1669,21 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
         double* hr = s->newton_hhost.data() + (size_t)n * n; // row-major for the device
         if (o->host_hessian_fn(o->host_user, s->hx, s->n, hc) != 0) return fail(QN_ABNORMAL_TERMINATION, "host Hessian callback failed");
         for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) hr[(size_t)i * n + j] = hc[i + (size_t)j * n];
+            for (int j = 0; j < n; ++j) {
+                hr[(size_t)i * n + j] = hc[i + (size_t)j * n];
+                if (j > i && hc[i + (size_t)j * n] != hc[j + (size_t)i * n]) symmetric = false;
+            }
         HIPCHK(hipMemcpyAsync(s->newton_hsrc, hr, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, st));
         hsrc = s->newton_hsrc; ld_src = (size_t)n;
     }
-    HIPCHK(hipMemsetAsync(s->newton_fail, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(s->newton_fail, 0, 2 * sizeof(int), st));
     if (s->hctl->small_n) { // reference-order arithmetic, one thread
         hipLaunchKernelGGL(newton_small_kernel, dim3(1), dim3(64), 0, st, hsrc, ld_src, n, s->V.g, s->V.d, s->V.s, s->newton_fail);
         HIPCHK(hipGetLastError());
         return QN_OK;
     }
+    if (!symmetric || s->newton_force_lu) return enqueue_newton_lu(s, hsrc, ld_src);
+    s->newton_chol_runs++;
     hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, s->newton_w, ld, n, n64, hsrc, ld_src);
     // blocked right-looking Cholesky, lower triangle in place.  Outer blocks of 256 columns: each 64-column panel is
     // factorised and applied to the REST OF ITS OUTER BLOCK only; the trailing matrix then takes one depth-256 update.
@@ -1641,6 +1722,14 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
     hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.s, x1, n, s->T.n_pad, 1.0);
     HIPCHK(hipGetLastError());
     s->stats.launches += 4 + (s->newton_big ? 0 : 4 * (uint64_t)(n64 / QN_NB));
+    // Not positive definite?  The reference's LU inverts any non-singular matrix (newton/mod.rs:36-41): take the pivoted-LU path.
+    // (The flag is read here, after everything was enqueued, so the convex case keeps its launch pipeline; the caller
+    // synchronises right after this function anyway.)
+    int chol_failed = 0;
+    HIPCHK(hipMemcpyAsync(&chol_failed, s->newton_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    s->stats.host_syncs++;
+    if (chol_failed) return enqueue_newton_lu(s, hsrc, ld_src);
     return QN_OK;
 }
 

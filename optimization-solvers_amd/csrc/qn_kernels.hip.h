@@ -722,6 +722,7 @@ __global__ void lse_finish_kernel(const QnLseArgs a) {
 #include "qn_fused.hip.h"
 #include "qn_sym.hip.h"
 #include "qn_newton.hip.h"
+#include "qn_lu.hip.h"
 #include "qn_ctl_step.hip.h"
 #include "qn_sym2.hip.h"
 

@@ -12,11 +12,28 @@ reference's own tests:
 
 Everything numeric happens in libqn_hip.so on the GPU; this file only marshals.
 """
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
 from . import _abi as A
+
+# Every live handle, so that interpreter exit can release them in dependency order (solvers and objectives before their
+# context) instead of whatever order module teardown picks -- a solver destroyed after its context would free device memory
+# through a dead stream.
+_live = {"solver": weakref.WeakSet(), "objective": weakref.WeakSet(), "context": weakref.WeakSet()}
+
+
+@atexit.register
+def _close_all():
+    for kind in ("solver", "objective", "context"):
+        for obj in list(_live[kind]):
+            try:
+                obj.close()
+            except Exception:  # noqa: BLE001
+                pass
 
 
 class SolverError(Exception):
@@ -119,6 +136,7 @@ class Context:
             buf = C.create_string_buffer(bytes(unique_id), A.UNIQUE_ID_BYTES)
             _check(L.qn_context_create_sharded(device, rank, world, buf, C.byref(self.h)))
         self.rank, self.world, self.device = rank, world, device
+        _live["context"].add(self)
 
     @staticmethod
     def unique_id():
@@ -301,6 +319,7 @@ class Objective:
 
     def __init__(self, ctx, handle, n):
         self.ctx, self.h, self.n = ctx, handle, n
+        _live["objective"].add(self)
 
     def __call__(self, x):
         x = _f64(x)
@@ -389,6 +408,7 @@ class _SolverBase:
         _check(A.lib().qn_solver_create(self.ctx.h, self.METHOD, tol, _dp(x0), x0.size, C.byref(self.h)))
         self.memoize = None  # None: 1 for device objectives, 0 for host closures
         self._trace_cap = 0
+        _live["solver"].add(self)
 
     @classmethod
     def new(cls, tol, x0, ctx=None):

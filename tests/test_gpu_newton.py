@@ -122,3 +122,151 @@ def test_config4_newton_n8192(qn, qo):
     q = qo.synth_rows(n, 0, n, P.SEED, diag, nthreads=qo.max_threads())
     xstar = np.linalg.solve(q, b)
     assert np.linalg.norm(xs[0] - xstar) <= 1e-9 * np.linalg.norm(xstar)
+
+
+# ---- Hessians that are not symmetric positive definite: the reference inverts them (LU), it does not reject them ----
+def _double_well_chain(n, seed=4, c=0.05):
+    """f = sum 1/4 (x_i^2 - a_i)^2 + c/2 sum (x_{i+1} - x_i)^2: the Hessian diag(3 x^2 - a) + c * tridiag(-1, 2, -1) is indefinite
+    wherever some |x_i| < sqrt(a_i / 3).  The start puts a third of the coordinates deep inside the concave region and the rest
+    well outside it, so the spectrum splits into [-2, -0.3] and [2, 6]: indefinite AND well conditioned (the comparison with the
+    oracle is then a tolerance-level statement, not a conditioning lottery)."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(0.5, 2.0, n)
+    x0 = rng.uniform(1.2, 1.5, n) * rng.choice([-1.0, 1.0], n)
+    x0[::3] = rng.uniform(-0.1, 0.1, x0[::3].size)
+
+    def fn(x):
+        w = x * x - a
+        d = np.diff(x)
+        g = x * w
+        g[:-1] -= c * d
+        g[1:] += c * d
+        return 0.25 * np.sum(w * w) + 0.5 * c * np.sum(d * d), g
+
+    def hess(x):
+        h = np.diag(3.0 * x * x - a)
+        lap = 2.0 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1)
+        lap[0, 0] = lap[-1, -1] = 1.0
+        return h + c * lap
+    return fn, hess, x0
+
+
+def _newton_pair(qn, qo, fn, hess, x0, ls_gpu, ls_ref, iters, tol=1e-10, force_lu=False):
+    ref = qo.Solver(qo.NEWTON, tol, x0)
+    ref.set_hessian(hess)
+    st_ref = ref.minimize(ls_ref, qo.PyOracle(fn), iters, 20, trace_cap=iters, trace_x=True)
+    s = qn.Newton(tol, x0)
+    if force_lu:
+        s.set_tiling(-5, 0)
+    s.set_trace(iters, with_x=True)
+    st = qo.OK
+    try:
+        s.minimize(ls_gpu, lambda x: qn.FuncEvalMultivariate(*fn(x)).with_hessian(hess(x)), iters, 20)
+    except qn.MaxIterReached:
+        st = qo.MAX_ITER_REACHED
+    return s, st, ref, st_ref
+
+
+@pytest.mark.parametrize("n", [2, 64, 777])
+@pytest.mark.parametrize("kind", ["indefinite", "nonsymmetric"])
+def test_newton_inverts_indefinite_and_nonsymmetric_hessians(qn, qo, n, kind):
+    """newton/mod.rs:36-41: `try_inverse` (LU with partial pivoting) succeeds on any non-singular matrix; only an exactly
+    singular one takes the -g branch.  n = 2 runs the reference-order kernel, 64 and 777 the blocked pivoted LU (qn_lu.hip.h):
+    after the Cholesky attempt reports a non-positive pivot (indefinite) or straight away (not symmetric bit for bit)."""
+    fn, hess0, x0 = _double_well_chain(n)
+    if kind == "nonsymmetric":  # the oracle hands over H + a skew part: still inverted as given
+        rng = np.random.default_rng(8)
+        k = 0.2 * np.triu(rng.standard_normal((n, n)), 1) / np.sqrt(n)
+        hess = lambda x: hess0(x) + k - k.T  # noqa: E731
+    else:
+        hess = hess0
+    ev = np.linalg.eigvalsh(hess0(x0))
+    assert ev[0] < 0.0 < ev[-1]  # indefinite at the start
+    iters = 4
+    s, st, ref, st_ref = _newton_pair(qn, qo, fn, hess, x0, qn.MoreThuente(), qo.morethuente(), iters)
+    tr, xs = s.trace()
+    assert st == st_ref and len(tr) == len(ref.trace) >= 1
+    # the first direction is the Newton direction -H^-1 g of the indefinite matrix, not -g
+    f0, g0 = fn(x0)
+    d_newton = -np.linalg.solve(hess(x0), g0)
+    step0 = xs[0] - x0
+    if tr[0]["t"] > 0:
+        cosang = step0 @ d_newton / (np.linalg.norm(step0) * np.linalg.norm(d_newton))
+        assert cosang > 1.0 - 1e-9
+        assert abs(step0 @ g0) < (1.0 - 1e-6) * np.linalg.norm(step0) * np.linalg.norm(g0)  # not the gradient direction
+    for k_, (a, b) in enumerate(zip(tr, ref.trace)):
+        assert (a["ls_cases"], a["n_evals"]) == (b["ls_cases"], b["n_evals"]), (k_, a, b)
+        assert abs(a["t"] - b["t"]) <= 1e-8 * abs(b["t"]), (k_, a["t"], b["t"])
+        assert np.linalg.norm(xs[k_] - ref.trace_x[k_]) <= 1e-8 * max(1.0, np.linalg.norm(ref.trace_x[k_])), k_
+    assert s.decrement_squared() is not None and ref.decrement_squared is not None
+    assert abs(s.decrement_squared() - ref.decrement_squared) <= 1e-7 * max(1.0, abs(ref.decrement_squared))
+
+
+def test_newton_device_objective_with_indefinite_matrix(qn, qo):
+    """device-resident quadratic whose matrix has negative eigenvalues: Cholesky reports it, the pivoted LU solves it"""
+    n = 200
+    q, b, x0, _ = P.synth_problem(qo, n, 100.0)
+    q = q.copy()
+    idx = np.arange(0, n, 7)
+    q[idx, idx] *= -1.0
+    assert np.linalg.eigvalsh(q)[0] < 0
+    oq = qo.QuadraticOracle(q, b)
+    ref = qo.Solver(qo.NEWTON, 1e-8, x0)
+    ref.set_hessian(oq)
+    # ONE iteration: the step lands on the saddle point Q^-1 b, where the next gradient is rounding noise
+    st_ref = ref.minimize(qo.backtracking(1e-4, 0.5), oq, 1, 30, trace_cap=3, trace_x=True)
+    s = qn.Newton(1e-8, x0)
+    s.set_trace(3, with_x=True)
+    st = qo.OK
+    try:
+        s.minimize(qn.BackTracking(1e-4, 0.5), qn.Quadratic(q, b), 1, 30)
+    except qn.MaxIterReached:
+        st = qo.MAX_ITER_REACHED
+    tr, xs = s.trace()
+    assert st == st_ref and len(tr) == len(ref.trace)
+    for k_, (a, r) in enumerate(zip(tr, ref.trace)):
+        assert a["n_evals"] == r["n_evals"] and abs(a["t"] - r["t"]) <= 1e-9 * abs(r["t"])
+        assert np.linalg.norm(xs[k_] - ref.trace_x[k_]) <= 1e-8 * max(1.0, np.linalg.norm(ref.trace_x[k_]))
+    xs_saddle = np.linalg.solve(q, b)
+    assert tr[0]["t"] == 1.0 and st == qo.MAX_ITER_REACHED
+    assert np.linalg.norm(xs[0] - xs_saddle) <= 1e-8 * np.linalg.norm(xs_saddle)
+
+
+@pytest.mark.parametrize("n", [64, 300])
+def test_newton_exactly_singular_large_hessian_takes_the_gradient_direction(qn, qo, n):
+    """n > 5: two identical rows make a pivot column exactly zero during the elimination -> d = -g, decrement untouched"""
+    fn, hess0, x0 = _double_well_chain(n, seed=6)
+
+    def hess(x):
+        h = np.zeros((n, n))
+        h[np.arange(n), np.arange(n)] = 1.0 + np.arange(n) % 3
+        h[5, :] = 0.0
+        h[9, :] = 0.0
+        h[5, 5] = h[5, 9] = h[9, 5] = h[9, 9] = 2.0  # rows 5 and 9 identical: singular, symmetric, PSD
+        return h
+    s, st, ref, st_ref = _newton_pair(qn, qo, fn, hess, x0, qn.BackTracking(1e-4, 0.5), qo.backtracking(1e-4, 0.5), 3)
+    assert st == st_ref
+    assert s.decrement_squared() is None and ref.decrement_squared is None
+    tr, xs = s.trace()
+    g0 = fn(x0)[1]
+    step0 = xs[0] - x0
+    assert abs(step0 @ g0 + np.linalg.norm(step0) * np.linalg.norm(g0)) <= 1e-12 * np.linalg.norm(step0) * np.linalg.norm(g0)
+    assert np.linalg.norm(xs[-1] - ref.trace_x[-1]) <= 1e-9 * max(1.0, np.linalg.norm(ref.trace_x[-1]))
+
+
+@pytest.mark.parametrize("n", [64, 130, 777, 1500])
+def test_pivoted_lu_path_agrees_with_the_cholesky_path_on_spd(qn, qo, n):
+    """diagnostics knob rows = -5: the same convex problem through both factorisations"""
+    q, b, x0, _ = P.synth_problem(qo, n, 1e3)
+    out = []
+    for force in (False, True):
+        s = qn.Newton(1e-8, x0)
+        if force:
+            s.set_tiling(-5, 0)
+        s.set_trace(5, with_x=True)
+        s.minimize(qn.MoreThuente(), qn.Quadratic(q, b), 50, 20)
+        out.append((s.k(), s.x(), s.decrement_squared(), s.trace()[1][0]))
+    assert out[0][0] == out[1][0]
+    assert np.linalg.norm(out[0][3] - out[1][3]) <= 1e-9 * np.linalg.norm(out[0][3])
+    xstar = np.linalg.solve(q, b)
+    assert np.linalg.norm(out[1][1] - xstar) <= 1e-9 * np.linalg.norm(xstar)
