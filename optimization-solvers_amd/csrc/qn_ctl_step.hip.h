@@ -354,8 +354,8 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
         if (tid < NW) cw = reinterpret_cast<const uint64_t*>(gctl)[tid];
         const bool want_ev = (expect_mask & ((1 << QN_PH_REQ_EVAL) | (1 << QN_PH_REQ_HPASS_EVAL))) != 0;
         const bool want_hp = (expect_mask & ((1 << QN_PH_REQ_HPASS) | (1 << QN_PH_REQ_HPASS_EVAL))) != 0;
-        if (want_ev) ctl_sum_partials<QN_NEVP>(V.F.evp, V.world, V.F.nblk, lds);                                   // waves 0..8
-        if (want_hp) ctl_sum_partials<QN_NHPP>(V.F.hpp, V.world, V.F.nblk, lds + QN_NEVP, want_ev ? QN_NEVP : 0); // waves 9..11
+        if (want_ev) ctl_sum_partials<QN_NEVP>(V.F.evp, V.F.pworld, V.F.nblk, lds);                                   // waves 0..8
+        if (want_hp) ctl_sum_partials<QN_NHPP>(V.F.hpp, V.F.pworld, V.F.nblk, lds + QN_NEVP, want_ev ? QN_NEVP : 0); // waves 9..11
         if (tid < NW) reinterpret_cast<uint64_t*>(&c)[tid] = cw;
         __syncthreads();
         if (!((1 << c.phase) & expect_mask)) return;

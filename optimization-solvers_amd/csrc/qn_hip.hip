@@ -629,6 +629,7 @@ struct qn_solver {
     int sym_nb = 0;
     bool no_sym = false, h_nonsym = false;
     bool h_lower_stale = false; // a symmetric-storage run is (or was) updating the upper block triangle only
+    double *symsh_xg = nullptr, *symsh_gath = nullptr; // row-sharded symmetric storage: gathered partial sums [world][2][n_pad]; mirror staging
     bool h_diag_stale = false;  // ... and (second-generation kernels) only the upper triangle of 16 x 16 sub-blocks inside the diagonal tiles
     // second-generation symmetric path (qn_sym2.hip.h): static work lists, per-workgroup scalars, double-buffered control block
     int *s2_items = nullptr, *s2_first = nullptr;
@@ -845,7 +846,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     for (auto& e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
-    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm);
+    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->symsh_xg); (void)hipFree(s->symsh_gath); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->s2_items); (void)hipFree(s->s2_first); (void)hipFree(s->s2_wgE); (void)hipFree(s->s2_wgH); (void)hipFree(s->s2_rp); (void)hipFree(s->s2_ctl);
@@ -1074,9 +1075,33 @@ static QnHPassArgs hpass_args(qn_solver* s, int expect_phase) {
     return a;
 }
 
+static QnSymShard sym_shard(const qn_solver* s) {
+    QnSymShard sh{};
+    sh.world = s->ctx->world; sh.rank = s->ctx->rank;
+    sh.nbl = s->T.rpr / QN_TB; sh.ioff = sh.rank * sh.nbl;
+    sh.xg = s->symsh_xg;
+    return sh;
+}
+
 // the symmetric-storage paths maintain the upper block triangle only: restore the lower one before anything reads whole rows
 static int ensure_full_h(qn_solver* s) {
     if (!s->H || !s->h_lower_stale) return QN_OK;
+    qn_context* c = s->ctx;
+    if (c->world > 1) { // row-sharded: the stale half of a block-row is maintained by other ranks (circulant windows, qn_sym.hip.h)
+        const size_t np = (size_t)s->T.n_pad, blk = (size_t)QN_TB * np;
+        const QnSymShard sh = sym_shard(s);
+        if (!s->symsh_gath) HIPCHK(hipMalloc((void**)&s->symsh_gath, (size_t)c->world * blk * sizeof(double)));
+        for (int il = 0; il < sh.nbl; ++il) {
+            HIPCHK(hipMemcpyAsync(s->symsh_gath + (size_t)c->rank * blk, s->H + (size_t)il * blk, blk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            QNCHK(exchange(c, s->symsh_gath, blk));
+            hipLaunchKernelGGL(symsh_mirror_kernel, dim3(sh.nbl, c->world), dim3(256), 0, c->stream, s->H, s->symsh_gath, s->T.n_pad,
+                               s->T.n_pad / QN_TB, il, sh);
+        }
+        HIPCHK(hipGetLastError());
+        s->h_lower_stale = false;
+        s->h_diag_stale = false;
+        return QN_OK;
+    }
     const int b32 = s->T.n_pad / 32;
     hipLaunchKernelGGL(sym2_mirror_kernel, dim3(b32, b32), dim3(256), 0, s->ctx->stream, s->H, s->T.n_pad); // (also inside the diagonal tiles)
     HIPCHK(hipGetLastError());
@@ -1440,6 +1465,29 @@ static int enqueue_eval_fused(Run& r, int after_h) {
         QnSymEvalArgs y{};
         y.Q = r.obj->Q; y.T = a.T; y.F = a.F; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_EVAL; y.after_h = after_h; y.nb = s->sym_nb; y.part = s->sym_part;
         y.nt = 0; // Q is only read: non-temporal loads measured no gain at n = 32768 and -4 % at n = 16384
+        if (c->world > 1) { // row-sharded: this rank's circulant half, partial sums gathered, epilogue on every rank
+            y.sh = sym_shard(s);
+            {
+                ProfScope ps(s, KC_EVAL);
+                hipLaunchKernelGGL(sym_eval_tile_kernel, dim3(qn_symsh_ntiles(y.nb, y.sh.nbl, y.sh.ioff)), dim3(QN_SYM_TPB), 0, c->stream, y);
+            }
+            {
+                ProfScope ps(s, KC_EREDUCE);
+                hipLaunchKernelGGL(symsh_eval_sum_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
+            }
+            HIPCHK(hipGetLastError());
+            {
+                ProfScope ps(s, KC_COMM);
+                QNCHK(exchange(c, s->symsh_xg, (size_t)s->T.n_pad));
+            }
+            {
+                ProfScope ps(s, KC_EREDUCE);
+                hipLaunchKernelGGL(symsh_eval_epi_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
+            }
+            s->stats.launches += 3;
+            HIPCHK(hipGetLastError());
+            return QN_OK;
+        }
         {
             ProfScope ps(s, KC_EVAL);
             hipLaunchKernelGGL(sym_eval_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
@@ -1476,6 +1524,29 @@ static int enqueue_hpass_fused(Run& r) {
         y.H = s->H; y.T = a.T; y.F = a.F; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_HPASS; y.nb = s->sym_nb; y.part = s->sym_part;
         y.nt = s->T.n_pad >= 8192; // past the Infinity Cache (same-box A/B: +7 % at n = 32768, +3 % at 8192, -1 % at 4096)
         s->h_lower_stale = true;
+        if (c->world > 1) {
+            y.sh = sym_shard(s);
+            {
+                ProfScope ps(s, KC_HPASS);
+                hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(qn_symsh_ntiles(y.nb, y.sh.nbl, y.sh.ioff)), dim3(QN_SYM_TPB), 0, c->stream, y);
+            }
+            {
+                ProfScope ps(s, KC_HREDUCE);
+                hipLaunchKernelGGL(symsh_hpass_sum_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
+            }
+            HIPCHK(hipGetLastError());
+            {
+                ProfScope ps(s, KC_COMM);
+                QNCHK(exchange(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
+            }
+            {
+                ProfScope ps(s, KC_HREDUCE);
+                hipLaunchKernelGGL(symsh_hpass_epi_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
+            }
+            s->stats.launches += 3;
+            HIPCHK(hipGetLastError());
+            return QN_OK;
+        }
         {
             ProfScope ps(s, KC_HPASS);
             hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
@@ -1818,7 +1889,9 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     s->V.fused_hint = h->fused;
     // ... and on the upper block triangle only (half the bytes) when H and Q are whole 128-tiles on one rank
     const bool sym_ok = c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
-    r.sym = r.fused && sym_ok && r.obj && r.obj->q_symmetric;
+    // ... row-sharded: every rank streams the circulant half of its own block-rows (whole 128-row blocks per rank)
+    const bool symsh_ok = c->world > 1 && (s->T.rpr % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
+    r.sym = r.fused && (sym_ok || symsh_ok) && r.obj && r.obj->q_symmetric;
     // the generic path's H pass alone (closures, log-sum-exp objective, SR1, bounded variants): same tiles, sums into V.hp
     r.sym_generic = !r.fused && sym_ok && s->H && s->hcs == 1 && (s->method == QN_BFGS || s->method == QN_DFP || s->method == QN_SR1);
     if (r.sym_generic) {
@@ -1829,7 +1902,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             s->sym_nb = nb;
         }
     }
-    r.sym2 = r.sym && !s->no_sym2 && (size_t)s->T.n_pad == s->n; // (the second-generation kernels keep no padding entries at zero)
+    r.sym2 = r.sym && c->world == 1 && !s->no_sym2 && (size_t)s->T.n_pad == s->n; // (the second-generation kernels keep no padding entries at zero)
     h->sym2 = r.sym2 ? 1 : 0;
     h->serviced = 0; h->ev_par = 0; h->ev_kind = QN_REQ_X; h->ev_t = 0.0;
     h->defer_u = 0;
@@ -1838,6 +1911,8 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     if (!(r.sym || r.sym_generic) || (s->h_diag_stale && !r.sym2)) QNCHK(ensure_full_h(s)); // ... and on whole rows of H (or whole diagonal tiles)
     if (r.fused) {
         QNCHK(solver_alloc_fused(s, r.sym));
+        s->V.F.pworld = r.sym ? 1 : c->world; // symmetric storage: every rank forms all the per-block partial sums itself
+        if (r.sym && c->world > 1 && !s->symsh_xg) QNCHK(dev_alloc_zero(&s->symsh_xg, (size_t)c->world * 2 * s->T.n_pad, c->stream));
         s->V.F.b = r.obj->b;
         if (!s->fused_live) { // import the canonical state (x, pending s and u) into the fused buffers
             const size_t vb = (size_t)s->T.n_pad * sizeof(double);
@@ -1967,6 +2042,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     uint64_t shard = (uint64_t)s->T.rpr * (uint64_t)s->T.n_pad * 8ull;
     const uint64_t full_shard = shard;
     if (r.sym || r.sym_generic) shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb + 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull; // the streamed tiles
+    if (r.sym && c->world > 1) shard = (uint64_t)qn_symsh_ntiles(s->sym_nb, s->T.rpr / QN_TB, c->rank * (s->T.rpr / QN_TB)) * (uint64_t)QN_TB * QN_TB * 8ull;
     if (r.sym2) // diagonal tiles: wave w (rows 16 w ...) reads 64 - 8 w lanes of 16 bytes per row = 73 728 of the 131 072 bytes
         shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb - 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull + (uint64_t)s->sym_nb * 73728ull;
     s->stats.h_bytes = (h->n_hpasses + h->n_hpass_rw) * shard;

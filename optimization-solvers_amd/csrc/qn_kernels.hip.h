@@ -56,6 +56,7 @@ struct QnFused {
     double* hpp;  // [world][QN_NHPP][nblk]
     const double* b;
     int nblk;     // row tiles per rank
+    int pworld;   // ranks whose partial rows evp / hpp hold: the context's world on the row path, 1 on the symmetric-storage paths
 };
 
 struct QnVecs {

@@ -32,6 +32,44 @@ template <bool NT> __device__ __forceinline__ void qn_sym_st(double* p, v2d v) {
     if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(p)); else st2(p, v);
 }
 
+// Row-sharded runs (one process per GPU): rank p stores whole rows of its `nbl` block-rows [ioff, ioff + nbl) and streams the
+// CIRCULANT half of them -- block-row I owns the tiles (I, (I + k) mod nb), k = 0 .. cnt(I) - 1, with cnt = (nb + 1) / 2 for odd
+// nb and nb / 2 + 1 (I < nb / 2) or nb / 2 (else) for even nb: every unordered pair {I, J} exactly once, the same number of tiles
+// per block-row to within one.  A tile's column part lands in a block-row that another rank may own, so each rank sums what ITS
+// tiles contributed to every block-row (symsh_sum_kernel), the per-rank partial n-vectors are all-gathered (the context's
+// exchange: RCCL or host-staged), and every rank adds them in rank order and runs the epilogue on the full vectors
+// (symsh_*_epi_kernel) -- replicated work on n-vectors, identical bits on every rank.  world == 1: the fields are unused.
+struct QnSymShard {
+    int world, rank, nbl, ioff;
+    double* xg; // gathered partial sums: [world][nrhs][n_pad], rank r's slice written by rank r
+};
+__device__ __host__ __forceinline__ int qn_symsh_cnt(int I, int nb) { return (nb & 1) ? (nb + 1) / 2 : (I < nb / 2 ? nb / 2 + 1 : nb / 2); }
+__device__ __host__ __forceinline__ bool qn_symsh_owns(int I, int J, int nb) { // is tile (I, J) in block-row I's circulant window?
+    int k = J - I;
+    if (k < 0) k += nb;
+    return k < qn_symsh_cnt(I, nb);
+}
+// launch-linear index t -> this rank's tile (I, J): local block-rows in order, each with its window
+__device__ __forceinline__ void qn_symsh_tile(int t, int nb, const QnSymShard& sh, int& I, int& J) {
+    int il, k;
+    if (nb & 1) { const int c = (nb + 1) / 2; il = t / c; k = t - il * c; }
+    else {
+        const int h = nb / 2;
+        int nbig = h - sh.ioff; // local block-rows with I < nb / 2 come first and have h + 1 tiles
+        nbig = nbig < 0 ? 0 : (nbig > sh.nbl ? sh.nbl : nbig);
+        if (t < nbig * (h + 1)) { il = t / (h + 1); k = t - il * (h + 1); }
+        else { const int u = t - nbig * (h + 1); il = nbig + u / h; k = u - (il - nbig) * h; }
+    }
+    I = sh.ioff + il;
+    J = I + k;
+    if (J >= nb) J -= nb;
+}
+static inline int qn_symsh_ntiles(int nb, int nbl, int ioff) {
+    int t = 0;
+    for (int il = 0; il < nbl; ++il) t += qn_symsh_cnt(ioff + il, nb);
+    return t;
+}
+
 struct QnSymEvalArgs {
     const double* Q;
     QnTile T;
@@ -42,6 +80,7 @@ struct QnSymEvalArgs {
     int nb;
     double* part; // [nb][nb][2][QN_TB]
     int nt;       // non-temporal tile loads
+    QnSymShard sh;
 };
 struct QnSymHPassArgs {
     double* H;
@@ -57,6 +96,7 @@ struct QnSymHPassArgs {
     const double *gsp, *gup, *gvy, *gvg;
     double* ghp;
     int nt; // non-temporal tile loads and stores
+    QnSymShard sh;
 };
 
 // launch-linear index t -> upper-triangle tile (I, J >= I), row-major over I
@@ -155,11 +195,13 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_eval_tile_kernel(const QnSymEv
     __shared__ double rowx[QN_TB];
     __shared__ double colred[QN_SYM_WAVES][QN_TB];
     int I, J;
-    qn_sym_tile(blockIdx.x, a.nb, I, J);
+    const bool sharded = a.sh.world > 1;
+    if (sharded) qn_symsh_tile(blockIdx.x, a.nb, a.sh, I, J); else qn_sym_tile(blockIdx.x, a.nb, I, J);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.T.n_pad;
     const int i0 = I * QN_TB, j0 = J * QN_TB, jc = j0 + 2 * lane;
-    const double* qbase = a.Q + (size_t)(i0 + wave * QN_SYM_RPW) * np + jc;
+    const int i0l = i0 - (sharded ? a.sh.ioff * QN_TB : 0); // row of the tile in this rank's storage
+    const double* qbase = a.Q + (size_t)(i0l + wave * QN_SYM_RPW) * np + jc;
     v2d h[QN_SYM_RPW]; // the wave's whole share of the tile is requested before the control block is read: the grid is a single
                        // wave of workgroups at n = 4096, so nothing else would hide the prologue's two dependent round trips
 #pragma unroll
@@ -190,7 +232,7 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_eval_tile_kernel(const QnSymEv
         QnWaveFold<8, 32>::run(racc, lane); // lanes with (lane & 7) == 0 hold row lane >> 3
         if ((lane & 7) == 0) a.part[(((size_t)I * a.nb + J) * 2 + 0) * QN_TB + wave * QN_SYM_RPW + rc + (lane >> 3)] = racc[0];
     }
-    if (J > I) {
+    if (J != I) { // (single rank: J > I; sharded: the window wraps around)
         colred[wave][2 * lane] = cx;
         colred[wave][2 * lane + 1] = cy;
         __syncthreads();
@@ -203,15 +245,10 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_eval_tile_kernel(const QnSymEv
     }
 }
 
-// block-row R: q_i = sum of its slots, then the epilogue of quad_eval_fused_kernel for these 128 rows
-__global__ __launch_bounds__(256) void sym_eval_reduce_kernel(const QnSymEvalArgs a) {
-    __shared__ double red4[4];
-    __shared__ double red[4][16];
-    __shared__ double halfbuf[QN_TB];
-    const int R = blockIdx.x, tid = threadIdx.x;
+// the epilogue of an evaluation for block-row R given q_i (threads 0..127; all 256 threads call it)
+__device__ __forceinline__ void qn_sym_eval_epilogue(const QnSymEvalArgs& a, const QnEvalReq& q, int R, double qi, double (*red)[16]) {
+    const int tid = threadIdx.x;
     const size_t np = (size_t)a.T.n_pad;
-    QnEvalReq q;
-    if (!qn_eval_request(a.ctl, a.F, a.expect_phase, a.after_h, red4, q)) return;
     const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
     double* __restrict__ xt = a.F.X0 + (size_t)(1 - q.xc) * np;
     const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
@@ -219,7 +256,6 @@ __global__ __launch_bounds__(256) void sym_eval_reduce_kernel(const QnSymEvalArg
     double p[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) p[k] = 0.0;
-    const double qi = qn_sym_slot_sum(a.part, a.nb, R, 0, halfbuf);
     if (tid < QN_TB) {
         const int gi = R * QN_TB + tid;
         double di;
@@ -248,6 +284,96 @@ __global__ __launch_bounds__(256) void sym_eval_reduce_kernel(const QnSymEvalArg
     if (tid < QN_NEVP) a.F.evp[(size_t)tid * a.F.nblk + R] = tot;
 }
 
+// block-row R: q_i = sum of its slots, then the epilogue of quad_eval_fused_kernel for these 128 rows
+__global__ __launch_bounds__(256) void sym_eval_reduce_kernel(const QnSymEvalArgs a) {
+    __shared__ double red4[4];
+    __shared__ double red[4][16];
+    __shared__ double halfbuf[QN_TB];
+    const int R = blockIdx.x;
+    QnEvalReq q;
+    if (!qn_eval_request(a.ctl, a.F, a.expect_phase, a.after_h, red4, q)) return;
+    const double qi = qn_sym_slot_sum(a.part, a.nb, R, 0, halfbuf);
+    qn_sym_eval_epilogue(a, q, R, qi, red);
+}
+
+// ---- row-sharded runs: what THIS rank's tiles contributed to block-row R, summed in a fixed order ----
+// The slots this rank wrote for block-row R: its own window (R local) and the column parts of the local block-rows whose
+// window contains R.  Threads 0..nb-1 flag their slot, the flags are compacted into an ascending list (fixed order), and the
+// two halves of the workgroup add one half of the list each, 16 loads in flight, exactly as qn_sym_slot_sum does.
+// All 256 threads call it; threads 0..127 get the total of row tid (zero when the rank contributed nothing).
+__device__ __forceinline__ int qn_symsh_slot_list(int nb, const QnSymShard& sh, int R, int* list /* LDS[nb] */, int* cnt4 /* LDS[8] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
+    const bool r_local = R >= sh.ioff && R < sh.ioff + sh.nbl;
+    int total = 0;
+    for (int base = 0; base < nb; base += (int)blockDim.x) { // nb <= blockDim.x in every supported configuration but one loop covers all
+        const int t = base + tid;
+        bool w = false;
+        if (t < nb) {
+            const bool t_local = t >= sh.ioff && t < sh.ioff + sh.nbl;
+            w = (r_local && qn_symsh_owns(R, t, nb)) || (t_local && t != R && qn_symsh_owns(t, R, nb));
+        }
+        const unsigned long long m = __ballot(w);
+        if (lane == 0) cnt4[wave] = __popcll(m);
+        __syncthreads();
+        int off = total;
+        for (int v = 0; v < wave; ++v) off += cnt4[v];
+        if (w) list[off + __popcll(m & ((1ull << lane) - 1ull))] = t;
+        for (int v = 0; v < nw; ++v) total += cnt4[v];
+        __syncthreads();
+    }
+    return total;
+}
+__device__ __forceinline__ double qn_symsh_slot_sum(const double* __restrict__ part, int nb, int R, int rhs, const int* list, int nlist,
+                                                    double* halfbuf /* LDS[128] */) {
+    const int i = threadIdx.x & (QN_TB - 1), half = threadIdx.x >> 7;
+    const int nh = (nlist + 1) / 2;
+    const int k_lo = half * nh, k_hi = (half == 0) ? nh : nlist;
+    const double* p = part + (((size_t)R * nb) * 2 + rhs) * QN_TB + i;
+    double acc = 0.0;
+    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = (k0 + q < k_hi) ? p[(size_t)list[k0 + q] * 2 * QN_TB] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = acc + v[q];
+    }
+    if (half == 1) halfbuf[i] = acc;
+    __syncthreads();
+    const double tot = (half == 0) ? acc + halfbuf[i] : 0.0;
+    __syncthreads();
+    return tot;
+}
+// sum over the ranks, in rank order, of the gathered partial sums for row gi of right-hand side `rhs` (nrhs per rank)
+__device__ __forceinline__ double qn_symsh_rank_sum(const QnSymShard& sh, int nrhs, int rhs, size_t np, int gi) {
+    const double* p = sh.xg + (size_t)rhs * np + gi;
+    double acc = p[0];
+    for (int r = 1; r < sh.world; ++r) acc = acc + p[(size_t)r * nrhs * np];
+    return acc;
+}
+
+// evaluation, block-row R: this rank's partial q for rows R*128 .. into its slice of the gather buffer
+__global__ __launch_bounds__(256) void symsh_eval_sum_kernel(const QnSymEvalArgs a) {
+    __shared__ int list[512];
+    __shared__ int cnt4[8];
+    __shared__ double halfbuf[QN_TB];
+    const int phase = a.ctl->phase;
+    if (phase != a.expect_phase && !(a.after_h && phase == QN_PH_REQ_HPASS_EVAL)) return;
+    const int R = blockIdx.x;
+    const int nlist = qn_symsh_slot_list(a.nb, a.sh, R, list, cnt4);
+    const double qi = qn_symsh_slot_sum(a.part, a.nb, R, 0, list, nlist, halfbuf);
+    if (threadIdx.x < QN_TB) a.sh.xg[(size_t)a.sh.rank * a.T.n_pad + (size_t)R * QN_TB + threadIdx.x] = qi;
+}
+// evaluation, block-row R, after the exchange: q_i = sum over ranks, then the epilogue (every rank, all block-rows)
+__global__ __launch_bounds__(256) void symsh_eval_epi_kernel(const QnSymEvalArgs a) {
+    __shared__ double red4[4];
+    __shared__ double red[4][16];
+    const int R = blockIdx.x;
+    QnEvalReq q;
+    if (!qn_eval_request(a.ctl, a.F, a.expect_phase, a.after_h, red4, q)) return;
+    const double qi = threadIdx.x < QN_TB ? qn_symsh_rank_sum(a.sh, 1, 0, (size_t)a.T.n_pad, R * QN_TB + (int)threadIdx.x) : 0.0;
+    qn_sym_eval_epilogue(a, q, R, qi, red);
+}
+
 // ------------------------------------------------------------------------------------------------
 // H pass: pending rank-2 update of the tile, row and column dots with [y, g+] (update pass) or [g] (direction pass)
 // ------------------------------------------------------------------------------------------------
@@ -259,6 +385,7 @@ __device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int
     const size_t np = (size_t)a.T.n_pad;
     const int n = a.T.n;
     const int i0 = I * QN_TB, j0 = J * QN_TB, jc = j0 + 2 * lane;
+    const int i0l = i0 - (a.sh.world > 1 ? a.sh.ioff * QN_TB : 0); // row of the tile in this rank's storage
     // r0v: update pass rhs0 = y (rhs1 = gt = g+); direction pass rhs0 = g
     if (tid < QN_TB) {
         rowv[0][tid] = PENDING ? sp[i0 + tid] : 0.0;
@@ -274,7 +401,7 @@ __device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int
     const bool c0ok = jc < n, c1ok = (jc + 1) < n;
     __syncthreads();
     double c0x = 0.0, c0y = 0.0, c1x = 0.0, c1y = 0.0;
-    double* hbase = a.H + (size_t)(i0 + wave * QN_SYM_RPW) * np + jc;
+    double* hbase = a.H + (size_t)(i0l + wave * QN_SYM_RPW) * np + jc;
     for (int rc = 0; rc < QN_SYM_RPW; rc += 8) {
         if (rc) {
 #pragma unroll
@@ -324,7 +451,7 @@ __device__ __forceinline__ void sym_hpass_tile_body(const QnSymHPassArgs& a, int
             a.part[(((size_t)I * a.nb + J) * 2 + rhs) * QN_TB + wave * QN_SYM_RPW + rc + r] = racc[0];
         }
     }
-    if (J > I) {
+    if (J != I) { // (single rank: J > I; sharded: the window wraps around)
         colred[wave][0][2 * lane] = c0x;
         colred[wave][0][2 * lane + 1] = c0y;
         if (NRHS == 2) { colred[wave][1][2 * lane] = c1x; colred[wave][1][2 * lane + 1] = c1y; }
@@ -343,13 +470,14 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_hpass_tile_kernel(const QnSymH
     __shared__ double rowv[4][QN_TB];
     __shared__ double colred[QN_SYM_WAVES][2][QN_TB];
     int I, J;
-    qn_sym_tile(blockIdx.x, a.nb, I, J);
+    if (a.sh.world > 1) qn_symsh_tile(blockIdx.x, a.nb, a.sh, I, J); else qn_sym_tile(blockIdx.x, a.nb, I, J);
     const size_t np = (size_t)a.T.n_pad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v2d h[8]; // the first rows are requested before the control block is read (all 32, as in the evaluation kernel, costs the
               // update kernel its second workgroup per CU: 256 VGPRs, 42 us instead of 34 at n = 4096)
     {
-        const double* hbase = a.H + (size_t)(I * QN_TB + wave * QN_SYM_RPW) * np + J * QN_TB + 2 * lane;
+        const int il = I - (a.sh.world > 1 ? a.sh.ioff : 0);
+        const double* hbase = a.H + (size_t)(il * QN_TB + wave * QN_SYM_RPW) * np + J * QN_TB + 2 * lane;
 #pragma unroll
         for (int r = 0; r < 8; ++r) h[r] = a.nt ? qn_sym_ld<true>(hbase + (size_t)r * np) : qn_sym_ld<false>(hbase + (size_t)r * np);
     }
@@ -378,32 +506,14 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_hpass_tile_kernel(const QnSymH
 #undef QN_SYM_BODY
 }
 
-// block-row R: u_i, v_i = sums of the slots; the epilogue of h_pass_fused_kernel for these 128 rows
-__global__ __launch_bounds__(256) void sym_hpass_reduce_kernel(const QnSymHPassArgs a) {
-    __shared__ double red[4][16];
-    __shared__ double halfbuf[QN_TB];
-    const int R = blockIdx.x, tid = threadIdx.x;
+// the epilogue of an H pass for block-row R given the sums of its two right-hand sides (threads 0..127; all 256 threads call it)
+__device__ __forceinline__ void qn_sym_hpass_epilogue(const QnSymHPassArgs& a, int sc, int nrhs, int R, double tot0, double tot1, double (*red)[16]) {
+    const int tid = threadIdx.x;
     const size_t np = (size_t)a.T.n_pad;
-    const QnCtl* __restrict__ ctl = a.ctl;
-    const int phase = ctl->phase;
-    if (phase != a.expect_phase && !(phase == QN_PH_REQ_HPASS_EVAL && !a.generic)) return;
-    const int nrhs = ctl->hp_nrhs;
-    if (a.generic) { // the control step does the rest (qn_ctl_step.hip.h, states AFTER_DIR / AFTER_U)
-        if (nrhs == 0) return;
-        const double t0 = qn_sym_slot_sum(a.part, a.nb, R, 0, halfbuf);
-        const double t1 = (nrhs == 2) ? qn_sym_slot_sum(a.part, a.nb, R, 1, halfbuf) : 0.0;
-        if (tid < QN_TB) {
-            a.ghp[(size_t)R * QN_TB + tid] = t0;
-            if (nrhs == 2) a.ghp[(size_t)a.T.rpr + (size_t)R * QN_TB + tid] = t1;
-        }
-        return;
-    }
-    const double* sstage = a.F.S0 + (size_t)(1 - ctl->sc) * np;
+    const double* sstage = a.F.S0 + (size_t)(1 - sc) * np;
     double p[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) p[k] = 0.0;
-    const double tot0 = qn_sym_slot_sum(a.part, a.nb, R, 0, halfbuf);
-    const double tot1 = (nrhs == 2) ? qn_sym_slot_sum(a.part, a.nb, R, 1, halfbuf) : 0.0; // nrhs is uniform
     if (tid < QN_TB) {
         const int gi = R * QN_TB + tid;
         const double gp = a.F.GT[gi];
@@ -421,6 +531,88 @@ __global__ __launch_bounds__(256) void sym_hpass_reduce_kernel(const QnSymHPassA
     if (nrhs == 2) {
         const double tot = qn_sym_block_totals<QN_NHPP>(p, red);
         if (tid < QN_NHPP) a.F.hpp[(size_t)tid * a.F.nblk + R] = tot;
+    }
+}
+
+// block-row R: u_i, v_i = sums of the slots; the epilogue of h_pass_fused_kernel for these 128 rows
+__global__ __launch_bounds__(256) void sym_hpass_reduce_kernel(const QnSymHPassArgs a) {
+    __shared__ double red[4][16];
+    __shared__ double halfbuf[QN_TB];
+    const int R = blockIdx.x, tid = threadIdx.x;
+    const QnCtl* __restrict__ ctl = a.ctl;
+    const int phase = ctl->phase;
+    if (phase != a.expect_phase && !(phase == QN_PH_REQ_HPASS_EVAL && !a.generic)) return;
+    const int nrhs = ctl->hp_nrhs;
+    if (a.generic) { // the control step does the rest (qn_ctl_step.hip.h, states AFTER_DIR / AFTER_U)
+        if (nrhs == 0) return;
+        const double t0 = qn_sym_slot_sum(a.part, a.nb, R, 0, halfbuf);
+        const double t1 = (nrhs == 2) ? qn_sym_slot_sum(a.part, a.nb, R, 1, halfbuf) : 0.0;
+        if (tid < QN_TB) {
+            a.ghp[(size_t)R * QN_TB + tid] = t0;
+            if (nrhs == 2) a.ghp[(size_t)a.T.rpr + (size_t)R * QN_TB + tid] = t1;
+        }
+        return;
+    }
+    const double tot0 = qn_sym_slot_sum(a.part, a.nb, R, 0, halfbuf);
+    const double tot1 = (nrhs == 2) ? qn_sym_slot_sum(a.part, a.nb, R, 1, halfbuf) : 0.0; // nrhs is uniform
+    qn_sym_hpass_epilogue(a, ctl->sc, nrhs, R, tot0, tot1, red);
+}
+// row-sharded runs, H pass, block-row R: this rank's partial sums into its slice of the gather buffer [world][2][n_pad]
+__global__ __launch_bounds__(256) void symsh_hpass_sum_kernel(const QnSymHPassArgs a) {
+    __shared__ int list[512];
+    __shared__ int cnt4[8];
+    __shared__ double halfbuf[QN_TB];
+    const QnCtl* __restrict__ ctl = a.ctl;
+    const int phase = ctl->phase;
+    if (phase != a.expect_phase && phase != QN_PH_REQ_HPASS_EVAL) return;
+    const int nrhs = ctl->hp_nrhs;
+    const int R = blockIdx.x;
+    const size_t np = (size_t)a.T.n_pad;
+    const int nlist = qn_symsh_slot_list(a.nb, a.sh, R, list, cnt4);
+    const double t0 = qn_symsh_slot_sum(a.part, a.nb, R, 0, list, nlist, halfbuf);
+    const double t1 = (nrhs == 2) ? qn_symsh_slot_sum(a.part, a.nb, R, 1, list, nlist, halfbuf) : 0.0;
+    if (threadIdx.x < QN_TB) {
+        double* out = a.sh.xg + (size_t)a.sh.rank * 2 * np + (size_t)R * QN_TB + threadIdx.x;
+        out[0] = t0;
+        out[np] = t1;
+    }
+}
+// ... after the exchange: u_i, v_i = sums over the ranks in rank order, then the epilogue (every rank, all block-rows)
+__global__ __launch_bounds__(256) void symsh_hpass_epi_kernel(const QnSymHPassArgs a) {
+    __shared__ double red[4][16];
+    const QnCtl* __restrict__ ctl = a.ctl;
+    const int phase = ctl->phase;
+    if (phase != a.expect_phase && phase != QN_PH_REQ_HPASS_EVAL) return;
+    const int nrhs = ctl->hp_nrhs;
+    const int R = blockIdx.x, gi = R * QN_TB + (int)threadIdx.x;
+    const size_t np = (size_t)a.T.n_pad;
+    double t0 = 0.0, t1 = 0.0;
+    if (threadIdx.x < QN_TB) {
+        t0 = qn_symsh_rank_sum(a.sh, 2, 0, np, gi);
+        if (nrhs == 2) t1 = qn_symsh_rank_sum(a.sh, 2, 1, np, gi);
+    }
+    qn_sym_hpass_epilogue(a, ctl->sc, nrhs, R, t0, t1, red);
+}
+
+// row-sharded runs, after a run: restore the block-rows' stale halves from the ranks that maintain them.  Step `il` of nbl: every
+// rank has contributed its local block-row il (128 whole rows) to `gath` [world][128][n_pad]; workgroup (jl, p) copies the
+// transpose of tile (I_p, J) -- I_p = p*nbl + il, J = ioff + jl -- into the local tile (J, I_p) when block-row I_p owns the pair.
+__global__ __launch_bounds__(256) void symsh_mirror_kernel(double* __restrict__ H, const double* __restrict__ gath, int n_pad, int nb, int il,
+                                                           const QnSymShard sh) {
+    __shared__ double t[32][33];
+    const int p = blockIdx.y, jl = blockIdx.x;
+    const int I = p * sh.nbl + il, J = sh.ioff + jl;
+    if (I == J || !qn_symsh_owns(I, J, nb)) return;
+    const size_t np = (size_t)n_pad;
+    const double* src = gath + (size_t)p * QN_TB * np + (size_t)J * QN_TB; // rows of block-row I_p, columns of block J
+    double* dst = H + (size_t)jl * QN_TB * np + (size_t)I * QN_TB;         // local rows of block J, columns of block I_p
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int sb = 0; sb < 16; ++sb) { // 4 x 4 sub-tiles of 32 x 32
+        const int bi = sb >> 2, bj = sb & 3;
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) t[r][tx] = src[(size_t)(bi * 32 + r) * np + bj * 32 + tx];
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) dst[(size_t)(bj * 32 + r) * np + bi * 32 + tx] = t[tx][r];
     }
 }
 

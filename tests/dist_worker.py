@@ -140,6 +140,60 @@ def main():
         (t4, x4), (t5, x5) = s4.trace(), s5.trace()
         result["lse_dfp_close"] = bool(len(t4) == len(t5) and [r["ls_cases"] for r in t4] == [r["ls_cases"] for r in t5]
                                        and np.linalg.norm(x4 - x5) <= 1e-9 * np.linalg.norm(x5))
+    elif mode == "gpu_sym":
+        # Row-sharded SYMMETRIC storage: the ranks share the one GPU, every rank streams the circulant half of its own block-rows,
+        # partial n-vectors are all-gathered (host-staged here) and summed in rank order.  Against the single-rank run of the same
+        # problem: same line-search cases and evaluation counts, iterates to the parity tolerance; between ranks: the same bits.
+        result["cases"] = []
+        for n in ([1024, 2048] if world == 2 else [128 * 3 * world]):  # nb = 8, 16 (even); world 3: nb = 9 (odd)
+            iters = 12
+            diag = P.synth_diag(n)
+            b, x0 = P.synth_vectors(n)
+            ctx = qn.dist.sharded_context(0, host_exchange=True)
+            obj = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx)
+            ctx1 = qn.Context(0)
+            obj1 = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx1)
+            case = {"n": n}
+            for method in ("bfgs", "dfp"):
+                mk = qn.BFGS if method == "bfgs" else qn.DFP
+                s = mk(1e-10, x0, ctx=ctx)
+                s.set_trace(iters, with_x=True)
+                s1 = mk(1e-10, x0, ctx=ctx1)
+                s1.set_trace(iters, with_x=True)
+                for sv, ob in ((s, obj), (s1, obj1)):
+                    try:
+                        sv.minimize(qn.MoreThuente(), ob, iters, 20)
+                    except qn.MaxIterReached:
+                        pass
+                (tr, xs), (tr1, xs1) = s.trace(), s1.trace()
+                st, st1 = s.stats(), s1.stats()
+                ok = len(tr) == len(tr1) == iters
+                ok = ok and all((a["ls_cases"], a["n_evals"], a["ls_iters"]) == (c["ls_cases"], c["n_evals"], c["ls_iters"]) for a, c in zip(tr, tr1))
+                ok = ok and all(abs(a["t"] - c["t"]) <= 1e-9 * abs(c["t"]) for a, c in zip(tr, tr1))
+                ok = ok and bool(np.linalg.norm(xs - xs1) <= 1e-9 * np.linalg.norm(xs1))
+                case[method + "_close"] = bool(ok)
+                case[method + "_path"] = [st["path"], st1["path"]]
+                case[method + "_bytes"] = [st["matrix_bytes_per_pass"], st1["matrix_bytes_per_pass"]]
+                case[method + "_x_hex"] = [float(v).hex() for v in xs[-1][:64]]
+                # the getter restores the stale halves from the ranks that maintain them: the whole matrix, symmetric, = single rank
+                h = s.approx_inv_hessian(all_ranks=True)
+                h1 = s1.approx_inv_hessian()
+                case[method + "_h_symmetric"] = bool(np.array_equal(h, h.T))
+                case[method + "_h_close"] = bool(np.linalg.norm(h - h1) <= 1e-8 * np.linalg.norm(h1))
+                case[method + "_h_hex"] = [float(v).hex() for v in h[n // 2, ::17]]
+                # ... and the run continues from there: on the symmetric path again, then on the row kernels (tiling -3)
+                for rows in (False, True):
+                    for sv, ob in ((s, obj), (s1, obj1)):
+                        if rows:
+                            sv.set_tiling(-3, 0)
+                        try:
+                            sv.minimize(qn.MoreThuente(), ob, 4, 20)
+                        except qn.MaxIterReached:
+                            pass
+                    xa, xb = s.x(), s1.x()
+                    case[method + ("_rows" if rows else "_again") + "_close"] = bool(np.linalg.norm(xa - xb) <= 1e-8 * np.linalg.norm(xb))
+                    case[method + ("_rows" if rows else "_again") + "_path"] = s.stats()["path"]
+            result["cases"].append(case)
     gathered = [None] * world
     dist.all_gather_object(gathered, result)
     if rank == 0:

@@ -19,3 +19,31 @@ def test_two_ranks_on_one_gpu_equal_single_rank_bitwise(tmp_path):
         assert r["trace_equal"] and r["x_equal"] and r["h_equal"], r
         assert r["objective_rows_ok"] and r["eval_equal"] and r["dfp_bt_equal"], r
         assert r["lse_eval_close"] and r["lse_dfp_close"], r
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_row_sharded_symmetric_storage(tmp_path, nproc):
+    """Row-sharded runs stream the symmetric half too (circulant windows over the block-rows, qn_sym.hip.h): two / three ranks
+    on the one GPU against the single-rank run -- same line-search decisions, iterates to the parity tolerance, identical bits
+    on every rank, half the matrix bytes per pass, and the getters / the row kernels see a whole matrix again afterwards."""
+    res = launch("gpu_sym", tmp_path, nproc=nproc, timeout=900)
+    assert len(res) == nproc
+    for r in res:
+        for case in r["cases"]:
+            n = case["n"]
+            nb = n // 128
+            for m in ("bfgs", "dfp"):
+                assert case[m + "_close"] and case[m + "_h_symmetric"] and case[m + "_h_close"], (r["rank"], case)
+                assert case[m + "_again_close"] and case[m + "_rows_close"], (r["rank"], case)
+                p_sh, p_1 = case[m + "_path"]
+                assert p_sh & 1 and p_sh & 2 and not p_sh & 16, p_sh   # fused, symmetric storage, first-generation tile kernels
+                assert case[m + "_again_path"] & 2 and not case[m + "_rows_path"] & 2
+                b_sh, b_1 = case[m + "_bytes"]
+                assert abs(nproc * b_sh - nb * (nb + 1) // 2 * 131072) <= nproc * (nb // nproc) * 131072  # balanced to one tile per block-row
+    for case_i in range(len(res[0]["cases"])):
+        nb = res[0]["cases"][case_i]["n"] // 128
+        for m in ("bfgs", "dfp"):
+            # the ranks' tiles together are the half matrix exactly: every pair of block-rows once
+            assert sum(r["cases"][case_i][m + "_bytes"][0] for r in res) == nb * (nb + 1) // 2 * 131072
+            assert len({tuple(r["cases"][case_i][m + "_x_hex"]) for r in res}) == 1  # replicated vector work: same bits everywhere
+            assert len({tuple(r["cases"][case_i][m + "_h_hex"]) for r in res}) == 1
