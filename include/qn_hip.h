@@ -62,13 +62,18 @@ int qn_context_create_sharded(int device, int rank, int world, const void* uniqu
 typedef int (*qn_host_allgather_fn)(void* user, const double* sendbuf, double* recvbuf, size_t count);
 int qn_context_create_sharded_host_exchange(int device, int rank, int world, qn_host_allgather_fn fn, void* user,
                                             qn_context** out);
+/* Host-exchange contexts only: on != 0 makes every exchange a stream-ordered triple (device-to-pinned copy, the callback as a
+ * host node of the stream, pinned-to-device copy) with no synchronisation, so the pipelined launch logic -- which RCCL runs use
+ * -- can be rehearsed with several ranks on one GPU.  The callback then runs on a runtime thread, not on the caller's. */
+int qn_context_set_host_exchange_async(qn_context* ctx, int on);
 void qn_context_destroy(qn_context* ctx);
 /* the row partition used for H and the objective's matrix: rows per rank (a multiple of 16) and padded dimension */
 int qn_partition(size_t n, int world, size_t* rows_per_rank, size_t* n_pad);
 /* diagnostics: create a 1-rank RCCL communicator on this context's GPU, all-gather a small buffer in place on the
  * context's stream and verify it (checks that librccl loads and that the calling convention matches) */
 int qn_comm_selftest(qn_context* ctx);
-/* collective (every rank calls it): one rank-tagged all-gather through the context's own exchange, verified on every rank */
+/* collective (every rank calls it): one rank-tagged all-gather through the context's own exchange, then three of different
+ * sizes as ONE group (the form the row kernels' exchanges take), each verified on every rank */
 int qn_context_comm_check(qn_context* ctx);
 /* measurement aid: the fixed part (ms) of what a hipEventRecord / launch / hipEventRecord bracket on the idle context stream
  * reports beyond the bracketed kernel's own duration: 2 * bracket(one empty kernel) - bracket(two empty kernels) */

@@ -108,7 +108,21 @@ struct qn_context {
     void* host_xchg_user = nullptr;
     std::vector<double> xchg_send, xchg_recv;
     uint64_t n_comm = 0;
+    // host-staged exchange in STREAM ORDER (qn_context_set_host_exchange_async): pinned staging, the callback runs as a
+    // hipLaunchHostFunc node between the two copies, nothing synchronises -- the pipelined launch logic can then be rehearsed
+    // with several ranks on one GPU
+    int host_async = 0;
+    double* pin = nullptr; // [send (cap) | recv (cap * world)]
+    size_t pin_cap = 0;
+    int host_async_failed = 0;
 };
+struct HostXchgNode { qn_context* c; size_t count; };
+static void host_xchg_node(void* p) {
+    HostXchgNode* nd = (HostXchgNode*)p;
+    qn_context* c = nd->c;
+    if (c->host_xchg(c->host_xchg_user, c->pin, c->pin + c->pin_cap, nd->count) != 0) c->host_async_failed = 1;
+    delete nd;
+}
 
 extern "C" int qn_device_count(int* out) {
     int n = 0;
@@ -180,10 +194,23 @@ extern "C" void qn_context_destroy(qn_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->pin) (void)hipHostFree(c->pin);
     delete c;
 }
-extern "C" int qn_context_synchronize(qn_context* c) { HIPCHK(hipStreamSynchronize(c->stream)); return QN_OK; }
+extern "C" int qn_context_synchronize(qn_context* c) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->host_async_failed) { c->host_async_failed = 0; return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed"); }
+    return QN_OK;
+}
+extern "C" int qn_context_set_host_exchange_async(qn_context* c, int on) {
+    if (!c) return fail(QN_ERROR_INPUT_PARAMS, "context is null");
+    if (on && c->world > 1 && !c->host_xchg) return fail(QN_ERROR_INPUT_PARAMS, "not a host-exchange context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->host_async = on ? 1 : 0;
+    return QN_OK;
+}
 extern "C" int qn_context_rank(const qn_context* c) { return c->rank; }
 extern "C" int qn_context_world(const qn_context* c) { return c->world; }
 extern "C" void* qn_context_stream(qn_context* c) { return (void*)c->stream; }
@@ -194,6 +221,19 @@ static int exchange(qn_context* c, double* buf, size_t count) {
     c->n_comm++;
     if (c->comm) {
         RCCLCHK(g_rccl.AllGather(buf + (size_t)c->rank * count, buf, count, kRcclDouble, c->comm, c->stream));
+        return QN_OK;
+    }
+    if (c->host_async) { // stream-ordered: D2H copy, host node, H2D copy; the caller's next synchronisation covers all three
+        if (count > c->pin_cap) {
+            HIPCHK(hipStreamSynchronize(c->stream)); // earlier nodes may still use the old staging area
+            if (c->pin) HIPCHK(hipHostFree(c->pin));
+            c->pin = nullptr;
+            c->pin_cap = std::max(count, (size_t)1 << 16);
+            HIPCHK(hipHostMalloc((void**)&c->pin, c->pin_cap * (size_t)(c->world + 1) * sizeof(double), hipHostMallocDefault));
+        }
+        HIPCHK(hipMemcpyAsync(c->pin, buf + (size_t)c->rank * count, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipLaunchHostFunc(c->stream, host_xchg_node, new HostXchgNode{c, count}));
+        HIPCHK(hipMemcpyAsync(buf, c->pin + c->pin_cap, count * (size_t)c->world * sizeof(double), hipMemcpyHostToDevice, c->stream));
         return QN_OK;
     }
     // host-staged exchange (tests / bring-up)
@@ -299,6 +339,37 @@ extern "C" int qn_context_comm_check(qn_context* c) {
         for (size_t i = 0; i < count; ++i)
             if (h[(size_t)r * count + i] != 1000.0 * (double)r + 0.25 * (double)i)
                 return fail(QN_ABNORMAL_TERMINATION, "comm check: all-gather returned wrong data");
+    // ... and the GROUPED path the row kernels use (three all-gathers of different sizes between ncclGroupStart / ncclGroupEnd:
+    // vector slices and per-workgroup partial sums), verified the same way
+    const size_t counts[3] = {1024, 1024, 9 * 32};
+    double* gb[3] = {nullptr, nullptr, nullptr};
+    std::vector<double> gh[3];
+    for (int k = 0; k < 3 && st == QN_OK; ++k) {
+        const size_t tot = counts[k] * (size_t)c->world;
+        gh[k].assign(tot, -1.0);
+        for (size_t i = 0; i < counts[k]; ++i) gh[k][(size_t)c->rank * counts[k] + i] = 1e6 * (k + 1) + 1000.0 * (double)c->rank + 0.5 * (double)i;
+        hipError_t e = hipMalloc((void**)&gb[k], tot * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpyAsync(gb[k], gh[k].data(), tot * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, std::string("comm check: ") + hipGetErrorString(e));
+    }
+    if (st == QN_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, "comm check: synchronize");
+    if (st == QN_OK) {
+        const XchgItem items[3] = {{gb[0], counts[0]}, {gb[1], counts[1]}, {gb[2], counts[2]}};
+        st = exchange_group(c, items, 3);
+    }
+    for (int k = 0; k < 3 && st == QN_OK; ++k) {
+        hipError_t e = hipMemcpyAsync(gh[k].data(), gb[k], gh[k].size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, std::string("comm check: ") + hipGetErrorString(e));
+    }
+    for (int k = 0; k < 3; ++k) (void)hipFree(gb[k]);
+    if (st != QN_OK) return st;
+    if (c->host_async_failed) { c->host_async_failed = 0; return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed"); }
+    for (int k = 0; k < 3; ++k)
+        for (int r = 0; r < c->world; ++r)
+            for (size_t i = 0; i < counts[k]; ++i)
+                if (gh[k][(size_t)r * counts[k] + i] != 1e6 * (k + 1) + 1000.0 * (double)r + 0.5 * (double)i)
+                    return fail(QN_ABNORMAL_TERMINATION, "comm check: grouped all-gather returned wrong data");
     return QN_OK;
 }
 
@@ -1945,7 +2016,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     }
 
     // only the quadratic objective's kernels are predicated on the control block; everything else is serviced synchronously
-    const bool can_pipeline = (r.oracle_tpl == QN_ORACLE_QUAD) && !callback && !(c->world > 1 && !c->comm);
+    const bool can_pipeline = (r.oracle_tpl == QN_ORACLE_QUAD) && !callback && !(c->world > 1 && !c->comm && !c->host_async);
     const bool sync = s->method == QN_NEWTON || s->sync_mode == 1 || (s->sync_mode == -1 && !(can_pipeline && o->memoize)) || !can_pipeline;
 
     int status = QN_ABNORMAL_TERMINATION;
@@ -2058,6 +2129,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     s->stats.total_obj_bytes += s->stats.obj_bytes;
     s->stats.path = (r.fused ? QN_PATH_FUSED : 0u) | (r.sym ? QN_PATH_SYM : 0u) | (r.sym_generic ? QN_PATH_SYM_GENERIC : 0u) |
                     (sync ? 0u : QN_PATH_PIPELINED) | (r.sym2 ? QN_PATH_SYM2 : 0u);
+    if (c->host_async_failed) { c->host_async_failed = 0; return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed"); }
     if (status == QN_ABNORMAL_TERMINATION) return fail(status, "solver state machine aborted");
     return status;
 }

@@ -154,6 +154,10 @@ class Context:
         """Collective: one verified rank-tagged all-gather through this context's exchange (RCCL or host-staged)."""
         _check(A.lib().qn_context_comm_check(self.h))
 
+    def set_host_exchange_async(self, on=True):
+        """Host-exchange contexts: run the exchange in stream order (no synchronisation), so sharded runs can be pipelined."""
+        _check(A.lib().qn_context_set_host_exchange_async(self.h, 1 if on else 0))
+
     def event_bracket_overhead_ms(self, reps=200):
         """Mean elapsed time an event / launch / event bracket reports for an empty kernel on the idle stream."""
         out = C.c_double(0.0)

@@ -193,6 +193,41 @@ def main():
                     xa, xb = s.x(), s1.x()
                     case[method + ("_rows" if rows else "_again") + "_close"] = bool(np.linalg.norm(xa - xb) <= 1e-8 * np.linalg.norm(xb))
                     case[method + ("_rows" if rows else "_again") + "_path"] = s.stats()["path"]
+            # the same exchange in STREAM ORDER (no synchronisation per exchange): the run is then pipelined -- every kernel and
+            # every exchange of an iteration enqueued ahead of the device-side decisions, as with RCCL -- and must give the same bits
+            ctx.comm_check()
+            s_sync = qn.BFGS(1e-10, x0, ctx=ctx)
+            s_sync.set_trace(iters, with_x=True)
+            try:
+                s_sync.minimize(qn.MoreThuente(), obj, iters, 20)
+            except qn.MaxIterReached:
+                pass
+            ctx.set_host_exchange_async(True)
+            ctx.comm_check()
+            s_pipe = qn.BFGS(1e-10, x0, ctx=ctx)
+            s_pipe.set_trace(iters, with_x=True)
+            try:
+                s_pipe.minimize(qn.MoreThuente(), obj, iters, 20)
+            except qn.MaxIterReached:
+                pass
+            case["pipelined_path"] = [s_sync.stats()["path"], s_pipe.stats()["path"]]
+            case["pipelined_equal"] = bool(s_sync.trace()[0] == s_pipe.trace()[0] and np.array_equal(s_sync.trace()[1], s_pipe.trace()[1]))
+            case["pipelined_syncs"] = [s_sync.stats()["host_syncs"], s_pipe.stats()["host_syncs"]]
+            # ... and on the row kernels (grouped exchanges)
+            outs = []
+            for asyn in (False, True):
+                ctx.set_host_exchange_async(asyn)
+                sr = qn.BFGS(1e-10, x0, ctx=ctx)
+                sr.set_tiling(-3, 0)
+                sr.set_trace(iters, with_x=True)
+                try:
+                    sr.minimize(qn.MoreThuente(), obj, iters, 20)
+                except qn.MaxIterReached:
+                    pass
+                outs.append((sr.trace()[1], sr.stats()["path"]))
+            case["rows_pipelined_equal"] = bool(np.array_equal(outs[0][0], outs[1][0]))
+            case["rows_pipelined_path"] = [outs[0][1], outs[1][1]]
+            ctx.set_host_exchange_async(False)
             result["cases"].append(case)
     gathered = [None] * world
     dist.all_gather_object(gathered, result)

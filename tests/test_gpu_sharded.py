@@ -40,6 +40,12 @@ def test_row_sharded_symmetric_storage(tmp_path, nproc):
                 assert case[m + "_again_path"] & 2 and not case[m + "_rows_path"] & 2
                 b_sh, b_1 = case[m + "_bytes"]
                 assert abs(nproc * b_sh - nb * (nb + 1) // 2 * 131072) <= nproc * (nb // nproc) * 131072  # balanced to one tile per block-row
+    for r in res:  # stream-ordered host exchange: pipelined (flag 8), far fewer synchronisations, the same bits
+        for case in r["cases"]:
+            assert case["pipelined_equal"] and case["rows_pipelined_equal"], case
+            assert not case["pipelined_path"][0] & 8 and case["pipelined_path"][1] & 8 and case["pipelined_path"][1] & 2
+            assert not case["rows_pipelined_path"][0] & 8 and case["rows_pipelined_path"][1] & 8
+            assert case["pipelined_syncs"][1] * 4 < case["pipelined_syncs"][0]  # (the control-block reads; the exchanges' own waits are not even counted)
     for case_i in range(len(res[0]["cases"])):
         nb = res[0]["cases"][case_i]["n"] // 128
         for m in ("bfgs", "dfp"):
