@@ -7,8 +7,9 @@
 One "step" = one BFGS iteration (direction, More-Thuente line search, rank-2 inverse-Hessian update) on the
 device-resident objective f = 1/2 x'Qx - b'x; Q, H, and every vector are in HBM before the timed region.
 N = 1 runs BASELINE.json configs[1] (n = 4096; one rank streams only the symmetric half of H and Q);
-N > 1 runs configs[2]'s problem (n = 32768) with H and Q row-sharded over the N ranks and one RCCL all-gather per mat-vec
-pass ("scaling": "strong" over N = 2,4,8).
+N > 1 runs configs[2]'s problem (n = 32768) with the rows of H and Q sharded over the N ranks; every rank streams the circulant
+half of its own block-rows (symmetric storage, as on one GPU) and one RCCL all-gather per mat-vec pass collects the ranks'
+partial n-vectors ("scaling": "strong" over N = 2,4,8).
 Timing: 5 regions, each = reset to (x0, H = I), W untimed warm-up iterations, exactly K timed iterations
 between barrier + synchronize brackets, max over ranks; the MEDIAN region is reported (all five are in `timing.region_ms`).
 Prints ONE JSON line on rank 0.  The product path is libqn_hip.so (hand-written gfx950 kernels); the CPU
@@ -148,7 +149,9 @@ def main():
         err = None
         try:
             ctx = qn.dist.sharded_context(dev, host_exchange=host_exchange)
-            ctx.comm_check()  # one verified all-gather before any solver state depends on the communicator
+            if host_exchange:
+                ctx.set_host_exchange_async(True)  # stream-ordered: the rehearsal runs the pipelined launch logic, as RCCL runs do
+            ctx.comm_check()  # verified all-gathers (single and grouped) before any solver state depends on the communicator
         except Exception as e:  # noqa: BLE001
             err = repr(e)
         okf = torch.tensor([0 if err else 1], dtype=torch.int32)
@@ -161,6 +164,7 @@ def main():
             rccl_error = err or "failed on another rank"
             host_exchange = True
             ctx = qn.dist.sharded_context(dev, host_exchange=True)
+            ctx.set_host_exchange_async(True)
             ctx.comm_check()
     else:
         ctx = qn.Context(device=local_rank)
@@ -257,11 +261,13 @@ def main():
         # conservative; the empty-kernel calibration is reported next to it for the record.
         bracket_ms = ctx.event_bracket_overhead_ms(200)
         ach = alg_h / (ms_h * 1e-3) / 1e9 if n_h else None
-        sym_pass = world == 1 and mat < 8.0 * n * n
+        sym_pass = bool(p1["path"] & 2)
         sym2 = bool(p1["path"] & 16)
         kname = ("s2_hpass_kernel (pending rank-2 update in place + row and column sums of [y, g+] over the symmetric half of H; its "
                  "prologue runs the solver's state machine)" if sym2 else
-                 "sym_hpass_tile_kernel (rank-2 update + row and column dots of [y, g+] over the upper block triangle of H)" if sym_pass else
+                 "sym_hpass_tile_kernel (rank-2 update + row and column dots of [y, g+] over the upper block triangle of H)" if (sym_pass and world == 1) else
+                 "sym_hpass_tile_kernel (rank-2 update + row and column dots of [y, g+] over this rank's share of the symmetric half of H: "
+                 "the circulant windows of its block-rows)" if sym_pass else
                  "h_pass_fused_kernel (fused rank-2 update + 2-RHS mat-vec over the rank's rows of H)")
         roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
@@ -300,7 +306,7 @@ def main():
 
     if rank == 0:
         mat_bytes = float(solver.stats()["matrix_bytes_per_pass"])  # per rank: the row shard, or the symmetric half (symmetric storage)
-        symmetric = world == 1 and mat_bytes < 8.0 * n * n
+        symmetric = bool(solver.stats()["path"] & 2)
         b_iter = world * (h_bytes + obj_bytes) / steps  # counted: (passes + read-write passes) x bytes per pass + evaluations x bytes per pass
         out = {
             "metric": METRIC, "value": its, "unit": "iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -311,9 +317,12 @@ def main():
                                    + ((", H and Q row-sharded, " + ("host-staged" if host_exchange else "RCCL") + " all-gather per pass") if world > 1 else "")
                                    + (", symmetric storage: only the symmetric half of H and Q is streamed" if symmetric else ""),
                        "matrix_layout": ("symmetric half of H and Q: 128 x 128 tiles above the diagonal + the upper triangles of the diagonal tiles"
-                                         if symmetric else "full row-major, row-sharded"),
+                                         if (symmetric and world == 1) else
+                                         "rows of H and Q sharded over the ranks; each rank streams the circulant half of its own 128-row "
+                                         "blocks (every pair of blocks once across the ranks), per-rank partial n-vectors all-gathered and "
+                                         "summed in rank order" if symmetric else "full row-major, row-sharded"),
                        "n": n, "line_search": args.ls, "tol": 1e-10, "parallelism": f"row-shard x{world}",
-                       "exchange": "none" if world == 1 else ("host-staged gloo (rehearsal)" if host_exchange else "rccl all-gather"),
+                       "exchange": "none" if world == 1 else ("host-staged gloo, stream-ordered (rehearsal)" if host_exchange else "rccl all-gather"),
                        **({"rccl_error": rccl_error} if rccl_error else {})},
             "timing": {"regions": regions, "reported": "median region", "region_ms": [1e3 * t for t in region_s],
                        "each_region": f"reset to (x0, H = I), {warmup} untimed iterations, then {steps} timed iterations",
@@ -342,7 +351,10 @@ def main():
                 ctx1 = qn.Context(device=local_rank % max(torch.cuda.device_count(), 1))
                 obj1 = qn.Quadratic.synthetic(n, SEED, diag, b, ctx=ctx1)
                 s1 = qn.BFGS(1e-10, x0, ctx=ctx1)
-                s1.set_tiling(-3, 0)  # the same algorithm as the N-rank run: fused row kernels on the full matrices
+                if symmetric:
+                    s1.set_tiling(-4, 0)  # the same kernels as the N-rank run: first-generation symmetric-storage tiles
+                else:
+                    s1.set_tiling(-3, 0)  # the same kernels as the N-rank run: fused row kernels on the full matrices
                 ref_steps = min(steps, 50)
                 run_iterations(qn, s1, ls, obj1, x0, min(warmup, 5))
                 ctx1.synchronize()
@@ -351,16 +363,17 @@ def main():
                 ctx1.synchronize()
                 dt1 = time.perf_counter() - t1
                 out["strong_scaling_ref"] = {"n_gpus": 1, "value": ref_steps / dt1, "unit": "iterations/s", "steps": ref_steps,
-                                             "note": f"same n={n} workload and the same kernels (full row-major matrices), unsharded, on rank 0's GPU "
-                                                     "after the timed region"}
-                # for the record: one GPU with the symmetric-storage path (half the bytes; not available row-sharded yet)
+                                             "note": f"same n={n} workload, same storage layout and the same kernels ("
+                                                     + ("symmetric half, first-generation tile kernels" if symmetric else "full row-major matrices")
+                                                     + "), unsharded, on rank 0's GPU after the timed region"}
+                # for the record: one GPU on its default path (symmetric storage, second-generation kernels: 5 launches per iteration)
                 s2 = qn.BFGS(1e-10, x0, ctx=ctx1)
                 run_iterations(qn, s2, ls, obj1, x0, min(warmup, 5))
                 ctx1.synchronize()
                 t2 = time.perf_counter()
                 run_iterations(qn, s2, ls, obj1, x0, ref_steps)
                 ctx1.synchronize()
-                out["strong_scaling_ref"]["single_gpu_symmetric_storage_value"] = ref_steps / (time.perf_counter() - t2)
+                out["strong_scaling_ref"]["single_gpu_default_path_value"] = ref_steps / (time.perf_counter() - t2)
                 del s1, s2, obj1, ctx1
             except Exception as e:  # noqa: BLE001 -- the reference leg must never lose the bench line
                 out["strong_scaling_ref"] = {"error": repr(e)}
