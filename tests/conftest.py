@@ -21,8 +21,12 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
-    # -m gpu on a box without a GPU must fail loudly, not skip: the HIP path is the product.
-    pass
+    # -m gpu on a box without a GPU must fail loudly, not skip or pass vacuously: the HIP path is the product.
+    expr = config.getoption("-m") or ""
+    wants_gpu = "gpu" in expr and "not gpu" not in expr
+    if wants_gpu and any(item.get_closest_marker("gpu") for item in items) and not _has_gpu():
+        raise pytest.UsageError("-m gpu was selected but no HIP device is visible: these tests drive libqn_hip.so on an MI355X "
+                                "and there is no CPU fallback to test instead")
 
 
 @pytest.fixture(scope="session")

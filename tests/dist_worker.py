@@ -149,11 +149,13 @@ def main():
             iters = 12
             diag = P.synth_diag(n)
             b, x0 = P.synth_vectors(n)
-            ctx = qn.dist.sharded_context(0, host_exchange=True)
+            rccl = os.environ.get("QN_TEST_EXCHANGE") == "rccl"  # one GPU per rank and the real collective (multi-GPU boxes only)
+            dev = rank if rccl else 0
+            ctx = qn.dist.sharded_context(dev, host_exchange=not rccl)
             obj = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx)
-            ctx1 = qn.Context(0)
+            ctx1 = qn.Context(dev)
             obj1 = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx1)
-            case = {"n": n}
+            case = {"n": n, "rccl": rccl}
             for method in ("bfgs", "dfp"):
                 mk = qn.BFGS if method == "bfgs" else qn.DFP
                 s = mk(1e-10, x0, ctx=ctx)
@@ -202,6 +204,32 @@ def main():
                 s_sync.minimize(qn.MoreThuente(), obj, iters, 20)
             except qn.MaxIterReached:
                 pass
+            if rccl:  # RCCL runs are pipelined by default: the synchronous pump is the other mode to compare with
+                s_sync2 = qn.BFGS(1e-10, x0, ctx=ctx)
+                s_sync2.set_sync_mode(1)
+                s_sync2.set_trace(iters, with_x=True)
+                try:
+                    s_sync2.minimize(qn.MoreThuente(), obj, iters, 20)
+                except qn.MaxIterReached:
+                    pass
+                case["pipelined_path"] = [s_sync2.stats()["path"], s_sync.stats()["path"]]
+                case["pipelined_equal"] = bool(s_sync2.trace()[0] == s_sync.trace()[0] and np.array_equal(s_sync2.trace()[1], s_sync.trace()[1]))
+                case["pipelined_syncs"] = [s_sync2.stats()["host_syncs"], s_sync.stats()["host_syncs"]]
+                outs = []
+                for sync in (1, 0):
+                    sr = qn.BFGS(1e-10, x0, ctx=ctx)
+                    sr.set_tiling(-3, 0)
+                    sr.set_sync_mode(sync)
+                    sr.set_trace(iters, with_x=True)
+                    try:
+                        sr.minimize(qn.MoreThuente(), obj, iters, 20)
+                    except qn.MaxIterReached:
+                        pass
+                    outs.append((sr.trace()[1], sr.stats()["path"]))
+                case["rows_pipelined_equal"] = bool(np.array_equal(outs[0][0], outs[1][0]))
+                case["rows_pipelined_path"] = [outs[0][1], outs[1][1]]
+                result["cases"].append(case)
+                continue
             ctx.set_host_exchange_async(True)
             ctx.comm_check()
             s_pipe = qn.BFGS(1e-10, x0, ctx=ctx)

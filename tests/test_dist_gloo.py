@@ -15,11 +15,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(mode, tmp_path, nproc=2, timeout=300):
+def launch(mode, tmp_path, nproc=2, timeout=300, extra_env=None):
     out = os.path.join(str(tmp_path), f"dist_{mode}.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), mode, out]
-    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     with open(out) as fh:

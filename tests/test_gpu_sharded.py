@@ -21,12 +21,15 @@ def test_two_ranks_on_one_gpu_equal_single_rank_bitwise(tmp_path):
         assert r["lse_eval_close"] and r["lse_dfp_close"], r
 
 
-@pytest.mark.parametrize("nproc", [2, 3])
-def test_row_sharded_symmetric_storage(tmp_path, nproc):
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _check_sharded_symmetric(res, nproc):
     """Row-sharded runs stream the symmetric half too (circulant windows over the block-rows, qn_sym.hip.h): two / three ranks
     on the one GPU against the single-rank run -- same line-search decisions, iterates to the parity tolerance, identical bits
     on every rank, half the matrix bytes per pass, and the getters / the row kernels see a whole matrix again afterwards."""
-    res = launch("gpu_sym", tmp_path, nproc=nproc, timeout=900)
     assert len(res) == nproc
     for r in res:
         for case in r["cases"]:
@@ -53,3 +56,14 @@ def test_row_sharded_symmetric_storage(tmp_path, nproc):
             assert sum(r["cases"][case_i][m + "_bytes"][0] for r in res) == nb * (nb + 1) // 2 * 131072
             assert len({tuple(r["cases"][case_i][m + "_x_hex"]) for r in res}) == 1  # replicated vector work: same bits everywhere
             assert len({tuple(r["cases"][case_i][m + "_h_hex"]) for r in res}) == 1
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_row_sharded_symmetric_storage(tmp_path, nproc):
+    _check_sharded_symmetric(launch("gpu_sym", tmp_path, nproc=nproc, timeout=900), nproc)
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs: the RCCL exchange between two devices (never available to this build so far)")
+def test_row_sharded_symmetric_storage_over_rccl_two_gpus(tmp_path):
+    """The same checks with one GPU per rank and the real RCCL all-gathers (single and grouped), pipelined against synchronous."""
+    _check_sharded_symmetric(launch("gpu_sym", tmp_path, nproc=2, timeout=900, extra_env={"QN_TEST_EXCHANGE": "rccl"}), 2)
