@@ -62,6 +62,10 @@ int qn_context_create_sharded(int device, int rank, int world, const void* uniqu
 typedef int (*qn_host_allgather_fn)(void* user, const double* sendbuf, double* recvbuf, size_t count);
 int qn_context_create_sharded_host_exchange(int device, int rank, int world, qn_host_allgather_fn fn, void* user,
                                             qn_context** out);
+/* Row-sharded runs on symmetric storage exchange per-rank PARTIAL n-vectors.  Default (on = 0): one all-gather, every rank adds
+ * the P contributions in rank order -- bitwise identical on all ranks, and identical between RCCL and the host-staged exchange.
+ * on != 0: ncclAllReduce(ncclSum) instead (the operation north_star names; 1/P of the bytes, RCCL's summation order). */
+int qn_context_set_allreduce(qn_context* ctx, int on);
 /* Host-exchange contexts only: on != 0 makes every exchange a stream-ordered triple (device-to-pinned copy, the callback as a
  * host node of the stream, pinned-to-device copy) with no synchronisation, so the pipelined launch logic -- which RCCL runs use
  * -- can be rehearsed with several ranks on one GPU.  The callback then runs on a runtime thread, not on the caller's. */

@@ -60,12 +60,14 @@ struct RcclApi {
     int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
     int (*CommDestroy)(RcclComm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr; // optional (qn_context_set_allreduce)
     const char* (*GetErrorString)(int) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
 };
 static RcclApi g_rccl;
 static const int kRcclDouble = 8; // ncclFloat64 / ncclDouble (rccl.h)
+static const int kRcclSum = 0;    // ncclSum
 
 static int rccl_load() {
     if (g_rccl.handle) return QN_OK;
@@ -80,6 +82,7 @@ static int rccl_load() {
     g_rccl.CommInitRank = (int (*)(RcclComm*, int, RcclUniqueId, int))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (int (*)(RcclComm))dlsym(h, "ncclCommDestroy");
     g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t))dlsym(h, "ncclAllReduce");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
     g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
     g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
@@ -111,6 +114,7 @@ struct qn_context {
     // host-staged exchange in STREAM ORDER (qn_context_set_host_exchange_async): pinned staging, the callback runs as a
     // hipLaunchHostFunc node between the two copies, nothing synchronises -- the pipelined launch logic can then be rehearsed
     // with several ranks on one GPU
+    int use_allreduce = 0; // symmetric-storage sharded runs: ncclAllReduce of the partial n-vectors instead of all-gather + rank-order sum
     int host_async = 0;
     double* pin = nullptr; // [send (cap) | recv (cap * world)]
     size_t pin_cap = 0;
@@ -203,6 +207,12 @@ extern "C" int qn_context_synchronize(qn_context* c) {
     if (c->host_async_failed) { c->host_async_failed = 0; return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed"); }
     return QN_OK;
 }
+extern "C" int qn_context_set_allreduce(qn_context* c, int on) {
+    if (!c) return fail(QN_ERROR_INPUT_PARAMS, "context is null");
+    if (on && c->comm && !g_rccl.AllReduce) return fail(QN_ERROR_INPUT_PARAMS, "librccl has no ncclAllReduce");
+    c->use_allreduce = on ? 1 : 0;
+    return QN_OK;
+}
 extern "C" int qn_context_set_host_exchange_async(qn_context* c, int on) {
     if (!c) return fail(QN_ERROR_INPUT_PARAMS, "context is null");
     if (on && c->world > 1 && !c->host_xchg) return fail(QN_ERROR_INPUT_PARAMS, "not a host-exchange context");
@@ -261,6 +271,30 @@ static int exchange_group(qn_context* c, const XchgItem* items, int nitems) {
         return QN_OK;
     }
     for (int i = 0; i < nitems; ++i) QNCHK(exchange(c, items[i].buf, items[i].count));
+    return QN_OK;
+}
+
+// Sum of `count` doubles per rank over the ranks: rank r's contribution lives at buf + r*count, the total lands in buf[0..count).
+// RCCL: ncclAllReduce(ncclSum) -- the operation north_star names; its summation order is RCCL's (ring / tree), identical on all
+// ranks but not the rank order of the default all-gather path.  Host exchange (tests): gathered and added in rank order.
+__global__ void xchg_rank_sum_kernel(double* __restrict__ buf, size_t count, int world) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        double acc = buf[i];
+        for (int r = 1; r < world; ++r) acc = acc + buf[(size_t)r * count + i];
+        buf[i] = acc;
+    }
+}
+static int exchange_sum(qn_context* c, double* buf, size_t count) {
+    if (c->world == 1) return QN_OK;
+    if (c->comm) {
+        if (!g_rccl.AllReduce) return fail(QN_ABNORMAL_TERMINATION, "librccl has no ncclAllReduce");
+        c->n_comm++;
+        RCCLCHK(g_rccl.AllReduce(buf + (size_t)c->rank * count, buf, count, kRcclDouble, kRcclSum, c->comm, c->stream));
+        return QN_OK;
+    }
+    QNCHK(exchange(c, buf, count));
+    hipLaunchKernelGGL(xchg_rank_sum_kernel, dim3((unsigned)std::min<size_t>((count + 255) / 256, 1024)), dim3(256), 0, c->stream, buf, count, c->world);
+    HIPCHK(hipGetLastError());
     return QN_OK;
 }
 
@@ -1151,6 +1185,7 @@ static QnSymShard sym_shard(const qn_solver* s) {
     sh.world = s->ctx->world; sh.rank = s->ctx->rank;
     sh.nbl = s->T.rpr / QN_TB; sh.ioff = sh.rank * sh.nbl;
     sh.xg = s->symsh_xg;
+    sh.nsum = s->ctx->use_allreduce ? 1 : sh.world; // all-reduce mode: the exchange already left the total in slice 0
     return sh;
 }
 
@@ -1549,7 +1584,8 @@ static int enqueue_eval_fused(Run& r, int after_h) {
             HIPCHK(hipGetLastError());
             {
                 ProfScope ps(s, KC_COMM);
-                QNCHK(exchange(c, s->symsh_xg, (size_t)s->T.n_pad));
+                if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, (size_t)s->T.n_pad));
+                else QNCHK(exchange(c, s->symsh_xg, (size_t)s->T.n_pad));
             }
             {
                 ProfScope ps(s, KC_EREDUCE);
@@ -1608,7 +1644,8 @@ static int enqueue_hpass_fused(Run& r) {
             HIPCHK(hipGetLastError());
             {
                 ProfScope ps(s, KC_COMM);
-                QNCHK(exchange(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
+                if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
+                else QNCHK(exchange(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
             }
             {
                 ProfScope ps(s, KC_HREDUCE);

@@ -41,6 +41,7 @@ template <bool NT> __device__ __forceinline__ void qn_sym_st(double* p, v2d v) {
 // (symsh_*_epi_kernel) -- replicated work on n-vectors, identical bits on every rank.  world == 1: the fields are unused.
 struct QnSymShard {
     int world, rank, nbl, ioff;
+    int nsum;   // slices of xg to add up after the exchange: world (all-gather, rank order), or 1 (an all-reduce left the total in slice 0)
     double* xg; // gathered partial sums: [world][nrhs][n_pad], rank r's slice written by rank r
 };
 __device__ __host__ __forceinline__ int qn_symsh_cnt(int I, int nb) { return (nb & 1) ? (nb + 1) / 2 : (I < nb / 2 ? nb / 2 + 1 : nb / 2); }
@@ -347,7 +348,7 @@ __device__ __forceinline__ double qn_symsh_slot_sum(const double* __restrict__ p
 __device__ __forceinline__ double qn_symsh_rank_sum(const QnSymShard& sh, int nrhs, int rhs, size_t np, int gi) {
     const double* p = sh.xg + (size_t)rhs * np + gi;
     double acc = p[0];
-    for (int r = 1; r < sh.world; ++r) acc = acc + p[(size_t)r * nrhs * np];
+    for (int r = 1; r < sh.nsum; ++r) acc = acc + p[(size_t)r * nrhs * np];
     return acc;
 }
 

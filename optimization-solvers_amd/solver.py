@@ -154,6 +154,10 @@ class Context:
         """Collective: one verified rank-tagged all-gather through this context's exchange (RCCL or host-staged)."""
         _check(A.lib().qn_context_comm_check(self.h))
 
+    def set_allreduce(self, on=True):
+        """Sharded symmetric storage: all-reduce the partial n-vectors (RCCL's order) instead of all-gather + rank-order sum."""
+        _check(A.lib().qn_context_set_allreduce(self.h, 1 if on else 0))
+
     def set_host_exchange_async(self, on=True):
         """Host-exchange contexts: run the exchange in stream order (no synchronisation), so sharded runs can be pipelined."""
         _check(A.lib().qn_context_set_host_exchange_async(self.h, 1 if on else 0))

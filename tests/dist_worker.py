@@ -204,6 +204,19 @@ def main():
                 s_sync.minimize(qn.MoreThuente(), obj, iters, 20)
             except qn.MaxIterReached:
                 pass
+            # the exchange as an all-reduce of the partial vectors (ncclAllReduce with RCCL; gathered and added in rank order by
+            # the host-staged stand-in, hence bit-identical to the default there, tolerance-level with RCCL's own order)
+            ctx.set_allreduce(True)
+            s_ar = qn.BFGS(1e-10, x0, ctx=ctx)
+            s_ar.set_trace(iters, with_x=True)
+            try:
+                s_ar.minimize(qn.MoreThuente(), obj, iters, 20)
+            except qn.MaxIterReached:
+                pass
+            ctx.set_allreduce(False)
+            xa, xb = s_ar.trace()[1], s_sync.trace()[1]
+            case["allreduce_ok"] = bool(np.array_equal(xa, xb)) if not rccl else bool(np.linalg.norm(xa - xb) <= 1e-9 * np.linalg.norm(xb))
+            case["allreduce_x_hex"] = [float(v).hex() for v in xa[-1][:64]]
             if rccl:  # RCCL runs are pipelined by default: the synchronous pump is the other mode to compare with
                 s_sync2 = qn.BFGS(1e-10, x0, ctx=ctx)
                 s_sync2.set_sync_mode(1)

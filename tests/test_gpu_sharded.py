@@ -45,7 +45,7 @@ def _check_sharded_symmetric(res, nproc):
                 assert abs(nproc * b_sh - nb * (nb + 1) // 2 * 131072) <= nproc * (nb // nproc) * 131072  # balanced to one tile per block-row
     for r in res:  # stream-ordered host exchange: pipelined (flag 8), far fewer synchronisations, the same bits
         for case in r["cases"]:
-            assert case["pipelined_equal"] and case["rows_pipelined_equal"], case
+            assert case["pipelined_equal"] and case["rows_pipelined_equal"] and case["allreduce_ok"], case
             assert not case["pipelined_path"][0] & 8 and case["pipelined_path"][1] & 8 and case["pipelined_path"][1] & 2
             assert not case["rows_pipelined_path"][0] & 8 and case["rows_pipelined_path"][1] & 8
             assert case["pipelined_syncs"][1] * 4 < case["pipelined_syncs"][0]  # (the control-block reads; the exchanges' own waits are not even counted)
@@ -56,6 +56,7 @@ def _check_sharded_symmetric(res, nproc):
             assert sum(r["cases"][case_i][m + "_bytes"][0] for r in res) == nb * (nb + 1) // 2 * 131072
             assert len({tuple(r["cases"][case_i][m + "_x_hex"]) for r in res}) == 1  # replicated vector work: same bits everywhere
             assert len({tuple(r["cases"][case_i][m + "_h_hex"]) for r in res}) == 1
+        assert len({tuple(r["cases"][case_i]["allreduce_x_hex"]) for r in res}) == 1  # all-reduce mode: the same bits on every rank too
 
 
 @pytest.mark.parametrize("nproc", [2, 3])
