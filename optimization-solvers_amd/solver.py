@@ -238,7 +238,47 @@ class _LineSearch:
         return t.value
 
 
-class MoreThuente(_LineSearch):
+def _device_dot(a, b, ctx=None):
+    """a.b with the library's dot kernel (nalgebra's accumulation order, mod.rs:35,47,55), operands uploaded for the call"""
+    ctx = ctx or default_context()
+    a, b = _f64(a), _f64(b)
+    da, db = DeviceBuffer(ctx, a), DeviceBuffer(ctx, b)
+    try:
+        return dot(ctx, a.size, da, db)
+    finally:
+        da.free()
+        db.free()
+
+
+class _WolfeConditions:
+    """SufficientDecreaseCondition / CurvatureCondition / WolfeConditions (line_search/mod.rs:25-83) as the reference's line-search
+    structs expose them; the dots run on the device.  (The line searches themselves evaluate these tests inside the device state
+    machine; these methods exist so that caller code written against the traits keeps working.)"""
+
+    def c1(self):
+        return self.s.c1 if self.s.kind in (A.LS_MORETHUENTE, A.LS_MORETHUENTE_B) else self.s.bt_c1
+
+    def c2(self):
+        return self.s.c2
+
+    def sufficient_decrease(self, f_k, f_kp1, grad_k, t, direction_k):  # mod.rs:27-36
+        return f_kp1 - f_k <= self.c1() * t * _device_dot(grad_k, direction_k)
+
+    def curvature_condition(self, grad_k, grad_kp1, direction_k):  # mod.rs:41-48
+        return _device_dot(grad_kp1, direction_k) >= self.c2() * _device_dot(grad_k, direction_k)
+
+    def strong_curvature_condition(self, grad_k, grad_kp1, direction_k):  # mod.rs:49-56
+        return abs(_device_dot(grad_kp1, direction_k)) <= self.c2() * abs(_device_dot(grad_k, direction_k))
+
+    def wolfe_conditions_with_directional_derivative(self, f_k, f_kp1, grad_k, grad_kp1, t, direction_k):  # mod.rs:60-71
+        return self.sufficient_decrease(f_k, f_kp1, grad_k, t, direction_k) and self.curvature_condition(grad_k, grad_kp1, direction_k)
+
+    def strong_wolfe_conditions_with_directional_derivative(self, f_k, f_kp1, grad_k, grad_kp1, t, direction_k):  # mod.rs:72-83
+        return (self.sufficient_decrease(f_k, f_kp1, grad_k, t, direction_k)
+                and self.strong_curvature_condition(grad_k, grad_kp1, direction_k))
+
+
+class MoreThuente(_LineSearch, _WolfeConditions):
     """morethuente.rs:6-62"""
 
     def __init__(self):
@@ -270,8 +310,8 @@ class MoreThuente(_LineSearch):
         return self
 
 
-class BackTracking(_LineSearch):
-    """backtracking.rs:3-11"""
+class BackTracking(_LineSearch, _WolfeConditions):
+    """backtracking.rs:3-11 (implements SufficientDecreaseCondition only, backtracking.rs:13-18: `c2` is not meaningful here)"""
 
     def __init__(self, c1, beta):
         self.s = A.LineSearchStruct()

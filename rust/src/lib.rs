@@ -21,7 +21,8 @@ pub mod ffi;
 use ffi::*;
 use nalgebra::{DMatrix, DVector};
 use optimization_solvers::{
-    ComputeDirection, Floating, FuncEvalMultivariate, LineSearch, LineSearchSolver, MoreThuente, SolverError,
+    ComputeDirection, CurvatureCondition, Floating, FuncEvalMultivariate, LineSearch, LineSearchSolver, MoreThuente, SolverError,
+    SufficientDecreaseCondition,
 };
 use std::ffi::CStr;
 use std::os::raw::{c_int, c_void};
@@ -230,6 +231,25 @@ macro_rules! impl_line_search {
 }
 impl_line_search!(GpuMoreThuente);
 impl_line_search!(GpuBackTracking);
+
+// The condition traits of line_search/mod.rs:25-83, as the reference implements them for its own structs (morethuente.rs,
+// backtracking.rs:13-18): only the sensitivities are supplied, the tests themselves are the traits' default methods (and
+// `WolfeConditions` follows from the blanket impl, mod.rs:85-86).
+impl SufficientDecreaseCondition for GpuMoreThuente {
+    fn c1(&self) -> Floating {
+        self.ls.c1
+    }
+}
+impl CurvatureCondition for GpuMoreThuente {
+    fn c2(&self) -> Floating {
+        self.ls.c2
+    }
+}
+impl SufficientDecreaseCondition for GpuBackTracking {
+    fn c1(&self) -> Floating {
+        self.ls.bt_c1
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // a device-resident objective (the benchmark's dense quadratic; log-sum-exp): evaluated by the library's own kernels

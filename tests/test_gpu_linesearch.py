@@ -76,3 +76,26 @@ def test_more_thuente_b_keeps_its_clipped_t_max(qn, qo):
     t_ref = qo.compute_step_len(ref, x, f, g, d, fn, 20)
     assert t == t_ref and t <= 0.5
     assert ls.s.t_max == ref.t_max == 0.5
+
+
+def test_wolfe_condition_predicates_of_the_line_search_structs(qn):
+    """SufficientDecreaseCondition / CurvatureCondition / WolfeConditions (line_search/mod.rs:25-83) on the mirror's line-search
+    structs: the weak and the strong curvature test, Armijo, and both conjunctions, against the formulas"""
+    rng = np.random.default_rng(12)
+    n = 300
+    g0, g1, d = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    d = -g0 + 0.1 * d  # a descent direction
+    mt = qn.MoreThuente().with_c1(1e-3).with_c2(0.8)
+    bt = qn.BackTracking(0.2, 0.5)
+    assert mt.c1() == 1e-3 and mt.c2() == 0.8 and bt.c1() == 0.2
+    gd0, gd1 = float(g0 @ d), float(g1 @ d)
+    for t, f0, f1 in [(1.0, 3.0, 3.0 + 1e-3 * gd0 * 0.5), (0.5, 3.0, 2.0), (1.0, 3.0, 3.5), (2.0, 0.0, 2.0 * 0.2 * gd0)]:
+        assert mt.sufficient_decrease(f0, f1, g0, t, d) == (f1 - f0 <= 1e-3 * t * gd0)
+        assert bt.sufficient_decrease(f0, f1, g0, t, d) == (f1 - f0 <= 0.2 * t * gd0)
+    for scale in (0.1, 0.79, 0.81, 1.5, -0.5, -1.2):
+        gk1 = g1 - ((gd1 - scale * gd0) / (d @ d)) * d  # g1 moved so that g1.d = scale * g0.d
+        weak, strong = mt.curvature_condition(g0, gk1, d), mt.strong_curvature_condition(g0, gk1, d)
+        assert weak == (scale * gd0 >= 0.8 * gd0) and strong == (abs(scale * gd0) <= 0.8 * abs(gd0)), scale
+        assert mt.wolfe_conditions_with_directional_derivative(3.0, 2.0, g0, gk1, 0.5, d) == weak
+        assert mt.strong_wolfe_conditions_with_directional_derivative(3.0, 2.0, g0, gk1, 0.5, d) == strong
+        assert not mt.strong_wolfe_conditions_with_directional_derivative(3.0, 3.5, g0, gk1, 1.0, d)

@@ -8,6 +8,7 @@ mkdir -p $out
 timeout -k 10 1500 python -m pytest tests -x -q -m gpu > $out/pytest.log 2>&1
 echo "pytest rc=$?" | tee -a $out/pytest.log
 tail -3 $out/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $out/smoke.log; tail -1 $out/smoke.log
 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_steps20.json 2> $out/bench_steps20.err || echo "bench20 failed"
 python bench.py > $out/bench_default.json 2> $out/bench_default.err || echo "bench default failed"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
