@@ -299,6 +299,14 @@ __device__ __forceinline__ int qn_s2_first_item(int g, int nb) {
 //   * lanes right of it (l >= 8 w + 8) work as in an off-diagonal tile.
 // So a diagonal item differs from an off-diagonal one by three per-lane constants; the row loop is the same straight-line code.
 // (The sub-blocks below the diagonal ones are not maintained: sym2_mirror_kernel restores them with the lower block triangle.)
+//
+// Measured and dropped (round 2, same-box A/B with tools/ab.sh, n = 4096): a second, look-ahead window in LDS -- the item after the
+// one in registers fetched by direct global-to-LDS loads (global_load_lds_dwordx4, 128 KB of dynamic LDS), requested while thread 0
+// runs the state machine, copied into the register window at the item boundary, no loads left in the row loops.  In-kernel time
+// stamps improved as predicted (row loops 2.0 -> 0.8 us and 0.8 -> 0.44 us, median workgroup 19.2 -> 17.5 us) but the launch as the
+// stream sees it got 3 us LONGER (event bracket 24.5 -> 27.6 us), and the iteration 88.3 -> 91.5 us.  With the compiler's builtin
+// instead of inline assembly every LDS access after a request waits for all outstanding loads (the state machine then sits behind
+// the whole tile window: +3 us in the prologue).  Also measured: the work list read one item ahead of its use (no change).
 __device__ __forceinline__ int qn_s2_col(bool diag, int lane, int wave) { return 2 * (diag ? max(lane, 8 * wave) : lane); }
 __device__ __forceinline__ bool qn_s2_row_on(bool diag, int lane, int wave) { return !diag || lane >= 8 * wave; }     // multiplier entries kept
 __device__ __forceinline__ bool qn_s2_col_on(bool diag, int lane, int wave) { return !diag || lane >= 8 * wave + 8; } // column sums kept
