@@ -2046,8 +2046,9 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.wgE = s->s2_wgE; a.hrp = s->s2_wgH; a.rp = s->s2_rp; a.ctl2 = s->s2_ctl;
         a.trace = s->V.trace; a.xtrace = s->V.xtrace;
         a.nt = s->T.n_pad >= 8192; // H past the Infinity Cache: every byte is touched once per pass
+        // (no synchronisation: the copy is stream-ordered in front of the launches, the mirror is pinned, and the host does not
+        // write it again before s2_peek has synchronised)
         HIPCHK(hipMemcpyAsync(s->s2_ctl, s->hctl, sizeof(QnCtl), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
     } else {
         QNCHK(poke_ctl(s));
     }
