@@ -145,7 +145,7 @@ def main():
         # partial n-vectors are all-gathered (host-staged here) and summed in rank order.  Against the single-rank run of the same
         # problem: same line-search cases and evaluation counts, iterates to the parity tolerance; between ranks: the same bits.
         result["cases"] = []
-        for n in ([1024, 2048] if world == 2 else [128 * 3 * world]):  # nb = 8, 16 (even); world 3: nb = 9 (odd)
+        for n in ([1024, 2048, 2040] if world == 2 else [128 * 3 * world]):  # nb = 8, 16 (even), 16 with 8 padding rows; world 3: nb = 9 (odd)
             iters = 12
             diag = P.synth_diag(n)
             b, x0 = P.synth_vectors(n)

@@ -34,7 +34,7 @@ def _check_sharded_symmetric(res, nproc):
     for r in res:
         for case in r["cases"]:
             n = case["n"]
-            nb = n // 128
+            nb = (n + 127) // 128
             for m in ("bfgs", "dfp"):
                 assert case[m + "_close"] and case[m + "_h_symmetric"] and case[m + "_h_close"], (r["rank"], case)
                 assert case[m + "_again_close"] and case[m + "_rows_close"], (r["rank"], case)
@@ -50,7 +50,7 @@ def _check_sharded_symmetric(res, nproc):
             assert not case["rows_pipelined_path"][0] & 8 and case["rows_pipelined_path"][1] & 8
             assert case["pipelined_syncs"][1] * 4 < case["pipelined_syncs"][0]  # (the control-block reads; the exchanges' own waits are not even counted)
     for case_i in range(len(res[0]["cases"])):
-        nb = res[0]["cases"][case_i]["n"] // 128
+        nb = (res[0]["cases"][case_i]["n"] + 127) // 128
         for m in ("bfgs", "dfp"):
             # the ranks' tiles together are the half matrix exactly: every pair of block-rows once
             assert sum(r["cases"][case_i][m + "_bytes"][0] for r in res) == nb * (nb + 1) // 2 * 131072
