@@ -1737,6 +1737,30 @@ static int enqueue_hpass_req(Run& r) {
         y.generic = 1; y.gsp = s->V.sp; y.gup = s->V.up; y.gvy = s->V.y; y.gvg = s->V.g; y.ghp = s->V.hp;
         y.nt = s->T.n_pad >= 8192; // past the Infinity Cache (same-box A/B: +7 % at n = 32768, +3 % at 8192, -1 % at 4096)
         s->h_lower_stale = true;
+        if (c->world > 1) { // row-sharded: the circulant half of this rank's block-rows; partial sums gathered, totals on every rank
+            y.sh = sym_shard(s);
+            {
+                ProfScope ps(s, KC_HPASS);
+                hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(qn_symsh_ntiles(y.nb, y.sh.nbl, y.sh.ioff)), dim3(QN_SYM_TPB), 0, c->stream, y);
+            }
+            {
+                ProfScope ps(s, KC_HREDUCE);
+                hipLaunchKernelGGL(symsh_hpass_sum_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
+            }
+            HIPCHK(hipGetLastError());
+            {
+                ProfScope ps(s, KC_COMM);
+                if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
+                else QNCHK(exchange(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
+            }
+            {
+                ProfScope ps(s, KC_HREDUCE);
+                hipLaunchKernelGGL(symsh_hpass_epi_generic_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
+            }
+            s->stats.launches += 3;
+            HIPCHK(hipGetLastError());
+            return QN_OK;
+        }
         {
             ProfScope ps(s, KC_HPASS);
             hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
@@ -2001,8 +2025,9 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     const bool symsh_ok = c->world > 1 && (s->T.rpr % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
     r.sym = r.fused && (sym_ok || symsh_ok) && r.obj && r.obj->q_symmetric;
     // the generic path's H pass alone (closures, log-sum-exp objective, SR1, bounded variants): same tiles, sums into V.hp
-    r.sym_generic = !r.fused && sym_ok && s->H && s->hcs == 1 && (s->method == QN_BFGS || s->method == QN_DFP || s->method == QN_SR1);
+    r.sym_generic = !r.fused && (sym_ok || symsh_ok) && s->H && s->hcs == 1 && (s->method == QN_BFGS || s->method == QN_DFP || s->method == QN_SR1);
     if (r.sym_generic) {
+        if (c->world > 1 && !s->symsh_xg) QNCHK(dev_alloc_zero(&s->symsh_xg, (size_t)c->world * 2 * s->T.n_pad, c->stream));
         const int nb = s->T.n_pad / QN_TB;
         if (s->sym_nb != nb) {
             if (s->sym_part) { HIPCHK(hipFree(s->sym_part)); s->sym_part = nullptr; }
@@ -2151,7 +2176,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     uint64_t shard = (uint64_t)s->T.rpr * (uint64_t)s->T.n_pad * 8ull;
     const uint64_t full_shard = shard;
     if (r.sym || r.sym_generic) shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb + 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull; // the streamed tiles
-    if (r.sym && c->world > 1) shard = (uint64_t)qn_symsh_ntiles(s->sym_nb, s->T.rpr / QN_TB, c->rank * (s->T.rpr / QN_TB)) * (uint64_t)QN_TB * QN_TB * 8ull;
+    if ((r.sym || r.sym_generic) && c->world > 1) shard = (uint64_t)qn_symsh_ntiles(s->sym_nb, s->T.rpr / QN_TB, c->rank * (s->T.rpr / QN_TB)) * (uint64_t)QN_TB * QN_TB * 8ull;
     if (r.sym2) // diagonal tiles: wave w (rows 16 w ...) reads 64 - 8 w lanes of 16 bytes per row = 73 728 of the 131 072 bytes
         shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb - 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull + (uint64_t)s->sym_nb * 73728ull;
     s->stats.h_bytes = (h->n_hpasses + h->n_hpass_rw) * shard;

@@ -595,6 +595,19 @@ __global__ __launch_bounds__(256) void symsh_hpass_epi_kernel(const QnSymHPassAr
     qn_sym_hpass_epilogue(a, ctl->sc, nrhs, R, t0, t1, red);
 }
 
+// ... the generic path's variant: the totals go to the gathered h_pass output the control step reads ([P][2][rpr], rank-major)
+__global__ __launch_bounds__(256) void symsh_hpass_epi_generic_kernel(const QnSymHPassArgs a) {
+    const QnCtl* __restrict__ ctl = a.ctl;
+    if (ctl->phase != a.expect_phase) return;
+    const int nrhs = ctl->hp_nrhs;
+    if (nrhs == 0 || threadIdx.x >= QN_TB) return; // (0: the pass only applied the pending update)
+    const int gi = blockIdx.x * QN_TB + (int)threadIdx.x;
+    const size_t np = (size_t)a.T.n_pad, rpr = (size_t)a.T.rpr;
+    double* out = a.ghp + ((size_t)gi / rpr) * 2 * rpr + (size_t)gi % rpr;
+    out[0] = qn_symsh_rank_sum(a.sh, 2, 0, np, gi);
+    if (nrhs == 2) out[rpr] = qn_symsh_rank_sum(a.sh, 2, 1, np, gi);
+}
+
 // row-sharded runs, after a run: restore the block-rows' stale halves from the ranks that maintain them.  Step `il` of nbl: every
 // rank has contributed its local block-row il (128 whole rows) to `gath` [world][128][n_pad]; workgroup (jl, p) copies the
 // transpose of tile (I_p, J) -- I_p = p*nbl + il, J = ioff + jl -- into the local tile (J, I_p) when block-row I_p owns the pair.

@@ -195,6 +195,40 @@ def main():
                     xa, xb = s.x(), s1.x()
                     case[method + ("_rows" if rows else "_again") + "_close"] = bool(np.linalg.norm(xa - xb) <= 1e-8 * np.linalg.norm(xb))
                     case[method + ("_rows" if rows else "_again") + "_path"] = s.stats()["path"]
+            # the GENERIC path (closures, log-sum-exp, SR1, bounded variants) runs its H pass on the same sharded tiles
+            gen = {}
+            for label, cx, ob in (("sh", ctx, obj), ("one", ctx1, obj1)):
+                sg = qn.DFP(1e-10, x0, ctx=cx)
+                sg.set_tiling(-1, 0)
+                sg.set_trace(8, with_x=True)
+                try:
+                    sg.minimize(qn.MoreThuente(), ob, 8, 20)
+                except qn.MaxIterReached:
+                    pass
+                gen[label] = (sg.trace(), sg.stats()["path"], sg.stats()["matrix_bytes_per_pass"])
+            (tg, xg), (t1, x1) = gen["sh"][0], gen["one"][0]
+            case["generic_close"] = bool(len(tg) == len(t1) and [r_["ls_cases"] for r_ in tg] == [r_["ls_cases"] for r_ in t1]
+                                         and np.linalg.norm(xg - x1) <= 1e-9 * np.linalg.norm(x1))
+            case["generic_path"] = [gen["sh"][1], gen["one"][1]]
+            case["generic_bytes"] = gen["sh"][2]
+            if n == 1024:  # log-sum-exp objective (rows of A sharded) + DFP: config 5's shape in small
+                rng = np.random.default_rng(7)
+                a_ = rng.standard_normal((300, n)) * (3.0 / np.sqrt(n))
+                c_ = rng.standard_normal(300)
+                xs0 = rng.standard_normal(n)
+                outs_l = []
+                for cx in (ctx, ctx1):
+                    lse = qn.LogSumExp(a_, c_, 0.1, ctx=cx)
+                    sl = qn.DFP(1e-10, xs0, ctx=cx)
+                    sl.set_trace(10, with_x=True)
+                    try:
+                        sl.minimize(qn.MoreThuente(), lse, 10, 20)
+                    except qn.MaxIterReached:
+                        pass
+                    outs_l.append((sl.trace(), sl.stats()["path"]))
+                (tl, xl), (tl1, xl1) = outs_l[0][0], outs_l[1][0]
+                case["lse_close"] = bool(len(tl) == len(tl1) and np.linalg.norm(xl - xl1) <= 1e-9 * np.linalg.norm(xl1))
+                case["lse_path"] = [outs_l[0][1], outs_l[1][1]]
             # the same exchange in STREAM ORDER (no synchronisation per exchange): the run is then pipelined -- every kernel and
             # every exchange of an iteration enqueued ahead of the device-side decisions, as with RCCL -- and must give the same bits
             ctx.comm_check()

@@ -43,6 +43,14 @@ def _check_sharded_symmetric(res, nproc):
                 assert case[m + "_again_path"] & 2 and not case[m + "_rows_path"] & 2
                 b_sh, b_1 = case[m + "_bytes"]
                 assert abs(nproc * b_sh - nb * (nb + 1) // 2 * 131072) <= nproc * (nb // nproc) * 131072  # balanced to one tile per block-row
+    for r in res:  # the generic path's H pass on the sharded tiles (flag 4), quadratic and log-sum-exp objectives
+        for case in r["cases"]:
+            assert case["generic_close"] and case["generic_path"][0] & 4 and not case["generic_path"][0] & 1, case
+            if "lse_close" in case:
+                assert case["lse_close"] and case["lse_path"][0] & 4, case
+    nbs = {case["n"]: (case["n"] + 127) // 128 for case in res[0]["cases"]}
+    for i, case in enumerate(res[0]["cases"]):
+        assert sum(r["cases"][i]["generic_bytes"] for r in res) == nbs[case["n"]] * (nbs[case["n"]] + 1) // 2 * 131072
     for r in res:  # stream-ordered host exchange: pipelined (flag 8), far fewer synchronisations, the same bits
         for case in r["cases"]:
             assert case["pipelined_equal"] and case["rows_pipelined_equal"] and case["allreduce_ok"], case
