@@ -195,6 +195,34 @@ def main():
                     xa, xb = s.x(), s1.x()
                     case[method + ("_rows" if rows else "_again") + "_close"] = bool(np.linalg.norm(xa - xb) <= 1e-8 * np.linalg.norm(xb))
                     case[method + ("_rows" if rows else "_again") + "_path"] = s.stats()["path"]
+            if n == 1024:  # More-Thuente's cases 2-4, the modified-updating switch and tu = +inf on the sharded tiles (mt_workloads.py)
+                import mt_workloads as W
+                ok_all, digits = True, []
+                for name, w in W.WORKLOADS.items():
+                    dg, bb, xx0 = W.inputs(n, name)
+                    runs = []
+                    for cx in (ctx, ctx1):
+                        ob = qn.Quadratic.synthetic(n, P.SEED, dg, bb, ctx=cx)
+                        sv = qn.BFGS(1e-10, xx0, ctx=cx)
+                        if w["h0"] is not None:
+                            sv.set_approx_inv_hessian(w["h0"] * np.eye(n))
+                        sv.set_trace(w["iters"], with_x=True)
+                        lsw = qn.MoreThuente()
+                        if w["t_max"] is not None:
+                            lsw = lsw.with_t_max(w["t_max"])
+                        try:
+                            sv.minimize(lsw, ob, w["iters"], 20)
+                        except qn.MaxIterReached:
+                            pass
+                        runs.append(sv.trace())
+                    (ta, xa_), (tb, xb_) = runs
+                    ok = len(ta) == len(tb) and all((u["ls_cases"], u["n_evals"]) == (v["ls_cases"], v["n_evals"]) for u, v in zip(ta, tb))
+                    ok = ok and all(abs(u["t"] - v["t"]) <= W.t_tol(name, v["gnorm"], tb[0]["gnorm"], 1e-9) * abs(v["t"]) for u, v in zip(ta, tb))
+                    ok = ok and bool(np.linalg.norm(xa_ - xb_) <= 1e-9 * max(1.0, np.linalg.norm(xb_)))
+                    ok_all = ok_all and bool(ok)
+                    digits += [d_ for r_ in ta for d_ in W.case_digits(r_["ls_cases"])]
+                case["mt_cases_ok"] = bool(ok_all)
+                case["mt_digits"] = [digits.count(k_) for k_ in (1, 2, 3, 4)]
             # the GENERIC path (closures, log-sum-exp, SR1, bounded variants) runs its H pass on the same sharded tiles
             gen = {}
             for label, cx, ob in (("sh", ctx, obj), ("one", ctx1, obj1)):

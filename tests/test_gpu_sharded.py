@@ -48,6 +48,8 @@ def _check_sharded_symmetric(res, nproc):
             assert case["generic_close"] and case["generic_path"][0] & 4 and not case["generic_path"][0] & 1, case
             if "lse_close" in case:
                 assert case["lse_close"] and case["lse_path"][0] & 4, case
+            if "mt_cases_ok" in case:  # cases 2, 3 and 4 really occurred on the sharded tiles, and matched the single-rank run
+                assert case["mt_cases_ok"] and min(case["mt_digits"][1:]) >= 3, case
     nbs = {case["n"]: (case["n"] + 127) // 128 for case in res[0]["cases"]}
     for i, case in enumerate(res[0]["cases"]):
         assert sum(r["cases"][i]["generic_bytes"] for r in res) == nbs[case["n"]] * (nbs[case["n"]] + 1) // 2 * 131072
