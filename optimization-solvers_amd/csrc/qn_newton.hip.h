@@ -51,6 +51,10 @@ __device__ __forceinline__ double qn_readlane_d(double v, int l) { // wave-unifo
 // then every wave applies both rank-1 updates with plain FMAs.  Measured on the way here: a fully unrolled one-wave
 // version 86 us (121 KB of cold instruction fetch), a predicated update 96 us (16 branches per step, serialised LDS
 // waits), selects instead of zeroed multipliers 57 us, separate L and X sweeps 36 us.  Rows/cols past n are identity padding.
+// Round 2, also measured and dropped: 16 columns at a time inside the owning wave (multipliers broadcast with v_readlane, four
+// barriers instead of 64, rank-16 updates by the other waves): 24.5 us -- the 15 dependent v_readlane pairs per column cost more
+// than the barrier they replace; and one fused launch per 64-column step (diagonal tile factorised redundantly in every panel
+// workgroup, left-looking in-block updates): 38.7 us per step against ~37 us for the three launches.
 #ifdef QN_DIAG_STAMPS
 #define QN_DSTAMP(i) do { if (threadIdx.x == 0) qn_diag_stamps[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
