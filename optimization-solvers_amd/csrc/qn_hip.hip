@@ -737,7 +737,7 @@ struct qn_solver {
     double *symsh_xg = nullptr, *symsh_gath = nullptr; // row-sharded symmetric storage: gathered partial sums [world][2][n_pad]; mirror staging
     bool h_diag_stale = false;  // ... and (second-generation kernels) only the upper triangle of 16 x 16 sub-blocks inside the diagonal tiles
     // second-generation symmetric path (qn_sym2.hip.h): static work lists, per-workgroup scalars, double-buffered control block
-    int *s2_items = nullptr, *s2_first = nullptr;
+    int* s2_items = nullptr;
     int s2_G = 0, s2_nb = 0, s2_maxk = 0;
     double *s2_wgE = nullptr, *s2_wgH = nullptr, *s2_rp = nullptr;
     QnCtl* s2_ctl = nullptr;
@@ -840,8 +840,8 @@ static int solver_alloc_sym2(qn_solver* s) {
     const int nb = s->T.n_pad / QN_TB;
     hipStream_t st = s->ctx->stream;
     if (s->s2_nb != nb) {
-        (void)hipFree(s->s2_items); (void)hipFree(s->s2_first); (void)hipFree(s->s2_wgE); (void)hipFree(s->s2_wgH); (void)hipFree(s->s2_rp);
-        s->s2_items = s->s2_first = nullptr; s->s2_wgE = s->s2_wgH = s->s2_rp = nullptr;
+        (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgE); (void)hipFree(s->s2_wgH); (void)hipFree(s->s2_rp);
+        s->s2_items = nullptr; s->s2_wgE = s->s2_wgH = s->s2_rp = nullptr;
         const int nitems = nb * (nb + 1) / 2;
         const int G = std::min(nitems, QN_S2_MAXG);
         std::vector<std::vector<int>> lists(G);
@@ -954,7 +954,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->symsh_xg); (void)hipFree(s->symsh_gath); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
-    (void)hipFree(s->s2_items); (void)hipFree(s->s2_first); (void)hipFree(s->s2_wgE); (void)hipFree(s->s2_wgH); (void)hipFree(s->s2_rp); (void)hipFree(s->s2_ctl);
+    (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgE); (void)hipFree(s->s2_wgH); (void)hipFree(s->s2_rp); (void)hipFree(s->s2_ctl);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
     delete s;
