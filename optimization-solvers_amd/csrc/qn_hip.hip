@@ -504,7 +504,10 @@ struct qn_objective {
     QnTile TA{}; // row partition of A (m rows)
     double mu = 0.0;
     int lse_rs = 1;
+    int lse_two_pass = 0; // diagnostics (QN_LSE_TWO_PASS=1 in the environment at creation): the round-1 two-pass evaluation
     double *lz = nullptr, *lw = nullptr, *lgpart = nullptr, *lgall = nullptr, *lscal = nullptr;
+    double *lwgms = nullptr, *lwgg = nullptr, *lms = nullptr; // one-pass evaluation: per-workgroup (m, S), G vectors; gathered per-rank (m, S)
+    int lse_G = 0, lse_kch = 0;                                 // its grid and column chunks per thread (0: two-pass evaluation)
 };
 
 static int objective_base(qn_context* ctx, size_t n, const double* b_host, qn_objective** out) {
@@ -584,6 +587,16 @@ extern "C" int qn_logsumexp_create(qn_context* ctx, size_t m, size_t n, const do
     QNCHK(dev_alloc_zero(&o->lgpart, (size_t)o->lse_rs * np, st));
     QNCHK(dev_alloc_zero(&o->lgall, (size_t)ctx->world * np, st));
     QNCHK(dev_alloc_zero(&o->lscal, 2, st));
+    o->lse_two_pass = getenv("QN_LSE_TWO_PASS") && atoi(getenv("QN_LSE_TWO_PASS")) != 0;
+    if (np <= 16384 && np >= 2) { // the one-pass evaluation keeps a whole row per workgroup in registers
+        int kch = 1;
+        while ((size_t)kch * 1024 < np) kch *= 2;
+        o->lse_kch = kch;
+        o->lse_G = (int)std::max<size_t>(1, std::min<size_t>(256, (mrpr + 3) / 4));
+        QNCHK(dev_alloc_zero(&o->lwgms, 2 * (size_t)o->lse_G, st));
+        QNCHK(dev_alloc_zero(&o->lwgg, (size_t)o->lse_G * np, st));
+        QNCHK(dev_alloc_zero(&o->lms, 2 * (size_t)ctx->world, st));
+    }
     HIPCHK(hipStreamSynchronize(st));
     return QN_OK;
 }
@@ -592,9 +605,41 @@ template <int R>
 static void launch_hpass(hipStream_t st, const QnHPassArgs& a);
 
 // enqueue one evaluation of the log-sum-exp objective at x_dev (n_pad entries): f -> f_dev, g -> g_dev
+template <int KCH>
+static int lse_launch_onepass(hipStream_t st, int G, const QnLseArgs& a, double* wgms, double* wgg) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)KCH * 1024 * sizeof(double);
+    if (!attr_set && lds > 48 * 1024) { // x in LDS: up to 128 KB of the CU's 160 KB
+        HIPCHK(hipFuncSetAttribute((const void*)lse_onepass_kernel<KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lse_onepass_kernel<KCH>), dim3(G), dim3(512), lds, st, a, wgms, wgg);
+    return QN_OK;
+}
+
 static int lse_enqueue_eval(qn_objective* o, const double* x_dev, double* f_dev, double* g_dev) {
     qn_context* c = o->ctx;
     hipStream_t st = c->stream;
+    if (o->lse_kch && !o->lse_two_pass) { // one pass over A (qn_kernels.hip.h): 8 m n / P bytes per evaluation instead of 16 m n / P
+        QnLseArgs a{};
+        a.A = o->Q; a.c = o->b; a.gall = o->lgall; a.x = x_dev; a.f_out = f_dev; a.g_out = g_dev; a.mu = o->mu;
+        a.m = (int)o->m; a.m_pad = o->TA.n_pad; a.mrpr = o->TA.rpr; a.n = (int)o->n; a.n_pad = o->T.n_pad;
+        a.world = c->world; a.rank = c->rank; a.rs = 1;
+        switch (o->lse_kch) {
+        case 1: QNCHK(lse_launch_onepass<1>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
+        case 2: QNCHK(lse_launch_onepass<2>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
+        case 4: QNCHK(lse_launch_onepass<4>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
+        case 8: QNCHK(lse_launch_onepass<8>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
+        default: QNCHK(lse_launch_onepass<16>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
+        }
+        hipLaunchKernelGGL(lse_combine_kernel, dim3((a.n_pad + 255) / 256), dim3(256), 0, st, a, o->lse_G, o->lwgms, o->lwgg, o->lms);
+        HIPCHK(hipGetLastError());
+        const XchgItem items[2] = {{o->lgall, (size_t)a.n_pad}, {o->lms, 2}};
+        QNCHK(exchange_group(c, items, 2));
+        hipLaunchKernelGGL(lse_finish1_kernel, dim3(std::min(1024, (a.n_pad + 255) / 256)), dim3(256), 0, st, a, o->lms);
+        HIPCHK(hipGetLastError());
+        return QN_OK;
+    }
     // pass 1: z = A_rows x (the H-pass kernel in plain mat-vec mode)
     QnHPassArgs h{};
     h.H = o->Q; h.T = o->TA; h.T.n_pad = o->T.n_pad; h.T.n = (int)o->n; h.T.cs = 1;
@@ -626,6 +671,7 @@ extern "C" void qn_objective_destroy(qn_objective* o) {
     (void)hipFree(o->Q); (void)hipFree(o->b);
     (void)hipFree(o->ex); (void)hipFree(o->eq); (void)hipFree(o->eg); (void)hipFree(o->ef);
     (void)hipFree(o->lz); (void)hipFree(o->lw); (void)hipFree(o->lgpart); (void)hipFree(o->lgall); (void)hipFree(o->lscal);
+    (void)hipFree(o->lwgms); (void)hipFree(o->lwgg); (void)hipFree(o->lms);
     delete o;
 }
 

@@ -630,8 +630,9 @@ __device__ __forceinline__ void small_update(double* H, int ld, int n, const dou
 
 // ------------------------------------------------------------------------------------------------
 // log-sum-exp objective: f = log sum_i exp(a_i'x + c_i) + mu/2 ||x||^2,
-// g = A' softmax(Ax + c) + mu x.  Two passes over this rank's rows of A per evaluation (16*m*n/P bytes):
-// z = A x (h_pass_kernel in mat-vec mode), then the column sums A'w.  Max-shifted for stability.
+// g = A' softmax(Ax + c) + mu x.  Max-shifted for stability.  n_pad <= 16384: ONE pass over this rank's rows of A per evaluation
+// (8*m*n/P bytes, lse_onepass_kernel below).  Wider problems: two passes (16*m*n/P bytes): z = A x (h_pass_kernel in mat-vec
+// mode), then the column sums A'w.
 // ------------------------------------------------------------------------------------------------
 struct QnLseArgs {
     const double* A;   // this rank's rows, [mrpr][n_pad]
@@ -718,6 +719,125 @@ __global__ void lse_finish_kernel(const QnLseArgs a) {
         a.g_out[j] = (j < a.n) ? t + a.mu * a.x[j] : 0.0;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.f_out = a.scal[0] + 0.5 * a.mu * a.scal[1];
+}
+
+// ---- the same evaluation in ONE pass over A (n_pad <= 16384) ----
+// A softmax needs max_i z_i before any weight is known -- hence the two passes above.  With the running rescale of a streaming
+// softmax one pass is enough: a workgroup walks its rows with a running maximum m, S = sum_i exp(z_i - m) and
+// G = sum_i exp(z_i - m) a_i; a new row updates m' = max(m, z), S <- S exp(m - m') + exp(z - m'), G <- G exp(m - m') + exp(z - m') a.
+// Each of the 512 threads keeps its KCH x 2 columns of the current row, of the prefetched next row and of G in registers
+// (3 x 64 VGPRs at n = 16384); x sits in LDS (128 KB at n = 16384); the row's dot product is the only cross-thread step (wave
+// butterfly, eight partials through LDS, ONE barrier per row -- a row is 128 KB, 5 us of HBM time per CU, the barrier hides in it).
+// lse_combine_kernel folds the workgroups' (m, S, G) in workgroup order, the ranks' results are exchanged once, lse_finish1_kernel
+// folds them in rank order: f = M + log S + mu/2 ||x||^2, g = G / S + mu x.  Every order is fixed: reproducible bit for bit.
+template <int KCH>
+__global__ __launch_bounds__(512) void lse_onepass_kernel(const QnLseArgs a, double* __restrict__ wgms, double* __restrict__ wgg) {
+    extern __shared__ __attribute__((aligned(16))) double lse_x[]; // KCH * 1024 entries of x, zero past n_pad
+    __shared__ double red[2][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int np = a.n_pad;
+    // column pair k of this thread: 2 tid + 1024 k; past the end the last pair is re-read (its x entries are zero, its G entries
+    // are never stored)
+#define QN_LSE_JC(k) min(2 * tid + 1024 * (k), np - 2)
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) {
+        const int j = 2 * tid + 1024 * k;
+        v2d xv = {0.0, 0.0};
+        if (j < np) xv = ld2(a.x + j);
+        lse_x[j] = xv.x; lse_x[j + 1] = xv.y;
+    }
+    __syncthreads();
+    const int G = gridDim.x, per = (a.mrpr + G - 1) / G;
+    const int r_lo = blockIdx.x * per;
+    const int r_hi = min(min(a.mrpr, r_lo + per), a.m - a.rank * a.mrpr); // (rows past m are padding)
+    v2d g[KCH], cur[KCH], nxt[KCH];
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) { g[k] = (v2d){0.0, 0.0}; cur[k] = (v2d){0.0, 0.0}; }
+    double m_run = -INFINITY, s_run = 0.0;
+    if (r_lo < r_hi) {
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) cur[k] = ld2(a.A + (size_t)r_lo * np + QN_LSE_JC(k));
+    }
+    for (int r = r_lo; r < r_hi; ++r) {
+        const double* nrow = a.A + (size_t)((r + 1 < r_hi) ? r + 1 : r) * np; // (last row: a harmless re-read, no branch)
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) nxt[k] = ld2(nrow + QN_LSE_JC(k));
+        double p = 0.0;
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) {
+            const int j = 2 * tid + 1024 * k;
+            const v2d xv = *reinterpret_cast<const v2d*>(&lse_x[j]);
+            p = __builtin_fma(cur[k].x, xv.x, p);
+            p = __builtin_fma(cur[k].y, xv.y, p);
+        }
+        p = qn_wave_sum(p);
+        if (lane == 0) red[r & 1][wave] = p;
+        __syncthreads();
+        double z = red[r & 1][0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) z = z + red[r & 1][w];
+        z = z + a.c[a.rank * a.mrpr + r];
+        const double m_new = fmax(m_run, z);
+        const double scale = exp(m_run - m_new), e = exp(z - m_new); // (first row: exp(-inf) = 0)
+        s_run = __builtin_fma(s_run, scale, e);
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) {
+            g[k].x = __builtin_fma(e, cur[k].x, g[k].x * scale);
+            g[k].y = __builtin_fma(e, cur[k].y, g[k].y * scale);
+            cur[k] = nxt[k];
+        }
+        m_run = m_new;
+    }
+    if (tid == 0) { wgms[2 * blockIdx.x] = m_run; wgms[2 * blockIdx.x + 1] = s_run; }
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) {
+        const int j = 2 * tid + 1024 * k;
+        if (j < np) st2(wgg + (size_t)blockIdx.x * np + j, g[k]);
+    }
+#undef QN_LSE_JC
+}
+
+// this rank's (m, S, G): the workgroups' results folded in workgroup order; G into gall[rank], (m, S) into lms[rank]
+__global__ __launch_bounds__(256) void lse_combine_kernel(const QnLseArgs a, int G, const double* __restrict__ wgms, const double* __restrict__ wgg,
+                                                          double* __restrict__ lms) {
+    __shared__ double fac[256];
+    __shared__ double lds[32];
+    const int tid = threadIdx.x;
+    const double mw = tid < G ? wgms[2 * tid] : -INFINITY;
+    const double mr = ctl_block_fmax(mw, lds);
+    fac[tid] = tid < G ? exp(mw - mr) : 0.0; // (a workgroup without rows: exp(-inf) = 0)
+    __syncthreads();
+    const int j = blockIdx.x * 256 + tid;
+    if (j < a.n_pad) {
+        double acc = 0.0;
+        for (int w = 0; w < G; ++w) acc = __builtin_fma(wgg[(size_t)w * a.n_pad + j], fac[w], acc);
+        a.gall[(size_t)a.rank * a.n_pad + j] = acc;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < G; ++w) s = __builtin_fma(wgms[2 * w + 1], fac[w], s);
+        lms[2 * a.rank] = mr; lms[2 * a.rank + 1] = s;
+    }
+}
+
+// the ranks' (m, S, G) folded in rank order: g = G / S + mu x ; f = M + log S + mu/2 ||x||^2
+__global__ __launch_bounds__(256) void lse_finish1_kernel(const QnLseArgs a, const double* __restrict__ lms) {
+    __shared__ double lds[32];
+    double M = lms[0];
+    for (int p = 1; p < a.world; ++p) M = fmax(M, lms[2 * p]);
+    double S = 0.0;
+    for (int p = 0; p < a.world; ++p) S = __builtin_fma(lms[2 * p + 1], exp(lms[2 * p] - M), S);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n_pad; j += gridDim.x * blockDim.x) {
+        double t = 0.0;
+        for (int p = 0; p < a.world; ++p) t = __builtin_fma(a.gall[(size_t)p * a.n_pad + j], exp(lms[2 * p] - M), t);
+        a.g_out[j] = (j < a.n) ? t / S + a.mu * a.x[j] : 0.0;
+    }
+    if (blockIdx.x == 0) {
+        double p[1] = {0.0};
+        for (int j = threadIdx.x; j < a.n; j += blockDim.x) p[0] = __builtin_fma(a.x[j], a.x[j], p[0]);
+        ctl_block_sum<1>(p, lds);
+        if (threadIdx.x == 0) *a.f_out = M + log(S) + 0.5 * a.mu * p[0];
+    }
 }
 
 #include "qn_fused.hip.h"

@@ -90,3 +90,40 @@ def test_config5_size_properties_dfp_morethuente_n16384(qn, qo):
     ref = qo.Solver(qo.DFP, 1e-10, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
     ref.minimize(qo.morethuente(), o, 3, 20, trace_cap=3, trace_x=True)
     _compare(tr[:3], xs[:3], ref.trace, ref.trace_x)
+
+
+@pytest.mark.parametrize("m,n", [(9, 2), (300, 200), (1030, 515), (64, 5000), (2100, 1024), (130, 16384)])
+def test_one_pass_evaluation_equals_two_pass_and_oracle(qn, qo, m, n, monkeypatch):
+    """n_pad <= 16384: the objective is evaluated in ONE pass over A (running-maximum softmax, lse_onepass_kernel); the
+    two-pass evaluation of round 1 (QN_LSE_TWO_PASS=1 at creation) and the oracle are the checkers.  Also points with a huge
+    spread of exponents, where an unshifted softmax would overflow."""
+    a, c, x0 = _problem(m, n)
+    mu = 0.05
+    one = qn.LogSumExp(a, c, mu)
+    monkeypatch.setenv("QN_LSE_TWO_PASS", "1")
+    two = qn.LogSumExp(a, c, mu)
+    monkeypatch.delenv("QN_LSE_TWO_PASS")
+    o = qo.LogSumExpOracle(a, c, mu, nthreads=4)
+    for scale in (1.0, 40.0, 3000.0):
+        x = x0 * scale
+        e1, e2 = one(x), two(x)
+        f_ref, g_ref = o(x)
+        for e in (e1, e2):
+            assert abs(e.f() - f_ref) <= 1e-12 * max(1.0, abs(f_ref)), (scale, e.f(), f_ref)
+            assert np.linalg.norm(e.g() - g_ref) <= 1e-12 * max(1.0, np.linalg.norm(g_ref)), scale
+        assert abs(e1.f() - e2.f()) <= 1e-13 * max(1.0, abs(e2.f()))
+    # the same pass as the oracle of a solver run
+    outs = []
+    for obj in (one, two):
+        s = qn.DFP(1e-10, x0)
+        s.set_trace(8, with_x=True)
+        try:
+            s.minimize(qn.MoreThuente(), obj, 8, 20)
+        except qn.MaxIterReached:
+            pass
+        outs.append(s.trace())
+    (t1, x1), (t2, x2) = outs
+    # (two evaluations that agree to 1e-13 give DFP trajectories that drift apart with the conditioning of the line search's
+    # interpolation -- differences of nearly equal f values: same decisions, iterates loosely)
+    assert [r["ls_cases"] for r in t1] == [r["ls_cases"] for r in t2]
+    assert np.linalg.norm(x1 - x2) <= 1e-6 * max(1.0, np.linalg.norm(x2))
