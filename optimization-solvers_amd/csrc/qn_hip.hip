@@ -632,7 +632,7 @@ static int lse_enqueue_eval(qn_objective* o, const double* x_dev, double* f_dev,
         case 8: QNCHK(lse_launch_onepass<8>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
         default: QNCHK(lse_launch_onepass<16>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
         }
-        hipLaunchKernelGGL(lse_combine_kernel, dim3((a.n_pad + 255) / 256), dim3(256), 0, st, a, o->lse_G, o->lwgms, o->lwgg, o->lms);
+        hipLaunchKernelGGL(lse_combine_kernel, dim3((a.n_pad + 63) / 64), dim3(256), 0, st, a, o->lse_G, o->lwgms, o->lwgg, o->lms);
         HIPCHK(hipGetLastError());
         const XchgItem items[2] = {{o->lgall, (size_t)a.n_pad}, {o->lms, 2}};
         QNCHK(exchange_group(c, items, 2));

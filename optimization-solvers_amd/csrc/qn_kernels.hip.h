@@ -797,22 +797,32 @@ __global__ __launch_bounds__(512) void lse_onepass_kernel(const QnLseArgs a, dou
 #undef QN_LSE_JC
 }
 
-// this rank's (m, S, G): the workgroups' results folded in workgroup order; G into gall[rank], (m, S) into lms[rank]
+// this rank's (m, S, G): the workgroups' results folded in a fixed order -- each quarter of the workgroups in workgroup order, 16
+// loads in flight, the four quarters then added in order; G into gall[rank], (m, S) into lms[rank].  64 columns per workgroup.
 __global__ __launch_bounds__(256) void lse_combine_kernel(const QnLseArgs a, int G, const double* __restrict__ wgms, const double* __restrict__ wgg,
                                                           double* __restrict__ lms) {
     __shared__ double fac[256];
     __shared__ double lds[32];
+    __shared__ double part[3][64];
     const int tid = threadIdx.x;
     const double mw = tid < G ? wgms[2 * tid] : -INFINITY;
     const double mr = ctl_block_fmax(mw, lds);
     fac[tid] = tid < G ? exp(mw - mr) : 0.0; // (a workgroup without rows: exp(-inf) = 0)
     __syncthreads();
-    const int j = blockIdx.x * 256 + tid;
-    if (j < a.n_pad) {
-        double acc = 0.0;
-        for (int w = 0; w < G; ++w) acc = __builtin_fma(wgg[(size_t)w * a.n_pad + j], fac[w], acc);
-        a.gall[(size_t)a.rank * a.n_pad + j] = acc;
+    const int c = tid & 63, q = tid >> 6;
+    const int j = min(blockIdx.x * 64 + c, a.n_pad - 1);
+    const int per = (G + 3) / 4, w_lo = q * per, w_hi = min(G, w_lo + per);
+    double acc = 0.0;
+    for (int w0 = w_lo; w0 < w_hi; w0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = (w0 + u < w_hi) ? wgg[(size_t)(w0 + u) * a.n_pad + j] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_fma(v[u], (w0 + u < w_hi) ? fac[w0 + u] : 0.0, acc);
     }
+    if (q > 0) part[q - 1][c] = acc;
+    __syncthreads();
+    if (q == 0 && blockIdx.x * 64 + c < a.n_pad) a.gall[(size_t)a.rank * a.n_pad + j] = ((acc + part[0][c]) + part[1][c]) + part[2][c];
     if (blockIdx.x == 0 && tid == 0) {
         double s = 0.0;
         for (int w = 0; w < G; ++w) s = __builtin_fma(wgms[2 * w + 1], fac[w], s);
