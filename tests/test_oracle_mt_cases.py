@@ -39,7 +39,8 @@ def test_case4_at_infinite_tu_ends_the_run_with_a_zero_step(qo):
 
     def fn(x):
         seen.append(x.copy())
-        return 0.5 * x @ (q @ x) - b @ x, q @ x - b
+        with np.errstate(invalid="ignore"):  # the line search hands over x + inf d once: inf - inf inside the products
+            return 0.5 * x @ (q @ x) - b @ x, q @ x - b
 
     s = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_AS_WRITTEN)
     st = s.minimize(qo.morethuente(), fn, 8, 20, trace_cap=8, trace_x=True)
