@@ -610,7 +610,10 @@ static int lse_launch_onepass(hipStream_t st, int G, const QnLseArgs& a, double*
     static bool attr_set = false;
     const size_t lds = (size_t)KCH * 1024 * sizeof(double);
     if (!attr_set && lds > 48 * 1024) { // x in LDS: up to 128 KB of the CU's 160 KB
-        HIPCHK(hipFuncSetAttribute((const void*)lse_onepass_kernel<KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (hipFuncSetAttribute((const void*)lse_onepass_kernel<KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1; // this device does not grant the LDS: the caller keeps the two-pass evaluation
+        }
         attr_set = true;
     }
     hipLaunchKernelGGL((lse_onepass_kernel<KCH>), dim3(G), dim3(512), lds, st, a, wgms, wgg);
@@ -625,13 +628,15 @@ static int lse_enqueue_eval(qn_objective* o, const double* x_dev, double* f_dev,
         a.A = o->Q; a.c = o->b; a.gall = o->lgall; a.x = x_dev; a.f_out = f_dev; a.g_out = g_dev; a.mu = o->mu;
         a.m = (int)o->m; a.m_pad = o->TA.n_pad; a.mrpr = o->TA.rpr; a.n = (int)o->n; a.n_pad = o->T.n_pad;
         a.world = c->world; a.rank = c->rank; a.rs = 1;
+        int lst;
         switch (o->lse_kch) {
-        case 1: QNCHK(lse_launch_onepass<1>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
-        case 2: QNCHK(lse_launch_onepass<2>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
-        case 4: QNCHK(lse_launch_onepass<4>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
-        case 8: QNCHK(lse_launch_onepass<8>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
-        default: QNCHK(lse_launch_onepass<16>(st, o->lse_G, a, o->lwgms, o->lwgg)); break;
+        case 1: lst = lse_launch_onepass<1>(st, o->lse_G, a, o->lwgms, o->lwgg); break;
+        case 2: lst = lse_launch_onepass<2>(st, o->lse_G, a, o->lwgms, o->lwgg); break;
+        case 4: lst = lse_launch_onepass<4>(st, o->lse_G, a, o->lwgms, o->lwgg); break;
+        case 8: lst = lse_launch_onepass<8>(st, o->lse_G, a, o->lwgms, o->lwgg); break;
+        default: lst = lse_launch_onepass<16>(st, o->lse_G, a, o->lwgms, o->lwgg); break;
         }
+        if (lst < 0) { o->lse_two_pass = 1; return lse_enqueue_eval(o, x_dev, f_dev, g_dev); }
         hipLaunchKernelGGL(lse_combine_kernel, dim3((a.n_pad + 63) / 64), dim3(256), 0, st, a, o->lse_G, o->lwgms, o->lwgg, o->lms);
         HIPCHK(hipGetLastError());
         const XchgItem items[2] = {{o->lgall, (size_t)a.n_pad}, {o->lms, 2}};
