@@ -307,6 +307,9 @@ __device__ __forceinline__ int qn_s2_first_item(int g, int nb) {
 // stream sees it got 3 us LONGER (event bracket 24.5 -> 27.6 us), and the iteration 88.3 -> 91.5 us.  With the compiler's builtin
 // instead of inline assembly every LDS access after a request waits for all outstanding loads (the state machine then sits behind
 // the whole tile window: +3 us in the prologue).  Also measured: the work list read one item ahead of its use (no change).
+// Why the look-ahead cannot pay at this size: the SLOWEST workgroup ends when the last byte of the 67 MB has arrived, and that is set
+// by the device's read rate (~4.9 TB/s here: 13.7 us) plus dispatch, first issue and one tail -- requesting everything earlier makes
+// the median workgroup finish sooner, not the last one.  (An unused 128 KB dynamic-LDS allocation by itself costs nothing.)
 __device__ __forceinline__ int qn_s2_col(bool diag, int lane, int wave) { return 2 * (diag ? max(lane, 8 * wave) : lane); }
 __device__ __forceinline__ bool qn_s2_row_on(bool diag, int lane, int wave) { return !diag || lane >= 8 * wave; }     // multiplier entries kept
 __device__ __forceinline__ bool qn_s2_col_on(bool diag, int lane, int wave) { return !diag || lane >= 8 * wave + 8; } // column sums kept
