@@ -790,7 +790,8 @@ struct qn_solver {
     // second-generation symmetric path (qn_sym2.hip.h): static work lists, per-workgroup scalars, double-buffered control block
     int* s2_items = nullptr;
     int s2_G = 0, s2_nb = 0, s2_maxk = 0;
-    double *s2_wgE = nullptr, *s2_wgH = nullptr, *s2_rp = nullptr;
+    double* s2_wgS = nullptr; // [2][s2_trows][QN_S2_ROW]: the sums a servicing launch leaves for the next launch's prologue, by launch parity
+    int s2_trows = 0;
     QnCtl* s2_ctl = nullptr;
     bool no_sym2 = false; // diagnostics: the first-generation tile kernels (qn_sym.hip.h)
     // After a fused run the iterate and the pending update's vectors stay where the fused kernels keep them (X0[xc], S0[sc], UN);
@@ -891,8 +892,8 @@ static int solver_alloc_sym2(qn_solver* s) {
     const int nb = s->T.n_pad / QN_TB;
     hipStream_t st = s->ctx->stream;
     if (s->s2_nb != nb) {
-        (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgE); (void)hipFree(s->s2_wgH); (void)hipFree(s->s2_rp);
-        s->s2_items = nullptr; s->s2_wgE = s->s2_wgH = s->s2_rp = nullptr;
+        (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS);
+        s->s2_items = nullptr; s->s2_wgS = nullptr;
         const int nitems = nb * (nb + 1) / 2;
         const int G = std::min(nitems, QN_S2_MAXG);
         std::vector<std::vector<int>> lists(G);
@@ -931,9 +932,8 @@ static int solver_alloc_sym2(qn_solver* s) {
         HIPCHK(hipMalloc((void**)&s->s2_items, items.size() * sizeof(int)));
         HIPCHK(hipMemcpy(s->s2_items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
         s->s2_maxk = (int)maxk;
-        QNCHK(dev_alloc_zero(&s->s2_wgE, (size_t)2 * G * QN_S2_ROW, st));
-        QNCHK(dev_alloc_zero(&s->s2_wgH, (size_t)nb * 2, st));
-        QNCHK(dev_alloc_zero(&s->s2_rp, (size_t)nb * QN_S2_ROW, st));
+        s->s2_trows = std::max(QN_S2_MAXG, (nb + 63) / 64 * 64);
+        QNCHK(dev_alloc_zero(&s->s2_wgS, (size_t)2 * s->s2_trows * QN_S2_ROW, st));
         s->s2_G = G;
         s->s2_nb = nb;
     }
@@ -1005,7 +1005,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->symsh_xg); (void)hipFree(s->symsh_gath); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
-    (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgE); (void)hipFree(s->s2_wgH); (void)hipFree(s->s2_rp); (void)hipFree(s->s2_ctl);
+    (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_ctl);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
     delete s;
@@ -1556,7 +1556,7 @@ static int s2_launch(Run& r, int kind) {
         s->h_lower_stale = true; s->h_diag_stale = true;
         break;
     case QN_S2_HREDUCE: hipLaunchKernelGGL(s2_hreduce_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
-    default: hipLaunchKernelGGL(s2_advance_kernel, dim3(1), dim3(QN_S2_TPB), 0, st, a); break;
+    default: hipLaunchKernelGGL(s2_advance_kernel, dim3(1), dim3(128), 0, st, a); break;
     }
     s->stats.launches++;
     HIPCHK(hipGetLastError());
@@ -2119,7 +2119,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         QnS2Args& a = r.s2;
         a.Q = r.obj->Q; a.H = s->H; a.n = (int)s->n; a.np = s->T.n_pad; a.nb = s->s2_nb; a.G = s->s2_G;
         a.item_ij = s->s2_items; a.maxk = s->s2_maxk; a.F = s->V.F; a.part = s->sym_part;
-        a.wgE = s->s2_wgE; a.hrp = s->s2_wgH; a.rp = s->s2_rp; a.ctl2 = s->s2_ctl;
+        a.wgS = s->s2_wgS; a.trows = s->s2_trows; a.ctl2 = s->s2_ctl;
         a.trace = s->V.trace; a.xtrace = s->V.xtrace;
         a.nt = s->T.n_pad >= 8192; // H past the Infinity Cache: every byte is touched once per pass
         // (no synchronisation: the copy is stream-ordered in front of the launches, the mirror is pinned, and the host does not

@@ -58,9 +58,11 @@ struct QnS2Args {
     int maxk;            // longest list
     QnFused F;           // X0, S0, G, GT, Y, UN, VV, b (UP is not used here: no kernel writes u while another reads it)
     double* part;        // [nb][nb][2][128] row / column slots
-    double* wgE;         // [2][G][QN_S2_ROW] evaluation scalars, double-buffered on ctl.ev_par
-    double* hrp;         // [nb][2] update-reduce partials per block-row: y'u, u'g+
-    double* rp;          // [nb][QN_S2_ROW]
+    double* wgS;         // [2][trows][QN_S2_ROW] what a servicing launch hands the state machine, one row of sums per workgroup:
+                         // evaluation tiles (G rows, QN_S2_NSE sums), accept-reduce (nb rows, QN_S2_NR), update-reduce (nb rows: y'u, u'g+).
+                         // Launch i writes half i & 1 and launch i + 1 -- whose prologue consumes the request -- reads it: the address
+                         // follows from the launch parity alone, so the rows are requested together with the control block.
+    int trows;           // rows per half: max(256, nb rounded up to 64)
     QnCtl* ctl2;         // [2]
     QnTraceRec* trace;
     double* xtrace;
@@ -80,7 +82,7 @@ struct QnS2Args {
 struct QnS2Lds {
     QnCtl c;
     double red[QN_S2_WAVES][8];
-    double tot[8];
+    int mine; // this launch services the pending request
 };
 
 // ---- the state machine's view of a finished request: consume its sums, then run until the next request ----
@@ -124,127 +126,111 @@ __device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const
     ctl_scalar_run(c, V, scratch, leader);
 }
 
-// Prologue of every sym2 kernel, in two parts so that a tile kernel can put its own loads in between.
-//   issue:  the control block and every partial sum the machine might want are requested FIRST (a wave's loads return in
-//           order: requested behind the 128 KB tile window they would wait for it).  Wave k < 6 takes column k of the three
-//           partial tables -- evaluation scalars per workgroup (both halves of the double buffer), accept-reduce and
-//           update-reduce partials per block-row -- 64 rows per load instruction.
-//   finish: the column the finished request produced is summed (fixed order: the lane's rows in row order, then a xor
-//           butterfly), the machine is advanced by thread 0 and workgroup 0 writes the new control block.
-//           Returns true when this launch is to service the pending request.
-//           (Measured and dropped: summing all four candidate tables before the control block has been read, which saves the
-//           barrier between "which table" and "its sum" -- same-box A/B at n = 4096: 87.2 us -> 89.1 us per iteration; the three
-//           extra butterflies per column wave cost more than the barrier.)
-#define QN_S2_PCH (QN_S2_MAXG / 64) // row chunks of 64 a wave loads per table at issue time
-struct QnS2Pro {
-    uint64_t cw;
-    double e0[QN_S2_PCH], e1[QN_S2_PCH], rr[QN_S2_PCH], hh[QN_S2_PCH];
-};
+// Prologue of every sym2 kernel: run by WAVE 0 ALONE, before that wave requests any tile data.
+//
+// Round 2 had all eight waves request their share of the first tile and only then look at the control block.  In-kernel time
+// stamps (tools/s2_stamps.py, n = 4096) showed what that costs: a wave's loads return in order and the first window of the whole
+// chip is a 33 MB burst, so the control block -- requested first -- was in LDS 5.4 us after kernel entry, the column sums 0.6 us
+// and the state machine on an LDS-resident control block 3.2 us later: the row loop started 9.4 us into a 19.5 us kernel, the
+// first window had landed 4 us earlier and nothing was in flight meanwhile.  A plain streaming kernel of the same shape with a
+// one-load prologue runs the phase in 13.5 us launch to launch (tools/seam_probe.hip) against 23.2 us.  So now:
+//   * waves 1..7 request their rows at once and wait at the workgroup barrier; wave 0 -- with nothing queued in front -- gets the
+//     control block and the previous launch's sums in one memory round trip of an idle queue, folds the sums, runs the machine and
+//     only then requests its own 16 rows (an eighth of the window, behind a burst that is over by then);
+//   * the sums of the previous launch sit in ONE table addressed by the launch parity (QnS2Args.wgS), so their address does not
+//     depend on the control block and there is one table to request instead of four;
+//   (Measured again and dropped: the machine on a private register copy of the control block.  Wave 0 holds no window while it
+//   runs, yet ~150 live words plus the machine's temporaries still do not fit 256 registers: 255 spills in the tile kernels.)
+//   The sums keep round 2's order (the lane's rows in row order, then the xor butterfly): same bits.
+#define QN_S2_PCH (QN_S2_MAXG / 64) // row chunks of 64 the wave loads from the table
 
 template <int KIND>
-__device__ __forceinline__ void qn_s2_pro_issue(const QnS2Args& a, QnS2Pro& P) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = (int)(sizeof(QnCtl) / 8);
-    static_assert(NW <= 256, "control block too large for one sweep");
-    const uint64_t* cin = reinterpret_cast<const uint64_t*>(a.ctl2 + a.parity);
-    P.cw = 0;
-    if (tid < NW) P.cw = cin[tid];
-#pragma unroll
-    for (int j = 0; j < QN_S2_PCH; ++j) { P.e0[j] = 0.0; P.e1[j] = 0.0; P.rr[j] = 0.0; P.hh[j] = 0.0; }
-    if (KIND != QN_S2_HREDUCE && wave < QN_S2_NSE) {
-#pragma unroll
-        for (int j = 0; j < QN_S2_PCH; ++j) {
-            const int g = j * 64 + lane;
-            if (g < a.G) {
-                P.e0[j] = a.wgE[(size_t)g * QN_S2_ROW + wave];
-                P.e1[j] = a.wgE[((size_t)a.G + g) * QN_S2_ROW + wave];
-            }
-            if (g < a.nb) {
-                if (wave < QN_S2_NR) P.rr[j] = a.rp[(size_t)g * QN_S2_ROW + wave];
-                if (wave < 2) P.hh[j] = a.hrp[(size_t)g * 2 + wave];
-            }
-        }
-    }
-}
-
-template <int KIND>
-__device__ __forceinline__ bool qn_s2_pro_finish(const QnS2Args& a, QnS2Lds& L, const QnS2Pro& P) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+__device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L) {
+    const int lane = threadIdx.x; // (wave 0)
     const bool leader = blockIdx.x == 0;
     constexpr int NW = (int)(sizeof(QnCtl) / 8);
-    uint64_t* cout = reinterpret_cast<uint64_t*>(a.ctl2 + (a.parity ^ 1));
-    if (tid < NW) reinterpret_cast<uint64_t*>(&L.c)[tid] = P.cw;
-    if (tid < 8) L.tot[tid] = 0.0;
-    __syncthreads();
+    static_assert(NW <= 128, "control block too large for two words per lane");
+    const uint64_t* cin = reinterpret_cast<const uint64_t*>(a.ctl2 + a.parity);
+    uint64_t* lc = reinterpret_cast<uint64_t*>(&L.c);
+    uint64_t cw0 = 0, cw1 = 0;
+    if (lane < NW) cw0 = cin[lane];
+    if (64 + lane < NW) cw1 = cin[64 + lane];
+    v2d tr[QN_S2_PCH][QN_S2_NSE / 2];
+    const double* T = a.wgS + (size_t)(a.parity ^ 1) * (size_t)a.trows * QN_S2_ROW;
+    if (KIND != QN_S2_HREDUCE) {
+#pragma unroll
+        for (int j = 0; j < QN_S2_PCH; ++j)
+#pragma unroll
+            for (int h = 0; h < QN_S2_NSE / 2; ++h) tr[j][h] = ld2(T + (size_t)(j * 64 + lane) * QN_S2_ROW + 2 * h); // (trows >= 256)
+    }
+    if (lane < NW) lc[lane] = cw0;
+    if (64 + lane < NW) lc[64 + lane] = cw1;
+    __builtin_amdgcn_wave_barrier(); // (one wave: its LDS accesses execute in program order; this only pins the compiler's order)
     QN_S2_STAMP(9);
-    QnCtl& c = L.c;
+    QnCtl& c = L.c; // (in LDS: a private register copy of all ~150 words does not fit beside the machine's own temporaries -- 255 spills)
+    int mine = 0;
     if (KIND == QN_S2_HREDUCE) { // no decision between the update tiles and their reduction: pass the control block on
-        const bool mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 1;
-        __syncthreads();
-        if (tid == 0 && mine) c.serviced = 2;
-        __syncthreads();
-        if (leader && tid < NW) cout[tid] = reinterpret_cast<const uint64_t*>(&L.c)[tid];
-        return mine;
+        mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 1;
+        if (lane == 0) { if (mine) c.serviced = 2; L.mine = mine; }
+        return;
     }
     const int ph = c.phase;
     if (ph == QN_PH_DONE) { // launches enqueued past the end of the run: pass the control block on, nothing else
-        if (leader && tid < NW) cout[tid] = P.cw;
-        return false;
+        if (lane == 0) L.mine = 0;
+        return;
     }
-    if (c.serviced == 2 && (ph == QN_PH_REQ_EVAL || ph == QN_PH_REQ_VEC || ph == QN_PH_REQ_HPASS)) { // uniform: c is in LDS
-        if (wave < QN_S2_NSE) {
+    double tot[QN_S2_NSE];
+#pragma unroll
+    for (int k = 0; k < QN_S2_NSE; ++k) tot[k] = 0.0;
+    if (c.serviced == 2 && (ph == QN_PH_REQ_EVAL || ph == QN_PH_REQ_VEC || ph == QN_PH_REQ_HPASS)) { // (uniform)
+        const int nrows = ph == QN_PH_REQ_EVAL ? a.G : a.nb;
+        const int ncol = ph == QN_PH_REQ_EVAL ? QN_S2_NSE : (ph == QN_PH_REQ_VEC ? QN_S2_NR : 2);
+#pragma unroll
+        for (int k = 0; k < QN_S2_NSE; ++k) {
             double acc = 0.0;
-            if (ph == QN_PH_REQ_EVAL) {
-                const bool odd = c.ev_par != 0;
 #pragma unroll
-                for (int j = 0; j < QN_S2_PCH; ++j) acc = acc + (odd ? P.e1[j] : P.e0[j]);
-            } else {
-                const bool vec = ph == QN_PH_REQ_VEC;
-#pragma unroll
-                for (int j = 0; j < QN_S2_PCH; ++j) acc = acc + (vec ? P.rr[j] : P.hh[j]);
-                for (int b = QN_S2_MAXG + lane; b < a.nb; b += 64) { // (block-rows past 256: n > 32768)
-                    if (vec) { if (wave < QN_S2_NR) acc = acc + a.rp[(size_t)b * QN_S2_ROW + wave]; }
-                    else if (wave < 2) acc = acc + a.hrp[(size_t)b * 2 + wave];
-                }
-            }
-            acc = qn_wave_sum(acc);
-            if (lane == 0) L.tot[wave] = acc;
+            for (int j = 0; j < QN_S2_PCH; ++j) acc = acc + ((j * 64 + lane < nrows && k < ncol) ? ((k & 1) ? tr[j][k / 2].y : tr[j][k / 2].x) : 0.0);
+            for (int b = QN_S2_MAXG + lane; b < nrows; b += 64) // (block-rows past 256: n > 32768)
+                if (k < ncol) acc = acc + T[(size_t)b * QN_S2_ROW + k];
+            tot[k] = qn_wave_sum(acc);
         }
-        __syncthreads();
     }
     QN_S2_STAMP(10);
     QnVecs V{};
     V.n = a.n; V.n_pad = a.np; V.trace = a.trace;
     for (int guard = 0; guard < 64; ++guard) { // (the n <= 5 reference-order code of the machine is never reached on this path: no scratch)
-        // (measured and dropped, as in round 1's control kernel: the machine on a register copy of the control block -- the
-        // compiler spills the copy to scratch memory, which is no faster than LDS)
-        if (tid == 0) qn_s2_advance(c, L.tot, V, leader, &L.red[0][0], guard > 0);
-        __syncthreads();
-        if (!(c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END)) break;
-        // the machine stopped because the iterate has to be recorded (trace with x): workgroup 0 copies it, all go on
-        if (leader) {
-            double* row = a.xtrace + (size_t)c.k * (size_t)a.n;
-            const double* xs = a.F.X0 + (size_t)c.xc * (size_t)a.np;
-            for (int i = tid; i < a.n; i += nthr) row[i] = xs[i];
+        int need_x = 0;
+        if (lane == 0) {
+            qn_s2_advance(c, tot, V, leader, &L.red[0][0], guard > 0);
+            need_x = c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END;
         }
-        __syncthreads();
-        if (tid == 0) c.xtrace_done = 1;
-        __syncthreads();
+        need_x = __builtin_amdgcn_readfirstlane(need_x);
+        if (!need_x) break;
+        // the machine stopped because the iterate has to be recorded (trace with x): workgroup 0 copies it, all go on
+        __builtin_amdgcn_wave_barrier();
+        if (leader) {
+            double* row = a.xtrace + (size_t)L.c.k * (size_t)a.n;
+            const double* xs = a.F.X0 + (size_t)L.c.xc * (size_t)a.np;
+            for (int i = lane; i < a.n; i += 64) row[i] = xs[i];
+        }
+        if (lane == 0) c.xtrace_done = 1;
     }
     QN_S2_STAMP(11);
-    bool mine = false;
-    if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == 0;
-    if (KIND == QN_S2_VEC) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
-    if (KIND == QN_S2_HTILE) mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 0;
-    const bool stuck = c.phase == QN_PH_RUNNING; // a state this path cannot service: abort, never spin
-    __syncthreads();
-    if (tid == 0) {
-        if (stuck) { c.status = 4; c.phase = QN_PH_DONE; }
+    if (lane == 0) {
+        if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == 0;
+        if (KIND == QN_S2_VEC) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
+        if (KIND == QN_S2_HTILE) mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 0;
+        if (c.phase == QN_PH_RUNNING) { c.status = 4; c.phase = QN_PH_DONE; } // a state this path cannot service: abort, never spin
         if (mine) c.serviced = (KIND == QN_S2_HTILE) ? 1 : 2; // as this launch leaves the request
+        L.mine = mine;
     }
-    __syncthreads();
-    if (leader && tid < NW) cout[tid] = reinterpret_cast<const uint64_t*>(&L.c)[tid];
-    return mine;
+}
+
+// after the workgroup barrier that follows the prologue: workgroup 0 hands the control block to the next launch
+__device__ __forceinline__ void qn_s2_ctl_out(const QnS2Args& a, const QnS2Lds& L) {
+    constexpr int NW = (int)(sizeof(QnCtl) / 8);
+    if (blockIdx.x == 0 && threadIdx.x < NW)
+        reinterpret_cast<uint64_t*>(a.ctl2 + (a.parity ^ 1))[threadIdx.x] = reinterpret_cast<const uint64_t*>(&L.c)[threadIdx.x];
 }
 
 // the evaluation request as the tile and the accept-reduce kernels decode it
@@ -343,13 +329,12 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
     QN_S2_STAMP(0);
-    // A wave's loads return in order.  So: the control block and the partial sums are requested first -- the prologue then never
-    // waits for the 128 KB window behind them -- and the window last (its first item is a function of blockIdx: no load).
+    // Wave 0 runs the prologue first (qn_s2_prologue_w0); waves 1..7 request the window at once.  The first item is a function of
+    // blockIdx: no load.
     int ij = qn_s2_first_item(blockIdx.x, a.nb);
-    QnS2Pro P;
-    qn_s2_pro_issue<QN_S2_EVAL>(a, P);
+    if (wave == 0) qn_s2_prologue_w0<QN_S2_EVAL>(a, L);
     int I = ij >> 16, J = ij & 0xffff;
-    // The wave's 16 rows of the first item are requested before the control block has arrived (their addresses do not depend on
+    // The wave's 16 rows of the first item are requested before the control block is known (their addresses do not depend on
     // it), and so are the first item's vector entries for BOTH settings of the two buffer toggles the control block holds
     // (x / trial point, pending / staged s); every register of the window is refilled with the next item's row the moment its
     // row is consumed: 128 KB in flight per workgroup across item boundaries, reductions and barriers.
@@ -365,11 +350,12 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         v1.x_c = ld2(a.F.X0 + np + jc); v1.s_c = ld2(a.F.S0 + np + jc);
     }
     QN_S2_STAMP(1);
-    if (!qn_s2_pro_finish<QN_S2_EVAL>(a, L, P)) return;
+    __syncthreads();
+    qn_s2_ctl_out(a, L);
+    if (!L.mine) return;
     QN_S2_STAMP(2);
     int stamp_k = 3;
     const QnEvalReq q = qn_s2_eval_req(L.c, false);
-    const int ev_par = L.c.ev_par;
     const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
     const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
     if (q.xc) { v0.x_r = v1.x_r; v0.x_c = v1.x_c; }
@@ -468,7 +454,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     }
     QN_S2_STAMP(15);
     if (tid == 0) {
-        double* out = a.wgE + ((size_t)ev_par * a.G + blockIdx.x) * QN_S2_ROW;
+        double* out = a.wgS + ((size_t)a.parity * a.trows + blockIdx.x) * QN_S2_ROW;
 #pragma unroll
         for (int k = 0; k < QN_S2_NSE; ++k) out[k] = wg[k];
     }
@@ -517,12 +503,11 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     __shared__ double bred[2][8];
     const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QnS2Slots S0;
-    {
-        QnS2Pro P;
-        qn_s2_pro_issue<QN_S2_VEC>(a, P);
-        qn_s2_slot_issue(a.part, a.nb, R, 0, S0);
-        if (!qn_s2_pro_finish<QN_S2_VEC>(a, L, P)) return;
-    }
+    if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC>(a, L);
+    qn_s2_slot_issue(a.part, a.nb, R, 0, S0);
+    __syncthreads();
+    qn_s2_ctl_out(a, L);
+    if (!L.mine) return;
     const size_t np = (size_t)a.np;
     const QnEvalReq q = qn_s2_eval_req(L.c, true);
     const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
@@ -553,7 +538,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
         if ((lane & 7) == 0) bred[wave][lane >> 3] = p[0];
     }
     __syncthreads();
-    if (tid < QN_S2_NR) a.rp[(size_t)R * QN_S2_ROW + tid] = bred[0][tid] + bred[1][tid];
+    if (tid < QN_S2_NR) a.wgS[((size_t)a.parity * a.trows + R) * QN_S2_ROW + tid] = bred[0][tid] + bred[1][tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -585,11 +570,10 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     __shared__ double colred[QN_S2_WAVES][2][QN_TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
-    int ij = qn_s2_first_item(blockIdx.x, a.nb); // (load order: control block and partial sums, then the window -- see s2_eval_kernel)
-    QnS2Pro P;
-    qn_s2_pro_issue<QN_S2_HTILE>(a, P);
+    int ij = qn_s2_first_item(blockIdx.x, a.nb);
+    if (wave == 0) qn_s2_prologue_w0<QN_S2_HTILE>(a, L); // (wave 0: the prologue first, then its rows -- see s2_eval_kernel)
     int I = ij >> 16, J = ij & 0xffff;
-    v2d h[QN_S2_RPW]; // the wave's 16 rows of the first item go out before the control block has arrived ...
+    v2d h[QN_S2_RPW]; // the wave's 16 rows of the first item go out before the control block is known ...
     double* hbase = a.H + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
 #pragma unroll
     for (int r = 0; r < QN_S2_RPW; ++r) h[r] = qn_sym_ld<NT>(hbase + (size_t)r * np);
@@ -606,7 +590,9 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         s1_r = a.F.S0[np + ir]; s1_c = ld2(a.F.S0 + np + jc);
         y_r = a.F.Y[ir]; y_c = ld2(a.F.Y + jc);
     }
-    if (!qn_s2_pro_finish<QN_S2_HTILE>(a, L, P)) return;
+    __syncthreads();
+    qn_s2_ctl_out(a, L);
+    if (!L.mine) return;
     QnS2HReq q;
     {
         const QnCtl& c = L.c;
@@ -706,13 +692,12 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
     __shared__ double bred[2][8];
     const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QnS2Slots S0, S1;
-    {
-        QnS2Pro P;
-        qn_s2_pro_issue<QN_S2_HREDUCE>(a, P);
-        qn_s2_slot_issue(a.part, a.nb, R, 0, S0);
-        qn_s2_slot_issue(a.part, a.nb, R, 1, S1);
-        if (!qn_s2_pro_finish<QN_S2_HREDUCE>(a, L, P)) return;
-    }
+    if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE>(a, L);
+    qn_s2_slot_issue(a.part, a.nb, R, 0, S0);
+    qn_s2_slot_issue(a.part, a.nb, R, 1, S1);
+    __syncthreads();
+    qn_s2_ctl_out(a, L);
+    if (!L.mine) return;
     const int nrhs = L.c.hp_nrhs;
     const double tot0 = qn_s2_slot_sum(a.part, a.nb, R, 0, S0, qbuf);
     const double tot1 = (nrhs == 2) ? qn_s2_slot_sum(a.part, a.nb, R, 1, S1, qbuf) : 0.0; // (uniform)
@@ -736,15 +721,15 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
         if ((lane & 7) == 0) bred[wave][lane >> 3] = p[0];
     }
     __syncthreads();
-    if (tid < 2) a.hrp[(size_t)R * 2 + tid] = bred[0][tid] + bred[1][tid];
+    if (tid < 2) a.wgS[((size_t)a.parity * a.trows + R) * QN_S2_ROW + tid] = bred[0][tid] + bred[1][tid];
 }
 
 // synchronous mode: the prologue alone (one workgroup)
-__global__ __launch_bounds__(QN_S2_TPB) void s2_advance_kernel(const QnS2Args a) {
+__global__ __launch_bounds__(128) void s2_advance_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
-    QnS2Pro P;
-    qn_s2_pro_issue<QN_S2_ADVANCE>(a, P);
-    (void)qn_s2_pro_finish<QN_S2_ADVANCE>(a, L, P);
+    if (threadIdx.x < 64) qn_s2_prologue_w0<QN_S2_ADVANCE>(a, L);
+    __syncthreads();
+    qn_s2_ctl_out(a, L);
 }
 
 // lower triangle <- transpose of the maintained upper one, 32 x 32 blocks through LDS; inside the diagonal blocks too
