@@ -46,285 +46,397 @@ __device__ __forceinline__ bool qn_check_is_scalar(const QnCtl& c) {
     return c.method != 2 && (c.small_n || c.gg_valid || c.method == 3);
 }
 
-// `side_effects`: false in all but one of the workgroups that run the machine redundantly (qn_sym2.hip.h): no trace stores
-__device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double* small_scratch, const bool side_effects = true) {
+// Every scalar state is a function of its own; ctl_scalar_run dispatches on the state and then runs the successions that are
+// certain or near-certain BACK TO BACK in straight-line code (qn_st_* below, QN_RUN_NEXT).  Why: the control block lives in LDS and
+// the machine is one lane's dependent chain.  As a `switch` inside a loop every state re-read what the previous one had just
+// stored -- the compiler cannot forward a store to a load across the loop's back edge -- and a run of six states cost ~100
+// serialised LDS round trips, 3 us of every sym2 prologue (tools/s2_stamps.py).  Inlined one after the other the stores are
+// forwarded, the `state == X` tests between them fold at compile time, and what remains is the arithmetic.  The functions are
+// the former `case` bodies verbatim: one source for every path, nothing is decided differently.
+// A state function returns false when the state needs all threads (the caller leaves the scalar run).
+// `side_effects`: false in all but one of the workgroups that run the machine redundantly (qn_sym2.hip.h): no trace stores.
+
+__device__ __forceinline__ void qn_st_begin(QnCtl& c) { // ls_solver.rs:74-76: only k is reset
+    c.k = 0;
+    // A fresh call evaluates the oracle at x_k and forms d = -H g from scratch (ls_solver.rs:79, bfgs.rs:47).  When it
+    // continues the previous call -- same immutable device objective, memoised oracle, state untouched -- both are already
+    // known: the last accepted evaluation IS f, g at x_k, and the direction is pending in its lazy form.
+    if (!c.warm) { c.have_cur_eval = 0; c.have_dir = 0; c.last_valid = 0; c.gg_valid = 0; }
+    else c.last_valid = 0;
+    c.n_oracle_calls = 0; c.n_oracle_evals = 0; c.n_hpasses = 0; c.n_hpass_rw = 0; c.n_iterations = 0;
+    c.status = -1;
+    c.state = QN_ST_LOOP_TOP;
+}
+
+__device__ __forceinline__ void qn_st_loop_top(QnCtl& c) { // ls_solver.rs:78-79
+    if (!(c.max_iter > c.k)) {
+        c.status = 1; // MaxIterReached, ls_solver.rs:109-110
+        c.phase = QN_PH_DONE;
+    } else {
+        c.tr_n_evals = 0; c.tr_ls_iters = 0; c.tr_ls_cases = 0; c.tr_ndigits = 0; c.tr_updated = 0;
+        c.ls_result = NAN;
+        c.n_oracle_calls++;
+        c.tr_n_evals++;
+        if (c.memoize && c.have_cur_eval) {
+            c.state = QN_ST_CHECK;
+        } else {
+            c.req_kind = QN_REQ_X; c.req_t = 0.0; c.req_need_vectors = 1;
+            c.after_state = QN_ST_AFTER_EVALX;
+            c.phase = QN_PH_REQ_EVAL;
+        }
+    }
+}
+
+__device__ __forceinline__ bool qn_st_after_evalx(QnCtl& c) {
+    if (!c.fused) return false;
+    c.f_k = c.f_e; // g <- gt is committed by the direction pass (h_pass row-block 0)
+    c.gg = c.st_gg; c.gg_valid = 1;
+    c.have_cur_eval = c.memoize;
+    c.have_dir = 0;
+    c.state = QN_ST_CHECK;
+    return true;
+}
+
+__device__ __forceinline__ bool qn_st_after_dir(QnCtl& c) {
+    if (!c.fused) return false;
+    c.n_hpasses++;
+    if (c.pending) c.n_hpass_rw++;
+    c.pending = 0;
+    c.dir_mode = 0; // d = -v
+    c.gd0_valid = 0; c.d_finite = 0; c.last_valid = 0;
+    c.state = QN_ST_LS_BEGIN;
+    return true;
+}
+
+__device__ __forceinline__ bool qn_st_after_next(QnCtl& c) { // bfgs.rs:94-102 from the sums staged by the accepted evaluation
+    if (!c.fused) return false;
+    c.s_norm = sqrt(c.st_ss); c.has_s_norm = 1;
+    c.y_norm = sqrt(c.st_yy); c.has_y_norm = 1;
+    c.ys = c.st_ys;
+    c.gg = c.st_gg; c.gg_valid = 1;
+    c.f_k = c.f_e;
+    c.xc ^= 1; // x <- x+ : the trial half of the double buffer becomes x
+    c.have_cur_eval = c.memoize;
+    c.have_dir = 0;
+    c.last_valid = 0;
+    if (c.s_norm < c.tol || c.y_norm < c.tol) { // bfgs.rs:106-112: H is not updated
+        c.state = QN_ST_ITER_END;
+    } else {
+        c.hp_lazy = 1; c.hp_nrhs = 2;
+        const double fk = c.f_k;
+        const bool will_continue = (c.k + 1 < c.max_iter) && !(isnan(fk) || isinf(fk)) && !(sqrt(c.gg) < c.tol);
+        if (will_continue && !c.callback_mode && !c.no_defer && !c.sym2) { // (sym2: every step is a prologue, nothing to save)
+            // Deferred update: everything the step after the H pass would decide is already known except the
+            // update's coefficients (they need y.u, u.g+, s.g+ from the pass).  Run the rest of the iteration
+            // bookkeeping now; the next evaluation request becomes QN_PH_REQ_HPASS_EVAL, its kernel derives the
+            // coefficients from the pass's partial sums, and the following step commits them.  One launch less.
+            c.defer_u = 1;
+            c.tr_updated = 1;
+            c.have_dir = 1; c.gd0_valid = 0; c.d_finite = 0;
+            c.state = QN_ST_ITER_END;
+        } else {
+            c.after_state = QN_ST_AFTER_U;
+            c.phase = QN_PH_REQ_HPASS;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool qn_st_after_u(QnCtl& c) { // coefficients of bfgs.rs:115-124 / dfp.rs:115-120 in rank-2 form
+    if (!c.fused) return false;
+    const double yu = c.hp_yu;
+    double c_ss, c_su, c_uu;
+    qn_update_coeffs(c.method, c.ys, yu, c_ss, c_su, c_uu);
+    c.c_ss = c_ss; c.c_su = c_su; c.c_uu = c_uu;
+    c.n_hpasses++;
+    if (c.pending) c.n_hpass_rw++;
+    c.pending = 1;
+    c.sc ^= 1; // the staged s becomes the pending s; the new u is already in UN
+    c.dir_mode = 1; c.dir_ug = c.hp_ug; c.dir_sg = c.hp_sg; // next direction formed on the fly by the evaluations
+    c.gd0_valid = 0; c.d_finite = 0;
+    c.have_dir = 1;
+    c.tr_updated = 1;
+    c.state = QN_ST_ITER_END;
+    return true;
+}
+
+__device__ __forceinline__ bool qn_st_check(QnCtl& c, const QnVecs& V, double* small_scratch) { // ls_solver.rs:37-40 (OutOfDomain), has_converged (bfgs.rs:64-76)
     const int n = V.n, n_pad = V.n_pad;
+    if (!qn_check_is_scalar(c)) return false; // gradient descent / unknown ||g||: all threads needed
+    if (c.method == 3) { // Newton: has_converged is the decrement test (newton/mod.rs:64-69)
+        c.gnorm = c.gg_valid ? sqrt(c.gg) : NAN; c.tr_f = c.f_k; c.tr_gnorm = c.gnorm;
+        const double f = c.f_k;
+        if (isnan(f) || isinf(f)) { c.status = 2; c.phase = QN_PH_DONE; }
+        else if (c.has_dec && c.dec * 0.5 < c.tol) { c.status = 0; c.phase = QN_PH_DONE; }
+        else { c.after_state = QN_ST_AFTER_NEWTON; c.phase = QN_PH_REQ_NEWTON; } // compute_direction, newton/mod.rs:26-49
+        return true;
+    }
+    double gnorm, gd0 = c.gd0;
+    int d_finite = c.d_finite;
+    if (c.small_n) { // reference order: norm = sqrt(dot), direction by column sweep (bfgs.rs:47)
+        gnorm = sqrt(ref_dot(V.g, V.g, n));
+        small_direction(V.H, n_pad, n, V.g, V.d, small_scratch, V.x, c.bounded ? V.lb : nullptr, c.bounded ? V.ub : nullptr);
+        if (c.ls_kind == 2) { // morethuente_b.rs:185-198
+            double cand = INFINITY;
+            for (int i = 0; i < n; ++i) {
+                const double di = V.d[i];
+                double v = INFINITY;
+                if (di > 0.0) v = (V.lub[i] - V.x[i]) / di; else if (di < 0.0) v = (V.llb[i] - V.x[i]) / di;
+                cand = fmin(v, cand);
+            }
+            c.mtb_cand = cand;
+        }
+        gd0 = ref_dot(V.g, V.d, n);
+        d_finite = 1;
+        for (int i = 0; i < n; ++i) d_finite &= isfinite(V.d[i]) ? 1 : 0;
+    } else {
+        gnorm = sqrt(c.gg);
+    }
+    c.gnorm = gnorm; c.tr_f = c.f_k; c.tr_gnorm = gnorm;
+    const double f = c.f_k;
+    if (isnan(f) || isinf(f)) {
+        c.status = 2; c.phase = QN_PH_DONE; // OutOfDomain
+    } else if ((c.has_s_norm && c.s_norm < c.tol) || (c.has_y_norm && c.y_norm < c.tol) || (gnorm < c.tol)) {
+        c.status = 0; c.phase = QN_PH_DONE;
+    } else if (c.small_n) {
+        c.gd0 = gd0; c.d_finite = d_finite; c.last_valid = 0;
+        c.state = QN_ST_LS_BEGIN;
+    } else if (c.have_dir) {
+        c.state = QN_ST_LS_BEGIN;
+    } else { // bfgs.rs:47 d = -(H g): one pass over H (applies a pending update on the way)
+        c.hp_nrhs = 1; c.hp_lazy = 0;
+        c.after_state = QN_ST_AFTER_DIR;
+        c.phase = QN_PH_REQ_HPASS;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void qn_st_ls_begin(QnCtl& c) {
+    c.ls_i = 0;
+    if (c.ls_kind == 2) c.mt_tmax = fmin(c.mt_tmax, c.mtb_cand); // morethuente_b.rs:201: self.t_max = self.t_max.min(candidate) -- persists
+    if (c.ls_kind == 0 || c.ls_kind == 2) { // morethuente.rs:173-178
+        c.use_mod = 0; c.conv = 0;
+        c.t = fmin(fmax(1.0, c.mt_tmin), c.mt_tmax);
+        c.tl = c.mt_tmin; c.tu = c.mt_tmax;
+        c.state = QN_ST_MT_LOOP;
+    } else { // backtracking.rs:28-29
+        c.t = 1.0;
+        c.state = QN_ST_BT_LOOP;
+    }
+}
+
+__device__ __forceinline__ void qn_st_mt_loop(QnCtl& c) { // morethuente.rs:181-182
+    if (!(c.ls_i < c.max_iter_ls)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :295-296
+    else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_MT_AFTER_T, 0); }
+}
+
+__device__ __forceinline__ void qn_st_mt_after_t(QnCtl& c) { // morethuente.rs:184-217
+    const double f_et = c.f_e, gd_t = c.gd_e, t = c.t;
+    const bool wolfe = (f_et - c.f_k <= c.mt_c1 * t * c.gd0) && (fabs(gd_t) <= c.mt_c2 * fabs(c.gd0));
+    if (wolfe || c.conv || t == c.tl || t == c.tu) {
+        tr_push_case(c, 0);
+        c.ls_result = t; c.state = QN_ST_AFTER_LS;
+    } else {
+        c.phi_t_f = f_et; c.phi_t_g = gd_t;
+        c.psi_t_f = f_et - c.f_k - c.mt_c1 * t * c.gd0; // psi, :140-149
+        c.psi_t_g = gd_t - c.mt_c1 * c.gd0;
+        if (!c.use_mod && c.psi_t_f <= 0. && c.phi_t_g > 0.) { c.use_mod = 1; c.tr_ls_cases |= QN_LS_MODIFIED_BIT; } // :212-215 (sticky)
+        req_eval_t(c, c.tl, QN_ST_MT_AFTER_TL, 0); // :217
+    }
+}
+
+__device__ __forceinline__ void qn_st_mt_after_tl(QnCtl& c) { // morethuente.rs:218-287
+    const double phi_tl_f = c.f_e, phi_tl_g = c.gd_e;
+    double f_tl, g_tl, f_t, g_t;
+    if (c.use_mod) { f_tl = phi_tl_f; g_tl = phi_tl_g; f_t = c.phi_t_f; g_t = c.phi_t_g; }
+    else {
+        f_tl = phi_tl_f - c.f_k - c.mt_c1 * c.tl * c.gd0;
+        g_tl = phi_tl_g - c.mt_c1 * c.gd0;
+        f_t = c.psi_t_f; g_t = c.psi_t_g;
+    }
+    c.sel_f_tl = f_tl; c.sel_g_tl = g_tl; c.sel_f_t = f_t; c.sel_g_t = g_t;
+    const double t = c.t, tl = c.tl, tu = c.tu;
+    if (f_t > f_tl) { // case 1
+        const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
+        const double tq = mt_quad1(tl, t, f_tl, f_t, g_tl);
+        tr_push_case(c, 1);
+        c.t = (fabs(tc - tl) < fabs(tq - tl)) ? tc : 0.5 * (tq + tc);
+        c.state = QN_ST_MT_FINISH;
+    } else if (g_t * g_tl < 0.) { // case 2
+        const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
+        const double ts = mt_quad2(tl, t, g_tl, g_t);
+        tr_push_case(c, 2);
+        c.t = (fabs(tc - t) >= fabs(ts - t)) ? tc : ts;
+        c.state = QN_ST_MT_FINISH;
+    } else if (fabs(g_t) <= fabs(g_tl)) { // case 3
+        const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
+        const double ts = mt_quad2(tl, t, g_tl, g_t);
+        tr_push_case(c, 3);
+        const double t_plus = (fabs(tc - t) < fabs(ts - t)) ? tc : ts;
+        if (t > tl) c.t = fmin(t_plus, t + c.mt_delta * (tu - t));
+        else c.t = fmax(t_plus, t + c.mt_delta * (tu - t));
+        c.state = QN_ST_MT_FINISH;
+    } else { // case 4: evaluates at tu (possibly +inf), :274-287
+        req_eval_t(c, c.tu, QN_ST_MT_AFTER_TU, 0);
+    }
+}
+
+__device__ __forceinline__ void qn_st_mt_after_tu(QnCtl& c) {
+    double f_tu, g_tu;
+    if (c.use_mod) { f_tu = c.f_e; g_tu = c.gd_e; }
+    else { f_tu = c.f_e - c.f_k - c.mt_c1 * c.tu * c.gd0; g_tu = c.gd_e - c.mt_c1 * c.gd0; }
+    tr_push_case(c, 4);
+    c.t = mt_cubic(c.tu, c.t, c.sel_f_t, f_tu, c.sel_g_t, g_tu); // :286, argument order as written
+    c.state = QN_ST_MT_FINISH;
+}
+
+__device__ __forceinline__ void qn_st_mt_finish(QnCtl& c) { // morethuente.rs:290-293: the NEW t with the OLD trial's f_t, g_t
+    c.t = fmin(fmax(c.t, c.mt_tmin), c.mt_tmax);
+    double tl = c.tl, tu = c.tu;
+    c.conv = mt_update_interval(c.sel_f_tl, c.sel_f_t, c.sel_g_t, &tl, c.t, &tu);
+    c.tl = tl; c.tu = tu;
+    c.ls_i++;
+    c.state = QN_ST_MT_LOOP;
+}
+
+__device__ __forceinline__ void qn_st_bt_loop(QnCtl& c) { // backtracking.rs:31-34
+    if (!(c.max_iter_ls > c.ls_i)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :54
+    else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_BT_AFTER, 0, c.ls_kind == 3 ? 1 : 0); }
+}
+
+__device__ __forceinline__ void qn_st_bt_after(QnCtl& c) { // backtracking.rs:37-51
+    const double f1 = c.f_e;
+    if (isnan(f1) || isinf(f1)) { c.t *= c.bt_beta; c.state = QN_ST_BT_LOOP; } // shrink, iteration not counted
+    else if (c.ls_kind == 3 ? (f1 - c.f_k <= (-c.bt_c1 / c.t) * c.bt_diff2) // backtracking_b.rs:24-34
+                            : (f1 - c.f_k <= c.bt_c1 * c.t * c.gd0)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; }
+    else { c.t *= c.bt_beta; c.ls_i++; c.state = QN_ST_BT_LOOP; }
+}
+
+__device__ __forceinline__ bool qn_st_after_ls(QnCtl& c) {
+    if (c.ls_only) { c.status = 0; c.phase = QN_PH_DONE; return true; } // compute_step_len returns the step, nothing else
+    if (c.method == 2 || c.method == 3) return false; // gradient descent / Newton: the default hook x += step*d needs all threads
+    req_eval_t(c, c.ls_result, QN_ST_AFTER_NEXT, 1); // bfgs.rs:94,98: oracle(x + step*d)
+    return true;
+}
+
+__device__ __forceinline__ bool qn_st_iter_end(QnCtl& c, const QnVecs& V, const bool side_effects) { // ls_solver.rs:104-107
+    const bool rec = c.k < c.trace_cap;
+    if (rec && c.trace_x && !c.xtrace_done) return false; // the iterate has to be copied by all threads first
+    if (rec) {
+        QnTraceRec r;
+        r.f = c.tr_f; r.gnorm = c.tr_gnorm; r.t = c.ls_result;
+        r.s_norm = c.has_s_norm ? c.s_norm : NAN;
+        r.y_norm = c.has_y_norm ? c.y_norm : NAN;
+        r.n_evals = c.tr_n_evals; r.ls_iters = c.tr_ls_iters; r.ls_cases = c.tr_ls_cases; r.updated = c.tr_updated;
+        if (side_effects) V.trace[c.k] = r;
+    }
+    c.xtrace_done = 0;
+    c.k += 1;
+    c.n_iterations++;
+    c.state = QN_ST_LOOP_TOP;
+    if (c.callback_mode) c.phase = QN_PH_ITER_DONE;
+    return true;
+}
+
+// run state function CALL when the machine is still running and in state ST; otherwise back to the dispatcher
+#define QN_RUN_NEXT(ST, CALL)                                           \
+    if (!(c.phase == QN_PH_RUNNING && c.state == (ST))) break;          \
+    CALL;
+#define QN_RUN_NEXT_B(ST, CALL)                                         \
+    if (!(c.phase == QN_PH_RUNNING && c.state == (ST))) break;          \
+    if (!(CALL)) return;
+
+__device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double* small_scratch, const bool side_effects = true) {
     for (int guard = 0; guard < (1 << 22); ++guard) {
         if (c.phase != QN_PH_RUNNING) return;
         switch (c.state) {
-        case QN_ST_BEGIN: { // ls_solver.rs:74-76: only k is reset
-            c.k = 0;
-            // A fresh call evaluates the oracle at x_k and forms d = -H g from scratch (ls_solver.rs:79, bfgs.rs:47).  When it
-            // continues the previous call -- same immutable device objective, memoised oracle, state untouched -- both are already
-            // known: the last accepted evaluation IS f, g at x_k, and the direction is pending in its lazy form.
-            if (!c.warm) { c.have_cur_eval = 0; c.have_dir = 0; c.last_valid = 0; c.gg_valid = 0; }
-            else c.last_valid = 0;
-            c.n_oracle_calls = 0; c.n_oracle_evals = 0; c.n_hpasses = 0; c.n_hpass_rw = 0; c.n_iterations = 0;
-            c.status = -1;
-            c.state = QN_ST_LOOP_TOP;
-        } break;
+        // (only the successions of the steady iteration are chained: every chained copy of a state is code, and the machine is
+        // inlined into every sym2 kernel)
+        case QN_ST_BEGIN:
+            qn_st_begin(c);
+            qn_st_loop_top(c);
+            break;
 
-        case QN_ST_LOOP_TOP: { // ls_solver.rs:78-79
-            if (!(c.max_iter > c.k)) {
-                c.status = 1; // MaxIterReached, ls_solver.rs:109-110
-                c.phase = QN_PH_DONE;
-            } else {
-                c.tr_n_evals = 0; c.tr_ls_iters = 0; c.tr_ls_cases = 0; c.tr_ndigits = 0; c.tr_updated = 0;
-                c.ls_result = NAN;
-                c.n_oracle_calls++;
-                c.tr_n_evals++;
-                if (c.memoize && c.have_cur_eval) {
-                    c.state = QN_ST_CHECK;
-                } else {
-                    c.req_kind = QN_REQ_X; c.req_t = 0.0; c.req_need_vectors = 1;
-                    c.after_state = QN_ST_AFTER_EVALX;
-                    c.phase = QN_PH_REQ_EVAL;
-                }
-            }
-        } break;
+        case QN_ST_LOOP_TOP: qn_st_loop_top(c); break;
 
-        case QN_ST_AFTER_EVALX: {
-            if (!c.fused) return;
-            c.f_k = c.f_e; // g <- gt is committed by the direction pass (h_pass row-block 0)
-            c.gg = c.st_gg; c.gg_valid = 1;
-            c.have_cur_eval = c.memoize;
-            c.have_dir = 0;
-            c.state = QN_ST_CHECK;
-        } break;
+        case QN_ST_AFTER_EVALX:
+            if (!qn_st_after_evalx(c)) return;
+            break;
 
-        case QN_ST_AFTER_DIR: {
-            if (!c.fused) return;
-            c.n_hpasses++;
-            if (c.pending) c.n_hpass_rw++;
-            c.pending = 0;
-            c.dir_mode = 0; // d = -v
-            c.gd0_valid = 0; c.d_finite = 0; c.last_valid = 0;
-            c.state = QN_ST_LS_BEGIN;
-        } break;
+        case QN_ST_AFTER_DIR:
+            if (!qn_st_after_dir(c)) return;
+            qn_st_ls_begin(c);
+            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop(c))
+            break;
 
-        case QN_ST_AFTER_NEXT: { // bfgs.rs:94-102 from the sums staged by the accepted evaluation
-            if (!c.fused) return;
-            c.s_norm = sqrt(c.st_ss); c.has_s_norm = 1;
-            c.y_norm = sqrt(c.st_yy); c.has_y_norm = 1;
-            c.ys = c.st_ys;
-            c.gg = c.st_gg; c.gg_valid = 1;
-            c.f_k = c.f_e;
-            c.xc ^= 1; // x <- x+ : the trial half of the double buffer becomes x
-            c.have_cur_eval = c.memoize;
-            c.have_dir = 0;
-            c.last_valid = 0;
-            if (c.s_norm < c.tol || c.y_norm < c.tol) { // bfgs.rs:106-112: H is not updated
-                c.state = QN_ST_ITER_END;
-            } else {
-                c.hp_lazy = 1; c.hp_nrhs = 2;
-                const double fk = c.f_k;
-                const bool will_continue = (c.k + 1 < c.max_iter) && !(isnan(fk) || isinf(fk)) && !(sqrt(c.gg) < c.tol);
-                if (will_continue && !c.callback_mode && !c.no_defer && !c.sym2) { // (sym2: every step is a prologue, nothing to save)
-                    // Deferred update: everything the step after the H pass would decide is already known except the
-                    // update's coefficients (they need y.u, u.g+, s.g+ from the pass).  Run the rest of the iteration
-                    // bookkeeping now; the next evaluation request becomes QN_PH_REQ_HPASS_EVAL, its kernel derives the
-                    // coefficients from the pass's partial sums, and the following step commits them.  One launch less.
-                    c.defer_u = 1;
-                    c.tr_updated = 1;
-                    c.have_dir = 1; c.gd0_valid = 0; c.d_finite = 0;
-                    c.state = QN_ST_ITER_END;
-                } else {
-                    c.after_state = QN_ST_AFTER_U;
-                    c.phase = QN_PH_REQ_HPASS;
-                }
-            }
-        } break;
+        case QN_ST_AFTER_NEXT:
+            if (!qn_st_after_next(c)) return;
+            break;
 
-        case QN_ST_AFTER_U: { // coefficients of bfgs.rs:115-124 / dfp.rs:115-120 in rank-2 form
-            if (!c.fused) return;
-            const double yu = c.hp_yu;
-            qn_update_coeffs(c.method, c.ys, yu, c.c_ss, c.c_su, c.c_uu);
-            c.n_hpasses++;
-            if (c.pending) c.n_hpass_rw++;
-            c.pending = 1;
-            c.sc ^= 1; // the staged s becomes the pending s; the new u is already in UN
-            c.dir_mode = 1; c.dir_ug = c.hp_ug; c.dir_sg = c.hp_sg; // next direction formed on the fly by the evaluations
-            c.gd0_valid = 0; c.d_finite = 0;
-            c.have_dir = 1;
-            c.tr_updated = 1;
-            c.state = QN_ST_ITER_END;
-        } break;
+        case QN_ST_AFTER_U: // ... the iteration ends, the next one begins: up to the first trial of its line search
+            if (!qn_st_after_u(c)) return;
+            QN_RUN_NEXT_B(QN_ST_ITER_END, qn_st_iter_end(c, V, side_effects))
+            QN_RUN_NEXT(QN_ST_LOOP_TOP, qn_st_loop_top(c))
+            QN_RUN_NEXT_B(QN_ST_CHECK, qn_st_check(c, V, small_scratch))
+            QN_RUN_NEXT(QN_ST_LS_BEGIN, qn_st_ls_begin(c))
+            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop(c))
+            break;
 
-        case QN_ST_CHECK: { // ls_solver.rs:37-40 (OutOfDomain), has_converged (bfgs.rs:64-76)
-            if (!qn_check_is_scalar(c)) return; // gradient descent / unknown ||g||: all threads needed
-            if (c.method == 3) { // Newton: has_converged is the decrement test (newton/mod.rs:64-69)
-                c.gnorm = c.gg_valid ? sqrt(c.gg) : NAN; c.tr_f = c.f_k; c.tr_gnorm = c.gnorm;
-                const double f = c.f_k;
-                if (isnan(f) || isinf(f)) { c.status = 2; c.phase = QN_PH_DONE; }
-                else if (c.has_dec && c.dec * 0.5 < c.tol) { c.status = 0; c.phase = QN_PH_DONE; }
-                else { c.after_state = QN_ST_AFTER_NEWTON; c.phase = QN_PH_REQ_NEWTON; } // compute_direction, newton/mod.rs:26-49
-                break;
-            }
-            double gnorm, gd0 = c.gd0;
-            int d_finite = c.d_finite;
-            if (c.small_n) { // reference order: norm = sqrt(dot), direction by column sweep (bfgs.rs:47)
-                gnorm = sqrt(ref_dot(V.g, V.g, n));
-                small_direction(V.H, n_pad, n, V.g, V.d, small_scratch, V.x, c.bounded ? V.lb : nullptr, c.bounded ? V.ub : nullptr);
-                if (c.ls_kind == 2) { // morethuente_b.rs:185-198
-                    double cand = INFINITY;
-                    for (int i = 0; i < n; ++i) {
-                        const double di = V.d[i];
-                        double v = INFINITY;
-                        if (di > 0.0) v = (V.lub[i] - V.x[i]) / di; else if (di < 0.0) v = (V.llb[i] - V.x[i]) / di;
-                        cand = fmin(v, cand);
-                    }
-                    c.mtb_cand = cand;
-                }
-                gd0 = ref_dot(V.g, V.d, n);
-                d_finite = 1;
-                for (int i = 0; i < n; ++i) d_finite &= isfinite(V.d[i]) ? 1 : 0;
-            } else {
-                gnorm = sqrt(c.gg);
-            }
-            c.gnorm = gnorm; c.tr_f = c.f_k; c.tr_gnorm = gnorm;
-            const double f = c.f_k;
-            if (isnan(f) || isinf(f)) {
-                c.status = 2; c.phase = QN_PH_DONE; // OutOfDomain
-            } else if ((c.has_s_norm && c.s_norm < c.tol) || (c.has_y_norm && c.y_norm < c.tol) || (gnorm < c.tol)) {
-                c.status = 0; c.phase = QN_PH_DONE;
-            } else if (c.small_n) {
-                c.gd0 = gd0; c.d_finite = d_finite; c.last_valid = 0;
-                c.state = QN_ST_LS_BEGIN;
-            } else if (c.have_dir) {
-                c.state = QN_ST_LS_BEGIN;
-            } else { // bfgs.rs:47 d = -(H g): one pass over H (applies a pending update on the way)
-                c.hp_nrhs = 1; c.hp_lazy = 0;
-                c.after_state = QN_ST_AFTER_DIR;
-                c.phase = QN_PH_REQ_HPASS;
-            }
-        } break;
+        case QN_ST_CHECK:
+            if (!qn_st_check(c, V, small_scratch)) return;
+            QN_RUN_NEXT(QN_ST_LS_BEGIN, qn_st_ls_begin(c))
+            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop(c))
+            break;
 
-        case QN_ST_LS_BEGIN: {
-            c.ls_i = 0;
-            if (c.ls_kind == 2) c.mt_tmax = fmin(c.mt_tmax, c.mtb_cand); // morethuente_b.rs:201: self.t_max = self.t_max.min(candidate) -- persists
-            if (c.ls_kind == 0 || c.ls_kind == 2) { // morethuente.rs:173-178
-                c.use_mod = 0; c.conv = 0;
-                c.t = fmin(fmax(1.0, c.mt_tmin), c.mt_tmax);
-                c.tl = c.mt_tmin; c.tu = c.mt_tmax;
-                c.state = QN_ST_MT_LOOP;
-            } else { // backtracking.rs:28-29
-                c.t = 1.0;
-                c.state = QN_ST_BT_LOOP;
-            }
-        } break;
+        case QN_ST_LS_BEGIN:
+            qn_st_ls_begin(c);
+            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop(c))
+            break;
 
-        case QN_ST_MT_LOOP: { // morethuente.rs:181-182
-            if (!(c.ls_i < c.max_iter_ls)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :295-296
-            else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_MT_AFTER_T, 0); }
-        } break;
+        case QN_ST_MT_LOOP: qn_st_mt_loop(c); break;
 
-        case QN_ST_MT_AFTER_T: { // morethuente.rs:184-217
-            const double f_et = c.f_e, gd_t = c.gd_e, t = c.t;
-            const bool wolfe = (f_et - c.f_k <= c.mt_c1 * t * c.gd0) && (fabs(gd_t) <= c.mt_c2 * fabs(c.gd0));
-            if (wolfe || c.conv || t == c.tl || t == c.tu) {
-                tr_push_case(c, 0);
-                c.ls_result = t; c.state = QN_ST_AFTER_LS;
-            } else {
-                c.phi_t_f = f_et; c.phi_t_g = gd_t;
-                c.psi_t_f = f_et - c.f_k - c.mt_c1 * t * c.gd0; // psi, :140-149
-                c.psi_t_g = gd_t - c.mt_c1 * c.gd0;
-                if (!c.use_mod && c.psi_t_f <= 0. && c.phi_t_g > 0.) { c.use_mod = 1; c.tr_ls_cases |= QN_LS_MODIFIED_BIT; } // :212-215 (sticky)
-                req_eval_t(c, c.tl, QN_ST_MT_AFTER_TL, 0); // :217
-            }
-        } break;
+        case QN_ST_MT_AFTER_T: // a trial came back: accepted (the step leaves the search), or the next trial from the memo of phi(tl)
+            qn_st_mt_after_t(c);
+            if (c.phase == QN_PH_RUNNING && c.state == QN_ST_AFTER_LS) { if (!qn_st_after_ls(c)) return; break; }
+            QN_RUN_NEXT(QN_ST_MT_AFTER_TL, qn_st_mt_after_tl(c))
+            QN_RUN_NEXT(QN_ST_MT_FINISH, qn_st_mt_finish(c))
+            qn_st_mt_loop(c);
+            break;
 
-        case QN_ST_MT_AFTER_TL: { // morethuente.rs:218-287
-            const double phi_tl_f = c.f_e, phi_tl_g = c.gd_e;
-            double f_tl, g_tl, f_t, g_t;
-            if (c.use_mod) { f_tl = phi_tl_f; g_tl = phi_tl_g; f_t = c.phi_t_f; g_t = c.phi_t_g; }
-            else {
-                f_tl = phi_tl_f - c.f_k - c.mt_c1 * c.tl * c.gd0;
-                g_tl = phi_tl_g - c.mt_c1 * c.gd0;
-                f_t = c.psi_t_f; g_t = c.psi_t_g;
-            }
-            c.sel_f_tl = f_tl; c.sel_g_tl = g_tl; c.sel_f_t = f_t; c.sel_g_t = g_t;
-            const double t = c.t, tl = c.tl, tu = c.tu;
-            if (f_t > f_tl) { // case 1
-                const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
-                const double tq = mt_quad1(tl, t, f_tl, f_t, g_tl);
-                tr_push_case(c, 1);
-                c.t = (fabs(tc - tl) < fabs(tq - tl)) ? tc : 0.5 * (tq + tc);
-                c.state = QN_ST_MT_FINISH;
-            } else if (g_t * g_tl < 0.) { // case 2
-                const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
-                const double ts = mt_quad2(tl, t, g_tl, g_t);
-                tr_push_case(c, 2);
-                c.t = (fabs(tc - t) >= fabs(ts - t)) ? tc : ts;
-                c.state = QN_ST_MT_FINISH;
-            } else if (fabs(g_t) <= fabs(g_tl)) { // case 3
-                const double tc = mt_cubic(tl, t, f_tl, f_t, g_tl, g_t);
-                const double ts = mt_quad2(tl, t, g_tl, g_t);
-                tr_push_case(c, 3);
-                const double t_plus = (fabs(tc - t) < fabs(ts - t)) ? tc : ts;
-                if (t > tl) c.t = fmin(t_plus, t + c.mt_delta * (tu - t));
-                else c.t = fmax(t_plus, t + c.mt_delta * (tu - t));
-                c.state = QN_ST_MT_FINISH;
-            } else { // case 4: evaluates at tu (possibly +inf), :274-287
-                req_eval_t(c, c.tu, QN_ST_MT_AFTER_TU, 0);
-            }
-        } break;
+        case QN_ST_MT_AFTER_TL:
+            qn_st_mt_after_tl(c);
+            QN_RUN_NEXT(QN_ST_MT_FINISH, qn_st_mt_finish(c))
+            qn_st_mt_loop(c);
+            break;
 
-        case QN_ST_MT_AFTER_TU: {
-            double f_tu, g_tu;
-            if (c.use_mod) { f_tu = c.f_e; g_tu = c.gd_e; }
-            else { f_tu = c.f_e - c.f_k - c.mt_c1 * c.tu * c.gd0; g_tu = c.gd_e - c.mt_c1 * c.gd0; }
-            tr_push_case(c, 4);
-            c.t = mt_cubic(c.tu, c.t, c.sel_f_t, f_tu, c.sel_g_t, g_tu); // :286, argument order as written
-            c.state = QN_ST_MT_FINISH;
-        } break;
+        case QN_ST_MT_AFTER_TU:
+            qn_st_mt_after_tu(c);
+            qn_st_mt_finish(c);
+            qn_st_mt_loop(c);
+            break;
 
-        case QN_ST_MT_FINISH: { // morethuente.rs:290-293: the NEW t with the OLD trial's f_t, g_t
-            c.t = fmin(fmax(c.t, c.mt_tmin), c.mt_tmax);
-            double tl = c.tl, tu = c.tu;
-            c.conv = mt_update_interval(c.sel_f_tl, c.sel_f_t, c.sel_g_t, &tl, c.t, &tu);
-            c.tl = tl; c.tu = tu;
-            c.ls_i++;
-            c.state = QN_ST_MT_LOOP;
-        } break;
+        case QN_ST_MT_FINISH:
+            qn_st_mt_finish(c);
+            qn_st_mt_loop(c);
+            break;
 
-        case QN_ST_BT_LOOP: { // backtracking.rs:31-34
-            if (!(c.max_iter_ls > c.ls_i)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :54
-            else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_BT_AFTER, 0, c.ls_kind == 3 ? 1 : 0); }
-        } break;
+        case QN_ST_BT_LOOP: qn_st_bt_loop(c); break;
 
-        case QN_ST_BT_AFTER: { // backtracking.rs:37-51
-            const double f1 = c.f_e;
-            if (isnan(f1) || isinf(f1)) { c.t *= c.bt_beta; c.state = QN_ST_BT_LOOP; } // shrink, iteration not counted
-            else if (c.ls_kind == 3 ? (f1 - c.f_k <= (-c.bt_c1 / c.t) * c.bt_diff2) // backtracking_b.rs:24-34
-                                    : (f1 - c.f_k <= c.bt_c1 * c.t * c.gd0)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; }
-            else { c.t *= c.bt_beta; c.ls_i++; c.state = QN_ST_BT_LOOP; }
-        } break;
+        case QN_ST_BT_AFTER:
+            qn_st_bt_after(c);
+            if (c.phase == QN_PH_RUNNING && c.state == QN_ST_AFTER_LS) { if (!qn_st_after_ls(c)) return; break; }
+            QN_RUN_NEXT(QN_ST_BT_LOOP, qn_st_bt_loop(c))
+            break;
 
         case QN_ST_LS_ONLY: return; // g.d needs all threads
 
-        case QN_ST_AFTER_LS: {
-            if (c.ls_only) { c.status = 0; c.phase = QN_PH_DONE; break; } // compute_step_len returns the step, nothing else
-            if (c.method == 2 || c.method == 3) return; // gradient descent / Newton: the default hook x += step*d needs all threads
-            req_eval_t(c, c.ls_result, QN_ST_AFTER_NEXT, 1); // bfgs.rs:94,98: oracle(x + step*d)
-        } break;
+        case QN_ST_AFTER_LS:
+            if (!qn_st_after_ls(c)) return;
+            break;
 
-        case QN_ST_ITER_END: { // ls_solver.rs:104-107
-            const bool rec = c.k < c.trace_cap;
-            if (rec && c.trace_x && !c.xtrace_done) return; // the iterate has to be copied by all threads first
-            if (rec) {
-                QnTraceRec r;
-                r.f = c.tr_f; r.gnorm = c.tr_gnorm; r.t = c.ls_result;
-                r.s_norm = c.has_s_norm ? c.s_norm : NAN;
-                r.y_norm = c.has_y_norm ? c.y_norm : NAN;
-                r.n_evals = c.tr_n_evals; r.ls_iters = c.tr_ls_iters; r.ls_cases = c.tr_ls_cases; r.updated = c.tr_updated;
-                if (side_effects) V.trace[c.k] = r;
-            }
-            c.xtrace_done = 0;
-            c.k += 1;
-            c.n_iterations++;
-            c.state = QN_ST_LOOP_TOP;
-            if (c.callback_mode) c.phase = QN_PH_ITER_DONE;
-        } break;
+        case QN_ST_ITER_END:
+            if (!qn_st_iter_end(c, V, side_effects)) return;
+            break;
 
         default:
             return; // a vector state
@@ -333,6 +445,8 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
     c.status = 4; // guard tripped
     c.phase = QN_PH_DONE;
 }
+#undef QN_RUN_NEXT
+#undef QN_RUN_NEXT_B
 
 // ------------------------------------------------------------------------------------------------
 // the kernel

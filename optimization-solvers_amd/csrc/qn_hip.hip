@@ -789,7 +789,7 @@ struct qn_solver {
     bool h_diag_stale = false;  // ... and (second-generation kernels) only the upper triangle of 16 x 16 sub-blocks inside the diagonal tiles
     // second-generation symmetric path (qn_sym2.hip.h): static work lists, per-workgroup scalars, double-buffered control block
     int* s2_items = nullptr;
-    int s2_G = 0, s2_nb = 0, s2_maxk = 0;
+    int s2_G = 0, s2_nb = 0, s2_maxk = 0, s2_inorder = 0;
     double* s2_wgS = nullptr; // [2][s2_trows][QN_S2_ROW]: the sums a servicing launch leaves for the next launch's prologue, by launch parity
     int s2_trows = 0;
     QnCtl* s2_ctl = nullptr;
@@ -908,15 +908,20 @@ static int solver_alloc_sym2(qn_solver* s) {
             heap.back() = e;
             std::push_heap(heap.begin(), heap.end());
         };
-        // the first G items go to workgroups 0 .. G-1 in order (the kernels compute a workgroup's first item from its index:
-        // qn_s2_first_item); the rest to whoever has streamed least so far
+        // the first min(2 G, items) items go out in order -- item t to workgroup t mod G -- so the kernels compute a workgroup's
+        // first two items from its index (qn_s2_item_of_index); the rest to whoever has streamed least so far
+        const int inorder = std::min(nitems, 2 * G);
+        std::vector<double> load0(G, 0.0);
         int handed = 0;
         auto hand = [&](int I, int J, double cost) {
-            if (handed < G) {
-                lists[handed].push_back((I << 16) | J);
-                for (auto& e : heap) if (-e.second == handed) e.first = -cost;
+            if (handed < inorder) {
+                lists[handed % G].push_back((I << 16) | J);
+                load0[handed % G] += cost;
                 ++handed;
-                if (handed == G) std::make_heap(heap.begin(), heap.end());
+                if (handed == inorder) {
+                    for (auto& e : heap) e.first = -load0[-e.second];
+                    std::make_heap(heap.begin(), heap.end());
+                }
             } else {
                 give(I, J, cost);
             }
@@ -932,6 +937,7 @@ static int solver_alloc_sym2(qn_solver* s) {
         HIPCHK(hipMalloc((void**)&s->s2_items, items.size() * sizeof(int)));
         HIPCHK(hipMemcpy(s->s2_items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
         s->s2_maxk = (int)maxk;
+        s->s2_inorder = inorder;
         s->s2_trows = std::max(QN_S2_MAXG, (nb + 63) / 64 * 64);
         QNCHK(dev_alloc_zero(&s->s2_wgS, (size_t)2 * s->s2_trows * QN_S2_ROW, st));
         s->s2_G = G;
@@ -2118,7 +2124,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         QNCHK(solver_alloc_sym2(s));
         QnS2Args& a = r.s2;
         a.Q = r.obj->Q; a.H = s->H; a.n = (int)s->n; a.np = s->T.n_pad; a.nb = s->s2_nb; a.G = s->s2_G;
-        a.item_ij = s->s2_items; a.maxk = s->s2_maxk; a.F = s->V.F; a.part = s->sym_part;
+        a.item_ij = s->s2_items; a.maxk = s->s2_maxk; a.inorder = s->s2_inorder; a.F = s->V.F; a.part = s->sym_part;
         a.wgS = s->s2_wgS; a.trows = s->s2_trows; a.ctl2 = s->s2_ctl;
         a.trace = s->V.trace; a.xtrace = s->V.xtrace;
         a.nt = s->T.n_pad >= 8192; // H past the Infinity Cache: every byte is touched once per pass

@@ -56,12 +56,15 @@ struct QnS2Args {
     const int* item_ij;  // [maxk][G]: k-th item of workgroup g = (I << 16) | J, J >= I (J == I: diagonal tile, upper triangle only);
                          // -1 = the list has ended.  Transposed so that a workgroup's first item is ONE coalesced load away.
     int maxk;            // longest list
+    int inorder;         // the first `inorder` items were dealt in order: item t is the (t / G)-th of workgroup t mod G
     QnFused F;           // X0, S0, G, GT, Y, UN, VV, b (UP is not used here: no kernel writes u while another reads it)
     double* part;        // [nb][nb][2][128] row / column slots
-    double* wgS;         // [2][trows][QN_S2_ROW] what a servicing launch hands the state machine, one row of sums per workgroup:
+    double* wgS;         // [2][QN_S2_ROW][trows] (column-major) what a servicing launch hands the state machine, one row of sums per workgroup:
                          // evaluation tiles (G rows, QN_S2_NSE sums), accept-reduce (nb rows, QN_S2_NR), update-reduce (nb rows: y'u, u'g+).
                          // Launch i writes half i & 1 and launch i + 1 -- whose prologue consumes the request -- reads it: the address
                          // follows from the launch parity alone, so the rows are requested together with the control block.
+                         // Column-major: every CU reads the whole table at kernel entry, all at once; as 64-byte rows that was
+                         // 768 line requests per CU on the same 16 KB (a chip-wide hot spot: 2 us), as columns it is 96.
     int trows;           // rows per half: max(256, nb rounded up to 64)
     QnCtl* ctl2;         // [2]
     QnTraceRec* trace;
@@ -88,42 +91,57 @@ struct QnS2Lds {
 // ---- the state machine's view of a finished request: consume its sums, then run until the next request ----
 // (measured and dropped: the machine as ONE out-of-line function shared by the five kernels -- the calling convention costs the
 // tile kernels ~600 bytes of scratch per lane around the call: 10.9 k instead of 11.8 k it/s)
+// (Measured again and dropped, round 3: the machine as ONE out-of-line function, now called from wave 0's prologue where no tile
+// window is live -- one copy of its code for the five kernels instead of five.  The call frame lives in scratch memory (400 bytes
+// per lane) and the machine then takes 8.4 us instead of 4-5: 11.0 k it/s against 12.3 k inlined, same box.)
 __device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const QnVecs& V, const bool leader, double* scratch, const bool resume) {
     const int ph = c.phase;
-    if (resume) { ctl_scalar_run(c, V, scratch, leader); return; } // (the machine had stopped for the x-trace copy)
-    if (ph == QN_PH_DONE) return;
-    if (ph == QN_PH_IDLE) {
-        c.serviced = 0;
-        c.state = c.ls_only ? QN_ST_LS_ONLY : QN_ST_BEGIN;
-        c.phase = QN_PH_RUNNING;
-        ctl_scalar_run(c, V, scratch, leader);
-        return;
+    bool run = resume; // (resume: the machine had stopped for the x-trace copy)
+    if (!resume) {
+        if (ph == QN_PH_DONE) return;
+        if (ph == QN_PH_IDLE) {
+            c.serviced = 0;
+            c.state = c.ls_only ? QN_ST_LS_ONLY : QN_ST_BEGIN;
+            c.phase = QN_PH_RUNNING;
+            run = true;
+        } else {
+            if (c.serviced != 2) return; // the request is still pending, or its tiles wait for their reduce launch
+            c.serviced = 0;
+            if (ph == QN_PH_REQ_EVAL) {
+                const double f = 0.5 * tot[0] - tot[1]; // f = 1/2 xt'(Q xt) - b'xt
+                const double gd = tot[2] - tot[3];      // g(xt)'d = d'(Q xt) - b'd
+                c.st_gd0 = tot[4]; c.st_dnf = tot[5];
+                if (c.req_kind == QN_REQ_T && !c.gd0_valid) { c.gd0 = tot[4]; c.d_finite = tot[5] == 0.0; c.gd0_valid = 1; }
+                c.f_e = f; c.gd_e = gd;
+                c.n_oracle_evals++;
+                c.ev_par ^= 1; c.ev_kind = c.req_kind; c.ev_t = c.req_t;
+                if (c.req_kind == QN_REQ_T) { c.last_valid = 1; c.last_t = c.req_t; c.f_last = f; c.gd_last = gd; }
+                else c.last_valid = 0;
+                if (c.req_need_vectors) { c.phase = QN_PH_REQ_VEC; return; } // the caller wants g+, y, s of this point too
+                c.state = c.after_state;
+            } else if (ph == QN_PH_REQ_VEC) {
+                c.st_yy = tot[0]; c.st_ys = tot[1]; c.st_gg = tot[2]; c.st_ss = tot[3]; c.hp_sg = tot[4];
+                c.state = c.after_state;
+            } else if (ph == QN_PH_REQ_HPASS) {
+                if (c.hp_nrhs == 2) { c.hp_yu = tot[0]; c.hp_ug = tot[1]; }
+                c.state = c.after_state;
+            } else {
+                return;
+            }
+            c.phase = QN_PH_RUNNING;
+            run = true;
+        }
     }
-    if (c.serviced != 2) return; // the request is still pending, or its tiles wait for their reduce launch
-    c.serviced = 0;
-    if (ph == QN_PH_REQ_EVAL) {
-        const double f = 0.5 * tot[0] - tot[1]; // f = 1/2 xt'(Q xt) - b'xt
-        const double gd = tot[2] - tot[3];      // g(xt)'d = d'(Q xt) - b'd
-        c.st_gd0 = tot[4]; c.st_dnf = tot[5];
-        if (c.req_kind == QN_REQ_T && !c.gd0_valid) { c.gd0 = tot[4]; c.d_finite = tot[5] == 0.0; c.gd0_valid = 1; }
-        c.f_e = f; c.gd_e = gd;
-        c.n_oracle_evals++;
-        c.ev_par ^= 1; c.ev_kind = c.req_kind; c.ev_t = c.req_t;
-        if (c.req_kind == QN_REQ_T) { c.last_valid = 1; c.last_t = c.req_t; c.f_last = f; c.gd_last = gd; }
-        else c.last_valid = 0;
-        if (c.req_need_vectors) { c.phase = QN_PH_REQ_VEC; return; } // the caller wants g+, y, s of this point too
-        c.state = c.after_state;
-    } else if (ph == QN_PH_REQ_VEC) {
-        c.st_yy = tot[0]; c.st_ys = tot[1]; c.st_gg = tot[2]; c.st_ss = tot[3]; c.hp_sg = tot[4];
-        c.state = c.after_state;
-    } else if (ph == QN_PH_REQ_HPASS) {
-        if (c.hp_nrhs == 2) { c.hp_yu = tot[0]; c.hp_ug = tot[1]; }
-        c.state = c.after_state;
-    } else {
-        return;
-    }
-    c.phase = QN_PH_RUNNING;
-    ctl_scalar_run(c, V, scratch, leader);
+    if (run) ctl_scalar_run(c, V, scratch, leader); // (ONE call site: the machine is inlined, and it is large)
+}
+
+// a wave-uniform double out of lane `l` (uniform) of a per-lane value: the row-side inputs of a tile (x_i, d_i, s_i, u_i, y_i,
+// g_i for the wave's 16 rows) live one row per lane and are broadcast into SGPRs as the row loop needs them -- no LDS staging,
+// no barrier, and no vector registers held across the loop for them
+__device__ __forceinline__ double qn_lane_bcast(const double v, const int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
 
 // Prologue of every sym2 kernel: run by WAVE 0 ALONE, before that wave requests any tile data.
@@ -143,6 +161,8 @@ __device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const
 //   runs, yet ~150 live words plus the machine's temporaries still do not fit 256 registers: 255 spills in the tile kernels.)
 //   The sums keep round 2's order (the lane's rows in row order, then the xor butterfly): same bits.
 #define QN_S2_PCH (QN_S2_MAXG / 64) // row chunks of 64 the wave loads from the table
+// (Measured and dropped, same-box A/B: waves 1..7 sleeping 1-2 us before their 112 KB burst so that wave 0's control block and
+// table come back from an idle memory system -- 12.2 k it/s without, 11.3-11.9 k with: the burst itself is on the critical path.)
 
 template <int KIND>
 __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L) {
@@ -150,18 +170,19 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L)
     const bool leader = blockIdx.x == 0;
     constexpr int NW = (int)(sizeof(QnCtl) / 8);
     static_assert(NW <= 128, "control block too large for two words per lane");
+    __builtin_amdgcn_s_setprio(3); // the workgroup waits for this wave: its instructions go first on the SIMD it shares
     const uint64_t* cin = reinterpret_cast<const uint64_t*>(a.ctl2 + a.parity);
     uint64_t* lc = reinterpret_cast<uint64_t*>(&L.c);
     uint64_t cw0 = 0, cw1 = 0;
     if (lane < NW) cw0 = cin[lane];
     if (64 + lane < NW) cw1 = cin[64 + lane];
-    v2d tr[QN_S2_PCH][QN_S2_NSE / 2];
+    double tr[QN_S2_PCH][QN_S2_NSE];
     const double* T = a.wgS + (size_t)(a.parity ^ 1) * (size_t)a.trows * QN_S2_ROW;
     if (KIND != QN_S2_HREDUCE) {
 #pragma unroll
-        for (int j = 0; j < QN_S2_PCH; ++j)
+        for (int k = 0; k < QN_S2_NSE; ++k)
 #pragma unroll
-            for (int h = 0; h < QN_S2_NSE / 2; ++h) tr[j][h] = ld2(T + (size_t)(j * 64 + lane) * QN_S2_ROW + 2 * h); // (trows >= 256)
+            for (int j = 0; j < QN_S2_PCH; ++j) tr[j][k] = T[(size_t)k * a.trows + j * 64 + lane]; // (trows >= 256)
     }
     if (lane < NW) lc[lane] = cw0;
     if (64 + lane < NW) lc[64 + lane] = cw1;
@@ -172,11 +193,13 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L)
     if (KIND == QN_S2_HREDUCE) { // no decision between the update tiles and their reduction: pass the control block on
         mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 1;
         if (lane == 0) { if (mine) c.serviced = 2; L.mine = mine; }
+        __builtin_amdgcn_s_setprio(0);
         return;
     }
     const int ph = c.phase;
     if (ph == QN_PH_DONE) { // launches enqueued past the end of the run: pass the control block on, nothing else
         if (lane == 0) L.mine = 0;
+        __builtin_amdgcn_s_setprio(0);
         return;
     }
     double tot[QN_S2_NSE];
@@ -185,15 +208,23 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L)
     if (c.serviced == 2 && (ph == QN_PH_REQ_EVAL || ph == QN_PH_REQ_VEC || ph == QN_PH_REQ_HPASS)) { // (uniform)
         const int nrows = ph == QN_PH_REQ_EVAL ? a.G : a.nb;
         const int ncol = ph == QN_PH_REQ_EVAL ? QN_S2_NSE : (ph == QN_PH_REQ_VEC ? QN_S2_NR : 2);
+        // The lane's rows in row order, then ONE halving butterfly over all columns at once (QnWaveFold: 17 exchanges instead of
+        // six 6-step butterflies).  It pairs lanes l and l ^ 32, then ^ 16, ... ^ 1 for every column exactly as qn_wave_sum
+        // does, and floating-point addition commutes: the totals have round 2's bits.
+        double acc[8];
 #pragma unroll
-        for (int k = 0; k < QN_S2_NSE; ++k) {
-            double acc = 0.0;
+        for (int k = 0; k < 8; ++k) {
+            acc[k] = 0.0;
+            if (k < QN_S2_NSE) {
 #pragma unroll
-            for (int j = 0; j < QN_S2_PCH; ++j) acc = acc + ((j * 64 + lane < nrows && k < ncol) ? ((k & 1) ? tr[j][k / 2].y : tr[j][k / 2].x) : 0.0);
-            for (int b = QN_S2_MAXG + lane; b < nrows; b += 64) // (block-rows past 256: n > 32768)
-                if (k < ncol) acc = acc + T[(size_t)b * QN_S2_ROW + k];
-            tot[k] = qn_wave_sum(acc);
+                for (int j = 0; j < QN_S2_PCH; ++j) acc[k] = acc[k] + ((j * 64 + lane < nrows && k < ncol) ? tr[j][k] : 0.0);
+                for (int b = QN_S2_MAXG + lane; b < nrows; b += 64) // (block-rows past 256: n > 32768)
+                    if (k < ncol) acc[k] = acc[k] + T[(size_t)k * a.trows + b];
+            }
         }
+        QnWaveFold<8, 32>::run(acc, lane); // lane l holds the total of column l >> 3
+#pragma unroll
+        for (int k = 0; k < QN_S2_NSE; ++k) tot[k] = qn_lane_bcast(acc[0], 8 * k);
     }
     QN_S2_STAMP(10);
     QnVecs V{};
@@ -224,6 +255,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L)
         if (mine) c.serviced = (KIND == QN_S2_HTILE) ? 1 : 2; // as this launch leaves the request
         L.mine = mine;
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // after the workgroup barrier that follows the prologue: workgroup 0 hands the control block to the next launch
@@ -252,28 +284,27 @@ __device__ __forceinline__ double qn_s2_wave_total(const double (*red)[8], int k
     return t;
 }
 
-// a wave-uniform double out of lane `l` (uniform) of a per-lane value: the row-side inputs of a tile (x_i, d_i, s_i, u_i, y_i,
-// g_i for the wave's 16 rows) live one row per lane and are broadcast into SGPRs as the row loop needs them -- no LDS staging,
-// no barrier, and no vector registers held across the loop for them
-__device__ __forceinline__ double qn_lane_bcast(const double v, const int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
-// The first item of workgroup g needs no load: the host hands the first G items out in order -- the off-diagonal tiles row-major
-// over (I, J > I), then the diagonal ones -- so it follows from g alone.
-__device__ __forceinline__ int qn_s2_first_item(int g, int nb) {
+// The first items of a workgroup need no load: the host deals the first min(2 G, items) items out in order -- item t goes to
+// workgroup t mod G as its (t / G)-th; the off-diagonal tiles row-major over (I, J > I), then the diagonal ones -- so they follow
+// from the workgroup's index alone (a dependent load at kernel entry is a memory round trip in front of everything).
+__device__ __forceinline__ int qn_s2_item_of_index(int t, int nb) {
     const int noff = nb * (nb - 1) / 2;
-    if (g >= noff) return ((g - noff) << 16) | (g - noff);
+    if (t >= noff) return ((t - noff) << 16) | (t - noff);
     // row I starts at t(I) = I (nb - 1) - I (I - 1) / 2
     const double bq = 2.0 * nb - 1.0;
-    int i = (int)((bq - sqrt(bq * bq - 8.0 * (double)g)) * 0.5);
+    int i = (int)((bq - sqrt(bq * bq - 8.0 * (double)t)) * 0.5);
     if (i < 0) i = 0;
     if (i > nb - 2) i = nb - 2;
-    while (i > 0 && i * (nb - 1) - i * (i - 1) / 2 > g) --i;
-    while ((i + 1) * (nb - 1) - (i + 1) * i / 2 <= g) ++i;
-    return (i << 16) | (i + 1 + (g - (i * (nb - 1) - i * (i - 1) / 2)));
+    while (i > 0 && i * (nb - 1) - i * (i - 1) / 2 > t) --i;
+    while ((i + 1) * (nb - 1) - (i + 1) * i / 2 <= t) ++i;
+    return (i << 16) | (i + 1 + (t - (i * (nb - 1) - i * (i - 1) / 2)));
+}
+__device__ __forceinline__ int qn_s2_first_item(int g, int nb) { return qn_s2_item_of_index(g, nb); }
+// the workgroup's second item (-1: none): in closed form when the host dealt it in order (a.inorder), from the list otherwise
+__device__ __forceinline__ int qn_s2_second_item(const QnS2Args& a) {
+    const int t = a.G + (int)blockIdx.x;
+    if (t < a.inorder) return qn_s2_item_of_index(t, a.nb);
+    return (a.maxk > 1) ? a.item_ij[(size_t)a.G + blockIdx.x] : -1;
 }
 
 // Diagonal items without a single per-element test.  Wave w owns rows 16 w .. 16 w + 15 of the tile; lane l owns columns 2 l, 2 l + 1.
@@ -326,12 +357,14 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     __shared__ double colsum[QN_TB];
     __shared__ double colred[QN_S2_WAVES][QN_TB];
     __shared__ double sred[QN_S2_WAVES][8];
+    __shared__ v2d park[QN_S2_WAVES - 1][QN_S2_RPW][64]; // 112 KB: the first item's rows of waves 1..7 (see below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
     QN_S2_STAMP(0);
     // Wave 0 runs the prologue first (qn_s2_prologue_w0); waves 1..7 request the window at once.  The first item is a function of
     // blockIdx: no load.
     int ij = qn_s2_first_item(blockIdx.x, a.nb);
+    const int ij1 = qn_s2_second_item(a); // the second item: what the parked window is refilled from
     if (wave == 0) qn_s2_prologue_w0<QN_S2_EVAL>(a, L);
     int I = ij >> 16, J = ij & 0xffff;
     // The wave's 16 rows of the first item are requested before the control block is known (their addresses do not depend on
@@ -348,6 +381,22 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         qn_s2_eval_vec_load(a, a.F.X0, a.F.S0, ir, jc, v0);
         v1.x_r = a.F.X0[np + ir]; v1.s_r = a.F.S0[np + ir];
         v1.x_c = ld2(a.F.X0 + np + jc); v1.s_c = ld2(a.F.S0 + np + jc);
+    }
+    // PARKING.  The prologue of wave 0 -- one memory round trip, the sums of 256 rows, the state machine on one lane -- takes
+    // 6-8 us, and the 128 KB register window lands in 5.  Round 2 let the memory system idle until the decision was there.
+    // Now waves 1..7 move each row of the first item into LDS the moment it arrives and request the same row of the SECOND item
+    // into the register it frees: 240 KB per CU stream back to back from kernel entry whatever the machine takes, the first
+    // item is then consumed from LDS and the second from registers.  (Wave 0 requests its rows after the prologue and consumes
+    // them as they come; a workgroup with one item parks nothing.)
+    const bool parked = wave != 0 && ij1 >= 0; // (wave-uniform)
+    if (parked) {
+        const int I1 = ij1 >> 16, J1 = ij1 & 0xffff;
+        const double* q1 = a.Q + (size_t)(I1 * QN_TB + wave * QN_S2_RPW) * np + (size_t)J1 * QN_TB + qn_s2_col(I1 == J1, lane, wave);
+#pragma unroll
+        for (int r = 0; r < QN_S2_RPW; ++r) {
+            park[wave - 1][r][lane] = h[r];
+            h[r] = ld2(q1 + (size_t)r * np);
+        }
     }
     QN_S2_STAMP(1);
     __syncthreads();
@@ -379,7 +428,8 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         }
         // the next item: where the window is refilled from while this one is consumed
         int ijn = -1;
-        if (it + 1 < a.maxk) ijn = a.item_ij[(size_t)(it + 1) * a.G + blockIdx.x];
+        if (it == 0) ijn = ij1;
+        else if (it + 1 < a.maxk) ijn = a.item_ij[(size_t)(it + 1) * a.G + blockIdx.x];
         const bool has_next = ijn >= 0; // (uniform)
         const int In = has_next ? (ijn >> 16) : I, Jn = has_next ? (ijn & 0xffff) : J;
         const double* qn = a.Q + (size_t)(In * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jn * QN_TB + qn_s2_col(In == Jn, lane, wave);
@@ -389,19 +439,30 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         ++stamp_k;
         double cx = 0.0, cy = 0.0, pf = 0.0, pg = 0.0;
         double racc[QN_S2_RPW];
-#pragma unroll
-        for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
-            const v2d hv = h[r];
-            h[r] = ld2(qn + (size_t)r * rstride); // the register this row frees takes the same row of the next item at once
-            const double xi = qn_lane_bcast(xr, r), di = qn_lane_bcast(dr, r);
-            double t0 = hv.x * xtj.x;
-            t0 = __builtin_fma(hv.y, xtj.y, t0);
-            racc[r] = t0;
-            cx = __builtin_fma(hv.x, xi, cx);
-            cy = __builtin_fma(hv.y, xi, cy);
-            pf = __builtin_fma(xi, t0, pf);
+#define QN_S2_EVAL_ROW(HV)                                                     \
+            const double xi = qn_lane_bcast(xr, r), di = qn_lane_bcast(dr, r); \
+            double t0 = (HV).x * xtj.x;                                         \
+            t0 = __builtin_fma((HV).y, xtj.y, t0);                              \
+            racc[r] = t0;                                                      \
+            cx = __builtin_fma((HV).x, xi, cx);                                 \
+            cy = __builtin_fma((HV).y, xi, cy);                                 \
+            pf = __builtin_fma(xi, t0, pf);                                    \
             pg = __builtin_fma(di, t0, pg);
+        if (parked && it == 0) { // the parked item: rows from LDS; the registers already hold the next item
+#pragma unroll
+            for (int r = 0; r < QN_S2_RPW; ++r) {
+                const v2d hv = park[wave - 1][r][lane];
+                QN_S2_EVAL_ROW(hv)
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
+                const v2d hv = h[r];
+                h[r] = ld2(qn + (size_t)r * rstride); // the register this row frees takes the same row of the next item at once
+                QN_S2_EVAL_ROW(hv)
+            }
         }
+#undef QN_S2_EVAL_ROW
         if (!qn_s2_col_on(diag, lane, wave)) { cx = 0.0; cy = 0.0; }
         // the next item's vector entries go out now: they fly while this item's sums are folded, exchanged and stored
         if (has_next) qn_s2_eval_vec_load(a, x, sp, In * QN_TB + wave * QN_S2_RPW + (lane & 15), Jn * QN_TB + 2 * lane, v0);
@@ -454,9 +515,9 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     }
     QN_S2_STAMP(15);
     if (tid == 0) {
-        double* out = a.wgS + ((size_t)a.parity * a.trows + blockIdx.x) * QN_S2_ROW;
+        double* out = a.wgS + (size_t)a.parity * a.trows * QN_S2_ROW + blockIdx.x;
 #pragma unroll
-        for (int k = 0; k < QN_S2_NSE; ++k) out[k] = wg[k];
+        for (int k = 0; k < QN_S2_NSE; ++k) out[(size_t)k * a.trows] = wg[k];
     }
 }
 
@@ -538,7 +599,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
         if ((lane & 7) == 0) bred[wave][lane >> 3] = p[0];
     }
     __syncthreads();
-    if (tid < QN_S2_NR) a.wgS[((size_t)a.parity * a.trows + R) * QN_S2_ROW + tid] = bred[0][tid] + bred[1][tid];
+    if (tid < QN_S2_NR) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = bred[0][tid] + bred[1][tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,9 +629,11 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     __shared__ QnS2Lds L;
     __shared__ double colsum[2][QN_TB]; // [rhs]: row part of a diagonal item, parked until its column part is summed
     __shared__ double colred[QN_S2_WAVES][2][QN_TB];
+    __shared__ v2d park[QN_S2_WAVES - 1][QN_S2_RPW][64]; // the first item's rows of waves 1..7, parked while wave 0 decides (s2_eval_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
     int ij = qn_s2_first_item(blockIdx.x, a.nb);
+    const int ij1 = qn_s2_second_item(a);
     if (wave == 0) qn_s2_prologue_w0<QN_S2_HTILE>(a, L); // (wave 0: the prologue first, then its rows -- see s2_eval_kernel)
     int I = ij >> 16, J = ij & 0xffff;
     v2d h[QN_S2_RPW]; // the wave's 16 rows of the first item go out before the control block is known ...
@@ -589,6 +652,16 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         qn_s2_hvec_load(spec, ir, jc, v0);
         s1_r = a.F.S0[np + ir]; s1_c = ld2(a.F.S0 + np + jc);
         y_r = a.F.Y[ir]; y_c = ld2(a.F.Y + jc);
+    }
+    const bool parked = wave != 0 && ij1 >= 0; // (wave-uniform)
+    if (parked) { // the rows of the first item into LDS as they arrive, the second item's rows into the registers they free
+        const int I1 = ij1 >> 16, J1 = ij1 & 0xffff;
+        const double* h1 = a.H + (size_t)(I1 * QN_TB + wave * QN_S2_RPW) * np + (size_t)J1 * QN_TB + qn_s2_col(I1 == J1, lane, wave);
+#pragma unroll
+        for (int r = 0; r < QN_S2_RPW; ++r) {
+            park[wave - 1][r][lane] = h[r];
+            h[r] = qn_sym_ld<NT>(h1 + (size_t)r * np);
+        }
     }
     __syncthreads();
     qn_s2_ctl_out(a, L);
@@ -620,42 +693,54 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         if (!qn_s2_row_on(diag, lane, wave)) { a0 = (v2d){0.0, 0.0}; a1 = (v2d){0.0, 0.0}; }
         // the next item: where the window is refilled from while this one is consumed
         int ijn = -1;
-        if (it + 1 < a.maxk) ijn = a.item_ij[(size_t)(it + 1) * a.G + blockIdx.x];
+        if (it == 0) ijn = ij1;
+        else if (it + 1 < a.maxk) ijn = a.item_ij[(size_t)(it + 1) * a.G + blockIdx.x];
         const bool has_next = ijn >= 0; // (uniform)
         const int In = has_next ? (ijn >> 16) : I, Jn = has_next ? (ijn & 0xffff) : J;
         double* hnext = a.H + (size_t)(In * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jn * QN_TB + qn_s2_col(In == Jn, lane, wave);
         const size_t rstride = has_next ? np : 0; // (none left: every lane re-reads one 16-byte word of this item)
         double c0x = 0.0, c0y = 0.0, c1x = 0.0, c1y = 0.0;
         double racc[QN_S2_RPW];
-#pragma unroll
-        for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
-            v2d hn = h[r];
-            h[r] = qn_sym_ld<NT>(hnext + (size_t)r * rstride); // the register this row frees takes the same row of the next item at once
-            const double si = qn_lane_bcast(sr, r), ui = qn_lane_bcast(ur, r);
-            if (BFGS) {
-                hn.x = hn.x + c_su * (si * uj.x + ui * sj.x);
-                hn.y = hn.y + c_su * (si * uj.y + ui * sj.y);
-            }
-            hn.x = hn.x + c_ss * (si * sj.x);
-            hn.y = hn.y + c_ss * (si * sj.y);
-            if (!BFGS) {
-                hn.x = hn.x + c_uu * (ui * uj.x);
-                hn.y = hn.y + c_uu * (ui * uj.y);
-            }
-            qn_sym_st<NT>(hbase + (size_t)r * np, hn);
-            const double y0 = qn_lane_bcast(y0r, r), y1 = qn_lane_bcast(y1r, r);
-            double t0 = hn.x * a0.x;
-            t0 = __builtin_fma(hn.y, a0.y, t0);
-            double t1 = hn.x * a1.x;
-            t1 = __builtin_fma(hn.y, a1.y, t1);
-            // first level of the 32-value butterfly (the row's sum for y against its sum for g+, lane against lane ^ 32) at
-            // once: two sums become one register; QnWaveFold<16, 16> finishes the same tree after the last row
-            racc[r] = (up ? t1 : t0) + qn_xor_lanes<32>(up ? t0 : t1);
-            c0x = __builtin_fma(hn.x, y0, c0x);
-            c0y = __builtin_fma(hn.y, y0, c0y);
-            c1x = __builtin_fma(hn.x, y1, c1x);
+#define QN_S2_H_ROW                                                                                                   \
+            const double si = qn_lane_bcast(sr, r), ui = qn_lane_bcast(ur, r);                                       \
+            if (BFGS) {                                                                                              \
+                hn.x = hn.x + c_su * (si * uj.x + ui * sj.x);                                                        \
+                hn.y = hn.y + c_su * (si * uj.y + ui * sj.y);                                                        \
+            }                                                                                                        \
+            hn.x = hn.x + c_ss * (si * sj.x);                                                                        \
+            hn.y = hn.y + c_ss * (si * sj.y);                                                                        \
+            if (!BFGS) {                                                                                             \
+                hn.x = hn.x + c_uu * (ui * uj.x);                                                                    \
+                hn.y = hn.y + c_uu * (ui * uj.y);                                                                    \
+            }                                                                                                        \
+            qn_sym_st<NT>(hbase + (size_t)r * np, hn);                                                               \
+            const double y0 = qn_lane_bcast(y0r, r), y1 = qn_lane_bcast(y1r, r);                                     \
+            double t0 = hn.x * a0.x;                                                                                 \
+            t0 = __builtin_fma(hn.y, a0.y, t0);                                                                      \
+            double t1 = hn.x * a1.x;                                                                                 \
+            t1 = __builtin_fma(hn.y, a1.y, t1);                                                                      \
+            /* first level of the 32-value butterfly (the row's sum for y against its sum for g+, lane against lane ^ 32) at \
+               once: two sums become one register; QnWaveFold<16, 16> finishes the same tree after the last row */     \
+            racc[r] = (up ? t1 : t0) + qn_xor_lanes<32>(up ? t0 : t1);                                               \
+            c0x = __builtin_fma(hn.x, y0, c0x);                                                                      \
+            c0y = __builtin_fma(hn.y, y0, c0y);                                                                      \
+            c1x = __builtin_fma(hn.x, y1, c1x);                                                                      \
             c1y = __builtin_fma(hn.y, y1, c1y);
+        if (parked && it == 0) { // the parked item: rows from LDS; the registers already hold the next item
+#pragma unroll
+            for (int r = 0; r < QN_S2_RPW; ++r) {
+                v2d hn = park[wave - 1][r][lane];
+                QN_S2_H_ROW
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
+                v2d hn = h[r];
+                h[r] = qn_sym_ld<NT>(hnext + (size_t)r * rstride); // the register this row frees takes the same row of the next item at once
+                QN_S2_H_ROW
+            }
         }
+#undef QN_S2_H_ROW
         if (!qn_s2_col_on(diag, lane, wave)) { c0x = 0.0; c0y = 0.0; c1x = 0.0; c1y = 0.0; }
         // the next item's vector entries go out now: they fly while this item's sums are folded, exchanged and stored
         if (has_next) qn_s2_hvec_load(q, In * QN_TB + wave * QN_S2_RPW + (lane & 15), Jn * QN_TB + qn_s2_col(In == Jn, lane, wave), v0);
@@ -721,7 +806,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
         if ((lane & 7) == 0) bred[wave][lane >> 3] = p[0];
     }
     __syncthreads();
-    if (tid < 2) a.wgS[((size_t)a.parity * a.trows + R) * QN_S2_ROW + tid] = bred[0][tid] + bred[1][tid];
+    if (tid < 2) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = bred[0][tid] + bred[1][tid];
 }
 
 // synchronous mode: the prologue alone (one workgroup)
