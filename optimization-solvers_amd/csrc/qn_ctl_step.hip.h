@@ -293,7 +293,7 @@ __device__ __forceinline__ void qn_st_mt_after_tu(QnCtl& c) {
 __device__ __forceinline__ void qn_st_mt_finish(QnCtl& c) { // morethuente.rs:290-293: the NEW t with the OLD trial's f_t, g_t
     c.t = fmin(fmax(c.t, c.mt_tmin), c.mt_tmax);
     double tl = c.tl, tu = c.tu;
-    c.conv = mt_update_interval(c.sel_f_tl, c.sel_f_t, c.sel_g_t, &tl, c.t, &tu);
+    c.conv = mt_update_interval(c.sel_f_tl, c.sel_f_t, c.sel_g_t, tl, c.t, tu);
     c.tl = tl; c.tu = tu;
     c.ls_i++;
     c.state = QN_ST_MT_LOOP;

@@ -474,11 +474,20 @@ __device__ __forceinline__ double q_val(const QnVecs& V, int i) {
 }
 
 // ---- scalar pieces of the More-Thuente search (morethuente.rs:64-132), thread 0 only ----
-__device__ __forceinline__ int mt_update_interval(double f_tl, double f_t, double g_t, double* tl, double t, double* tu) {
-    if (f_t > f_tl) { *tu = t; return 0; }                         // U1
-    else if (g_t * (*tl - t) > 0.) { *tl = t; return 0; }          // U2
-    else if (g_t * (*tl - t) < 0.) { *tu = *tl; *tl = t; return 0; } // U3
-    return 1;                                                      // interval converged to a point
+// (By value and by reference, with selects: as `double* tl, double* tu` the compiler merged the stores `*tl = t` / `*tu = t` into
+// ONE store through a selected pointer, which forced both locals into scratch memory -- an indexed scratch store, two scratch
+// loads and an s_waitcnt vmcnt(0) in the middle of the state machine, i.e. a trip to memory behind whatever the kernel streams.)
+__device__ __forceinline__ int mt_update_interval(double f_tl, double f_t, double g_t, double& tl, double t, double& tu) {
+    const double tl0 = tl, tu0 = tu;
+    const double w = g_t * (tl0 - t);
+    double ntl = tl0, ntu = tu0;
+    int conv = 0;
+    if (f_t > f_tl) ntu = t;                 // U1
+    else if (w > 0.) ntl = t;                // U2
+    else if (w < 0.) { ntu = tl0; ntl = t; } // U3
+    else conv = 1;                           // interval converged to a point
+    tl = ntl; tu = ntu;
+    return conv;
 }
 __device__ __forceinline__ double mt_cubic(double ta, double tb, double f_ta, double f_tb, double g_ta, double g_tb) {
     const double s = 3. * (f_tb - f_ta) / (tb - ta);

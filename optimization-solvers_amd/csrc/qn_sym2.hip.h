@@ -352,166 +352,219 @@ __device__ __forceinline__ void qn_s2_eval_vec_load(const QnS2Args& a, const dou
     v.x_c = ld2(x + jc); v.v_c = ld2(a.F.VV + jc); v.s_c = ld2(sp + jc); v.u_c = ld2(a.F.UN + jc);
 }
 
+// One item of the evaluation: the wave's 16 rows against the trial point, folded.  Leaves the column part of the wave's rows
+// in colred_w[128] and the wave's six scalar sums in sred_w[8] (LDS, exchanged by the caller after ONE workgroup barrier for
+// a pair of items) and returns the row total this lane owns (lanes with (lane & 3) == 0: row lane >> 2 of the wave's 16).
+// FROM_PARK: the rows come from the LDS copy parked during the prologue; otherwise from the register window, each register
+// refilled with the same row of the item at `refill` the moment it is consumed (rstride 0: nothing follows, every lane re-reads
+// one 16-byte word -- a single request per instruction).
+template <bool FROM_PARK>
+__device__ __forceinline__ double qn_s2_eval_item(const QnEvalReq& q, const QnS2EvalVec& v, const bool diag, const int lane, const int wave,
+                                                  v2d (&h)[QN_S2_RPW], const v2d* __restrict__ parkw, const double* __restrict__ refill, const size_t rstride,
+                                                  double* __restrict__ colred_w, double* __restrict__ sred_w) {
+    // row side: lane l holds row 16 w + (l & 15) of the tile; column side: this lane's two columns
+    double dr;
+    const double xr = qn_s2_trial(q, v.x_r, v.v_r, v.s_r, v.u_r, dr);
+    double p1 = 0.0, p3 = 0.0, p4 = 0.0, p5 = 0.0; // diagonal items: b'xt, b'd, g'd, #non-finite d over block I (lanes 0..15 of every wave)
+    if (diag && lane < 16) { p1 = v.b_r * xr; p3 = v.b_r * dr; p4 = v.g_r * dr; p5 = isfinite(dr) ? 0.0 : 1.0; }
+    v2d xtj, dj;
+    {
+        double d0, d1;
+        xtj.x = qn_s2_trial(q, v.x_c.x, v.v_c.x, v.s_c.x, v.u_c.x, d0);
+        xtj.y = qn_s2_trial(q, v.x_c.y, v.v_c.y, v.s_c.y, v.u_c.y, d1);
+        dj.x = d0; dj.y = d1;
+    }
+    if (!qn_s2_row_on(diag, lane, wave)) { xtj = (v2d){0.0, 0.0}; dj = (v2d){0.0, 0.0}; }
+    double cx = 0.0, cy = 0.0, pf = 0.0, pg = 0.0;
+    double racc[QN_S2_RPW];
+#pragma unroll
+    for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
+        v2d hv;
+        if (FROM_PARK) hv = parkw[r * 64 + lane];
+        else { hv = h[r]; h[r] = ld2(refill + (size_t)r * rstride); } // the register this row frees takes the same row of the next item at once
+        const double xi = qn_lane_bcast(xr, r), di = qn_lane_bcast(dr, r);
+        double t0 = hv.x * xtj.x;
+        t0 = __builtin_fma(hv.y, xtj.y, t0);
+        racc[r] = t0;
+        cx = __builtin_fma(hv.x, xi, cx);
+        cy = __builtin_fma(hv.y, xi, cy);
+        pf = __builtin_fma(xi, t0, pf);
+        pg = __builtin_fma(di, t0, pg);
+    }
+    if (!qn_s2_col_on(diag, lane, wave)) { cx = 0.0; cy = 0.0; }
+    pf = __builtin_fma(xtj.x, cx, pf); pf = __builtin_fma(xtj.y, cy, pf); // xt_J'(column part): the mirrored half of xt'Q xt
+    pg = __builtin_fma(dj.x, cx, pg); pg = __builtin_fma(dj.y, cy, pg);   // d_J'(column part) = xt_I'Q_IJ d_J
+    colred_w[2 * lane] = cx;
+    colred_w[2 * lane + 1] = cy;
+    {
+        double sv[8] = {pf, pg, p1, p3, p4, p5, 0.0, 0.0};
+        QnWaveFold<8, 32>::run(sv, lane);
+        if ((lane & 7) == 0) sred_w[lane >> 3] = sv[0];
+    }
+    QnWaveFold<QN_S2_RPW, 32>::run(racc, lane); // lanes with (lane & 3) == 0 hold the total of row lane >> 2
+    return racc[0];
+}
+
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
-    __shared__ double colsum[QN_TB];
-    __shared__ double colred[QN_S2_WAVES][QN_TB];
-    __shared__ double sred[QN_S2_WAVES][8];
-    __shared__ v2d park[QN_S2_WAVES - 1][QN_S2_RPW][64]; // 112 KB: the first item's rows of waves 1..7 (see below)
+    __shared__ double colsum[3][QN_TB];
+    __shared__ double colred[3][QN_S2_WAVES][QN_TB]; // [item of the group]
+    __shared__ double sred[3][QN_S2_WAVES][8];
+    __shared__ v2d park[QN_S2_WAVES][QN_S2_RPW][64]; // 128 KB: the first item's rows, parked while wave 0 decides (see below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
     QN_S2_STAMP(0);
-    // Wave 0 runs the prologue first (qn_s2_prologue_w0); waves 1..7 request the window at once.  The first item is a function of
-    // blockIdx: no load.
-    int ij = qn_s2_first_item(blockIdx.x, a.nb);
+    // Wave 0 runs the prologue first (qn_s2_prologue_w0); waves 1..7 request the window at once.  The first two items are
+    // functions of blockIdx: no load.
+    const int ij0 = qn_s2_first_item(blockIdx.x, a.nb);
     const int ij1 = qn_s2_second_item(a); // the second item: what the parked window is refilled from
     if (wave == 0) qn_s2_prologue_w0<QN_S2_EVAL>(a, L);
-    int I = ij >> 16, J = ij & 0xffff;
     // The wave's 16 rows of the first item are requested before the control block is known (their addresses do not depend on
     // it), and so are the first item's vector entries for BOTH settings of the two buffer toggles the control block holds
     // (x / trial point, pending / staged s); every register of the window is refilled with the next item's row the moment its
     // row is consumed: 128 KB in flight per workgroup across item boundaries, reductions and barriers.
     v2d h[QN_S2_RPW];
-    const double* qb = a.Q + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
-#pragma unroll
-    for (int r = 0; r < QN_S2_RPW; ++r) h[r] = ld2(qb + (size_t)r * np);
-    QnS2EvalVec v0, v1; // v0: x = X0[0], s = S0[0]; v1 holds the other halves' x and s entries
+    const bool parked = ij1 >= 0; // (uniform) a workgroup with one item parks nothing
     {
+        // wave 0 comes here after the prologue: when the first item is parked its rows are in LDS already (below), and its window
+        // takes the second item's rows at once
+        const int ijw = (wave == 0 && parked) ? ij1 : ij0;
+        const int I = ijw >> 16, J = ijw & 0xffff;
+        const double* qb = a.Q + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
+#pragma unroll
+        for (int r = 0; r < QN_S2_RPW; ++r) h[r] = ld2(qb + (size_t)r * np);
+    }
+    QnS2EvalVec va, v1; // va: x = X0[0], s = S0[0]; v1 holds the other halves' x and s entries
+    {
+        const int I = ij0 >> 16, J = ij0 & 0xffff;
         const int ir = I * QN_TB + wave * QN_S2_RPW + (lane & 15), jc = J * QN_TB + 2 * lane;
-        qn_s2_eval_vec_load(a, a.F.X0, a.F.S0, ir, jc, v0);
+        qn_s2_eval_vec_load(a, a.F.X0, a.F.S0, ir, jc, va);
         v1.x_r = a.F.X0[np + ir]; v1.s_r = a.F.S0[np + ir];
         v1.x_c = ld2(a.F.X0 + np + jc); v1.s_c = ld2(a.F.S0 + np + jc);
     }
     // PARKING.  The prologue of wave 0 -- one memory round trip, the sums of 256 rows, the state machine on one lane -- takes
-    // 6-8 us, and the 128 KB register window lands in 5.  Round 2 let the memory system idle until the decision was there.
+    // 6-9 us, and the 128 KB register window lands in 5.  Round 2 let the memory system idle until the decision was there.
     // Now waves 1..7 move each row of the first item into LDS the moment it arrives and request the same row of the SECOND item
-    // into the register it frees: 240 KB per CU stream back to back from kernel entry whatever the machine takes, the first
-    // item is then consumed from LDS and the second from registers.  (Wave 0 requests its rows after the prologue and consumes
-    // them as they come; a workgroup with one item parks nothing.)
-    const bool parked = wave != 0 && ij1 >= 0; // (wave-uniform)
-    if (parked) {
+    // into the register it frees: 256 KB per CU stream back to back from kernel entry whatever the machine takes, the first
+    // item is then consumed from LDS and the second from registers.  Wave 0's sixteen rows of the first item are fetched and
+    // parked by the other waves too (three rows each, behind their own): a wave that asked for its rows only after the
+    // prologue was 3 us behind the rest at the pair's barrier (in-kernel time stamps).
+    if (parked && wave != 0) {
         const int I1 = ij1 >> 16, J1 = ij1 & 0xffff;
         const double* q1 = a.Q + (size_t)(I1 * QN_TB + wave * QN_S2_RPW) * np + (size_t)J1 * QN_TB + qn_s2_col(I1 == J1, lane, wave);
 #pragma unroll
         for (int r = 0; r < QN_S2_RPW; ++r) {
-            park[wave - 1][r][lane] = h[r];
+            park[wave][r][lane] = h[r];
             h[r] = ld2(q1 + (size_t)r * np);
         }
+        const int I0 = ij0 >> 16, J0 = ij0 & 0xffff;
+        const double* q0 = a.Q + (size_t)(I0 * QN_TB) * np + (size_t)J0 * QN_TB + 2 * lane; // wave 0's rows: no clone lanes (qn_s2_col(., ., 0) = 2 lane)
+        const int r0 = (wave - 1) * 3;
+        v2d t3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t3[k] = ld2(q0 + (size_t)min(r0 + k, QN_S2_RPW - 1) * np);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (r0 + k < QN_S2_RPW) park[0][r0 + k][lane] = t3[k];
     }
     QN_S2_STAMP(1);
     __syncthreads();
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
     QN_S2_STAMP(2);
-    int stamp_k = 3;
     const QnEvalReq q = qn_s2_eval_req(L.c, false);
     const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
     const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
-    if (q.xc) { v0.x_r = v1.x_r; v0.x_c = v1.x_c; }
-    if (q.sc) { v0.s_r = v1.s_r; v0.s_c = v1.s_c; }
+    if (q.xc) { va.x_r = v1.x_r; va.x_c = v1.x_c; }
+    if (q.sc) { va.s_r = v1.s_r; va.s_c = v1.s_c; }
     double wg[QN_S2_NSE]; // thread 0: this workgroup's running totals (items in list order)
 #pragma unroll
     for (int k = 0; k < QN_S2_NSE; ++k) wg[k] = 0.0;
-    for (int it = 0;; ++it) {
-        const bool diag = I == J; // (uniform)
-        // row side: lane l holds row 16 w + (l & 15) of the tile; column side: this lane's two columns
-        double dr;
-        const double xr = qn_s2_trial(q, v0.x_r, v0.v_r, v0.s_r, v0.u_r, dr);
-        double p1 = 0.0, p3 = 0.0, p4 = 0.0, p5 = 0.0; // diagonal items: b'xt, b'd, g'd, #non-finite d over block I (lanes 0..15 of every wave)
-        if (diag && lane < 16) { p1 = v0.b_r * xr; p3 = v0.b_r * dr; p4 = v0.g_r * dr; p5 = isfinite(dr) ? 0.0 : 1.0; }
-        v2d xtj, dj;
-        {
-            double d0, d1;
-            xtj.x = qn_s2_trial(q, v0.x_c.x, v0.v_c.x, v0.s_c.x, v0.u_c.x, d0);
-            xtj.y = qn_s2_trial(q, v0.x_c.y, v0.v_c.y, v0.s_c.y, v0.u_c.y, d1);
-            dj.x = d0; dj.y = d1;
+    // Items are taken in GROUPS of two -- three when an odd item is left at the end of the list: the rows of all of them are
+    // consumed and folded back to back, then ONE exchange through LDS, one barrier and one set of slot stores serves the group
+    // (round 2 did all of that per item: 2-3 us of fold / barrier / store latency each, with every byte already on chip).  The
+    // group of three matters at n = 4096: 528 items on 256 CUs leave sixteen workgroups with a third (diagonal) item, and as a
+    // round of its own it kept the whole launch waiting 5 us for those sixteen (in-kernel time stamps of the workgroups' ends).
+    int ija = ij0, ijb = ij1;
+    QnS2EvalVec vb;
+    for (int it = 0;; it += 2) {
+        const int Ia = ija >> 16, Ja = ija & 0xffff, Ib = ijb >> 16, Jb = ijb & 0xffff;
+        const bool has_b = ijb >= 0; // (uniform)
+        const bool diag_a = Ia == Ja, diag_b = has_b && Ib == Jb;
+        // the items after this pair: where the window is refilled from while item b is consumed
+        int ijc = -1, ijd = -1;
+        if (has_b && it + 2 < a.maxk) ijc = a.item_ij[(size_t)(it + 2) * a.G + blockIdx.x];
+        if (ijc >= 0 && it + 3 < a.maxk) ijd = a.item_ij[(size_t)(it + 3) * a.G + blockIdx.x];
+        const bool take_c = ijc >= 0 && ijd < 0; // the last, odd item joins this group
+        const double* qb_ = has_b ? a.Q + (size_t)(Ib * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jb * QN_TB + qn_s2_col(diag_b, lane, wave)
+                                  : a.Q + (size_t)(Ia * QN_TB + wave * QN_S2_RPW) * np + (size_t)Ja * QN_TB + qn_s2_col(diag_a, lane, wave);
+        const int Ic = ijc >> 16, Jc = ijc & 0xffff;
+        const bool diag_c = take_c && Ic == Jc;
+        const double* qc_ = ijc >= 0 ? a.Q + (size_t)(Ic * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jc * QN_TB + qn_s2_col(Ic == Jc, lane, wave) : qb_;
+        const int Id = ijd >> 16, Jd = ijd & 0xffff;
+        const double* qd_ = ijd >= 0 ? a.Q + (size_t)(Id * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jd * QN_TB + qn_s2_col(Id == Jd, lane, wave) : qc_;
+        double row_a, row_b = 0.0, row_c = 0.0;
+        if (parked && it == 0) row_a = qn_s2_eval_item<true>(q, va, diag_a, lane, wave, h, &park[wave][0][0], nullptr, 0, colred[0][wave], sred[0][wave]);
+        else row_a = qn_s2_eval_item<false>(q, va, diag_a, lane, wave, h, nullptr, qb_, has_b ? np : 0, colred[0][wave], sred[0][wave]);
+        if (has_b) {
+            qn_s2_eval_vec_load(a, x, sp, Ib * QN_TB + wave * QN_S2_RPW + (lane & 15), Jb * QN_TB + 2 * lane, vb);
+            row_b = qn_s2_eval_item<false>(q, vb, diag_b, lane, wave, h, nullptr, qc_, ijc >= 0 ? np : 0, colred[1][wave], sred[1][wave]);
         }
-        // the next item: where the window is refilled from while this one is consumed
-        int ijn = -1;
-        if (it == 0) ijn = ij1;
-        else if (it + 1 < a.maxk) ijn = a.item_ij[(size_t)(it + 1) * a.G + blockIdx.x];
-        const bool has_next = ijn >= 0; // (uniform)
-        const int In = has_next ? (ijn >> 16) : I, Jn = has_next ? (ijn & 0xffff) : J;
-        const double* qn = a.Q + (size_t)(In * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jn * QN_TB + qn_s2_col(In == Jn, lane, wave);
-        const size_t rstride = has_next ? np : 0; // (no next item: every lane re-reads one 16-byte word of this one, a single request per instruction)
-        if (!qn_s2_row_on(diag, lane, wave)) { xtj = (v2d){0.0, 0.0}; dj = (v2d){0.0, 0.0}; }
-        if (stamp_k < 13) QN_S2_STAMP(stamp_k); // vectors ready
-        ++stamp_k;
-        double cx = 0.0, cy = 0.0, pf = 0.0, pg = 0.0;
-        double racc[QN_S2_RPW];
-#define QN_S2_EVAL_ROW(HV)                                                     \
-            const double xi = qn_lane_bcast(xr, r), di = qn_lane_bcast(dr, r); \
-            double t0 = (HV).x * xtj.x;                                         \
-            t0 = __builtin_fma((HV).y, xtj.y, t0);                              \
-            racc[r] = t0;                                                      \
-            cx = __builtin_fma((HV).x, xi, cx);                                 \
-            cy = __builtin_fma((HV).y, xi, cy);                                 \
-            pf = __builtin_fma(xi, t0, pf);                                    \
-            pg = __builtin_fma(di, t0, pg);
-        if (parked && it == 0) { // the parked item: rows from LDS; the registers already hold the next item
-#pragma unroll
-            for (int r = 0; r < QN_S2_RPW; ++r) {
-                const v2d hv = park[wave - 1][r][lane];
-                QN_S2_EVAL_ROW(hv)
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
-                const v2d hv = h[r];
-                h[r] = ld2(qn + (size_t)r * rstride); // the register this row frees takes the same row of the next item at once
-                QN_S2_EVAL_ROW(hv)
-            }
-        }
-#undef QN_S2_EVAL_ROW
-        if (!qn_s2_col_on(diag, lane, wave)) { cx = 0.0; cy = 0.0; }
-        // the next item's vector entries go out now: they fly while this item's sums are folded, exchanged and stored
-        if (has_next) qn_s2_eval_vec_load(a, x, sp, In * QN_TB + wave * QN_S2_RPW + (lane & 15), Jn * QN_TB + 2 * lane, v0);
-        qn_keepalive(cx); qn_keepalive(pf);
-        if (stamp_k < 13) QN_S2_STAMP(stamp_k); // row loop done
-        ++stamp_k;
-        pf = __builtin_fma(xtj.x, cx, pf); pf = __builtin_fma(xtj.y, cy, pf); // xt_J'(column part): the mirrored half of xt'Q xt
-        pg = __builtin_fma(dj.x, cx, pg); pg = __builtin_fma(dj.y, cy, pg);   // d_J'(column part) = xt_I'Q_IJ d_J
-        colred[wave][2 * lane] = cx;
-        colred[wave][2 * lane + 1] = cy;
-        {
-            double sv[8] = {pf, pg, p1, p3, p4, p5, 0.0, 0.0};
-            QnWaveFold<8, 32>::run(sv, lane);
-            if ((lane & 7) == 0) sred[wave][lane >> 3] = sv[0];
-        }
-        QnWaveFold<QN_S2_RPW, 32>::run(racc, lane); // lanes with (lane & 3) == 0 hold the total of row lane >> 2
-        if (it == 0) { qn_keepalive(racc[0]); QN_S2_STAMP(12); }
+        // the next item's vector entries go out now: for the item that joins this group, or for the next group while this
+        // one's sums are exchanged and stored
+        if (ijc >= 0) qn_s2_eval_vec_load(a, x, sp, Ic * QN_TB + wave * QN_S2_RPW + (lane & 15), Jc * QN_TB + 2 * lane, va);
+        if (take_c) row_c = qn_s2_eval_item<false>(q, va, diag_c, lane, wave, h, nullptr, qd_, 0, colred[2][wave], sred[2][wave]);
+        if (it == 0) { qn_keepalive(row_a); qn_keepalive(row_b); qn_keepalive(row_c); QN_S2_STAMP(3); }
         __syncthreads();
-        if (it == 0) QN_S2_STAMP(13);
-        if (tid < QN_TB) {
-            double acc = colred[0][tid];
+        if (it == 0) QN_S2_STAMP(4);
+        if (tid < 3 * QN_TB) { // threads 0..127: item a's column part, 128..255: item b's, 256..383: item c's
+            const int e = tid >> 7, cidx = tid & (QN_TB - 1);
+            if (e == 0 || (e == 1 && has_b) || (e == 2 && take_c)) {
+                double acc = colred[e][0][cidx];
 #pragma unroll
-            for (int w = 1; w < QN_S2_WAVES; ++w) acc = acc + colred[w][tid];
-            if (diag) colsum[tid] = acc; // both parts of a diagonal tile belong to block-row I: one slot
-            else a.part[(((size_t)J * a.nb + I) * 2 + 0) * QN_TB + tid] = acc;
-        }
-        if (tid == 0) {
-            wg[0] = wg[0] + qn_s2_wave_total(sred, 0);
-            wg[2] = wg[2] + qn_s2_wave_total(sred, 1);
-            if (diag) {
-                wg[1] = wg[1] + qn_s2_wave_total(sred, 2);
-                wg[3] = wg[3] + qn_s2_wave_total(sred, 3);
-                wg[4] = wg[4] + qn_s2_wave_total(sred, 4);
-                wg[5] = wg[5] + qn_s2_wave_total(sred, 5);
+                for (int w = 1; w < QN_S2_WAVES; ++w) acc = acc + colred[e][w][cidx];
+                const bool dg = e == 0 ? diag_a : (e == 1 ? diag_b : diag_c);
+                const int Ie = e == 0 ? Ia : (e == 1 ? Ib : Ic), Je = e == 0 ? Ja : (e == 1 ? Jb : Jc);
+                if (dg) colsum[e][cidx] = acc; // both parts of a diagonal tile belong to block-row I: one slot
+                else a.part[(((size_t)Je * a.nb + Ie) * 2 + 0) * QN_TB + cidx] = acc;
             }
         }
-        if (it == 0) QN_S2_STAMP(14);
-        if (diag) __syncthreads(); // (uniform: I, J are the same in every thread)
+        if (tid == 0) { // (items in list order: a, b, c)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                if (e == 0 || (e == 1 && has_b) || (e == 2 && take_c)) {
+                    wg[0] = wg[0] + qn_s2_wave_total(sred[e], 0);
+                    wg[2] = wg[2] + qn_s2_wave_total(sred[e], 1);
+                    if (e == 0 ? diag_a : (e == 1 ? diag_b : diag_c)) {
+                        wg[1] = wg[1] + qn_s2_wave_total(sred[e], 2);
+                        wg[3] = wg[3] + qn_s2_wave_total(sred[e], 3);
+                        wg[4] = wg[4] + qn_s2_wave_total(sred[e], 4);
+                        wg[5] = wg[5] + qn_s2_wave_total(sred[e], 5);
+                    }
+                }
+            }
+        }
+        if (diag_a || diag_b || diag_c) __syncthreads(); // (uniform)
         if ((lane & 3) == 0) {
             const int rl = wave * QN_S2_RPW + (lane >> 2);
-            double v = racc[0];
-            if (diag) v = v + colsum[rl];
-            a.part[(((size_t)I * a.nb + J) * 2 + 0) * QN_TB + rl] = v;
+            double v = row_a;
+            if (diag_a) v = v + colsum[0][rl];
+            a.part[(((size_t)Ia * a.nb + Ja) * 2 + 0) * QN_TB + rl] = v;
+            if (has_b) {
+                v = row_b;
+                if (diag_b) v = v + colsum[1][rl];
+                a.part[(((size_t)Ib * a.nb + Jb) * 2 + 0) * QN_TB + rl] = v;
+            }
+            if (take_c) {
+                v = row_c;
+                if (diag_c) v = v + colsum[2][rl];
+                a.part[(((size_t)Ic * a.nb + Jc) * 2 + 0) * QN_TB + rl] = v;
+            }
         }
-        if (stamp_k < 13) QN_S2_STAMP(stamp_k); // item done
-        ++stamp_k;
-        if (!has_next) break;
-        I = In; J = Jn;
-        __syncthreads(); // colred / colsum / sred are rewritten by the next item
+        if (it == 0) QN_S2_STAMP(5);
+        if (ijc < 0 || take_c) break;
+        ija = ijc; ijb = ijd;
+        __syncthreads(); // colred / colsum / sred are rewritten by the next group
     }
     QN_S2_STAMP(15);
     if (tid == 0) {
@@ -629,13 +682,15 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     __shared__ QnS2Lds L;
     __shared__ double colsum[2][QN_TB]; // [rhs]: row part of a diagonal item, parked until its column part is summed
     __shared__ double colred[QN_S2_WAVES][2][QN_TB];
-    __shared__ v2d park[QN_S2_WAVES - 1][QN_S2_RPW][64]; // the first item's rows of waves 1..7, parked while wave 0 decides (s2_eval_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
     int ij = qn_s2_first_item(blockIdx.x, a.nb);
     const int ij1 = qn_s2_second_item(a);
     if (wave == 0) qn_s2_prologue_w0<QN_S2_HTILE>(a, L); // (wave 0: the prologue first, then its rows -- see s2_eval_kernel)
     int I = ij >> 16, J = ij & 0xffff;
+    // (Measured and dropped, rocprofv3 averages on the same box: parking the first item in LDS as the evaluation does.  This
+    // kernel's prologue consumes an accept-reduce -- a short run of the machine -- and every row is written back as well:
+    // 26.2 us without parking, 28.0-28.4 with.)
     v2d h[QN_S2_RPW]; // the wave's 16 rows of the first item go out before the control block is known ...
     double* hbase = a.H + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
 #pragma unroll
@@ -652,16 +707,6 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         qn_s2_hvec_load(spec, ir, jc, v0);
         s1_r = a.F.S0[np + ir]; s1_c = ld2(a.F.S0 + np + jc);
         y_r = a.F.Y[ir]; y_c = ld2(a.F.Y + jc);
-    }
-    const bool parked = wave != 0 && ij1 >= 0; // (wave-uniform)
-    if (parked) { // the rows of the first item into LDS as they arrive, the second item's rows into the registers they free
-        const int I1 = ij1 >> 16, J1 = ij1 & 0xffff;
-        const double* h1 = a.H + (size_t)(I1 * QN_TB + wave * QN_S2_RPW) * np + (size_t)J1 * QN_TB + qn_s2_col(I1 == J1, lane, wave);
-#pragma unroll
-        for (int r = 0; r < QN_S2_RPW; ++r) {
-            park[wave - 1][r][lane] = h[r];
-            h[r] = qn_sym_ld<NT>(h1 + (size_t)r * np);
-        }
     }
     __syncthreads();
     qn_s2_ctl_out(a, L);
@@ -726,19 +771,11 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
             c0y = __builtin_fma(hn.y, y0, c0y);                                                                      \
             c1x = __builtin_fma(hn.x, y1, c1x);                                                                      \
             c1y = __builtin_fma(hn.y, y1, c1y);
-        if (parked && it == 0) { // the parked item: rows from LDS; the registers already hold the next item
 #pragma unroll
-            for (int r = 0; r < QN_S2_RPW; ++r) {
-                v2d hn = park[wave - 1][r][lane];
-                QN_S2_H_ROW
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
-                v2d hn = h[r];
-                h[r] = qn_sym_ld<NT>(hnext + (size_t)r * rstride); // the register this row frees takes the same row of the next item at once
-                QN_S2_H_ROW
-            }
+        for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
+            v2d hn = h[r];
+            h[r] = qn_sym_ld<NT>(hnext + (size_t)r * rstride); // the register this row frees takes the same row of the next item at once
+            QN_S2_H_ROW
         }
 #undef QN_S2_H_ROW
         if (!qn_s2_col_on(diag, lane, wave)) { c0x = 0.0; c0y = 0.0; c1x = 0.0; c1y = 0.0; }

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as ge
 qn = ge.load_package()
 A = qn._abi
-A.LIB_PATH = os.path.join(ROOT, "optimization-solvers_amd", "lib", "libqn_hip_stamps.so")
+A.LIB_PATH = os.path.join(ROOT, "optimization-solvers_amd", "lib", os.environ.get("QN_STAMPS_LIB", "libqn_hip_stamps.so"))
 import problems as P
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -25,21 +25,24 @@ cnt = 64 * 256 * 16
 buf = np.zeros(cnt, dtype=np.uint64)
 L.qn_debug_stamps(s.h, buf.ctypes.data_as(C.c_void_p), cnt)
 st = buf.reshape(64, 256, 16).astype(np.int64)
-names = ["entry->loads issued", "prologue", "vec loads 1", "rows 1", "tail 1", "vec loads 2", "rows 2", "tail 2"]
+# stamps (ns after the workgroup's entry, median over workgroups): 9 control block in LDS, 10 sums of the previous launch's table,
+# 11 machine done, 1 wave 0 has requested its rows, 2 after the workgroup barrier (prologue end), 3 first pair: rows consumed and
+# folded, 4 after the pair's barrier, 5 pair's slots stored, 15 end
+order = [9, 10, 11, 1, 2, 3, 4, 5, 15]
+label = {9: "ctl", 10: "sums", 11: "machine", 1: "w0 issued", 2: "barrier", 3: "pair folded", 4: "pair barrier", 5: "pair stored", 15: "end"}
 for slot in range(64):
     t = st[slot]
-    if t[0, 15] == 0 or t[0, 0] == 0:
+    if t[0, 15] == 0 or t[0, 0] == 0 or t[0, 3] == 0:
         continue  # not an evaluation launch that did work
-    wg = t[:, 0] > 0
+    wg = (t[:, 0] > 0) & (t[:, 15] > 0)
     t = t[wg]
     span = (t[:, 15].max() - t[:, 0].min()) * 10
-    d = []
-    for k in range(1, 9):
-        ok = (t[:, k] > 0) & (t[:, k - 1] > 0)
-        d.append(int(np.median((t[ok, k] - t[ok, k - 1]) * 10)) if ok.any() else None)
-    tot = int(np.median((t[:, 15] - t[:, 0]) * 10))
     start_spread = int((t[:, 0].max() - t[:, 0].min()) * 10)
-    pro = [int(np.median((t[:, k] - t[:, 1]) * 10)) for k in (9, 10, 11, 2)]
-    print(f"slot {slot:2d}: span {span} ns, start spread {start_spread}, median wg total {tot}; " + ", ".join(f"{nm} {v}" for nm, v in zip(names, d))
-          + f"; prologue from its start: ctl in LDS {pro[0]}, sums {pro[1]}, machine done {pro[2]}, end {pro[3]}"
-          + "; tail 1 from rows-done: folds %d, barrier %d, sums %d" % tuple(int(np.median((t[:, k] - t[:, 4]) * 10)) for k in (12, 13, 14)))
+    parts = []
+    for k in order:
+        ok = (t[:, k] > 0) & (t[:, k] >= t[:, 0]) & (t[:, k] - t[:, 0] < 100000)
+        parts.append("%s %d" % (label[k], int(np.median((t[ok, k] - t[ok, 0]) * 10))) if ok.any() else "%s -" % label[k])
+    end = (t[:, 15] - t[:, 0].min()) * 10
+    late = np.argsort(end)[-8:]
+    print(f"slot {slot:2d}: span {span} ns, start spread {start_spread}; " + ", ".join(parts)
+          + "; workgroup ends p50 %d p90 %d max %d, last: %s" % (np.median(end), np.percentile(end, 90), end.max(), " ".join("%d@%d" % (g, end[g]) for g in late)))
