@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -489,7 +490,9 @@ extern "C" void qn_backtracking_new(qn_linesearch* ls, double c1, double beta) {
 // objectives
 // ------------------------------------------------------------------------------------------------
 enum { OBJ_QUADRATIC = 1, OBJ_LOGSUMEXP = 2 };
+static std::atomic<uint64_t> g_objective_serial{0}; // objectives are numbered at creation: an address can come back after a destroy, a serial cannot
 struct qn_objective {
+    uint64_t serial = ++g_objective_serial;
     qn_context* ctx = nullptr;
     int kind = 0;
     size_t n = 0;
@@ -607,14 +610,16 @@ static void launch_hpass(hipStream_t st, const QnHPassArgs& a);
 // enqueue one evaluation of the log-sum-exp objective at x_dev (n_pad entries): f -> f_dev, g -> g_dev
 template <int KCH>
 static int lse_launch_onepass(hipStream_t st, int G, const QnLseArgs& a, double* wgms, double* wgg) {
-    static bool attr_set = false;
+    static bool attr_set[64] = {}; // per device: hipFuncSetAttribute applies to the current device only
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     const size_t lds = (size_t)KCH * 1024 * sizeof(double);
-    if (!attr_set && lds > 48 * 1024) { // x in LDS: up to 128 KB of the CU's 160 KB
+    if ((dev < 0 || dev >= 64 || !attr_set[dev]) && lds > 48 * 1024) { // x in LDS: up to 128 KB of the CU's 160 KB
         if (hipFuncSetAttribute((const void*)lse_onepass_kernel<KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             return -1; // this device does not grant the LDS: the caller keeps the two-pass evaluation
         }
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((lse_onepass_kernel<KCH>), dim3(G), dim3(512), lds, st, a, wgms, wgg);
     return QN_OK;
@@ -797,8 +802,10 @@ struct qn_solver {
     // After a fused run the iterate and the pending update's vectors stay where the fused kernels keep them (X0[xc], S0[sc], UN);
     // they are copied back to the canonical buffers only when something other than the next fused run wants them.
     bool fused_live = false;
-    // the previous qn_minimize ended on the iteration cap of a fused, memoised run on `warm_obj`; nothing has touched the state since
-    const void* warm_obj = nullptr;
+    // the previous qn_minimize ended on the iteration cap of a fused, memoised run on the objective with this serial (0: none);
+    // nothing has touched the state since.  A serial, not the pointer: destroy A, create B of the same size and the allocator
+    // hands the address back -- the run on B would have inherited f, g and the lazy direction of A.
+    uint64_t warm_obj = 0;
     int* newton_fail = nullptr; // [0]: the factorisation met a bad pivot, [1]: the staged Hessian is not symmetric bit for bit
     int *newton_piv = nullptr, *newton_perm = nullptr; // LU fallback (qn_lu.hip.h): pivot rows, row permutation
     std::vector<int> newton_piv_host;
@@ -1085,7 +1092,7 @@ extern "C" double qn_solver_tol(const qn_solver* s) { return s->tol; }
 
 // canonical buffers <- fused buffers (the lazy half of qn_minimize's export)
 static int fused_export(qn_solver* s) {
-    s->warm_obj = nullptr; // whoever asks for the canonical buffers may change them: the next call starts from scratch
+    s->warm_obj = 0; // whoever asks for the canonical buffers may change them: the next call starts from scratch
     if (!s->fused_live) return QN_OK;
     qn_context* c = s->ctx;
     const QnCtl* h = s->hctl;
@@ -1163,7 +1170,7 @@ extern "C" int qn_solver_reset(qn_solver* s, const double* x0_host) {
         s->h_lower_stale = false; s->h_diag_stale = false;
         s->h_nonsym = false;
     }
-    s->fused_live = false; s->warm_obj = nullptr; // (whatever the fused buffers hold is dropped with the rest of the state)
+    s->fused_live = false; s->warm_obj = 0; // (whatever the fused buffers hold is dropped with the rest of the state)
     HIPCHK(hipMemsetAsync(s->vec_block, 0, 9 * (size_t)s->T.n_pad * sizeof(double), st));
     HIPCHK(hipMemcpyAsync(s->V.x, x0_host, s->n * sizeof(double), hipMemcpyHostToDevice, st));
     memset(s->hctl, 0, sizeof(QnCtl));
@@ -1350,6 +1357,18 @@ extern "C" int qn_solver_compute_direction(qn_solver* s, const double* g_host, d
     }
     (void)hipFree(buf);
     if (st != QN_OK) return st;
+    if (s->bounded) { // BFGSB / DFPB / SR1B: P(x - H g) - x with the solver's box (bfgs_b.rs:66-77), not -H g
+        std::vector<double> x(n), lb(n), ub(n);
+        QNCHK(qn_solver_get_x(s, x.data()));
+        HIPCHK(hipMemcpy(lb.data(), s->bounds_block, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ub.data(), s->bounds_block + np, n * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            double t = x[i] - d_host[i];
+            t = std::fmin(std::fmax(t, lb[i]), ub[i]);
+            d_host[i] = t - x[i];
+        }
+        return QN_OK;
+    }
     for (size_t i = 0; i < n; ++i) d_host[i] = -d_host[i];
     return QN_OK;
 }
@@ -2079,7 +2098,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     // ... and on the upper block triangle only (half the bytes) when H and Q are whole 128-tiles on one rank
     const bool sym_ok = c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
     // ... row-sharded: every rank streams the circulant half of its own block-rows (whole 128-row blocks per rank)
-    const bool symsh_ok = c->world > 1 && (s->T.rpr % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
+    const bool symsh_ok = c->world > 1 && (s->T.rpr % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && s->T.n_pad / QN_TB <= 512 && !s->no_sym && !s->h_nonsym; // (nb <= 512: the LDS slot lists of symsh_*_sum_kernel)
     r.sym = r.fused && (sym_ok || symsh_ok) && r.obj && r.obj->q_symmetric;
     // the generic path's H pass alone (closures, log-sum-exp objective, SR1, bounded variants): same tiles, sums into V.hp
     r.sym_generic = !r.fused && (sym_ok || symsh_ok) && s->H && s->hcs == 1 && (s->method == QN_BFGS || s->method == QN_DFP || s->method == QN_SR1);
@@ -2113,7 +2132,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             }
             h->xc = 0; h->sc = 0;
         } // (else: a fused run left them there; xc / sc in the control block say which halves are current)
-        h->warm = (s->fused_live && s->warm_obj == (const void*)r.obj && h->memoize && h->pending && !ls_only) ? 1 : 0;
+        h->warm = (s->fused_live && s->warm_obj != 0 && s->warm_obj == r.obj->serial && h->memoize && h->pending && !ls_only) ? 1 : 0;
         if (!h->warm) { h->dir_mode = 0; h->gd0_valid = 0; }
     } else {
         h->warm = 0;
@@ -2224,7 +2243,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     // triangle of H stays stale (ensure_full_h) until a getter, a setter or a run on another path asks for them.  A solve made
     // of several qn_minimize calls (warm restarts, a harness timing short calls) pays for neither.
     if (r.fused) s->fused_live = true;
-    s->warm_obj = (r.fused && status == QN_MAX_ITER_REACHED && h->memoize && h->have_cur_eval && h->have_dir) ? (const void*)r.obj : nullptr;
+    s->warm_obj = (r.fused && status == QN_MAX_ITER_REACHED && h->memoize && h->have_cur_eval && h->have_dir) ? r.obj->serial : 0;
     if (ls->kind == QN_LS_MORETHUENTE_B) ls->t_max = h->mt_tmax; // morethuente_b.rs:201: the clipped t_max stays in the line search
     s->stats.iterations = h->n_iterations;
     s->stats.oracle_calls = h->n_oracle_calls;

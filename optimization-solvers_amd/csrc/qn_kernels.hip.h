@@ -816,7 +816,8 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(const QnLseArgs a, int
     const int tid = threadIdx.x;
     const double mw = tid < G ? wgms[2 * tid] : -INFINITY;
     const double mr = ctl_block_fmax(mw, lds);
-    fac[tid] = tid < G ? exp(mw - mr) : 0.0; // (a workgroup without rows: exp(-inf) = 0)
+    // (a workgroup without rows: exp(-inf) = 0; a RANK without rows -- every maximum -inf -- would make exp(-inf - (-inf)) = NaN)
+    fac[tid] = (tid < G && mw != -INFINITY) ? exp(mw - mr) : 0.0;
     __syncthreads();
     const int c = tid & 63, q = tid >> 6;
     const int j = min(blockIdx.x * 64 + c, a.n_pad - 1);
@@ -845,10 +846,10 @@ __global__ __launch_bounds__(256) void lse_finish1_kernel(const QnLseArgs a, con
     double M = lms[0];
     for (int p = 1; p < a.world; ++p) M = fmax(M, lms[2 * p]);
     double S = 0.0;
-    for (int p = 0; p < a.world; ++p) S = __builtin_fma(lms[2 * p + 1], exp(lms[2 * p] - M), S);
+    for (int p = 0; p < a.world; ++p) S = __builtin_fma(lms[2 * p + 1], lms[2 * p] != -INFINITY ? exp(lms[2 * p] - M) : 0.0, S); // (a rank that owns no real row contributes nothing)
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n_pad; j += gridDim.x * blockDim.x) {
         double t = 0.0;
-        for (int p = 0; p < a.world; ++p) t = __builtin_fma(a.gall[(size_t)p * a.n_pad + j], exp(lms[2 * p] - M), t);
+        for (int p = 0; p < a.world; ++p) t = __builtin_fma(a.gall[(size_t)p * a.n_pad + j], lms[2 * p] != -INFINITY ? exp(lms[2 * p] - M) : 0.0, t);
         a.g_out[j] = (j < a.n) ? t / S + a.mu * a.x[j] : 0.0;
     }
     if (blockIdx.x == 0) {

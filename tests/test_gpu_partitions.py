@@ -1,0 +1,163 @@
+"""BASELINE.json's partitions at their real rank counts, rehearsed on one GPU: config 3 = the inverse Hessian row-sharded 8 ways
+(n = 32768), config 5 = DFP + More-Thuente on the log-sum-exp objective 4 ways (n = m = 16384).  The ranks are threads of this
+process (tests/thread_ranks.py: the box admits 6 GPU processes), the exchange is the host-staged one, in both of its modes:
+all-gather of the partial vectors + rank-order sum, and the all-reduce stand-in.  Checked against the single-rank run of the same
+problem on the same GPU (line-search cases, evaluation counts, steps and iterates to the parity tolerance), between the ranks
+(the same bits everywhere), against the oracle's rank-2 mode for the first iterations, and through what the partition promises:
+every pair of block-rows streamed exactly once across the ranks."""
+import numpy as np
+import pytest
+
+import problems as P
+from thread_ranks import run_ranks
+
+pytestmark = pytest.mark.gpu
+
+T_TOL, X_TOL = 1e-9, 1e-9
+
+
+def _trace_close(tr, xs, tr1, xs1):
+    assert len(tr) == len(tr1)
+    for a, c in zip(tr, tr1):
+        assert (a["ls_cases"], a["n_evals"], a["ls_iters"]) == (c["ls_cases"], c["n_evals"], c["ls_iters"])
+        assert abs(a["t"] - c["t"]) <= T_TOL * abs(c["t"])
+    for k in range(len(xs1)):
+        assert np.linalg.norm(xs[k] - xs1[k]) <= X_TOL * max(1.0, np.linalg.norm(xs1[k]))
+
+
+def _run(qn, solver, ls, obj, iters):
+    solver.set_trace(iters, with_x=True)
+    try:
+        solver.minimize(ls, obj, iters, 20)
+    except qn.MaxIterReached:
+        pass
+    return solver.trace()
+
+
+def _sharded_quadratic(qn, n, world, iters, allreduce, want_h):
+    diag = P.synth_diag(n)
+    b, x0 = P.synth_vectors(n)
+
+    def body(rank, world_, group):
+        ctx = qn.Context(0, rank=rank, world=world_, host_allgather=group.allgather_fn(rank))
+        ctx.comm_check()
+        if allreduce:
+            ctx.set_allreduce(True)
+        obj = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx)
+        s = qn.BFGS(1e-10, x0, ctx=ctx)
+        tr, xs = _run(qn, s, qn.MoreThuente(), obj, iters)
+        st = s.stats()
+        out = {"tr": tr, "xs": xs, "path": st["path"], "bytes": st["matrix_bytes_per_pass"]}
+        if want_h:
+            out["h"] = s.approx_inv_hessian(all_ranks=True)  # collective: the stale halves come from the ranks that own the pairs
+        group.sync()
+        s.close(); obj.close(); ctx.close()
+        return out
+
+    return run_ranks(world, body), (diag, b, x0)
+
+
+def _single_rank_quadratic(qn, n, iters, inputs, first_generation=True):
+    diag, b, x0 = inputs
+    obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
+    s = qn.BFGS(1e-10, x0)
+    if first_generation:
+        s.set_tiling(-4, 0)  # the first-generation tile kernels: the ones the sharded layout runs
+    tr, xs = _run(qn, s, qn.MoreThuente(), obj, iters)
+    return s, obj, tr, xs
+
+
+def _check_partition(res, world, n):
+    nb = n // 128
+    for r in res:
+        assert r["path"] & 1 and r["path"] & 2 and not r["path"] & 16  # fused, symmetric storage, first-generation tile kernels
+    assert sum(r["bytes"] for r in res) == nb * (nb + 1) // 2 * 131072  # every pair of block-rows exactly once
+    assert max(r["bytes"] for r in res) - min(r["bytes"] for r in res) <= (nb // world) * 131072  # balanced to a tile per block-row
+    for r in res[1:]:  # replicated vector work: the same bits on every rank
+        assert np.array_equal(r["xs"], res[0]["xs"]) and r["tr"] == res[0]["tr"]
+
+
+@pytest.mark.parametrize("allreduce", [False, True])
+def test_config3_partition_8_ranks_n4096_vs_single_rank_and_oracle(qn, qo, allreduce):
+    """P = 8, rpr / 128 = 4 block-rows per rank, nb = 32 even (cnt(I) split at I < nb / 2): config 3's shape at a size the oracle
+    follows."""
+    n, world, iters = 4096, 8, 12
+    res, inputs = _sharded_quadratic(qn, n, world, iters, allreduce, want_h=not allreduce)
+    _check_partition(res, world, n)
+    s1, obj1, tr1, xs1 = _single_rank_quadratic(qn, n, iters, inputs)
+    _trace_close(res[0]["tr"], res[0]["xs"], tr1, xs1)
+    if not allreduce:
+        h, h1 = res[0]["h"], s1.approx_inv_hessian()
+        assert np.array_equal(h, h.T)
+        assert np.linalg.norm(h - h1) <= 1e-8 * np.linalg.norm(h1)
+        for r in res[1:]:
+            assert np.array_equal(r["h"], h)
+    # the first 6 iterations against the oracle's rank-2 mode (threaded: it is the CPU baseline of bench.py)
+    diag, b, x0 = inputs
+    q = qo.synth_rows(n, 0, n, P.SEED, diag)
+    ref = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
+    ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b, nthreads=qo.max_threads()), 6, 20, trace_cap=6, trace_x=True)
+    _trace_close(res[0]["tr"][:6], res[0]["xs"][:6], ref.trace, ref.trace_x)
+
+
+def test_config3_partition_8_ranks_n32768(qn, qo):
+    """BASELINE.json config 3 itself: n = 32768, 8 ranks (2 GiB of H and Q rows per rank, 32 block-rows each, nb = 256), all on
+    the one GPU, against the unsharded run of the same problem (16 GiB) on the same kernels."""
+    n, world, iters = 32768, 8, 6
+    res, inputs = _sharded_quadratic(qn, n, world, iters, allreduce=False, want_h=False)
+    _check_partition(res, world, n)
+    s1, obj1, tr1, xs1 = _single_rank_quadratic(qn, n, iters, inputs)
+    _trace_close(res[0]["tr"], res[0]["xs"], tr1, xs1)
+    f = np.array([r["f"] for r in res[0]["tr"]])
+    assert np.all(np.diff(f) < 0)
+    s1.close(); obj1.close()
+    # ... and the literal all-reduce stand-in at full size: the same bits as the all-gather + rank-order sum (host-staged: it IS
+    # gathered and added in rank order; RCCL's own order is tolerance-level, tests/test_gpu_sharded.py on a multi-GPU box)
+    res_ar, _ = _sharded_quadratic(qn, n, world, iters, allreduce=True, want_h=False)
+    for r in res_ar:
+        assert np.array_equal(r["xs"], res[0]["xs"])
+
+
+def test_config5_partition_4_ranks_dfp_logsumexp_n16384(qn, qo):
+    """BASELINE.json config 5: DFP + More-Thuente on the n = m = 16384 log-sum-exp objective, rows of A (and of H) sharded 4 ways.
+    The H pass runs on the sharded symmetric tiles (generic path), the objective's gradient is summed over the ranks in rank
+    order."""
+    n = m = 16384
+    world, iters, mu = 4, 6, 0.1
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((m, n)) * (2.0 / np.sqrt(n))
+    c = rng.standard_normal(m)
+    x0 = rng.standard_normal(n)
+
+    def body(rank, world_, group):
+        ctx = qn.Context(0, rank=rank, world=world_, host_allgather=group.allgather_fn(rank))
+        obj = qn.LogSumExp(a, c, mu, ctx=ctx)
+        s = qn.DFP(1e-10, x0, ctx=ctx)
+        tr, xs = _run(qn, s, qn.MoreThuente(), obj, iters)
+        st = s.stats()
+        ev = obj(xs[-1])
+        out = {"tr": tr, "xs": xs, "path": st["path"], "bytes": st["matrix_bytes_per_pass"], "f": ev.f(), "g": ev.g()}
+        group.sync()
+        s.close(); obj.close(); ctx.close()
+        return out
+
+    res = run_ranks(world, body)
+    nb = n // 128
+    for r in res:
+        assert r["path"] & 4 and not r["path"] & 1  # generic path, H pass on the (sharded) symmetric tiles
+        assert np.array_equal(r["xs"], res[0]["xs"]) and r["tr"] == res[0]["tr"] and r["f"] == res[0]["f"] and np.array_equal(r["g"], res[0]["g"])
+    assert sum(r["bytes"] for r in res) == nb * (nb + 1) // 2 * 131072
+    obj1 = qn.LogSumExp(a, c, mu)
+    s1 = qn.DFP(1e-10, x0)
+    tr1, xs1 = _run(qn, s1, qn.MoreThuente(), obj1, iters)
+    _trace_close(res[0]["tr"], res[0]["xs"], tr1, xs1)
+    f = np.array([r["f"] for r in res[0]["tr"]])
+    assert np.all(np.diff(f) < 0)
+    # the sharded objective against the threaded CPU oracle at full size, and the first iterations against its rank-2 restatement
+    o = qo.LogSumExpOracle(a, c, mu, nthreads=qo.max_threads())
+    f_ref, g_ref = o(res[0]["xs"][-1])
+    assert abs(res[0]["f"] - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
+    assert np.linalg.norm(res[0]["g"] - g_ref) <= 1e-11 * np.linalg.norm(g_ref)
+    ref = qo.Solver(qo.DFP, 1e-10, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
+    ref.minimize(qo.morethuente(), o, 3, 20, trace_cap=3, trace_x=True)
+    _trace_close(res[0]["tr"][:3], res[0]["xs"][:3], ref.trace, ref.trace_x)

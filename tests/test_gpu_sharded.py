@@ -74,7 +74,11 @@ def test_row_sharded_symmetric_storage(tmp_path, nproc):
     _check_sharded_symmetric(launch("gpu_sym", tmp_path, nproc=nproc, timeout=900), nproc)
 
 
-@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs: the RCCL exchange between two devices (never available to this build so far)")
-def test_row_sharded_symmetric_storage_over_rccl_two_gpus(tmp_path):
-    """The same checks with one GPU per rank and the real RCCL all-gathers (single and grouped), pipelined against synchronous."""
-    _check_sharded_symmetric(launch("gpu_sym", tmp_path, nproc=2, timeout=900, extra_env={"QN_TEST_EXCHANGE": "rccl"}), 2)
+@pytest.mark.parametrize("nproc", [2, 4, 8])
+def test_row_sharded_symmetric_storage_over_rccl(tmp_path, nproc):
+    """The same checks with one GPU per rank and the real RCCL exchange (all-gathers, single and grouped, and ncclAllReduce),
+    pipelined against synchronous: runs at 2, 4 and 8 ranks on the first box that has that many GPUs (none was available to
+    this build in rounds 1-3; the partitions themselves are rehearsed on one GPU in tests/test_gpu_partitions.py)."""
+    if _device_count() < nproc:
+        pytest.skip("needs %d GPUs: the RCCL exchange between devices" % nproc)
+    _check_sharded_symmetric(launch("gpu_sym", tmp_path, nproc=nproc, timeout=900, extra_env={"QN_TEST_EXCHANGE": "rccl"}), nproc)

@@ -147,6 +147,39 @@ def test_continued_calls_are_one_run_bit_for_bit(qn, qo, tiling):
     assert np.linalg.norm(four.x() - one.x()) <= 1e-9 * np.linalg.norm(one.x())
 
 
+def test_objective_destroyed_and_recreated_between_calls_is_not_a_continuation(qn, qo):
+    """The warm continuation must know the objective by identity, not by address: run to the iteration cap on A, destroy A,
+    create B (same size: the allocator is likely to hand the address back) with another Q and b, continue.  The second call has
+    to evaluate B at x_k and form the direction from scratch -- as the reference does on every minimize() (ls_solver.rs:79) --
+    and so equal a solver that was handed (x_k, H_k) and ran on B cold."""
+    n = 1024
+    q, b, x0, _ = P.synth_problem(qo, n)
+    rng = np.random.default_rng(11)
+    q2 = q + np.diag(rng.uniform(0.5, 3.0, n))
+    b2 = b + rng.standard_normal(n)
+    for attempt in range(4):  # several tries: each destroy / create is a chance for the address to come back
+        a_obj = qn.Quadratic(q, b)
+        s = qn.BFGS(1e-10, x0)
+        with pytest.raises(qn.MaxIterReached):
+            s.minimize(qn.MoreThuente(), a_obj, 8, 20)
+        xk, hk = s.x(), s.approx_inv_hessian()
+        # (the getters above export nothing that would end a continuation on the fast path: re-run to the cap to arm it again)
+        s2 = qn.BFGS(1e-10, x0)
+        with pytest.raises(qn.MaxIterReached):
+            s2.minimize(qn.MoreThuente(), a_obj, 8, 20)
+        a_obj.close()
+        b_obj = qn.Quadratic(q2, b2)
+        with pytest.raises(qn.MaxIterReached):
+            s2.minimize(qn.MoreThuente(), b_obj, 6, 20)
+        cold = qn.BFGS(1e-10, xk)
+        cold.set_approx_inv_hessian(hk)
+        with pytest.raises(qn.MaxIterReached):
+            cold.minimize(qn.MoreThuente(), b_obj, 6, 20)
+        assert s2.stats()["oracle_evals"] == cold.stats()["oracle_evals"]  # the evaluation at x_k on B was made
+        assert np.linalg.norm(s2.x() - cold.x()) <= 1e-9 * max(1.0, np.linalg.norm(cold.x()))
+        b_obj.close()
+
+
 def test_non_symmetric_user_hessian_uses_the_full_matrix(qn, qo):
     n = 1024
     q, b, x0, _ = P.synth_problem(qo, n)

@@ -103,3 +103,25 @@ def test_compute_direction_and_secant_update_vs_oracle_formulas(qn, qo):
     with pytest.raises(qn.ErrorInputParams):
         qn.GradientDescent(1e-8, np.zeros(4)).secant_update(np.ones(4), np.ones(4))
     assert np.array_equal(qn.GradientDescent(1e-8, np.zeros(4)).compute_direction((0.0, np.arange(4.0))), -np.arange(4.0))
+
+
+def test_bounded_solver_direction_hook_is_projected(qn, qo):
+    """BFGSB / DFPB / SR1B::compute_direction is P(x - H g) - x with the solver's box (bfgs_b.rs:66-77, dfp_b.rs, sr1_b.rs), not
+    -H g: the hook must not hand a binding a direction that leaves the box."""
+    n = 130
+    rng = np.random.default_rng(5)
+    m = rng.standard_normal((n, n))
+    h0 = m @ m.T / n + np.eye(n)
+    g = rng.standard_normal(n)
+    lb, ub = -0.3 * np.ones(n), 0.4 * np.ones(n)
+    x0 = rng.uniform(-1.0, 1.0, n)  # projected onto the box by the constructor (bfgs_b.rs:49)
+    for mk in (qn.BFGSB, qn.DFPB, qn.SR1B):
+        sol = mk(1e-10, x0, lb, ub)
+        sol.set_approx_inv_hessian(h0)
+        x = sol.x()
+        assert np.array_equal(x, np.minimum(np.maximum(x0, lb), ub))
+        d = sol.compute_direction((0.0, g))
+        want = np.minimum(np.maximum(x - h0 @ g, lb), ub) - x
+        assert np.linalg.norm(d - want) <= 1e-12 * max(1.0, np.linalg.norm(want))
+        assert np.all(x + d >= lb - 1e-15) and np.all(x + d <= ub + 1e-15)
+        assert np.linalg.norm(d + h0 @ g) > 1e-3  # (the box is active: the unprojected direction is something else)
