@@ -65,9 +65,13 @@ def totals(solver):
 
 
 def cpu_baseline(n, iters):
-    """CPU port timed on the host cores: the oracle restatement with the O(n^2) rank-2 update (the reference's
-    literal update is O(n^3): 2.7e11 flop per iteration at n = 4096), reference call sequence (5 oracle calls per
-    iteration), OpenMP over all cores."""
+    """CPU port timed on the host cores (CPU-B): the oracle restatement with the O(n^2) rank-2 update (the
+    reference's literal update is O(n^3): 2.7e11 flop per iteration at n = 4096), reference call sequence (5 oracle calls per
+    iteration), OpenMP over all cores.  Every sweep is contiguous per thread -- the symmetric H and Q are read by rows = columns,
+    four rows per thread in flight, pages first touched by the thread that streams them -- so the port is bandwidth-bound and
+    the achieved GB/s is printed next to the core count."""
+    os.environ.setdefault("OMP_PROC_BIND", "true")  # (before the OpenMP runtime starts: the oracle library is loaded below)
+    os.environ.setdefault("OMP_PLACES", "cores")
     from oracle import qn_oracle as qo
     threads = qo.max_threads()
     diag, b, x0 = synth_inputs(n)
@@ -78,11 +82,16 @@ def cpu_baseline(n, iters):
     s.minimize(qo.morethuente(), o, 3, 20)  # warm the caches / thread pool, and size the sample
     rate = 3.0 / max(time.perf_counter() - t0, 1e-6)
     iters = int(min(max(iters, 12.0 * rate), 250))  # ~10-15 s of CPU work, well inside the pre-convergence window
+    bytes0, calls0 = s.bytes_streamed, o.calls
     t0 = time.perf_counter()
     s.minimize(qo.morethuente(), o, iters, 20)  # warm restart: continues from the warmed-up state
     dt = time.perf_counter() - t0
     k = s.k
+    moved = (s.bytes_streamed - bytes0) + (o.calls - calls0) * 8.0 * n * n
     out = {"value": k / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
+           "achieved_GBs": moved / dt / 1e9, "bytes_per_iteration": moved / max(k, 1),
+           "bytes_note": "matrix bytes the port streams: 8 n^2 per oracle call (full Q by rows), 8 n^2 per mat-vec with H (u = H y, "
+                         "d = -H g), 16 n^2 for the rank-2 update",
            "sample": f"{k} BFGS+MoreThuente iterations at n={n} (same Q, b, x0 as the GPU run), rank-2 O(n^2) update, "
                      f"reference oracle-call sequence (5 calls per iteration), OpenMP x{threads}, {dt:.1f} s"}
     # the reference's own formulation (dense n x n products, single thread as matrixmultiply is built) at a size it finishes
@@ -260,33 +269,56 @@ def main():
         # rocprofv3 on the same run the raw bracket is 2-3 us above the profiler's kernel duration, so `achieved` below is slightly
         # conservative; the empty-kernel calibration is reported next to it for the record.
         bracket_ms = ctx.event_bracket_overhead_ms(200)
-        ach = alg_h / (ms_h * 1e-3) / 1e9 if n_h else None
+        ach_h = alg_h / (ms_h * 1e-3) / 1e9 if n_h else None
+        ach_e = alg_q / (ms_e * 1e-3) / 1e9 if n_e else None
         sym_pass = bool(p1["path"] & 2)
         sym2 = bool(p1["path"] & 16)
-        kname = ("s2_hpass_kernel (pending rank-2 update in place + row and column sums of [y, g+] over the symmetric half of H; its "
+        hname = ("s2_hpass_kernel (pending rank-2 update in place + row and column sums of [y, g+] over the symmetric half of H; its "
                  "prologue runs the solver's state machine)" if sym2 else
                  "sym_hpass_tile_kernel (rank-2 update + row and column dots of [y, g+] over the upper block triangle of H)" if (sym_pass and world == 1) else
                  "sym_hpass_tile_kernel (rank-2 update + row and column dots of [y, g+] over this rank's share of the symmetric half of H: "
                  "the circulant windows of its block-rows)" if sym_pass else
                  "h_pass_fused_kernel (fused rank-2 update + 2-RHS mat-vec over the rank's rows of H)")
-        roofline = {"bound": "hbm", "kernel": kname,
+        ename = ("s2_eval_kernel (f(x + t d) and g(x + t d)'d from the symmetric half of Q: first tile parked in LDS while wave 0 runs the "
+                 "solver's state machine, items in groups with one exchange)" if sym2 else
+                 "sym_eval_tile_kernel (Q (x + t d) from the upper block triangle of Q)" if sym_pass else
+                 "quad_eval_fused_kernel (Q_rows (x + t d), trial point and direction formed on the fly)")
+        # The `roofline` object is about the DOMINANT kernel: the one with the largest share of the GPU time of the timed pattern
+        # (launches x average duration in this pass; the pass launches exactly the work of the timed region, one request at a time).
+        # The other streaming kernel, the small reduce launches and a time-weighted figure over all of them are listed beside it.
+        t_e, t_h = (n_e * ms_e if n_e else 0.0), (n_h * ms_h if n_h else 0.0)
+        t_small = (n_er * ms_er if n_er else 0.0) + (n_hr * ms_hr if n_hr else 0.0)
+        t_all = t_e + t_h + t_small
+        dom_is_eval = t_e > t_h
+        ach, ms_dom, n_dom, alg_dom = (ach_e, ms_e, n_e, alg_q) if dom_is_eval else (ach_h, ms_h, n_h, alg_h)
+        tw = ((n_e or 0) * alg_q + (n_h or 0) * alg_h) / (t_all * 1e-3) / 1e9 if t_all > 0 else None
+        hsub = {"kernel": hname, "algorithmic_bytes_per_launch": alg_h, "avg_launch_ms": ms_h, "launches_timed": n_h, "achieved": ach_h,
+                "frac": (ach_h / HBM_PEAK_GBS) if ach_h else None, "time_share": (t_h / t_all) if t_all else None,
+                # the pass as the iteration pays for it: tile launch + its slot-reduction launch (symmetric storage only)
+                "pass_with_reduce": ({"avg_ms": ms_h + ms_hr, "achieved": alg_h / ((ms_h + ms_hr) * 1e-3) / 1e9,
+                                      "frac": alg_h / ((ms_h + ms_hr) * 1e-3) / 1e9 / HBM_PEAK_GBS, "reduce_avg_launch_ms": ms_hr,
+                                      "reduce_launches_timed": n_hr} if (n_h and n_hr) else None),
+                # SURVEY.md 8(d) counts 16 n^2 / P bytes per H pass (full matrix read + written); the symmetric-storage path does
+                # the same pass on half of them, so its rate in full-matrix terms is higher than the bytes it really moves
+                "full_matrix_equivalent_GBs": (16.0 * n * n / world) / (ms_h * 1e-3) / 1e9 if n_h else None}
+        esub = {"kernel": ename, "algorithmic_bytes_per_launch": alg_q, "avg_launch_ms": ms_e, "launches_timed": n_e, "achieved": ach_e,
+                "frac": (ach_e / HBM_PEAK_GBS) if ach_e else None, "time_share": (t_e / t_all) if t_all else None,
+                "accept_reduce_avg_launch_ms": ms_er, "accept_reduce_launches_timed": n_er}
+        roofline = {"bound": "hbm", "kernel": ename if dom_is_eval else hname,
+                    "dominant_by": "largest share of the GPU time of the timed launch pattern (launches x average duration)",
+                    "time_share": ((t_e if dom_is_eval else t_h) / t_all) if t_all else None,
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                     "traffic": None,
                     "traffic_source": None,
                     "achievable_note": "plain read+write streams reach 4.9-5.4 TB/s on this device (hipMemcpy D2D 5.0 TB/s; "
                                        "profiles/r01_c_bw_probe.txt); peak is the 8 TB/s HBM3E spec",
-                    "algorithmic_bytes_per_launch": alg_h, "avg_launch_ms": ms_h, "launches_timed": n_h,
-                    # the pass as the iteration pays for it: tile launch + its slot-reduction launch (symmetric storage only)
-                    "pass_with_reduce": ({"avg_ms": ms_h + ms_hr, "achieved": alg_h / ((ms_h + ms_hr) * 1e-3) / 1e9,
-                                          "frac": alg_h / ((ms_h + ms_hr) * 1e-3) / 1e9 / HBM_PEAK_GBS, "reduce_avg_launch_ms": ms_hr,
-                                          "reduce_launches_timed": n_hr} if (n_h and n_hr) else None),
-                    # SURVEY.md 8(d) counts 16 n^2 / P bytes per H pass (full matrix read + written); the symmetric-storage path does
-                    # the same pass on half of them, so its rate in full-matrix terms is higher than the bytes it really moves
-                    "full_matrix_equivalent_GBs": (16.0 * n * n / world) / (ms_h * 1e-3) / 1e9 if n_h else None,
+                    "algorithmic_bytes_per_launch": alg_dom, "avg_launch_ms": ms_dom, "launches_timed": n_dom,
+                    "all_kernels_time_weighted": {"achieved": tw, "frac": (tw / HBM_PEAK_GBS) if tw else None,
+                                                  "note": "algorithmic bytes of every streaming launch / summed durations of ALL launches of the "
+                                                          "pass (tile kernels and their reduce launches)"},
+                    "update_pass": hsub,
+                    "quad_matvec": esub,
                     "event_bracket_fixed_overhead_ms_not_subtracted": bracket_ms,
-                    "quad_matvec": {"algorithmic_bytes_per_launch": alg_q, "avg_launch_ms": ms_e, "launches_timed": n_e,
-                                    "achieved": (alg_q / (ms_e * 1e-3) / 1e9) if n_e else None,
-                                    "accept_reduce_avg_launch_ms": ms_er, "accept_reduce_launches_timed": n_er},
                     "ctl_step": {"avg_launch_ms": ms_c, "launches_timed": n_c,
                                  "note": ("synchronous profiling pass only: in the timed (pipelined) region the state machine runs inside "
                                           "the prologue of the streaming kernels, there is no control launch") if sym2 else None},
@@ -296,7 +328,10 @@ def main():
         if os.path.exists(pmc):
             try:
                 key = f"n{n}_p{world}" + ("_sym2" if sym2 else "_sym" if sym_pass else "")
-                roofline["traffic"] = json.load(open(pmc)).get(key, {}).get("h_pass_bytes_per_launch")
+                rec = json.load(open(pmc)).get(key, {})
+                roofline["traffic"] = rec.get("quad_eval_bytes_per_launch" if dom_is_eval else "h_pass_bytes_per_launch")
+                roofline["update_pass"]["traffic"] = rec.get("h_pass_bytes_per_launch")
+                roofline["quad_matvec"]["traffic"] = rec.get("quad_eval_bytes_per_launch")
                 if roofline["traffic"] is not None:
                     roofline["traffic_source"] = (f"profiles/pmc_traffic.json[{key}]: HBM bytes per launch from separate rocprofv3 --pmc "
                                                   "FETCH_SIZE / WRITE_SIZE passes of this build (gfx950 x2 correction on FETCH_SIZE); an "

@@ -100,6 +100,36 @@ static void gemv_colmajor_mt(const double* a, const double* x, double* y, size_t
     }
 }
 
+/* The same sums once more for a matrix that is SYMMETRIC BIT FOR BIT (H under the rank-2 form, the benchmark's Q): a_ij is
+ * also stored at a[j + i*n], so y_i = sum_j a[j + i*n] x_j sweeps row i = column i contiguously, in the same strict left-to-right
+ * order over j and with the same two roundings per term (no FMA): bit-identical to the column sweep, but every thread streams
+ * its own contiguous block of memory instead of striding through all n columns.  Four rows per thread are in flight (four
+ * independent dependent-add chains; a single chain is latency-bound at one element per ~4 cycles).  This is what makes the
+ * OpenMP port a BANDWIDTH-bound CPU baseline (CPU-B) rather than a cache-miss-bound one. */
+static void gemv_symmetric_rows_mt(const double* a, const double* x, double* y, size_t n, int nthreads) {
+    if (n == 0) return;
+#pragma omp parallel for num_threads(nthreads) schedule(static) if (nthreads > 1 && n >= 256)
+    for (size_t ib = 0; ib < (n + 3) / 4; ++ib) {
+        const size_t i = 4 * ib;
+        if (i + 4 <= n) {
+            const double *r0 = a + i * n, *r1 = r0 + n, *r2 = r1 + n, *r3 = r2 + n;
+            double a0 = r0[0] * x[0], a1 = r1[0] * x[0], a2 = r2[0] * x[0], a3 = r3[0] * x[0];
+            for (size_t j = 1; j < n; ++j) {
+                const double xj = x[j];
+                a0 = r0[j] * xj + a0; a1 = r1[j] * xj + a1; a2 = r2[j] * xj + a2; a3 = r3[j] * xj + a3;
+            }
+            y[i] = a0; y[i + 1] = a1; y[i + 2] = a2; y[i + 3] = a3;
+        } else {
+            for (size_t k = i; k < n; ++k) {
+                const double* r = a + k * n;
+                double acc = r[0] * x[0];
+                for (size_t j = 1; j < n; ++j) acc = r[j] * x[j] + acc;
+                y[k] = acc;
+            }
+        }
+    }
+}
+
 /* x + t*d : `step * direction` materialises fl(t*d_i), then the sum rounds again.
  * ls_solver.rs:60 ; bfgs.rs:94 ; backtracking.rs:32 ; morethuente.rs:182,217,276 */
 void qo_axpy_new(const double* x, double t, const double* d, double* out, size_t n) {
@@ -394,6 +424,8 @@ double qo_compute_step_len(const qo_linesearch* ls, const double* x, double f0, 
 
 struct qo_solver {
     int method, update_mode, nthreads;
+    int h_symmetric; /* H == H' bit for bit (identity, kept so by the rank-2 form): its mat-vec may sweep rows = columns contiguously */
+    double bytes_streamed; /* matrix bytes this solver's own sweeps moved (mat-vecs with H, the rank-2 update); the oracle counts its own */
     size_t n, k;
     double tol;
     double* x;
@@ -440,8 +472,17 @@ qo_solver* qo_solver_create(int method, double tol, const double* x0, size_t n, 
     s->work = (double*)calloc(4 * nn, sizeof(double));
     if (method == QO_BFGS || method == QO_DFP || method == QO_SR1) {
         /* bfgs.rs:27-39: H = I (the reference also keeps a second identity matrix; not needed here) */
-        s->h = (double*)calloc(nn * nn, sizeof(double));
-        for (size_t i = 0; i < n; ++i) s->h[i + i * n] = 1.0;
+        s->h = (double*)malloc(nn * nn * sizeof(double));
+        /* first touch in parallel, in blocks of four columns as the sweeps partition them: on a multi-socket host the pages of a
+         * thread's columns land on its own memory node (a single-threaded calloc + identity put all of H on one node) */
+#pragma omp parallel for num_threads(s->nthreads) schedule(static) if (s->nthreads > 1 && n >= 256)
+        for (size_t jb = 0; jb < (n + 3) / 4; ++jb)
+            for (size_t j = 4 * jb; j < n && j < 4 * jb + 4; ++j) {
+                double* hj = s->h + j * n;
+                for (size_t i = 0; i < n; ++i) hj[i] = 0.0;
+                hj[j] = 1.0;
+            }
+        s->h_symmetric = 1;
     }
     return s;
 }
@@ -461,7 +502,15 @@ const double* qo_solver_x(const qo_solver* s) { return s->x; }
 const double* qo_solver_inv_hessian(const qo_solver* s) { return s->h; }
 int qo_solver_s_norm(const qo_solver* s, double* out) { if (s->has_s_norm && out) *out = s->s_norm; return s->has_s_norm; }
 int qo_solver_y_norm(const qo_solver* s, double* out) { if (s->has_y_norm && out) *out = s->y_norm; return s->has_y_norm; }
-void qo_solver_set_inv_hessian(qo_solver* s, const double* h) { if (s->h) memcpy(s->h, h, sizeof(double) * s->n * s->n); }
+void qo_solver_set_inv_hessian(qo_solver* s, const double* h) {
+    if (!s->h) return;
+    memcpy(s->h, h, sizeof(double) * s->n * s->n);
+    s->h_symmetric = 1;
+    for (size_t i = 0; i < s->n && s->h_symmetric; ++i)
+        for (size_t j = i + 1; j < s->n; ++j)
+            if (h[i + j * s->n] != h[j + i * s->n]) { s->h_symmetric = 0; break; }
+}
+double qo_solver_bytes_streamed(const qo_solver* s) { return s->bytes_streamed; }
 
 /* has_converged: bfgs.rs:64-76 (dfp.rs identical) ; gradient_descent.rs:46-53 */
 static int has_converged(const qo_solver* s, const double* g) {
@@ -548,10 +597,17 @@ static void sr1_update_as_written(qo_solver* so, const double* s, const double* 
  *   DFP : H + c_ss s s' + c_uu u u',           c_ss = 1/(s.y), c_uu = -1/(y.u)
  * evaluated element-wise as ((H + c_su*t1) + c_ss*(s_i s_j)) + c_uu*(u_i u_j), t1 = s_i u_j + u_i s_j,
  * i.e. with commutative inner sums, so H stays bitwise symmetric.  This is the formula the HIP path uses. */
+static void solver_gemv_h(qo_solver* so, const double* x, double* y) {
+    if (so->h_symmetric && so->update_mode == QO_UPDATE_RANK2) gemv_symmetric_rows_mt(so->h, x, y, so->n, so->nthreads);
+    else gemv_colmajor_mt(so->h, x, y, so->n, so->nthreads);
+    so->bytes_streamed += 8.0 * (double)so->n * (double)so->n;
+}
+
 static void rank2_update(qo_solver* so, const double* s, const double* y) {
     const size_t n = so->n;
     double* u = so->u;
-    gemv_colmajor_mt(so->h, y, u, n, so->nthreads);
+    solver_gemv_h(so, y, u);
+    so->bytes_streamed += 16.0 * (double)n * (double)n; /* the update below reads and writes every entry */
     double ys = qo_dot(y, s, n);
     double yu = qo_dot(y, u, n);
     double c_ss, c_su, c_uu;
@@ -686,7 +742,7 @@ int qo_minimize(qo_solver* so, const qo_linesearch* ls, qo_oracle_fn oracle, voi
             newton_direction(so);
         } else {
             /* bfgs.rs:47: (-&H) * g.  Negating every H_ij first gives bit-for-bit -(H g). */
-            gemv_colmajor_mt(so->h, so->g, so->d, n, so->nthreads);
+            solver_gemv_h(so, so->g, so->d);
             if (so->lb) { /* bfgs_b.rs:72-75: P(x - H g) - x */
                 for (size_t i = 0; i < n; ++i) {
                     double t = so->x[i] - so->d[i];
@@ -762,12 +818,26 @@ int qo_quadratic_eval(void* user, const double* x, size_t n, double* f, double* 
     qo_quadratic* p = (qo_quadratic*)user;
     const double* q = p->q;
     p->calls++;
+    /* (four rows per thread in flight: one dependent-add chain per row is latency-bound; same sums, same order, per row) */
 #pragma omp parallel for num_threads(p->nthreads) schedule(static) if (p->nthreads > 1 && n >= 256)
-    for (size_t i = 0; i < n; ++i) {
-        const double* qi = q + i * n;
-        double acc = 0.0;
-        for (size_t j = 0; j < n; ++j) acc += qi[j] * x[j];
-        g[i] = acc; /* holds (Qx)_i for now */
+    for (size_t ib = 0; ib < (n + 3) / 4; ++ib) {
+        const size_t i = 4 * ib;
+        if (i + 4 <= n) {
+            const double *r0 = q + i * n, *r1 = r0 + n, *r2 = r1 + n, *r3 = r2 + n;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            for (size_t j = 0; j < n; ++j) {
+                const double xj = x[j];
+                a0 += r0[j] * xj; a1 += r1[j] * xj; a2 += r2[j] * xj; a3 += r3[j] * xj;
+            }
+            g[i] = a0; g[i + 1] = a1; g[i + 2] = a2; g[i + 3] = a3; /* holds (Qx)_i for now */
+        } else {
+            for (size_t k = i; k < n; ++k) {
+                const double* qi = q + k * n;
+                double acc = 0.0;
+                for (size_t j = 0; j < n; ++j) acc += qi[j] * x[j];
+                g[k] = acc;
+            }
+        }
     }
     double xq = qo_dot(x, g, n);
     double bx = qo_dot(p->b, x, n);
@@ -795,12 +865,14 @@ double qo_synth_u(uint64_t seed, uint64_t i, uint64_t j) {
 void qo_synth_fill_rows(double* q_rows, size_t n, size_t row0, size_t nrows, uint64_t seed,
                         const double* diag, int nthreads) {
     const double inv_n = 1.0 / (double)n;
+    /* (blocks of four rows per thread: the first touch of the pages follows the evaluation's partition) */
 #pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static) if (nthreads > 1)
-    for (size_t r = 0; r < nrows; ++r) {
-        size_t i = row0 + r;
-        double* qi = q_rows + r * n;
-        for (size_t j = 0; j < n; ++j) qi[j] = (i == j) ? diag[i] : qo_synth_u(seed, i, j) * inv_n;
-    }
+    for (size_t rb = 0; rb < (nrows + 3) / 4; ++rb)
+        for (size_t r = 4 * rb; r < nrows && r < 4 * rb + 4; ++r) {
+            size_t i = row0 + r;
+            double* qi = q_rows + r * n;
+            for (size_t j = 0; j < n; ++j) qi[j] = (i == j) ? diag[i] : qo_synth_u(seed, i, j) * inv_n;
+        }
 }
 
 /* f = log sum_i exp(a_i'x + c_i) + mu/2 x'x ; g = A' softmax(Ax + c) + mu x (max-shifted) */

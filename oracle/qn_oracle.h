@@ -117,6 +117,7 @@ size_t qo_solver_n(const qo_solver* s);
 size_t qo_solver_k(const qo_solver* s);
 const double* qo_solver_x(const qo_solver* s);
 const double* qo_solver_inv_hessian(const qo_solver* s); /* column-major n x n, NULL for gradient descent */
+double qo_solver_bytes_streamed(const qo_solver* s);    /* matrix bytes the solver's own sweeps moved so far (mat-vecs with H: 8 n^2 each, the rank-2 update: 16 n^2) */
 int qo_solver_s_norm(const qo_solver* s, double* out);   /* returns 0 for Option::None */
 int qo_solver_y_norm(const qo_solver* s, double* out);
 void qo_solver_set_inv_hessian(qo_solver* s, const double* h_colmajor);

@@ -87,6 +87,8 @@ def lib():
     L.qo_solver_x.restype = dp
     L.qo_solver_x.argtypes = [C.c_void_p]
     L.qo_solver_inv_hessian.restype = dp
+    L.qo_solver_bytes_streamed.restype = C.c_double
+    L.qo_solver_bytes_streamed.argtypes = [C.c_void_p]
     L.qo_solver_inv_hessian.argtypes = [C.c_void_p]
     L.qo_solver_s_norm.restype = C.c_int
     L.qo_solver_s_norm.argtypes = [C.c_void_p, dp]
@@ -341,6 +343,11 @@ class Solver:
     @property
     def k(self):
         return lib().qo_solver_k(self.h)
+
+    @property
+    def bytes_streamed(self):
+        """matrix bytes the solver's own sweeps have moved (mat-vecs with H, the rank-2 update); the objective counts its calls"""
+        return lib().qo_solver_bytes_streamed(self.h)
 
     @property
     def approx_inv_hessian(self):

@@ -9,8 +9,8 @@ import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d.get('roofline')
 line='%.1f it/s  %.2f us' % (d['value'], 1e3*d['ms_per_step'])
 if r:
-    q=r['quad_matvec']
-    line+=' | eval %.2f vec %.2f hpass %.2f hreduce %.2f us' % (1e3*q['avg_launch_ms'], 1e3*(q['accept_reduce_avg_launch_ms'] or 0), 1e3*r['avg_launch_ms'], 1e3*((r['pass_with_reduce'] or {}).get('reduce_avg_launch_ms') or 0))
+    q=r['quad_matvec']; u=r['update_pass']
+    line+=' | eval %.2f vec %.2f hpass %.2f hreduce %.2f us' % (1e3*q['avg_launch_ms'], 1e3*(q['accept_reduce_avg_launch_ms'] or 0), 1e3*u['avg_launch_ms'], 1e3*((u['pass_with_reduce'] or {}).get('reduce_avg_launch_ms') or 0))
 print(line)")
     echo "$lib $v"
   done

@@ -9,12 +9,20 @@ import __graft_entry__ as ge
 qn = ge.load_package()
 n = m = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+# argv[3]: scale of A's entries (x 1/sqrt(n)); argv[4]: scale of x0.  The default instance (2, 1) is the round-1/2 one: t = 1 is
+# accepted almost every iteration there (1.05 evaluations per iteration).  `30 3` is the instance that SEARCHES: a sharper softmax
+# and a far start, More-Thuente interpolates (cases 1-3), > 1.5 evaluations per iteration.
+a_scale = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0
+x_scale = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+h0_scale = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0  # argv[5]: initial inverse Hessian h0 * I (default: the reference's I)
 rng = np.random.default_rng(11)
-a = rng.standard_normal((m, n)) * (2.0 / np.sqrt(n))
+a = rng.standard_normal((m, n)) * (a_scale / np.sqrt(n))
 c = rng.standard_normal(m)
-x0 = rng.standard_normal(n)
+x0 = rng.standard_normal(n) * x_scale
 obj = qn.LogSumExp(a, c, 0.1)
 s = qn.DFP(1e-10, x0)
+if h0_scale != 1.0:
+    s.set_approx_inv_hessian_scaled_identity(h0_scale) if hasattr(s, "set_approx_inv_hessian_scaled_identity") else s.set_approx_inv_hessian(h0_scale * np.eye(n))
 def run(k):
     try:
         s.minimize(qn.MoreThuente(), obj, k, 20)
@@ -25,9 +33,18 @@ qn.default_context().synchronize()
 st0 = s.stats(); t0 = time.perf_counter()
 two_pass = os.environ.get("QN_LSE_TWO_PASS", "0") not in ("", "0") or n > 16384
 a_bytes = (16.0 if two_pass else 8.0) * m * n
+s.set_trace(iters, with_x=False)
 run(iters)
 qn.default_context().synchronize()
 dt = time.perf_counter() - t0; st1 = s.stats()
+tr, _ = s.trace()
+digits = [0] * 5
+for r in tr:
+    v, k = r["ls_cases"] & ~(1 << 30), 0
+    while v:
+        digits[v & 7] += 1; v >>= 3; k += 1
+    digits[0] += 1  # (the accepting trial is pushed as digit 0: count iterations)
+s.set_trace(0, with_x=False)
 s.set_profiling(True); p0 = s.stats(); run(8); p1 = s.stats(); s.set_profiling(False)
 n_h = p1["n_hpass_timed"] - p0["n_hpass_timed"]; t_h = p1["t_hpass_ms"] - p0["t_hpass_ms"]
 evals = st1["total_oracle_evals"] - st0["total_oracle_evals"]  # cumulative counters (the per-call ones restart with every minimize)
@@ -38,7 +55,9 @@ ev_ms = []
 for _ in range(5):
     qn.default_context().synchronize(); t1 = time.perf_counter(); obj(x0); qn.default_context().synchronize(); ev_ms.append((time.perf_counter() - t1) * 1e3)
 ev = sorted(ev_ms)[len(ev_ms) // 2]
-out = {"config": f"DFP + MoreThuente, n=m={n} log-sum-exp (mu=0.1), f64, 1xMI355X (BASELINE.json config 5 runs it on 4)",
+out = {"config": f"DFP + MoreThuente, n=m={n} log-sum-exp (mu=0.1, A ~ N(0, ({a_scale:g}/sqrt n)^2), x0 ~ {x_scale:g} N(0, 1), H0 = {h0_scale:g} I), f64, 1xMI355X (BASELINE.json config 5 runs it on 4)",
+       "line_search": {"iterations_traced": len(tr), "more_thuente_cases_1_to_4": digits[1:], "modified_updating_switch_thrown": sum(1 for r in tr if r["ls_cases"] & (1 << 30)),
+                       "trial_steps_per_iteration": sum(r["ls_iters"] for r in tr) / max(len(tr), 1)},
        "iterations_per_s": iters / dt, "ms_per_iteration": 1e3 * dt / iters, "oracle_evals_per_iteration": evals / iters,
        "h_pass": {"avg_launch_ms": h_ms, "algorithmic_bytes": 2.0 * p1["matrix_bytes_per_pass"],
                   "layout": "upper block triangle of H (128 x 128 tiles)" if p1["matrix_bytes_per_pass"] < 8.0 * n * n else "full row-major",

@@ -7,6 +7,6 @@ for path in sys.argv[1:]:
   print("timing", d.get("timing"))
   print("accounting", d.get("iteration_accounting"))
   r = d.get("roofline") or {}
-  print("roofline", {k: r.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches_timed", "pass_with_reduce", "traffic")})
-  print("eval", r.get("quad_matvec")); print("ctl", r.get("ctl_step"))
+  print("roofline", {k: r.get(k) for k in ("kernel", "time_share", "achieved", "frac", "avg_launch_ms", "launches_timed", "traffic", "all_kernels_time_weighted")})
+  print("update_pass", r.get("update_pass")); print("eval", r.get("quad_matvec")); print("ctl", r.get("ctl_step"))
   if "cpu_baseline" in d: print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["sample"])
