@@ -76,24 +76,29 @@ def cpu_baseline(n, iters):
     threads = qo.max_threads()
     diag, b, x0 = synth_inputs(n)
     q = qo.synth_rows(n, 0, n, SEED, diag, nthreads=threads)
-    s = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=threads)
     o = qo.QuadraticOracle(q, b, nthreads=threads)
-    t0 = time.perf_counter()
-    s.minimize(qo.morethuente(), o, 3, 20)  # warm the caches / thread pool, and size the sample
-    rate = 3.0 / max(time.perf_counter() - t0, 1e-6)
-    iters = int(min(max(iters, 12.0 * rate), 250))  # ~10-15 s of CPU work, well inside the pre-convergence window
-    bytes0, calls0 = s.bytes_streamed, o.calls
-    t0 = time.perf_counter()
-    s.minimize(qo.morethuente(), o, iters, 20)  # warm restart: continues from the warmed-up state
-    dt = time.perf_counter() - t0
-    k = s.k
-    moved = (s.bytes_streamed - bytes0) + (o.calls - calls0) * 8.0 * n * n
+    # ~10 s of CPU work.  One run stays inside the pre-convergence window (the restatement needs ~350 iterations on this family;
+    # past convergence y's -> 0 and the timings mean nothing), so the sample is a series of runs of `per_run` iterations, each
+    # from (x0, H = I) after 3 untimed iterations -- the GPU leg's protocol.  Solver creation is not timed.
+    per_run = int(min(max(iters, 30), 250))
+    k, dt, moved, runs = 0, 0.0, 0.0, 0
+    while dt < 10.0 and runs < 200:
+        s = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=threads)
+        s.minimize(qo.morethuente(), o, 3, 20)  # warm the caches / thread pool
+        bytes0, calls0 = s.bytes_streamed, o.calls
+        t0 = time.perf_counter()
+        s.minimize(qo.morethuente(), o, per_run, 20)  # warm restart: continues from the warmed-up state
+        dt += time.perf_counter() - t0
+        k += s.k
+        moved += (s.bytes_streamed - bytes0) + (o.calls - calls0) * 8.0 * n * n
+        runs += 1
+        del s
     out = {"value": k / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
            "achieved_GBs": moved / dt / 1e9, "bytes_per_iteration": moved / max(k, 1),
            "bytes_note": "matrix bytes the port streams: 8 n^2 per oracle call (full Q by rows), 8 n^2 per mat-vec with H (u = H y, "
                          "d = -H g), 16 n^2 for the rank-2 update",
-           "sample": f"{k} BFGS+MoreThuente iterations at n={n} (same Q, b, x0 as the GPU run), rank-2 O(n^2) update, "
-                     f"reference oracle-call sequence (5 calls per iteration), OpenMP x{threads}, {dt:.1f} s"}
+           "sample": f"{k} BFGS+MoreThuente iterations at n={n} in {runs} runs of {per_run} from (x0, H = I) (same Q, b, x0 as the GPU run), "
+                     f"rank-2 O(n^2) update, reference oracle-call sequence (5 calls per iteration), OpenMP x{threads}, {dt:.1f} s"}
     # the reference's own formulation (dense n x n products, single thread as matrixmultiply is built) at a size it finishes
     n_small = 384
     d2, b2, x2 = synth_inputs(n_small)
@@ -378,7 +383,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, 30 if n <= 4096 else 4)
+            out["cpu_baseline"] = cpu_baseline(n, 200 if n <= 4096 else 4)
         if world > 1 and not args.no_scaling_ref:
             # strong-scaling denominator: the SAME workload unsharded on rank 0's GPU alone (N = 1 of the default run
             # is configs[1], a different problem size, so value(N)/value(1) across default runs is not an efficiency)
