@@ -266,6 +266,12 @@ __device__ __forceinline__ void qn_s2_ctl_out(const QnS2Args& a, const QnS2Lds& 
 }
 
 // the evaluation request as the tile and the accept-reduce kernels decode it
+// (the request's scalars are the same in every lane: pinned into scalar registers -- as vector registers the row loops' register
+// pressure pushed them out to scratch memory, three 16-byte reloads in front of every item)
+__device__ __forceinline__ double qn_uniform(const double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <bool PIN>
 __device__ __forceinline__ QnEvalReq qn_s2_eval_req(const QnCtl& c, bool last_eval) {
     QnEvalReq q;
     q.is_t = (last_eval ? c.ev_kind : c.req_kind) == QN_REQ_T;
@@ -273,6 +279,13 @@ __device__ __forceinline__ QnEvalReq qn_s2_eval_req(const QnCtl& c, bool last_ev
     q.mode = c.dir_mode;
     q.c_ss = c.c_ss; q.c_su = c.c_su; q.c_uu = c.c_uu; q.ug = c.dir_ug; q.sg = c.dir_sg;
     q.xc = c.xc; q.sc = c.sc;
+    if (PIN) { // (the tile kernel; the accept-reduce has registers to spare and only pays the readfirstlane latency)
+        q.is_t = __builtin_amdgcn_readfirstlane(q.is_t) != 0;
+        q.t = qn_uniform(q.t);
+        q.mode = __builtin_amdgcn_readfirstlane(q.mode);
+        q.c_ss = qn_uniform(q.c_ss); q.c_su = qn_uniform(q.c_su); q.c_uu = qn_uniform(q.c_uu); q.ug = qn_uniform(q.ug); q.sg = qn_uniform(q.sg);
+        q.xc = __builtin_amdgcn_readfirstlane(q.xc); q.sc = __builtin_amdgcn_readfirstlane(q.sc);
+    }
     return q;
 }
 
@@ -352,12 +365,25 @@ __device__ __forceinline__ void qn_s2_eval_vec_load(const QnS2Args& a, const dou
     v.x_c = ld2(x + jc); v.v_c = ld2(a.F.VV + jc); v.s_c = ld2(sp + jc); v.u_c = ld2(a.F.UN + jc);
 }
 
-// One item of the evaluation: the wave's 16 rows against the trial point, folded.  Leaves the column part of the wave's rows
-// in colred_w[128] and the wave's six scalar sums in sred_w[8] (LDS, exchanged by the caller after ONE workgroup barrier for
-// a pair of items) and returns the row total this lane owns (lanes with (lane & 3) == 0: row lane >> 2 of the wave's 16).
+// One item of the evaluation: the wave's 16 rows against the trial point, folded.
+// CONDITIONING (round 3).  f = 1/2 xt'Q xt - b'xt and g(xt)'d = d'Q xt - b'd are what the line search reads.  Round 2 summed
+// xt'Q xt, b'xt, d'Q xt and b'd separately and subtracted the totals: each pair is a difference of two sums of size ~ ||b|| ||d||
+// whose value is ~ ||g|| ||d||, i.e. a loss of ||b|| / ||g|| in relative accuracy that the reference -- which forms g = Q x - b
+// entry by entry and only then the dot product (bfgs.rs:98, line_search/mod.rs:35,47) -- does not have.  The 60-digit pin of
+// tests/golden/mt_exact_n1024.json measured it: 1.3e-10 from the truth where the f64 restatement is 5.9e-14 (workload
+// "case2_mod", ||g_k|| / ||b|| ~ 1e-5).  Now, on a DIAGONAL item, the lane that owns the diagonal entry of row i subtracts b_i
+// (2 b_i for f) from its partial row sum before the multiplication by d_i (x_i): for a diagonally dominant Q -- the benchmark
+// family, and any well-scaled SPD problem -- that partial is Q_ii xt_i + one neighbour, i.e. ~ b_i, and the cancellation happens
+// there, entry by entry, as in the reference.  The workgroup's sums are then x'(Q xt - 2 b) and d'(Q xt - b) outright; the
+// columns for b'xt and b'd stay in the table (zero) so that the state machine's formulas are unchanged.
 // FROM_PARK: the rows come from the LDS copy parked during the prologue; otherwise from the register window, each register
 // refilled with the same row of the item at `refill` the moment it is consumed (rstride 0: nothing follows, every lane re-reads
 // one 16-byte word -- a single request per instruction).
+// Leaves the column part of the wave's rows in colred_w[128] and the wave's scalar sums in sred_w[8] (LDS, exchanged by the
+// caller after ONE workgroup barrier for a group of items) and returns the row total this lane owns (lanes with (lane & 3) == 0:
+// row lane >> 2 of the wave's 16).
+// (`diag` is a run-time, wave-uniform flag on purpose: a second instantiation of the row loops per call site made the kernel's code
+// 30 % larger, and every OTHER kernel of the iteration started ~1 us later -- rocprofv3 averages, same box: instruction fetch.)
 template <bool FROM_PARK>
 __device__ __forceinline__ double qn_s2_eval_item(const QnEvalReq& q, const QnS2EvalVec& v, const bool diag, const int lane, const int wave,
                                                   v2d (&h)[QN_S2_RPW], const v2d* __restrict__ parkw, const double* __restrict__ refill, const size_t rstride,
@@ -365,8 +391,8 @@ __device__ __forceinline__ double qn_s2_eval_item(const QnEvalReq& q, const QnS2
     // row side: lane l holds row 16 w + (l & 15) of the tile; column side: this lane's two columns
     double dr;
     const double xr = qn_s2_trial(q, v.x_r, v.v_r, v.s_r, v.u_r, dr);
-    double p1 = 0.0, p3 = 0.0, p4 = 0.0, p5 = 0.0; // diagonal items: b'xt, b'd, g'd, #non-finite d over block I (lanes 0..15 of every wave)
-    if (diag && lane < 16) { p1 = v.b_r * xr; p3 = v.b_r * dr; p4 = v.g_r * dr; p5 = isfinite(dr) ? 0.0 : 1.0; }
+    double p4 = 0.0, p5 = 0.0; // diagonal items: g'd, #non-finite d over block I (lanes 0..15 of every wave)
+    if (diag && lane < 16) { p4 = v.g_r * dr; p5 = isfinite(dr) ? 0.0 : 1.0; }
     v2d xtj, dj;
     {
         double d0, d1;
@@ -377,6 +403,11 @@ __device__ __forceinline__ double qn_s2_eval_item(const QnEvalReq& q, const QnS2
     if (!qn_s2_row_on(diag, lane, wave)) { xtj = (v2d){0.0, 0.0}; dj = (v2d){0.0, 0.0}; }
     double cx = 0.0, cy = 0.0, pf = 0.0, pg = 0.0;
     double racc[QN_S2_RPW];
+    // lane 8 w + k holds the diagonal entries of the wave's rows 2 k and 2 k + 1: it fetches their b once (a per-row broadcast
+    // through scalar registers cost the row loop its registers)
+    const int dl = lane - 8 * wave;
+    double b_lo = 0.0, b_hi = 0.0;
+    if (diag) { b_lo = __shfl(v.b_r, (2 * dl) & 15); b_hi = __shfl(v.b_r, (2 * dl + 1) & 15); }
 #pragma unroll
     for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
         v2d hv;
@@ -388,8 +419,10 @@ __device__ __forceinline__ double qn_s2_eval_item(const QnEvalReq& q, const QnS2
         racc[r] = t0;
         cx = __builtin_fma(hv.x, xi, cx);
         cy = __builtin_fma(hv.y, xi, cy);
-        pf = __builtin_fma(xi, t0, pf);
-        pg = __builtin_fma(di, t0, pg);
+        // the lane that holds Q_ii (column 16 w + r of a diagonal tile): b_i leaves here, against Q_ii xt_i (b_lo = b_hi = 0 otherwise)
+        const double bsel = (dl == (r >> 1)) ? ((r & 1) ? b_hi : b_lo) : 0.0;
+        pf = __builtin_fma(xi, t0 - (bsel + bsel), pf);
+        pg = __builtin_fma(di, t0 - bsel, pg);
     }
     if (!qn_s2_col_on(diag, lane, wave)) { cx = 0.0; cy = 0.0; }
     pf = __builtin_fma(xtj.x, cx, pf); pf = __builtin_fma(xtj.y, cy, pf); // xt_J'(column part): the mirrored half of xt'Q xt
@@ -397,14 +430,13 @@ __device__ __forceinline__ double qn_s2_eval_item(const QnEvalReq& q, const QnS2
     colred_w[2 * lane] = cx;
     colred_w[2 * lane + 1] = cy;
     {
-        double sv[8] = {pf, pg, p1, p3, p4, p5, 0.0, 0.0};
+        double sv[8] = {pf, pg, 0.0, 0.0, p4, p5, 0.0, 0.0};
         QnWaveFold<8, 32>::run(sv, lane);
         if ((lane & 7) == 0) sred_w[lane >> 3] = sv[0];
     }
     QnWaveFold<QN_S2_RPW, 32>::run(racc, lane); // lanes with (lane & 3) == 0 hold the total of row lane >> 2
     return racc[0];
 }
-
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
     __shared__ double colsum[3][QN_TB];
@@ -472,14 +504,15 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
     QN_S2_STAMP(2);
-    const QnEvalReq q = qn_s2_eval_req(L.c, false);
+    const QnEvalReq q = qn_s2_eval_req<true>(L.c, false);
     const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
     const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
     if (q.xc) { va.x_r = v1.x_r; va.x_c = v1.x_c; }
     if (q.sc) { va.s_r = v1.s_r; va.s_c = v1.s_c; }
-    double wg[QN_S2_NSE]; // thread 0: this workgroup's running totals (items in list order)
-#pragma unroll
-    for (int k = 0; k < QN_S2_NSE; ++k) wg[k] = 0.0;
+    // threads 0..5: this workgroup's running total of scalar k (items in list order; waves in order inside an item).  One
+    // register pair per thread -- thread 0 holding all six cost the row loops twelve registers -- and six short chains of LDS
+    // reads instead of one long one at the end of the launch.
+    double wgk = 0.0;
     // Items are taken in GROUPS of two -- three when an odd item is left at the end of the list: the rows of all of them are
     // consumed and folded back to back, then ONE exchange through LDS, one barrier and one set of slot stores serves the group
     // (round 2 did all of that per item: 2-3 us of fold / barrier / store latency each, with every byte already on chip).  The
@@ -496,24 +529,25 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         if (has_b && it + 2 < a.maxk) ijc = a.item_ij[(size_t)(it + 2) * a.G + blockIdx.x];
         if (ijc >= 0 && it + 3 < a.maxk) ijd = a.item_ij[(size_t)(it + 3) * a.G + blockIdx.x];
         const bool take_c = ijc >= 0 && ijd < 0; // the last, odd item joins this group
-        const double* qb_ = has_b ? a.Q + (size_t)(Ib * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jb * QN_TB + qn_s2_col(diag_b, lane, wave)
-                                  : a.Q + (size_t)(Ia * QN_TB + wave * QN_S2_RPW) * np + (size_t)Ja * QN_TB + qn_s2_col(diag_a, lane, wave);
         const int Ic = ijc >> 16, Jc = ijc & 0xffff;
         const bool diag_c = take_c && Ic == Jc;
-        const double* qc_ = ijc >= 0 ? a.Q + (size_t)(Ic * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jc * QN_TB + qn_s2_col(Ic == Jc, lane, wave) : qb_;
-        const int Id = ijd >> 16, Jd = ijd & 0xffff;
-        const double* qd_ = ijd >= 0 ? a.Q + (size_t)(Id * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jd * QN_TB + qn_s2_col(Id == Jd, lane, wave) : qc_;
+        // (each refill address is formed right in front of the item that uses it: three address pairs held across the items cost
+        // registers the row loops need)
+        auto tile_ptr = [&](int ij_) {
+            const int I_ = ij_ >> 16, J_ = ij_ & 0xffff;
+            return a.Q + (size_t)(I_ * QN_TB + wave * QN_S2_RPW) * np + (size_t)J_ * QN_TB + qn_s2_col(I_ == J_, lane, wave);
+        };
         double row_a, row_b = 0.0, row_c = 0.0;
         if (parked && it == 0) row_a = qn_s2_eval_item<true>(q, va, diag_a, lane, wave, h, &park[wave][0][0], nullptr, 0, colred[0][wave], sred[0][wave]);
-        else row_a = qn_s2_eval_item<false>(q, va, diag_a, lane, wave, h, nullptr, qb_, has_b ? np : 0, colred[0][wave], sred[0][wave]);
+        else row_a = qn_s2_eval_item<false>(q, va, diag_a, lane, wave, h, nullptr, tile_ptr(has_b ? ijb : ija), has_b ? np : 0, colred[0][wave], sred[0][wave]);
         if (has_b) {
             qn_s2_eval_vec_load(a, x, sp, Ib * QN_TB + wave * QN_S2_RPW + (lane & 15), Jb * QN_TB + 2 * lane, vb);
-            row_b = qn_s2_eval_item<false>(q, vb, diag_b, lane, wave, h, nullptr, qc_, ijc >= 0 ? np : 0, colred[1][wave], sred[1][wave]);
+            row_b = qn_s2_eval_item<false>(q, vb, diag_b, lane, wave, h, nullptr, tile_ptr(ijc >= 0 ? ijc : ijb), ijc >= 0 ? np : 0, colred[1][wave], sred[1][wave]);
         }
         // the next item's vector entries go out now: for the item that joins this group, or for the next group while this
         // one's sums are exchanged and stored
         if (ijc >= 0) qn_s2_eval_vec_load(a, x, sp, Ic * QN_TB + wave * QN_S2_RPW + (lane & 15), Jc * QN_TB + 2 * lane, va);
-        if (take_c) row_c = qn_s2_eval_item<false>(q, va, diag_c, lane, wave, h, nullptr, qd_, 0, colred[2][wave], sred[2][wave]);
+        if (take_c) row_c = qn_s2_eval_item<false>(q, va, diag_c, lane, wave, h, nullptr, tile_ptr(ijc), 0, colred[2][wave], sred[2][wave]);
         if (it == 0) { qn_keepalive(row_a); qn_keepalive(row_b); qn_keepalive(row_c); QN_S2_STAMP(3); }
         __syncthreads();
         if (it == 0) QN_S2_STAMP(4);
@@ -529,19 +563,12 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
                 else a.part[(((size_t)Je * a.nb + Ie) * 2 + 0) * QN_TB + cidx] = acc;
             }
         }
-        if (tid == 0) { // (items in list order: a, b, c)
+        if (tid < QN_S2_NSE) { // (items in list order: a, b, c; scalars 2..5 exist on diagonal items only)
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
-                if (e == 0 || (e == 1 && has_b) || (e == 2 && take_c)) {
-                    wg[0] = wg[0] + qn_s2_wave_total(sred[e], 0);
-                    wg[2] = wg[2] + qn_s2_wave_total(sred[e], 1);
-                    if (e == 0 ? diag_a : (e == 1 ? diag_b : diag_c)) {
-                        wg[1] = wg[1] + qn_s2_wave_total(sred[e], 2);
-                        wg[3] = wg[3] + qn_s2_wave_total(sred[e], 3);
-                        wg[4] = wg[4] + qn_s2_wave_total(sred[e], 4);
-                        wg[5] = wg[5] + qn_s2_wave_total(sred[e], 5);
-                    }
-                }
+                const bool have = e == 0 || (e == 1 && has_b) || (e == 2 && take_c);
+                const bool dg = e == 0 ? diag_a : (e == 1 ? diag_b : diag_c);
+                if (have && (tid < 2 || dg)) wgk = wgk + qn_s2_wave_total(sred[e], tid);
             }
         }
         if (diag_a || diag_b || diag_c) __syncthreads(); // (uniform)
@@ -567,10 +594,9 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         __syncthreads(); // colred / colsum / sred are rewritten by the next group
     }
     QN_S2_STAMP(15);
-    if (tid == 0) {
-        double* out = a.wgS + (size_t)a.parity * a.trows * QN_S2_ROW + blockIdx.x;
-#pragma unroll
-        for (int k = 0; k < QN_S2_NSE; ++k) out[(size_t)k * a.trows] = wg[k];
+    if (tid < QN_S2_NSE) { // sred column -> table column: xt'(Q xt - 2b), d'(Q xt - b), (b'xt = 0), (b'd = 0), g'd, #non-finite d
+        const int col = tid == 1 ? 2 : (tid == 2 ? 1 : tid);
+        a.wgS[((size_t)a.parity * QN_S2_ROW + col) * a.trows + blockIdx.x] = wgk;
     }
 }
 
@@ -623,7 +649,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
     const size_t np = (size_t)a.np;
-    const QnEvalReq q = qn_s2_eval_req(L.c, true);
+    const QnEvalReq q = qn_s2_eval_req<false>(L.c, true);
     const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
     double* __restrict__ xt = a.F.X0 + (size_t)(1 - q.xc) * np;
     const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
