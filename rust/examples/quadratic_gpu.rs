@@ -22,7 +22,7 @@ fn main() {
     let mut ls = GpuMoreThuente::default();
     let mut seen = 0usize;
     let mut on_iteration = |s: &GpuBFGS| seen = *s.k();
-    solver.minimize(&mut ls, f_and_g, max_iter_solver, max_iter_line_search, Some(&mut on_iteration)).unwrap();
+    solver.minimize_on_device(&mut ls, f_and_g, max_iter_solver, max_iter_line_search, Some(&mut on_iteration)).unwrap();
     println!("closure on the host : k = {}, ||g|| = {:e}", solver.k(), f_and_g(solver.x()).g().norm());
     assert_eq!(seen, *solver.k());
 
@@ -32,9 +32,15 @@ fn main() {
     solver2.minimize_objective(&mut ls, &objective, max_iter_solver, max_iter_line_search).unwrap();
     println!("objective on device : k = {}, f = {:e}", solver2.k(), objective.eval(solver2.x()).unwrap().f());
 
-    // 3. the reference's template loop (ls_solver.rs:66-111) through the trait: H g and the secant update on the GPU
-    let mut solver3 = GpuBFGS::new(tol, x0);
-    LineSearchSolver::minimize(&mut solver3, &mut ls, f_and_g, max_iter_solver, max_iter_line_search, None).unwrap();
+    // 3. the reference's template loop (ls_solver.rs:66-111) through the trait: H g and the secant update on the GPU.
+    //    `solver.minimize(..)` IS the trait method (no inherent method of that name), so a reference call site compiles unchanged
+    //    -- with a GPU line search, or with the reference's own `MoreThuente` running on the host:
+    let mut solver3 = GpuBFGS::new(tol, x0.clone());
+    solver3.minimize(&mut ls, f_and_g, max_iter_solver, max_iter_line_search, None).unwrap();
     println!("trait hooks         : k = {}", LineSearchSolver::k(&solver3));
     assert!((solver.x() - solver3.x()).norm() <= 1e-9);
+    let mut solver4 = GpuBFGS::new(tol, x0);
+    let mut reference_ls = optimization_solvers::MoreThuente::default();
+    solver4.minimize(&mut reference_ls, f_and_g, max_iter_solver, max_iter_line_search, None).unwrap();
+    assert!((solver.x() - solver4.x()).norm() <= 1e-9);
 }

@@ -7,11 +7,13 @@
 //!
 //! Two ways in, both with the reference's names and signatures:
 //!
-//! * **the whole loop on the device** -- `GpuBFGS::minimize(&mut ls, oracle, max_iter_solver, max_iter_line_search, callback)`
-//!   is an inherent method with the signature of `LineSearchSolver::minimize` (ls_solver.rs:66-111), so `solver.minimize(..)`
-//!   call sites compile unchanged and resolve to it.  One `qn_minimize` call runs every iteration; the closure is called
-//!   through a trampoline in exactly the reference's order.  `minimize_objective` takes a device-resident objective instead
-//!   (no host round trip at all: the benchmark path).
+//! * **the whole loop on the device** -- `GpuBFGS::minimize_on_device(&mut ls, oracle, max_iter_solver, max_iter_line_search,
+//!   callback)` has the argument list of `LineSearchSolver::minimize` (ls_solver.rs:66-111) and takes a GPU line search.  One
+//!   `qn_minimize` call runs every iteration; the closure is called through a trampoline in exactly the reference's order.
+//!   `minimize_objective` takes a device-resident objective instead (no host round trip at all: the benchmark path).
+//!   (It is NOT called `minimize`: an inherent method of that name would shadow the trait's for every call site, including
+//!   those that pass the reference's own `MoreThuente` / `BackTracking`, which are not GPU line searches -- a compile error
+//!   where a fall-back was meant.  `solver.minimize(..)` therefore always means the trait method below.)
 //! * **hook by hook** -- `impl ComputeDirection` / `impl LineSearchSolver` provide `compute_direction`, `has_converged`,
 //!   `update_next_iterate`, `xk`, `k`, ... so generic code written against the traits (`fn run<S: LineSearchSolver>(..)`)
 //!   drives the reference's own template loop with the matrix work (H g, the secant update) on the GPU, and
@@ -392,11 +394,16 @@ macro_rules! gpu_solver {
                 &self.core.tol
             }
 
-            /// `LineSearchSolver::minimize` (ls_solver.rs:66-111), the whole loop in ONE `qn_minimize` call.  Same signature
-            /// as the trait method (inherent methods win method resolution, so `solver.minimize(..)` call sites pick this
-            /// one whenever the line search is a GPU one); the closure is called in exactly the reference's order: loop top
-            /// (:79), every line-search evaluation, the gradient at the accepted point (bfgs.rs:98).
-            pub fn minimize<LS: GpuLineSearch>(
+            /// `LineSearchSolver::minimize` (ls_solver.rs:66-111), the whole loop in ONE `qn_minimize` call.  Same argument
+            /// list as the trait method, but under ANOTHER NAME on purpose: Rust resolves `solver.minimize(..)` to an
+            /// inherent method of that name before it looks at traits, so an inherent `minimize<LS: GpuLineSearch>` would have
+            /// turned every call site that passes one of the reference's own line searches (`MoreThuente`, `BackTracking`:
+            /// not `GpuLineSearch`) into a compile error instead of a fall-back.  As it is, `solver.minimize(..)` is the
+            /// trait's default method for ANY `LS: LineSearch` (hook by hook through the ABI, see `impl LineSearchSolver`
+            /// below), and `solver.minimize_on_device(..)` is the fast path for the GPU line searches.  The closure is
+            /// called in exactly the reference's order: loop top (:79), every line-search evaluation, the gradient at the
+            /// accepted point (bfgs.rs:98).
+            pub fn minimize_on_device<LS: GpuLineSearch>(
                 &mut self,
                 line_search: &mut LS,
                 mut oracle: impl FnMut(&DVector<Floating>) -> FuncEvalMultivariate,
