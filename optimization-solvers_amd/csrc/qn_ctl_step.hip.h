@@ -56,6 +56,11 @@ __device__ __forceinline__ bool qn_check_is_scalar(const QnCtl& c) {
 // A state function returns false when the state needs all threads (the caller leaves the scalar run).
 // `side_effects`: false in all but one of the workgroups that run the machine redundantly (qn_sym2.hip.h): no trace stores.
 
+// LEAN: the instantiation for the fused symmetric path (qn_sym2.hip.h), where the host has already excluded n <= 5, Newton,
+// gradient descent, bounded solvers / line searches, callbacks and qn_compute_step_len (minimize_impl: `r.fused`): the branches for
+// those are compiled out.  Same decisions on that path by construction; about half the code -- and the machine is inlined into
+// every kernel of an iteration, where code size is instruction-fetch time behind the kernel's data burst.
+template <bool LEAN>
 __device__ __forceinline__ void qn_st_begin(QnCtl& c) { // ls_solver.rs:74-76: only k is reset
     c.k = 0;
     // A fresh call evaluates the oracle at x_k and forms d = -H g from scratch (ls_solver.rs:79, bfgs.rs:47).  When it
@@ -68,6 +73,7 @@ __device__ __forceinline__ void qn_st_begin(QnCtl& c) { // ls_solver.rs:74-76: o
     c.state = QN_ST_LOOP_TOP;
 }
 
+template <bool LEAN>
 __device__ __forceinline__ void qn_st_loop_top(QnCtl& c) { // ls_solver.rs:78-79
     if (!(c.max_iter > c.k)) {
         c.status = 1; // MaxIterReached, ls_solver.rs:109-110
@@ -87,8 +93,9 @@ __device__ __forceinline__ void qn_st_loop_top(QnCtl& c) { // ls_solver.rs:78-79
     }
 }
 
+template <bool LEAN>
 __device__ __forceinline__ bool qn_st_after_evalx(QnCtl& c) {
-    if (!c.fused) return false;
+    if (!LEAN && !c.fused) return false;
     c.f_k = c.f_e; // g <- gt is committed by the direction pass (h_pass row-block 0)
     c.gg = c.st_gg; c.gg_valid = 1;
     c.have_cur_eval = c.memoize;
@@ -97,8 +104,9 @@ __device__ __forceinline__ bool qn_st_after_evalx(QnCtl& c) {
     return true;
 }
 
+template <bool LEAN>
 __device__ __forceinline__ bool qn_st_after_dir(QnCtl& c) {
-    if (!c.fused) return false;
+    if (!LEAN && !c.fused) return false;
     c.n_hpasses++;
     if (c.pending) c.n_hpass_rw++;
     c.pending = 0;
@@ -108,8 +116,9 @@ __device__ __forceinline__ bool qn_st_after_dir(QnCtl& c) {
     return true;
 }
 
+template <bool LEAN>
 __device__ __forceinline__ bool qn_st_after_next(QnCtl& c) { // bfgs.rs:94-102 from the sums staged by the accepted evaluation
-    if (!c.fused) return false;
+    if (!LEAN && !c.fused) return false;
     c.s_norm = sqrt(c.st_ss); c.has_s_norm = 1;
     c.y_norm = sqrt(c.st_yy); c.has_y_norm = 1;
     c.ys = c.st_ys;
@@ -125,7 +134,7 @@ __device__ __forceinline__ bool qn_st_after_next(QnCtl& c) { // bfgs.rs:94-102 f
         c.hp_lazy = 1; c.hp_nrhs = 2;
         const double fk = c.f_k;
         const bool will_continue = (c.k + 1 < c.max_iter) && !(isnan(fk) || isinf(fk)) && !(sqrt(c.gg) < c.tol);
-        if (will_continue && !c.callback_mode && !c.no_defer && !c.sym2) { // (sym2: every step is a prologue, nothing to save)
+        if (!LEAN && will_continue && !c.callback_mode && !c.no_defer && !c.sym2) { // (sym2: every step is a prologue, nothing to save)
             // Deferred update: everything the step after the H pass would decide is already known except the
             // update's coefficients (they need y.u, u.g+, s.g+ from the pass).  Run the rest of the iteration
             // bookkeeping now; the next evaluation request becomes QN_PH_REQ_HPASS_EVAL, its kernel derives the
@@ -142,8 +151,9 @@ __device__ __forceinline__ bool qn_st_after_next(QnCtl& c) { // bfgs.rs:94-102 f
     return true;
 }
 
+template <bool LEAN>
 __device__ __forceinline__ bool qn_st_after_u(QnCtl& c) { // coefficients of bfgs.rs:115-124 / dfp.rs:115-120 in rank-2 form
-    if (!c.fused) return false;
+    if (!LEAN && !c.fused) return false;
     const double yu = c.hp_yu;
     double c_ss, c_su, c_uu;
     qn_update_coeffs(c.method, c.ys, yu, c_ss, c_su, c_uu);
@@ -160,10 +170,11 @@ __device__ __forceinline__ bool qn_st_after_u(QnCtl& c) { // coefficients of bfg
     return true;
 }
 
+template <bool LEAN>
 __device__ __forceinline__ bool qn_st_check(QnCtl& c, const QnVecs& V, double* small_scratch) { // ls_solver.rs:37-40 (OutOfDomain), has_converged (bfgs.rs:64-76)
     const int n = V.n, n_pad = V.n_pad;
-    if (!qn_check_is_scalar(c)) return false; // gradient descent / unknown ||g||: all threads needed
-    if (c.method == 3) { // Newton: has_converged is the decrement test (newton/mod.rs:64-69)
+    if (!LEAN && !qn_check_is_scalar(c)) return false; // gradient descent / unknown ||g||: all threads needed
+    if (!LEAN && c.method == 3) { // Newton: has_converged is the decrement test (newton/mod.rs:64-69)
         c.gnorm = c.gg_valid ? sqrt(c.gg) : NAN; c.tr_f = c.f_k; c.tr_gnorm = c.gnorm;
         const double f = c.f_k;
         if (isnan(f) || isinf(f)) { c.status = 2; c.phase = QN_PH_DONE; }
@@ -173,7 +184,7 @@ __device__ __forceinline__ bool qn_st_check(QnCtl& c, const QnVecs& V, double* s
     }
     double gnorm, gd0 = c.gd0;
     int d_finite = c.d_finite;
-    if (c.small_n) { // reference order: norm = sqrt(dot), direction by column sweep (bfgs.rs:47)
+    if (!LEAN && c.small_n) { // reference order: norm = sqrt(dot), direction by column sweep (bfgs.rs:47)
         gnorm = sqrt(ref_dot(V.g, V.g, n));
         small_direction(V.H, n_pad, n, V.g, V.d, small_scratch, V.x, c.bounded ? V.lb : nullptr, c.bounded ? V.ub : nullptr);
         if (c.ls_kind == 2) { // morethuente_b.rs:185-198
@@ -198,7 +209,7 @@ __device__ __forceinline__ bool qn_st_check(QnCtl& c, const QnVecs& V, double* s
         c.status = 2; c.phase = QN_PH_DONE; // OutOfDomain
     } else if ((c.has_s_norm && c.s_norm < c.tol) || (c.has_y_norm && c.y_norm < c.tol) || (gnorm < c.tol)) {
         c.status = 0; c.phase = QN_PH_DONE;
-    } else if (c.small_n) {
+    } else if (!LEAN && c.small_n) {
         c.gd0 = gd0; c.d_finite = d_finite; c.last_valid = 0;
         c.state = QN_ST_LS_BEGIN;
     } else if (c.have_dir) {
@@ -211,10 +222,11 @@ __device__ __forceinline__ bool qn_st_check(QnCtl& c, const QnVecs& V, double* s
     return true;
 }
 
+template <bool LEAN>
 __device__ __forceinline__ void qn_st_ls_begin(QnCtl& c) {
     c.ls_i = 0;
-    if (c.ls_kind == 2) c.mt_tmax = fmin(c.mt_tmax, c.mtb_cand); // morethuente_b.rs:201: self.t_max = self.t_max.min(candidate) -- persists
-    if (c.ls_kind == 0 || c.ls_kind == 2) { // morethuente.rs:173-178
+    if (!LEAN && c.ls_kind == 2) c.mt_tmax = fmin(c.mt_tmax, c.mtb_cand); // morethuente_b.rs:201: self.t_max = self.t_max.min(candidate) -- persists
+    if (c.ls_kind == 0 || (!LEAN && c.ls_kind == 2)) { // morethuente.rs:173-178
         c.use_mod = 0; c.conv = 0;
         c.t = fmin(fmax(1.0, c.mt_tmin), c.mt_tmax);
         c.tl = c.mt_tmin; c.tu = c.mt_tmax;
@@ -225,11 +237,13 @@ __device__ __forceinline__ void qn_st_ls_begin(QnCtl& c) {
     }
 }
 
+template <bool LEAN>
 __device__ __forceinline__ void qn_st_mt_loop(QnCtl& c) { // morethuente.rs:181-182
     if (!(c.ls_i < c.max_iter_ls)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :295-296
-    else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_MT_AFTER_T, 0); }
+    else { c.tr_ls_iters++; req_eval_t<LEAN>(c, c.t, QN_ST_MT_AFTER_T, 0); }
 }
 
+template <bool LEAN>
 __device__ __forceinline__ void qn_st_mt_after_t(QnCtl& c) { // morethuente.rs:184-217
     const double f_et = c.f_e, gd_t = c.gd_e, t = c.t;
     const bool wolfe = (f_et - c.f_k <= c.mt_c1 * t * c.gd0) && (fabs(gd_t) <= c.mt_c2 * fabs(c.gd0));
@@ -241,10 +255,11 @@ __device__ __forceinline__ void qn_st_mt_after_t(QnCtl& c) { // morethuente.rs:1
         c.psi_t_f = f_et - c.f_k - c.mt_c1 * t * c.gd0; // psi, :140-149
         c.psi_t_g = gd_t - c.mt_c1 * c.gd0;
         if (!c.use_mod && c.psi_t_f <= 0. && c.phi_t_g > 0.) { c.use_mod = 1; c.tr_ls_cases |= QN_LS_MODIFIED_BIT; } // :212-215 (sticky)
-        req_eval_t(c, c.tl, QN_ST_MT_AFTER_TL, 0); // :217
+        req_eval_t<LEAN>(c, c.tl, QN_ST_MT_AFTER_TL, 0); // :217
     }
 }
 
+template <bool LEAN>
 __device__ __forceinline__ void qn_st_mt_after_tl(QnCtl& c) { // morethuente.rs:218-287
     const double phi_tl_f = c.f_e, phi_tl_g = c.gd_e;
     double f_tl, g_tl, f_t, g_t;
@@ -277,10 +292,11 @@ __device__ __forceinline__ void qn_st_mt_after_tl(QnCtl& c) { // morethuente.rs:
         else c.t = fmax(t_plus, t + c.mt_delta * (tu - t));
         c.state = QN_ST_MT_FINISH;
     } else { // case 4: evaluates at tu (possibly +inf), :274-287
-        req_eval_t(c, c.tu, QN_ST_MT_AFTER_TU, 0);
+        req_eval_t<LEAN>(c, c.tu, QN_ST_MT_AFTER_TU, 0);
     }
 }
 
+template <bool LEAN>
 __device__ __forceinline__ void qn_st_mt_after_tu(QnCtl& c) {
     double f_tu, g_tu;
     if (c.use_mod) { f_tu = c.f_e; g_tu = c.gd_e; }
@@ -290,6 +306,7 @@ __device__ __forceinline__ void qn_st_mt_after_tu(QnCtl& c) {
     c.state = QN_ST_MT_FINISH;
 }
 
+template <bool LEAN>
 __device__ __forceinline__ void qn_st_mt_finish(QnCtl& c) { // morethuente.rs:290-293: the NEW t with the OLD trial's f_t, g_t
     c.t = fmin(fmax(c.t, c.mt_tmin), c.mt_tmax);
     double tl = c.tl, tu = c.tu;
@@ -299,26 +316,30 @@ __device__ __forceinline__ void qn_st_mt_finish(QnCtl& c) { // morethuente.rs:29
     c.state = QN_ST_MT_LOOP;
 }
 
+template <bool LEAN>
 __device__ __forceinline__ void qn_st_bt_loop(QnCtl& c) { // backtracking.rs:31-34
     if (!(c.max_iter_ls > c.ls_i)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :54
-    else { c.tr_ls_iters++; req_eval_t(c, c.t, QN_ST_BT_AFTER, 0, c.ls_kind == 3 ? 1 : 0); }
+    else { c.tr_ls_iters++; req_eval_t<LEAN>(c, c.t, QN_ST_BT_AFTER, 0, (!LEAN && c.ls_kind == 3) ? 1 : 0); }
 }
 
+template <bool LEAN>
 __device__ __forceinline__ void qn_st_bt_after(QnCtl& c) { // backtracking.rs:37-51
     const double f1 = c.f_e;
     if (isnan(f1) || isinf(f1)) { c.t *= c.bt_beta; c.state = QN_ST_BT_LOOP; } // shrink, iteration not counted
-    else if (c.ls_kind == 3 ? (f1 - c.f_k <= (-c.bt_c1 / c.t) * c.bt_diff2) // backtracking_b.rs:24-34
+    else if ((!LEAN && c.ls_kind == 3) ? (f1 - c.f_k <= (-c.bt_c1 / c.t) * c.bt_diff2) // backtracking_b.rs:24-34
                             : (f1 - c.f_k <= c.bt_c1 * c.t * c.gd0)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; }
     else { c.t *= c.bt_beta; c.ls_i++; c.state = QN_ST_BT_LOOP; }
 }
 
+template <bool LEAN>
 __device__ __forceinline__ bool qn_st_after_ls(QnCtl& c) {
-    if (c.ls_only) { c.status = 0; c.phase = QN_PH_DONE; return true; } // compute_step_len returns the step, nothing else
-    if (c.method == 2 || c.method == 3) return false; // gradient descent / Newton: the default hook x += step*d needs all threads
-    req_eval_t(c, c.ls_result, QN_ST_AFTER_NEXT, 1); // bfgs.rs:94,98: oracle(x + step*d)
+    if (!LEAN && c.ls_only) { c.status = 0; c.phase = QN_PH_DONE; return true; } // compute_step_len returns the step, nothing else
+    if (!LEAN && (c.method == 2 || c.method == 3)) return false; // gradient descent / Newton: the default hook x += step*d needs all threads
+    req_eval_t<LEAN>(c, c.ls_result, QN_ST_AFTER_NEXT, 1); // bfgs.rs:94,98: oracle(x + step*d)
     return true;
 }
 
+template <bool LEAN>
 __device__ __forceinline__ bool qn_st_iter_end(QnCtl& c, const QnVecs& V, const bool side_effects) { // ls_solver.rs:104-107
     const bool rec = c.k < c.trace_cap;
     if (rec && c.trace_x && !c.xtrace_done) return false; // the iterate has to be copied by all threads first
@@ -334,7 +355,7 @@ __device__ __forceinline__ bool qn_st_iter_end(QnCtl& c, const QnVecs& V, const 
     c.k += 1;
     c.n_iterations++;
     c.state = QN_ST_LOOP_TOP;
-    if (c.callback_mode) c.phase = QN_PH_ITER_DONE;
+    if (!LEAN && c.callback_mode) c.phase = QN_PH_ITER_DONE;
     return true;
 }
 
@@ -346,6 +367,7 @@ __device__ __forceinline__ bool qn_st_iter_end(QnCtl& c, const QnVecs& V, const 
     if (!(c.phase == QN_PH_RUNNING && c.state == (ST))) break;          \
     if (!(CALL)) return;
 
+template <bool LEAN = false>
 __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double* small_scratch, const bool side_effects = true) {
     for (int guard = 0; guard < (1 << 22); ++guard) {
         if (c.phase != QN_PH_RUNNING) return;
@@ -353,89 +375,89 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
         // (only the successions of the steady iteration are chained: every chained copy of a state is code, and the machine is
         // inlined into every sym2 kernel)
         case QN_ST_BEGIN:
-            qn_st_begin(c);
-            qn_st_loop_top(c);
+            qn_st_begin<LEAN>(c);
+            qn_st_loop_top<LEAN>(c);
             break;
 
-        case QN_ST_LOOP_TOP: qn_st_loop_top(c); break;
+        case QN_ST_LOOP_TOP: qn_st_loop_top<LEAN>(c); break;
 
         case QN_ST_AFTER_EVALX:
-            if (!qn_st_after_evalx(c)) return;
+            if (!qn_st_after_evalx<LEAN>(c)) return;
             break;
 
         case QN_ST_AFTER_DIR:
-            if (!qn_st_after_dir(c)) return;
-            qn_st_ls_begin(c);
-            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop(c))
+            if (!qn_st_after_dir<LEAN>(c)) return;
+            qn_st_ls_begin<LEAN>(c);
+            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop<LEAN>(c))
             break;
 
         case QN_ST_AFTER_NEXT:
-            if (!qn_st_after_next(c)) return;
+            if (!qn_st_after_next<LEAN>(c)) return;
             break;
 
         case QN_ST_AFTER_U: // ... the iteration ends, the next one begins: up to the first trial of its line search
-            if (!qn_st_after_u(c)) return;
-            QN_RUN_NEXT_B(QN_ST_ITER_END, qn_st_iter_end(c, V, side_effects))
-            QN_RUN_NEXT(QN_ST_LOOP_TOP, qn_st_loop_top(c))
-            QN_RUN_NEXT_B(QN_ST_CHECK, qn_st_check(c, V, small_scratch))
-            QN_RUN_NEXT(QN_ST_LS_BEGIN, qn_st_ls_begin(c))
-            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop(c))
+            if (!qn_st_after_u<LEAN>(c)) return;
+            QN_RUN_NEXT_B(QN_ST_ITER_END, qn_st_iter_end<LEAN>(c, V, side_effects))
+            QN_RUN_NEXT(QN_ST_LOOP_TOP, qn_st_loop_top<LEAN>(c))
+            QN_RUN_NEXT_B(QN_ST_CHECK, qn_st_check<LEAN>(c, V, small_scratch))
+            QN_RUN_NEXT(QN_ST_LS_BEGIN, qn_st_ls_begin<LEAN>(c))
+            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop<LEAN>(c))
             break;
 
         case QN_ST_CHECK:
-            if (!qn_st_check(c, V, small_scratch)) return;
-            QN_RUN_NEXT(QN_ST_LS_BEGIN, qn_st_ls_begin(c))
-            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop(c))
+            if (!qn_st_check<LEAN>(c, V, small_scratch)) return;
+            QN_RUN_NEXT(QN_ST_LS_BEGIN, qn_st_ls_begin<LEAN>(c))
+            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop<LEAN>(c))
             break;
 
         case QN_ST_LS_BEGIN:
-            qn_st_ls_begin(c);
-            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop(c))
+            qn_st_ls_begin<LEAN>(c);
+            QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop<LEAN>(c))
             break;
 
-        case QN_ST_MT_LOOP: qn_st_mt_loop(c); break;
+        case QN_ST_MT_LOOP: qn_st_mt_loop<LEAN>(c); break;
 
         case QN_ST_MT_AFTER_T: // a trial came back: accepted (the step leaves the search), or the next trial from the memo of phi(tl)
-            qn_st_mt_after_t(c);
-            if (c.phase == QN_PH_RUNNING && c.state == QN_ST_AFTER_LS) { if (!qn_st_after_ls(c)) return; break; }
-            QN_RUN_NEXT(QN_ST_MT_AFTER_TL, qn_st_mt_after_tl(c))
-            QN_RUN_NEXT(QN_ST_MT_FINISH, qn_st_mt_finish(c))
-            qn_st_mt_loop(c);
+            qn_st_mt_after_t<LEAN>(c);
+            if (c.phase == QN_PH_RUNNING && c.state == QN_ST_AFTER_LS) { if (!qn_st_after_ls<LEAN>(c)) return; break; }
+            QN_RUN_NEXT(QN_ST_MT_AFTER_TL, qn_st_mt_after_tl<LEAN>(c))
+            QN_RUN_NEXT(QN_ST_MT_FINISH, qn_st_mt_finish<LEAN>(c))
+            qn_st_mt_loop<LEAN>(c);
             break;
 
         case QN_ST_MT_AFTER_TL:
-            qn_st_mt_after_tl(c);
-            QN_RUN_NEXT(QN_ST_MT_FINISH, qn_st_mt_finish(c))
-            qn_st_mt_loop(c);
+            qn_st_mt_after_tl<LEAN>(c);
+            QN_RUN_NEXT(QN_ST_MT_FINISH, qn_st_mt_finish<LEAN>(c))
+            qn_st_mt_loop<LEAN>(c);
             break;
 
         case QN_ST_MT_AFTER_TU:
-            qn_st_mt_after_tu(c);
-            qn_st_mt_finish(c);
-            qn_st_mt_loop(c);
+            qn_st_mt_after_tu<LEAN>(c);
+            qn_st_mt_finish<LEAN>(c);
+            qn_st_mt_loop<LEAN>(c);
             break;
 
         case QN_ST_MT_FINISH:
-            qn_st_mt_finish(c);
-            qn_st_mt_loop(c);
+            qn_st_mt_finish<LEAN>(c);
+            qn_st_mt_loop<LEAN>(c);
             break;
 
-        case QN_ST_BT_LOOP: qn_st_bt_loop(c); break;
+        case QN_ST_BT_LOOP: qn_st_bt_loop<LEAN>(c); break;
 
         case QN_ST_BT_AFTER:
-            qn_st_bt_after(c);
-            if (c.phase == QN_PH_RUNNING && c.state == QN_ST_AFTER_LS) { if (!qn_st_after_ls(c)) return; break; }
-            QN_RUN_NEXT(QN_ST_BT_LOOP, qn_st_bt_loop(c))
+            qn_st_bt_after<LEAN>(c);
+            if (c.phase == QN_PH_RUNNING && c.state == QN_ST_AFTER_LS) { if (!qn_st_after_ls<LEAN>(c)) return; break; }
+            QN_RUN_NEXT(QN_ST_BT_LOOP, qn_st_bt_loop<LEAN>(c))
             break;
 
         case QN_ST_LS_ONLY: return; // g.d needs all threads
 
         case QN_ST_AFTER_LS:
-            if (!qn_st_after_ls(c)) return;
+            if (!qn_st_after_ls<LEAN>(c)) return;
             break;
 
         case QN_ST_ITER_END:
-            if (!qn_st_iter_end(c, V, side_effects)) return;
+            if (!qn_st_iter_end<LEAN>(c, V, side_effects)) return;
             break;
 
         default:

@@ -514,17 +514,18 @@ __device__ __forceinline__ void tr_push_case(QnCtl& c, int digit) {
 
 // One oracle call of the reference's sequence at x + t d.  With memoisation a call whose point was already
 // evaluated is answered from the memo (the values are identical; see include/qn_hip.h qn_oracle.memoize).
+template <bool LEAN = false>
 __device__ __forceinline__ void req_eval_t(QnCtl& c, double t, int after_state, int need_vectors, int project = 0) {
     c.n_oracle_calls++;
     c.tr_n_evals++;
-    if (c.memoize && !project && !c.last_projected) {
+    if (LEAN || (c.memoize && !project && !c.last_projected)) {
         if (!need_vectors && t == 0.0 && c.d_finite) { // x + 0*d == x: phi(0) = (f_k, g_k.d)
             c.f_e = c.f_k; c.gd_e = c.gd0; c.state = after_state;
             return;
         }
         if (c.last_valid && c.last_t == t) {
             c.f_e = c.f_last; c.gd_e = c.gd_last;
-            if (c.sym2 && need_vectors) { // the scalars are known; the vectors of that point are still slots (qn_sym2.hip.h)
+            if ((LEAN || c.sym2) && need_vectors) { // the scalars are known; the vectors of that point are still slots (qn_sym2.hip.h)
                 c.after_state = after_state;
                 c.phase = QN_PH_REQ_VEC;
                 return;
@@ -538,7 +539,7 @@ __device__ __forceinline__ void req_eval_t(QnCtl& c, double t, int after_state, 
     c.req_project = project;
     c.req_need_vectors = need_vectors;
     c.after_state = after_state;
-    c.phase = c.defer_u ? QN_PH_REQ_HPASS_EVAL : QN_PH_REQ_EVAL;
+    c.phase = (!LEAN && c.defer_u) ? QN_PH_REQ_HPASS_EVAL : QN_PH_REQ_EVAL;
 }
 
 // ------------------------------------------------------------------------------------------------

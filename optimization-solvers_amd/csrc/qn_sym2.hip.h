@@ -132,7 +132,7 @@ __device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const
             run = true;
         }
     }
-    if (run) ctl_scalar_run(c, V, scratch, leader); // (ONE call site: the machine is inlined, and it is large)
+    if (run) ctl_scalar_run<true>(c, V, scratch, leader); // (ONE call site: the machine is inlined, and it is large; LEAN: qn_ctl_step.hip.h)
 }
 
 // a wave-uniform double out of lane `l` (uniform) of a per-lane value: the row-side inputs of a tile (x_i, d_i, s_i, u_i, y_i,
