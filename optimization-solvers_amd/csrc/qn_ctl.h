@@ -108,7 +108,9 @@ struct QnCtl {
     int32_t hp_nrhs, hp_lazy;
 
     // ---- pending symmetric rank-2 update: H_true = H_stored + c_su (sp up' + up sp') + c_ss sp sp' + c_uu up up'
-    int32_t pending, _pad1;
+    int32_t pending;
+    int32_t spec_tiles; // sym2, folded accept-reduce: the launch that formed the vectors of the accepted point ran the update tiles of the
+                        // pass the machine is about to ask for (qn_sym2.hip.h, s2_hpass_kernel); cleared when that request is met
     double c_ss, c_su, c_uu;
 
     // ---- evaluation results / memo ----

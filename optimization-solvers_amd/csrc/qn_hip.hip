@@ -795,10 +795,16 @@ struct qn_solver {
     // second-generation symmetric path (qn_sym2.hip.h): static work lists, per-workgroup scalars, double-buffered control block
     int* s2_items = nullptr;
     int s2_G = 0, s2_nb = 0, s2_maxk = 0, s2_inorder = 0;
+    double* s2_partE = nullptr; // [nb][nb][128]: row / column slots of the last evaluation (QnS2Args.partE)
     double* s2_wgS = nullptr; // [2][s2_trows][QN_S2_ROW]: the sums a servicing launch leaves for the next launch's prologue, by launch parity
     int s2_trows = 0;
     QnCtl* s2_ctl = nullptr;
     bool no_sym2 = false; // diagnostics: the first-generation tile kernels (qn_sym.hip.h)
+    bool fold = false; // sym2 with the accept-reduce folded into the update-tile launch (four launches per iteration instead of five).
+                       // OFF by default -- measured, rocprofv3 averages, n = 4096, same box: the accept-reduce launch (6.7 us) goes, the
+                       // update-tile launch gets 5 us longer (every workgroup sums the slots of its own six blocks: 48 MB of L2 reads
+                       // instead of 1 MB, and the prologue there is the long run of the machine) and the update-reduce 2.4 us (its
+                       // prologue now runs the machine): 80.3 against 79.4 us per iteration.
     // After a fused run the iterate and the pending update's vectors stay where the fused kernels keep them (X0[xc], S0[sc], UN);
     // they are copied back to the canonical buffers only when something other than the next fused run wants them.
     bool fused_live = false;
@@ -899,8 +905,8 @@ static int solver_alloc_sym2(qn_solver* s) {
     const int nb = s->T.n_pad / QN_TB;
     hipStream_t st = s->ctx->stream;
     if (s->s2_nb != nb) {
-        (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS);
-        s->s2_items = nullptr; s->s2_wgS = nullptr;
+        (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE);
+        s->s2_items = nullptr; s->s2_wgS = nullptr; s->s2_partE = nullptr;
         const int nitems = nb * (nb + 1) / 2;
         const int G = std::min(nitems, QN_S2_MAXG);
         std::vector<std::vector<int>> lists(G);
@@ -947,6 +953,7 @@ static int solver_alloc_sym2(qn_solver* s) {
         s->s2_inorder = inorder;
         s->s2_trows = std::max(QN_S2_MAXG, (nb + 63) / 64 * 64);
         QNCHK(dev_alloc_zero(&s->s2_wgS, (size_t)2 * s->s2_trows * QN_S2_ROW, st));
+        QNCHK(dev_alloc_zero(&s->s2_partE, (size_t)nb * nb * QN_TB, st));
         s->s2_G = G;
         s->s2_nb = nb;
     }
@@ -1018,7 +1025,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->symsh_xg); (void)hipFree(s->symsh_gath); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
-    (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_ctl);
+    (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE); (void)hipFree(s->s2_ctl);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
     delete s;
@@ -1068,6 +1075,7 @@ extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_sp
     if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; }
     if (rows_per_block == -3) { s->no_sym = 1; rows_per_block = 0; }   // diagnostics: fused row kernels on the full matrices
     if (rows_per_block == -5) { s->newton_force_lu = 1; return QN_OK; } // diagnostics: Newton by pivoted LU even for an SPD Hessian
+    if (rows_per_block == -6) { s->fold = 1; return QN_OK; }           // measurement: sym2 with the folded accept-reduce (see qn_solver::fold)
     if (rows_per_block == -4) { s->no_sym2 = 1; rows_per_block = 0; }  // diagnostics: first-generation symmetric tile kernels (8 launches per iteration)
     if (rows_per_block == -2) { s->no_defer = 1; rows_per_block = 0; } // diagnostics: fused kernels, update step not deferred // diagnostics: -1 selects the generic (non-fused) kernels
     if (rows_per_block != 0 && rows_per_block != 2 && rows_per_block != 4 && rows_per_block != 8 && rows_per_block != 16)
@@ -1571,12 +1579,15 @@ static int s2_launch(Run& r, int kind) {
     case QN_S2_EVAL: hipLaunchKernelGGL(s2_eval_kernel, dim3(a.G), dim3(QN_S2_TPB), 0, st, a); break;
     case QN_S2_VEC: hipLaunchKernelGGL(s2_vec_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
     case QN_S2_HTILE:
-        if (s->method == QN_BFGS) {
-            if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            else hipLaunchKernelGGL((s2_hpass_kernel<false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        if (a.fold) { // (n <= 4096: H stays in the Infinity Cache, no streaming hints)
+            if (s->method == QN_BFGS) hipLaunchKernelGGL((s2_hpass_kernel<false, true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            else hipLaunchKernelGGL((s2_hpass_kernel<false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        } else if (s->method == QN_BFGS) {
+            if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            else hipLaunchKernelGGL((s2_hpass_kernel<false, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         } else {
-            if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            else hipLaunchKernelGGL((s2_hpass_kernel<false, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, false, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         }
         s->h_lower_stale = true; s->h_diag_stale = true;
         break;
@@ -2113,7 +2124,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     }
     r.sym2 = r.sym && c->world == 1 && !s->no_sym2 && (size_t)s->T.n_pad == s->n; // (the second-generation kernels keep no padding entries at zero)
     h->sym2 = r.sym2 ? 1 : 0;
-    h->serviced = 0; h->ev_par = 0; h->ev_kind = QN_REQ_X; h->ev_t = 0.0;
+    h->serviced = 0; h->ev_par = 0; h->ev_kind = QN_REQ_X; h->ev_t = 0.0; h->spec_tiles = 0;
     h->defer_u = 0;
     h->no_defer = s->no_defer;
     if (!r.fused) QNCHK(fused_export(s)); // another path takes over: it works on the canonical buffers
@@ -2144,7 +2155,10 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         QnS2Args& a = r.s2;
         a.Q = r.obj->Q; a.H = s->H; a.n = (int)s->n; a.np = s->T.n_pad; a.nb = s->s2_nb; a.G = s->s2_G;
         a.item_ij = s->s2_items; a.maxk = s->s2_maxk; a.inorder = s->s2_inorder; a.F = s->V.F; a.part = s->sym_part;
-        a.wgS = s->s2_wgS; a.trows = s->s2_trows; a.ctl2 = s->s2_ctl;
+        a.wgS = s->s2_wgS; a.trows = s->s2_trows; a.ctl2 = s->s2_ctl; a.partE = s->s2_partE;
+        // folded accept-reduce (s2_hpass_kernel): every workgroup holds at most three items, so the blocks whose slots it sums fit
+        // its LDS staging area -- n <= 4096 with 256 workgroups; larger n keeps the accept-reduce launch (7 us of 250+)
+        a.fold = (s->s2_maxk <= 3 && s->s2_nb <= 32 && s->fold) ? 1 : 0;
         a.trace = s->V.trace; a.xtrace = s->V.xtrace;
         a.nt = s->T.n_pad >= 8192; // H past the Infinity Cache: every byte is touched once per pass
         // (no synchronisation: the copy is stream-ordered in front of the launches, the mirror is pinned, and the host does not
@@ -2166,14 +2180,15 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 QNCHK(s2_peek(r));
                 const int ph = h->phase;
                 if (ph == QN_PH_DONE) { status = h->status; break; }
-                if (h->serviced != 0) return fail(QN_ABNORMAL_TERMINATION, "sym2: request in an unexpected service state");
+                const bool tiles_done = ph == QN_PH_REQ_HPASS && h->serviced == 1; // (folded accept-reduce: the tiles ran with the vectors)
+                if (h->serviced != 0 && !tiles_done) return fail(QN_ABNORMAL_TERMINATION, "sym2: request in an unexpected service state");
                 if (ph == QN_PH_REQ_EVAL) QNCHK(s2_launch(r, QN_S2_EVAL));
-                else if (ph == QN_PH_REQ_VEC) QNCHK(s2_launch(r, QN_S2_VEC));
-                else if (ph == QN_PH_REQ_HPASS) { QNCHK(s2_launch(r, QN_S2_HTILE)); QNCHK(s2_launch(r, QN_S2_HREDUCE)); }
+                else if (ph == QN_PH_REQ_VEC) QNCHK(s2_launch(r, r.s2.fold ? QN_S2_HTILE : QN_S2_VEC));
+                else if (ph == QN_PH_REQ_HPASS) { if (!tiles_done) QNCHK(s2_launch(r, QN_S2_HTILE)); QNCHK(s2_launch(r, QN_S2_HREDUCE)); }
                 else return fail(QN_ABNORMAL_TERMINATION, "sym2: control block in an unexpected phase");
                 QNCHK(s2_launch(r, QN_S2_ADVANCE));
             }
-        } else { // pipelined: [eval x slots, accept-reduce, update tiles, update-reduce] per period, each launch predicated in its prologue
+        } else { // pipelined: [eval x slots, (accept-reduce,) update tiles, update-reduce] per period, each launch predicated in its prologue
             const int slots = (ls->kind == QN_LS_MORETHUENTE) ? 2 : 4;
             bool first = true;
             for (;;) {
@@ -2189,7 +2204,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 first = false;
                 for (int64_t p = 0; p < periods; ++p) {
                     for (int e = 0; e < slots; ++e) QNCHK(s2_launch(r, QN_S2_EVAL));
-                    QNCHK(s2_launch(r, QN_S2_VEC));
+                    if (!r.s2.fold) QNCHK(s2_launch(r, QN_S2_VEC)); // (folded into the update tiles otherwise)
                     QNCHK(s2_launch(r, QN_S2_HTILE));
                     QNCHK(s2_launch(r, QN_S2_HREDUCE));
                 }

@@ -58,7 +58,10 @@ struct QnS2Args {
     int maxk;            // longest list
     int inorder;         // the first `inorder` items were dealt in order: item t is the (t / G)-th of workgroup t mod G
     QnFused F;           // X0, S0, G, GT, Y, UN, VV, b (UP is not used here: no kernel writes u while another reads it)
-    double* part;        // [nb][nb][2][128] row / column slots
+    double* part;        // [nb][nb][2][128] row / column slots of the update pass ([y, g+])
+    double* partE;       // [nb][nb][128] row / column slots of the last evaluation (Q (x + t d)): a buffer of its own, because the launch that
+                         // turns them into vectors also writes the update pass's slots (folded accept-reduce)
+    int fold;            // the accept-reduce runs inside the update-tile launch (workgroups hold <= 3 items: n <= 4096)
     double* wgS;         // [2][QN_S2_ROW][trows] (column-major) what a servicing launch hands the state machine, one row of sums per workgroup:
                          // evaluation tiles (G rows, QN_S2_NSE sums), accept-reduce (nb rows, QN_S2_NR), update-reduce (nb rows: y'u, u'g+).
                          // Launch i writes half i & 1 and launch i + 1 -- whose prologue consumes the request -- reads it: the address
@@ -133,6 +136,19 @@ __device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const
         }
     }
     if (run) ctl_scalar_run<true>(c, V, scratch, leader); // (ONE call site: the machine is inlined, and it is large; LEAN: qn_ctl_step.hip.h)
+    // Folded accept-reduce: the launch that formed g+, y, s of the accepted point ran the update tiles as well, BEFORE the machine
+    // had seen ||s||, ||y|| (the tiles only need the vectors and the coefficients of the PENDING update, all known then).  Now that
+    // the machine has consumed those sums: if it asks for exactly that pass, its tiles are done (the reduce launch is what is left);
+    // if it does not (step or gradient change below tol: bfgs.rs:106-112 -- the run then ends at the next loop top), the tiles
+    // have still applied the pending update to the stored matrix, which is all `pending` stands for.
+    // (spec_tiles = the number of right-hand sides the tiles ran with: 2 = [y, g+] after an accepted step, 1 = g after the evaluation
+    // at x that opens a run.)
+    if (c.spec_tiles && c.phase != QN_PH_RUNNING && c.phase != QN_PH_REQ_VEC) {
+        const int ran = c.spec_tiles;
+        c.spec_tiles = 0;
+        if (c.phase == QN_PH_REQ_HPASS && c.serviced == 0 && c.hp_nrhs == ran) c.serviced = 1;
+        else if (c.pending) { c.pending = 0; c.n_hpasses++; c.n_hpass_rw++; }
+    }
 }
 
 // a wave-uniform double out of lane `l` (uniform) of a per-lane value: the row-side inputs of a tile (x_i, d_i, s_i, u_i, y_i,
@@ -178,24 +194,16 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L)
     if (64 + lane < NW) cw1 = cin[64 + lane];
     double tr[QN_S2_PCH][QN_S2_NSE];
     const double* T = a.wgS + (size_t)(a.parity ^ 1) * (size_t)a.trows * QN_S2_ROW;
-    if (KIND != QN_S2_HREDUCE) {
 #pragma unroll
-        for (int k = 0; k < QN_S2_NSE; ++k)
+    for (int k = 0; k < QN_S2_NSE; ++k)
 #pragma unroll
-            for (int j = 0; j < QN_S2_PCH; ++j) tr[j][k] = T[(size_t)k * a.trows + j * 64 + lane]; // (trows >= 256)
-    }
+        for (int j = 0; j < QN_S2_PCH; ++j) tr[j][k] = T[(size_t)k * a.trows + j * 64 + lane]; // (trows >= 256)
     if (lane < NW) lc[lane] = cw0;
     if (64 + lane < NW) lc[64 + lane] = cw1;
     __builtin_amdgcn_wave_barrier(); // (one wave: its LDS accesses execute in program order; this only pins the compiler's order)
     QN_S2_STAMP(9);
     QnCtl& c = L.c; // (in LDS: a private register copy of all ~150 words does not fit beside the machine's own temporaries -- 255 spills)
     int mine = 0;
-    if (KIND == QN_S2_HREDUCE) { // no decision between the update tiles and their reduction: pass the control block on
-        mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 1;
-        if (lane == 0) { if (mine) c.serviced = 2; L.mine = mine; }
-        __builtin_amdgcn_s_setprio(0);
-        return;
-    }
     const int ph = c.phase;
     if (ph == QN_PH_DONE) { // launches enqueued past the end of the run: pass the control block on, nothing else
         if (lane == 0) L.mine = 0;
@@ -250,9 +258,16 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L)
     if (lane == 0) {
         if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == 0;
         if (KIND == QN_S2_VEC) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
-        if (KIND == QN_S2_HTILE) mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 0;
+        if (KIND == QN_S2_HTILE) { // 2: the accepted point's slots -> vectors AND the update tiles (folded accept-reduce); 1: the tiles of a pending pass
+            if (a.fold && c.phase == QN_PH_REQ_VEC && c.serviced == 0) mine = 2;
+            else if (c.phase == QN_PH_REQ_HPASS && c.serviced == 0) mine = 1;
+        }
+        if (KIND == QN_S2_HREDUCE) mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 1;
         if (c.phase == QN_PH_RUNNING) { c.status = 4; c.phase = QN_PH_DONE; } // a state this path cannot service: abort, never spin
-        if (mine) c.serviced = (KIND == QN_S2_HTILE) ? 1 : 2; // as this launch leaves the request
+        if (mine) { // as this launch leaves the request
+            if (KIND == QN_S2_HTILE) { c.serviced = mine == 2 ? 2 : 1; if (mine == 2) c.spec_tiles = c.ev_kind == QN_REQ_T ? 2 : 1; }
+            else c.serviced = 2;
+        }
         L.mine = mine;
     }
     __builtin_amdgcn_s_setprio(0);
@@ -560,7 +575,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
                 const bool dg = e == 0 ? diag_a : (e == 1 ? diag_b : diag_c);
                 const int Ie = e == 0 ? Ia : (e == 1 ? Ib : Ic), Je = e == 0 ? Ja : (e == 1 ? Jb : Jc);
                 if (dg) colsum[e][cidx] = acc; // both parts of a diagonal tile belong to block-row I: one slot
-                else a.part[(((size_t)Je * a.nb + Ie) * 2 + 0) * QN_TB + cidx] = acc;
+                else a.partE[((size_t)Je * a.nb + Ie) * QN_TB + cidx] = acc;
             }
         }
         if (tid < QN_S2_NSE) { // (items in list order: a, b, c; scalars 2..5 exist on diagonal items only)
@@ -576,16 +591,16 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
             const int rl = wave * QN_S2_RPW + (lane >> 2);
             double v = row_a;
             if (diag_a) v = v + colsum[0][rl];
-            a.part[(((size_t)Ia * a.nb + Ja) * 2 + 0) * QN_TB + rl] = v;
+            a.partE[((size_t)Ia * a.nb + Ja) * QN_TB + rl] = v;
             if (has_b) {
                 v = row_b;
                 if (diag_b) v = v + colsum[1][rl];
-                a.part[(((size_t)Ib * a.nb + Jb) * 2 + 0) * QN_TB + rl] = v;
+                a.partE[((size_t)Ib * a.nb + Jb) * QN_TB + rl] = v;
             }
             if (take_c) {
                 v = row_c;
                 if (diag_c) v = v + colsum[2][rl];
-                a.part[(((size_t)Ic * a.nb + Jc) * 2 + 0) * QN_TB + rl] = v;
+                a.partE[((size_t)Ic * a.nb + Jc) * QN_TB + rl] = v;
             }
         }
         if (it == 0) QN_S2_STAMP(5);
@@ -604,27 +619,29 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
 // combined in order through LDS.  In two steps, so that the first 16 slots of every quarter (all of them up to n = 8192) are in
 // flight while the control block is still on its way: the addresses do not depend on it.
 struct QnS2Slots { double v[16]; };
+template <int NRHS = 2>
 __device__ __forceinline__ void qn_s2_slot_issue(const double* __restrict__ part, int nb, int R, int rhs, QnS2Slots& S) {
     const int i = threadIdx.x & (QN_TB - 1), qd = threadIdx.x >> 7;
     const int per = (nb + 3) / 4;
     const int k_lo = qd * per, k_hi = min(nb, k_lo + per);
-    const double* p = part + (((size_t)R * nb) * 2 + rhs) * QN_TB + i;
+    const double* p = part + (((size_t)R * nb) * NRHS + rhs) * QN_TB + i;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) S.v[u] = (k_lo + u < k_hi) ? p[(size_t)(k_lo + u) * 2 * QN_TB] : 0.0;
+    for (int u = 0; u < 16; ++u) S.v[u] = (k_lo + u < k_hi) ? p[(size_t)(k_lo + u) * NRHS * QN_TB] : 0.0;
 }
 // threads 0..127 return the total of row (tid & 127); all 512 threads call it
+template <int NRHS = 2>
 __device__ __forceinline__ double qn_s2_slot_sum(const double* __restrict__ part, int nb, int R, int rhs, const QnS2Slots& S, double (*qbuf)[QN_TB]) {
     const int i = threadIdx.x & (QN_TB - 1), qd = threadIdx.x >> 7;
     const int per = (nb + 3) / 4;
     const int k_lo = qd * per, k_hi = min(nb, k_lo + per);
-    const double* p = part + (((size_t)R * nb) * 2 + rhs) * QN_TB + i;
+    const double* p = part + (((size_t)R * nb) * NRHS + rhs) * QN_TB + i;
     double acc = 0.0;
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc = acc + S.v[u];
     for (int k0 = k_lo + 16; k0 < k_hi; k0 += 16) {
         double v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = (k0 + u < k_hi) ? p[(size_t)(k0 + u) * 2 * QN_TB] : 0.0;
+        for (int u = 0; u < 16; ++u) v[u] = (k0 + u < k_hi) ? p[(size_t)(k0 + u) * NRHS * QN_TB] : 0.0;
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc = acc + v[u];
     }
@@ -644,7 +661,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QnS2Slots S0;
     if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC>(a, L);
-    qn_s2_slot_issue(a.part, a.nb, R, 0, S0);
+    qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0);
     __syncthreads();
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     double* __restrict__ xt = a.F.X0 + (size_t)(1 - q.xc) * np;
     const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
     double* __restrict__ sstage = a.F.S0 + (size_t)(1 - q.sc) * np;
-    const double qi = qn_s2_slot_sum(a.part, a.nb, R, 0, S0, qbuf);
+    const double qi = qn_s2_slot_sum<1>(a.partE, a.nb, R, 0, S0, qbuf);
     double p[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = 0.0;
@@ -697,26 +714,83 @@ struct QnS2HVec {
     double s_r, u_r, y0_r, y1_r;
     v2d s_c, u_c, a0, a1;
 };
+template <bool RHS = true> // (false: s and u only -- the right-hand sides come from LDS)
 __device__ __forceinline__ void qn_s2_hvec_load(const QnS2HReq& q, const int ir, const int jc, QnS2HVec& v) {
-    v.s_r = q.sp[ir]; v.u_r = q.up[ir]; v.y0_r = q.r0v[ir]; v.y1_r = q.gt[ir];
-    v.s_c = ld2(q.sp + jc); v.u_c = ld2(q.up + jc); v.a0 = ld2(q.r0v + jc); v.a1 = ld2(q.gt + jc);
+    v.s_r = q.sp[ir]; v.u_r = q.up[ir];
+    v.s_c = ld2(q.sp + jc); v.u_c = ld2(q.up + jc);
+    if (RHS) { v.y0_r = q.r0v[ir]; v.y1_r = q.gt[ir]; v.a0 = ld2(q.r0v + jc); v.a1 = ld2(q.gt + jc); }
 }
 
+// FOLDED ACCEPT-REDUCE (round 3; workgroups with <= 3 items, i.e. n <= 4096: QnS2Args.fold).  Round 2 turned the accepted
+// evaluation's slots into vectors in a launch of its own (s2_vec_kernel: 7 us at n = 4096, most of it a kernel boundary, a control
+// block round trip and a run of the state machine), and only then started the update tiles.  But the tiles need nothing the
+// machine decides after the acceptance: the vectors g+, y of the accepted point, and the PENDING update's s, u and coefficients.
+// So this kernel also answers QN_PH_REQ_VEC (L.mine == 2): every workgroup sums the evaluation's slots for the blocks of its OWN
+// items (<= 6 blocks x 32 slots x 1 KB, L2-resident; the same order as qn_s2_slot_sum, hence the same bits), forms g+ = q - b and
+// y = g+ - g for them in LDS, and goes on into the tiles; the workgroup that holds the diagonal item (R, R) also writes block R
+// of the vectors (g+, y, x+, s) and its five sums.  The machine consumes those sums in the NEXT launch's prologue and finds the
+// tiles of the pass it then asks for already done (QnCtl.spec_tiles, qn_s2_advance).  An evaluation at x itself (the first of a
+// run) is followed by a direction pass: g+ in both right-hand sides, as s2_hreduce_kernel expects it.
+#define QN_S2_FOLD_ITEMS 3
+#define QN_S2_FOLD_BLOCKS (2 * QN_S2_FOLD_ITEMS)
+
 // BFGS: true -> the update has the (s u' + u s') and s s' terms (bfgs.rs:115-124); false -> DFP: s s' and u u' (dfp.rs:115-120)
-template <bool NT, bool BFGS>
+// FOLD: the instantiation for a.fold (its right-hand sides always come from LDS: staged from the vectors when the request is a
+// plain update pass); the other one is round 2's kernel, vectors from global memory, any number of items.
+template <bool NT, bool BFGS, bool FOLD>
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
     __shared__ double colsum[2][QN_TB]; // [rhs]: row part of a diagonal item, parked until its column part is summed
     __shared__ double colred[QN_S2_WAVES][2][QN_TB];
+    __shared__ double fq[FOLD ? QN_S2_FOLD_BLOCKS : 1][4][QN_TB]; // folded accept-reduce: the quarters of the blocks' slot sums, ...
+    __shared__ double fbg[FOLD ? QN_S2_FOLD_BLOCKS : 1][2][QN_TB]; // ... b and g of the blocks, ...
+    __shared__ double fv[FOLD ? QN_S2_FOLD_BLOCKS : 1][3][QN_TB]; // ... and what they become: [0] first right-hand side (y or g+), [1] g+, [2] y
+    __shared__ double fred[2][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
     int ij = qn_s2_first_item(blockIdx.x, a.nb);
     const int ij1 = qn_s2_second_item(a);
+    const int ij2 = (FOLD && ij1 >= 0 && a.maxk > 2) ? a.item_ij[(size_t)2 * a.G + blockIdx.x] : -1;
     if (wave == 0) qn_s2_prologue_w0<QN_S2_HTILE>(a, L); // (wave 0: the prologue first, then its rows -- see s2_eval_kernel)
     int I = ij >> 16, J = ij & 0xffff;
+    // Folded accept-reduce: the quarters of the slot sums of the workgroup's blocks (task = entry e of quarter qd, for all six
+    // blocks), and b and g of those blocks.  None of the addresses depends on the control block, so this is done by the waves that
+    // wait for wave 0; wave 0's own share (entries 0..63 of the first quarter) is dealt to waves 1..6, a block each, so that wave
+    // 0 comes out of the prologue with nothing but its rows to request.  ALL of a wave's loads go out before its 16 rows do: a
+    // wave's loads return in order, these are cache hits, and behind the rows they would wait for the whole first window (first
+    // version, measured: the workgroup barrier moved from 5.5 to 12 us into the kernel).  Block b of the list: I of item b / 2
+    // (b even), J (b odd); a missing item repeats the first block.
+    int blk[QN_S2_FOLD_BLOCKS];
+    {
+        const int ijs[QN_S2_FOLD_ITEMS] = {ij, ij1 >= 0 ? ij1 : ij, ij2 >= 0 ? ij2 : ij};
+#pragma unroll
+        for (int k = 0; k < QN_S2_FOLD_ITEMS; ++k) { blk[2 * k] = ijs[k] >> 16; blk[2 * k + 1] = ijs[k] & 0xffff; }
+    }
+    double sv[QN_S2_FOLD_BLOCKS][8], sx[8], bg[QN_S2_FOLD_BLOCKS];
+    if (FOLD && wave > 0) {
+        const int per = (a.nb + 3) / 4; // (fold: nb <= 32, so a quarter is at most 8 slots)
+        const int e = tid & (QN_TB - 1), qd = tid >> 7;
+        const int k_lo = qd * per, k_hi = min(a.nb, k_lo + per);
+#pragma unroll
+        for (int b = 0; b < QN_S2_FOLD_BLOCKS; ++b) {
+            const double* p = a.partE + ((size_t)blk[b] * a.nb) * QN_TB + e;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[b][u] = (k_lo + u < k_hi) ? p[(size_t)(k_lo + u) * QN_TB] : 0.0;
+        }
+        if (wave <= QN_S2_FOLD_BLOCKS) { // wave 0's share of block wave - 1: entries 0..63 of quarter 0
+            const double* p = a.partE + ((size_t)blk[wave - 1] * a.nb) * QN_TB + lane;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sx[u] = (u < min(a.nb, per)) ? p[(size_t)u * QN_TB] : 0.0;
+        }
+        if (wave >= 4) { // (waves 4, 5: b; waves 6, 7: g -- committed by the update-reduce of the iteration before)
+            const double* src = (wave >= 6) ? a.F.G : a.F.b;
+#pragma unroll
+            for (int b = 0; b < QN_S2_FOLD_BLOCKS; ++b) bg[b] = src[blk[b] * QN_TB + e];
+        }
+    }
     // (Measured and dropped, rocprofv3 averages on the same box: parking the first item in LDS as the evaluation does.  This
-    // kernel's prologue consumes an accept-reduce -- a short run of the machine -- and every row is written back as well:
-    // 26.2 us without parking, 28.0-28.4 with.)
+    // kernel's prologue consumes an evaluation that is accepted -- a short run of the machine -- and every row is written back as
+    // well: 26.2 us without parking, 28.0-28.4 with.)
     v2d h[QN_S2_RPW]; // the wave's 16 rows of the first item go out before the control block is known ...
     double* hbase = a.H + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
 #pragma unroll
@@ -730,14 +804,37 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         const int ir = I * QN_TB + wave * QN_S2_RPW + (lane & 15), jc = J * QN_TB + qn_s2_col(I == J, lane, wave);
         QnS2HReq spec;
         spec.sp = a.F.S0; spec.up = a.F.UN; spec.r0v = a.F.GT; spec.gt = a.F.GT;
-        qn_s2_hvec_load(spec, ir, jc, v0);
+        qn_s2_hvec_load<!FOLD>(spec, ir, jc, v0);
         s1_r = a.F.S0[np + ir]; s1_c = ld2(a.F.S0 + np + jc);
-        y_r = a.F.Y[ir]; y_c = ld2(a.F.Y + jc);
+        if (!FOLD) { y_r = a.F.Y[ir]; y_c = ld2(a.F.Y + jc); }
+    }
+    if (FOLD && wave > 0) {
+        const int e = tid & (QN_TB - 1), qd = tid >> 7;
+#pragma unroll
+        for (int b = 0; b < QN_S2_FOLD_BLOCKS; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = acc + sv[b][u];
+            fq[b][qd][e] = acc;
+        }
+        if (wave <= QN_S2_FOLD_BLOCKS) {
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = acc + sx[u];
+            fq[wave - 1][0][lane] = acc;
+        }
+        if (wave >= 4) {
+#pragma unroll
+            for (int b = 0; b < QN_S2_FOLD_BLOCKS; ++b) fbg[b][(wave - 4) >> 1][e] = bg[b];
+        }
     }
     __syncthreads();
     qn_s2_ctl_out(a, L);
-    if (!L.mine) return;
+    const int mine = L.mine;
+    if (!mine) return;
+    const bool fold = FOLD && mine == 2; // (uniform)
     QnS2HReq q;
+    bool nrhs2;
     {
         const QnCtl& c = L.c;
         q.pending = c.pending != 0;
@@ -745,9 +842,39 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         q.sp = a.F.S0 + (size_t)c.sc * np;
         q.up = a.F.UN;
         q.gt = a.F.GT;
-        q.r0v = (c.hp_nrhs == 2) ? a.F.Y : a.F.GT; // a direction pass (bfgs.rs:47) multiplies g twice: slot 0 is what its reduce reads
+        // a direction pass (bfgs.rs:47) multiplies g twice: slot 0 is what its reduce reads.  Folded: the pass that will be asked
+        // for is an update pass after an evaluation at x + t d, a direction pass after one at x itself.
+        nrhs2 = fold ? (c.ev_kind == QN_REQ_T) : (c.hp_nrhs == 2);
+        q.r0v = nrhs2 ? a.F.Y : a.F.GT;
         if (c.sc) { v0.s_r = s1_r; v0.s_c = s1_c; }
-        if (c.hp_nrhs == 2) { v0.y0_r = y_r; v0.a0 = y_c; }
+        if (!FOLD && nrhs2) { v0.y0_r = y_r; v0.a0 = y_c; }
+    }
+    if (FOLD) { // quarters -> totals -> g+, y of the workgroup's blocks, in LDS
+        if (tid < QN_TB) {
+            if (fold) { // (uniform)
+#pragma unroll
+                for (int b = 0; b < QN_S2_FOLD_BLOCKS; ++b) {
+                    const double qi = ((fq[b][0][tid] + fq[b][1][tid]) + fq[b][2][tid]) + fq[b][3][tid]; // (the order of qn_s2_slot_sum)
+                    const double gti = qi - fbg[b][0][tid];
+                    const double yi = gti - fbg[b][1][tid];
+                    fv[b][0][tid] = nrhs2 ? yi : gti;
+                    fv[b][1][tid] = gti;
+                    fv[b][2][tid] = yi;
+                }
+            } else { // a plain pass (the run's machine asked for one the speculation had not covered): the vectors are in memory
+#pragma unroll
+                for (int b = 0; b < QN_S2_FOLD_BLOCKS; ++b) {
+                    const int gi = blk[b] * QN_TB + tid;
+                    fv[b][0][tid] = q.r0v[gi];
+                    fv[b][1][tid] = q.gt[gi];
+                }
+            }
+        }
+        __syncthreads();
+        // the first item's right-hand sides come from LDS now (blocks 0 and 1 of the list)
+        const int rr = wave * QN_S2_RPW + (lane & 15), cc = qn_s2_col(I == J, lane, wave);
+        v0.y0_r = fv[0][0][rr]; v0.y1_r = fv[0][1][rr];
+        v0.a0 = (v2d){fv[1][0][cc], fv[1][0][cc + 1]}; v0.a1 = (v2d){fv[1][1][cc], fv[1][1][cc + 1]};
     }
     // The row loop below is branch-free.  No update pending (the first pass of a run) = an update with zero coefficients and
     // zero vectors: H + 0 (0 0) = H.  (The path requires n = n_pad: no padding entries to keep at zero.)
@@ -765,6 +892,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         // the next item: where the window is refilled from while this one is consumed
         int ijn = -1;
         if (it == 0) ijn = ij1;
+        else if (FOLD) { if (it == 1) ijn = ij2; }
         else if (it + 1 < a.maxk) ijn = a.item_ij[(size_t)(it + 1) * a.G + blockIdx.x];
         const bool has_next = ijn >= 0; // (uniform)
         const int In = has_next ? (ijn >> 16) : I, Jn = has_next ? (ijn & 0xffff) : J;
@@ -772,41 +900,46 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         const size_t rstride = has_next ? np : 0; // (none left: every lane re-reads one 16-byte word of this item)
         double c0x = 0.0, c0y = 0.0, c1x = 0.0, c1y = 0.0;
         double racc[QN_S2_RPW];
-#define QN_S2_H_ROW                                                                                                   \
-            const double si = qn_lane_bcast(sr, r), ui = qn_lane_bcast(ur, r);                                       \
-            if (BFGS) {                                                                                              \
-                hn.x = hn.x + c_su * (si * uj.x + ui * sj.x);                                                        \
-                hn.y = hn.y + c_su * (si * uj.y + ui * sj.y);                                                        \
-            }                                                                                                        \
-            hn.x = hn.x + c_ss * (si * sj.x);                                                                        \
-            hn.y = hn.y + c_ss * (si * sj.y);                                                                        \
-            if (!BFGS) {                                                                                             \
-                hn.x = hn.x + c_uu * (ui * uj.x);                                                                    \
-                hn.y = hn.y + c_uu * (ui * uj.y);                                                                    \
-            }                                                                                                        \
-            qn_sym_st<NT>(hbase + (size_t)r * np, hn);                                                               \
-            const double y0 = qn_lane_bcast(y0r, r), y1 = qn_lane_bcast(y1r, r);                                     \
-            double t0 = hn.x * a0.x;                                                                                 \
-            t0 = __builtin_fma(hn.y, a0.y, t0);                                                                      \
-            double t1 = hn.x * a1.x;                                                                                 \
-            t1 = __builtin_fma(hn.y, a1.y, t1);                                                                      \
-            /* first level of the 32-value butterfly (the row's sum for y against its sum for g+, lane against lane ^ 32) at \
-               once: two sums become one register; QnWaveFold<16, 16> finishes the same tree after the last row */     \
-            racc[r] = (up ? t1 : t0) + qn_xor_lanes<32>(up ? t0 : t1);                                               \
-            c0x = __builtin_fma(hn.x, y0, c0x);                                                                      \
-            c0y = __builtin_fma(hn.y, y0, c0y);                                                                      \
-            c1x = __builtin_fma(hn.x, y1, c1x);                                                                      \
-            c1y = __builtin_fma(hn.y, y1, c1y);
 #pragma unroll
         for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
             v2d hn = h[r];
             h[r] = qn_sym_ld<NT>(hnext + (size_t)r * rstride); // the register this row frees takes the same row of the next item at once
-            QN_S2_H_ROW
+            const double si = qn_lane_bcast(sr, r), ui = qn_lane_bcast(ur, r);
+            if (BFGS) {
+                hn.x = hn.x + c_su * (si * uj.x + ui * sj.x);
+                hn.y = hn.y + c_su * (si * uj.y + ui * sj.y);
+            }
+            hn.x = hn.x + c_ss * (si * sj.x);
+            hn.y = hn.y + c_ss * (si * sj.y);
+            if (!BFGS) {
+                hn.x = hn.x + c_uu * (ui * uj.x);
+                hn.y = hn.y + c_uu * (ui * uj.y);
+            }
+            qn_sym_st<NT>(hbase + (size_t)r * np, hn);
+            const double y0 = qn_lane_bcast(y0r, r), y1 = qn_lane_bcast(y1r, r);
+            double t0 = hn.x * a0.x;
+            t0 = __builtin_fma(hn.y, a0.y, t0);
+            double t1 = hn.x * a1.x;
+            t1 = __builtin_fma(hn.y, a1.y, t1);
+            // first level of the 32-value butterfly (the row's sum for y against its sum for g+, lane against lane ^ 32) at
+            // once: two sums become one register; QnWaveFold<16, 16> finishes the same tree after the last row
+            racc[r] = (up ? t1 : t0) + qn_xor_lanes<32>(up ? t0 : t1);
+            c0x = __builtin_fma(hn.x, y0, c0x);
+            c0y = __builtin_fma(hn.y, y0, c0y);
+            c1x = __builtin_fma(hn.x, y1, c1x);
+            c1y = __builtin_fma(hn.y, y1, c1y);
         }
-#undef QN_S2_H_ROW
         if (!qn_s2_col_on(diag, lane, wave)) { c0x = 0.0; c0y = 0.0; c1x = 0.0; c1y = 0.0; }
         // the next item's vector entries go out now: they fly while this item's sums are folded, exchanged and stored
-        if (has_next) qn_s2_hvec_load(q, In * QN_TB + wave * QN_S2_RPW + (lane & 15), Jn * QN_TB + qn_s2_col(In == Jn, lane, wave), v0);
+        if (has_next) {
+            const int irn = In * QN_TB + wave * QN_S2_RPW + (lane & 15), ccn = qn_s2_col(In == Jn, lane, wave);
+            qn_s2_hvec_load<!FOLD>(q, irn, Jn * QN_TB + ccn, v0);
+            if (FOLD) { // (blocks 2 (it + 1), 2 (it + 1) + 1 of the list)
+                const int rr = wave * QN_S2_RPW + (lane & 15), bI = 2 * (it + 1), bJ = bI + 1;
+                v0.y0_r = fv[bI][0][rr]; v0.y1_r = fv[bI][1][rr];
+                v0.a0 = (v2d){fv[bJ][0][ccn], fv[bJ][0][ccn + 1]}; v0.a1 = (v2d){fv[bJ][1][ccn], fv[bJ][1][ccn + 1]};
+            }
+        }
         QnWaveFold<QN_S2_RPW, 16>::run(racc, lane); // lanes with (lane & 1) == 0: total of row (lane >> 1) & 15 for rhs lane >> 5
         colred[wave][0][2 * lane] = c0x;
         colred[wave][0][2 * lane + 1] = c0y;
@@ -815,7 +948,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         if ((lane & 1) == 0) {
             const int rhs = lane >> 5, rl = wave * QN_S2_RPW + ((lane >> 1) & 15);
             if (diag) colsum[rhs][rl] = racc[0]; // the column part of a diagonal tile lands in the same slot: park the row part
-            else a.part[(((size_t)I * a.nb + J) * 2 + rhs) * QN_TB + rl] = racc[0];
+            else a.part[(unsigned)(((I * a.nb + J) * 2 + rhs) * QN_TB + rl)] = racc[0]; // (32-bit slot offsets: nb <= 2048)
         }
         __syncthreads();
         if (tid < 2 * QN_TB) {
@@ -823,12 +956,45 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
             double acc = colred[0][crhs][c];
 #pragma unroll
             for (int w = 1; w < QN_S2_WAVES; ++w) acc = acc + colred[w][crhs][c];
-            if (diag) a.part[(((size_t)I * a.nb + I) * 2 + crhs) * QN_TB + c] = colsum[crhs][c] + acc; // row part + column part
-            else a.part[(((size_t)J * a.nb + I) * 2 + crhs) * QN_TB + c] = acc;
+            if (diag) a.part[(unsigned)(((I * a.nb + I) * 2 + crhs) * QN_TB + c)] = colsum[crhs][c] + acc; // row part + column part
+            else a.part[(unsigned)(((J * a.nb + I) * 2 + crhs) * QN_TB + c)] = acc;
         }
         if (!has_next) break;
         I = In; J = Jn; hbase = hnext;
         __syncthreads(); // the LDS staging areas are rewritten by the next item
+    }
+    if (!fold) return; // (uniform)
+    // Folded accept-reduce, the owner's part: the workgroup that holds the diagonal item (R, R) writes block R of the vectors
+    // (g+, y, x+, s = x+ - x: bfgs.rs:94-99) and block R's five sums -- after its tiles, because nothing in this launch reads them
+    // (every workgroup has formed the entries it needs itself) and the tiles are what the launch is waiting for.
+    const QnEvalReq qe = qn_s2_eval_req<false>(L.c, true);
+    const double* __restrict__ x = a.F.X0 + (size_t)qe.xc * np;
+    double* __restrict__ xt = a.F.X0 + (size_t)(1 - qe.xc) * np;
+    const double* __restrict__ spv = a.F.S0 + (size_t)qe.sc * np;
+    double* __restrict__ sstage = a.F.S0 + (size_t)(1 - qe.sc) * np;
+#pragma unroll 1
+    for (int k = 0; k < QN_S2_FOLD_ITEMS; ++k) {
+        const int ij_k = k == 0 ? ij : (k == 1 ? ij1 : ij2);
+        if (ij_k < 0 || (ij_k >> 16) != (ij_k & 0xffff)) continue; // (uniform)
+        const int R = ij_k >> 16;
+        __syncthreads(); // fred is reused
+        if (tid < QN_TB) {
+            const int gi = R * QN_TB + tid;
+            const double gti = fv[2 * k][1][tid], yi = fv[2 * k][2][tid];
+            double di;
+            const double xi = x[gi];
+            const double xti = qn_trial_entry(qe, x, a.F.VV, spv, a.F.UN, gi, &di);
+            const double si = xti - xi; // s = x+ - x, not t d (bfgs.rs:96)
+            a.F.GT[gi] = gti;
+            a.F.Y[gi] = yi;
+            xt[gi] = xti;
+            sstage[gi] = si;
+            double p[8] = {yi * yi, yi * si, gti * gti, si * si, si * gti, 0.0, 0.0, 0.0};
+            QnWaveFold<8, 32>::run(p, lane);
+            if ((lane & 7) == 0) fred[wave][lane >> 3] = p[0]; // (threads 0..127 = waves 0, 1)
+        }
+        __syncthreads();
+        if (tid < QN_S2_NR) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = fred[0][tid] + fred[1][tid]; // (as s2_vec_kernel)
     }
 }
 

@@ -78,6 +78,42 @@ def test_symmetric_path_is_bitwise_reproducible_across_modes(qn, qo):
         assert np.array_equal(other[2], runs[0][2]) and np.array_equal(other[3], runs[0][3])
 
 
+@pytest.mark.parametrize("method,lsname", [("bfgs", "mt"), ("dfp", "mt"), ("bfgs", "bt")])
+def test_folded_accept_reduce_is_the_same_run_bit_for_bit(qn, qo, method, lsname):
+    """set_tiling(-6, 0): the launch that runs the update tiles also turns the accepted evaluation's slots into vectors (four
+    launches per iteration; s2_hpass_kernel<.., FOLD>).  Same sums in the same order: the trace, the iterates and the inverse
+    Hessian must equal the default five-launch pattern bit for bit, pipelined and synchronous, and across a continued call."""
+    n = 1280
+    q, b, x0, _ = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+    base, st0 = _run(qn, method, lsname, obj, x0, 35)
+    tr0, xs0 = base.trace()
+    for sync in (0, 1):
+        s, st = _run(qn, method, lsname, obj, x0, 35, tiling=(-6, 0), sync=sync)
+        tr, xs = s.trace()
+        assert st == st0 and tr == tr0
+        assert np.array_equal(xs, xs0) and np.array_equal(s.approx_inv_hessian(), base.approx_inv_hessian())
+        assert s.stats()["launches"] < base.stats()["launches"] or sync
+    # a run that converges (the speculative tiles of the last accepted point are not followed by a pass) and is then continued
+    tol = 1e-3
+    pair = []  # (tol 1e-3: converges in a few dozen iterations)
+    for tiling in (None, (-6, 0)):
+        s = (qn.BFGS if method == "bfgs" else qn.DFP)(tol, x0)
+        if tiling:
+            s.set_tiling(*tiling)
+        ls = qn.MoreThuente() if lsname == "mt" else qn.BackTracking(1e-4, 0.5)
+        s.minimize(ls, obj, 200, 20)
+        k1, x1 = s.k(), s.x()
+        s.set_x(x1 + 0.25)  # ... from a new point, on the inverse Hessian the first call left
+        try:
+            s.minimize(ls, obj, 15, 20)
+        except qn.MaxIterReached:
+            pass
+        pair.append((k1, s.k(), s.x(), s.approx_inv_hessian()))
+    assert pair[0][0] == pair[1][0] and pair[0][1] == pair[1][1]
+    assert np.array_equal(pair[0][2], pair[1][2]) and np.array_equal(pair[0][3], pair[1][3])
+
+
 def test_warm_restart_continues_on_the_mirrored_hessian(qn, qo):
     """Two minimize calls of 10 iterations follow one of 20: the lower triangle restored between the calls is the right one
     (the second call's first pass applies the pending update to it)."""
