@@ -795,6 +795,9 @@ struct qn_solver {
     // second-generation symmetric path (qn_sym2.hip.h): static work lists, per-workgroup scalars, double-buffered control block
     int* s2_items = nullptr;
     int s2_G = 0, s2_nb = 0, s2_maxk = 0, s2_inorder = 0;
+    int s2_sl_first = 0, s2_sl_per = 0, s2_sl_cfg = -1; // row slivers (QnS2Args.sl_first / sl_per); the switches the lists were built for
+    bool no_sliver = false;    // diagnostics: sym2 without row slivers (round 2's work lists)
+    bool h_sliver_whole = false; // the diagonal tiles that sliver rows read are complete (both triangles): kept so by sliver-mode update passes
     double* s2_partE = nullptr; // [nb][nb][128]: row / column slots of the last evaluation (QnS2Args.partE)
     double* s2_wgS = nullptr; // [2][s2_trows][QN_S2_ROW]: the sums a servicing launch leaves for the next launch's prologue, by launch parity
     int s2_trows = 0;
@@ -904,11 +907,21 @@ static int solver_alloc_fused(qn_solver* s, bool sym) {
 static int solver_alloc_sym2(qn_solver* s) {
     const int nb = s->T.n_pad / QN_TB;
     hipStream_t st = s->ctx->stream;
-    if (s->s2_nb != nb) {
+    const int cfg = (s->fold ? 1 : 0) | (s->no_sliver ? 2 : 0);
+    if (s->s2_nb != nb || s->s2_sl_cfg != cfg) {
         (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE);
         s->s2_items = nullptr; s->s2_wgS = nullptr; s->s2_partE = nullptr;
+        s->s2_nb = 0;
         const int nitems = nb * (nb + 1) / 2;
         const int G = std::min(nitems, QN_S2_MAXG);
+        // Row slivers (qn_sym2.hip.h, qn_s2_eval_sliver): when the tiles do not deal out evenly and the L left over can be cut into
+        // one 8-row sliver per workgroup (16 L = G: n = 4096 on 256 workgroups), the last L diagonal tiles leave the work lists.
+        // (Every workgroup then has the same, even number of items: the sliver joins the last PAIR of the evaluation kernel.)
+        int L = nitems > G ? nitems % G : 0;
+        if (!(L > 0 && 16 * L == G && L <= nb && ((nitems - L) / G) % 2 == 0 && !s->fold && !s->no_sliver)) L = 0;
+        s->s2_sl_first = nb - L;
+        s->s2_sl_per = L ? G / L : 0;
+        s->s2_sl_cfg = cfg;
         std::vector<std::vector<int>> lists(G);
         std::vector<std::pair<double, int>> heap; // (-load, workgroup): max-heap on the least loaded
         for (int g = 0; g < G; ++g) heap.push_back({0.0, -g});
@@ -923,7 +936,7 @@ static int solver_alloc_sym2(qn_solver* s) {
         };
         // the first min(2 G, items) items go out in order -- item t to workgroup t mod G -- so the kernels compute a workgroup's
         // first two items from its index (qn_s2_item_of_index); the rest to whoever has streamed least so far
-        const int inorder = std::min(nitems, 2 * G);
+        const int inorder = std::min(nitems - L, 2 * G);
         std::vector<double> load0(G, 0.0);
         int handed = 0;
         auto hand = [&](int I, int J, double cost) {
@@ -941,7 +954,7 @@ static int solver_alloc_sym2(qn_solver* s) {
         };
         for (int I = 0; I < nb; ++I)
             for (int J = I + 1; J < nb; ++J) hand(I, J, 1.0);
-        for (int I = 0; I < nb; ++I) hand(I, I, 0.5625);
+        for (int I = 0; I < nb - L; ++I) hand(I, I, 0.5625);
         size_t maxk = 0;
         for (int g = 0; g < G; ++g) maxk = std::max(maxk, lists[g].size());
         std::vector<int> items(maxk * (size_t)G, -1); // [k][g]: the workgroup's k-th item; -1 ends its list
@@ -1075,6 +1088,7 @@ extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_sp
     if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; }
     if (rows_per_block == -3) { s->no_sym = 1; rows_per_block = 0; }   // diagnostics: fused row kernels on the full matrices
     if (rows_per_block == -5) { s->newton_force_lu = 1; return QN_OK; } // diagnostics: Newton by pivoted LU even for an SPD Hessian
+    if (rows_per_block == -7) { s->no_sliver = !s->no_sliver; return QN_OK; } // diagnostics: sym2 without row slivers (toggles)
     if (rows_per_block == -6) { s->fold = 1; return QN_OK; }           // measurement: sym2 with the folded accept-reduce (see qn_solver::fold)
     if (rows_per_block == -4) { s->no_sym2 = 1; rows_per_block = 0; }  // diagnostics: first-generation symmetric tile kernels (8 launches per iteration)
     if (rows_per_block == -2) { s->no_defer = 1; rows_per_block = 0; } // diagnostics: fused kernels, update step not deferred // diagnostics: -1 selects the generic (non-fused) kernels
@@ -1590,6 +1604,7 @@ static int s2_launch(Run& r, int kind) {
             else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         }
         s->h_lower_stale = true; s->h_diag_stale = true;
+        s->h_sliver_whole = a.sl_per != 0; // (sliver rows update every entry of their tiles; without them only the upper sub-blocks are kept)
         break;
     case QN_S2_HREDUCE: hipLaunchKernelGGL(s2_hreduce_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
     default: hipLaunchKernelGGL(s2_advance_kernel, dim3(1), dim3(128), 0, st, a); break;
@@ -2159,6 +2174,10 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         // folded accept-reduce (s2_hpass_kernel): every workgroup holds at most three items, so the blocks whose slots it sums fit
         // its LDS staging area -- n <= 4096 with 256 workgroups; larger n keeps the accept-reduce launch (7 us of 250+)
         a.fold = (s->s2_maxk <= 3 && s->s2_nb <= 32 && s->fold) ? 1 : 0;
+        a.sl_first = s->s2_sl_first; a.sl_per = s->s2_sl_per;
+        // sliver rows read the diagonal tiles sl_first .. nb - 1 whole: a run of another kind since the last sliver-mode update
+        // pass (or none yet) may have left their lower sub-blocks behind -- restore them once
+        if (a.sl_per && !s->h_sliver_whole) { QNCHK(ensure_full_h(s)); s->h_sliver_whole = true; }
         a.trace = s->V.trace; a.xtrace = s->V.xtrace;
         a.nt = s->T.n_pad >= 8192; // H past the Infinity Cache: every byte is touched once per pass
         // (no synchronisation: the copy is stream-ordered in front of the launches, the mirror is pinned, and the host does not

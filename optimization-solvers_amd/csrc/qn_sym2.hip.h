@@ -62,6 +62,9 @@ struct QnS2Args {
     double* partE;       // [nb][nb][128] row / column slots of the last evaluation (Q (x + t d)): a buffer of its own, because the launch that
                          // turns them into vectors also writes the update pass's slots (folded accept-reduce)
     int fold;            // the accept-reduce runs inside the update-tile launch (workgroups hold <= 3 items: n <= 4096)
+    int sl_first, sl_per; // ROW SLIVERS (sl_per != 0): the diagonal tiles sl_first .. nb - 1 are not on any work list; each is cut
+                         // into sl_per slivers of 8 rows, one per workgroup (workgroup g: tile sl_first + g / sl_per, sliver g % sl_per,
+                         // wave w its row 8 (g % sl_per) + w), taken after the workgroup's last item -- see qn_s2_eval_sliver
     double* wgS;         // [2][QN_S2_ROW][trows] (column-major) what a servicing launch hands the state machine, one row of sums per workgroup:
                          // evaluation tiles (G rows, QN_S2_NSE sums), accept-reduce (nb rows, QN_S2_NR), update-reduce (nb rows: y'u, u'g+).
                          // Launch i writes half i & 1 and launch i + 1 -- whose prologue consumes the request -- reads it: the address
@@ -81,8 +84,10 @@ struct QnS2Args {
 };
 #ifdef QN_S2_STAMPS
 #define QN_S2_STAMP(k) do { if (threadIdx.x == 0 && a.dbg && blockIdx.x < 256) a.dbg[(((size_t)(a.slot & 63)) * 256 + blockIdx.x) * 16 + (k)] = wall_clock64(); } while (0)
+#define QN_S2_STAMP_T(k, t) do { if (threadIdx.x == (t) && a.dbg && blockIdx.x < 256) a.dbg[(((size_t)(a.slot & 63)) * 256 + blockIdx.x) * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define QN_S2_STAMP(k) do { } while (0)
+#define QN_S2_STAMP_T(k, t) do { } while (0)
 #endif
 
 struct QnS2Lds {
@@ -180,8 +185,11 @@ __device__ __forceinline__ double qn_lane_bcast(const double v, const int l) {
 // (Measured and dropped, same-box A/B: waves 1..7 sleeping 1-2 us before their 112 KB burst so that wave 0's control block and
 // table come back from an idle memory system -- 12.2 k it/s without, 11.3-11.9 k with: the burst itself is on the critical path.)
 
-template <int KIND>
-__device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L) {
+struct QnS2NoEarly { __device__ __forceinline__ void operator()() const {} };
+// `early`: requests the caller wants in flight while the machine runs (issued right behind the control block and the table, so
+// that those two still come back first: a wave's loads return in order)
+template <int KIND, class Early = QnS2NoEarly>
+__device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L, Early&& early = Early()) {
     const int lane = threadIdx.x; // (wave 0)
     const bool leader = blockIdx.x == 0;
     constexpr int NW = (int)(sizeof(QnCtl) / 8);
@@ -194,16 +202,26 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L)
     if (64 + lane < NW) cw1 = cin[64 + lane];
     double tr[QN_S2_PCH][QN_S2_NSE];
     const double* T = a.wgS + (size_t)(a.parity ^ 1) * (size_t)a.trows * QN_S2_ROW;
+    const bool no_decision = KIND == QN_S2_HREDUCE && !a.fold; // (uniform) nothing to decide between the update tiles and their reduction
+    if (!no_decision) {
 #pragma unroll
-    for (int k = 0; k < QN_S2_NSE; ++k)
+        for (int k = 0; k < QN_S2_NSE; ++k)
 #pragma unroll
-        for (int j = 0; j < QN_S2_PCH; ++j) tr[j][k] = T[(size_t)k * a.trows + j * 64 + lane]; // (trows >= 256)
+            for (int j = 0; j < QN_S2_PCH; ++j) tr[j][k] = T[(size_t)k * a.trows + j * 64 + lane]; // (trows >= 256)
+    }
+    early();
     if (lane < NW) lc[lane] = cw0;
     if (64 + lane < NW) lc[64 + lane] = cw1;
     __builtin_amdgcn_wave_barrier(); // (one wave: its LDS accesses execute in program order; this only pins the compiler's order)
     QN_S2_STAMP(9);
     QnCtl& c = L.c; // (in LDS: a private register copy of all ~150 words does not fit beside the machine's own temporaries -- 255 spills)
     int mine = 0;
+    if (no_decision) { // pass the control block on (with the folded accept-reduce this prologue is where the machine sees the accepted point)
+        mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 1;
+        if (lane == 0) { if (mine) c.serviced = 2; L.mine = mine; }
+        __builtin_amdgcn_s_setprio(0);
+        return;
+    }
     const int ph = c.phase;
     if (ph == QN_PH_DONE) { // launches enqueued past the end of the run: pass the control block on, nothing else
         if (lane == 0) L.mine = 0;
@@ -375,7 +393,9 @@ struct QnS2EvalVec {
     double x_r, v_r, s_r, u_r, b_r, g_r;
     v2d x_c, v_c, s_c, u_c;
 };
-__device__ __forceinline__ void qn_s2_eval_vec_load(const QnS2Args& a, const double* x, const double* sp, const int ir, const int jc, QnS2EvalVec& v) {
+__device__ __forceinline__ void qn_s2_eval_vec_load(const QnS2Args& a, const double* x, const double* sp, const unsigned ir, const unsigned jc, QnS2EvalVec& v) {
+    // (unsigned indices: the loads take a scalar base and a 32-bit lane offset -- as 64-bit lane addresses, ten of them hoisted out
+    // of the item loop, they pushed the row loops' window into scratch memory)
     v.x_r = x[ir]; v.v_r = a.F.VV[ir]; v.s_r = sp[ir]; v.u_r = a.F.UN[ir]; v.b_r = a.F.b[ir]; v.g_r = a.F.G[ir];
     v.x_c = ld2(x + jc); v.v_c = ld2(a.F.VV + jc); v.s_c = ld2(sp + jc); v.u_c = ld2(a.F.UN + jc);
 }
@@ -452,6 +472,57 @@ __device__ __forceinline__ double qn_s2_eval_item(const QnEvalReq& q, const QnS2
     QnWaveFold<QN_S2_RPW, 32>::run(racc, lane); // lanes with (lane & 3) == 0 hold the total of row lane >> 2
     return racc[0];
 }
+// ROW SLIVERS (round 3).  nb (nb + 1) / 2 tiles do not divide by the 256 workgroups: at n = 4096 it is 528 = 2 x 256 + 16, so
+// sixteen workgroups streamed a third tile while 240 CUs idled -- in-kernel time stamps showed every tile kernel's last workgroups
+// ending 4-5 us after the median one, a fifth of the launch.  Now the 512 items that deal out evenly are the work lists (the
+// off-diagonal tiles and the first diagonal ones; the list order puts the diagonal tiles last), and the sixteen diagonal tiles
+// that are left over are cut into 16 slivers of 8 rows each -- 256 slivers, one per workgroup, one ROW per wave.  A row of a
+// diagonal tile is used WHOLE (all 128 columns: the tile is symmetric in memory, Q by construction and H because the slivers of
+// the update pass maintain every entry of these tiles), so a sliver has a row part only: no column part, no extra slots, the
+// reduce kernels are unchanged.  The row is requested through the refill path of the workgroup's last item (stride 0: every
+// register of the window receives it), its vector entries with the last item's, and its sums join the last group's exchange.
+struct QnS2Sliver {
+    int D, row; // diagonal tile, and this WAVE's row in it
+};
+__device__ __forceinline__ QnS2Sliver qn_s2_sliver(const QnS2Args& a, const int wave) {
+    QnS2Sliver s;
+    const int per = a.sl_per ? a.sl_per : 1; // (no slivers: the result is not used -- but a division by zero would let the compiler assume sl_per != 0 everywhere)
+    s.D = a.sl_first + (int)blockIdx.x / per;
+    s.row = 8 * ((int)blockIdx.x % per) + wave;
+    return s;
+}
+// evaluation: row i of Q_DD against the trial point's block D, in two steps.  qn_s2_sliver_prep turns the sliver's vector entries
+// into the trial point's entries as soon as they arrive (before the last item's row loop: seven values stay live across it instead
+// of the fourteen loaded ones -- the loop has no registers to spare); qn_s2_eval_sliver consumes the row.  It returns (lane 48) the
+// row's share of q_i; the wave's scalar sums -- xt_i (Q_DD xt_D - 2 b)_i, d_i (Q_DD xt_D - b)_i with b_i leaving on the lane that
+// holds Q_ii (see CONDITIONING above), g_i d_i and the non-finite count -- go to sred_w as an item's do.
+struct QnS2SliverVec {
+    v2d xtj;                 // the trial point at this lane's two columns of block D
+    double xr, dr, b, gd, nf; // the wave's row: xt_i, d_i, b_i, g_i d_i, d_i non-finite (the same in every lane)
+};
+__device__ __forceinline__ QnS2SliverVec qn_s2_sliver_prep(const QnEvalReq& q, const QnS2EvalVec& v) {
+    QnS2SliverVec o;
+    double dr, d0, d1;
+    o.xr = qn_s2_trial(q, v.x_r, v.v_r, v.s_r, v.u_r, dr);
+    o.dr = dr;
+    o.xtj.x = qn_s2_trial(q, v.x_c.x, v.v_c.x, v.s_c.x, v.u_c.x, d0);
+    o.xtj.y = qn_s2_trial(q, v.x_c.y, v.v_c.y, v.s_c.y, v.u_c.y, d1);
+    o.b = v.b_r;
+    o.gd = v.g_r * dr;
+    o.nf = isfinite(dr) ? 0.0 : 1.0;
+    return o;
+}
+__device__ __forceinline__ double qn_s2_eval_sliver(const QnS2SliverVec& v, const v2d hv, const int row, const int lane, double* __restrict__ sred_w) {
+    double t0 = hv.x * v.xtj.x;
+    t0 = __builtin_fma(hv.y, v.xtj.y, t0);
+    const double bsel = (lane == (row >> 1)) ? v.b : 0.0;
+    double sv[8] = {v.xr * (t0 - (bsel + bsel)), v.dr * (t0 - bsel), 0.0, 0.0, 0.0, 0.0, t0, 0.0};
+    if (lane == 0) { sv[4] = v.gd; sv[5] = v.nf; }
+    QnWaveFold<8, 32>::run(sv, lane);
+    if ((lane & 7) == 0 && lane < 48) sred_w[lane >> 3] = sv[0];
+    return sv[0]; // lane 48: the row's total
+}
+
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
     __shared__ double colsum[3][QN_TB];
@@ -465,29 +536,36 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     // functions of blockIdx: no load.
     const int ij0 = qn_s2_first_item(blockIdx.x, a.nb);
     const int ij1 = qn_s2_second_item(a); // the second item: what the parked window is refilled from
-    if (wave == 0) qn_s2_prologue_w0<QN_S2_EVAL>(a, L);
     // The wave's 16 rows of the first item are requested before the control block is known (their addresses do not depend on
     // it), and so are the first item's vector entries for BOTH settings of the two buffer toggles the control block holds
     // (x / trial point, pending / staged s); every register of the window is refilled with the next item's row the moment its
     // row is consumed: 128 KB in flight per workgroup across item boundaries, reductions and barriers.
+    // WAVE 0 requests no tile rows before the workgroup barrier (round 3, in-kernel time stamps): its sixteen loads, issued
+    // after the machine, sat behind the other seven waves' 240 in the CU's memory queue -- the barrier came 0.6 to 2.6 us after
+    // the machine had finished, whatever it took -- and nothing it loads is needed before the first item is done: its rows of
+    // the first item are parked by the other waves, its window takes the SECOND item after the barrier and fills while the
+    // first is consumed from LDS.  Only its vector entries go out early, behind the control block.
     v2d h[QN_S2_RPW];
     const bool parked = ij1 >= 0; // (uniform) a workgroup with one item parks nothing
-    {
-        // wave 0 comes here after the prologue: when the first item is parked its rows are in LDS already (below), and its window
-        // takes the second item's rows at once
-        const int ijw = (wave == 0 && parked) ? ij1 : ij0;
-        const int I = ijw >> 16, J = ijw & 0xffff;
-        const double* qb = a.Q + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
-#pragma unroll
-        for (int r = 0; r < QN_S2_RPW; ++r) h[r] = ld2(qb + (size_t)r * np);
-    }
     QnS2EvalVec va, v1; // va: x = X0[0], s = S0[0]; v1 holds the other halves' x and s entries
-    {
+    auto vec_spec = [&]() {
         const int I = ij0 >> 16, J = ij0 & 0xffff;
         const int ir = I * QN_TB + wave * QN_S2_RPW + (lane & 15), jc = J * QN_TB + 2 * lane;
         qn_s2_eval_vec_load(a, a.F.X0, a.F.S0, ir, jc, va);
         v1.x_r = a.F.X0[np + ir]; v1.s_r = a.F.S0[np + ir];
         v1.x_c = ld2(a.F.X0 + np + jc); v1.s_c = ld2(a.F.S0 + np + jc);
+    };
+    auto window_load = [&](const int ijw) {
+        const int I = ijw >> 16, J = ijw & 0xffff;
+        const double* qb = a.Q + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
+#pragma unroll
+        for (int r = 0; r < QN_S2_RPW; ++r) h[r] = ld2(qb + (size_t)r * np);
+    };
+    if (wave == 0) {
+        qn_s2_prologue_w0<QN_S2_EVAL>(a, L, vec_spec);
+    } else {
+        window_load(ij0);
+        vec_spec();
     }
     // PARKING.  The prologue of wave 0 -- one memory round trip, the sums of 256 rows, the state machine on one lane -- takes
     // 6-9 us, and the 128 KB register window lands in 5.  Round 2 let the memory system idle until the decision was there.
@@ -499,26 +577,33 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     if (parked && wave != 0) {
         const int I1 = ij1 >> 16, J1 = ij1 & 0xffff;
         const double* q1 = a.Q + (size_t)(I1 * QN_TB + wave * QN_S2_RPW) * np + (size_t)J1 * QN_TB + qn_s2_col(I1 == J1, lane, wave);
-#pragma unroll
-        for (int r = 0; r < QN_S2_RPW; ++r) {
-            park[wave][r][lane] = h[r];
-            h[r] = ld2(q1 + (size_t)r * np);
-        }
+        // (wave 0's rows are requested BEFORE the second item's: a wave's loads return in order, and behind the refills these three
+        // -- which the barrier below waits for -- arrived with the last byte of the second window, 9.5 us into the kernel: the
+        // workgroup then started on the first item when both had landed, however early the machine was done)
         const int I0 = ij0 >> 16, J0 = ij0 & 0xffff;
         const double* q0 = a.Q + (size_t)(I0 * QN_TB) * np + (size_t)J0 * QN_TB + 2 * lane; // wave 0's rows: no clone lanes (qn_s2_col(., ., 0) = 2 lane)
         const int r0 = (wave - 1) * 3;
         v2d t3[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) t3[k] = ld2(q0 + (size_t)min(r0 + k, QN_S2_RPW - 1) * np);
+        QN_S2_STAMP_T(6, 448); // (wave 7: everything requested)
+#pragma unroll
+        for (int r = 0; r < QN_S2_RPW; ++r) {
+            park[wave][r][lane] = h[r];
+            h[r] = ld2(q1 + (size_t)r * np);
+        }
+        QN_S2_STAMP_T(7, 448); // (its sixteen rows parked)
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (r0 + k < QN_S2_RPW) park[0][r0 + k][lane] = t3[k];
+            if (r0 + k < QN_S2_RPW) park[0][r0 + k][lane] = t3[k]; // (they came in right behind the wave's own sixteen)
+        QN_S2_STAMP_T(8, 448);
     }
     QN_S2_STAMP(1);
     __syncthreads();
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
     QN_S2_STAMP(2);
+    if (wave == 0) window_load(parked ? ij1 : ij0); // (parked: its rows of the first item are in LDS)
     const QnEvalReq q = qn_s2_eval_req<true>(L.c, false);
     const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
     const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
@@ -552,17 +637,36 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
             const int I_ = ij_ >> 16, J_ = ij_ & 0xffff;
             return a.Q + (size_t)(I_ * QN_TB + wave * QN_S2_RPW) * np + (size_t)J_ * QN_TB + qn_s2_col(I_ == J_, lane, wave);
         };
+        // (row slivers: every workgroup has exactly a.maxk items and one sliver, which joins the last group in item c's place)
+        const bool sliver = a.sl_per != 0 && ijc < 0; // (uniform)
+        const QnS2Sliver sl = qn_s2_sliver(a, wave);
+        const double* slp = a.Q + (size_t)(sl.D * QN_TB + sl.row) * np + (size_t)sl.D * QN_TB + 2 * lane;
+        QnS2SliverVec slv{};
         double row_a, row_b = 0.0, row_c = 0.0;
         if (parked && it == 0) row_a = qn_s2_eval_item<true>(q, va, diag_a, lane, wave, h, &park[wave][0][0], nullptr, 0, colred[0][wave], sred[0][wave]);
-        else row_a = qn_s2_eval_item<false>(q, va, diag_a, lane, wave, h, nullptr, tile_ptr(has_b ? ijb : ija), has_b ? np : 0, colred[0][wave], sred[0][wave]);
+        else row_a = qn_s2_eval_item<false>(q, va, diag_a, lane, wave, h, nullptr, has_b ? tile_ptr(ijb) : (sliver ? slp : tile_ptr(ija)), has_b ? np : 0, colred[0][wave], sred[0][wave]);
         if (has_b) {
             qn_s2_eval_vec_load(a, x, sp, Ib * QN_TB + wave * QN_S2_RPW + (lane & 15), Jb * QN_TB + 2 * lane, vb);
-            row_b = qn_s2_eval_item<false>(q, vb, diag_b, lane, wave, h, nullptr, tile_ptr(ijc >= 0 ? ijc : ijb), ijc >= 0 ? np : 0, colred[1][wave], sred[1][wave]);
+            if (sliver) { // the sliver's entries fly behind item b's
+                // (the indices pass through an empty asm: as loop invariants the ten lane addresses were formed once, in front of
+                // the item loop, and held in twenty registers across the row loops)
+                unsigned sir = sl.D * QN_TB + sl.row, sjc = sl.D * QN_TB + 2 * lane;
+                asm volatile("" : "+v"(sir), "+v"(sjc));
+                qn_s2_eval_vec_load(a, x, sp, sir, sjc, va);
+                slv = qn_s2_sliver_prep(q, va);
+            }
+            row_b = qn_s2_eval_item<false>(q, vb, diag_b, lane, wave, h, nullptr, ijc >= 0 ? tile_ptr(ijc) : (sliver ? slp : tile_ptr(ijb)), ijc >= 0 ? np : 0, colred[1][wave], sred[1][wave]);
+        } else if (sliver) {
+            unsigned sir = sl.D * QN_TB + sl.row, sjc = sl.D * QN_TB + 2 * lane;
+            asm volatile("" : "+v"(sir), "+v"(sjc));
+            qn_s2_eval_vec_load(a, x, sp, sir, sjc, va);
+            slv = qn_s2_sliver_prep(q, va);
         }
         // the next item's vector entries go out now: for the item that joins this group, or for the next group while this
         // one's sums are exchanged and stored
         if (ijc >= 0) qn_s2_eval_vec_load(a, x, sp, Ic * QN_TB + wave * QN_S2_RPW + (lane & 15), Jc * QN_TB + 2 * lane, va);
         if (take_c) row_c = qn_s2_eval_item<false>(q, va, diag_c, lane, wave, h, nullptr, tile_ptr(ijc), 0, colred[2][wave], sred[2][wave]);
+        if (sliver) row_c = qn_s2_eval_sliver(slv, h[0], sl.row, lane, sred[2][wave]); // (h[0]: the window holds the sliver's row sixteen times)
         if (it == 0) { qn_keepalive(row_a); qn_keepalive(row_b); qn_keepalive(row_c); QN_S2_STAMP(3); }
         __syncthreads();
         if (it == 0) QN_S2_STAMP(4);
@@ -575,14 +679,14 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
                 const bool dg = e == 0 ? diag_a : (e == 1 ? diag_b : diag_c);
                 const int Ie = e == 0 ? Ia : (e == 1 ? Ib : Ic), Je = e == 0 ? Ja : (e == 1 ? Jb : Jc);
                 if (dg) colsum[e][cidx] = acc; // both parts of a diagonal tile belong to block-row I: one slot
-                else a.partE[((size_t)Je * a.nb + Ie) * QN_TB + cidx] = acc;
+                else a.partE[(unsigned)((Je * a.nb + Ie) * QN_TB + cidx)] = acc;
             }
         }
         if (tid < QN_S2_NSE) { // (items in list order: a, b, c; scalars 2..5 exist on diagonal items only)
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
-                const bool have = e == 0 || (e == 1 && has_b) || (e == 2 && take_c);
-                const bool dg = e == 0 ? diag_a : (e == 1 ? diag_b : diag_c);
+                const bool have = e == 0 || (e == 1 && has_b) || (e == 2 && (take_c || sliver));
+                const bool dg = e == 0 ? diag_a : (e == 1 ? diag_b : (diag_c || sliver));
                 if (have && (tid < 2 || dg)) wgk = wgk + qn_s2_wave_total(sred[e], tid);
             }
         }
@@ -591,18 +695,19 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
             const int rl = wave * QN_S2_RPW + (lane >> 2);
             double v = row_a;
             if (diag_a) v = v + colsum[0][rl];
-            a.partE[((size_t)Ia * a.nb + Ja) * QN_TB + rl] = v;
+            a.partE[(unsigned)((Ia * a.nb + Ja) * QN_TB + rl)] = v;
             if (has_b) {
                 v = row_b;
                 if (diag_b) v = v + colsum[1][rl];
-                a.partE[((size_t)Ib * a.nb + Jb) * QN_TB + rl] = v;
+                a.partE[(unsigned)((Ib * a.nb + Jb) * QN_TB + rl)] = v;
             }
             if (take_c) {
                 v = row_c;
                 if (diag_c) v = v + colsum[2][rl];
-                a.partE[((size_t)Ic * a.nb + Jc) * QN_TB + rl] = v;
+                a.partE[(unsigned)((Ic * a.nb + Jc) * QN_TB + rl)] = v;
             }
         }
+        if (sliver && lane == 48) a.partE[(unsigned)((sl.D * a.nb + sl.D) * QN_TB + sl.row)] = row_c;
         if (it == 0) QN_S2_STAMP(5);
         if (ijc < 0 || take_c) break;
         ija = ijc; ijb = ijd;
@@ -715,7 +820,7 @@ struct QnS2HVec {
     v2d s_c, u_c, a0, a1;
 };
 template <bool RHS = true> // (false: s and u only -- the right-hand sides come from LDS)
-__device__ __forceinline__ void qn_s2_hvec_load(const QnS2HReq& q, const int ir, const int jc, QnS2HVec& v) {
+__device__ __forceinline__ void qn_s2_hvec_load(const QnS2HReq& q, const unsigned ir, const unsigned jc, QnS2HVec& v) {
     v.s_r = q.sp[ir]; v.u_r = q.up[ir];
     v.s_c = ld2(q.sp + jc); v.u_c = ld2(q.up + jc);
     if (RHS) { v.y0_r = q.r0v[ir]; v.y1_r = q.gt[ir]; v.a0 = ld2(q.r0v + jc); v.a1 = ld2(q.gt + jc); }
@@ -751,8 +856,24 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     int ij = qn_s2_first_item(blockIdx.x, a.nb);
     const int ij1 = qn_s2_second_item(a);
     const int ij2 = (FOLD && ij1 >= 0 && a.maxk > 2) ? a.item_ij[(size_t)2 * a.G + blockIdx.x] : -1;
-    if (wave == 0) qn_s2_prologue_w0<QN_S2_HTILE>(a, L); // (wave 0: the prologue first, then its rows -- see s2_eval_kernel)
     int I = ij >> 16, J = ij & 0xffff;
+    // Wave 0 runs the prologue; it requests nothing but its vector entries before the workgroup barrier (see s2_eval_kernel): its
+    // 16 rows of the first item are fetched by waves 1..7 -- three rows each, behind their own -- and handed over in LDS.
+    __shared__ v2d park0[QN_S2_RPW][64];
+    // the first item's vector entries, for both settings of what the control block decides: which half of the s double buffer
+    // is the pending one, and whether the first right-hand side is y (update pass) or g (direction pass)
+    QnS2HVec v0;
+    double s1_r, y_r;
+    v2d s1_c, y_c;
+    auto vec_spec = [&]() {
+        const int ir = I * QN_TB + wave * QN_S2_RPW + (lane & 15), jc = J * QN_TB + qn_s2_col(I == J, lane, wave);
+        QnS2HReq spec;
+        spec.sp = a.F.S0; spec.up = a.F.UN; spec.r0v = a.F.GT; spec.gt = a.F.GT;
+        qn_s2_hvec_load<!FOLD>(spec, ir, jc, v0);
+        s1_r = a.F.S0[np + ir]; s1_c = ld2(a.F.S0 + np + jc);
+        if (!FOLD) { y_r = a.F.Y[ir]; y_c = ld2(a.F.Y + jc); }
+    };
+    if (wave == 0) qn_s2_prologue_w0<QN_S2_HTILE>(a, L, vec_spec);
     // Folded accept-reduce: the quarters of the slot sums of the workgroup's blocks (task = entry e of quarter qd, for all six
     // blocks), and b and g of those blocks.  None of the addresses depends on the control block, so this is done by the waves that
     // wait for wave 0; wave 0's own share (entries 0..63 of the first quarter) is dealt to waves 1..6, a block each, so that wave
@@ -791,22 +912,20 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     // (Measured and dropped, rocprofv3 averages on the same box: parking the first item in LDS as the evaluation does.  This
     // kernel's prologue consumes an evaluation that is accepted -- a short run of the machine -- and every row is written back as
     // well: 26.2 us without parking, 28.0-28.4 with.)
-    v2d h[QN_S2_RPW]; // the wave's 16 rows of the first item go out before the control block is known ...
+    v2d h[QN_S2_RPW]; // the wave's 16 rows of the first item go out before the control block is known
     double* hbase = a.H + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
+    if (wave != 0) {
 #pragma unroll
-    for (int r = 0; r < QN_S2_RPW; ++r) h[r] = qn_sym_ld<NT>(hbase + (size_t)r * np);
-    // ... and so do the first item's vector entries, for both settings of what the control block decides: which half of the s
-    // double buffer is the pending one, and whether the first right-hand side is y (update pass) or g (direction pass)
-    QnS2HVec v0;
-    double s1_r, y_r;
-    v2d s1_c, y_c;
-    {
-        const int ir = I * QN_TB + wave * QN_S2_RPW + (lane & 15), jc = J * QN_TB + qn_s2_col(I == J, lane, wave);
-        QnS2HReq spec;
-        spec.sp = a.F.S0; spec.up = a.F.UN; spec.r0v = a.F.GT; spec.gt = a.F.GT;
-        qn_s2_hvec_load<!FOLD>(spec, ir, jc, v0);
-        s1_r = a.F.S0[np + ir]; s1_c = ld2(a.F.S0 + np + jc);
-        if (!FOLD) { y_r = a.F.Y[ir]; y_c = ld2(a.F.Y + jc); }
+        for (int r = 0; r < QN_S2_RPW; ++r) h[r] = qn_sym_ld<NT>(hbase + (size_t)r * np);
+        vec_spec();
+        const double* q0 = a.H + (size_t)(I * QN_TB) * np + (size_t)J * QN_TB + 2 * lane; // wave 0's rows: no clone lanes (qn_s2_col(., ., 0) = 2 lane)
+        const int r0 = (wave - 1) * 3;
+        v2d t3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t3[k] = qn_sym_ld<NT>(q0 + (size_t)min(r0 + k, QN_S2_RPW - 1) * np);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (r0 + k < QN_S2_RPW) park0[r0 + k][lane] = t3[k];
     }
     if (FOLD && wave > 0) {
         const int e = tid & (QN_TB - 1), qd = tid >> 7;
@@ -832,6 +951,10 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     qn_s2_ctl_out(a, L);
     const int mine = L.mine;
     if (!mine) return;
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < QN_S2_RPW; ++r) h[r] = park0[r][lane];
+    }
     const bool fold = FOLD && mine == 2; // (uniform)
     QnS2HReq q;
     bool nrhs2;
@@ -881,6 +1004,15 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     const bool pend = q.pending;
     const double c_ss = pend ? q.c_ss : 0.0, c_su = pend ? q.c_su : 0.0, c_uu = pend ? q.c_uu : 0.0;
     const bool up = (lane & 32) != 0;
+    const bool slv = !FOLD && a.sl_per != 0; // (uniform; the host never combines the folded accept-reduce with row slivers)
+    // (the sliver's addresses are formed where they are used, behind an empty asm: as loop invariants they were held in registers
+    // across the row loops, which have none to spare)
+    auto sliver_ptr = [&]() {
+        const QnS2Sliver sl = qn_s2_sliver(a, wave);
+        unsigned r = sl.D * QN_TB + sl.row, c = sl.D * QN_TB + 2 * lane;
+        asm volatile("" : "+v"(r), "+v"(c));
+        return a.H + (size_t)r * np + c;
+    };
     for (int it = 0;; ++it) {
         const bool diag = I == J; // (uniform)
         const double sr = pend ? v0.s_r : 0.0, ur = pend ? v0.u_r : 0.0;
@@ -897,7 +1029,8 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         const bool has_next = ijn >= 0; // (uniform)
         const int In = has_next ? (ijn >> 16) : I, Jn = has_next ? (ijn & 0xffff) : J;
         double* hnext = a.H + (size_t)(In * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jn * QN_TB + qn_s2_col(In == Jn, lane, wave);
-        const size_t rstride = has_next ? np : 0; // (none left: every lane re-reads one 16-byte word of this item)
+        if (!has_next && slv) hnext = sliver_ptr(); // the workgroup's row sliver follows its last item (see qn_s2_eval_sliver)
+        const size_t rstride = has_next ? np : 0; // (none left: every lane re-reads one 16-byte word -- of this item, or the sliver's row)
         double c0x = 0.0, c0y = 0.0, c1x = 0.0, c1y = 0.0;
         double racc[QN_S2_RPW];
 #pragma unroll
@@ -939,6 +1072,11 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
                 v0.y0_r = fv[bI][0][rr]; v0.y1_r = fv[bI][1][rr];
                 v0.a0 = (v2d){fv[bJ][0][ccn], fv[bJ][0][ccn + 1]}; v0.a1 = (v2d){fv[bJ][1][ccn], fv[bJ][1][ccn + 1]};
             }
+        } else if (slv) { // the sliver's: its one row (the same entry in every lane) and block D's columns
+            const QnS2Sliver sl = qn_s2_sliver(a, wave);
+            unsigned r = sl.D * QN_TB + sl.row, c = sl.D * QN_TB + 2 * lane;
+            asm volatile("" : "+v"(r), "+v"(c));
+            qn_s2_hvec_load<true>(q, r, c, v0);
         }
         QnWaveFold<QN_S2_RPW, 16>::run(racc, lane); // lanes with (lane & 1) == 0: total of row (lane >> 1) & 15 for rhs lane >> 5
         colred[wave][0][2 * lane] = c0x;
@@ -962,6 +1100,31 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         if (!has_next) break;
         I = In; J = Jn; hbase = hnext;
         __syncthreads(); // the LDS staging areas are rewritten by the next item
+    }
+    if (slv) { // row sl.row of the diagonal tile (D, D), all 128 columns: the update in place, and the row's two sums (no column part)
+        v2d hn = h[0]; // (the window holds the row sixteen times)
+        const double si = pend ? v0.s_r : 0.0, ui = pend ? v0.u_r : 0.0;
+        v2d sj = {0.0, 0.0}, uj = {0.0, 0.0};
+        if (pend) { sj = v0.s_c; uj = v0.u_c; }
+        if (BFGS) {
+            hn.x = hn.x + c_su * (si * uj.x + ui * sj.x);
+            hn.y = hn.y + c_su * (si * uj.y + ui * sj.y);
+        }
+        hn.x = hn.x + c_ss * (si * sj.x);
+        hn.y = hn.y + c_ss * (si * sj.y);
+        if (!BFGS) {
+            hn.x = hn.x + c_uu * (ui * uj.x);
+            hn.y = hn.y + c_uu * (ui * uj.y);
+        }
+        qn_sym_st<NT>(sliver_ptr(), hn);
+        double t0 = hn.x * v0.a0.x;
+        t0 = __builtin_fma(hn.y, v0.a0.y, t0);
+        double t1 = hn.x * v0.a1.x;
+        t1 = __builtin_fma(hn.y, v0.a1.y, t1);
+        double tt[2] = {t0, t1};
+        QnWaveFold<2, 32>::run(tt, lane); // lane 32 k: the total of right-hand side k
+        const QnS2Sliver sl = qn_s2_sliver(a, wave);
+        if ((lane & 31) == 0) a.part[(unsigned)(((sl.D * a.nb + sl.D) * 2 + (lane >> 5)) * QN_TB + sl.row)] = tt[0];
     }
     if (!fold) return; // (uniform)
     // Folded accept-reduce, the owner's part: the workgroup that holds the diagonal item (R, R) writes block R of the vectors

@@ -102,7 +102,10 @@ def test_folded_accept_reduce_is_the_same_run_bit_for_bit(qn, qo, method, lsname
         if tiling:
             s.set_tiling(*tiling)
         ls = qn.MoreThuente() if lsname == "mt" else qn.BackTracking(1e-4, 0.5)
-        s.minimize(ls, obj, 200, 20)
+        try:
+            s.minimize(ls, obj, 200, 20)
+        except qn.MaxIterReached:
+            pass  # (fixed-ratio backtracking does not get there in 200 iterations: the continued call is still compared)
         k1, x1 = s.k(), s.x()
         s.set_x(x1 + 0.25)  # ... from a new point, on the inverse Hessian the first call left
         try:
@@ -112,6 +115,52 @@ def test_folded_accept_reduce_is_the_same_run_bit_for_bit(qn, qo, method, lsname
         pair.append((k1, s.k(), s.x(), s.approx_inv_hessian()))
     assert pair[0][0] == pair[1][0] and pair[0][1] == pair[1][1]
     assert np.array_equal(pair[0][2], pair[1][2]) and np.array_equal(pair[0][3], pair[1][3])
+
+
+@pytest.mark.parametrize("method,lsname", [("bfgs", "mt"), ("dfp", "mt"), ("bfgs", "bt")])
+def test_row_slivers_at_4096(qn, qo, method, lsname):
+    """n = 4096: 528 tiles on 256 workgroups.  The sixteen diagonal tiles left over after two rounds are cut into 8-row slivers, one
+    per workgroup (qn_sym2.hip.h, qn_s2_eval_sliver); set_tiling(-7, 0) switches back to whole tiles (round 2's work lists).  Other
+    association of the sums, same run: decisions equal, steps and iterates to the parity tolerance, H complete and bitwise
+    symmetric; pipelined and synchronous identical; and a solver may change between the two layouts from call to call."""
+    n = 4096
+    q, b, x0, _ = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+    iters = 24
+    s, st = _run(qn, method, lsname, obj, x0, iters)
+    r, st_r = _run(qn, method, lsname, obj, x0, iters, tiling=(-7, 0))
+    assert s.stats()["path"] & 16 and r.stats()["path"] & 16
+    (tr, xs), (tr_r, xs_r) = s.trace(), r.trace()
+    assert st == st_r and len(tr) == len(tr_r) >= 10
+    assert [(a["n_evals"], a["ls_cases"]) for a in tr] == [(a["n_evals"], a["ls_cases"]) for a in tr_r]
+    assert np.allclose([a["t"] for a in tr], [a["t"] for a in tr_r], rtol=1e-9, atol=0)
+    assert np.allclose([a["f"] for a in tr], [a["f"] for a in tr_r], rtol=1e-9, atol=0)
+    assert np.linalg.norm(xs[-1] - xs_r[-1]) <= 1e-9 * max(1.0, np.linalg.norm(xs_r[-1]))
+    h, h_r = s.approx_inv_hessian(), r.approx_inv_hessian()
+    assert np.array_equal(h, h.T) and np.array_equal(h_r, h_r.T)
+    assert np.abs(h - h_r).max() <= 1e-9 * np.abs(h_r).max()
+    sy, st_y = _run(qn, method, lsname, obj, x0, iters, sync=1)
+    assert st_y == st and sy.trace()[0] == tr and np.array_equal(sy.approx_inv_hessian(), h)
+    # against the oracle, as the parity sweep does
+    ref = qo.Solver(qo.BFGS if method == "bfgs" else qo.DFP, 1e-10, x0, qo.UPDATE_RANK2)
+    ls = qo.morethuente() if lsname == "mt" else qo.backtracking(1e-4, 0.5)
+    ref.minimize(ls, qo.QuadraticOracle(q, b), iters, 20, trace_cap=iters, trace_x=True)
+    k = min(len(tr), len(ref.trace))
+    for a, c in zip(tr[:k], ref.trace[:k]):
+        assert a["n_evals"] == c["n_evals"] and abs(a["t"] - c["t"]) <= 1e-9 * abs(c["t"])
+    assert np.linalg.norm(xs[k - 1] - ref.trace_x[k - 1]) <= 1e-9 * max(1.0, np.linalg.norm(ref.trace_x[k - 1]))
+    # layouts alternate on one solver: slivers -> whole tiles -> slivers, 8 iterations each, against the run above
+    m = (qn.BFGS if method == "bfgs" else qn.DFP)(1e-10, x0)
+    ls = qn.MoreThuente() if lsname == "mt" else qn.BackTracking(1e-4, 0.5)
+    for leg in range(3):
+        try:
+            m.minimize(ls, obj, 8, 20)
+        except qn.MaxIterReached:
+            pass
+        m.set_tiling(-7, 0)
+    assert np.linalg.norm(m.x() - xs[-1]) <= 1e-9 * max(1.0, np.linalg.norm(xs[-1]))
+    hm = m.approx_inv_hessian()
+    assert np.array_equal(hm, hm.T) and np.abs(hm - h).max() <= 1e-9 * np.abs(h).max()
 
 
 def test_warm_restart_continues_on_the_mirrored_hessian(qn, qo):
