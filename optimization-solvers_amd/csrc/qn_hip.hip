@@ -817,6 +817,8 @@ struct qn_solver {
     uint64_t warm_obj = 0;
     int* newton_fail = nullptr; // [0]: the factorisation met a bad pivot, [1]: the staged Hessian is not symmetric bit for bit
     int *newton_piv = nullptr, *newton_perm = nullptr; // LU fallback (qn_lu.hip.h): pivot rows, row permutation
+    double* newton_panel = nullptr; // ... and the column-major copy of the 64-column panel being factorised
+    bool newton_lu_percol = false;  // diagnostics: the panel factorisation with two launches per column (rounds 1-2)
     std::vector<int> newton_piv_host;
     uint64_t newton_lu_runs = 0, newton_chol_runs = 0;
     int newton_force_lu = 0; // diagnostics (qn_solver_set_tiling rows = -5): skip the Cholesky attempt
@@ -1035,7 +1037,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     for (auto& e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
-    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->symsh_xg); (void)hipFree(s->symsh_gath); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm);
+    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->symsh_xg); (void)hipFree(s->symsh_gath); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm); (void)hipFree(s->newton_panel);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE); (void)hipFree(s->s2_ctl);
@@ -1082,12 +1084,20 @@ extern "C" int qn_debug_stamps(qn_solver* s, unsigned long long* out, size_t cou
 }
 #endif
 
+#ifdef QN_LU_STAMPS
+extern "C" int qn_debug_lu_stamps(unsigned long long* out) { // diagnostic build: the stamps of the LAST panel's step launches
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(qn_lu_dbg), sizeof(unsigned long long) * 64 * 16));
+    return QN_OK;
+}
+#endif
 extern "C" int qn_solver_set_profiling(qn_solver* s, int on) { s->profiling = on; return QN_OK; }
 extern "C" int qn_solver_set_sync_mode(qn_solver* s, int sync) { s->sync_mode = sync; return QN_OK; }
 extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits) {
     if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; }
     if (rows_per_block == -3) { s->no_sym = 1; rows_per_block = 0; }   // diagnostics: fused row kernels on the full matrices
     if (rows_per_block == -5) { s->newton_force_lu = 1; return QN_OK; } // diagnostics: Newton by pivoted LU even for an SPD Hessian
+    if (rows_per_block == -8) { s->newton_lu_percol = 1; return QN_OK; } // diagnostics: ... with the per-column panel kernels
     if (rows_per_block == -7) { s->no_sliver = !s->no_sliver; return QN_OK; } // diagnostics: sym2 without row slivers (toggles)
     if (rows_per_block == -6) { s->fold = 1; return QN_OK; }           // measurement: sym2 with the folded accept-reduce (see qn_solver::fold)
     if (rows_per_block == -4) { s->no_sym2 = 1; rows_per_block = 0; }  // diagnostics: first-generation symmetric tile kernels (8 launches per iteration)
@@ -1900,13 +1910,34 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     HIPCHK(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
     hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, W, ld, n, n64, hsrc, ld_src); // both triangles
     uint64_t launches = 1;
+    if (!s->newton_panel) HIPCHK(hipMalloc((void**)&s->newton_panel, (size_t)QN_NB * QN_LU_PT * QN_LU_RPT * sizeof(double)));
     for (int p0 = 0; p0 < nlu; p0 += QN_NB) {
-        for (int k = p0; k < p0 + QN_NB; ++k) {
-            hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(1024), 0, st, W, ld, k, p0, nlu, s->newton_piv, flag);
-            const int below = nlu - k - 1;
-            if (below > 0)
-                hipLaunchKernelGGL(lu_col_step_kernel, dim3(std::min(1024, (below + 31) / 32)), dim3(256), 0, st, W, ld, k, p0, nlu, flag);
-            launches += 2;
+        const int m = nlu - p0;
+        if (m <= QN_LU_PT * QN_LU_RPT && !s->newton_lu_percol) {
+            // the panel in a column-major buffer, four columns at a time (qn_lu.hip.h: 19 launches instead of 128)
+            double* P = s->newton_panel;
+            const size_t pld = (size_t)QN_LU_PT * QN_LU_RPT;
+            hipLaunchKernelGGL(lu_panel_load_kernel, dim3(m / QN_NB), dim3(256), 0, st, W, ld, p0, P, pld, flag);
+            for (int sp = 0; sp <= QN_NB / QN_LU_SUB; ++sp) {
+                const int ncol_b = sp >= 1 ? std::max(0, QN_NB - QN_LU_SUB * (sp + 1)) : 0; // role B: the columns right of sub-panel sp
+                const int grid = sp == 0 ? 1 : 2 + ncol_b;                                    // (workgroup 1: role C)
+                const int rpt = (m + QN_LU_PT - 1) / QN_LU_PT; // rows per thread: the smallest instantiation that holds the panel
+                if (rpt <= 1) hipLaunchKernelGGL(lu_panel_step_kernel<1>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
+                else if (rpt <= 2) hipLaunchKernelGGL(lu_panel_step_kernel<2>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
+                else if (rpt <= 4) hipLaunchKernelGGL(lu_panel_step_kernel<4>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
+                else if (rpt <= 8) hipLaunchKernelGGL(lu_panel_step_kernel<8>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
+                else hipLaunchKernelGGL(lu_panel_step_kernel<QN_LU_RPT>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
+            }
+            hipLaunchKernelGGL(lu_panel_store_kernel, dim3(m / QN_NB), dim3(256), 0, st, W, ld, p0, P, pld, flag);
+            launches += 3 + QN_NB / QN_LU_SUB;
+        } else {
+            for (int k = p0; k < p0 + QN_NB; ++k) {
+                hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(1024), 0, st, W, ld, k, p0, nlu, s->newton_piv, flag);
+                const int below = nlu - k - 1;
+                if (below > 0)
+                    hipLaunchKernelGGL(lu_col_step_kernel, dim3(std::min(1024, (below + 31) / 32)), dim3(256), 0, st, W, ld, k, p0, nlu, flag);
+                launches += 2;
+            }
         }
         const int right = nlu - p0 - QN_NB;
         if (nlu > QN_NB)

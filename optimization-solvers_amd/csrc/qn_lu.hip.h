@@ -20,9 +20,10 @@
 //                          v_readlane broadcasts), then updates its rows of the running right-hand side
 //     lu_bwd_step_kernel   the same from the bottom with U (both sweeps read W by rows: contiguous)
 //
-// This path is a fallback, sized for correctness first: two launches per column keep the panel factorisation simple (no grid-wide
-// synchronisation inside a kernel); at n = 8192 it is ~10^4 small launches plus 128 MFMA updates.
-// Differences from nalgebra that stay at tolerance level: nalgebra scales the column by the reciprocal of the pivot, this divides;
+// Rounds 1-2 ran the panel with these two launches per column (~16 000 small launches at n = 8192: 146-196 ms per Newton
+// iteration, rocprofv3 r03_a); they remain the path for panels of more than 8192 rows and the reference the panel kernels below
+// are pinned against bit for bit (tests/test_gpu_newton.py).  Round 3: lu_panel_step_kernel -- 19 launches per panel, 67 ms.
+// As nalgebra's gauss_step, the column is scaled by the reciprocal of the pivot.  Difference that stays at tolerance level:
 // nalgebra forms the explicit inverse and multiplies, this solves with the factors.
 #pragma once
 
@@ -71,14 +72,296 @@ __global__ __launch_bounds__(256) void lu_col_step_kernel(double* __restrict__ W
     const int jc = p0 + 64 - k; // columns k .. p0 + 63 of the pivot row
     if (tid < jc) urow[tid] = W[(size_t)k * ld + k + tid];
     __syncthreads();
-    const double ukk = urow[0];
+    const double inv_ukk = 1.0 / urow[0]; // nalgebra's gauss_step scales the column by the reciprocal of the pivot (`coeffs *= inv_diag`)
     const int r = tid >> 3, c8 = tid & 7; // 32 rows per workgroup, 8 lanes (64 contiguous bytes) per row
     for (int i = k + 1 + blockIdx.x * 32 + r; i < nrows; i += gridDim.x * 32) {
         double* row = W + (size_t)i * ld + k;
-        const double l = row[0] / ukk; // (all 8 lanes of the row read it in the same wave instruction, before lane 0's store below)
+        const double l = row[0] * inv_ukk; // (all 8 lanes of the row read it in the same wave instruction, before lane 0's store below)
         for (int c = 1 + c8; c < jc; c += 8) row[c] = row[c] - l * urow[c];
         if (c8 == 0) row[0] = l;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PANEL FACTORISATION WITHOUT ONE LAUNCH PER COLUMN (round 3).  Partial pivoting is a chain of n dependent steps -- search a
+// column, swap, eliminate -- and two launches per step made the chain 2 n kernel boundaries (16 384 at n = 8192: 120 of the
+// path's 146 ms).  Now the 64-column panel is copied into a column-major buffer P (lu_panel_load_kernel: every column
+// contiguous) and worked on four columns at a time by lu_panel_step_kernel, launched 17 times per panel:
+//   workgroup 0 (role A), launch s < 16: sub-panel s = columns 4 s .. 4 s + 3.  ONE workgroup of 512 threads holds all its rows
+//     in registers (16 rows x 4 columns per thread: panels of up to 8192 rows) and runs the four pivot steps with two workgroup
+//     barriers each -- search (wave butterflies, 8 candidates through LDS), swap and broadcast of the pivot row through LDS,
+//     elimination in registers;
+//   workgroups 2 .. (role B), launch s >= 1: one column right of sub-panel s each, bringing it up to date with sub-panel s - 1:
+//     its four row swaps, the 4 x 4 unit-lower solve for the column's U entries, the rank-4 update of the rows below (role A does
+//     the same for its own four columns before it factors them).  A and B only read sub-panel s - 1, which nobody writes in
+//     launch s: no synchronisation inside the launch;
+//   workgroup 1 (role C), launch s >= 2: the swaps of sub-panel s - 1 on the columns LEFT of it (finished multipliers) -- one
+//     launch late, because in launch s - 1 role B was still reading those of sub-panel s - 2 in the old row order.
+// The arithmetic is the per-column kernels' (the column scaled by the reciprocal of the pivot as nalgebra's gauss_step does, a - l u
+// with separate rounding, updates applied in column order): the factors are the same bits, and the old kernels stay as the path
+// for panels of more than 8192 rows.
+// Where the time goes (rocprofv3 + in-kernel stamps, n = 8192, one factorisation = 67 ms with its two solves): the 2176 step
+// launches 39.8 ms -- role A is ONE CU working through a dependent chain: ~2.5 us per pivot step at 16 rows per thread (search
+// 1.3, exchange 0.3, elimination 0.8: instruction issue, not memory), 4.6 us of launch and flag read, and its 768 KB of column
+// traffic at a single CU's rate; the rank-64 MFMA updates 12.4 ms (HBM-bound: each re-reads and re-writes the trailing matrix,
+// 46 GB in all -- a 128-column panel would halve it); triangular solve of U12 4.5 ms; the two vector solves 6 ms.
+// ------------------------------------------------------------------------------------------------
+#define QN_LU_SUB 4
+#define QN_LU_PT 512
+#define QN_LU_RPT 16 // rows per thread: 8192 rows per panel at most (512 x 16: 1024 x 8 left the four pivot steps 128 registers -- three spilled words, each reload a memory round trip inside the dependent chain)
+
+// P[c][i] = W[p0 + i][p0 + c], i < m (m a multiple of 64): 64 x 64 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void lu_panel_load_kernel(const double* __restrict__ W, size_t ld, int p0, double* __restrict__ P, size_t pld,
+                                                            const int* __restrict__ fail) {
+    if (*fail) return;
+    __shared__ double T[QN_NB][QN_NB + 1];
+    const int i0 = blockIdx.x * QN_NB;
+    for (int e = threadIdx.x; e < QN_NB * QN_NB; e += 256) T[e >> 6][e & 63] = W[(size_t)(p0 + i0 + (e >> 6)) * ld + p0 + (e & 63)];
+    __syncthreads();
+    for (int e = threadIdx.x; e < QN_NB * QN_NB; e += 256) P[(size_t)(e >> 6) * pld + i0 + (e & 63)] = T[e & 63][e >> 6];
+}
+__global__ __launch_bounds__(256) void lu_panel_store_kernel(double* __restrict__ W, size_t ld, int p0, const double* __restrict__ P, size_t pld,
+                                                             const int* __restrict__ fail) {
+    if (*fail) return;
+    __shared__ double T[QN_NB][QN_NB + 1];
+    const int i0 = blockIdx.x * QN_NB;
+    for (int e = threadIdx.x; e < QN_NB * QN_NB; e += 256) T[e & 63][e >> 6] = P[(size_t)(e >> 6) * pld + i0 + (e & 63)];
+    __syncthreads();
+    for (int e = threadIdx.x; e < QN_NB * QN_NB; e += 256) W[(size_t)(p0 + i0 + (e >> 6)) * ld + p0 + (e & 63)] = T[e >> 6][e & 63];
+}
+
+#ifdef QN_LU_STAMPS
+__device__ unsigned long long qn_lu_dbg[64 * 16];
+#define QN_LU_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && s < 64) qn_lu_dbg[s * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define QN_LU_STAMP(k) do { } while (0)
+#endif
+// RPT: rows per thread -- 16 for the first panels of an 8192-row matrix, fewer as the panels get shorter (the loops over a thread's
+// rows are unrolled, registers: a short panel must not pay for sixteen predicated copies of every step)
+template <int RPT>
+__global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restrict__ P, size_t pld, int m, int s, int p0, int* __restrict__ piv,
+                                                                 int* __restrict__ fail) {
+    QN_LU_STAMP(0);
+    if (*fail) return;
+    QN_LU_STAMP(1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    if (b == 1) { // role C: the swaps of sub-panel s - 1 on the columns left of it
+        const int r0 = QN_LU_SUB * (s - 1);
+        if (s >= 2 && tid < r0) {
+            double* col = P + (size_t)tid * pld;
+            int ix[2 * QN_LU_SUB];
+#pragma unroll
+            for (int q = 0; q < QN_LU_SUB; ++q) { ix[q] = r0 + q; ix[QN_LU_SUB + q] = piv[p0 + r0 + q] - p0; }
+            double v[2 * QN_LU_SUB];
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e) v[e] = col[ix[e]];
+            int canon[2 * QN_LU_SUB];
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e) {
+                canon[e] = e;
+#pragma unroll
+                for (int f = 2 * QN_LU_SUB - 1; f >= 0; --f)
+                    if (f < e && ix[f] == ix[e]) canon[e] = f;
+            }
+#pragma unroll
+            for (int q = 0; q < QN_LU_SUB; ++q) {
+                const int sa = canon[q], sb = canon[QN_LU_SUB + q];
+                double va = 0.0, vb = 0.0;
+#pragma unroll
+                for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) va = v[e]; if (e == sb) vb = v[e]; }
+#pragma unroll
+                for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) v[e] = vb; else if (e == sb) v[e] = va; }
+            }
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e)
+                if (canon[e] == e) col[ix[e]] = v[e];
+        }
+        return;
+    }
+    const bool isA = b == 0;
+    if (isA && s >= QN_NB / QN_LU_SUB) return;
+    const int c0 = isA ? QN_LU_SUB * s : QN_LU_SUB * (s + 1) + (b - 2); // first column of this workgroup
+    const int nc = isA ? QN_LU_SUB : 1;
+    __shared__ double U[QN_LU_SUB][QN_LU_SUB]; // U[q][j]: row r0 + q of column c0 + j after the solve
+    __shared__ double bv[QN_LU_SUB][16];
+    __shared__ int bi[QN_LU_SUB][16];
+    __shared__ double rowk[QN_LU_SUB][QN_LU_SUB], rowp[QN_LU_SUB][QN_LU_SUB];
+    // ---- bring the columns up to date with sub-panel s - 1 ----
+    const int r0 = QN_LU_SUB * (s - 1);
+    if (s >= 1) {
+        if (tid < nc) { // thread j, column c0 + j: the four swaps, then the unit-lower 4 x 4 solve
+            // Two memory round trips, not fourteen: the pivots first, then the eight entries the swaps can touch and the six
+            // multipliers, all at once; the swaps are replayed on those eight in registers (two slots may name the same row: the
+            // first slot of a row holds its value), and only then is anything stored.  (First version, in-order loads and stores on
+            // the column: every launch of this kernel took 16 us even on a 64-row panel.)
+            double* col = P + (size_t)(c0 + tid) * pld;
+            int ix[2 * QN_LU_SUB];
+#pragma unroll
+            for (int q = 0; q < QN_LU_SUB; ++q) { ix[q] = r0 + q; ix[QN_LU_SUB + q] = piv[p0 + r0 + q] - p0; }
+            double v[2 * QN_LU_SUB], l11[QN_LU_SUB][QN_LU_SUB];
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e) v[e] = col[ix[e]];
+#pragma unroll
+            for (int c = 0; c < QN_LU_SUB - 1; ++c)
+#pragma unroll
+                for (int r = c + 1; r < QN_LU_SUB; ++r) l11[r][c] = P[(size_t)(r0 + c) * pld + r0 + r];
+            int canon[2 * QN_LU_SUB]; // the first slot that names the same row
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e) {
+                canon[e] = e;
+#pragma unroll
+                for (int f = 2 * QN_LU_SUB - 1; f >= 0; --f)
+                    if (f < e && ix[f] == ix[e]) canon[e] = f;
+            }
+#pragma unroll
+            for (int q = 0; q < QN_LU_SUB; ++q) { // swap rows r0 + q and piv[r0 + q] (slots q and 4 + q), in pivot order
+                const int sa = canon[q], sb = canon[QN_LU_SUB + q];
+                double va = 0.0, vb = 0.0;
+#pragma unroll
+                for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) va = v[e]; if (e == sb) vb = v[e]; }
+#pragma unroll
+                for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) v[e] = vb; else if (e == sb) v[e] = va; }
+            }
+            // slots 0..3 are canonical for rows r0 .. r0 + 3 (distinct rows, first in the list): the solve works on them
+#pragma unroll
+            for (int c = 0; c < QN_LU_SUB - 1; ++c)
+#pragma unroll
+                for (int r = c + 1; r < QN_LU_SUB; ++r) v[r] = v[r] - l11[r][c] * v[c];
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e)
+                if (canon[e] == e) col[ix[e]] = v[e];
+#pragma unroll
+            for (int q = 0; q < QN_LU_SUB; ++q) U[q][tid] = v[q];
+        }
+        __syncthreads(); // (the swapped entries are read below by other threads of this workgroup: same CU, same L1)
+    }
+    double a[QN_LU_SUB][RPT];
+#pragma unroll
+    for (int jr = 0; jr < RPT; ++jr) {
+        const int i = tid + QN_LU_PT * jr;
+#pragma unroll
+        for (int j = 0; j < QN_LU_SUB; ++j) a[j][jr] = (i < m && j < nc) ? P[(size_t)(c0 + j) * pld + i] : 0.0;
+    }
+    if (s >= 1) {
+#pragma unroll
+        for (int jr = 0; jr < RPT; ++jr) {
+            const int i = tid + QN_LU_PT * jr;
+            if (i >= r0 + QN_LU_SUB && i < m) {
+                double l[QN_LU_SUB];
+#pragma unroll
+                for (int q = 0; q < QN_LU_SUB; ++q) l[q] = P[(size_t)(r0 + q) * pld + i];
+#pragma unroll
+                for (int j = 0; j < QN_LU_SUB; ++j)
+                    if (j < nc) {
+#pragma unroll
+                        for (int q = 0; q < QN_LU_SUB; ++q) a[j][jr] = a[j][jr] - l[q] * U[q][j]; // (column order: the per-column kernels' rounding)
+                    }
+            }
+        }
+    }
+    if (!isA) {
+#pragma unroll
+        for (int jr = 0; jr < RPT; ++jr) {
+            const int i = tid + QN_LU_PT * jr;
+            if (i >= r0 + QN_LU_SUB && i < m) P[(size_t)c0 * pld + i] = a[0][jr];
+        }
+        return;
+    }
+    // ---- role A: the four pivot steps of sub-panel s, rows in registers ----
+    QN_LU_STAMP(2);
+    bool failed = false;
+#pragma unroll
+    for (int j = 0; j < QN_LU_SUB; ++j) {
+        const int k = QN_LU_SUB * s + j; // pivot position (panel row = panel column)
+        double best = -1.0;
+        int idx = 0x7fffffff;
+#pragma unroll
+        for (int jr = 0; jr < RPT; ++jr) {
+            const int i = tid + QN_LU_PT * jr;
+            const double v = fabs(a[j][jr]);
+            if (i >= k && i < m && v > best) { best = v; idx = i; } // ascending i per thread: the first maximum (nalgebra's icamax)
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(idx, off, 64);
+            if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+        }
+        if (lane == 0) { bv[j][wave] = best; bi[j][wave] = idx; }
+        if (j == 0) QN_LU_STAMP(3);
+        __syncthreads();
+        if (j == 0) QN_LU_STAMP(4);
+        best = bv[j][0]; idx = bi[j][0];
+#pragma unroll
+        for (int w = 1; w < QN_LU_PT / 64; ++w) {
+            const double ov = bv[j][w];
+            const int oi = bi[j][w];
+            if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+        }
+        if (!(best > 0.0) || idx >= m) { failed = true; idx = k; } // no non-zero entry in this column: singular (newton/mod.rs:43-46)
+        const int p = idx;
+        if (tid == 0) { piv[p0 + k] = p0 + p; if (failed) *fail = 1; }
+        if (failed) break; // (uniform: every thread reduced the same sixteen candidates)
+        // Rows k and p meet in LDS: their owners publish them, take each other's, and everybody reads the pivot row.  Row k
+        // (k < 64) is thread k's first row; row p is found by its one owner under a branch the other waves skip (first version:
+        // every thread compared every one of its rows with k and p, twice -- a third of the step).
+        const int tp = p & (QN_LU_PT - 1), jp = p / QN_LU_PT; // (uniform)
+        double cp[QN_LU_SUB]; // this thread's row in slot jp (selects on a uniform condition: no per-lane compares, no divergent branch)
+#pragma unroll
+        for (int jj = 0; jj < QN_LU_SUB; ++jj) cp[jj] = a[jj][0];
+#pragma unroll
+        for (int jr = 1; jr < RPT; ++jr)
+            if (jr == jp) {
+#pragma unroll
+                for (int jj = 0; jj < QN_LU_SUB; ++jj) cp[jj] = a[jj][jr];
+            }
+        if (tid == k) {
+#pragma unroll
+            for (int jj = 0; jj < QN_LU_SUB; ++jj) rowk[j][jj] = a[jj][0];
+        }
+        if (tid == tp) {
+#pragma unroll
+            for (int jj = 0; jj < QN_LU_SUB; ++jj) rowp[j][jj] = cp[jj];
+        }
+        __syncthreads();
+        {
+            const bool own_p = tid == tp && p != k, own_k = tid == k && p != k;
+#pragma unroll
+            for (int jr = 0; jr < RPT; ++jr) {
+                const bool hit = own_p && jr == jp;
+#pragma unroll
+                for (int jj = 0; jj < QN_LU_SUB; ++jj) a[jj][jr] = hit ? rowk[j][jj] : a[jj][jr];
+            }
+            // (after the owner of p: when both rows are this thread's, row k ends up with the pivot row)
+#pragma unroll
+            for (int jj = 0; jj < QN_LU_SUB; ++jj) a[jj][0] = own_k ? rowp[j][jj] : a[jj][0];
+        }
+        if (j == 0) QN_LU_STAMP(5);
+        const double inv_ukk = 1.0 / rowp[j][j]; // (one division per step and thread: eight of them per thread made a step 3 us on this one CU)
+#pragma unroll
+        for (int jr = 0; jr < RPT; ++jr) {
+            const int i = tid + QN_LU_PT * jr;
+            if (i > k && i < m) {
+                const double l = a[j][jr] * inv_ukk;
+                a[j][jr] = l;
+#pragma unroll
+                for (int jj = 0; jj < QN_LU_SUB; ++jj)
+                    if (jj > j) a[jj][jr] = a[jj][jr] - l * rowp[j][jj];
+            }
+        }
+        if (j == 0) QN_LU_STAMP(6);
+        if (j == 3) QN_LU_STAMP(7);
+    }
+#pragma unroll
+    for (int jr = 0; jr < RPT; ++jr) {
+        const int i = tid + QN_LU_PT * jr;
+        if (i >= QN_LU_SUB * s && i < m) {
+#pragma unroll
+            for (int j = 0; j < QN_LU_SUB; ++j) P[(size_t)(c0 + j) * pld + i] = a[j][jr];
+        }
+    }
+    QN_LU_STAMP(8);
 }
 
 __global__ __launch_bounds__(256) void lu_swap_rows_kernel(double* __restrict__ W, size_t ld, int p0, int ncols, const int* __restrict__ piv,

@@ -270,3 +270,34 @@ def test_pivoted_lu_path_agrees_with_the_cholesky_path_on_spd(qn, qo, n):
     assert np.linalg.norm(out[0][3] - out[1][3]) <= 1e-9 * np.linalg.norm(out[0][3])
     xstar = np.linalg.solve(q, b)
     assert np.linalg.norm(out[1][1] - xstar) <= 1e-9 * np.linalg.norm(xstar)
+
+
+@pytest.mark.parametrize("n", [64, 200, 777, 1300])
+def test_panel_lu_equals_the_per_column_lu_bit_for_bit(qn, qo, n):
+    """qn_lu.hip.h: the 64-column panel is factorised four columns at a time by one workgroup that holds the rows in registers
+    (19 launches per panel); set_tiling(-8, 0) selects rounds 1-2's two launches per column.  Same pivots (first maximum), same
+    arithmetic in the same order: the iterates are the same bits.  Non-symmetric, indefinite Hessian (row swaps do occur)."""
+    fn, hess0, x0 = _double_well_chain(n)
+    rng = np.random.default_rng(8)
+    k = 0.2 * np.triu(rng.standard_normal((n, n)), 1) / np.sqrt(n)
+    hess = lambda x: hess0(x) + k - k.T  # noqa: E731
+    runs = []
+    for percol in (False, True):
+        s = qn.Newton(1e-10, x0)
+        if percol:
+            s.set_tiling(-8, 0)
+        s.set_trace(3, with_x=True)
+        try:
+            s.minimize(qn.MoreThuente(), lambda x: qn.FuncEvalMultivariate(*fn(x)).with_hessian(hess(x)), 3, 20)
+        except qn.MaxIterReached:
+            pass
+        tr, xs = s.trace()
+        runs.append((tr, xs, s.stats()["launches"]))
+    key = lambda tr: [(r["f"], r["gnorm"], r["t"], r["n_evals"], r["ls_cases"]) for r in tr]  # noqa: E731  (s_norm / y_norm are NaN: Newton has none)
+    assert key(runs[0][0]) == key(runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    assert runs[0][2] < runs[1][2]
+    # and the direction is the Newton direction of the matrix as given
+    f0, g0 = fn(x0)
+    d_newton = -np.linalg.solve(hess(x0), g0)
+    step0 = runs[0][1][0] - x0
+    assert step0 @ d_newton / (np.linalg.norm(step0) * np.linalg.norm(d_newton)) > 1.0 - 1e-9

@@ -1,0 +1,32 @@
+"""Diagnostic: in-kernel time stamps of lu_panel_step_kernel's role A (build csrc/qn_hip.hip with -DQN_LU_STAMPS into
+optimization-solvers_amd/lib/libqn_hip_lustamps.so); prints, for the step launches of the last panel, ns since kernel entry."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as ge
+qn = ge.load_package()
+A = qn._abi
+A.LIB_PATH = os.path.join(ROOT, "optimization-solvers_amd", "lib", "libqn_hip_lustamps.so")
+import problems as P
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+diag = P.synth_diag(n); b, x0 = P.synth_vectors(n)
+obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
+s = qn.Newton(1e-8, x0)
+s.set_tiling(-5, 0)
+s.minimize(qn.MoreThuente(), obj, 1, 20) if False else None
+try:
+    s.minimize(qn.MoreThuente(), obj, 1, 20)
+except qn.MaxIterReached:
+    pass
+buf = np.zeros(64 * 16, dtype=np.uint64)
+L = A.lib()
+L.qn_debug_lu_stamps.argtypes = [C.c_void_p]
+L.qn_debug_lu_stamps(buf.ctypes.data_as(C.c_void_p))
+st = buf.reshape(64, 16).astype(np.int64)
+names = ["entry", "flag read", "columns loaded/updated", "search done", "after barrier", "rows exchanged", "step 0 done", "step 3 done", "stored"]
+for s_ in range(17):
+    t = st[s_]
+    if t[0] == 0:
+        continue
+    print("launch s=%2d:" % s_, ", ".join("%s %d" % (names[k], (t[k] - t[0]) * 10) for k in range(1, 9) if t[k] > 0))
