@@ -8,9 +8,9 @@ repo="${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel 2>/dev/null || pwd)}"
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$repo"
 python3 tools/bench_config5.py 16384 20 > $out/config5_default.json 2> $out/config5_default.err
-python3 tools/bench_config5.py 16384 20 30 3 > $out/config5_search.json 2> $out/config5_search.err
+python3 tools/bench_config5.py 16384 20 300 10 30 > $out/config5_search.json 2> $out/config5_search.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5 -o c5 -- python3 tools/bench_config5.py 16384 10 > $out/c5_rocprof.json 2> $out/c5_rocprof.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5s -o c5s -- python3 tools/bench_config5.py 16384 10 30 3 > $out/c5s_rocprof.json 2> $out/c5s_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5s -o c5s -- python3 tools/bench_config5.py 16384 10 300 10 30 > $out/c5s_rocprof.json 2> $out/c5s_rocprof.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/c5_fetch -o f -- python3 tools/bench_config5.py 16384 4 > /dev/null 2> $out/c5_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/c5_write -o w -- python3 tools/bench_config5.py 16384 4 > /dev/null 2> $out/c5_write.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/newton -o nw -- python3 tools/newton_time.py 8192 > $out/newton_chol.txt 2> $out/newton_chol.err
