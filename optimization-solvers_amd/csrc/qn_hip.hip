@@ -859,20 +859,40 @@ struct ProfScope { // brackets one launch (or one exchange) with events when pro
 static void prof_collect(qn_solver* s) {
     if (s->events.empty()) return;
     (void)hipStreamSynchronize(s->ctx->stream);
+    // In pipelined mode the launch pattern runs ahead of the decisions, so some bracketed launches found their request not
+    // pending and returned from the prologue (a few microseconds).  They are not work: a class's sums take only the launches
+    // that lasted more than half its median (in synchronous mode every launch is real and passes).
+    std::vector<std::vector<float>> dur(8);
+    std::vector<std::pair<int, float>> all;
+    all.reserve(s->events.size());
     for (auto& e : s->events) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-            switch (e.cls) {
-            case KC_HPASS: s->stats.t_hpass_ms += ms; s->stats.n_hpass_timed++; break;
-            case KC_EVAL: s->stats.t_eval_ms += ms; s->stats.n_eval_timed++; break;
-            case KC_CTL: s->stats.t_ctl_ms += ms; s->stats.n_ctl_timed++; break;
-            case KC_HREDUCE: s->stats.t_hreduce_ms += ms; s->stats.n_hreduce_timed++; break;
-            case KC_EREDUCE: s->stats.t_ereduce_ms += ms; s->stats.n_ereduce_timed++; break;
-            default: s->stats.t_comm_ms += ms; s->stats.n_comm_timed++; break;
-            }
-        }
+        const bool ok = hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess;
+        const int cls = (e.cls >= 0 && e.cls < 7) ? e.cls : 7;
+        if (ok) { dur[cls].push_back(ms); all.push_back({e.cls, ms}); }
         s->event_pool.push_back(e.a);
         s->event_pool.push_back(e.b);
+    }
+    float floor_ms[8];
+    for (int c = 0; c < 8; ++c) {
+        floor_ms[c] = 0.f;
+        if (dur[c].size() >= 8) {
+            std::nth_element(dur[c].begin(), dur[c].begin() + dur[c].size() / 2, dur[c].end());
+            floor_ms[c] = 0.5f * dur[c][dur[c].size() / 2];
+        }
+    }
+    for (auto& e : all) {
+        const int cls = (e.first >= 0 && e.first < 7) ? e.first : 7;
+        const float ms = e.second;
+        if (ms < floor_ms[cls]) continue;
+        switch (e.first) {
+        case KC_HPASS: s->stats.t_hpass_ms += ms; s->stats.n_hpass_timed++; break;
+        case KC_EVAL: s->stats.t_eval_ms += ms; s->stats.n_eval_timed++; break;
+        case KC_CTL: s->stats.t_ctl_ms += ms; s->stats.n_ctl_timed++; break;
+        case KC_HREDUCE: s->stats.t_hreduce_ms += ms; s->stats.n_hreduce_timed++; break;
+        case KC_EREDUCE: s->stats.t_ereduce_ms += ms; s->stats.n_ereduce_timed++; break;
+        default: s->stats.t_comm_ms += ms; s->stats.n_comm_timed++; break;
+        }
     }
     s->events.clear();
 }
