@@ -272,7 +272,10 @@ int qn_solver_set_sync_mode(qn_solver* s, int sync);
 /* tuning: rows per workgroup tile (4, 8 or 16), column splits (>= 1); 0 keeps the default.  Diagnostics: rows = -1 selects the
  * generic (non-fused) kernels, -2 the fused kernels without the deferred update step, -3 the fused ROW kernels on the full
  * matrices instead of the symmetric-storage tiles, -4 the first-generation symmetric tile kernels (separate control
- * launches); col_splits = 100 + U selects U column chunks per loop trip */
+ * launches), -5 Newton by pivoted LU even for an SPD Hessian, -6 the second-generation path with the accept-reduce folded into
+ * the update-tile launch (4 launches per iteration; measured neutral, off by default), -7 toggles the row slivers of that path
+ * (n = 4096: whole tiles only, as in round 2), -8 the LU panel with two launches per column (rounds 1-2);
+ * col_splits = 100 + U selects U column chunks per loop trip */
 int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits);
 
 /* ---------------------------------------------------------------------------------------------
