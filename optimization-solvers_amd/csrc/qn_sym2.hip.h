@@ -667,7 +667,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         if (ijc >= 0) qn_s2_eval_vec_load(a, x, sp, Ic * QN_TB + wave * QN_S2_RPW + (lane & 15), Jc * QN_TB + 2 * lane, va);
         if (take_c) row_c = qn_s2_eval_item<false>(q, va, diag_c, lane, wave, h, nullptr, tile_ptr(ijc), 0, colred[2][wave], sred[2][wave]);
         if (sliver) row_c = qn_s2_eval_sliver(slv, h[0], sl.row, lane, sred[2][wave]); // (h[0]: the window holds the sliver's row sixteen times)
-        if (it == 0) { qn_keepalive(row_a); qn_keepalive(row_b); qn_keepalive(row_c); QN_S2_STAMP(3); }
+        if (it == 0) { qn_keepalive(row_a); qn_keepalive(row_b); qn_keepalive(row_c); QN_S2_STAMP(3); QN_S2_STAMP_T(12, 448); QN_S2_STAMP_T(13, 192); }
         __syncthreads();
         if (it == 0) QN_S2_STAMP(4);
         if (tid < 3 * QN_TB) { // threads 0..127: item a's column part, 128..255: item b's, 256..383: item c's
