@@ -333,17 +333,16 @@ __device__ __forceinline__ double qn_s2_wave_total(const double (*red)[8], int k
 // The first items of a workgroup need no load: the host deals the first min(2 G, items) items out in order -- item t goes to
 // workgroup t mod G as its (t / G)-th; the off-diagonal tiles row-major over (I, J > I), then the diagonal ones -- so they follow
 // from the workgroup's index alone (a dependent load at kernel entry is a memory round trip in front of everything).
+// (An integer loop on purpose: the argument is uniform, so this is a dozen SCALAR instructions in one cache line of code.  Round 3
+// started with the closed form through a double-precision square root: ~150 instructions per call, twice, in front of the first
+// load of every wave -- and a kernel starts with a cold instruction cache behind an L2 that the tile stream has just swept:
+// in-kernel stamps showed the last wave of a workgroup issuing its sixteen row loads 6 us after kernel entry.)
 __device__ __forceinline__ int qn_s2_item_of_index(int t, int nb) {
     const int noff = nb * (nb - 1) / 2;
     if (t >= noff) return ((t - noff) << 16) | (t - noff);
-    // row I starts at t(I) = I (nb - 1) - I (I - 1) / 2
-    const double bq = 2.0 * nb - 1.0;
-    int i = (int)((bq - sqrt(bq * bq - 8.0 * (double)t)) * 0.5);
-    if (i < 0) i = 0;
-    if (i > nb - 2) i = nb - 2;
-    while (i > 0 && i * (nb - 1) - i * (i - 1) / 2 > t) --i;
-    while ((i + 1) * (nb - 1) - (i + 1) * i / 2 <= t) ++i;
-    return (i << 16) | (i + 1 + (t - (i * (nb - 1) - i * (i - 1) / 2)));
+    int i = 0, len = nb - 1; // block-row i has len tiles right of the diagonal
+    while (t >= len) { t -= len; --len; ++i; }
+    return (i << 16) | (i + 1 + t);
 }
 __device__ __forceinline__ int qn_s2_first_item(int g, int nb) { return qn_s2_item_of_index(g, nb); }
 // the workgroup's second item (-1: none): in closed form when the host dealt it in order (a.inorder), from the list otherwise
@@ -422,7 +421,7 @@ __device__ __forceinline__ void qn_s2_eval_vec_load(const QnS2Args& a, const dou
 template <bool FROM_PARK>
 __device__ __forceinline__ double qn_s2_eval_item(const QnEvalReq& q, const QnS2EvalVec& v, const bool diag, const int lane, const int wave,
                                                   v2d (&h)[QN_S2_RPW], const v2d* __restrict__ parkw, const double* __restrict__ refill, const size_t rstride,
-                                                  double* __restrict__ colred_w, double* __restrict__ sred_w) {
+                                                  double* __restrict__ colred_w, double (&sacc)[4]) {
     // row side: lane l holds row 16 w + (l & 15) of the tile; column side: this lane's two columns
     double dr;
     const double xr = qn_s2_trial(q, v.x_r, v.v_r, v.s_r, v.u_r, dr);
@@ -436,40 +435,47 @@ __device__ __forceinline__ double qn_s2_eval_item(const QnEvalReq& q, const QnS2
         dj.x = d0; dj.y = d1;
     }
     if (!qn_s2_row_on(diag, lane, wave)) { xtj = (v2d){0.0, 0.0}; dj = (v2d){0.0, 0.0}; }
-    double cx = 0.0, cy = 0.0, pf = 0.0, pg = 0.0;
+    double cx = 0.0, cy = 0.0;
     double racc[QN_S2_RPW];
-    // lane 8 w + k holds the diagonal entries of the wave's rows 2 k and 2 k + 1: it fetches their b once (a per-row broadcast
-    // through scalar registers cost the row loop its registers)
-    const int dl = lane - 8 * wave;
-    double b_lo = 0.0, b_hi = 0.0;
-    if (diag) { b_lo = __shfl(v.b_r, (2 * dl) & 15); b_hi = __shfl(v.b_r, (2 * dl + 1) & 15); }
+    // The row loop is the bare minimum: one product pair for the row part, one for the column part, one scalar broadcast.  (Until
+    // the middle of round 3 it also carried the two scalar sums -- x_i (q_i - 2 b_i) and d_i (q_i - b_i), with b leaving on the
+    // lane that holds Q_ii -- at seven more instructions and a second broadcast per row.  In-kernel stamps of the last and the
+    // first wave of a SIMD showed the two waves that share it taking 7.5 us between them for two items: the phase behind the
+    // workgroup barrier is instruction issue, not memory.  The scalars now come from the sixteen ROW TOTALS after the fold.)
 #pragma unroll
     for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
         v2d hv;
         if (FROM_PARK) hv = parkw[r * 64 + lane];
         else { hv = h[r]; h[r] = ld2(refill + (size_t)r * rstride); } // the register this row frees takes the same row of the next item at once
-        const double xi = qn_lane_bcast(xr, r), di = qn_lane_bcast(dr, r);
+        const double xi = qn_lane_bcast(xr, r);
         double t0 = hv.x * xtj.x;
         t0 = __builtin_fma(hv.y, xtj.y, t0);
         racc[r] = t0;
         cx = __builtin_fma(hv.x, xi, cx);
         cy = __builtin_fma(hv.y, xi, cy);
-        // the lane that holds Q_ii (column 16 w + r of a diagonal tile): b_i leaves here, against Q_ii xt_i (b_lo = b_hi = 0 otherwise)
-        const double bsel = (dl == (r >> 1)) ? ((r & 1) ? b_hi : b_lo) : 0.0;
-        pf = __builtin_fma(xi, t0 - (bsel + bsel), pf);
-        pg = __builtin_fma(di, t0 - bsel, pg);
     }
     if (!qn_s2_col_on(diag, lane, wave)) { cx = 0.0; cy = 0.0; }
-    pf = __builtin_fma(xtj.x, cx, pf); pf = __builtin_fma(xtj.y, cy, pf); // xt_J'(column part): the mirrored half of xt'Q xt
-    pg = __builtin_fma(dj.x, cx, pg); pg = __builtin_fma(dj.y, cy, pg);   // d_J'(column part) = xt_I'Q_IJ d_J
     colred_w[2 * lane] = cx;
     colred_w[2 * lane + 1] = cy;
-    {
-        double sv[8] = {pf, pg, 0.0, 0.0, p4, p5, 0.0, 0.0};
-        QnWaveFold<8, 32>::run(sv, lane);
-        if ((lane & 7) == 0) sred_w[lane >> 3] = sv[0];
-    }
     QnWaveFold<QN_S2_RPW, 32>::run(racc, lane); // lanes with (lane & 3) == 0 hold the total of row lane >> 2
+    // the wave's scalar sums: the column part on every lane, the row part on the sixteen lanes that hold a row total.  On a
+    // diagonal item b_i is subtracted from the row's total over this tile -- Q_ii xt_i and its neighbours, i.e. ~ b_i for a
+    // diagonally dominant Q: the cancellation of g = Q x - b happens here, row by row, before the multiplication by d_i (x_i)
+    // and before any further summation (see CONDITIONING above; the 60-digit pin bounds it).
+    double pf = xtj.x * cx, pg = dj.x * cx;
+    pf = __builtin_fma(xtj.y, cy, pf); // xt_J'(column part): the mirrored half of xt'Q xt
+    pg = __builtin_fma(dj.y, cy, pg);  // d_J'(column part) = xt_I'Q_IJ d_J
+    {
+        const int rq = lane >> 2;
+        const double xq = __shfl(xr, rq), dq = __shfl(dr, rq);
+        const double bq = diag ? __shfl(v.b_r, rq) : 0.0;
+        if ((lane & 3) == 0) {
+            pf = __builtin_fma(xq, racc[0] - (bq + bq), pf);
+            pg = __builtin_fma(dq, racc[0] - bq, pg);
+        }
+    }
+    // (the lane's partial scalars are ADDED to the group's: one fold serves all the items of a group -- s2_eval_kernel)
+    sacc[0] = sacc[0] + pf; sacc[1] = sacc[1] + pg; sacc[2] = sacc[2] + p4; sacc[3] = sacc[3] + p5;
     return racc[0];
 }
 // ROW SLIVERS (round 3).  nb (nb + 1) / 2 tiles do not divide by the 256 workgroups: at n = 4096 it is 528 = 2 x 256 + 16, so
@@ -512,22 +518,21 @@ __device__ __forceinline__ QnS2SliverVec qn_s2_sliver_prep(const QnEvalReq& q, c
     o.nf = isfinite(dr) ? 0.0 : 1.0;
     return o;
 }
-__device__ __forceinline__ double qn_s2_eval_sliver(const QnS2SliverVec& v, const v2d hv, const int row, const int lane, double* __restrict__ sred_w) {
+__device__ __forceinline__ double qn_s2_eval_sliver(const QnS2SliverVec& v, const v2d hv, const int row, const int lane, double (&sacc)[4]) {
     double t0 = hv.x * v.xtj.x;
     t0 = __builtin_fma(hv.y, v.xtj.y, t0);
     const double bsel = (lane == (row >> 1)) ? v.b : 0.0;
-    double sv[8] = {v.xr * (t0 - (bsel + bsel)), v.dr * (t0 - bsel), 0.0, 0.0, 0.0, 0.0, t0, 0.0};
-    if (lane == 0) { sv[4] = v.gd; sv[5] = v.nf; }
-    QnWaveFold<8, 32>::run(sv, lane);
-    if ((lane & 7) == 0 && lane < 48) sred_w[lane >> 3] = sv[0];
-    return sv[0]; // lane 48: the row's total
+    sacc[0] = sacc[0] + v.xr * (t0 - (bsel + bsel));
+    sacc[1] = sacc[1] + v.dr * (t0 - bsel);
+    if (lane == 0) { sacc[2] = sacc[2] + v.gd; sacc[3] = sacc[3] + v.nf; }
+    return t0; // this lane's share of the row's total: folded with the group's scalars (value 6 of the group fold)
 }
 
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
     __shared__ double colsum[3][QN_TB];
     __shared__ double colred[3][QN_S2_WAVES][QN_TB]; // [item of the group]
-    __shared__ double sred[3][QN_S2_WAVES][8];
+    __shared__ double sred[QN_S2_WAVES][8]; // the group's scalar sums per wave (one fold for all its items)
     __shared__ v2d park[QN_S2_WAVES][QN_S2_RPW][64]; // 128 KB: the first item's rows, parked while wave 0 decides (see below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
@@ -535,7 +540,6 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     // Wave 0 runs the prologue first (qn_s2_prologue_w0); waves 1..7 request the window at once.  The first two items are
     // functions of blockIdx: no load.
     const int ij0 = qn_s2_first_item(blockIdx.x, a.nb);
-    const int ij1 = qn_s2_second_item(a); // the second item: what the parked window is refilled from
     // The wave's 16 rows of the first item are requested before the control block is known (their addresses do not depend on
     // it), and so are the first item's vector entries for BOTH settings of the two buffer toggles the control block holds
     // (x / trial point, pending / staged s); every register of the window is refilled with the next item's row the moment its
@@ -546,7 +550,6 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     // the first item are parked by the other waves, its window takes the SECOND item after the barrier and fills while the
     // first is consumed from LDS.  Only its vector entries go out early, behind the control block.
     v2d h[QN_S2_RPW];
-    const bool parked = ij1 >= 0; // (uniform) a workgroup with one item parks nothing
     QnS2EvalVec va, v1; // va: x = X0[0], s = S0[0]; v1 holds the other halves' x and s entries
     auto vec_spec = [&]() {
         const int I = ij0 >> 16, J = ij0 & 0xffff;
@@ -564,9 +567,13 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     if (wave == 0) {
         qn_s2_prologue_w0<QN_S2_EVAL>(a, L, vec_spec);
     } else {
+        QN_S2_STAMP_T(13, 448);
         window_load(ij0);
+        QN_S2_STAMP_T(14, 448);
         vec_spec();
     }
+    const int ij1 = qn_s2_second_item(a); // the second item: what the parked window is refilled from (after the first requests: nothing in front of them)
+    const bool parked = ij1 >= 0;         // (uniform) a workgroup with one item parks nothing
     // PARKING.  The prologue of wave 0 -- one memory round trip, the sums of 256 rows, the state machine on one lane -- takes
     // 6-9 us, and the 128 KB register window lands in 5.  Round 2 let the memory system idle until the decision was there.
     // Now waves 1..7 move each row of the first item into LDS the moment it arrives and request the same row of the SECOND item
@@ -643,8 +650,9 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         const double* slp = a.Q + (size_t)(sl.D * QN_TB + sl.row) * np + (size_t)sl.D * QN_TB + 2 * lane;
         QnS2SliverVec slv{};
         double row_a, row_b = 0.0, row_c = 0.0;
-        if (parked && it == 0) row_a = qn_s2_eval_item<true>(q, va, diag_a, lane, wave, h, &park[wave][0][0], nullptr, 0, colred[0][wave], sred[0][wave]);
-        else row_a = qn_s2_eval_item<false>(q, va, diag_a, lane, wave, h, nullptr, has_b ? tile_ptr(ijb) : (sliver ? slp : tile_ptr(ija)), has_b ? np : 0, colred[0][wave], sred[0][wave]);
+        double sacc[4] = {0.0, 0.0, 0.0, 0.0}; // x'(Q xt - 2b), d'(Q xt - b), g'd, #non-finite d: this lane's share over the group's items
+        if (parked && it == 0) row_a = qn_s2_eval_item<true>(q, va, diag_a, lane, wave, h, &park[wave][0][0], nullptr, 0, colred[0][wave], sacc);
+        else row_a = qn_s2_eval_item<false>(q, va, diag_a, lane, wave, h, nullptr, has_b ? tile_ptr(ijb) : (sliver ? slp : tile_ptr(ija)), has_b ? np : 0, colred[0][wave], sacc);
         if (has_b) {
             qn_s2_eval_vec_load(a, x, sp, Ib * QN_TB + wave * QN_S2_RPW + (lane & 15), Jb * QN_TB + 2 * lane, vb);
             if (sliver) { // the sliver's entries fly behind item b's
@@ -655,7 +663,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
                 qn_s2_eval_vec_load(a, x, sp, sir, sjc, va);
                 slv = qn_s2_sliver_prep(q, va);
             }
-            row_b = qn_s2_eval_item<false>(q, vb, diag_b, lane, wave, h, nullptr, ijc >= 0 ? tile_ptr(ijc) : (sliver ? slp : tile_ptr(ijb)), ijc >= 0 ? np : 0, colred[1][wave], sred[1][wave]);
+            row_b = qn_s2_eval_item<false>(q, vb, diag_b, lane, wave, h, nullptr, ijc >= 0 ? tile_ptr(ijc) : (sliver ? slp : tile_ptr(ijb)), ijc >= 0 ? np : 0, colred[1][wave], sacc);
         } else if (sliver) {
             unsigned sir = sl.D * QN_TB + sl.row, sjc = sl.D * QN_TB + 2 * lane;
             asm volatile("" : "+v"(sir), "+v"(sjc));
@@ -665,9 +673,16 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         // the next item's vector entries go out now: for the item that joins this group, or for the next group while this
         // one's sums are exchanged and stored
         if (ijc >= 0) qn_s2_eval_vec_load(a, x, sp, Ic * QN_TB + wave * QN_S2_RPW + (lane & 15), Jc * QN_TB + 2 * lane, va);
-        if (take_c) row_c = qn_s2_eval_item<false>(q, va, diag_c, lane, wave, h, nullptr, tile_ptr(ijc), 0, colred[2][wave], sred[2][wave]);
-        if (sliver) row_c = qn_s2_eval_sliver(slv, h[0], sl.row, lane, sred[2][wave]); // (h[0]: the window holds the sliver's row sixteen times)
-        if (it == 0) { qn_keepalive(row_a); qn_keepalive(row_b); qn_keepalive(row_c); QN_S2_STAMP(3); QN_S2_STAMP_T(12, 448); QN_S2_STAMP_T(13, 192); }
+        if (take_c) row_c = qn_s2_eval_item<false>(q, va, diag_c, lane, wave, h, nullptr, tile_ptr(ijc), 0, colred[2][wave], sacc);
+        double t0s = 0.0;
+        if (sliver) t0s = qn_s2_eval_sliver(slv, h[0], sl.row, lane, sacc); // (h[0]: the window holds the sliver's row sixteen times)
+        { // ONE fold for the group: the four scalars and the sliver's row total (value 6: lane 48 holds it)
+            double sv[8] = {sacc[0], sacc[1], 0.0, 0.0, sacc[2], sacc[3], t0s, 0.0};
+            QnWaveFold<8, 32>::run(sv, lane);
+            if ((lane & 7) == 0 && lane < 48) sred[wave][lane >> 3] = sv[0];
+            if (sliver) row_c = sv[0];
+        }
+        if (it == 0) { qn_keepalive(row_a); qn_keepalive(row_b); qn_keepalive(row_c); QN_S2_STAMP(3); QN_S2_STAMP_T(12, 448); }
         __syncthreads();
         if (it == 0) QN_S2_STAMP(4);
         if (tid < 3 * QN_TB) { // threads 0..127: item a's column part, 128..255: item b's, 256..383: item c's
@@ -682,14 +697,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
                 else a.partE[(unsigned)((Je * a.nb + Ie) * QN_TB + cidx)] = acc;
             }
         }
-        if (tid < QN_S2_NSE) { // (items in list order: a, b, c; scalars 2..5 exist on diagonal items only)
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const bool have = e == 0 || (e == 1 && has_b) || (e == 2 && (take_c || sliver));
-                const bool dg = e == 0 ? diag_a : (e == 1 ? diag_b : (diag_c || sliver));
-                if (have && (tid < 2 || dg)) wgk = wgk + qn_s2_wave_total(sred[e], tid);
-            }
-        }
+        if (tid < QN_S2_NSE) wgk = wgk + qn_s2_wave_total(sred, tid); // (waves in order; scalars 2..5 are zero off the diagonal items)
         if (diag_a || diag_b || diag_c) __syncthreads(); // (uniform)
         if ((lane & 3) == 0) {
             const int rl = wave * QN_S2_RPW + (lane >> 2);
