@@ -113,6 +113,13 @@ __device__ __forceinline__ double qn_wave_sum(double v) {
     return v;
 }
 
+// (The swap form below is used for the 16-value folds of the tile kernels' row totals only.  Measured with rocprofv3 on one box:
+// there it takes 0.7 us off the evaluation kernel; used in the 8-value folds as well -- the prologue's table sums, the small
+// kernels' dot products -- the accept-reduce kernel got 1.2 us SLOWER and the update-reduce 0.4, for reasons the instruction
+// counts do not show.)
+#ifndef QN_FOLD_SWAP_MIN_V
+#define QN_FOLD_SWAP_MIN_V 16
+#endif
 // ---- halving butterfly: V values per lane -> lane l ends with the wave total of value (l >> (6 - log2 V)) in v[0]
 template <int CNT, int OFF>
 struct QnWaveFold {
@@ -121,13 +128,35 @@ struct QnWaveFold {
         if constexpr (OFF >= 1) {
             if constexpr (CNT > 1) {
                 constexpr int HALF = CNT / 2;
-                const bool up = (lane & OFF) != 0;
+                if constexpr ((OFF == 32 || OFF == 16) && V >= QN_FOLD_SWAP_MIN_V) {
+                    // v_permlane32_swap A, B exchanges the upper half of A with the lower half of B (v_permlane16_swap: the odd
+                    // 16-lane rows of A with the even rows of B): afterwards A' + B' IS the folded pair -- value i in the lanes
+                    // with (lane & OFF) == 0, value i + HALF in the others, each lane holding its own entry plus its partner's.
+                    // No selects and no copies: three instructions per exchange instead of nine (round 3: the phase behind the
+                    // workgroup barrier of the tile kernels is instruction issue).  Same pairs, and a + b = b + a: same bits.
 #pragma unroll
-                for (int i = 0; i < HALF; ++i) {
-                    const double keep = up ? v[i + HALF] : v[i];
-                    const double send = up ? v[i] : v[i + HALF];
-                    const double recv = qn_xor_lanes<OFF>(send);
-                    v[i] = keep + recv;
+                    for (int i = 0; i < HALF; ++i) {
+                        const int alo = __double2loint(v[i]), ahi = __double2hiint(v[i]);
+                        const int blo = __double2loint(v[i + HALF]), bhi = __double2hiint(v[i + HALF]);
+                        if constexpr (OFF == 32) {
+                            const auto rl = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+                            const auto rh = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+                            v[i] = __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+                        } else {
+                            const auto rl = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+                            const auto rh = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+                            v[i] = __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+                        }
+                    }
+                } else {
+                    const bool up = (lane & OFF) != 0;
+#pragma unroll
+                    for (int i = 0; i < HALF; ++i) {
+                        const double keep = up ? v[i + HALF] : v[i];
+                        const double send = up ? v[i] : v[i + HALF];
+                        const double recv = qn_xor_lanes<OFF>(send);
+                        v[i] = keep + recv;
+                    }
                 }
                 QnWaveFold<HALF, OFF / 2>::run(v, lane);
             } else {

@@ -38,6 +38,7 @@
 // one-workgroup `advance` launch that runs the prologue alone -- bit-identical by construction).
 // Reference lines served: ls_solver.rs:66-111, bfgs.rs:42-127, dfp.rs:115-120, morethuente.rs:165-297, backtracking.rs:20-58.
 #pragma once
+#include <type_traits>
 
 #define QN_S2_TPB 512
 #define QN_S2_WAVES 8
@@ -567,9 +568,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     if (wave == 0) {
         qn_s2_prologue_w0<QN_S2_EVAL>(a, L, vec_spec);
     } else {
-        QN_S2_STAMP_T(13, 448);
         window_load(ij0);
-        QN_S2_STAMP_T(14, 448);
         vec_spec();
     }
     const int ij1 = qn_s2_second_item(a); // the second item: what the parked window is refilled from (after the first requests: nothing in front of them)
@@ -627,7 +626,13 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     // round of its own it kept the whole launch waiting 5 us for those sixteen (in-kernel time stamps of the workgroups' ends).
     int ija = ij0, ijb = ij1;
     QnS2EvalVec vb;
-    for (int it = 0;; it += 2) {
+    // The FIRST group is peeled out of the loop over groups (the same body, instantiated twice).  Inside the loop the compiler
+    // had to assume that loads of the previous trip were still pending when the parked item's LDS reads reuse their registers,
+    // and put `s_waitcnt vmcnt(5..0)` in front of them: counted in order, those waits held the parked item back until the SECOND
+    // item's rows had all arrived -- the overlap the parking exists for was gone (in-kernel stamps: 3.4 us for an item that is
+    // entirely in LDS).
+    auto run_group = [&](auto first_tag, const int it) __attribute__((always_inline)) -> bool {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const int Ia = ija >> 16, Ja = ija & 0xffff, Ib = ijb >> 16, Jb = ijb & 0xffff;
         const bool has_b = ijb >= 0; // (uniform)
         const bool diag_a = Ia == Ja, diag_b = has_b && Ib == Jb;
@@ -651,8 +656,9 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         QnS2SliverVec slv{};
         double row_a, row_b = 0.0, row_c = 0.0;
         double sacc[4] = {0.0, 0.0, 0.0, 0.0}; // x'(Q xt - 2b), d'(Q xt - b), g'd, #non-finite d: this lane's share over the group's items
-        if (parked && it == 0) row_a = qn_s2_eval_item<true>(q, va, diag_a, lane, wave, h, &park[wave][0][0], nullptr, 0, colred[0][wave], sacc);
+        if (FIRST && parked) row_a = qn_s2_eval_item<true>(q, va, diag_a, lane, wave, h, &park[wave][0][0], nullptr, 0, colred[0][wave], sacc);
         else row_a = qn_s2_eval_item<false>(q, va, diag_a, lane, wave, h, nullptr, has_b ? tile_ptr(ijb) : (sliver ? slp : tile_ptr(ija)), has_b ? np : 0, colred[0][wave], sacc);
+        if (FIRST) { qn_keepalive(row_a); QN_S2_STAMP_T(13, 448); }
         if (has_b) {
             qn_s2_eval_vec_load(a, x, sp, Ib * QN_TB + wave * QN_S2_RPW + (lane & 15), Jb * QN_TB + 2 * lane, vb);
             if (sliver) { // the sliver's entries fly behind item b's
@@ -674,6 +680,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         // one's sums are exchanged and stored
         if (ijc >= 0) qn_s2_eval_vec_load(a, x, sp, Ic * QN_TB + wave * QN_S2_RPW + (lane & 15), Jc * QN_TB + 2 * lane, va);
         if (take_c) row_c = qn_s2_eval_item<false>(q, va, diag_c, lane, wave, h, nullptr, tile_ptr(ijc), 0, colred[2][wave], sacc);
+        if (FIRST) { qn_keepalive(row_b); QN_S2_STAMP_T(14, 448); }
         double t0s = 0.0;
         if (sliver) t0s = qn_s2_eval_sliver(slv, h[0], sl.row, lane, sacc); // (h[0]: the window holds the sliver's row sixteen times)
         { // ONE fold for the group: the four scalars and the sliver's row total (value 6: lane 48 holds it)
@@ -682,9 +689,9 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
             if ((lane & 7) == 0 && lane < 48) sred[wave][lane >> 3] = sv[0];
             if (sliver) row_c = sv[0];
         }
-        if (it == 0) { qn_keepalive(row_a); qn_keepalive(row_b); qn_keepalive(row_c); QN_S2_STAMP(3); QN_S2_STAMP_T(12, 448); }
+        if (FIRST) { qn_keepalive(row_a); qn_keepalive(row_b); qn_keepalive(row_c); QN_S2_STAMP(3); QN_S2_STAMP_T(12, 448); }
         __syncthreads();
-        if (it == 0) QN_S2_STAMP(4);
+        if (FIRST) QN_S2_STAMP(4);
         if (tid < 3 * QN_TB) { // threads 0..127: item a's column part, 128..255: item b's, 256..383: item c's
             const int e = tid >> 7, cidx = tid & (QN_TB - 1);
             if (e == 0 || (e == 1 && has_b) || (e == 2 && take_c)) {
@@ -716,11 +723,15 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
             }
         }
         if (sliver && lane == 48) a.partE[(unsigned)((sl.D * a.nb + sl.D) * QN_TB + sl.row)] = row_c;
-        if (it == 0) QN_S2_STAMP(5);
-        if (ijc < 0 || take_c) break;
+        if (FIRST) QN_S2_STAMP(5);
+        if (ijc < 0 || take_c) return true;
         ija = ijc; ijb = ijd;
         __syncthreads(); // colred / colsum / sred are rewritten by the next group
-    }
+        return false;
+    };
+    if (!run_group(std::true_type{}, 0))
+        for (int it = 2;; it += 2)
+            if (run_group(std::false_type{}, it)) break;
     QN_S2_STAMP(15);
     if (tid < QN_S2_NSE) { // sred column -> table column: xt'(Q xt - 2b), d'(Q xt - b), (b'xt = 0), (b'd = 0), g'd, #non-finite d
         const int col = tid == 1 ? 2 : (tid == 2 ? 1 : tid);

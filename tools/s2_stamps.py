@@ -28,8 +28,8 @@ st = buf.reshape(64, 256, 16).astype(np.int64)
 # stamps (ns after the workgroup's entry, median over workgroups): 9 control block in LDS, 10 sums of the previous launch's table,
 # 11 machine done, 1 wave 0 has requested its rows, 2 after the workgroup barrier (prologue end), 3 first pair: rows consumed and
 # folded, 4 after the pair's barrier, 5 pair's slots stored, 15 end
-order = [9, 10, 11, 1, 13, 14, 6, 7, 8, 2, 12, 3, 4, 5, 15]
-label = {12: "w7 pair folded", 13: "w7 entry", 14: "w7 rows requested", 6: "w7 requested", 7: "w7 parked", 8: "w7 at barrier", 9: "ctl", 10: "sums", 11: "machine", 1: "w0 at barrier", 2: "barrier", 3: "w0 pair folded", 4: "pair barrier", 5: "pair stored", 15: "end"}
+order = [9, 10, 11, 1, 6, 7, 8, 2, 13, 14, 12, 3, 4, 5, 15]
+label = {12: "w7 pair folded", 13: "w7 item a done", 14: "w7 item b done", 6: "w7 requested", 7: "w7 parked", 8: "w7 at barrier", 9: "ctl", 10: "sums", 11: "machine", 1: "w0 at barrier", 2: "barrier", 3: "w0 pair folded", 4: "pair barrier", 5: "pair stored", 15: "end"}
 for slot in range(64):
     t = st[slot]
     if t[0, 15] == 0 or t[0, 0] == 0 or t[0, 3] == 0:
