@@ -797,6 +797,7 @@ struct qn_solver {
     int s2_G = 0, s2_nb = 0, s2_maxk = 0, s2_inorder = 0;
     int s2_sl_first = 0, s2_sl_per = 0, s2_sl_cfg = -1; // row slivers (QnS2Args.sl_first / sl_per); the switches the lists were built for
     bool no_sliver = false;    // diagnostics: sym2 without row slivers (round 2's work lists)
+    bool no_pair = false;      // diagnostics: the general evaluation kernel where the two-items-and-a-sliver instance would run
     bool h_sliver_whole = false; // the diagonal tiles that sliver rows read are complete (both triangles): kept so by sliver-mode update passes
     double* s2_partE = nullptr; // [nb][nb][128]: row / column slots of the last evaluation (QnS2Args.partE)
     double* s2_wgS = nullptr; // [2][s2_trows][QN_S2_ROW]: the sums a servicing launch leaves for the next launch's prologue, by launch parity
@@ -1118,6 +1119,7 @@ extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_sp
     if (rows_per_block == -3) { s->no_sym = 1; rows_per_block = 0; }   // diagnostics: fused row kernels on the full matrices
     if (rows_per_block == -5) { s->newton_force_lu = 1; return QN_OK; } // diagnostics: Newton by pivoted LU even for an SPD Hessian
     if (rows_per_block == -8) { s->newton_lu_percol = 1; return QN_OK; } // diagnostics: ... with the per-column panel kernels
+    if (rows_per_block == -9) { s->no_pair = !s->no_pair; return QN_OK; }     // diagnostics: general evaluation kernel (toggles)
     if (rows_per_block == -7) { s->no_sliver = !s->no_sliver; return QN_OK; } // diagnostics: sym2 without row slivers (toggles)
     if (rows_per_block == -6) { s->fold = 1; return QN_OK; }           // measurement: sym2 with the folded accept-reduce (see qn_solver::fold)
     if (rows_per_block == -4) { s->no_sym2 = 1; rows_per_block = 0; }  // diagnostics: first-generation symmetric tile kernels (8 launches per iteration)
@@ -1620,7 +1622,10 @@ static int s2_launch(Run& r, int kind) {
     const int cls = kind == QN_S2_EVAL ? KC_EVAL : kind == QN_S2_VEC ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS : kind == QN_S2_HREDUCE ? KC_HREDUCE : KC_CTL;
     ProfScope ps(s, cls);
     switch (kind) {
-    case QN_S2_EVAL: hipLaunchKernelGGL(s2_eval_kernel, dim3(a.G), dim3(QN_S2_TPB), 0, st, a); break;
+    case QN_S2_EVAL:
+        if (a.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        else hipLaunchKernelGGL(s2_eval_kernel<false>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        break;
     case QN_S2_VEC: hipLaunchKernelGGL(s2_vec_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
     case QN_S2_HTILE:
         if (a.fold) { // (n <= 4096: H stays in the Infinity Cache, no streaming hints)
@@ -2226,6 +2231,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         // its LDS staging area -- n <= 4096 with 256 workgroups; larger n keeps the accept-reduce launch (7 us of 250+)
         a.fold = (s->s2_maxk <= 3 && s->s2_nb <= 32 && s->fold) ? 1 : 0;
         a.sl_first = s->s2_sl_first; a.sl_per = s->s2_sl_per;
+        a.pair = (a.sl_per != 0 && s->s2_maxk == 2 && s->s2_inorder == 2 * s->s2_G && !s->no_pair) ? 1 : 0;
         // sliver rows read the diagonal tiles sl_first .. nb - 1 whole: a run of another kind since the last sliver-mode update
         // pass (or none yet) may have left their lower sub-blocks behind -- restore them once
         if (a.sl_per && !s->h_sliver_whole) { QNCHK(ensure_full_h(s)); s->h_sliver_whole = true; }

@@ -62,6 +62,7 @@ struct QnS2Args {
     double* part;        // [nb][nb][2][128] row / column slots of the update pass ([y, g+])
     double* partE;       // [nb][nb][128] row / column slots of the last evaluation (Q (x + t d)): a buffer of its own, because the launch that
                          // turns them into vectors also writes the update pass's slots (folded accept-reduce)
+    int pair;            // every workgroup has two list items and a sliver: s2_eval_kernel<true>
     int fold;            // the accept-reduce runs inside the update-tile launch (workgroups hold <= 3 items: n <= 4096)
     int sl_first, sl_per; // ROW SLIVERS (sl_per != 0): the diagonal tiles sl_first .. nb - 1 are not on any work list; each is cut
                          // into sl_per slivers of 8 rows, one per workgroup (workgroup g: tile sl_first + g / sl_per, sliver g % sl_per,
@@ -529,6 +530,11 @@ __device__ __forceinline__ double qn_s2_eval_sliver(const QnS2SliverVec& v, cons
     return t0; // this lane's share of the row's total: folded with the group's scalars (value 6 of the group fold)
 }
 
+// PAIR: every workgroup has exactly two list items and one row sliver (n = 4096 on 256 workgroups: QnS2Args.pair).  The general
+// body decides at run time whether there is a second item, a third one, a list to read, a sliver, a parked window; with those
+// five flags known the compiler drops the variants they select between and the register copies at their joins -- the phase
+// behind the workgroup barrier is instruction issue.
+template <bool PAIR>
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
     __shared__ double colsum[3][QN_TB];
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         vec_spec();
     }
     const int ij1 = qn_s2_second_item(a); // the second item: what the parked window is refilled from (after the first requests: nothing in front of them)
-    const bool parked = ij1 >= 0;         // (uniform) a workgroup with one item parks nothing
+    const bool parked = PAIR || ij1 >= 0; // (uniform) a workgroup with one item parks nothing
     // PARKING.  The prologue of wave 0 -- one memory round trip, the sums of 256 rows, the state machine on one lane -- takes
     // 6-9 us, and the 128 KB register window lands in 5.  Round 2 let the memory system idle until the decision was there.
     // Now waves 1..7 move each row of the first item into LDS the moment it arrives and request the same row of the SECOND item
@@ -634,12 +640,12 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     auto run_group = [&](auto first_tag, const int it) __attribute__((always_inline)) -> bool {
         constexpr bool FIRST = decltype(first_tag)::value;
         const int Ia = ija >> 16, Ja = ija & 0xffff, Ib = ijb >> 16, Jb = ijb & 0xffff;
-        const bool has_b = ijb >= 0; // (uniform)
+        const bool has_b = PAIR || ijb >= 0; // (uniform)
         const bool diag_a = Ia == Ja, diag_b = has_b && Ib == Jb;
         // the items after this pair: where the window is refilled from while item b is consumed
         int ijc = -1, ijd = -1;
-        if (has_b && it + 2 < a.maxk) ijc = a.item_ij[(size_t)(it + 2) * a.G + blockIdx.x];
-        if (ijc >= 0 && it + 3 < a.maxk) ijd = a.item_ij[(size_t)(it + 3) * a.G + blockIdx.x];
+        if (!PAIR && has_b && it + 2 < a.maxk) ijc = a.item_ij[(size_t)(it + 2) * a.G + blockIdx.x];
+        if (!PAIR && ijc >= 0 && it + 3 < a.maxk) ijd = a.item_ij[(size_t)(it + 3) * a.G + blockIdx.x];
         const bool take_c = ijc >= 0 && ijd < 0; // the last, odd item joins this group
         const int Ic = ijc >> 16, Jc = ijc & 0xffff;
         const bool diag_c = take_c && Ic == Jc;
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
             return a.Q + (size_t)(I_ * QN_TB + wave * QN_S2_RPW) * np + (size_t)J_ * QN_TB + qn_s2_col(I_ == J_, lane, wave);
         };
         // (row slivers: every workgroup has exactly a.maxk items and one sliver, which joins the last group in item c's place)
-        const bool sliver = a.sl_per != 0 && ijc < 0; // (uniform)
+        const bool sliver = PAIR || (a.sl_per != 0 && ijc < 0); // (uniform)
         const QnS2Sliver sl = qn_s2_sliver(a, wave);
         const double* slp = a.Q + (size_t)(sl.D * QN_TB + sl.row) * np + (size_t)sl.D * QN_TB + 2 * lane;
         QnS2SliverVec slv{};
@@ -729,9 +735,11 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         __syncthreads(); // colred / colsum / sred are rewritten by the next group
         return false;
     };
-    if (!run_group(std::true_type{}, 0))
-        for (int it = 2;; it += 2)
-            if (run_group(std::false_type{}, it)) break;
+    if (!run_group(std::true_type{}, 0)) {
+        if (!PAIR)
+            for (int it = 2;; it += 2)
+                if (run_group(std::false_type{}, it)) break;
+    }
     QN_S2_STAMP(15);
     if (tid < QN_S2_NSE) { // sred column -> table column: xt'(Q xt - 2b), d'(Q xt - b), (b'xt = 0), (b'd = 0), g'd, #non-finite d
         const int col = tid == 1 ? 2 : (tid == 2 ? 1 : tid);

@@ -141,6 +141,10 @@ def test_row_slivers_at_4096(qn, qo, method, lsname):
     assert np.abs(h - h_r).max() <= 1e-9 * np.abs(h_r).max()
     sy, st_y = _run(qn, method, lsname, obj, x0, iters, sync=1)
     assert st_y == st and sy.trace()[0] == tr and np.array_equal(sy.approx_inv_hessian(), h)
+    # the evaluation kernel's two-items-and-a-sliver instance (s2_eval_kernel<true>) against the general body on the same lists:
+    # the same sums in the same order
+    g, st_g = _run(qn, method, lsname, obj, x0, iters, tiling=(-9, 0))
+    assert st_g == st and g.trace()[0] == tr and np.array_equal(g.approx_inv_hessian(), h)
     # against the oracle, as the parity sweep does
     ref = qo.Solver(qo.BFGS if method == "bfgs" else qo.DFP, 1e-10, x0, qo.UPDATE_RANK2)
     ls = qo.morethuente() if lsname == "mt" else qo.backtracking(1e-4, 0.5)
