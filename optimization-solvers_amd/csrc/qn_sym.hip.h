@@ -115,6 +115,7 @@ __device__ __forceinline__ void qn_sym_tile(int t, int nb, int& I, int& J) {
 // the evaluation request, decoded exactly as quad_eval_fused_kernel decodes it (incl. the deferred update's coefficients)
 struct QnEvalReq {
     double t, c_ss, c_su, c_uu, ug, sg;
+    double al, be; // second-generation path only: d = -(v + al s + be u), al = c_su (u.g) + c_ss (s.g), be = c_su (s.g) + c_uu (u.g)
     int mode, xc, sc;
     bool is_t;
 };

@@ -313,7 +313,14 @@ __device__ __forceinline__ QnEvalReq qn_s2_eval_req(const QnCtl& c, bool last_ev
     q.t = last_eval ? c.ev_t : c.req_t;
     q.mode = c.dir_mode;
     q.c_ss = c.c_ss; q.c_su = c.c_su; q.c_uu = c.c_uu; q.ug = c.dir_ug; q.sg = c.dir_sg;
+    // The lazy direction -H+ g+ = -(v + c_su (s (u.g) + u (s.g)) + c_ss s (s.g) + c_uu u (u.g)) with the two vector coefficients
+    // formed ONCE per wave: every lane forms d at three indices per item, and at thirteen operations each the trial points were a
+    // fifth of the instructions behind the workgroup barrier.  (Same formula in the evaluation tiles and in the accept-reduce:
+    // the x+ that is stored is the point that was evaluated.)
+    q.al = q.c_su * q.ug + q.c_ss * q.sg;
+    q.be = q.c_su * q.sg + q.c_uu * q.ug;
     q.xc = c.xc; q.sc = c.sc;
+    if (PIN) { q.al = qn_uniform(q.al); q.be = qn_uniform(q.be); }
     if (PIN) { // (the tile kernel; the accept-reduce has registers to spare and only pays the readfirstlane latency)
         q.is_t = __builtin_amdgcn_readfirstlane(q.is_t) != 0;
         q.t = qn_uniform(q.t);
@@ -384,7 +391,7 @@ __device__ __forceinline__ bool qn_s2_col_on(bool diag, int lane, int wave) { re
 // x + t d at one index from loaded values: the arithmetic of qn_trial_entry (qn_sym.hip.h), which the accept-reduce uses
 __device__ __forceinline__ double qn_s2_trial(const QnEvalReq& q, const double xi, const double vi, const double si, const double ui, double& d) {
     if (!q.is_t) { d = 0.0; return xi; }
-    d = qn_dir1(q.mode, vi, q.mode ? si : 0.0, q.mode ? ui : 0.0, q.c_ss, q.c_su, q.c_uu, q.ug, q.sg);
+    d = q.mode ? -(vi + __builtin_fma(q.be, ui, q.al * si)) : -vi;
     const double td = q.t * d; // `step * direction` rounds first (bfgs.rs:94)
     return xi + td;
 }
@@ -811,7 +818,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
         const int gi = R * QN_TB + tid;
         double di;
         const double xi = x[gi];
-        const double xti = qn_trial_entry(q, x, a.F.VV, sp, a.F.UN, gi, &di);
+        const double xti = qn_s2_trial(q, xi, a.F.VV[gi], sp[gi], a.F.UN[gi], di);
         const double bi = a.F.b[gi], go = a.F.G[gi];
         const double gti = qi - bi;
         const double yi = gti - go;
@@ -1173,7 +1180,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
             const double gti = fv[2 * k][1][tid], yi = fv[2 * k][2][tid];
             double di;
             const double xi = x[gi];
-            const double xti = qn_trial_entry(qe, x, a.F.VV, spv, a.F.UN, gi, &di);
+            const double xti = qn_s2_trial(qe, xi, a.F.VV[gi], spv[gi], a.F.UN[gi], di);
             const double si = xti - xi; // s = x+ - x, not t d (bfgs.rs:96)
             a.F.GT[gi] = gti;
             a.F.Y[gi] = yi;
