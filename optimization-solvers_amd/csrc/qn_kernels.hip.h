@@ -121,14 +121,14 @@ __device__ __forceinline__ double qn_wave_sum(double v) {
 #define QN_FOLD_SWAP_MIN_V 16
 #endif
 // ---- halving butterfly: V values per lane -> lane l ends with the wave total of value (l >> (6 - log2 V)) in v[0]
-template <int CNT, int OFF>
+template <int CNT, int OFF, bool SWAP = false> // SWAP: the swap form (below) whatever the number of values
 struct QnWaveFold {
     template <int V>
     static __device__ __forceinline__ void run(double (&v)[V], int lane) {
         if constexpr (OFF >= 1) {
             if constexpr (CNT > 1) {
                 constexpr int HALF = CNT / 2;
-                if constexpr ((OFF == 32 || OFF == 16) && V >= QN_FOLD_SWAP_MIN_V) {
+                if constexpr ((OFF == 32 || OFF == 16) && (SWAP || V >= QN_FOLD_SWAP_MIN_V)) {
                     // v_permlane32_swap A, B exchanges the upper half of A with the lower half of B (v_permlane16_swap: the odd
                     // 16-lane rows of A with the even rows of B): afterwards A' + B' IS the folded pair -- value i in the lanes
                     // with (lane & OFF) == 0, value i + HALF in the others, each lane holding its own entry plus its partner's.
@@ -158,10 +158,10 @@ struct QnWaveFold {
                         v[i] = keep + recv;
                     }
                 }
-                QnWaveFold<HALF, OFF / 2>::run(v, lane);
+                QnWaveFold<HALF, OFF / 2, SWAP>::run(v, lane);
             } else {
                 v[0] = v[0] + qn_xor_lanes<OFF>(v[0]);
-                QnWaveFold<1, OFF / 2>::run(v, lane);
+                QnWaveFold<1, OFF / 2, SWAP>::run(v, lane);
             }
         }
     }

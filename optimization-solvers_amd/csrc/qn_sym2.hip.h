@@ -698,7 +698,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         if (sliver) t0s = qn_s2_eval_sliver(slv, h[0], sl.row, lane, sacc); // (h[0]: the window holds the sliver's row sixteen times)
         { // ONE fold for the group: the four scalars and the sliver's row total (value 6: lane 48 holds it)
             double sv[8] = {sacc[0], sacc[1], 0.0, 0.0, sacc[2], sacc[3], t0s, 0.0};
-            QnWaveFold<8, 32>::run(sv, lane);
+            QnWaveFold<8, 32, true>::run(sv, lane);
             if ((lane & 7) == 0 && lane < 48) sred[wave][lane >> 3] = sv[0];
             if (sliver) row_c = sv[0];
         }
