@@ -799,9 +799,11 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     __shared__ double bred[2][8];
     const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QnS2Slots S0;
+    QN_S2_STAMP(0);
     if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC>(a, L);
     qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0);
     __syncthreads();
+    QN_S2_STAMP(2);
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
     const size_t np = (size_t)a.np;
@@ -835,6 +837,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     }
     __syncthreads();
     if (tid < QN_S2_NR) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = bred[0][tid] + bred[1][tid];
+    QN_S2_STAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------------

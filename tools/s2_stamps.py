@@ -32,6 +32,11 @@ order = [9, 10, 11, 1, 6, 7, 8, 2, 13, 14, 12, 3, 4, 5, 15]
 label = {12: "w7 pair folded", 13: "w7 item a done", 14: "w7 item b done", 6: "w7 requested", 7: "w7 parked", 8: "w7 at barrier", 9: "ctl", 10: "sums", 11: "machine", 1: "w0 at barrier", 2: "barrier", 3: "w0 pair folded", 4: "pair barrier", 5: "pair stored", 15: "end"}
 for slot in range(64):
     t = st[slot]
+    if t[0, 14] != 0 and t[0, 0] != 0 and t[0, 3] == 0:  # an accept-reduce launch that did work (32 workgroups; stamp 3 is the evaluation's)
+        w = t[:32]
+        print("slot %2d (accept-reduce): ctl %d, sums %d, machine %d, barrier %d, end %d; last workgroup's end %d" % (
+            slot, *[int(np.median((w[:, k] - w[:, 0]) * 10)) for k in (9, 10, 11, 2, 14)], int((w[:, 14].max() - w[:, 0].min()) * 10)))
+        continue
     if t[0, 15] == 0 or t[0, 0] == 0 or t[0, 3] == 0:
         continue  # not an evaluation launch that did work
     wg = (t[:, 0] > 0) & (t[:, 15] > 0)
