@@ -22,7 +22,7 @@
 //
 // Rounds 1-2 ran the panel with these two launches per column (~16 000 small launches at n = 8192: 146-196 ms per Newton
 // iteration, rocprofv3 r03_a); they remain the path for panels of more than 8192 rows and the reference the panel kernels below
-// are pinned against bit for bit (tests/test_gpu_newton.py).  Round 3: lu_panel_step_kernel -- 19 launches per panel, 67 ms.
+// are pinned against bit for bit (tests/test_gpu_newton.py).  Round 3: lu_panel_step_kernel -- 19 launches per panel, 65 ms.
 // As nalgebra's gauss_step, the column is scaled by the reciprocal of the pivot.  Difference that stays at tolerance level:
 // nalgebra forms the explicit inverse and multiplies, this solves with the factors.
 #pragma once
@@ -282,12 +282,12 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restr
             const double v = fabs(a[j][jr]);
             if (i >= k && i < m && v > best) { best = v; idx = i; } // ascending i per thread: the first maximum (nalgebra's icamax)
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(idx, off, 64);
-            if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
-        }
+        // (xor butterfly on the VALU data path -- DPP / v_permlane*_swap, qn_xor_lanes -- instead of __shfl_xor: that is three
+        // ds_bpermute round trips per level, ~2000 cycles of LDS-pipeline latency inside every pivot step of the chain)
+#define QN_LU_ARGMAX_LEVEL(OFF) { const double ov = qn_xor_lanes<OFF>(best); const int oi = qn_xor_lanes_i<OFF>(idx); \
+                                  if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; } }
+        QN_LU_ARGMAX_LEVEL(32) QN_LU_ARGMAX_LEVEL(16) QN_LU_ARGMAX_LEVEL(8) QN_LU_ARGMAX_LEVEL(4) QN_LU_ARGMAX_LEVEL(2) QN_LU_ARGMAX_LEVEL(1)
+#undef QN_LU_ARGMAX_LEVEL
         if (lane == 0) { bv[j][wave] = best; bi[j][wave] = idx; }
         if (j == 0) QN_LU_STAMP(3);
         __syncthreads();
@@ -462,8 +462,7 @@ __global__ __launch_bounds__(256) void lu_fwd_step_kernel(const double* __restri
     const double xl = xk[lane];
     for (int r = k0 + QN_NB + blockIdx.x * 4 + wave; r < nrows; r += gridDim.x * 4) {
         double p = W[(size_t)r * ld + k0 + lane] * xl;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+        p = qn_wave_sum(p); // (xor 32, 16, ... 1 on the VALU data path: the same order as the __shfl_xor loop it replaces)
         if (lane == 0) rhs[r] = rhs[r] - p;
     }
 }
@@ -491,8 +490,7 @@ __global__ __launch_bounds__(256) void lu_bwd_step_kernel(const double* __restri
     const double zl = zk[lane];
     for (int r = blockIdx.x * 4 + wave; r < k0; r += gridDim.x * 4) {
         double p = W[(size_t)r * ld + k0 + lane] * zl;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+        p = qn_wave_sum(p); // (xor 32, 16, ... 1 on the VALU data path: the same order as the __shfl_xor loop it replaces)
         if (lane == 0) rhs[r] = rhs[r] - p;
     }
 }
