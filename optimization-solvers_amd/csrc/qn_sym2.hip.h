@@ -800,8 +800,10 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QnS2Slots S0;
     QN_S2_STAMP(0);
-    if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC>(a, L);
-    qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0);
+    // (wave 0 requests its share of the slots behind the control block and the table, BEFORE it runs the machine: requested after
+    // it -- 3.5 us into a 6 us kernel -- they were what the slot sums waited for)
+    if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC>(a, L, [&]() { qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0); });
+    else qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0);
     __syncthreads();
     QN_S2_STAMP(2);
     qn_s2_ctl_out(a, L);
@@ -1206,9 +1208,8 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
     __shared__ double bred[2][8];
     const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QnS2Slots S0, S1;
-    if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE>(a, L);
-    qn_s2_slot_issue(a.part, a.nb, R, 0, S0);
-    qn_s2_slot_issue(a.part, a.nb, R, 1, S1);
+    if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE>(a, L, [&]() { qn_s2_slot_issue(a.part, a.nb, R, 0, S0); qn_s2_slot_issue(a.part, a.nb, R, 1, S1); });
+    else { qn_s2_slot_issue(a.part, a.nb, R, 0, S0); qn_s2_slot_issue(a.part, a.nb, R, 1, S1); }
     __syncthreads();
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
