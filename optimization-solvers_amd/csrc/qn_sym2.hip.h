@@ -892,6 +892,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     __shared__ double fred[2][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
+    QN_S2_STAMP(0);
     int ij = qn_s2_first_item(blockIdx.x, a.nb);
     const int ij1 = qn_s2_second_item(a);
     const int ij2 = (FOLD && ij1 >= 0 && a.maxk > 2) ? a.item_ij[(size_t)2 * a.G + blockIdx.x] : -1;
@@ -990,6 +991,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     qn_s2_ctl_out(a, L);
     const int mine = L.mine;
     if (!mine) return;
+    QN_S2_STAMP(2);
     if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < QN_S2_RPW; ++r) h[r] = park0[r][lane];
@@ -1042,7 +1044,6 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     // zero vectors: H + 0 (0 0) = H.  (The path requires n = n_pad: no padding entries to keep at zero.)
     const bool pend = q.pending;
     const double c_ss = pend ? q.c_ss : 0.0, c_su = pend ? q.c_su : 0.0, c_uu = pend ? q.c_uu : 0.0;
-    const bool up = (lane & 32) != 0;
     const bool slv = !FOLD && a.sl_per != 0; // (uniform; the host never combines the folded accept-reduce with row slivers)
     // (the sliver's addresses are formed where they are used, behind an empty asm: as loop invariants they were held in registers
     // across the row loops, which have none to spare)
@@ -1095,7 +1096,12 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
             t1 = __builtin_fma(hn.y, a1.y, t1);
             // first level of the 32-value butterfly (the row's sum for y against its sum for g+, lane against lane ^ 32) at
             // once: two sums become one register; QnWaveFold<16, 16> finishes the same tree after the last row
-            racc[r] = (up ? t1 : t0) + qn_xor_lanes<32>(up ? t0 : t1);
+            // (as one v_permlane32_swap of the pair per half: A' + B' is the folded pair -- no selects: QnWaveFold)
+            {
+                const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(t0), __double2loint(t1), false, false);
+                const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(t0), __double2hiint(t1), false, false);
+                racc[r] = __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+            }
             c0x = __builtin_fma(hn.x, y0, c0x);
             c0y = __builtin_fma(hn.y, y0, c0y);
             c1x = __builtin_fma(hn.x, y1, c1x);
@@ -1117,6 +1123,8 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
             asm volatile("" : "+v"(r), "+v"(c));
             qn_s2_hvec_load<true>(q, r, c, v0);
         }
+        if (it == 0) { qn_keepalive(racc[0]); QN_S2_STAMP(3); QN_S2_STAMP_T(12, 448); }
+        if (it == 1) { qn_keepalive(racc[0]); QN_S2_STAMP(6); QN_S2_STAMP_T(13, 448); }
         QnWaveFold<QN_S2_RPW, 16>::run(racc, lane); // lanes with (lane & 1) == 0: total of row (lane >> 1) & 15 for rhs lane >> 5
         colred[wave][0][2 * lane] = c0x;
         colred[wave][0][2 * lane + 1] = c0y;
@@ -1136,6 +1144,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
             if (diag) a.part[(unsigned)(((I * a.nb + I) * 2 + crhs) * QN_TB + c)] = colsum[crhs][c] + acc; // row part + column part
             else a.part[(unsigned)(((J * a.nb + I) * 2 + crhs) * QN_TB + c)] = acc;
         }
+        if (it == 0) QN_S2_STAMP(5);
         if (!has_next) break;
         I = In; J = Jn; hbase = hnext;
         __syncthreads(); // the LDS staging areas are rewritten by the next item
@@ -1165,6 +1174,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         const QnS2Sliver sl = qn_s2_sliver(a, wave);
         if ((lane & 31) == 0) a.part[(unsigned)(((sl.D * a.nb + sl.D) * 2 + (lane >> 5)) * QN_TB + sl.row)] = tt[0];
     }
+    QN_S2_STAMP(15);
     if (!fold) return; // (uniform)
     // Folded accept-reduce, the owner's part: the workgroup that holds the diagonal item (R, R) writes block R of the vectors
     // (g+, y, x+, s = x+ - x: bfgs.rs:94-99) and block R's five sums -- after its tiles, because nothing in this launch reads them

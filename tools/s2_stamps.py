@@ -37,6 +37,13 @@ for slot in range(64):
         print("slot %2d (accept-reduce): ctl %d, sums %d, machine %d, barrier %d, end %d; last workgroup's end %d" % (
             slot, *[int(np.median((w[:, k] - w[:, 0]) * 10)) for k in (9, 10, 11, 2, 14)], int((w[:, 14].max() - w[:, 0].min()) * 10)))
         continue
+    if t[0, 6] != 0 and t[0, 15] != 0 and t[0, 0] != 0 and t[0, 4] == 0:  # an update-tile launch (stamps 3 / 6: rows of item 1 / 2 consumed by wave 0, 12 / 13: by wave 7)
+        wg = t[:, 15] > 0
+        w = t[wg]
+        end = (w[:, 15] - w[:, 0].min()) * 10
+        print("slot %2d (update tiles): " % slot + ", ".join("%s %d" % (nm, int(np.median((w[:, k] - w[:, 0]) * 10))) for nm, k in (("ctl", 9), ("sums", 10), ("machine", 11), ("barrier", 2), ("w0 item 1 rows", 3), ("w7 item 1 rows", 12), ("item 1 stored", 5), ("w0 item 2 rows", 6), ("w7 item 2 rows", 13), ("end", 15)))
+              + "; workgroup ends p50 %d p90 %d max %d" % (np.median(end), np.percentile(end, 90), end.max()))
+        continue
     if t[0, 15] == 0 or t[0, 0] == 0 or t[0, 3] == 0:
         continue  # not an evaluation launch that did work
     wg = (t[:, 0] > 0) & (t[:, 15] > 0)
