@@ -274,7 +274,8 @@ int qn_solver_set_sync_mode(qn_solver* s, int sync);
  * matrices instead of the symmetric-storage tiles, -4 the first-generation symmetric tile kernels (separate control
  * launches), -5 Newton by pivoted LU even for an SPD Hessian, -6 the second-generation path with the accept-reduce folded into
  * the update-tile launch (4 launches per iteration; measured neutral, off by default), -7 toggles the row slivers of that path
- * (n = 4096: whole tiles only, as in round 2), -8 the LU panel with two launches per column (rounds 1-2);
+ * (n = 4096: whole tiles only, as in round 2), -8 the LU panel with two launches per column (rounds 1-2), -9 toggles the
+ * evaluation kernel's two-items-and-a-sliver instance (off: the general body on the same work lists);
  * col_splits = 100 + U selects U column chunks per loop trip */
 int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits);
 
