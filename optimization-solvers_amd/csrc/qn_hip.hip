@@ -2239,7 +2239,9 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.nt = s->T.n_pad >= 8192; // H past the Infinity Cache: every byte is touched once per pass
         // (no synchronisation: the copy is stream-ordered in front of the launches, the mirror is pinned, and the host does not
         // write it again before s2_peek has synchronised)
-        HIPCHK(hipMemcpyAsync(s->s2_ctl, s->hctl, sizeof(QnCtl), hipMemcpyHostToDevice, c->stream));
+        // (a one-workgroup launch that reads the pinned mirror, not hipMemcpyAsync: the copy path put ~8 us in front of the first
+        // kernel of every call -- 0.6 % of the driver's 20-step region)
+        hipLaunchKernelGGL(s2_ctl_upload_kernel, dim3(1), dim3(256), 0, c->stream, s->hctl, s->s2_ctl);
     } else {
         QNCHK(poke_ctl(s));
     }

@@ -1249,6 +1249,12 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
     if (tid < 2) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = bred[0][tid] + bred[1][tid];
 }
 
+// the host's control block (pinned memory) -> ctl2[0]: a launch instead of a copy-engine transfer in front of the first kernel
+__global__ __launch_bounds__(256) void s2_ctl_upload_kernel(const QnCtl* __restrict__ host_ctl, QnCtl* __restrict__ dev_ctl) {
+    constexpr int NW = (int)(sizeof(QnCtl) / 8);
+    if ((int)threadIdx.x < NW) reinterpret_cast<uint64_t*>(dev_ctl)[threadIdx.x] = reinterpret_cast<const uint64_t*>(host_ctl)[threadIdx.x];
+}
+
 // synchronous mode: the prologue alone (one workgroup)
 __global__ __launch_bounds__(128) void s2_advance_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
