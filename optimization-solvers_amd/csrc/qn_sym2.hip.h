@@ -951,7 +951,10 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     }
     // (Measured and dropped, rocprofv3 averages on the same box: parking the first item in LDS as the evaluation does.  This
     // kernel's prologue consumes an evaluation that is accepted -- a short run of the machine -- and every row is written back as
-    // well: 26.2 us without parking, 28.0-28.4 with.)
+    // well: 26.2 us without parking, 28.0-28.4 with.  Again at the end of round 3, with wave 0's loads behind the barrier and two
+    // straight-line copies of the row loop: 22.9-23.0 against 23.1-23.8 us, and the small kernels 0.1-0.2 us slower: dropped.
+    // Also without effect on this kernel: the BFGS update as s q' + q s' with q = c_su u + (c_ss / 2) s (eight VALU instructions
+    // fewer per row, still bitwise symmetric), and an instance for exactly two items and a sliver.)
     v2d h[QN_S2_RPW]; // the wave's 16 rows of the first item go out before the control block is known
     double* hbase = a.H + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
     if (wave != 0) {
