@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define QN_ABI_VERSION 2
+#define QN_ABI_VERSION 3
 
 /* SolverError (ls_solver.rs:10-20); 0 is Ok(()) */
 typedef enum {
@@ -257,6 +257,10 @@ typedef struct {
      * t_hpass_ms / t_eval_ms then hold the tile kernels alone */
     double   t_hreduce_ms, t_ereduce_ms;
     uint64_t n_hreduce_timed, n_ereduce_timed;
+    /* row-sharded runs: collectives enqueued by every qn_minimize call of this solver so far -- of n-vectors (mat-vec partials:
+     * the all-reduce north_star names, as an all-gather + rank-order sum or as ncclAllReduce), and of per-workgroup scalars
+     * (8 KB per rank: what an evaluation hands the line search on the second-generation path) */
+    uint64_t total_xchg_vector, total_xchg_scalar;
 } qn_stats;
 #define QN_PATH_FUSED 1u       /* fused fast path (device quadratic, memoised): no kernel but the streaming ones touches an n-vector */
 #define QN_PATH_SYM 2u         /* ... on the symmetric half of H and Q only */

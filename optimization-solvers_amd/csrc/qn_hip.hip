@@ -112,6 +112,7 @@ struct qn_context {
     void* host_xchg_user = nullptr;
     std::vector<double> xchg_send, xchg_recv;
     uint64_t n_comm = 0;
+    uint64_t n_xchg_vector = 0, n_xchg_scalar = 0; // collectives a solver enqueued on this context: of n-vectors, of per-workgroup scalars
     // host-staged exchange in STREAM ORDER (qn_context_set_host_exchange_async): pinned staging, the callback runs as a
     // hipLaunchHostFunc node between the two copies, nothing synchronises -- the pipelined launch logic can then be rehearsed
     // with several ranks on one GPU
@@ -645,6 +646,7 @@ static int lse_enqueue_eval(qn_objective* o, const double* x_dev, double* f_dev,
         hipLaunchKernelGGL(lse_combine_kernel, dim3((a.n_pad + 63) / 64), dim3(256), 0, st, a, o->lse_G, o->lwgms, o->lwgg, o->lms);
         HIPCHK(hipGetLastError());
         const XchgItem items[2] = {{o->lgall, (size_t)a.n_pad}, {o->lms, 2}};
+        c->n_xchg_vector++;
         QNCHK(exchange_group(c, items, 2));
         hipLaunchKernelGGL(lse_finish1_kernel, dim3(std::min(1024, (a.n_pad + 255) / 256)), dim3(256), 0, st, a, o->lms);
         HIPCHK(hipGetLastError());
@@ -658,6 +660,7 @@ static int lse_enqueue_eval(qn_objective* o, const double* x_dev, double* f_dev,
     h.sp = x_dev; h.up = x_dev;
     launch_hpass<8>(st, h);
     HIPCHK(hipGetLastError());
+    c->n_xchg_vector++;
     QNCHK(exchange(c, o->lz, 2 * (size_t)o->TA.rpr));
     QnLseArgs a{};
     a.A = o->Q; a.c = o->b; a.z = o->lz; a.w = o->lw; a.gpart = o->lgpart; a.gall = o->lgall; a.x = x_dev;
@@ -669,6 +672,7 @@ static int lse_enqueue_eval(qn_objective* o, const double* x_dev, double* f_dev,
     hipLaunchKernelGGL(lse_colsum_kernel, dim3((a.n_pad + QN_CHUNK - 1) / QN_CHUNK, a.rs), dim3(QN_TPB), 0, st, a);
     hipLaunchKernelGGL(lse_reduce_splits_kernel, dim3(std::min(1024, (a.n_pad + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
+    c->n_xchg_vector++;
     QNCHK(exchange(c, o->lgall, (size_t)a.n_pad));
     hipLaunchKernelGGL(lse_finish_kernel, dim3(std::min(1024, (a.n_pad + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
@@ -799,6 +803,10 @@ struct qn_solver {
     bool no_sliver = false;    // diagnostics: sym2 without row slivers (round 2's work lists)
     bool no_pair = false;      // diagnostics: the general evaluation kernel where the two-items-and-a-sliver instance would run
     bool h_sliver_whole = false; // the diagonal tiles that sliver rows read are complete (both triangles): kept so by sliver-mode update passes
+    double* s2_evS = nullptr;   // row-sharded: [2][world][QN_S2SH_NEC][QN_S2_MAXG] the ranks' evaluation scalars, by launch parity (QnS2Args.evS)
+    int *s2_sl_off = nullptr, *s2_sl_idx = nullptr; // row-sharded: per block-row, the slots this rank's tiles write (QnS2Args.sl_off / sl_idx)
+    int s2_sl_nb = 0;
+    int s2_slots_hint = 0;      // row-sharded, pipelined: evaluation launches (each followed by a collective) enqueued per period
     double* s2_partE = nullptr; // [nb][nb][128]: row / column slots of the last evaluation (QnS2Args.partE)
     double* s2_wgS = nullptr; // [2][s2_trows][QN_S2_ROW]: the sums a servicing launch leaves for the next launch's prologue, by launch parity
     int s2_trows = 0;
@@ -925,61 +933,129 @@ static int solver_alloc_fused(qn_solver* s, bool sym) {
     return QN_OK;
 }
 
-// sym2: work items (off-diagonal tiles cost 1, diagonal tiles -- upper triangle only -- 0.5625), assigned to min(items, 512)
-// workgroups by longest-processing-time-first so that every workgroup streams the same number of bytes to within one tile
+// Row-sharded symmetric storage (both generations of kernels): per block-row R, the slots this rank's tiles write -- R's own
+// window (row parts; a diagonal tile's single slot) and the column parts of the local block-rows whose windows contain R.  Every
+// unordered pair of block-rows is owned once, so no slot appears twice; ascending order = the summation order of the rank's share.
+static int solver_alloc_symsh_lists(qn_solver* s) {
+    const int nb = s->T.n_pad / QN_TB;
+    if (s->s2_sl_off && s->s2_sl_nb == nb) return QN_OK;
+    (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx);
+    s->s2_sl_off = nullptr; s->s2_sl_idx = nullptr;
+    const int nbl = s->T.rpr / QN_TB, ioff = s->ctx->rank * nbl;
+    std::vector<int> off(nb + 1, 0), idx;
+    for (int R = 0; R < nb; ++R) {
+        const bool r_local = R >= ioff && R < ioff + nbl;
+        for (int t = 0; t < nb; ++t) {
+            const bool t_local = t >= ioff && t < ioff + nbl;
+            if ((r_local && qn_symsh_owns(R, t, nb)) || (t_local && t != R && qn_symsh_owns(t, R, nb))) idx.push_back(t);
+        }
+        off[R + 1] = (int)idx.size();
+    }
+    if (idx.empty()) idx.push_back(0);
+    HIPCHK(hipMalloc((void**)&s->s2_sl_off, off.size() * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&s->s2_sl_idx, idx.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(s->s2_sl_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->s2_sl_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    s->s2_sl_nb = nb;
+    return QN_OK;
+}
+
+// sym2: work items (off-diagonal tiles cost 1, diagonal tiles -- upper triangle only -- 0.5625), assigned to min(items, 256)
+// workgroups by longest-processing-time-first so that every workgroup streams the same number of bytes to within one tile.
+// Row-sharded runs: the items are the tiles of the rank's circulant windows (qn_sym.hip.h), the grid is the same on every rank
+// (the ranks' per-workgroup scalars are exchanged as rows of one table), and the rank gets the list of slots its tiles write.
 static int solver_alloc_sym2(qn_solver* s) {
     const int nb = s->T.n_pad / QN_TB;
     hipStream_t st = s->ctx->stream;
-    const int cfg = (s->fold ? 1 : 0) | (s->no_sliver ? 2 : 0);
+    const int world = s->ctx->world, rank = s->ctx->rank;
+    const bool sharded = world > 1;
+    const int cfg = (s->fold ? 1 : 0) | (s->no_sliver ? 2 : 0) | (sharded ? 4 : 0);
     if (s->s2_nb != nb || s->s2_sl_cfg != cfg) {
         (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE);
+        (void)hipFree(s->s2_evS);
         s->s2_items = nullptr; s->s2_wgS = nullptr; s->s2_partE = nullptr;
+        s->s2_evS = nullptr;
         s->s2_nb = 0;
-        const int nitems = nb * (nb + 1) / 2;
-        const int G = std::min(nitems, QN_S2_MAXG);
+        const int nbl = s->T.rpr / QN_TB, ioff = rank * nbl; // (sharded: this rank's block-rows)
+        int nitems = nb * (nb + 1) / 2;
+        int G = std::min(nitems, QN_S2_MAXG);
+        if (sharded) {
+            // every rank launches the same grid: the smallest share of tiles bounds it (each workgroup has at least one item)
+            nitems = qn_symsh_ntiles(nb, nbl, ioff);
+            int least = nitems;
+            for (int r = 0; r < world; ++r) least = std::min(least, qn_symsh_ntiles(nb, nbl, r * nbl));
+            G = std::min(least, QN_S2_MAXG);
+            if (G < 1) return fail(QN_ABNORMAL_TERMINATION, "sym2: a rank without tiles");
+        }
+        std::vector<std::vector<int>> lists;
+        int inorder = 0;
+        // deals the items to G lists; L: the last L diagonal tiles stay off the lists (row slivers)
+        auto deal = [&](int L) {
+            lists.assign(G, std::vector<int>());
+            std::vector<std::pair<double, int>> heap; // (-load, workgroup): max-heap on the least loaded
+            for (int g = 0; g < G; ++g) heap.push_back({0.0, -g});
+            std::make_heap(heap.begin(), heap.end());
+            auto give = [&](int I, int J, double cost) {
+                std::pop_heap(heap.begin(), heap.end());
+                auto e = heap.back();
+                lists[-e.second].push_back((I << 16) | J);
+                e.first -= cost;
+                heap.back() = e;
+                std::push_heap(heap.begin(), heap.end());
+            };
+            if (sharded) { // the windows' off-diagonal tiles in window order, then the diagonal ones (the cheap items last)
+                inorder = 0; // (the kernels read every item from the list: qn_s2_first_item_of)
+                for (int il = 0; il < nbl; ++il) {
+                    const int I = ioff + il, cnt = qn_symsh_cnt(I, nb);
+                    for (int k = 1; k < cnt; ++k) give(I, (I + k) % nb, 1.0);
+                }
+                for (int il = 0; il < nbl; ++il) give(ioff + il, ioff + il, 0.5625);
+                return;
+            }
+            // the first min(2 G, items) items go out in order -- item t to workgroup t mod G -- so the kernels compute a workgroup's
+            // first two items from its index (qn_s2_item_of_index); the rest to whoever has streamed least so far
+            inorder = std::min(nitems - L, 2 * G);
+            std::vector<double> load0(G, 0.0);
+            int handed = 0;
+            auto hand = [&](int I, int J, double cost) {
+                if (handed < inorder) {
+                    lists[handed % G].push_back((I << 16) | J);
+                    load0[handed % G] += cost;
+                    ++handed;
+                    if (handed == inorder) {
+                        for (auto& e : heap) e.first = -load0[-e.second];
+                        std::make_heap(heap.begin(), heap.end());
+                    }
+                } else {
+                    give(I, J, cost);
+                }
+            };
+            for (int I = 0; I < nb; ++I)
+                for (int J = I + 1; J < nb; ++J) hand(I, J, 1.0);
+            for (int I = 0; I < nb - L; ++I) hand(I, I, 0.5625);
+        };
         // Row slivers (qn_sym2.hip.h, qn_s2_eval_sliver): when the tiles do not deal out evenly and the L left over can be cut into
         // one 8-row sliver per workgroup (16 L = G: n = 4096 on 256 workgroups), the last L diagonal tiles leave the work lists.
-        // (Every workgroup then has the same, even number of items: the sliver joins the last PAIR of the evaluation kernel.)
-        int L = nitems > G ? nitems % G : 0;
+        // The kernels take the sliver in the place of a last, odd item: EVERY list must then have the same, even length -- true
+        // when all items go out in order (n = 4096), not in general once the heap deals a tail of mixed costs (nb = 991
+        // passed the arithmetic test with lists of different, odd lengths -- the sliver of such a workgroup was never evaluated).
+        // So the lists are checked after the deal, and dealt again without slivers if they are not uniform.
+        int L = (!sharded && nitems > G) ? nitems % G : 0;
         if (!(L > 0 && 16 * L == G && L <= nb && ((nitems - L) / G) % 2 == 0 && !s->fold && !s->no_sliver)) L = 0;
+        deal(L);
+        if (L) {
+            bool uniform = true;
+            for (int g = 0; g < G; ++g) uniform = uniform && lists[g].size() == lists[0].size() && lists[g].size() % 2 == 0;
+            if (!uniform) { L = 0; deal(0); }
+        }
         s->s2_sl_first = nb - L;
         s->s2_sl_per = L ? G / L : 0;
+        if (s->s2_sl_per != 0 && (G % L != 0 || s->s2_sl_per != 16)) return fail(QN_ABNORMAL_TERMINATION, "sym2: row slivers do not tile the grid");
         s->s2_sl_cfg = cfg;
-        std::vector<std::vector<int>> lists(G);
-        std::vector<std::pair<double, int>> heap; // (-load, workgroup): max-heap on the least loaded
-        for (int g = 0; g < G; ++g) heap.push_back({0.0, -g});
-        std::make_heap(heap.begin(), heap.end());
-        auto give = [&](int I, int J, double cost) {
-            std::pop_heap(heap.begin(), heap.end());
-            auto e = heap.back();
-            lists[-e.second].push_back((I << 16) | J);
-            e.first -= cost;
-            heap.back() = e;
-            std::push_heap(heap.begin(), heap.end());
-        };
-        // the first min(2 G, items) items go out in order -- item t to workgroup t mod G -- so the kernels compute a workgroup's
-        // first two items from its index (qn_s2_item_of_index); the rest to whoever has streamed least so far
-        const int inorder = std::min(nitems - L, 2 * G);
-        std::vector<double> load0(G, 0.0);
-        int handed = 0;
-        auto hand = [&](int I, int J, double cost) {
-            if (handed < inorder) {
-                lists[handed % G].push_back((I << 16) | J);
-                load0[handed % G] += cost;
-                ++handed;
-                if (handed == inorder) {
-                    for (auto& e : heap) e.first = -load0[-e.second];
-                    std::make_heap(heap.begin(), heap.end());
-                }
-            } else {
-                give(I, J, cost);
-            }
-        };
-        for (int I = 0; I < nb; ++I)
-            for (int J = I + 1; J < nb; ++J) hand(I, J, 1.0);
-        for (int I = 0; I < nb - L; ++I) hand(I, I, 0.5625);
         size_t maxk = 0;
         for (int g = 0; g < G; ++g) maxk = std::max(maxk, lists[g].size());
+        for (int g = 0; g < G; ++g)
+            if (lists[g].empty()) return fail(QN_ABNORMAL_TERMINATION, "sym2: a workgroup without items");
         std::vector<int> items(maxk * (size_t)G, -1); // [k][g]: the workgroup's k-th item; -1 ends its list
         for (int g = 0; g < G; ++g)
             for (size_t k = 0; k < lists[g].size(); ++k) items[k * (size_t)G + g] = lists[g][k];
@@ -990,6 +1066,9 @@ static int solver_alloc_sym2(qn_solver* s) {
         s->s2_trows = std::max(QN_S2_MAXG, (nb + 63) / 64 * 64);
         QNCHK(dev_alloc_zero(&s->s2_wgS, (size_t)2 * s->s2_trows * QN_S2_ROW, st));
         QNCHK(dev_alloc_zero(&s->s2_partE, (size_t)nb * nb * QN_TB, st));
+        if (sharded) {
+            QNCHK(dev_alloc_zero(&s->s2_evS, (size_t)2 * world * QN_S2SH_NEC * QN_S2_MAXG, st));
+        }
         s->s2_G = G;
         s->s2_nb = nb;
     }
@@ -1062,6 +1141,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE); (void)hipFree(s->s2_ctl);
+    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
     delete s;
@@ -1303,6 +1383,7 @@ static QnSymShard sym_shard(const qn_solver* s) {
     sh.world = s->ctx->world; sh.rank = s->ctx->rank;
     sh.nbl = s->T.rpr / QN_TB; sh.ioff = sh.rank * sh.nbl;
     sh.xg = s->symsh_xg;
+    sh.sl_off = s->s2_sl_off; sh.sl_idx = s->s2_sl_idx;
     sh.nsum = s->ctx->use_allreduce ? 1 : sh.world; // all-reduce mode: the exchange already left the total in slice 0
     return sh;
 }
@@ -1315,6 +1396,8 @@ static int ensure_full_h(qn_solver* s) {
         const size_t np = (size_t)s->T.n_pad, blk = (size_t)QN_TB * np;
         const QnSymShard sh = sym_shard(s);
         if (!s->symsh_gath) HIPCHK(hipMalloc((void**)&s->symsh_gath, (size_t)c->world * blk * sizeof(double)));
+        if (s->h_diag_stale) // (second-generation tiles: inside the local diagonal tiles only the upper 16 x 16 sub-blocks are current)
+            hipLaunchKernelGGL(s2sh_diag_mirror_kernel, dim3(QN_TB / 32, QN_TB / 32, sh.nbl), dim3(256), 0, c->stream, s->H, s->T.n_pad, sh.ioff);
         for (int il = 0; il < sh.nbl; ++il) {
             HIPCHK(hipMemcpyAsync(s->symsh_gath + (size_t)c->rank * blk, s->H + (size_t)il * blk, blk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
             QNCHK(exchange(c, s->symsh_gath, blk));
@@ -1619,16 +1702,32 @@ static int s2_launch(Run& r, int kind) {
     a.dbg = s->V.dbg; a.slot = (int)r.s2_launches;
 #endif
     r.s2_launches++;
-    const int cls = kind == QN_S2_EVAL ? KC_EVAL : kind == QN_S2_VEC ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS : kind == QN_S2_HREDUCE ? KC_HREDUCE : KC_CTL;
+    const int cls = kind == QN_S2_EVAL ? KC_EVAL : (kind == QN_S2_VEC || kind == QN_S2_VSUM) ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS
+                  : (kind == QN_S2_HREDUCE || kind == QN_S2_HSUM) ? KC_HREDUCE : KC_CTL;
     ProfScope ps(s, cls);
+    const bool sh = a.sh_world > 1; // row-sharded: the SHARD instantiations (qn_sym2sh.hip.h)
     switch (kind) {
     case QN_S2_EVAL:
-        if (a.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        if (sh) hipLaunchKernelGGL((s2_eval_kernel<false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        else if (a.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         else hipLaunchKernelGGL(s2_eval_kernel<false>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         break;
-    case QN_S2_VEC: hipLaunchKernelGGL(s2_vec_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
+    case QN_S2_VSUM: hipLaunchKernelGGL(s2sh_vsum_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
+    case QN_S2_HSUM: hipLaunchKernelGGL(s2sh_hsum_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
+    case QN_S2_VEC:
+        if (sh) hipLaunchKernelGGL(s2_vec_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
+        else hipLaunchKernelGGL(s2_vec_kernel<false>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
+        break;
     case QN_S2_HTILE:
-        if (a.fold) { // (n <= 4096: H stays in the Infinity Cache, no streaming hints)
+        if (sh) {
+            if (s->method == QN_BFGS) {
+                if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, true, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+                else hipLaunchKernelGGL((s2_hpass_kernel<false, true, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            } else {
+                if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+                else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            }
+        } else if (a.fold) { // (n <= 4096: H stays in the Infinity Cache, no streaming hints)
             if (s->method == QN_BFGS) hipLaunchKernelGGL((s2_hpass_kernel<false, true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
             else hipLaunchKernelGGL((s2_hpass_kernel<false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         } else if (s->method == QN_BFGS) {
@@ -1641,8 +1740,14 @@ static int s2_launch(Run& r, int kind) {
         s->h_lower_stale = true; s->h_diag_stale = true;
         s->h_sliver_whole = a.sl_per != 0; // (sliver rows update every entry of their tiles; without them only the upper sub-blocks are kept)
         break;
-    case QN_S2_HREDUCE: hipLaunchKernelGGL(s2_hreduce_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
-    default: hipLaunchKernelGGL(s2_advance_kernel, dim3(1), dim3(128), 0, st, a); break;
+    case QN_S2_HREDUCE:
+        if (sh) hipLaunchKernelGGL(s2_hreduce_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
+        else hipLaunchKernelGGL(s2_hreduce_kernel<false>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
+        break;
+    default:
+        if (sh) hipLaunchKernelGGL(s2_advance_kernel<true>, dim3(1), dim3(128), 0, st, a);
+        else hipLaunchKernelGGL(s2_advance_kernel<false>, dim3(1), dim3(128), 0, st, a);
+        break;
     }
     s->stats.launches++;
     HIPCHK(hipGetLastError());
@@ -1654,6 +1759,53 @@ static int s2_peek(Run& r) { // the control block the last enqueued launch write
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
     s->stats.host_syncs++;
     return QN_OK;
+}
+
+// ---- one request of the sym2 machine = its launches and, row-sharded, the collectives between them ----
+// An evaluation: the tiles, then (sharded) ONE exchange of the ranks' per-workgroup scalars -- 8 KB per rank, whatever n is.
+static int s2_do_eval(Run& r) {
+    QNCHK(s2_launch(r, QN_S2_EVAL));
+    qn_solver* s = r.s;
+    qn_context* c = s->ctx;
+    if (r.s2.sh_world > 1) {
+        ProfScope ps(s, KC_COMM);
+        const size_t cnt = (size_t)QN_S2SH_NEC * QN_S2_MAXG;
+        double* half = s->s2_evS + (size_t)((r.s2_launches - 1) & 1) * (size_t)c->world * cnt; // the half the launch above wrote
+        c->n_xchg_scalar++;
+        if (c->use_allreduce) QNCHK(exchange_sum(c, half, cnt));
+        else QNCHK(exchange(c, half, cnt));
+    }
+    return QN_OK;
+}
+// the accepted point's vectors: (sharded) this rank's slot sums, the exchange of ONE n-vector, the epilogue on every rank
+static int s2_do_vec(Run& r) {
+    qn_solver* s = r.s;
+    qn_context* c = s->ctx;
+    if (r.s2.sh_world > 1) {
+        QNCHK(s2_launch(r, QN_S2_VSUM));
+        {
+            ProfScope ps(s, KC_COMM);
+            c->n_xchg_vector++;
+            if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, (size_t)s->T.n_pad));
+            else QNCHK(exchange(c, s->symsh_xg, (size_t)s->T.n_pad));
+        }
+        return s2_launch(r, QN_S2_VEC);
+    }
+    return s2_launch(r, r.s2.fold ? QN_S2_HTILE : QN_S2_VEC);
+}
+// the update pass: tiles (unless the folded accept-reduce ran them), (sharded) partial sums and the exchange of [u, v], the reduce
+static int s2_do_hpass(Run& r, bool tiles) {
+    qn_solver* s = r.s;
+    qn_context* c = s->ctx;
+    if (tiles) QNCHK(s2_launch(r, QN_S2_HTILE));
+    if (r.s2.sh_world > 1) {
+        QNCHK(s2_launch(r, QN_S2_HSUM));
+        ProfScope ps(s, KC_COMM);
+        c->n_xchg_vector++;
+        if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
+        else QNCHK(exchange(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
+    }
+    return s2_launch(r, QN_S2_HREDUCE);
 }
 
 static int launch_ctl_mask(Run& r, int expect_mask) {
@@ -1721,6 +1873,7 @@ static int enqueue_eval_fused(Run& r, int after_h) {
             HIPCHK(hipGetLastError());
             {
                 ProfScope ps(s, KC_COMM);
+                c->n_xchg_vector++;
                 if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, (size_t)s->T.n_pad));
                 else QNCHK(exchange(c, s->symsh_xg, (size_t)s->T.n_pad));
             }
@@ -1753,6 +1906,7 @@ static int enqueue_eval_fused(Run& r, int after_h) {
     if (c->world > 1) {
         ProfScope ps(s, KC_COMM);
         const XchgItem items[3] = {{s->V.F.GT, (size_t)s->T.rpr}, {s->V.F.Y, (size_t)s->T.rpr}, {s->V.F.evp, (size_t)QN_NEVP * s->V.F.nblk}};
+        c->n_xchg_vector++;
         QNCHK(exchange_group(c, items, 3));
     }
     return QN_OK;
@@ -1781,6 +1935,7 @@ static int enqueue_hpass_fused(Run& r) {
             HIPCHK(hipGetLastError());
             {
                 ProfScope ps(s, KC_COMM);
+                c->n_xchg_vector++;
                 if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
                 else QNCHK(exchange(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
             }
@@ -1813,6 +1968,7 @@ static int enqueue_hpass_fused(Run& r) {
     if (c->world > 1) {
         ProfScope ps(s, KC_COMM);
         const XchgItem items[3] = {{s->V.F.UN, (size_t)s->T.rpr}, {s->V.F.VV, (size_t)s->T.rpr}, {s->V.F.hpp, (size_t)QN_NHPP * s->V.F.nblk}};
+        c->n_xchg_vector++;
         QNCHK(exchange_group(c, items, 3));
     }
     return QN_OK;
@@ -1837,6 +1993,7 @@ static int enqueue_eval(Run& r, int after_h = 0) {
         }
         if (c->world > 1) {
             ProfScope ps(s, KC_COMM);
+            c->n_xchg_vector++;
             QNCHK(exchange(c, s->V.q, (size_t)s->qcs * s->T.rpr));
         }
         return QN_OK;
@@ -1887,6 +2044,7 @@ static int enqueue_hpass_req(Run& r) {
             HIPCHK(hipGetLastError());
             {
                 ProfScope ps(s, KC_COMM);
+                c->n_xchg_vector++;
                 if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
                 else QNCHK(exchange(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
             }
@@ -1917,6 +2075,7 @@ static int enqueue_hpass_req(Run& r) {
     }
     if (c->world > 1) {
         ProfScope ps(s, KC_COMM);
+        c->n_xchg_vector++;
         QNCHK(exchange(c, s->V.hp, (size_t)s->hcs * 2 * s->T.rpr));
     }
     return QN_OK;
@@ -2125,6 +2284,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     qn_context* c = s->ctx;
     HIPCHK(hipSetDevice(c->device));
     Run r{s, o, nullptr, QN_ORACLE_GENERIC, false};
+    const uint64_t xv0 = c->n_xchg_vector, xs0 = c->n_xchg_scalar; // (collectives of this call, for qn_stats)
     if (o->kind == QN_ORACLE_OBJECTIVE) {
         if (!o->objective) return fail(QN_ERROR_INPUT_PARAMS, "objective is null");
         if (o->objective->ctx != c || o->objective->n != s->n) return fail(QN_ERROR_INPUT_PARAMS, "objective does not match the solver");
@@ -2180,10 +2340,11 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     // ... and on the upper block triangle only (half the bytes) when H and Q are whole 128-tiles on one rank
     const bool sym_ok = c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
     // ... row-sharded: every rank streams the circulant half of its own block-rows (whole 128-row blocks per rank)
-    const bool symsh_ok = c->world > 1 && (s->T.rpr % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && s->T.n_pad / QN_TB <= 512 && !s->no_sym && !s->h_nonsym; // (nb <= 512: the LDS slot lists of symsh_*_sum_kernel)
+    const bool symsh_ok = c->world > 1 && (s->T.rpr % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
     r.sym = r.fused && (sym_ok || symsh_ok) && r.obj && r.obj->q_symmetric;
     // the generic path's H pass alone (closures, log-sum-exp objective, SR1, bounded variants): same tiles, sums into V.hp
     r.sym_generic = !r.fused && (sym_ok || symsh_ok) && s->H && s->hcs == 1 && (s->method == QN_BFGS || s->method == QN_DFP || s->method == QN_SR1);
+    if ((r.sym || r.sym_generic) && c->world > 1) QNCHK(solver_alloc_symsh_lists(s));
     if (r.sym_generic) {
         if (c->world > 1 && !s->symsh_xg) QNCHK(dev_alloc_zero(&s->symsh_xg, (size_t)c->world * 2 * s->T.n_pad, c->stream));
         const int nb = s->T.n_pad / QN_TB;
@@ -2193,7 +2354,8 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             s->sym_nb = nb;
         }
     }
-    r.sym2 = r.sym && c->world == 1 && !s->no_sym2 && (size_t)s->T.n_pad == s->n; // (the second-generation kernels keep no padding entries at zero)
+    // (the second-generation kernels keep no padding entries at zero; row-sharded: the SHARD instantiations, qn_sym2sh.hip.h)
+    r.sym2 = r.sym && !s->no_sym2 && (size_t)s->T.n_pad == s->n && (c->world == 1 || c->world <= 64);
     h->sym2 = r.sym2 ? 1 : 0;
     h->serviced = 0; h->ev_par = 0; h->ev_kind = QN_REQ_X; h->ev_t = 0.0; h->spec_tiles = 0;
     h->defer_u = 0;
@@ -2237,6 +2399,13 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         if (a.sl_per && !s->h_sliver_whole) { QNCHK(ensure_full_h(s)); s->h_sliver_whole = true; }
         a.trace = s->V.trace; a.xtrace = s->V.xtrace;
         a.nt = s->T.n_pad >= 8192; // H past the Infinity Cache: every byte is touched once per pass
+        a.sh_world = c->world; a.sh_rank = c->rank; a.sh_ioff = c->rank * (s->T.rpr / QN_TB);
+        a.sh_nsum = c->use_allreduce ? 1 : c->world;
+        a.evS = s->s2_evS; a.xg = s->symsh_xg; a.sl_off = s->s2_sl_off; a.sl_idx = s->s2_sl_idx;
+        if (c->world > 1) { // the rank streams half of ITS rows: that share decides whether H passes through the Infinity Cache
+            a.fold = 0; a.pair = 0;
+            a.nt = ((size_t)s->T.rpr * s->T.n_pad * 8 / 2) >= ((size_t)64 << 20);
+        }
         // (no synchronisation: the copy is stream-ordered in front of the launches, the mirror is pinned, and the host does not
         // write it again before s2_peek has synchronised)
         // (a one-workgroup launch that reads the pinned mirror, not hipMemcpyAsync: the copy path put ~8 us in front of the first
@@ -2260,18 +2429,31 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 if (ph == QN_PH_DONE) { status = h->status; break; }
                 const bool tiles_done = ph == QN_PH_REQ_HPASS && h->serviced == 1; // (folded accept-reduce: the tiles ran with the vectors)
                 if (h->serviced != 0 && !tiles_done) return fail(QN_ABNORMAL_TERMINATION, "sym2: request in an unexpected service state");
-                if (ph == QN_PH_REQ_EVAL) QNCHK(s2_launch(r, QN_S2_EVAL));
-                else if (ph == QN_PH_REQ_VEC) QNCHK(s2_launch(r, r.s2.fold ? QN_S2_HTILE : QN_S2_VEC));
-                else if (ph == QN_PH_REQ_HPASS) { if (!tiles_done) QNCHK(s2_launch(r, QN_S2_HTILE)); QNCHK(s2_launch(r, QN_S2_HREDUCE)); }
+                if (ph == QN_PH_REQ_EVAL) QNCHK(s2_do_eval(r));
+                else if (ph == QN_PH_REQ_VEC) QNCHK(s2_do_vec(r));
+                else if (ph == QN_PH_REQ_HPASS) QNCHK(s2_do_hpass(r, !tiles_done));
                 else return fail(QN_ABNORMAL_TERMINATION, "sym2: control block in an unexpected phase");
                 QNCHK(s2_launch(r, QN_S2_ADVANCE));
             }
         } else { // pipelined: [eval x slots, (accept-reduce,) update tiles, update-reduce] per period, each launch predicated in its prologue
-            const int slots = (ls->kind == QN_LS_MORETHUENTE) ? 2 : 4;
+            // Row-sharded: every evaluation launch is followed by a collective whether the machine uses the slot or not (RCCL cannot
+            // be predicated from the device), so the pattern is sized to the line search in use: two slots per period to start
+            // with (More-Thuente on a quadratic: t = 1, then one interpolation; backtracking near the solution: t = 1), and from
+            // the second batch on what the run has needed so far -- the counters are replicated, every rank sizes alike.  An
+            // iteration that needs more evaluations than a period holds rolls over into the next one: only time is lost.
+            int slots = (ls->kind == QN_LS_MORETHUENTE) ? 2 : 4;
+            if (r.s2.sh_world > 1) slots = s->s2_slots_hint ? s->s2_slots_hint : 2;
             bool first = true;
+            uint64_t ev0 = 0, it0 = 0;
             for (;;) {
                 if (!first) {
                     QNCHK(s2_peek(r));
+                    if (r.s2.sh_world > 1 && h->n_iterations > it0) { // evaluations per iteration of the batch just run, rounded up
+                        const uint64_t di = h->n_iterations - it0, de = h->n_oracle_evals - ev0;
+                        slots = (int)std::min<uint64_t>(4, std::max<uint64_t>(1, (de + di - 1) / di));
+                        s->s2_slots_hint = slots; // (the next call starts from it)
+                    }
+                    ev0 = h->n_oracle_evals; it0 = h->n_iterations;
                     if (h->phase == QN_PH_DONE) { status = h->status; break; }
                 }
                 int64_t remaining = h->max_iter - (first ? 0 : h->k);
@@ -2281,12 +2463,11 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 const int64_t periods = std::min<int64_t>(remaining + ((first && !h->warm) ? 1 : 0), 256);
                 first = false;
                 for (int64_t p = 0; p < periods; ++p) {
-                    for (int e = 0; e < slots; ++e) QNCHK(s2_launch(r, QN_S2_EVAL));
-                    if (!r.s2.fold) QNCHK(s2_launch(r, QN_S2_VEC)); // (folded into the update tiles otherwise)
-                    QNCHK(s2_launch(r, QN_S2_HTILE));
-                    QNCHK(s2_launch(r, QN_S2_HREDUCE));
+                    for (int e = 0; e < slots; ++e) QNCHK(s2_do_eval(r));
+                    if (!r.s2.fold) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise)
+                    QNCHK(s2_do_hpass(r, true));
                 }
-                QNCHK(s2_launch(r, QN_S2_EVAL));
+                QNCHK(s2_do_eval(r));
             }
         }
     } else {
@@ -2348,6 +2529,11 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     if ((r.sym || r.sym_generic) && c->world > 1) shard = (uint64_t)qn_symsh_ntiles(s->sym_nb, s->T.rpr / QN_TB, c->rank * (s->T.rpr / QN_TB)) * (uint64_t)QN_TB * QN_TB * 8ull;
     if (r.sym2) // diagonal tiles: wave w (rows 16 w ...) reads 64 - 8 w lanes of 16 bytes per row = 73 728 of the 131 072 bytes
         shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb - 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull + (uint64_t)s->sym_nb * 73728ull;
+    if (r.sym2 && c->world > 1) { // this rank's windows: one diagonal tile per local block-row, the rest whole tiles
+        const uint64_t nbl = (uint64_t)(s->T.rpr / QN_TB);
+        const uint64_t nt = (uint64_t)qn_symsh_ntiles(s->sym_nb, (int)nbl, c->rank * (int)nbl);
+        shard = (nt - nbl) * (uint64_t)QN_TB * QN_TB * 8ull + nbl * 73728ull;
+    }
     s->stats.h_bytes = (h->n_hpasses + h->n_hpass_rw) * shard;
     if (r.sym2) s->stats.h_bytes = 2 * h->n_hpasses * shard; // (its one branch-free body writes every pass back, pending update or not)
     s->stats.obj_bytes = (r.oracle_tpl == QN_ORACLE_QUAD) ? h->n_oracle_evals * (r.sym ? shard : full_shard) : 0;
@@ -2359,6 +2545,8 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     s->stats.total_h_passes += s->stats.h_passes;
     s->stats.total_h_bytes += s->stats.h_bytes;
     s->stats.total_obj_bytes += s->stats.obj_bytes;
+    s->stats.total_xchg_vector += c->n_xchg_vector - xv0;
+    s->stats.total_xchg_scalar += c->n_xchg_scalar - xs0;
     s->stats.path = (r.fused ? QN_PATH_FUSED : 0u) | (r.sym ? QN_PATH_SYM : 0u) | (r.sym_generic ? QN_PATH_SYM_GENERIC : 0u) |
                     (sync ? 0u : QN_PATH_PIPELINED) | (r.sym2 ? QN_PATH_SYM2 : 0u);
     if (c->host_async_failed) { c->host_async_failed = 0; return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed"); }

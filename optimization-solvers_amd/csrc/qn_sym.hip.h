@@ -43,6 +43,7 @@ struct QnSymShard {
     int world, rank, nbl, ioff;
     int nsum;   // slices of xg to add up after the exchange: world (all-gather, rank order), or 1 (an all-reduce left the total in slice 0)
     double* xg; // gathered partial sums: [world][nrhs][n_pad], rank r's slice written by rank r
+    const int *sl_off, *sl_idx; // the slots of block-row R that THIS rank's tiles write: sl_idx[sl_off[R] .. sl_off[R + 1]), ascending (built by the host)
 };
 __device__ __host__ __forceinline__ int qn_symsh_cnt(int I, int nb) { return (nb & 1) ? (nb + 1) / 2 : (I < nb / 2 ? nb / 2 + 1 : nb / 2); }
 __device__ __host__ __forceinline__ bool qn_symsh_owns(int I, int J, int nb) { // is tile (I, J) in block-row I's circulant window?
@@ -300,31 +301,10 @@ __global__ __launch_bounds__(256) void sym_eval_reduce_kernel(const QnSymEvalArg
 
 // ---- row-sharded runs: what THIS rank's tiles contributed to block-row R, summed in a fixed order ----
 // The slots this rank wrote for block-row R: its own window (R local) and the column parts of the local block-rows whose
-// window contains R.  Threads 0..nb-1 flag their slot, the flags are compacted into an ascending list (fixed order), and the
-// two halves of the workgroup add one half of the list each, 16 loads in flight, exactly as qn_sym_slot_sum does.
-// All 256 threads call it; threads 0..127 get the total of row tid (zero when the rank contributed nothing).
-__device__ __forceinline__ int qn_symsh_slot_list(int nb, const QnSymShard& sh, int R, int* list /* LDS[nb] */, int* cnt4 /* LDS[8] */) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
-    const bool r_local = R >= sh.ioff && R < sh.ioff + sh.nbl;
-    int total = 0;
-    for (int base = 0; base < nb; base += (int)blockDim.x) { // nb <= blockDim.x in every supported configuration but one loop covers all
-        const int t = base + tid;
-        bool w = false;
-        if (t < nb) {
-            const bool t_local = t >= sh.ioff && t < sh.ioff + sh.nbl;
-            w = (r_local && qn_symsh_owns(R, t, nb)) || (t_local && t != R && qn_symsh_owns(t, R, nb));
-        }
-        const unsigned long long m = __ballot(w);
-        if (lane == 0) cnt4[wave] = __popcll(m);
-        __syncthreads();
-        int off = total;
-        for (int v = 0; v < wave; ++v) off += cnt4[v];
-        if (w) list[off + __popcll(m & ((1ull << lane) - 1ull))] = t;
-        for (int v = 0; v < nw; ++v) total += cnt4[v];
-        __syncthreads();
-    }
-    return total;
-}
+// window contains R -- an ascending list per block-row that the host builds once (QnSymShard.sl_off / sl_idx; rounds 2-3
+// compacted it in 512 words of LDS at every launch, which capped nb at 512).  The two halves of the workgroup add one half of the
+// list each, 16 loads in flight, exactly as qn_sym_slot_sum does.  All 256 threads call it; threads 0..127 get the total of row
+// tid (zero when the rank contributed nothing).
 __device__ __forceinline__ double qn_symsh_slot_sum(const double* __restrict__ part, int nb, int R, int rhs, const int* list, int nlist,
                                                     double* halfbuf /* LDS[128] */) {
     const int i = threadIdx.x & (QN_TB - 1), half = threadIdx.x >> 7;
@@ -355,13 +335,12 @@ __device__ __forceinline__ double qn_symsh_rank_sum(const QnSymShard& sh, int nr
 
 // evaluation, block-row R: this rank's partial q for rows R*128 .. into its slice of the gather buffer
 __global__ __launch_bounds__(256) void symsh_eval_sum_kernel(const QnSymEvalArgs a) {
-    __shared__ int list[512];
-    __shared__ int cnt4[8];
     __shared__ double halfbuf[QN_TB];
     const int phase = a.ctl->phase;
     if (phase != a.expect_phase && !(a.after_h && phase == QN_PH_REQ_HPASS_EVAL)) return;
     const int R = blockIdx.x;
-    const int nlist = qn_symsh_slot_list(a.nb, a.sh, R, list, cnt4);
+    const int* list = a.sh.sl_idx + a.sh.sl_off[R];
+    const int nlist = a.sh.sl_off[R + 1] - a.sh.sl_off[R];
     const double qi = qn_symsh_slot_sum(a.part, a.nb, R, 0, list, nlist, halfbuf);
     if (threadIdx.x < QN_TB) a.sh.xg[(size_t)a.sh.rank * a.T.n_pad + (size_t)R * QN_TB + threadIdx.x] = qi;
 }
@@ -561,8 +540,6 @@ __global__ __launch_bounds__(256) void sym_hpass_reduce_kernel(const QnSymHPassA
 }
 // row-sharded runs, H pass, block-row R: this rank's partial sums into its slice of the gather buffer [world][2][n_pad]
 __global__ __launch_bounds__(256) void symsh_hpass_sum_kernel(const QnSymHPassArgs a) {
-    __shared__ int list[512];
-    __shared__ int cnt4[8];
     __shared__ double halfbuf[QN_TB];
     const QnCtl* __restrict__ ctl = a.ctl;
     const int phase = ctl->phase;
@@ -570,7 +547,8 @@ __global__ __launch_bounds__(256) void symsh_hpass_sum_kernel(const QnSymHPassAr
     const int nrhs = ctl->hp_nrhs;
     const int R = blockIdx.x;
     const size_t np = (size_t)a.T.n_pad;
-    const int nlist = qn_symsh_slot_list(a.nb, a.sh, R, list, cnt4);
+    const int* list = a.sh.sl_idx + a.sh.sl_off[R];
+    const int nlist = a.sh.sl_off[R + 1] - a.sh.sl_off[R];
     const double t0 = qn_symsh_slot_sum(a.part, a.nb, R, 0, list, nlist, halfbuf);
     const double t1 = (nrhs == 2) ? qn_symsh_slot_sum(a.part, a.nb, R, 1, list, nlist, halfbuf) : 0.0;
     if (threadIdx.x < QN_TB) {

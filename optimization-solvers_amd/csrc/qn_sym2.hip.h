@@ -47,8 +47,12 @@
 #define QN_S2_NSE 6    // evaluation scalars per workgroup: xt'Q xt, b'xt, d'Q xt, b'd, g'd, #non-finite d
 #define QN_S2_NR 5     // accept-reduce partials per block-row: y'y, y's, g+'g+, s's, s'g+
 #define QN_S2_ROW 8    // doubles per partial row in memory (64 B: loaded as 16-byte pieces)
+#define QN_S2SH_NEC 4  // row-sharded runs: the evaluation scalars that are exchanged, per workgroup: x'(Q xt - 2 b), d'(Q xt - b), g'd,
+                       // #non-finite d (the table's b'xt and b'd columns are zero by construction: see CONDITIONING below)
+#define QN_S2SH_EB 4   // ... and the slices of them a prologue requests at a time
 
-enum { QN_S2_ADVANCE = 0, QN_S2_EVAL = 1, QN_S2_VEC = 2, QN_S2_HTILE = 3, QN_S2_HREDUCE = 4 };
+enum { QN_S2_ADVANCE = 0, QN_S2_EVAL = 1, QN_S2_VEC = 2, QN_S2_HTILE = 3, QN_S2_HREDUCE = 4,
+       QN_S2_VSUM = 5, QN_S2_HSUM = 6 }; // (row-sharded runs, qn_sym2sh.hip.h: this rank's slot sums, in front of the exchange of an n-vector)
 
 struct QnS2Args {
     const double* Q;
@@ -79,6 +83,15 @@ struct QnS2Args {
     double* xtrace;
     int parity;          // this launch reads ctl2[parity] and writes ctl2[parity ^ 1]
     int nt;              // non-temporal tile accesses on H (past the Infinity Cache)
+    // ---- row-sharded runs (SHARD instantiations; qn_sym2sh.hip.h) ----
+    int sh_world, sh_rank; // ranks of the run, this rank
+    int sh_ioff;           // first block-row this rank stores: tile (I, J) lives at local block-row I - sh_ioff
+    int sh_nsum;           // slices to add up after an exchange: sh_world (all-gather, rank order) or 1 (an all-reduce left the total in slice 0)
+    double* evS;           // [2][sh_world][QN_S2SH_NEC][QN_S2_MAXG]: the evaluation scalars of every rank's workgroups, by launch parity;
+                           // slice r written by rank r's evaluation tiles, the others filled in by the exchange that follows the launch
+    double* xg;            // [sh_world][2][np]: the ranks' partial n-vectors (q of the accepted evaluation; [u, v] of the update pass)
+    const int* sl_off;     // [nb + 1] the slots of block-row R that THIS rank's tiles write are sl_idx[sl_off[R] .. sl_off[R + 1]), ascending
+    const int* sl_idx;
 #ifdef QN_S2_STAMPS
     unsigned long long* dbg; // diagnostic build: dbg[((slot % 64) * 256 + workgroup) * 16 + k] = wall clock (10 ns) at stamp k
     int slot;
@@ -190,7 +203,12 @@ __device__ __forceinline__ double qn_lane_bcast(const double v, const int l) {
 struct QnS2NoEarly { __device__ __forceinline__ void operator()() const {} };
 // `early`: requests the caller wants in flight while the machine runs (issued right behind the control block and the table, so
 // that those two still come back first: a wave's loads return in order)
-template <int KIND, class Early = QnS2NoEarly>
+// SHARD (row-sharded runs, qn_sym2sh.hip.h): the machine is the same and runs on every rank from the same inputs.  What differs
+// is where an EVALUATION's sums come from -- every rank's workgroups left theirs in its slice of evS and the exchange behind the
+// launch has brought in the other ranks' slices: this prologue adds them all up, ranks in order, so every rank has the same
+// bits -- and that a request for vectors takes two launches with an exchange of n-vectors in between (serviced: 0 pending,
+// 1 tiles / partial sums done, 3 partial sums of an update pass done, 2 complete).
+template <int KIND, bool SHARD = false, class Early = QnS2NoEarly>
 __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L, Early&& early = Early()) {
     const int lane = threadIdx.x; // (wave 0)
     const bool leader = blockIdx.x == 0;
@@ -204,13 +222,30 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     if (64 + lane < NW) cw1 = cin[64 + lane];
     double tr[QN_S2_PCH][QN_S2_NSE];
     const double* T = a.wgS + (size_t)(a.parity ^ 1) * (size_t)a.trows * QN_S2_ROW;
-    const bool no_decision = KIND == QN_S2_HREDUCE && !a.fold; // (uniform) nothing to decide between the update tiles and their reduction
+    // launches with nothing to decide in front of them: the second (and third) launch of a request pass the control block on
+    constexpr bool kPass = KIND == QN_S2_HSUM || (SHARD && (KIND == QN_S2_VEC || KIND == QN_S2_HREDUCE));
+    const bool no_decision = kPass || (KIND == QN_S2_HREDUCE && !a.fold); // (uniform) nothing to decide between the update tiles and their reduction
     if (!no_decision) {
 #pragma unroll
         for (int k = 0; k < QN_S2_NSE; ++k)
 #pragma unroll
             for (int j = 0; j < QN_S2_PCH; ++j) tr[j][k] = T[(size_t)k * a.trows + j * 64 + lane]; // (trows >= 256)
     }
+    // SHARD: the evaluation scalars of the first QN_S2SH_EB ranks go out now as well (every entry of evS is valid at all times --
+    // rows past the grid stay zero -- so nothing about them depends on the control block; lane l takes rows 2 l, 2 l + 1 and
+    // 128 + 2 l, 129 + 2 l of each column)
+    v2d es[SHARD ? QN_S2SH_EB : 1][QN_S2SH_NEC][2];
+    const double* E = SHARD ? a.evS + (size_t)(a.parity ^ 1) * (size_t)a.sh_world * (QN_S2SH_NEC * QN_S2_MAXG) : nullptr;
+    auto es_load = [&](const int r0) {
+#pragma unroll
+        for (int rr = 0; rr < QN_S2SH_EB; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < QN_S2SH_NEC; ++cc)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    es[rr][cc][hh] = (r0 + rr < a.sh_nsum) ? ld2(E + ((size_t)(r0 + rr) * QN_S2SH_NEC + cc) * QN_S2_MAXG + hh * 128 + 2 * lane) : (v2d){0.0, 0.0};
+    };
+    if (SHARD && !no_decision) es_load(0);
     early();
     if (lane < NW) lc[lane] = cw0;
     if (64 + lane < NW) lc[64 + lane] = cw1;
@@ -219,8 +254,11 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     QnCtl& c = L.c; // (in LDS: a private register copy of all ~150 words does not fit beside the machine's own temporaries -- 255 spills)
     int mine = 0;
     if (no_decision) { // pass the control block on (with the folded accept-reduce this prologue is where the machine sees the accepted point)
-        mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 1;
-        if (lane == 0) { if (mine) c.serviced = 2; L.mine = mine; }
+        constexpr int want_ph = (KIND == QN_S2_VEC) ? QN_PH_REQ_VEC : QN_PH_REQ_HPASS;
+        constexpr int from = (SHARD && KIND == QN_S2_HREDUCE) ? 3 : 1; // (sharded update pass: tiles 0 -> 1, partial sums 1 -> 3, reduce 3 -> 2)
+        constexpr int to = (KIND == QN_S2_HSUM) ? 3 : 2;
+        mine = c.phase == want_ph && c.serviced == from;
+        if (lane == 0) { if (mine) c.serviced = to; L.mine = mine; }
         __builtin_amdgcn_s_setprio(0);
         return;
     }
@@ -240,14 +278,37 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
         // six 6-step butterflies).  It pairs lanes l and l ^ 32, then ^ 16, ... ^ 1 for every column exactly as qn_wave_sum
         // does, and floating-point addition commutes: the totals have round 2's bits.
         double acc[8];
+        if (SHARD && ph == QN_PH_REQ_EVAL) { // (uniform)
+            // Entry by entry the ranks in rank order FIRST (what an all-reduce would have left in slice 0: with sh_nsum == 1 this
+            // loop is empty, and the host-staged stand-in of the tests then gives the very bits of the all-gather), then the lane's
+            // four rows of a column in row order, then the butterfly over the lanes.
+            v2d rs[QN_S2SH_NEC][2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            acc[k] = 0.0;
-            if (k < QN_S2_NSE) {
+            for (int cc = 0; cc < QN_S2SH_NEC; ++cc) { rs[cc][0] = es[0][cc][0]; rs[cc][1] = es[0][cc][1]; }
+            for (int r0 = 0; r0 < a.sh_nsum; r0 += QN_S2SH_EB) {
+                if (r0) es_load(r0);
 #pragma unroll
-                for (int j = 0; j < QN_S2_PCH; ++j) acc[k] = acc[k] + ((j * 64 + lane < nrows && k < ncol) ? tr[j][k] : 0.0);
-                for (int b = QN_S2_MAXG + lane; b < nrows; b += 64) // (block-rows past 256: n > 32768)
-                    if (k < ncol) acc[k] = acc[k] + T[(size_t)k * a.trows + b];
+                for (int rr = 0; rr < QN_S2SH_EB; ++rr)
+                    if (r0 + rr > 0 && r0 + rr < a.sh_nsum) { // (uniform)
+#pragma unroll
+                        for (int cc = 0; cc < QN_S2SH_NEC; ++cc) { rs[cc][0] = rs[cc][0] + es[rr][cc][0]; rs[cc][1] = rs[cc][1] + es[rr][cc][1]; }
+                    }
+            }
+            double ea[QN_S2SH_NEC];
+#pragma unroll
+            for (int cc = 0; cc < QN_S2SH_NEC; ++cc) ea[cc] = ((rs[cc][0].x + rs[cc][0].y) + rs[cc][1].x) + rs[cc][1].y;
+            // the table's columns: x'(Q xt - 2b), (b'xt = 0), d'(Q xt - b), (b'd = 0), g'd, #non-finite d
+            acc[0] = ea[0]; acc[1] = 0.0; acc[2] = ea[1]; acc[3] = 0.0; acc[4] = ea[2]; acc[5] = ea[3]; acc[6] = 0.0; acc[7] = 0.0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                acc[k] = 0.0;
+                if (k < QN_S2_NSE) {
+#pragma unroll
+                    for (int j = 0; j < QN_S2_PCH; ++j) acc[k] = acc[k] + ((j * 64 + lane < nrows && k < ncol) ? tr[j][k] : 0.0);
+                    for (int b = QN_S2_MAXG + lane; b < nrows; b += 64) // (block-rows past 256: n > 32768)
+                        if (k < ncol) acc[k] = acc[k] + T[(size_t)k * a.trows + b];
+                }
             }
         }
         QnWaveFold<8, 32>::run(acc, lane); // lane l holds the total of column l >> 3
@@ -277,7 +338,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     QN_S2_STAMP(11);
     if (lane == 0) {
         if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == 0;
-        if (KIND == QN_S2_VEC) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
+        if (KIND == QN_S2_VEC || KIND == QN_S2_VSUM) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
         if (KIND == QN_S2_HTILE) { // 2: the accepted point's slots -> vectors AND the update tiles (folded accept-reduce); 1: the tiles of a pending pass
             if (a.fold && c.phase == QN_PH_REQ_VEC && c.serviced == 0) mine = 2;
             else if (c.phase == QN_PH_REQ_HPASS && c.serviced == 0) mine = 1;
@@ -286,6 +347,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
         if (c.phase == QN_PH_RUNNING) { c.status = 4; c.phase = QN_PH_DONE; } // a state this path cannot service: abort, never spin
         if (mine) { // as this launch leaves the request
             if (KIND == QN_S2_HTILE) { c.serviced = mine == 2 ? 2 : 1; if (mine == 2) c.spec_tiles = c.ev_kind == QN_REQ_T ? 2 : 1; }
+            else if (KIND == QN_S2_VSUM) c.serviced = 1; // (the exchange and the reduce launch follow)
             else c.serviced = 2;
         }
         L.mine = mine;
@@ -354,6 +416,13 @@ __device__ __forceinline__ int qn_s2_item_of_index(int t, int nb) {
     return (i << 16) | (i + 1 + t);
 }
 __device__ __forceinline__ int qn_s2_first_item(int g, int nb) { return qn_s2_item_of_index(g, nb); }
+// Row-sharded runs (SHARD): the rank's tiles are its block-rows' circulant windows (qn_sym.hip.h: J = (I + k) mod nb, so J < I
+// occurs), dealt by the host like any other list -- the first item is read, not computed: one scalar load in front of a launch
+// that streams ~16 tiles per workgroup -- and tile (I, J) lives at the rank's local block-row I - sh_ioff.
+template <bool SHARD>
+__device__ __forceinline__ int qn_s2_first_item_of(const QnS2Args& a) { return SHARD ? a.item_ij[blockIdx.x] : qn_s2_first_item(blockIdx.x, a.nb); }
+template <bool SHARD>
+__device__ __forceinline__ int qn_s2_lrow(const QnS2Args& a, const int I) { return SHARD ? I - a.sh_ioff : I; }
 // the workgroup's second item (-1: none): in closed form when the host dealt it in order (a.inorder), from the list otherwise
 __device__ __forceinline__ int qn_s2_second_item(const QnS2Args& a) {
     const int t = a.G + (int)blockIdx.x;
@@ -541,8 +610,9 @@ __device__ __forceinline__ double qn_s2_eval_sliver(const QnS2SliverVec& v, cons
 // body decides at run time whether there is a second item, a third one, a list to read, a sliver, a parked window; with those
 // five flags known the compiler drops the variants they select between and the register copies at their joins -- the phase
 // behind the workgroup barrier is instruction issue.
-template <bool PAIR>
+template <bool PAIR, bool SHARD = false>
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a) {
+    static_assert(!(PAIR && SHARD), "the two-items-and-a-sliver instance is the single-rank n = 4096 one");
     __shared__ QnS2Lds L;
     __shared__ double colsum[3][QN_TB];
     __shared__ double colred[3][QN_S2_WAVES][QN_TB]; // [item of the group]
@@ -553,7 +623,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     QN_S2_STAMP(0);
     // Wave 0 runs the prologue first (qn_s2_prologue_w0); waves 1..7 request the window at once.  The first two items are
     // functions of blockIdx: no load.
-    const int ij0 = qn_s2_first_item(blockIdx.x, a.nb);
+    const int ij0 = qn_s2_first_item_of<SHARD>(a);
     // The wave's 16 rows of the first item are requested before the control block is known (their addresses do not depend on
     // it), and so are the first item's vector entries for BOTH settings of the two buffer toggles the control block holds
     // (x / trial point, pending / staged s); every register of the window is refilled with the next item's row the moment its
@@ -574,12 +644,12 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     };
     auto window_load = [&](const int ijw) {
         const int I = ijw >> 16, J = ijw & 0xffff;
-        const double* qb = a.Q + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
+        const double* qb = a.Q + (size_t)(qn_s2_lrow<SHARD>(a, I) * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
 #pragma unroll
         for (int r = 0; r < QN_S2_RPW; ++r) h[r] = ld2(qb + (size_t)r * np);
     };
     if (wave == 0) {
-        qn_s2_prologue_w0<QN_S2_EVAL>(a, L, vec_spec);
+        qn_s2_prologue_w0<QN_S2_EVAL, SHARD>(a, L, vec_spec);
     } else {
         window_load(ij0);
         vec_spec();
@@ -595,12 +665,12 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     // prologue was 3 us behind the rest at the pair's barrier (in-kernel time stamps).
     if (parked && wave != 0) {
         const int I1 = ij1 >> 16, J1 = ij1 & 0xffff;
-        const double* q1 = a.Q + (size_t)(I1 * QN_TB + wave * QN_S2_RPW) * np + (size_t)J1 * QN_TB + qn_s2_col(I1 == J1, lane, wave);
+        const double* q1 = a.Q + (size_t)(qn_s2_lrow<SHARD>(a, I1) * QN_TB + wave * QN_S2_RPW) * np + (size_t)J1 * QN_TB + qn_s2_col(I1 == J1, lane, wave);
         // (wave 0's rows are requested BEFORE the second item's: a wave's loads return in order, and behind the refills these three
         // -- which the barrier below waits for -- arrived with the last byte of the second window, 9.5 us into the kernel: the
         // workgroup then started on the first item when both had landed, however early the machine was done)
         const int I0 = ij0 >> 16, J0 = ij0 & 0xffff;
-        const double* q0 = a.Q + (size_t)(I0 * QN_TB) * np + (size_t)J0 * QN_TB + 2 * lane; // wave 0's rows: no clone lanes (qn_s2_col(., ., 0) = 2 lane)
+        const double* q0 = a.Q + (size_t)(qn_s2_lrow<SHARD>(a, I0) * QN_TB) * np + (size_t)J0 * QN_TB + 2 * lane; // wave 0's rows: no clone lanes (qn_s2_col(., ., 0) = 2 lane)
         const int r0 = (wave - 1) * 3;
         v2d t3[3];
 #pragma unroll
@@ -660,10 +730,10 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         // registers the row loops need)
         auto tile_ptr = [&](int ij_) {
             const int I_ = ij_ >> 16, J_ = ij_ & 0xffff;
-            return a.Q + (size_t)(I_ * QN_TB + wave * QN_S2_RPW) * np + (size_t)J_ * QN_TB + qn_s2_col(I_ == J_, lane, wave);
+            return a.Q + (size_t)(qn_s2_lrow<SHARD>(a, I_) * QN_TB + wave * QN_S2_RPW) * np + (size_t)J_ * QN_TB + qn_s2_col(I_ == J_, lane, wave);
         };
         // (row slivers: every workgroup has exactly a.maxk items and one sliver, which joins the last group in item c's place)
-        const bool sliver = PAIR || (a.sl_per != 0 && ijc < 0); // (uniform)
+        const bool sliver = PAIR || (!SHARD && a.sl_per != 0 && ijc < 0); // (uniform; row-sharded runs have no slivers)
         const QnS2Sliver sl = qn_s2_sliver(a, wave);
         const double* slp = a.Q + (size_t)(sl.D * QN_TB + sl.row) * np + (size_t)sl.D * QN_TB + 2 * lane;
         QnS2SliverVec slv{};
@@ -750,7 +820,11 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     QN_S2_STAMP(15);
     if (tid < QN_S2_NSE) { // sred column -> table column: xt'(Q xt - 2b), d'(Q xt - b), (b'xt = 0), (b'd = 0), g'd, #non-finite d
         const int col = tid == 1 ? 2 : (tid == 2 ? 1 : tid);
-        a.wgS[((size_t)a.parity * QN_S2_ROW + col) * a.trows + blockIdx.x] = wgk;
+        if (!SHARD) a.wgS[((size_t)a.parity * QN_S2_ROW + col) * a.trows + blockIdx.x] = wgk;
+        else if (tid != 2 && tid != 3) { // this rank's slice of the exchanged scalars: the four columns that are not zero by construction
+            const int ec = tid < 2 ? tid : tid - 2;
+            a.evS[(((size_t)a.parity * a.sh_world + a.sh_rank) * QN_S2SH_NEC + ec) * QN_S2_MAXG + blockIdx.x] = wgk;
+        }
     }
 }
 
@@ -793,6 +867,9 @@ __device__ __forceinline__ double qn_s2_slot_sum(const double* __restrict__ part
 
 // accept-reduce: block-row R of the LAST evaluation becomes vectors: q_i, g+ = q - b, y = g+ - g, x+ and s = x+ - x
 // (bfgs.rs:94-99), and the five sums the update needs
+// SHARD (row-sharded runs): q_i is the sum over the ranks, in rank order, of the partial vectors the exchange has gathered in xg
+// (each rank's share summed by s2sh_vsum_kernel, qn_sym2sh.hip.h); every rank forms every block-row: replicated work, the same bits.
+template <bool SHARD = false>
 __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
     __shared__ double qbuf[3][QN_TB];
@@ -802,7 +879,8 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     QN_S2_STAMP(0);
     // (wave 0 requests its share of the slots behind the control block and the table, BEFORE it runs the machine: requested after
     // it -- 3.5 us into a 6 us kernel -- they were what the slot sums waited for)
-    if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC>(a, L, [&]() { qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0); });
+    if (SHARD) { if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC, true>(a, L); }
+    else if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC>(a, L, [&]() { qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0); });
     else qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0);
     __syncthreads();
     QN_S2_STAMP(2);
@@ -814,7 +892,13 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     double* __restrict__ xt = a.F.X0 + (size_t)(1 - q.xc) * np;
     const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
     double* __restrict__ sstage = a.F.S0 + (size_t)(1 - q.sc) * np;
-    const double qi = qn_s2_slot_sum<1>(a.partE, a.nb, R, 0, S0, qbuf);
+    double qi = 0.0;
+    if (!SHARD) qi = qn_s2_slot_sum<1>(a.partE, a.nb, R, 0, S0, qbuf);
+    else if (tid < QN_TB) {
+        const double* xp = a.xg + (size_t)R * QN_TB + tid;
+        qi = xp[0];
+        for (int r = 1; r < a.sh_nsum; ++r) qi = qi + xp[(size_t)r * np];
+    }
     double p[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = 0.0;
@@ -881,8 +965,9 @@ __device__ __forceinline__ void qn_s2_hvec_load(const QnS2HReq& q, const unsigne
 // BFGS: true -> the update has the (s u' + u s') and s s' terms (bfgs.rs:115-124); false -> DFP: s s' and u u' (dfp.rs:115-120)
 // FOLD: the instantiation for a.fold (its right-hand sides always come from LDS: staged from the vectors when the request is a
 // plain update pass); the other one is round 2's kernel, vectors from global memory, any number of items.
-template <bool NT, bool BFGS, bool FOLD>
+template <bool NT, bool BFGS, bool FOLD, bool SHARD = false>
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a) {
+    static_assert(!(FOLD && SHARD), "the folded accept-reduce is a single-rank variant");
     __shared__ QnS2Lds L;
     __shared__ double colsum[2][QN_TB]; // [rhs]: row part of a diagonal item, parked until its column part is summed
     __shared__ double colred[QN_S2_WAVES][2][QN_TB];
@@ -893,7 +978,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.np;
     QN_S2_STAMP(0);
-    int ij = qn_s2_first_item(blockIdx.x, a.nb);
+    int ij = qn_s2_first_item_of<SHARD>(a);
     const int ij1 = qn_s2_second_item(a);
     const int ij2 = (FOLD && ij1 >= 0 && a.maxk > 2) ? a.item_ij[(size_t)2 * a.G + blockIdx.x] : -1;
     int I = ij >> 16, J = ij & 0xffff;
@@ -913,7 +998,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         s1_r = a.F.S0[np + ir]; s1_c = ld2(a.F.S0 + np + jc);
         if (!FOLD) { y_r = a.F.Y[ir]; y_c = ld2(a.F.Y + jc); }
     };
-    if (wave == 0) qn_s2_prologue_w0<QN_S2_HTILE>(a, L, vec_spec);
+    if (wave == 0) qn_s2_prologue_w0<QN_S2_HTILE, SHARD>(a, L, vec_spec);
     // Folded accept-reduce: the quarters of the slot sums of the workgroup's blocks (task = entry e of quarter qd, for all six
     // blocks), and b and g of those blocks.  None of the addresses depends on the control block, so this is done by the waves that
     // wait for wave 0; wave 0's own share (entries 0..63 of the first quarter) is dealt to waves 1..6, a block each, so that wave
@@ -956,12 +1041,12 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     // Also without effect on this kernel: the BFGS update as s q' + q s' with q = c_su u + (c_ss / 2) s (eight VALU instructions
     // fewer per row, still bitwise symmetric), and an instance for exactly two items and a sliver.)
     v2d h[QN_S2_RPW]; // the wave's 16 rows of the first item go out before the control block is known
-    double* hbase = a.H + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
+    double* hbase = a.H + (size_t)(qn_s2_lrow<SHARD>(a, I) * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
     if (wave != 0) {
 #pragma unroll
         for (int r = 0; r < QN_S2_RPW; ++r) h[r] = qn_sym_ld<NT>(hbase + (size_t)r * np);
         vec_spec();
-        const double* q0 = a.H + (size_t)(I * QN_TB) * np + (size_t)J * QN_TB + 2 * lane; // wave 0's rows: no clone lanes (qn_s2_col(., ., 0) = 2 lane)
+        const double* q0 = a.H + (size_t)(qn_s2_lrow<SHARD>(a, I) * QN_TB) * np + (size_t)J * QN_TB + 2 * lane; // wave 0's rows: no clone lanes (qn_s2_col(., ., 0) = 2 lane)
         const int r0 = (wave - 1) * 3;
         v2d t3[3];
 #pragma unroll
@@ -1047,7 +1132,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     // zero vectors: H + 0 (0 0) = H.  (The path requires n = n_pad: no padding entries to keep at zero.)
     const bool pend = q.pending;
     const double c_ss = pend ? q.c_ss : 0.0, c_su = pend ? q.c_su : 0.0, c_uu = pend ? q.c_uu : 0.0;
-    const bool slv = !FOLD && a.sl_per != 0; // (uniform; the host never combines the folded accept-reduce with row slivers)
+    const bool slv = !FOLD && !SHARD && a.sl_per != 0; // (uniform; the host never combines the folded accept-reduce with row slivers)
     // (the sliver's addresses are formed where they are used, behind an empty asm: as loop invariants they were held in registers
     // across the row loops, which have none to spare)
     auto sliver_ptr = [&]() {
@@ -1071,7 +1156,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         else if (it + 1 < a.maxk) ijn = a.item_ij[(size_t)(it + 1) * a.G + blockIdx.x];
         const bool has_next = ijn >= 0; // (uniform)
         const int In = has_next ? (ijn >> 16) : I, Jn = has_next ? (ijn & 0xffff) : J;
-        double* hnext = a.H + (size_t)(In * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jn * QN_TB + qn_s2_col(In == Jn, lane, wave);
+        double* hnext = a.H + (size_t)(qn_s2_lrow<SHARD>(a, In) * QN_TB + wave * QN_S2_RPW) * np + (size_t)Jn * QN_TB + qn_s2_col(In == Jn, lane, wave);
         if (!has_next && slv) hnext = sliver_ptr(); // the workgroup's row sliver follows its last item (see qn_s2_eval_sliver)
         const size_t rstride = has_next ? np : 0; // (none left: every lane re-reads one 16-byte word -- of this item, or the sliver's row)
         double c0x = 0.0, c0y = 0.0, c1x = 0.0, c1y = 0.0;
@@ -1215,20 +1300,31 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
 
 // update-reduce: u_i, v_i = sums of block-row R's slots, the partials of y'u and u'g+ (the update's coefficients and the next
 // direction need them); commits g <- g+ (the evaluation kernels read g for g'd)
+template <bool SHARD = false> // (row-sharded: the totals are the rank-order sums of the gathered partial [u, v]: see s2_vec_kernel)
 __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
     __shared__ double qbuf[3][QN_TB];
     __shared__ double bred[2][8];
     const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QnS2Slots S0, S1;
-    if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE>(a, L, [&]() { qn_s2_slot_issue(a.part, a.nb, R, 0, S0); qn_s2_slot_issue(a.part, a.nb, R, 1, S1); });
+    if (SHARD) { if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE, true>(a, L); }
+    else if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE>(a, L, [&]() { qn_s2_slot_issue(a.part, a.nb, R, 0, S0); qn_s2_slot_issue(a.part, a.nb, R, 1, S1); });
     else { qn_s2_slot_issue(a.part, a.nb, R, 0, S0); qn_s2_slot_issue(a.part, a.nb, R, 1, S1); }
     __syncthreads();
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
     const int nrhs = L.c.hp_nrhs;
-    const double tot0 = qn_s2_slot_sum(a.part, a.nb, R, 0, S0, qbuf);
-    const double tot1 = (nrhs == 2) ? qn_s2_slot_sum(a.part, a.nb, R, 1, S1, qbuf) : 0.0; // (uniform)
+    double tot0 = 0.0, tot1 = 0.0;
+    if (!SHARD) {
+        tot0 = qn_s2_slot_sum(a.part, a.nb, R, 0, S0, qbuf);
+        tot1 = (nrhs == 2) ? qn_s2_slot_sum(a.part, a.nb, R, 1, S1, qbuf) : 0.0; // (uniform)
+    } else if (tid < QN_TB) { // xg: [rank][rhs][np]
+        const size_t np = (size_t)a.np;
+        const double* xp = a.xg + (size_t)R * QN_TB + tid;
+        tot0 = xp[0]; tot1 = xp[np];
+        for (int r = 1; r < a.sh_nsum; ++r) { tot0 = tot0 + xp[(size_t)r * 2 * np]; tot1 = tot1 + xp[(size_t)r * 2 * np + np]; }
+        if (nrhs != 2) tot1 = 0.0;
+    }
     double p[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = 0.0;
@@ -1259,9 +1355,10 @@ __global__ __launch_bounds__(256) void s2_ctl_upload_kernel(const QnCtl* __restr
 }
 
 // synchronous mode: the prologue alone (one workgroup)
+template <bool SHARD = false>
 __global__ __launch_bounds__(128) void s2_advance_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
-    if (threadIdx.x < 64) qn_s2_prologue_w0<QN_S2_ADVANCE>(a, L);
+    if (threadIdx.x < 64) qn_s2_prologue_w0<QN_S2_ADVANCE, SHARD>(a, L);
     __syncthreads();
     qn_s2_ctl_out(a, L);
 }

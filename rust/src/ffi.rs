@@ -1,10 +1,10 @@
-//! `extern "C"` declarations for include/qn_hip.h (QN_ABI_VERSION 2): one `pub fn` per entry point, parameter for parameter.
+//! `extern "C"` declarations for include/qn_hip.h (QN_ABI_VERSION 3): one `pub fn` per entry point, parameter for parameter.
 //! tests/test_abi_load.py parses this file and the header and compares names, arity and every parameter / return type.
 //! NOT COMPILED in the build image (no Rust toolchain) -- see ../Cargo.toml.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const QN_ABI_VERSION: c_int = 2;
+pub const QN_ABI_VERSION: c_int = 3;
 
 // qn_status == SolverError (ls_solver.rs:10-20); 0 is Ok(())
 pub const QN_OK: c_int = 0;
@@ -124,6 +124,8 @@ pub struct qn_stats {
     pub t_ereduce_ms: f64,
     pub n_hreduce_timed: u64,
     pub n_ereduce_timed: u64,
+    pub total_xchg_vector: u64,
+    pub total_xchg_scalar: u64,
 }
 
 extern "C" {

@@ -195,6 +195,23 @@ def main():
                     xa, xb = s.x(), s1.x()
                     case[method + ("_rows" if rows else "_again") + "_close"] = bool(np.linalg.norm(xa - xb) <= 1e-8 * np.linalg.norm(xb))
                     case[method + ("_rows" if rows else "_again") + "_path"] = s.stats()["path"]
+            # rounds 1-3's sharded kernels (tile, sum, exchange, epilogue, control step) stay reachable: set_tiling(-4)
+            sg1 = qn.BFGS(1e-10, x0, ctx=ctx)
+            sg1.set_tiling(-4, 0)
+            sg1.set_trace(iters, with_x=True)
+            sr1 = qn.BFGS(1e-10, x0, ctx=ctx1)
+            sr1.set_trace(iters, with_x=True)
+            for sv, ob in ((sg1, obj), (sr1, obj1)):
+                try:
+                    sv.minimize(qn.MoreThuente(), ob, iters, 20)
+                except qn.MaxIterReached:
+                    pass
+            (tg1, xg1), (tr1_, xr1) = sg1.trace(), sr1.trace()
+            case["gen1_close"] = bool(len(tg1) == len(tr1_) == iters
+                                      and all((a["ls_cases"], a["n_evals"]) == (c["ls_cases"], c["n_evals"]) for a, c in zip(tg1, tr1_))
+                                      and np.linalg.norm(xg1 - xr1) <= 1e-9 * np.linalg.norm(xr1))
+            case["gen1_path"] = sg1.stats()["path"]
+            case["gen1_bytes"] = sg1.stats()["matrix_bytes_per_pass"]
             if n == 1024:  # More-Thuente's cases 2-4, the modified-updating switch and tu = +inf on the sharded tiles (mt_workloads.py)
                 import mt_workloads as W
                 ok_all, digits = True, []

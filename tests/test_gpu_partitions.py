@@ -34,7 +34,7 @@ def _run(qn, solver, ls, obj, iters):
     return solver.trace()
 
 
-def _sharded_quadratic(qn, n, world, iters, allreduce, want_h):
+def _sharded_quadratic(qn, n, world, iters, allreduce, want_h, first_generation=False):
     diag = P.synth_diag(n)
     b, x0 = P.synth_vectors(n)
 
@@ -45,9 +45,12 @@ def _sharded_quadratic(qn, n, world, iters, allreduce, want_h):
             ctx.set_allreduce(True)
         obj = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx)
         s = qn.BFGS(1e-10, x0, ctx=ctx)
+        if first_generation:
+            s.set_tiling(-4, 0)  # rounds 1-3: tile, sum, exchange, epilogue, control step per evaluation or pass
         tr, xs = _run(qn, s, qn.MoreThuente(), obj, iters)
         st = s.stats()
-        out = {"tr": tr, "xs": xs, "path": st["path"], "bytes": st["matrix_bytes_per_pass"]}
+        out = {"tr": tr, "xs": xs, "path": st["path"], "bytes": st["matrix_bytes_per_pass"], "launches": st["launches"],
+               "xchg": (st["total_xchg_vector"], st["total_xchg_scalar"]), "evals": st["oracle_evals"], "iters": st["iterations"]}
         if want_h:
             out["h"] = s.approx_inv_hessian(all_ranks=True)  # collective: the stale halves come from the ranks that own the pairs
         group.sync()
@@ -57,34 +60,48 @@ def _sharded_quadratic(qn, n, world, iters, allreduce, want_h):
     return run_ranks(world, body), (diag, b, x0)
 
 
-def _single_rank_quadratic(qn, n, iters, inputs, first_generation=True):
+def _single_rank_quadratic(qn, n, iters, inputs, first_generation=False):
     diag, b, x0 = inputs
     obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
     s = qn.BFGS(1e-10, x0)
     if first_generation:
-        s.set_tiling(-4, 0)  # the first-generation tile kernels: the ones the sharded layout runs
+        s.set_tiling(-4, 0)  # the first-generation tile kernels
     tr, xs = _run(qn, s, qn.MoreThuente(), obj, iters)
     return s, obj, tr, xs
 
 
-def _check_partition(res, world, n):
+def _check_partition(res, world, n, first_generation=False):
     nb = n // 128
     for r in res:
-        assert r["path"] & 1 and r["path"] & 2 and not r["path"] & 16  # fused, symmetric storage, first-generation tile kernels
-    assert sum(r["bytes"] for r in res) == nb * (nb + 1) // 2 * 131072  # every pair of block-rows exactly once
+        assert r["path"] & 1 and r["path"] & 2  # fused, symmetric storage
+        assert bool(r["path"] & 16) == (not first_generation)  # second-generation structure: the machine in the kernels' prologues
+    # every pair of block-rows exactly once; the second-generation kernels stream a diagonal tile as its upper triangle (73 728 B)
+    diag_tile = 131072 if first_generation else 73728
+    assert sum(r["bytes"] for r in res) == nb * (nb - 1) // 2 * 131072 + nb * diag_tile
     assert max(r["bytes"] for r in res) - min(r["bytes"] for r in res) <= (nb // world) * 131072  # balanced to a tile per block-row
+    if not first_generation:
+        # the launch contract of qn_sym2sh.hip.h: per iteration E evaluation launches + 5 (vsum, vec, update tiles, hsum, hreduce),
+        # E scalar exchanges and 2 exchanges of n-vectors (+ one evaluation and one direction pass that open the run, and what the
+        # synchronous pump of this harness adds: one prologue-only launch per request)
+        for r in res:
+            it, ev = r["iters"], r["evals"]
+            xv, xs_ = r["xchg"]
+            assert xs_ == ev and xv == 2 * it + 2, (xv, xs_, it, ev)
+            requests = ev + (it + 1) + (it + 1)  # evaluations, accepted points (+ the one at x0), passes (+ the direction pass)
+            assert r["launches"] == ev + 2 * (it + 1) + 3 * (it + 1) + requests + 1, (r["launches"], it, ev)
     for r in res[1:]:  # replicated vector work: the same bits on every rank
         assert np.array_equal(r["xs"], res[0]["xs"]) and r["tr"] == res[0]["tr"]
 
 
+@pytest.mark.parametrize("first_generation", [False, True])
 @pytest.mark.parametrize("allreduce", [False, True])
-def test_config3_partition_8_ranks_n4096_vs_single_rank_and_oracle(qn, qo, allreduce):
+def test_config3_partition_8_ranks_n4096_vs_single_rank_and_oracle(qn, qo, allreduce, first_generation):
     """P = 8, rpr / 128 = 4 block-rows per rank, nb = 32 even (cnt(I) split at I < nb / 2): config 3's shape at a size the oracle
-    follows."""
+    follows.  Both generations of the sharded kernels: the default (qn_sym2sh.hip.h) and rounds 1-3's (set_tiling(-4))."""
     n, world, iters = 4096, 8, 12
-    res, inputs = _sharded_quadratic(qn, n, world, iters, allreduce, want_h=not allreduce)
-    _check_partition(res, world, n)
-    s1, obj1, tr1, xs1 = _single_rank_quadratic(qn, n, iters, inputs)
+    res, inputs = _sharded_quadratic(qn, n, world, iters, allreduce, want_h=not allreduce, first_generation=first_generation)
+    _check_partition(res, world, n, first_generation)
+    s1, obj1, tr1, xs1 = _single_rank_quadratic(qn, n, iters, inputs, first_generation)
     _trace_close(res[0]["tr"], res[0]["xs"], tr1, xs1)
     if not allreduce:
         h, h1 = res[0]["h"], s1.approx_inv_hessian()

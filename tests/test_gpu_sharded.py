@@ -39,10 +39,13 @@ def _check_sharded_symmetric(res, nproc):
                 assert case[m + "_close"] and case[m + "_h_symmetric"] and case[m + "_h_close"], (r["rank"], case)
                 assert case[m + "_again_close"] and case[m + "_rows_close"], (r["rank"], case)
                 p_sh, p_1 = case[m + "_path"]
-                assert p_sh & 1 and p_sh & 2 and not p_sh & 16, p_sh   # fused, symmetric storage, first-generation tile kernels
+                assert p_sh & 1 and p_sh & 2, p_sh   # fused, symmetric storage
+                # whole 128-blocks (n = n_pad): the second-generation structure (qn_sym2sh.hip.h); padded n: rounds 1-3's kernels
+                assert bool(p_sh & 16) == (n % 128 == 0), (n, p_sh)
                 assert case[m + "_again_path"] & 2 and not case[m + "_rows_path"] & 2
                 b_sh, b_1 = case[m + "_bytes"]
                 assert abs(nproc * b_sh - nb * (nb + 1) // 2 * 131072) <= nproc * (nb // nproc) * 131072  # balanced to one tile per block-row
+            assert case["gen1_close"] and case["gen1_path"] & 2 and not case["gen1_path"] & 16, case  # rounds 1-3's kernels, still reachable
     for r in res:  # the generic path's H pass on the sharded tiles (flag 4), quadratic and log-sum-exp objectives
         for case in r["cases"]:
             assert case["generic_close"] and case["generic_path"][0] & 4 and not case["generic_path"][0] & 1, case
@@ -60,10 +63,14 @@ def _check_sharded_symmetric(res, nproc):
             assert not case["rows_pipelined_path"][0] & 8 and case["rows_pipelined_path"][1] & 8
             assert case["pipelined_syncs"][1] * 4 < case["pipelined_syncs"][0]  # (the control-block reads; the exchanges' own waits are not even counted)
     for case_i in range(len(res[0]["cases"])):
-        nb = (res[0]["cases"][case_i]["n"] + 127) // 128
+        n_i = res[0]["cases"][case_i]["n"]
+        nb = (n_i + 127) // 128
+        # the ranks' tiles together are the half matrix exactly: every pair of block-rows once
+        assert sum(r["cases"][case_i]["gen1_bytes"] for r in res) == nb * (nb + 1) // 2 * 131072
         for m in ("bfgs", "dfp"):
-            # the ranks' tiles together are the half matrix exactly: every pair of block-rows once
-            assert sum(r["cases"][case_i][m + "_bytes"][0] for r in res) == nb * (nb + 1) // 2 * 131072
+            # (the second-generation kernels stream a diagonal tile as its upper triangle: 73 728 of its 131 072 bytes)
+            diag_tile = 73728 if n_i % 128 == 0 else 131072
+            assert sum(r["cases"][case_i][m + "_bytes"][0] for r in res) == nb * (nb - 1) // 2 * 131072 + nb * diag_tile
             assert len({tuple(r["cases"][case_i][m + "_x_hex"]) for r in res}) == 1  # replicated vector work: same bits everywhere
             assert len({tuple(r["cases"][case_i][m + "_h_hex"]) for r in res}) == 1
         assert len({tuple(r["cases"][case_i]["allreduce_x_hex"]) for r in res}) == 1  # all-reduce mode: the same bits on every rank too
