@@ -16,8 +16,10 @@ Prints ONE JSON line on rank 0.  The product path is libqn_hip.so (hand-written 
 oracle is used only for the `cpu_baseline` leg.  No GPU => hard failure, never a fallback.
 """
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -61,18 +63,34 @@ def totals(solver):
     """Counters that accumulate over every qn_minimize call of the solver (the per-call ones restart with k)."""
     st = solver.stats()
     return {k: st[k] for k in ("total_minimize_calls", "total_iterations", "total_oracle_calls", "total_oracle_evals", "total_h_passes",
-                               "total_h_bytes", "total_obj_bytes", "launches", "host_syncs")}
+                               "total_h_bytes", "total_obj_bytes", "launches", "host_syncs", "total_xchg_vector", "total_xchg_scalar")}
 
 
 def cpu_baseline(n, iters):
+    """The `cpu_baseline` leg in a FRESH CHILD PROCESS.  Round 3 ran it in the bench process, where `import
+    torch` had already started an OpenMP runtime: OMP_PROC_BIND / OMP_PLACES set afterwards never applied, and the driver's run
+    printed 41.7 it/s where the same code reached 87-137.  The child is started with the pinning in its environment before any
+    OpenMP runtime exists, never touches the GPU (it imports numpy and the oracle only), and prints one JSON object."""
+    env = dict(os.environ)
+    env.setdefault("OMP_PROC_BIND", "true")
+    env.setdefault("OMP_PLACES", "cores")
+    env.pop("OMP_NUM_THREADS", None)  # (torch.distributed.run exports OMP_NUM_THREADS=1 to its workers)
+    cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(n), str(iters)],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    if cp.returncode != 0:
+        return {"error": f"cpu_baseline child failed (rc {cp.returncode}): {cp.stderr[-400:]}"}
+    out = json.loads(cp.stdout.strip().splitlines()[-1])
+    out["process"] = "fresh child process, OMP_PROC_BIND=%s OMP_PLACES=%s" % (env["OMP_PROC_BIND"], env["OMP_PLACES"])
+    return out
+
+
+def cpu_baseline_child(n, iters):
     """CPU port timed on the host cores (CPU-B): the oracle restatement with the O(n^2) rank-2 update (the
     reference's literal update is O(n^3): 2.7e11 flop per iteration at n = 4096), reference call sequence (5 oracle calls per
     iteration), OpenMP over all cores.  Every sweep is contiguous per thread -- the symmetric H and Q are read by rows = columns,
     four rows per thread in flight, pages first touched by the thread that streams them -- so the port is bandwidth-bound and
     the achieved GB/s is printed next to the core count."""
-    os.environ.setdefault("OMP_PROC_BIND", "true")  # (before the OpenMP runtime starts: the oracle library is loaded below)
-    os.environ.setdefault("OMP_PLACES", "cores")
-    from oracle import qn_oracle as qo
+    from oracle import qn_oracle as qo  # (the first OpenMP runtime of this process: the pinning is in the environment already)
     threads = qo.max_threads()
     diag, b, x0 = synth_inputs(n)
     q = qo.synth_rows(n, 0, n, SEED, diag, nthreads=threads)
@@ -95,6 +113,7 @@ def cpu_baseline(n, iters):
         del s
     out = {"value": k / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
            "achieved_GBs": moved / dt / 1e9, "bytes_per_iteration": moved / max(k, 1),
+           "numa_nodes": len(glob.glob("/sys/devices/system/node/node[0-9]*")) or None,
            "bytes_note": "matrix bytes the port streams: 8 n^2 per oracle call (full Q by rows), 8 n^2 per mat-vec with H (u = H y, "
                          "d = -H g), 16 n^2 for the rank-2 update",
            "sample": f"{k} BFGS+MoreThuente iterations at n={n} in {runs} runs of {per_run} from (x0, H = I) (same Q, b, x0 as the GPU run), "
@@ -116,6 +135,9 @@ def cpu_baseline(n, iters):
 
 
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--cpu-baseline-child":  # (no torch, no GPU: see cpu_baseline)
+        print(json.dumps(cpu_baseline_child(int(sys.argv[2]), int(sys.argv[3]))), flush=True)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
@@ -173,13 +195,20 @@ def main():
         if int(okf.item()) == 0:
             if host_exchange:
                 sys.exit(f"rank {rank}: host-staged exchange failed: {err}")
-            # RCCL could not be brought up on some rank: keep the run alive on the host-staged exchange and SAY SO in the line
-            print(f"[bench rank {rank}] RCCL exchange unavailable ({err}); falling back to host-staged gloo exchange", file=sys.stderr)
+            # RCCL could not be brought up on some rank.  A scaling point through any other exchange is not a measurement of anything
+            # north_star names: print the line WITHOUT a value, with the error, and fail.  The host-staged
+            # exchange stays strictly behind QN_BENCH_EXCHANGE=host (harness rehearsal on a one-GPU box).
             rccl_error = err or "failed on another rank"
-            host_exchange = True
-            ctx = qn.dist.sharded_context(dev, host_exchange=True)
-            ctx.set_host_exchange_async(True)
-            ctx.comm_check()
+            print(f"[bench rank {rank}] RCCL exchange unavailable: {rccl_error}", file=sys.stderr)
+            if rank == 0:
+                print(json.dumps({"metric": METRIC, "value": None, "unit": "iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                                  "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                                  "data": "synthetic", "config": {"workload": f"BFGS + MoreThuente::default, n={n} convex quadratic, f64, {world}xMI355X",
+                                                                  "exchange": "rccl", "rccl_error": rccl_error},
+                                  "error": "the RCCL communicator could not be brought up on every rank: nothing was measured"}), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(3)
     else:
         ctx = qn.Context(device=local_rank)
 
@@ -285,13 +314,17 @@ def main():
         ach_e = alg_q / (ms_e * 1e-3) / 1e9 if n_e else None
         sym_pass = bool(p1["path"] & 2)
         sym2 = bool(p1["path"] & 16)
-        hname = ("s2_hpass_kernel (pending rank-2 update in place + row and column sums of [y, g+] over the symmetric half of H; its "
+        hname = ("s2_hpass_kernel<.., SHARD> (pending rank-2 update in place + row and column sums of [y, g+] over this rank's share of the "
+                 "symmetric half of H -- the circulant windows of its block-rows; its prologue runs the solver's state machine)" if (sym2 and world > 1) else
+                 "s2_hpass_kernel (pending rank-2 update in place + row and column sums of [y, g+] over the symmetric half of H; its "
                  "prologue runs the solver's state machine)" if sym2 else
                  "sym_hpass_tile_kernel (rank-2 update + row and column dots of [y, g+] over the upper block triangle of H)" if (sym_pass and world == 1) else
                  "sym_hpass_tile_kernel (rank-2 update + row and column dots of [y, g+] over this rank's share of the symmetric half of H: "
                  "the circulant windows of its block-rows)" if sym_pass else
                  "h_pass_fused_kernel (fused rank-2 update + 2-RHS mat-vec over the rank's rows of H)")
-        ename = ("s2_eval_kernel (f(x + t d) and g(x + t d)'d from the symmetric half of Q: first tile parked in LDS while wave 0 runs the "
+        ename = ("s2_eval_kernel<.., SHARD> (this rank's share of f(x + t d) and g(x + t d)'d from its windows of Q: per-workgroup scalars, "
+                 "exchanged as 8 KB per rank and summed in rank order by the next launch's prologue)" if (sym2 and world > 1) else
+                 "s2_eval_kernel (f(x + t d) and g(x + t d)'d from the symmetric half of Q: first tile parked in LDS while wave 0 runs the "
                  "solver's state machine, items in groups with one exchange)" if sym2 else
                  "sym_eval_tile_kernel (Q (x + t d) from the upper block triangle of Q)" if sym_pass else
                  "quad_eval_fused_kernel (Q_rows (x + t d), trial point and direction formed on the fly)")
@@ -357,6 +390,15 @@ def main():
     if rank == 0:
         mat_bytes = float(solver.stats()["matrix_bytes_per_pass"])  # per rank: the row shard, or the symmetric half (symmetric storage)
         symmetric = bool(solver.stats()["path"] & 2)
+        second_gen = bool(solver.stats()["path"] & 16)
+        # what the default layout of this shape is, and whether the run fell back from it (nothing in the line said so)
+        layout_fallback = None
+        if not symmetric:
+            layout_fallback = ("full rows (2x the bytes): the symmetric-storage layout needs whole 128-row blocks per rank and n >= 1024"
+                               if args.tiling is None else "full rows: selected with --tiling")
+        elif not second_gen:
+            layout_fallback = ("first-generation tile kernels (separate sum / epilogue / control launches): the second-generation path needs "
+                               "n = n_pad" if args.tiling is None else "first-generation tile kernels: selected with --tiling")
         b_iter = world * (h_bytes + obj_bytes) / steps  # counted: (passes + read-write passes) x bytes per pass + evaluations x bytes per pass
         out = {
             "metric": METRIC, "value": its, "unit": "iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -371,6 +413,10 @@ def main():
                                          "rows of H and Q sharded over the ranks; each rank streams the circulant half of its own 128-row "
                                          "blocks (every pair of blocks once across the ranks), per-rank partial n-vectors all-gathered and "
                                          "summed in rank order" if symmetric else "full row-major, row-sharded"),
+                       "kernels": ("second generation: the state machine in every kernel's prologue; per iteration E evaluation launches + "
+                                   + ("5 (partial sums, vectors, update tiles, partial sums, reduce), E scalar + 2 n-vector collectives" if world > 1
+                                      else "3 (vectors, update tiles, reduce)")) if second_gen else "first generation",
+                       "layout_fallback": layout_fallback,
                        "n": n, "line_search": args.ls, "tol": 1e-10, "parallelism": f"row-shard x{world}",
                        "exchange": "none" if world == 1 else ("host-staged gloo, stream-ordered (rehearsal)" if host_exchange else "rccl all-gather"),
                        **({"rccl_error": rccl_error} if rccl_error else {})},
@@ -389,6 +435,9 @@ def main():
                                      "whole_iteration_hbm_frac": b_iter * its / (world * HBM_PEAK_GBS * 1e9),
                                      "h_bytes_counted": h_bytes, "objective_bytes_counted": obj_bytes,
                                      "launches": acc["launches"], "host_syncs": acc["host_syncs"],
+                                     "launches_per_iteration": acc["launches"] / steps,
+                                     "collectives_of_n_vectors": acc["total_xchg_vector"], "collectives_of_scalars": acc["total_xchg_scalar"],
+                                     "collectives_per_iteration": {"n_vectors": acc["total_xchg_vector"] / steps, "scalars_8KB": acc["total_xchg_scalar"] / steps},
                                      "note": "counters are the solver's cumulative totals differenced around the median timed region"},
             "roofline": roofline,
         }
@@ -401,10 +450,11 @@ def main():
                 ctx1 = qn.Context(device=local_rank % max(torch.cuda.device_count(), 1))
                 obj1 = qn.Quadratic.synthetic(n, SEED, diag, b, ctx=ctx1)
                 s1 = qn.BFGS(1e-10, x0, ctx=ctx1)
-                if symmetric:
+                if symmetric and not second_gen:
                     s1.set_tiling(-4, 0)  # the same kernels as the N-rank run: first-generation symmetric-storage tiles
-                else:
+                elif not symmetric:
                     s1.set_tiling(-3, 0)  # the same kernels as the N-rank run: fused row kernels on the full matrices
+                # (second generation: the single-GPU default path IS the N-rank run's kernels, unsharded)
                 ref_steps = min(steps, 50)
                 run_iterations(qn, s1, ls, obj1, x0, min(warmup, 5))
                 ctx1.synchronize()
@@ -414,17 +464,22 @@ def main():
                 dt1 = time.perf_counter() - t1
                 out["strong_scaling_ref"] = {"n_gpus": 1, "value": ref_steps / dt1, "unit": "iterations/s", "steps": ref_steps,
                                              "note": f"same n={n} workload, same storage layout and the same kernels ("
-                                                     + ("symmetric half, first-generation tile kernels" if symmetric else "full row-major matrices")
+                                                     + ("symmetric half, second-generation kernels" if second_gen else
+                                                        "symmetric half, first-generation tile kernels" if symmetric else "full row-major matrices")
                                                      + "), unsharded, on rank 0's GPU after the timed region"}
                 # for the record: one GPU on its default path (symmetric storage, second-generation kernels: 5 launches per iteration)
-                s2 = qn.BFGS(1e-10, x0, ctx=ctx1)
-                run_iterations(qn, s2, ls, obj1, x0, min(warmup, 5))
-                ctx1.synchronize()
-                t2 = time.perf_counter()
-                run_iterations(qn, s2, ls, obj1, x0, ref_steps)
-                ctx1.synchronize()
-                out["strong_scaling_ref"]["single_gpu_default_path_value"] = ref_steps / (time.perf_counter() - t2)
-                del s1, s2, obj1, ctx1
+                if second_gen and symmetric:
+                    out["strong_scaling_ref"]["single_gpu_default_path_value"] = out["strong_scaling_ref"]["value"]  # (the same run)
+                else:
+                    s2 = qn.BFGS(1e-10, x0, ctx=ctx1)
+                    run_iterations(qn, s2, ls, obj1, x0, min(warmup, 5))
+                    ctx1.synchronize()
+                    t2 = time.perf_counter()
+                    run_iterations(qn, s2, ls, obj1, x0, ref_steps)
+                    ctx1.synchronize()
+                    out["strong_scaling_ref"]["single_gpu_default_path_value"] = ref_steps / (time.perf_counter() - t2)
+                    del s2
+                del s1, obj1, ctx1
             except Exception as e:  # noqa: BLE001 -- the reference leg must never lose the bench line
                 out["strong_scaling_ref"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

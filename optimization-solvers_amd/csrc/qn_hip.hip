@@ -806,6 +806,7 @@ struct qn_solver {
     double* s2_evS = nullptr;   // row-sharded: [2][world][QN_S2SH_NEC][QN_S2_MAXG] the ranks' evaluation scalars, by launch parity (QnS2Args.evS)
     int *s2_sl_off = nullptr, *s2_sl_idx = nullptr; // row-sharded: per block-row, the slots this rank's tiles write (QnS2Args.sl_off / sl_idx)
     int s2_sl_nb = 0;
+    int* symsh_tiles = nullptr; // row-sharded, first-generation kernels: this rank's tiles in launch order (QnSymShard.tiles)
     int s2_slots_hint = 0;      // row-sharded, pipelined: evaluation launches (each followed by a collective) enqueued per period
     double* s2_partE = nullptr; // [nb][nb][128]: row / column slots of the last evaluation (QnS2Args.partE)
     double* s2_wgS = nullptr; // [2][s2_trows][QN_S2_ROW]: the sums a servicing launch leaves for the next launch's prologue, by launch parity
@@ -939,9 +940,17 @@ static int solver_alloc_fused(qn_solver* s, bool sym) {
 static int solver_alloc_symsh_lists(qn_solver* s) {
     const int nb = s->T.n_pad / QN_TB;
     if (s->s2_sl_off && s->s2_sl_nb == nb) return QN_OK;
-    (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx);
-    s->s2_sl_off = nullptr; s->s2_sl_idx = nullptr;
+    (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx); (void)hipFree(s->symsh_tiles);
+    s->s2_sl_off = nullptr; s->s2_sl_idx = nullptr; s->symsh_tiles = nullptr;
     const int nbl = s->T.rpr / QN_TB, ioff = s->ctx->rank * nbl;
+    {
+        std::vector<int> tiles;
+        for (int il = 0; il < nbl; ++il)
+            for (int k = 0, I = ioff + il; k < qn_symsh_cnt(I, nb); ++k) tiles.push_back((I << 16) | ((I + k) % nb));
+        if (tiles.empty()) tiles.push_back(0);
+        HIPCHK(hipMalloc((void**)&s->symsh_tiles, tiles.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(s->symsh_tiles, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     std::vector<int> off(nb + 1, 0), idx;
     for (int R = 0; R < nb; ++R) {
         const bool r_local = R >= ioff && R < ioff + nbl;
@@ -1141,7 +1150,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE); (void)hipFree(s->s2_ctl);
-    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx);
+    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx); (void)hipFree(s->symsh_tiles);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
     delete s;
@@ -1383,7 +1392,7 @@ static QnSymShard sym_shard(const qn_solver* s) {
     sh.world = s->ctx->world; sh.rank = s->ctx->rank;
     sh.nbl = s->T.rpr / QN_TB; sh.ioff = sh.rank * sh.nbl;
     sh.xg = s->symsh_xg;
-    sh.sl_off = s->s2_sl_off; sh.sl_idx = s->s2_sl_idx;
+    sh.sl_off = s->s2_sl_off; sh.sl_idx = s->s2_sl_idx; sh.tiles = s->symsh_tiles;
     sh.nsum = s->ctx->use_allreduce ? 1 : sh.world; // all-reduce mode: the exchange already left the total in slice 0
     return sh;
 }

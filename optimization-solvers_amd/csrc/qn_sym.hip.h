@@ -34,8 +34,11 @@ template <bool NT> __device__ __forceinline__ void qn_sym_st(double* p, v2d v) {
 
 // Row-sharded runs (one process per GPU): rank p stores whole rows of its `nbl` block-rows [ioff, ioff + nbl) and streams the
 // CIRCULANT half of them -- block-row I owns the tiles (I, (I + k) mod nb), k = 0 .. cnt(I) - 1, with cnt = (nb + 1) / 2 for odd
-// nb and nb / 2 + 1 (I < nb / 2) or nb / 2 (else) for even nb: every unordered pair {I, J} exactly once, the same number of tiles
-// per block-row to within one.  A tile's column part lands in a block-row that another rank may own, so each rank sums what ITS
+// nb; for even nb the pair {I, I + nb / 2} has two candidates, and it goes to I when I mod (nb / 2) is even, to I + nb / 2 when it
+// is odd (cnt = nb / 2 + 1 or nb / 2): every unordered pair {I, J} exactly once, the same number of tiles per block-row to within
+// one -- and, because the long windows ALTERNATE along the block-rows, the same number of tiles per RANK to within one (rounds 2-3
+// gave all the long windows to I < nb / 2: at P = 8, n = 32768 ranks 0-3 streamed 4128 tiles and ranks 4-7 4096, and an
+// iteration takes as long as its slowest rank).  A tile's column part lands in a block-row that another rank may own, so each rank sums what ITS
 // tiles contributed to every block-row (symsh_sum_kernel), the per-rank partial n-vectors are all-gathered (the context's
 // exchange: RCCL or host-staged), and every rank adds them in rank order and runs the epilogue on the full vectors
 // (symsh_*_epi_kernel) -- replicated work on n-vectors, identical bits on every rank.  world == 1: the fields are unused.
@@ -43,28 +46,19 @@ struct QnSymShard {
     int world, rank, nbl, ioff;
     int nsum;   // slices of xg to add up after the exchange: world (all-gather, rank order), or 1 (an all-reduce left the total in slice 0)
     double* xg; // gathered partial sums: [world][nrhs][n_pad], rank r's slice written by rank r
+    const int* tiles;           // this rank's tiles in launch order, (I << 16) | J: the local block-rows in order, each with its window (built by the host)
     const int *sl_off, *sl_idx; // the slots of block-row R that THIS rank's tiles write: sl_idx[sl_off[R] .. sl_off[R + 1]), ascending (built by the host)
 };
-__device__ __host__ __forceinline__ int qn_symsh_cnt(int I, int nb) { return (nb & 1) ? (nb + 1) / 2 : (I < nb / 2 ? nb / 2 + 1 : nb / 2); }
+__device__ __host__ __forceinline__ int qn_symsh_cnt(int I, int nb) {
+    if (nb & 1) return (nb + 1) / 2;
+    const int h = nb / 2;
+    const bool longw = (I < h) ? ((I & 1) == 0) : (((I - h) & 1) == 1); // of the pair {I0, I0 + h}: I0 when I0 is even, I0 + h when it is odd
+    return longw ? h + 1 : h;
+}
 __device__ __host__ __forceinline__ bool qn_symsh_owns(int I, int J, int nb) { // is tile (I, J) in block-row I's circulant window?
     int k = J - I;
     if (k < 0) k += nb;
     return k < qn_symsh_cnt(I, nb);
-}
-// launch-linear index t -> this rank's tile (I, J): local block-rows in order, each with its window
-__device__ __forceinline__ void qn_symsh_tile(int t, int nb, const QnSymShard& sh, int& I, int& J) {
-    int il, k;
-    if (nb & 1) { const int c = (nb + 1) / 2; il = t / c; k = t - il * c; }
-    else {
-        const int h = nb / 2;
-        int nbig = h - sh.ioff; // local block-rows with I < nb / 2 come first and have h + 1 tiles
-        nbig = nbig < 0 ? 0 : (nbig > sh.nbl ? sh.nbl : nbig);
-        if (t < nbig * (h + 1)) { il = t / (h + 1); k = t - il * (h + 1); }
-        else { const int u = t - nbig * (h + 1); il = nbig + u / h; k = u - (il - nbig) * h; }
-    }
-    I = sh.ioff + il;
-    J = I + k;
-    if (J >= nb) J -= nb;
 }
 static inline int qn_symsh_ntiles(int nb, int nbl, int ioff) {
     int t = 0;
@@ -199,7 +193,7 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_eval_tile_kernel(const QnSymEv
     __shared__ double colred[QN_SYM_WAVES][QN_TB];
     int I, J;
     const bool sharded = a.sh.world > 1;
-    if (sharded) qn_symsh_tile(blockIdx.x, a.nb, a.sh, I, J); else qn_sym_tile(blockIdx.x, a.nb, I, J);
+    if (sharded) { const int ij = a.sh.tiles[blockIdx.x]; I = ij >> 16; J = ij & 0xffff; } else qn_sym_tile(blockIdx.x, a.nb, I, J);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t np = (size_t)a.T.n_pad;
     const int i0 = I * QN_TB, j0 = J * QN_TB, jc = j0 + 2 * lane;
@@ -451,7 +445,7 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_hpass_tile_kernel(const QnSymH
     __shared__ double rowv[4][QN_TB];
     __shared__ double colred[QN_SYM_WAVES][2][QN_TB];
     int I, J;
-    if (a.sh.world > 1) qn_symsh_tile(blockIdx.x, a.nb, a.sh, I, J); else qn_sym_tile(blockIdx.x, a.nb, I, J);
+    if (a.sh.world > 1) { const int ij = a.sh.tiles[blockIdx.x]; I = ij >> 16; J = ij & 0xffff; } else qn_sym_tile(blockIdx.x, a.nb, I, J);
     const size_t np = (size_t)a.T.n_pad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v2d h[8]; // the first rows are requested before the control block is read (all 32, as in the evaluation kernel, costs the

@@ -24,62 +24,83 @@
 #pragma once
 
 // Slot sums of block-row R over the slots THIS rank's tiles wrote (host-built ascending list: the rank's own window when R is
-// local, and the column parts of the local block-rows whose windows contain R).  4 x 128 threads: each quarter adds a quarter
-// of the list in list order, 16 loads in flight, the quarters are combined in order through LDS (qn_s2_slot_sum's scheme; no
-// limit on nb -- the first generation compacted the list in 512 LDS words).  Threads 0..127 return row (tid & 127)'s total.
+// local, and the column parts of the local block-rows whose windows contain R; no limit on nb -- the first generation compacted
+// the list in 512 LDS words).  Nothing here depends on the control block, so the sums are formed WHILE wave 0 runs the prologue:
+// waves 1..7 take a contiguous seventh of the list each, a whole slot (128 rows) per 16-byte load instruction -- lane l holds rows
+// 2 l, 2 l + 1 -- a dozen slots in flight, added in list order; the waves' partial sums meet in LDS and are added in wave order
+// behind the workgroup barrier the prologue needs anyway.  (First version, measured on one rank of the P = 8, n = 32768
+// partition: the slots requested after the barrier, 8 bytes per lane, sixteen at a time through a dependent index load --
+// 27 us per launch, and two of them per iteration.)
+#define QN_S2SH_SB 12 // slots in flight per wave
 template <int NRHS>
-__device__ __forceinline__ double qn_s2sh_list_sum(const double* __restrict__ part, const int nb, const int R, const int rhs, const int* __restrict__ list,
-                                                   const int nlist, double (*qbuf)[QN_TB]) {
-    const int i = threadIdx.x & (QN_TB - 1), qd = threadIdx.x >> 7;
-    const int per = (nlist + 3) / 4;
-    const int k_lo = qd * per, k_hi = min(nlist, k_lo + per);
-    const double* p = part + (((size_t)R * nb) * NRHS + rhs) * QN_TB + i;
-    double acc = 0.0;
-    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
-        double v[16];
+__device__ __forceinline__ void qn_s2sh_wave_sums(const double* __restrict__ part, const int nb, const int R, const int* __restrict__ list, const int nlist,
+                                                  const int wave, const int lane, double (*red)[NRHS][QN_TB]) { // red[QN_S2_WAVES - 1][NRHS][128]
+    constexpr int NW = QN_S2_WAVES - 1;
+    const int per = (nlist + NW - 1) / NW;
+    const int wv = __builtin_amdgcn_readfirstlane(wave); // (uniform: the list entries below are then scalar loads)
+    const int k_lo = (wv - 1) * per, k_hi = min(nlist, k_lo + per);
+    const double* p = part + ((size_t)R * nb) * NRHS * QN_TB + 2 * lane;
+    v2d acc[NRHS];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = (k0 + u < k_hi) ? p[(size_t)list[k0 + u] * NRHS * QN_TB] : 0.0;
+    for (int h = 0; h < NRHS; ++h) acc[h] = (v2d){0.0, 0.0};
+    for (int k0 = k_lo; k0 < k_hi; k0 += QN_S2SH_SB) {
+        v2d v[QN_S2SH_SB][NRHS];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc = acc + v[u];
+        for (int u = 0; u < QN_S2SH_SB; ++u) {
+            const int slot = (k0 + u < k_hi) ? list[k0 + u] : -1; // (wave-uniform: scalar loads)
+#pragma unroll
+            for (int h = 0; h < NRHS; ++h) v[u][h] = (slot >= 0) ? ld2(p + ((size_t)slot * NRHS + h) * QN_TB) : (v2d){0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < QN_S2SH_SB; ++u)
+#pragma unroll
+            for (int h = 0; h < NRHS; ++h) acc[h] = acc[h] + v[u][h];
     }
-    if (qd > 0) qbuf[qd - 1][i] = acc;
-    __syncthreads();
-    const double tot = (qd == 0) ? ((acc + qbuf[0][i]) + qbuf[1][i]) + qbuf[2][i] : 0.0;
-    __syncthreads(); // qbuf is reused by the next call
-    return tot;
+#pragma unroll
+    for (int h = 0; h < NRHS; ++h) { red[wave - 1][h][2 * lane] = acc[h].x; red[wave - 1][h][2 * lane + 1] = acc[h].y; }
+}
+// ... behind the barrier: thread (h, i) adds the waves' shares of row i, right-hand side h, in wave order
+template <int NRHS>
+__device__ __forceinline__ double qn_s2sh_wave_total(const double (*red)[NRHS][QN_TB], const int h, const int i) {
+    double t = red[0][h][i];
+#pragma unroll
+    for (int w = 1; w < QN_S2_WAVES - 1; ++w) t = t + red[w][h][i];
+    return t;
 }
 
 // accepted evaluation, block-row R: this rank's share of q = Q (x + t d) into its slice of xg ([rank][np]); the exchange and
 // s2_vec_kernel<true> follow.  Its prologue is where the machine sees the evaluation that gets accepted (QN_PH_REQ_VEC).
 __global__ __launch_bounds__(QN_S2_TPB) void s2sh_vsum_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
-    __shared__ double qbuf[3][QN_TB];
-    const int R = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    __shared__ double red[QN_S2_WAVES - 1][1][QN_TB];
+    const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave == 0) qn_s2_prologue_w0<QN_S2_VSUM, true>(a, L);
+    else {
+        const int lo = a.sl_off[R];
+        qn_s2sh_wave_sums<1>(a.partE, a.nb, R, a.sl_idx + lo, a.sl_off[R + 1] - lo, wave, lane, red);
+    }
     __syncthreads();
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
-    const int lo = a.sl_off[R], nlist = a.sl_off[R + 1] - lo;
-    const double qi = qn_s2sh_list_sum<1>(a.partE, a.nb, R, 0, a.sl_idx + lo, nlist, qbuf);
-    if (tid < QN_TB) a.xg[(size_t)a.sh_rank * (size_t)a.np + (size_t)R * QN_TB + tid] = qi;
+    if (tid < QN_TB) a.xg[(size_t)a.sh_rank * (size_t)a.np + (size_t)R * QN_TB + tid] = qn_s2sh_wave_total<1>(red, 0, tid);
 }
 
 // update pass, block-row R: this rank's share of [u, v] = H+ [y, g+] (direction pass: [H g, -]) into its slice of xg ([rank][2][np])
 __global__ __launch_bounds__(QN_S2_TPB) void s2sh_hsum_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
-    __shared__ double qbuf[3][QN_TB];
-    const int R = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    __shared__ double red[QN_S2_WAVES - 1][2][QN_TB];
+    const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave == 0) qn_s2_prologue_w0<QN_S2_HSUM, true>(a, L);
+    else {
+        const int lo = a.sl_off[R];
+        qn_s2sh_wave_sums<2>(a.part, a.nb, R, a.sl_idx + lo, a.sl_off[R + 1] - lo, wave, lane, red);
+    }
     __syncthreads();
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
-    const int lo = a.sl_off[R], nlist = a.sl_off[R + 1] - lo;
-    const double t0 = qn_s2sh_list_sum<2>(a.part, a.nb, R, 0, a.sl_idx + lo, nlist, qbuf);
-    const double t1 = qn_s2sh_list_sum<2>(a.part, a.nb, R, 1, a.sl_idx + lo, nlist, qbuf);
-    if (tid < QN_TB) {
-        double* out = a.xg + (size_t)a.sh_rank * 2 * (size_t)a.np + (size_t)R * QN_TB + tid;
-        out[0] = t0;
-        out[a.np] = t1;
+    if (tid < 2 * QN_TB) {
+        const int h = tid >> 7, i = tid & (QN_TB - 1);
+        a.xg[((size_t)a.sh_rank * 2 + h) * (size_t)a.np + (size_t)R * QN_TB + i] = qn_s2sh_wave_total<2>(red, h, i);
     }
 }
 
