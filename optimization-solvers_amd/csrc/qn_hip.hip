@@ -74,10 +74,13 @@ static int rccl_load() {
     if (g_rccl.handle) return QN_OK;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* h = nullptr;
-    for (const char* nm : names) {
-        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
-    }
+    const char* forced = getenv("QN_RCCL_LIB"); // the one library to load (deployments with their own build; rehearsals of a missing one)
+    if (forced && *forced) h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    else
+        for (const char* nm : names) {
+            h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
     if (!h) return fail(QN_ABNORMAL_TERMINATION, std::string("cannot load librccl: ") + dlerror());
     g_rccl.GetUniqueId = (int (*)(RcclUniqueId*))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(RcclComm*, int, RcclUniqueId, int))dlsym(h, "ncclCommInitRank");
@@ -611,16 +614,16 @@ static void launch_hpass(hipStream_t st, const QnHPassArgs& a);
 // enqueue one evaluation of the log-sum-exp objective at x_dev (n_pad entries): f -> f_dev, g -> g_dev
 template <int KCH>
 static int lse_launch_onepass(hipStream_t st, int G, const QnLseArgs& a, double* wgms, double* wgg) {
-    static bool attr_set[64] = {}; // per device: hipFuncSetAttribute applies to the current device only
+    static std::atomic<bool> attr_set[64]; // per device: hipFuncSetAttribute applies to the current device only (atomic: ranks may be threads)
     int dev = 0;
     (void)hipGetDevice(&dev);
     const size_t lds = (size_t)KCH * 1024 * sizeof(double);
-    if ((dev < 0 || dev >= 64 || !attr_set[dev]) && lds > 48 * 1024) { // x in LDS: up to 128 KB of the CU's 160 KB
+    if ((dev < 0 || dev >= 64 || !attr_set[dev].load()) && lds > 48 * 1024) { // x in LDS: up to 128 KB of the CU's 160 KB
         if (hipFuncSetAttribute((const void*)lse_onepass_kernel<KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             return -1; // this device does not grant the LDS: the caller keeps the two-pass evaluation
         }
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true);
     }
     hipLaunchKernelGGL((lse_onepass_kernel<KCH>), dim3(G), dim3(512), lds, st, a, wgms, wgg);
     return QN_OK;
@@ -871,7 +874,8 @@ static void prof_collect(qn_solver* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     // In pipelined mode the launch pattern runs ahead of the decisions, so some bracketed launches found their request not
     // pending and returned from the prologue (a few microseconds).  They are not work: a class's sums take only the launches
-    // that lasted more than half its median (in synchronous mode every launch is real and passes).
+    // that lasted more than half its LONGEST launch (in synchronous mode every launch is real and passes; a median-based floor failed
+    // when most of a class's launches were skipped -- backtracking's four slots per period, a run that ends early in a batch).
     std::vector<std::vector<float>> dur(8);
     std::vector<std::pair<int, float>> all;
     all.reserve(s->events.size());
@@ -886,10 +890,7 @@ static void prof_collect(qn_solver* s) {
     float floor_ms[8];
     for (int c = 0; c < 8; ++c) {
         floor_ms[c] = 0.f;
-        if (dur[c].size() >= 8) {
-            std::nth_element(dur[c].begin(), dur[c].begin() + dur[c].size() / 2, dur[c].end());
-            floor_ms[c] = 0.5f * dur[c][dur[c].size() / 2];
-        }
+        if (dur[c].size() >= 8) floor_ms[c] = 0.5f * *std::max_element(dur[c].begin(), dur[c].end());
     }
     for (auto& e : all) {
         const int cls = (e.first >= 0 && e.first < 7) ? e.first : 7;
@@ -1014,6 +1015,14 @@ static int solver_alloc_sym2(qn_solver* s) {
             };
             if (sharded) { // the windows' off-diagonal tiles in window order, then the diagonal ones (the cheap items last)
                 inorder = 0; // (the kernels read every item from the list: qn_s2_first_item_of)
+                if (getenv("QN_EXP_DEAL") && !strcmp(getenv("QN_EXP_DEAL"), "contig")) { // EXPERIMENT: consecutive tiles per workgroup
+                    std::vector<int> all;
+                    for (int il = 0; il < nbl; ++il)
+                        for (int k = 0, I = ioff + il; k < qn_symsh_cnt(I, nb); ++k) all.push_back((I << 16) | ((I + k) % nb));
+                    for (int g = 0; g < G; ++g)
+                        for (size_t t = all.size() * g / G; t < all.size() * (g + 1) / G; ++t) lists[g].push_back(all[t]);
+                    return;
+                }
                 for (int il = 0; il < nbl; ++il) {
                     const int I = ioff + il, cnt = qn_symsh_cnt(I, nb);
                     for (int k = 1; k < cnt; ++k) give(I, (I + k) % nb, 1.0);
@@ -1130,7 +1139,9 @@ extern "C" int qn_solver_create(qn_context* ctx, int method, double tol, const d
     s->V.f_dev = s->f_dev;
     HIPCHK(hipMalloc((void**)&s->ctl, sizeof(QnCtl)));
     HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(QnCtl), st));
-    HIPCHK(hipHostMalloc((void**)&s->hctl, sizeof(QnCtl), hipHostMallocDefault));
+    // (mapped + coherent, explicitly: s2_ctl_upload_kernel reads the mirror from the device, call after call -- with a non-coherent
+    // mapping the second call could be served a stale line from L2)
+    HIPCHK(hipHostMalloc((void**)&s->hctl, sizeof(QnCtl), hipHostMallocMapped | hipHostMallocCoherent));
     memset(s->hctl, 0, sizeof(QnCtl));
     HIPCHK(hipHostMalloc((void**)&s->hx, n * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&s->hg, (n + 1) * sizeof(double), hipHostMallocDefault));
@@ -2415,11 +2426,13 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             a.fold = 0; a.pair = 0;
             a.nt = ((size_t)s->T.rpr * s->T.n_pad * 8 / 2) >= ((size_t)64 << 20);
         }
+        if (getenv("QN_EXP_NT")) a.nt = atoi(getenv("QN_EXP_NT")); // EXPERIMENT
         // (no synchronisation: the copy is stream-ordered in front of the launches, the mirror is pinned, and the host does not
         // write it again before s2_peek has synchronised)
         // (a one-workgroup launch that reads the pinned mirror, not hipMemcpyAsync: the copy path put ~8 us in front of the first
         // kernel of every call -- 0.6 % of the driver's 20-step region)
         hipLaunchKernelGGL(s2_ctl_upload_kernel, dim3(1), dim3(256), 0, c->stream, s->hctl, s->s2_ctl);
+        HIPCHK(hipGetLastError());
     } else {
         QNCHK(poke_ctl(s));
     }

@@ -272,12 +272,15 @@ def test_pivoted_lu_path_agrees_with_the_cholesky_path_on_spd(qn, qo, n):
     assert np.linalg.norm(out[1][1] - xstar) <= 1e-9 * np.linalg.norm(xstar)
 
 
-@pytest.mark.parametrize("n", [64, 200, 777, 1300])
+@pytest.mark.parametrize("n", [64, 200, 777, 1300, 4200])
 def test_panel_lu_equals_the_per_column_lu_bit_for_bit(qn, qo, n):
     """qn_lu.hip.h: the 64-column panel is factorised four columns at a time by one workgroup that holds the rows in registers
     (19 launches per panel); set_tiling(-8, 0) selects rounds 1-2's two launches per column.  Same pivots (first maximum), same
-    arithmetic in the same order: the iterates are the same bits.  Non-symmetric, indefinite Hessian (row swaps do occur)."""
+    arithmetic in the same order: the iterates are the same bits.  Non-symmetric, indefinite Hessian (row swaps do occur).
+    n = 4200: panels of more than 2048 and more than 4096 rows -- the 8- and 16-rows-per-thread instantiations of the step kernel,
+    which are the ones config 4 (n = 8192) runs."""
     fn, hess0, x0 = _double_well_chain(n)
+    iters = 3 if n <= 2000 else 1
     rng = np.random.default_rng(8)
     k = 0.2 * np.triu(rng.standard_normal((n, n)), 1) / np.sqrt(n)
     hess = lambda x: hess0(x) + k - k.T  # noqa: E731
@@ -286,9 +289,9 @@ def test_panel_lu_equals_the_per_column_lu_bit_for_bit(qn, qo, n):
         s = qn.Newton(1e-10, x0)
         if percol:
             s.set_tiling(-8, 0)
-        s.set_trace(3, with_x=True)
+        s.set_trace(iters, with_x=True)
         try:
-            s.minimize(qn.MoreThuente(), lambda x: qn.FuncEvalMultivariate(*fn(x)).with_hessian(hess(x)), 3, 20)
+            s.minimize(qn.MoreThuente(), lambda x: qn.FuncEvalMultivariate(*fn(x)).with_hessian(hess(x)), iters, 20)
         except qn.MaxIterReached:
             pass
         tr, xs = s.trace()

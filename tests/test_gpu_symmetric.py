@@ -167,6 +167,29 @@ def test_row_slivers_at_4096(qn, qo, method, lsname):
     assert np.array_equal(hm, hm.T) and np.abs(hm - h).max() <= 1e-9 * np.abs(h).max()
 
 
+@pytest.mark.parametrize("n", [1152, 3200])
+def test_second_generation_without_slivers_and_without_the_pair_instance(qn, qo, n):
+    """Sizes whose work lists carry NO row slivers (sl_per == 0) and where the two-items-and-a-sliver instance of the evaluation
+    kernel cannot run (pair == 0): n = 1152 (nb = 9: 45 items, one per workgroup) and n = 3200 (nb = 25: 325 items on 256
+    workgroups -- lists of one and of two items side by side).  Round 3's memory fault lived exactly here: the kernels divided by
+    the sliver count unconditionally and the compiler deleted the guarded no-sliver path (qn_s2_sliver).  The host now also refuses
+    work lists whose sliver count does not tile the grid (solver_alloc_sym2).  Against the row kernels, pipelined = synchronous."""
+    q, b, x0, _ = P.synth_problem(qo, n)
+    obj = qn.Quadratic(q, b)
+    iters = 16
+    s, st = _run(qn, "bfgs", "mt", obj, x0, iters)
+    assert s.stats()["path"] & 16 and s.stats()["matrix_bytes_per_pass"] == sym_bytes(n)
+    r, st_r = _run(qn, "bfgs", "mt", obj, x0, iters, tiling=(-3, 0))
+    (tr, xs), (tr_r, xs_r) = s.trace(), r.trace()
+    assert st == st_r and len(tr) == len(tr_r) == iters
+    assert [(a["n_evals"], a["ls_cases"]) for a in tr] == [(a["n_evals"], a["ls_cases"]) for a in tr_r]
+    assert np.linalg.norm(xs[-1] - xs_r[-1]) <= 1e-9 * max(1.0, np.linalg.norm(xs_r[-1]))
+    y, st_y = _run(qn, "bfgs", "mt", obj, x0, iters, sync=1)
+    assert st_y == st and y.trace()[0] == tr and np.array_equal(y.trace()[1], xs)
+    h = s.approx_inv_hessian()
+    assert np.array_equal(h, h.T) and np.array_equal(y.approx_inv_hessian(), h)
+
+
 def test_warm_restart_continues_on_the_mirrored_hessian(qn, qo):
     """Two minimize calls of 10 iterations follow one of 20: the lower triangle restored between the calls is the right one
     (the second call's first pass applies the pending update to it)."""
