@@ -1015,14 +1015,6 @@ static int solver_alloc_sym2(qn_solver* s) {
             };
             if (sharded) { // the windows' off-diagonal tiles in window order, then the diagonal ones (the cheap items last)
                 inorder = 0; // (the kernels read every item from the list: qn_s2_first_item_of)
-                if (getenv("QN_EXP_DEAL") && !strcmp(getenv("QN_EXP_DEAL"), "contig")) { // EXPERIMENT: consecutive tiles per workgroup
-                    std::vector<int> all;
-                    for (int il = 0; il < nbl; ++il)
-                        for (int k = 0, I = ioff + il; k < qn_symsh_cnt(I, nb); ++k) all.push_back((I << 16) | ((I + k) % nb));
-                    for (int g = 0; g < G; ++g)
-                        for (size_t t = all.size() * g / G; t < all.size() * (g + 1) / G; ++t) lists[g].push_back(all[t]);
-                    return;
-                }
                 for (int il = 0; il < nbl; ++il) {
                     const int I = ioff + il, cnt = qn_symsh_cnt(I, nb);
                     for (int k = 1; k < cnt; ++k) give(I, (I + k) % nb, 1.0);
@@ -1728,8 +1720,11 @@ static int s2_launch(Run& r, int kind) {
     const bool sh = a.sh_world > 1; // row-sharded: the SHARD instantiations (qn_sym2sh.hip.h)
     switch (kind) {
     case QN_S2_EVAL:
-        if (sh) hipLaunchKernelGGL((s2_eval_kernel<false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-        else if (a.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        if (sh) {
+            if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            else hipLaunchKernelGGL((s2_eval_kernel<false, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        } else if (a.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        else if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         else hipLaunchKernelGGL(s2_eval_kernel<false>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         break;
     case QN_S2_VSUM: hipLaunchKernelGGL(s2sh_vsum_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
@@ -2426,7 +2421,14 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             a.fold = 0; a.pair = 0;
             a.nt = ((size_t)s->T.rpr * s->T.n_pad * 8 / 2) >= ((size_t)64 << 20);
         }
-        if (getenv("QN_EXP_NT")) a.nt = atoi(getenv("QN_EXP_NT")); // EXPERIMENT
+        // Q's tiles with non-temporal loads once an evaluation streams well past the Infinity Cache (256 MB).  Measured (round 4,
+        // tools/stream_shape_probe.hip: a plain read of 537 MB in this launch shape runs at 6.1-6.3 TB/s, non-temporal at 6.5-6.85;
+        // bench.py same box): n = 32768 on one GPU 723 -> 662 us per evaluation (6.49 TB/s), 327 -> 341 it/s; one rank of the
+        // P = 8 partition 114 -> 103 us; n = 8192 (268 MB per evaluation: the cache still holds part of it) no gain -- plain there.
+        const size_t q_stream = c->world > 1 ? (size_t)s->T.rpr * s->T.n_pad * 8 / 2 : (size_t)s->T.n_pad * s->T.n_pad * 8 / 2;
+        a.ntq = q_stream >= ((size_t)400 << 20);
+        if (getenv("QN_S2_NT")) a.nt = atoi(getenv("QN_S2_NT"));    // (diagnostics: tools/README.md)
+        if (getenv("QN_S2_NTQ")) a.ntq = atoi(getenv("QN_S2_NTQ"));
         // (no synchronisation: the copy is stream-ordered in front of the launches, the mirror is pinned, and the host does not
         // write it again before s2_peek has synchronised)
         // (a one-workgroup launch that reads the pinned mirror, not hipMemcpyAsync: the copy path put ~8 us in front of the first
@@ -2471,7 +2473,9 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 if (!first) {
                     QNCHK(s2_peek(r));
                     if (r.s2.sh_world > 1 && h->n_iterations > it0) { // evaluations per iteration of the batch just run, rounded up
-                        const uint64_t di = h->n_iterations - it0, de = h->n_oracle_evals - ev0;
+                        const uint64_t di = h->n_iterations - it0;
+                        uint64_t de = h->n_oracle_evals - ev0;
+                        if (it0 == 0 && !h->warm && de > 0) de -= 1; // (the evaluation at x0 that opens a run had a period of its own)
                         slots = (int)std::min<uint64_t>(4, std::max<uint64_t>(1, (de + di - 1) / di));
                         s->s2_slots_hint = slots; // (the next call starts from it)
                     }

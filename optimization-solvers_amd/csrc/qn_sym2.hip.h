@@ -83,6 +83,7 @@ struct QnS2Args {
     double* xtrace;
     int parity;          // this launch reads ctl2[parity] and writes ctl2[parity ^ 1]
     int nt;              // non-temporal tile accesses on H (past the Infinity Cache)
+    int ntq;             // ... and non-temporal loads of Q's tiles
     // ---- row-sharded runs (SHARD instantiations; qn_sym2sh.hip.h) ----
     int sh_world, sh_rank; // ranks of the run, this rank
     int sh_ioff;           // first block-row this rank stores: tile (I, J) lives at local block-row I - sh_ioff
@@ -496,7 +497,7 @@ __device__ __forceinline__ void qn_s2_eval_vec_load(const QnS2Args& a, const dou
 // row lane >> 2 of the wave's 16).
 // (`diag` is a run-time, wave-uniform flag on purpose: a second instantiation of the row loops per call site made the kernel's code
 // 30 % larger, and every OTHER kernel of the iteration started ~1 us later -- rocprofv3 averages, same box: instruction fetch.)
-template <bool FROM_PARK>
+template <bool FROM_PARK, bool NTQ = false> // NTQ: non-temporal refills (Q past the Infinity Cache: every byte is read once per evaluation)
 __device__ __forceinline__ double qn_s2_eval_item(const QnEvalReq& q, const QnS2EvalVec& v, const bool diag, const int lane, const int wave,
                                                   v2d (&h)[QN_S2_RPW], const v2d* __restrict__ parkw, const double* __restrict__ refill, const size_t rstride,
                                                   double* __restrict__ colred_w, double (&sacc)[4]) {
@@ -524,7 +525,7 @@ __device__ __forceinline__ double qn_s2_eval_item(const QnEvalReq& q, const QnS2
     for (int r = 0; r < QN_S2_RPW; ++r) { // row r of the wave's 16
         v2d hv;
         if (FROM_PARK) hv = parkw[r * 64 + lane];
-        else { hv = h[r]; h[r] = ld2(refill + (size_t)r * rstride); } // the register this row frees takes the same row of the next item at once
+        else { hv = h[r]; h[r] = qn_sym_ld<NTQ>(refill + (size_t)r * rstride); } // the register this row frees takes the same row of the next item at once
         const double xi = qn_lane_bcast(xr, r);
         double t0 = hv.x * xtj.x;
         t0 = __builtin_fma(hv.y, xtj.y, t0);
@@ -610,7 +611,7 @@ __device__ __forceinline__ double qn_s2_eval_sliver(const QnS2SliverVec& v, cons
 // body decides at run time whether there is a second item, a third one, a list to read, a sliver, a parked window; with those
 // five flags known the compiler drops the variants they select between and the register copies at their joins -- the phase
 // behind the workgroup barrier is instruction issue.
-template <bool PAIR, bool SHARD = false>
+template <bool PAIR, bool SHARD = false, bool NTQ = false>
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a) {
     static_assert(!(PAIR && SHARD), "the two-items-and-a-sliver instance is the single-rank n = 4096 one");
     __shared__ QnS2Lds L;
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         const int I = ijw >> 16, J = ijw & 0xffff;
         const double* qb = a.Q + (size_t)(qn_s2_lrow<SHARD>(a, I) * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
 #pragma unroll
-        for (int r = 0; r < QN_S2_RPW; ++r) h[r] = ld2(qb + (size_t)r * np);
+        for (int r = 0; r < QN_S2_RPW; ++r) h[r] = qn_sym_ld<NTQ>(qb + (size_t)r * np);
     };
     if (wave == 0) {
         qn_s2_prologue_w0<QN_S2_EVAL, SHARD>(a, L, vec_spec);
@@ -674,12 +675,12 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         const int r0 = (wave - 1) * 3;
         v2d t3[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) t3[k] = ld2(q0 + (size_t)min(r0 + k, QN_S2_RPW - 1) * np);
+        for (int k = 0; k < 3; ++k) t3[k] = qn_sym_ld<NTQ>(q0 + (size_t)min(r0 + k, QN_S2_RPW - 1) * np);
         QN_S2_STAMP_T(6, 448); // (wave 7: everything requested)
 #pragma unroll
         for (int r = 0; r < QN_S2_RPW; ++r) {
             park[wave][r][lane] = h[r];
-            h[r] = ld2(q1 + (size_t)r * np);
+            h[r] = qn_sym_ld<NTQ>(q1 + (size_t)r * np);
         }
         QN_S2_STAMP_T(7, 448); // (its sixteen rows parked)
 #pragma unroll
@@ -739,8 +740,8 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         QnS2SliverVec slv{};
         double row_a, row_b = 0.0, row_c = 0.0;
         double sacc[4] = {0.0, 0.0, 0.0, 0.0}; // x'(Q xt - 2b), d'(Q xt - b), g'd, #non-finite d: this lane's share over the group's items
-        if (FIRST && parked) row_a = qn_s2_eval_item<true>(q, va, diag_a, lane, wave, h, &park[wave][0][0], nullptr, 0, colred[0][wave], sacc);
-        else row_a = qn_s2_eval_item<false>(q, va, diag_a, lane, wave, h, nullptr, has_b ? tile_ptr(ijb) : (sliver ? slp : tile_ptr(ija)), has_b ? np : 0, colred[0][wave], sacc);
+        if (FIRST && parked) row_a = qn_s2_eval_item<true, NTQ>(q, va, diag_a, lane, wave, h, &park[wave][0][0], nullptr, 0, colred[0][wave], sacc);
+        else row_a = qn_s2_eval_item<false, NTQ>(q, va, diag_a, lane, wave, h, nullptr, has_b ? tile_ptr(ijb) : (sliver ? slp : tile_ptr(ija)), has_b ? np : 0, colred[0][wave], sacc);
         if (FIRST) { qn_keepalive(row_a); QN_S2_STAMP_T(13, 448); }
         if (has_b) {
             qn_s2_eval_vec_load(a, x, sp, Ib * QN_TB + wave * QN_S2_RPW + (lane & 15), Jb * QN_TB + 2 * lane, vb);
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
                 qn_s2_eval_vec_load(a, x, sp, sir, sjc, va);
                 slv = qn_s2_sliver_prep(q, va);
             }
-            row_b = qn_s2_eval_item<false>(q, vb, diag_b, lane, wave, h, nullptr, ijc >= 0 ? tile_ptr(ijc) : (sliver ? slp : tile_ptr(ijb)), ijc >= 0 ? np : 0, colred[1][wave], sacc);
+            row_b = qn_s2_eval_item<false, NTQ>(q, vb, diag_b, lane, wave, h, nullptr, ijc >= 0 ? tile_ptr(ijc) : (sliver ? slp : tile_ptr(ijb)), ijc >= 0 ? np : 0, colred[1][wave], sacc);
         } else if (sliver) {
             unsigned sir = sl.D * QN_TB + sl.row, sjc = sl.D * QN_TB + 2 * lane;
             asm volatile("" : "+v"(sir), "+v"(sjc));
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         // the next item's vector entries go out now: for the item that joins this group, or for the next group while this
         // one's sums are exchanged and stored
         if (ijc >= 0) qn_s2_eval_vec_load(a, x, sp, Ic * QN_TB + wave * QN_S2_RPW + (lane & 15), Jc * QN_TB + 2 * lane, va);
-        if (take_c) row_c = qn_s2_eval_item<false>(q, va, diag_c, lane, wave, h, nullptr, tile_ptr(ijc), 0, colred[2][wave], sacc);
+        if (take_c) row_c = qn_s2_eval_item<false, NTQ>(q, va, diag_c, lane, wave, h, nullptr, tile_ptr(ijc), 0, colred[2][wave], sacc);
         if (FIRST) { qn_keepalive(row_b); QN_S2_STAMP_T(14, 448); }
         double t0s = 0.0;
         if (sliver) t0s = qn_s2_eval_sliver(slv, h[0], sl.row, lane, sacc); // (h[0]: the window holds the sliver's row sixteen times)
