@@ -260,20 +260,24 @@ def main():
     h_bytes, obj_bytes = acc["total_h_bytes"], acc["total_obj_bytes"]
     its = steps / elapsed
 
-    # fixed cost of one qn_minimize call (control-block round trips, enqueue of the launch pattern, any state hand-over): a call
-    # that is allowed zero iterations returns Err(MaxIterReached) from the first loop top (ls_solver.rs:78,109-110)
-    call_ms = []
-    for _ in range(7):
-        barrier()
-        t0 = time.perf_counter()
-        try:
-            solver.minimize(ls, obj, 0, 20)
-        except qn.MaxIterReached:
-            pass
-        ctx.synchronize()
-        call_ms.append(1e3 * (time.perf_counter() - t0))
-    call_ms.sort()
-    per_call_fixed_ms = call_ms[len(call_ms) // 2]
+    # fixed cost of one qn_minimize call (entry, the first launch from an idle queue, the last launch's report, the return): wall time
+    # of warm calls of 4 and of 24 iterations, the same run continued, medians of 7 -- two points of a straight line whose slope is an
+    # iteration and whose intercept is the call.  (Rounds 2-3 timed a call that is allowed 0 iterations: that one enqueues a whole
+    # period of launches which then all find nothing to do -- 0.06 ms, twice what a call costs inside a timed region.)
+    def timed_call(k):
+        ts = []
+        for _ in range(7):
+            solver.reset(x0)
+            run_iterations(qn, solver, ls, obj, x0, 5)
+            barrier()
+            t0 = time.perf_counter()
+            run_iterations(qn, solver, ls, obj, x0, k)
+            ctx.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return 1e3 * ts[len(ts) // 2]
+    t4, t24 = timed_call(4), timed_call(24)
+    per_call_fixed_ms = max(0.0, t4 - 4.0 * (t24 - t4) / 20.0)
 
     # kernel-level roofline: same workload again with every launch bracketed by HIP events on the solver's stream
     roofline = None
@@ -424,8 +428,9 @@ def main():
                        "each_region": f"reset to (x0, H = I), {warmup} untimed iterations, then {steps} timed iterations",
                        "qn_minimize_calls_in_region": acc["total_minimize_calls"],
                        "per_call_fixed_ms": per_call_fixed_ms,
-                       "per_call_fixed_note": "median wall time of a qn_minimize call allowed 0 iterations (control block round trips + "
-                                              "launch pattern); it is inside every timed region once per call"},
+                       "per_call_fixed_note": "intercept of the line through the median wall times of warm calls of 4 and of 24 iterations "
+                                              "(entry, first launch from an idle queue, the last launch's report to the host, return); "
+                                              "it is inside every timed region once per call"},
             "iteration_accounting": {"oracle_calls_reference_sequence": calls, "oracle_evaluations_distinct": evals,
                                      "evaluations_per_iteration": evals / steps, "oracle_calls_per_iteration": calls / steps,
                                      "h_passes": acc["total_h_passes"],

@@ -844,6 +844,9 @@ struct qn_solver {
     int fused_nblk = 0;
     QnCtl* ctl = nullptr;  // device
     QnCtl* hctl = nullptr; // pinned host mirror
+    QnCtl* hrep = nullptr; // pinned: the control block as the last launch of a sym2 batch left it (written by the device)
+    unsigned long long* hrep_flag = nullptr;
+    unsigned long long rep_seq = 0;
     double *hx = nullptr, *hg = nullptr; // pinned staging for host oracles
     size_t trace_cap = 0;
     int trace_x = 0;
@@ -1133,8 +1136,10 @@ extern "C" int qn_solver_create(qn_context* ctx, int method, double tol, const d
     HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(QnCtl), st));
     // (mapped + coherent, explicitly: s2_ctl_upload_kernel reads the mirror from the device, call after call -- with a non-coherent
     // mapping the second call could be served a stale line from L2)
-    HIPCHK(hipHostMalloc((void**)&s->hctl, sizeof(QnCtl), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(s->hctl, 0, sizeof(QnCtl));
+    HIPCHK(hipHostMalloc((void**)&s->hctl, 2 * sizeof(QnCtl) + 64, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(s->hctl, 0, 2 * sizeof(QnCtl) + 64);
+    s->hrep = s->hctl + 1;                                                    // what a batch's last launch reports (QnS2Args.rep)
+    s->hrep_flag = reinterpret_cast<unsigned long long*>(s->hctl + 2);        // ... and the sequence number it stores behind it
     HIPCHK(hipHostMalloc((void**)&s->hx, n * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&s->hg, (n + 1) * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipMemcpyAsync(s->V.x, x0_host, n * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1703,6 +1708,7 @@ struct Run {
     bool sym2 = false;        // second-generation symmetric path (qn_sym2.hip.h)
     QnS2Args s2{};
     uint64_t s2_launches = 0; // parity of the control-block double buffer = launches so far & 1
+    unsigned long long report_seq = 0; // != 0: the next launch reports its control block to the host (s2_wait_report)
 };
 
 static int s2_launch(Run& r, int kind) {
@@ -1710,6 +1716,9 @@ static int s2_launch(Run& r, int kind) {
     hipStream_t st = s->ctx->stream;
     QnS2Args a = r.s2;
     a.parity = (int)(r.s2_launches & 1);
+    a.ctl_first = r.s2_launches == 0 ? s->hctl : nullptr; // (the first launch of a call takes the control block from the pinned mirror)
+    a.rep = s->hrep; a.rep_flag = s->hrep_flag; a.rep_seq = r.report_seq;
+    r.report_seq = 0;
 #ifdef QN_S2_STAMPS
     a.dbg = s->V.dbg; a.slot = (int)r.s2_launches;
 #endif
@@ -1821,6 +1830,26 @@ static int s2_do_hpass(Run& r, bool tiles) {
         else QNCHK(exchange(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
     }
     return s2_launch(r, QN_S2_HREDUCE);
+}
+
+// The control block of the launch that was told to report (Run.report_seq) -> host mirror, without synchronising the stream: the
+// launch stores the block and then the sequence number into pinned memory, the host spins on the number.  (Round 3 copied the block
+// back with hipMemcpyAsync + hipStreamSynchronize: a copy-engine transfer and an interrupt-driven wake-up at the end of every call,
+// ~25 us of the 64 us a call cost beyond its iterations.)
+static int s2_wait_report(Run& r, unsigned long long seq) {
+    qn_solver* s = r.s;
+    volatile unsigned long long* flag = s->hrep_flag;
+    for (uint64_t spins = 0;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 0xfff) == 0xfff) { // the stream has drained and nothing reported: a launch failed
+            hipError_t e = hipStreamQuery(s->ctx->stream);
+            if (e == hipSuccess) { if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break; return fail(QN_ABNORMAL_TERMINATION, "sym2: the batch ended without a report"); }
+            if (e != hipErrorNotReady) return fail(QN_ABNORMAL_TERMINATION, std::string("sym2 batch: ") + hipGetErrorString(e));
+        }
+    }
+    memcpy(s->hctl, s->hrep, sizeof(QnCtl));
+    s->stats.host_syncs++;
+    return QN_OK;
 }
 
 static int launch_ctl_mask(Run& r, int expect_mask) {
@@ -2429,12 +2458,10 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.ntq = q_stream >= ((size_t)400 << 20);
         if (getenv("QN_S2_NT")) a.nt = atoi(getenv("QN_S2_NT"));    // (diagnostics: tools/README.md)
         if (getenv("QN_S2_NTQ")) a.ntq = atoi(getenv("QN_S2_NTQ"));
-        // (no synchronisation: the copy is stream-ordered in front of the launches, the mirror is pinned, and the host does not
-        // write it again before s2_peek has synchronised)
-        // (a one-workgroup launch that reads the pinned mirror, not hipMemcpyAsync: the copy path put ~8 us in front of the first
-        // kernel of every call -- 0.6 % of the driver's 20-step region)
-        hipLaunchKernelGGL(s2_ctl_upload_kernel, dim3(1), dim3(256), 0, c->stream, s->hctl, s->s2_ctl);
-        HIPCHK(hipGetLastError());
+        // (nothing is uploaded here: the FIRST launch of the call reads the control block from the pinned, device-mapped mirror
+        // itself -- QnS2Args.ctl_first.  Round 3 went from hipMemcpyAsync (~8 us in front of the first kernel of every call) to a
+        // one-workgroup upload launch (~4 us); now there is neither.  The host does not write the mirror again before the batch's
+        // last launch has reported, or s2_peek has synchronised.)
     } else {
         QNCHK(poke_ctl(s));
     }
@@ -2469,9 +2496,10 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             if (r.s2.sh_world > 1) slots = s->s2_slots_hint ? s->s2_slots_hint : 2;
             bool first = true;
             uint64_t ev0 = 0, it0 = 0;
+            unsigned long long seq = 0;
             for (;;) {
                 if (!first) {
-                    QNCHK(s2_peek(r));
+                    QNCHK(s2_wait_report(r, seq));
                     if (r.s2.sh_world > 1 && h->n_iterations > it0) { // evaluations per iteration of the batch just run, rounded up
                         const uint64_t di = h->n_iterations - it0;
                         uint64_t de = h->n_oracle_evals - ev0;
@@ -2493,6 +2521,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                     if (!r.s2.fold) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise)
                     QNCHK(s2_do_hpass(r, true));
                 }
+                seq = r.report_seq = ++s->rep_seq; // (the batch's last launch reports: the evaluation launch below)
                 QNCHK(s2_do_eval(r));
             }
         }

@@ -82,6 +82,11 @@ struct QnS2Args {
     QnTraceRec* trace;
     double* xtrace;
     int parity;          // this launch reads ctl2[parity] and writes ctl2[parity ^ 1]
+    // the two ends of a qn_minimize call, without a copy-engine transfer or a launch of their own (round 4: per-call cost):
+    const QnCtl* ctl_first; // the FIRST launch of a call reads the control block from the host's pinned, device-mapped mirror (null otherwise)
+    QnCtl* rep;             // the LAST launch of an enqueued batch also stores the control block it hands on into pinned host memory, ...
+    unsigned long long* rep_flag; // ... then this sequence number behind it (system-scope release): the host spins on the flag instead of
+    unsigned long long rep_seq;   //     synchronising the stream and copying the block back (0: this launch does not report)
     int nt;              // non-temporal tile accesses on H (past the Infinity Cache)
     int ntq;             // ... and non-temporal loads of Q's tiles
     // ---- row-sharded runs (SHARD instantiations; qn_sym2sh.hip.h) ----
@@ -216,7 +221,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     constexpr int NW = (int)(sizeof(QnCtl) / 8);
     static_assert(NW <= 128, "control block too large for two words per lane");
     __builtin_amdgcn_s_setprio(3); // the workgroup waits for this wave: its instructions go first on the SIMD it shares
-    const uint64_t* cin = reinterpret_cast<const uint64_t*>(a.ctl2 + a.parity);
+    const uint64_t* cin = reinterpret_cast<const uint64_t*>(a.ctl_first ? a.ctl_first : a.ctl2 + a.parity);
     uint64_t* lc = reinterpret_cast<uint64_t*>(&L.c);
     uint64_t cw0 = 0, cw1 = 0;
     if (lane < NW) cw0 = cin[lane];
@@ -357,10 +362,19 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
 }
 
 // after the workgroup barrier that follows the prologue: workgroup 0 hands the control block to the next launch
+// (called by every thread of the workgroup, from uniform control flow: the reporting branch holds a barrier)
 __device__ __forceinline__ void qn_s2_ctl_out(const QnS2Args& a, const QnS2Lds& L) {
     constexpr int NW = (int)(sizeof(QnCtl) / 8);
     if (blockIdx.x == 0 && threadIdx.x < NW)
         reinterpret_cast<uint64_t*>(a.ctl2 + (a.parity ^ 1))[threadIdx.x] = reinterpret_cast<const uint64_t*>(&L.c)[threadIdx.x];
+    if (a.rep_seq != 0 && blockIdx.x == 0) { // (uniform) the batch's last launch: the host is waiting for this block
+        if (threadIdx.x < NW) {
+            reinterpret_cast<uint64_t*>(a.rep)[threadIdx.x] = reinterpret_cast<const uint64_t*>(&L.c)[threadIdx.x];
+            __threadfence_system();
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.rep_flag, a.rep_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // the evaluation request as the tile and the accept-reduce kernels decode it
@@ -1347,12 +1361,6 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
     }
     __syncthreads();
     if (tid < 2) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = bred[0][tid] + bred[1][tid];
-}
-
-// the host's control block (pinned memory) -> ctl2[0]: a launch instead of a copy-engine transfer in front of the first kernel
-__global__ __launch_bounds__(256) void s2_ctl_upload_kernel(const QnCtl* __restrict__ host_ctl, QnCtl* __restrict__ dev_ctl) {
-    constexpr int NW = (int)(sizeof(QnCtl) / 8);
-    if ((int)threadIdx.x < NW) reinterpret_cast<uint64_t*>(dev_ctl)[threadIdx.x] = reinterpret_cast<const uint64_t*>(host_ctl)[threadIdx.x];
 }
 
 // synchronous mode: the prologue alone (one workgroup)
