@@ -621,6 +621,19 @@ __device__ __forceinline__ double qn_s2_eval_sliver(const QnS2SliverVec& v, cons
     return t0; // this lane's share of the row's total: folded with the group's scalars (value 6 of the group fold)
 }
 
+// Measured and dropped, round 4 (n = 4096, rocprofv3 averages of three alternating runs per build on one box): the request
+// PREDICTED by the waves that stream.  In the two transitions of a benchmark iteration the request is a short function of scalars
+// -- after an update pass: t = 1 and the direction's coefficients from y's, y'u, u'g+, s'g+; after a rejected trial: More-Thuente's
+// interpolated step with phi(t_l) from the memo -- so waves 1..7 computed it themselves (the control block by scalar loads, the
+// table's totals published in LDS by wave 0 3-4 us in, the machine's own functions), multiplied their rows out of the register
+// window as they arrived (each row copied to the park in case the prediction was wrong), and compared with the machine's request
+// at the group's exchange: equal field for field in all 256 workgroups of every launch, results bit-identical.  But the kernel got
+// SLOWER: 16.2-16.3 us against 15.5 (and 14.4 k against 14.9 k it/s).  In-kernel stamps say why: a wave that has filled its share of
+// the CU's memory queue is held at its next request until the queue drains -- the prediction, wherever it is placed behind the
+// first twelve row requests, is reached 6.1-7.0 us after entry, when the machine is done anyway -- and rows that are multiplied
+// between the requests hold back the refills of the second item, whose last byte then arrives later than with the parking
+// loop, which keeps the queue full until 7 us.  What the waves cannot do is request and multiply at the same time; that would
+// take producer and consumer waves of their own and a park for both items (LDS holds one).
 // PAIR: every workgroup has exactly two list items and one row sliver (n = 4096 on 256 workgroups: QnS2Args.pair).  The general
 // body decides at run time whether there is a second item, a third one, a list to read, a sliver, a parked window; with those
 // five flags known the compiler drops the variants they select between and the register copies at their joins -- the phase
