@@ -809,6 +809,7 @@ struct qn_solver {
     double* s2_evS = nullptr;   // row-sharded: [2][world][QN_S2SH_NEC][QN_S2_MAXG] the ranks' evaluation scalars, by launch parity (QnS2Args.evS)
     int *s2_sl_off = nullptr, *s2_sl_idx = nullptr; // row-sharded: per block-row, the slots this rank's tiles write (QnS2Args.sl_off / sl_idx)
     int s2_sl_nb = 0;
+    bool h_placed = false;      // H's placement has been measured (place_h)
     int* symsh_tiles = nullptr; // row-sharded, first-generation kernels: this rank's tiles in launch order (QnSymShard.tiles)
     int s2_slots_hint = 0;      // row-sharded, pipelined: evaluation launches (each followed by a collective) enqueued per period
     double* s2_partE = nullptr; // [nb][nb][128]: row / column slots of the last evaluation (QnS2Args.partE)
@@ -1852,6 +1853,73 @@ static int s2_wait_report(Run& r, unsigned long long seq) {
     return QN_OK;
 }
 
+// Where the inverse Hessian lives decides how fast the update pass runs on it while it is Infinity-Cache resident (qn_sym2.hip.h,
+// PLACEMENT PROBE: one H in eight is 18 % slower for as long as it lives).  Probes that only move H's bytes do not see it, so the
+// probe is the update kernel ITSELF: a direction pass with no update pending (H + 0: every tile read, written back with the
+// values it had, slots into the scratch buffer) on the solver's H and on a second allocation -- a third one when the two differ,
+// to know which was the odd one -- and H moves to the best.  Once per solver, at its first run on the second-generation path;
+// ~1 ms, up to three times H's size for that long; QN_H_PLACEMENT=0 switches it off, =2 prints what it measured.
+static int place_h(Run& r) {
+    qn_solver* s = r.s;
+    if (s->h_placed) return QN_OK;
+    s->h_placed = true;
+    const size_t np = s->T.n_pad, bytes = (size_t)s->T.rpr * np * sizeof(double);
+    const char* sw = getenv("QN_H_PLACEMENT");
+    if ((sw && atoi(sw) == 0) || s->ctx->world != 1 || bytes > ((size_t)160 << 20) || r.s2.fold) return QN_OK; // (larger H: streamed from HBM anyway)
+    hipStream_t st = s->ctx->stream;
+    // the request: a direction pass (one right-hand side, g in both places), nothing pending; the vectors it multiplies are whatever
+    // the fused buffers hold (zeros before the first run) -- only the duration matters, and H comes back as it was
+    QnCtl* pc = s->hrep; // (pinned, device-mapped; the report area is free between calls)
+    memcpy(pc, s->hctl, sizeof(QnCtl));
+    pc->phase = QN_PH_REQ_HPASS; pc->serviced = 0; pc->hp_nrhs = 1; pc->pending = 0; pc->after_state = QN_ST_AFTER_DIR; pc->sym2 = 1; pc->fused = 1;
+    pc->spec_tiles = 0; pc->sc = 0; pc->xc = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    auto time_on = [&](double* H, float* out_us) -> int {
+        QnS2Args a = r.s2;
+        a.H = H; a.parity = 0; a.ctl_first = pc; a.rep_seq = 0;
+        float t[6];
+        for (int rep = 0; rep < 6; ++rep) {
+            HIPCHK(hipEventRecord(e0, st));
+            if (s->method == QN_BFGS) hipLaunchKernelGGL((s2_hpass_kernel<false, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            HIPCHK(hipEventRecord(e1, st));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            t[rep] = ms * 1e3f;
+        }
+        std::sort(t + 2, t + 6); // (the first two repetitions bring the tiles in)
+        *out_us = t[3];
+        return QN_OK;
+    };
+    double* cand[3] = {s->H, nullptr, nullptr};
+    float us[3] = {0.f, 0.f, 0.f};
+    int ncand = 1, keep = 0;
+    int status = time_on(cand[0], &us[0]);
+    for (int k = 1; k < 3 && status == QN_OK; ++k) {
+        if (k == 2 && std::fabs(us[0] - us[1]) <= 0.06f * std::min(us[0], us[1])) break; // the two agree: both are the common case
+        if (hipMalloc((void**)&cand[k], bytes) != hipSuccess) { (void)hipGetLastError(); cand[k] = nullptr; break; } // (no room: keep what there is)
+        ++ncand;
+        if (hipMemcpyAsync(cand[k], s->H, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { status = fail(QN_ABNORMAL_TERMINATION, "H placement: copy failed"); break; }
+        status = time_on(cand[k], &us[k]);
+    }
+    if (status == QN_OK)
+        for (int k = 1; k < ncand; ++k)
+            if (us[k] < 0.96f * us[keep]) keep = k; // (the one it has, unless another is clearly better)
+    if (sw && atoi(sw) == 2) fprintf(stderr, "[qn] H placement: %d candidates, update kernel %.2f %.2f %.2f us, kept %d\n", ncand, us[0], us[1], us[2], keep);
+    (void)hipStreamSynchronize(st);
+    for (int k = 0; k < ncand; ++k)
+        if (k != keep && cand[k]) (void)hipFree(cand[k]);
+    s->H = cand[keep];
+    s->V.H = s->H;
+    r.s2.H = s->H;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return status;
+}
+
 static int launch_ctl_mask(Run& r, int expect_mask) {
     qn_solver* s = r.s;
     ProfScope ps(s, KC_CTL);
@@ -2471,6 +2539,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     const bool sync = s->method == QN_NEWTON || s->sync_mode == 1 || (s->sync_mode == -1 && !(can_pipeline && o->memoize)) || !can_pipeline;
 
     int status = QN_ABNORMAL_TERMINATION;
+    if (r.sym2) QNCHK(place_h(r)); // (once per solver: H where the update kernel runs fastest)
     if (r.sym2) {
         if (sync) { // one request at a time: [service launch(es), advance], the host reads the control block in between
             QNCHK(s2_launch(r, QN_S2_ADVANCE));

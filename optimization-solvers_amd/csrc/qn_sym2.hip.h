@@ -1376,6 +1376,48 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
     if (tid < 2) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = bred[0][tid] + bred[1][tid];
 }
 
+// PLACEMENT PROBE (round 4).  At n = 4096 about one inverse Hessian in eight runs the update kernel at 29.7 us instead of 25.2 for
+// as long as it lives.  What the measurements say:
+//   * it is a property of the ALLOCATION, not of the process (tools/slow_mode_probe.py: several solvers in one process, each with
+//     an H of its own -- one slow one among fast ones, while the evaluation kernel on the process's one Q never changes);
+//   * it is decided behind the L2 (tools/slow_mode_pmc.sh, profiles/r04_c_slow_mode_pmc_per_solver.txt): a slow H has no
+//     translation misses (TCP_UTCL1_TRANSLATION_MISS = 0 in both modes), the same requests to the fabric (TCC_EA0_RDREQ / WRREQ
+//     equal to 0.02 %) and the same L2 hit count to 2 % -- the same 70 MB of reads and 70 MB of writes are served more slowly by
+//     what lies behind the fabric, and no counter of this tool chain looks there;
+//   * it is an INTERACTION: a pass over H alone runs equally fast on a slow and on a fast allocation (first version of this
+//     probe: 21.8 us on every candidate, and slow solvers all the same).  The Infinity Cache holds H's half and Q's half side by
+//     side (2 x 67 MB of 256); where H sits relative to Q decides how much of H the two evaluations of an iteration leave there.
+// So the library measures the pattern itself: with the objective in hand (the first run on the fast path) it times the update
+// pass's bytes -- every workgroup its first two list items of H, read into the 16-row window and written back -- BEHIND two reads
+// of Q's half in the same shape, on the solver's H and on a second allocation, a third one when they differ, and moves H to the
+// best (qn_hip.hip, place_h).
+template <bool WRITE>
+__global__ __launch_bounds__(QN_S2_TPB, 2) void s2_place_probe_kernel(double* __restrict__ M, const int nb, const int np_, const int G, double* __restrict__ sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t np = (size_t)np_;
+    const int nitems = nb * (nb + 1) / 2;
+    double acc = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+        const int t = k * G + (int)blockIdx.x;
+        if (t >= nitems) break;
+        const int ij = qn_s2_item_of_index(t, nb);
+        const int I = ij >> 16, J = ij & 0xffff;
+        double* hb = M + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + 2 * lane;
+        v2d h[QN_S2_RPW];
+#pragma unroll
+        for (int r = 0; r < QN_S2_RPW; ++r) h[r] = ld2(hb + (size_t)r * np);
+#pragma unroll
+        for (int r = 0; r < QN_S2_RPW; ++r) {
+            if (WRITE) {
+                asm volatile("" : "+v"(h[r])); // (opaque: a store of the value just loaded from the same address is a store the compiler may drop)
+                st2(hb + (size_t)r * np, h[r]);
+            } else acc += h[r].x + h[r].y;
+        }
+    }
+    if (!WRITE && acc == 12345.678) sink[blockIdx.x] = acc; // (keeps the loads)
+}
+
 // synchronous mode: the prologue alone (one workgroup)
 template <bool SHARD = false>
 __global__ __launch_bounds__(128) void s2_advance_kernel(const QnS2Args a) {
