@@ -907,18 +907,27 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     QN_S2_STAMP(0);
     // (wave 0 requests its share of the slots behind the control block and the table, BEFORE it runs the machine: requested after
     // it -- 3.5 us into a 6 us kernel -- they were what the slot sums waited for)
-    if (SHARD) { if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC, true>(a, L); }
-    else if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC>(a, L, [&]() { qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0); });
-    else qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0);
+    // ... and so do the vector entries of the block's rows (threads 0..127), for both settings of the two buffer toggles the control
+    // block holds: requested behind the barrier they were a memory round trip between the machine's answer and the arithmetic
+    // (round 4: 0.7 us of a 7.5 us kernel whose critical path is the machine).
+    const size_t np = (size_t)a.np;
+    double e_x0 = 0.0, e_x1 = 0.0, e_v = 0.0, e_s0 = 0.0, e_s1 = 0.0, e_u = 0.0, e_b = 0.0, e_g = 0.0;
+    auto entries = [&]() {
+        if (tid < QN_TB) {
+            const int gi = R * QN_TB + tid;
+            e_x0 = a.F.X0[gi]; e_x1 = a.F.X0[np + gi]; e_v = a.F.VV[gi]; e_s0 = a.F.S0[gi]; e_s1 = a.F.S0[np + gi];
+            e_u = a.F.UN[gi]; e_b = a.F.b[gi]; e_g = a.F.G[gi];
+        }
+    };
+    if (SHARD) { if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC, true>(a, L, entries); else entries(); }
+    else if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC>(a, L, [&]() { qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0); entries(); });
+    else { qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0); entries(); }
     __syncthreads();
     QN_S2_STAMP(2);
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
-    const size_t np = (size_t)a.np;
     const QnEvalReq q = qn_s2_eval_req<false>(L.c, true);
-    const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
     double* __restrict__ xt = a.F.X0 + (size_t)(1 - q.xc) * np;
-    const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
     double* __restrict__ sstage = a.F.S0 + (size_t)(1 - q.sc) * np;
     double qi = 0.0;
     if (!SHARD) qi = qn_s2_slot_sum<1>(a.partE, a.nb, R, 0, S0, qbuf);
@@ -933,9 +942,9 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     if (tid < QN_TB) {
         const int gi = R * QN_TB + tid;
         double di;
-        const double xi = x[gi];
-        const double xti = qn_s2_trial(q, xi, a.F.VV[gi], sp[gi], a.F.UN[gi], di);
-        const double bi = a.F.b[gi], go = a.F.G[gi];
+        const double xi = q.xc ? e_x1 : e_x0;
+        const double xti = qn_s2_trial(q, xi, e_v, q.sc ? e_s1 : e_s0, e_u, di);
+        const double bi = e_b, go = e_g;
         const double gti = qi - bi;
         const double yi = gti - go;
         const double si = xti - xi; // s = x+ - x, not t d (bfgs.rs:96)
