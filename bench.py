@@ -416,8 +416,8 @@ def main():
                 roofline["quad_matvec"]["traffic"] = rec.get("quad_eval_bytes_per_launch")
                 if roofline["traffic"] is not None:
                     roofline["traffic_source"] = (f"profiles/pmc_traffic.json[{key}]: HBM bytes per launch from separate rocprofv3 --pmc "
-                                                  "FETCH_SIZE / WRITE_SIZE passes of this build (gfx950 x2 correction on FETCH_SIZE); an "
-                                                  "offline figure, not a counter read during this run")
+                                                  "FETCH_SIZE / WRITE_SIZE passes (gfx950 x2 correction on FETCH_SIZE); an offline figure, "
+                                                  "not a counter read during this run; recorded on: " + str(rec.get("build", "an earlier build")))
             except Exception:  # noqa: BLE001
                 pass
 
