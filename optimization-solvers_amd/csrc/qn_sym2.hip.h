@@ -1077,6 +1077,13 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
     // straight-line copies of the row loop: 22.9-23.0 against 23.1-23.8 us, and the small kernels 0.1-0.2 us slower: dropped.
     // Also without effect on this kernel: the BFGS update as s q' + q s' with q = c_su u + (c_ss / 2) s (eight VALU instructions
     // fewer per row, still bitwise symmetric), and an instance for exactly two items and a sliver.)
+    // Measured and dropped, round 4: a SPECULATIVE START -- when the launch follows the accept-reduce, everything this pass needs
+    // (g+, y, the pending update's s, u and coefficients) is in the control block as the previous launch left it, so waves 1..7
+    // went from their requests straight into the row loop, wave 0 followed when the machine was done, no barrier in between
+    // (bookkeeping: the folded accept-reduce's spec_tiles).  Bit-identical, 124 GPU tests green -- and 23.4 us against 23.7: the
+    // in-kernel stamps did not move (wave 7 through the first item at 13.1 us with and without the barrier at 5.8).  This kernel is
+    // bound by what a CU's memory pipeline takes: 256 KB read + 256 KB written + a sliver at ~29 KB/us is 18.3 us, which is when
+    // the median workgroup ends; the barrier was never what the rows waited for.
     v2d h[QN_S2_RPW]; // the wave's 16 rows of the first item go out before the control block is known
     double* hbase = a.H + (size_t)(qn_s2_lrow<SHARD>(a, I) * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, lane, wave);
     if (wave != 0) {
