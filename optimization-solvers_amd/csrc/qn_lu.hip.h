@@ -103,8 +103,14 @@ __global__ __launch_bounds__(256) void lu_col_step_kernel(double* __restrict__ W
 // Where the time goes (rocprofv3 + in-kernel stamps, n = 8192, one factorisation = 67 ms with its two solves): the 2176 step
 // launches 39.8 ms -- role A is ONE CU working through a dependent chain: ~2.5 us per pivot step at 16 rows per thread (search
 // 1.3, exchange 0.3, elimination 0.8: instruction issue, not memory), 4.6 us of launch and flag read, and its 768 KB of column
-// traffic at a single CU's rate; the rank-64 MFMA updates 12.4 ms (HBM-bound: each re-reads and re-writes the trailing matrix,
-// 46 GB in all -- a 128-column panel would halve it); triangular solve of U12 4.5 ms; the two vector solves 6 ms.
+// traffic at a single CU's rate; the rank-64 MFMA updates 12.4 ms; triangular solve of U12 4.5 ms; the two vector solves 6 ms.
+// Round 4, measured and dropped: TWO-LEVEL BLOCKING -- panels applied only inside an outer block of 256 columns, the columns right
+// of it given the block row by block substitution and ONE update of depth 256 (a quarter of the 46 GB the rank-64 updates move,
+// which round 3 took for their bound).  Correct (30 Newton tests green), and 66.0 ms against 65-67: the updates went from 12.4 to
+// 10.2 ms only -- they are MFMA-bound (3.7e11 flop per factorisation at the 47.8 TFLOP/s a pure f64 MFMA loop sustains here: 7.7
+// ms), not HBM-bound -- while the block substitution added 92 launches of the U12 solve, whose one thread per column takes 35 us
+// whatever the width (4.5 -> 7.6 ms).  What would pay is that solve on the matrix cores (the 64 x 64 unit-lower inverse once per
+// panel, then a product) and the vector solves in fewer, wider steps; the chain of step launches (39 ms) is untouched by either.
 // ------------------------------------------------------------------------------------------------
 #define QN_LU_SUB 4
 #define QN_LU_PT 512
