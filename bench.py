@@ -8,8 +8,9 @@ One "step" = one BFGS iteration (direction, More-Thuente line search, rank-2 inv
 device-resident objective f = 1/2 x'Qx - b'x; Q, H, and every vector are in HBM before the timed region.
 N = 1 runs BASELINE.json configs[1] (n = 4096; one rank streams only the symmetric half of H and Q);
 N > 1 runs configs[2]'s problem (n = 32768) with the rows of H and Q sharded over the N ranks; every rank streams the circulant
-half of its own block-rows (symmetric storage, as on one GPU) and one RCCL all-gather per mat-vec pass collects the ranks'
-partial n-vectors ("scaling": "strong" over N = 2,4,8).
+half of its own block-rows (symmetric storage, the same kernels as on one GPU); per iteration the ranks exchange 8 KB of scalars
+per evaluation and the partial n-vectors of the accepted point and of the update pass over RCCL ("scaling": "strong" over
+N = 2,4,8).  If RCCL cannot be brought up the line carries no value and the run fails: nothing else is a measurement.
 Timing: 5 regions, each = reset to (x0, H = I), W untimed warm-up iterations, exactly K timed iterations
 between barrier + synchronize brackets, max over ranks; the MEDIAN region is reported (all five are in `timing.region_ms`).
 Prints ONE JSON line on rank 0.  The product path is libqn_hip.so (hand-written gfx950 kernels); the CPU
@@ -440,7 +441,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BFGS + MoreThuente::default (max_iter_line_search 20), n={n} convex quadratic "
                                    f"(random SPD Q, kappa=1e3, seed 0x5EED0001), f64, {world}xMI355X"
-                                   + ((", H and Q row-sharded, " + ("host-staged" if host_exchange else "RCCL") + " all-gather per pass") if world > 1 else "")
+                                   + ((", H and Q row-sharded, " + ("host-staged" if host_exchange else "RCCL") + " exchanges (per iteration: 8 KB of scalars per "
+                                       "evaluation, the partial n-vectors of the accepted point and of the update pass)") if world > 1 else "")
                                    + (", symmetric storage: only the symmetric half of H and Q is streamed" if symmetric else ""),
                        "matrix_layout": ("symmetric half of H and Q: 128 x 128 tiles above the diagonal + the upper triangles of the diagonal tiles"
                                          if (symmetric and world == 1) else
