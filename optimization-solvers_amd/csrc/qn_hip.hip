@@ -2510,20 +2510,23 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         // pass (or none yet) may have left their lower sub-blocks behind -- restore them once
         if (a.sl_per && !s->h_sliver_whole) { QNCHK(ensure_full_h(s)); s->h_sliver_whole = true; }
         a.trace = s->V.trace; a.xtrace = s->V.xtrace;
-        a.nt = s->T.n_pad >= 8192; // H past the Infinity Cache: every byte is touched once per pass
         a.sh_world = c->world; a.sh_rank = c->rank; a.sh_ioff = c->rank * (s->T.rpr / QN_TB);
         a.sh_nsum = c->use_allreduce ? 1 : c->world;
         a.evS = s->s2_evS; a.xg = s->symsh_xg; a.sl_off = s->s2_sl_off; a.sl_idx = s->s2_sl_idx;
-        if (c->world > 1) { // the rank streams half of ITS rows: that share decides whether H passes through the Infinity Cache
-            a.fold = 0; a.pair = 0;
-            a.nt = ((size_t)s->T.rpr * s->T.n_pad * 8 / 2) >= ((size_t)64 << 20);
-        }
-        // Q's tiles with non-temporal loads once an evaluation streams well past the Infinity Cache (256 MB).  Measured (round 4,
-        // tools/stream_shape_probe.hip: a plain read of 537 MB in this launch shape runs at 6.1-6.3 TB/s, non-temporal at 6.5-6.85;
-        // bench.py same box): n = 32768 on one GPU 723 -> 662 us per evaluation (6.49 TB/s), 327 -> 341 it/s; one rank of the
-        // P = 8 partition 114 -> 103 us; n = 8192 (268 MB per evaluation: the cache still holds part of it) no gain -- plain there.
-        const size_t q_stream = c->world > 1 ? (size_t)s->T.rpr * s->T.n_pad * 8 / 2 : (size_t)s->T.n_pad * s->T.n_pad * 8 / 2;
-        a.ntq = q_stream >= ((size_t)400 << 20);
+        if (c->world > 1) { a.fold = 0; a.pair = 0; }
+        // WHO GETS THE INFINITY CACHE (256 MB).  Per iteration a rank streams its half of Q twice (read) and its half of H once
+        // (read + written); non-temporal accesses pass the cache by.  Measured (round 4, bench.py same box, it/s for the policies
+        // H plain / Q plain, H plain / Q non-temporal, H non-temporal / Q plain, both non-temporal):
+        //     n =  4096 (2 x  67 MB): both plain (known since round 1)          n =  5120 (2 x 105 MB): 10 101   9 905   9 473   9 188
+        //     n =  6144 (2 x 151 MB):  7 624  *8 020*  7 676   7 421            n =  8192 (2 x 268 MB):  4 262  *4 860*  4 756   4 656
+        //     n = 10240 (2 x 419 MB):  2 738   2 962   2 941  *3 101*           n = 12288 (2 x 604 MB):  2 017   2 122   2 166  *2 271*
+        // While both halves fit, everything stays plain; when they do not, H is the better tenant (its bytes are touched twice per
+        // pass) and Q is streamed past it -- until H's half alone is well over the cache's size, where nothing is worth keeping.
+        // tools/stream_shape_probe.hip has the ceilings (a plain read 6.1-6.3 TB/s, non-temporal 6.5-6.85; read + write 5.2 / 5.5-5.6).
+        const size_t half = c->world > 1 ? (size_t)s->T.rpr * s->T.n_pad * 8 / 2 : (size_t)s->T.n_pad * s->T.n_pad * 8 / 2;
+        if (2 * half <= ((size_t)230 << 20)) { a.nt = 0; a.ntq = 0; }
+        else if (half <= ((size_t)320 << 20)) { a.nt = 0; a.ntq = 1; }
+        else { a.nt = 1; a.ntq = 1; }
         if (getenv("QN_S2_NT")) a.nt = atoi(getenv("QN_S2_NT"));    // (diagnostics: tools/README.md)
         if (getenv("QN_S2_NTQ")) a.ntq = atoi(getenv("QN_S2_NTQ"));
         // (nothing is uploaded here: the FIRST launch of the call reads the control block from the pinned, device-mapped mirror
