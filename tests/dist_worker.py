@@ -333,6 +333,26 @@ def main():
             case["pipelined_path"] = [s_sync.stats()["path"], s_pipe.stats()["path"]]
             case["pipelined_equal"] = bool(s_sync.trace()[0] == s_pipe.trace()[0] and np.array_equal(s_sync.trace()[1], s_pipe.trace()[1]))
             case["pipelined_syncs"] = [s_sync.stats()["host_syncs"], s_pipe.stats()["host_syncs"]]
+            # ... with a line search whose evaluations per iteration vary (backtracking from a scaled-down H: several halvings at
+            # first, one evaluation later): the pipelined pattern is sized to what the run needs and iterations roll over into the
+            # next period when it is too short -- the same bits as the synchronous pump, and as many collectives as it enqueues
+            bt = {}
+            for asyn in (False, True):
+                ctx.set_host_exchange_async(asyn)
+                sb = qn.DFP(1e-10, x0, ctx=ctx)
+                sb.set_approx_inv_hessian(8.0 * np.eye(n))
+                sb.set_trace(iters, with_x=True)
+                try:
+                    sb.minimize(qn.BackTracking(1e-4, 0.5), obj, iters, 20)
+                except qn.MaxIterReached:
+                    pass
+                stb = sb.stats()
+                bt[asyn] = (sb.trace(), stb["path"], stb["oracle_evals"], stb["total_xchg_scalar"], stb["total_xchg_vector"])
+            case["bt_pipelined_equal"] = bool(bt[False][0][0] == bt[True][0][0] and np.array_equal(bt[False][0][1], bt[True][0][1]))
+            case["bt_paths"] = [bt[False][1], bt[True][1]]
+            case["bt_evals"] = [bt[False][2], bt[True][2]]
+            case["bt_xchg"] = [[bt[False][3], bt[False][4]], [bt[True][3], bt[True][4]]]
+            case["bt_evals_per_iteration_max"] = max(r_["n_evals"] for r_ in bt[False][0][0])
             # ... and on the row kernels (grouped exchanges)
             outs = []
             for asyn in (False, True):

@@ -62,6 +62,12 @@ def _check_sharded_symmetric(res, nproc):
             assert not case["pipelined_path"][0] & 8 and case["pipelined_path"][1] & 8 and case["pipelined_path"][1] & 2
             assert not case["rows_pipelined_path"][0] & 8 and case["rows_pipelined_path"][1] & 8
             assert case["pipelined_syncs"][1] * 4 < case["pipelined_syncs"][0]  # (the control-block reads; the exchanges' own waits are not even counted)
+            if "bt_pipelined_equal" in case:  # backtracking with a varying number of evaluations per iteration: sized pattern, roll-over
+                assert case["bt_pipelined_equal"] and case["bt_evals"][0] == case["bt_evals"][1], case
+                assert not case["bt_paths"][0] & 8 and case["bt_paths"][1] & 8
+                assert case["bt_evals_per_iteration_max"] >= 3  # (the workload does search: more evaluations than the two slots a period starts with)
+                if case["n"] % 128 == 0:  # second-generation structure: the synchronous pump enqueues exactly one scalar exchange per evaluation
+                    assert case["bt_xchg"][0][0] == case["bt_evals"][0] and case["bt_xchg"][1][0] >= case["bt_evals"][1], case
     for case_i in range(len(res[0]["cases"])):
         n_i = res[0]["cases"][case_i]["n"]
         nb = (n_i + 127) // 128
