@@ -109,6 +109,8 @@ static int rccl_load() {
 struct qn_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // Newton's Cholesky: the bulk of a trailing update, beside the next block's chain of small kernels (created on first use)
+    std::vector<hipEvent_t> la_events; // ... and the events that order the two streams
     int rank = 0, world = 1;
     RcclComm comm = nullptr;
     qn_host_allgather_fn host_xchg = nullptr;
@@ -203,6 +205,8 @@ extern "C" void qn_context_destroy(qn_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    for (auto e : c->la_events) (void)hipEventDestroy(e);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->pin) (void)hipHostFree(c->pin);
     delete c;
@@ -2323,7 +2327,42 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
     // stream -- was measured and dropped: the chain's single-workgroup kernels sat behind the bulk kernel's ~10^4
     // workgroups until it drained, 21 us -> 240-280 us each, and the iteration got 7 % slower.)
     const int KB = 4 * QN_NB;
-    for (int K0 = 0; K0 < n64; K0 += KB) {
+    // LOOK-AHEAD (round 4).  The chain of an outer block -- 4 x (diagonal block, panel, in-block update): ~150 us of small, dependent
+    // kernels -- needs only the block's own 256 columns up to date; the rest of the trailing matrix (up to 0.4 ms of MFMA work per
+    // block at n = 8192) is needed one block later.  So the trailing update is cut in two: the next block's columns on the solver's
+    // stream, the rest on a second stream, ordered by events (E_b: block b's panel columns are final; F_b: the bulk of block b is
+    // done, awaited before the look-ahead columns of block b + 1 are touched again).  Round 1 measured this and dropped it: the
+    // chain's one-workgroup kernels starved behind the bulk grid's 10^4 workgroups (21 us -> 240-280 us each).  What is different
+    // now: the bulk launch asks for so much LDS that only QN_CHOL_BULK_WGS (2) of its workgroups fit a CU, which leaves wave slots,
+    // registers and LDS on EVERY CU for the chain's workgroups the moment they are launched, and the chain's kernels raise their
+    // waves' priority (s_setprio).  Measured at n = 8192 (tools/newton_time.py, tools/chol_timeline.py): 9.93-9.97 -> 9.34-9.41 ms per
+    // Newton iteration.  The bulk keeps its pace (16.3 GFLOP in 360 us = 45 TFLOP/s for the first block), the chain's kernels take
+    // twice their solo time beside it (diagonal block 22 -> 29-40 us, panel 7 -> 10-19, in-block update 9 -> 20-26): the first ten
+    // blocks are bound by the bulk, the rest by the chain.  Also measured: the bulk stream restricted to 192-240 CUs
+    // (hipExtStreamCreateWithCUMask; the chain's workgroups still land on busy CUs: no gain), 1, 3 and 4 bulk workgroups per CU.
+    static const int la_on = getenv("QN_CHOL_LOOKAHEAD") ? atoi(getenv("QN_CHOL_LOOKAHEAD")) : 1;
+    static const int bulk_wgs = getenv("QN_CHOL_BULK_WGS") ? std::max(1, atoi(getenv("QN_CHOL_BULK_WGS"))) : 2;
+    const int nblocks = (n64 + KB - 1) / KB;
+    const bool la = la_on && nblocks >= 4;
+    if (la) {
+        if (!c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        while ((int)c->la_events.size() < 2 * nblocks) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->la_events.push_back(e); }
+    }
+    // (static LDS of chol_syrk_kernel: 2 x 32 x 65 doubles = 33 KB; the CU has 160 KB: the dynamic part tops a workgroup up to 160 / bulk_wgs)
+    size_t bulk_lds = (size_t)std::max(0, (160 * 1024) / bulk_wgs - 34 * 1024);
+    if (la && bulk_lds > 0) { // (more than the default 64 KB per workgroup needs the attribute; refused: run the bulk without the cap)
+        static std::atomic<int> attr_state[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && attr_state[dev].load() == 0) {
+            const bool ok = hipFuncSetAttribute((const void*)chol_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bulk_lds) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            attr_state[dev].store(ok ? 1 : 2);
+        }
+        if (dev < 0 || dev >= 64 || attr_state[dev].load() != 1) bulk_lds = 0;
+    }
+    int last_f = -1;
+    for (int K0 = 0, b = 0; K0 < n64; K0 += KB, ++b) {
         const int Kend = std::min(K0 + KB, n64);
         for (int k0 = K0; k0 < Kend; k0 += QN_NB) {
             double* invl = s->newton_invl + (size_t)(k0 / QN_NB) * QN_NB * QN_NB;
@@ -2332,15 +2371,30 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
             if (nrt > 0) hipLaunchKernelGGL(chol_panel_kernel, dim3(nrt), dim3(256), 0, st, s->newton_w, ld, k0, invl, s->newton_fail);
             const int nct = (Kend - k0 - QN_NB) / QN_NB; // column tiles left in this outer block
             if (nrt > 0 && nct > 0)
-                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nrt, nct)), dim3(256), 0, st, s->newton_w, ld, k0, QN_NB, k0 + QN_NB, nct, s->newton_fail);
+                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nrt, nct)), dim3(256), 0, st, s->newton_w, ld, k0, QN_NB, k0 + QN_NB, nct, s->newton_fail, 1);
             s->stats.launches += 3;
         }
         const int nt = (n64 - Kend) / QN_NB;
         if (nt > 0) {
-            hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt, nt)), dim3(256), 0, st, s->newton_w, ld, K0, Kend - K0, Kend, nt, s->newton_fail);
+            const int nla = la ? std::min(KB / QN_NB, nt) : nt; // tile columns of the next outer block
+            // the next block's columns on this stream -- once the PREVIOUS bulk, which wrote them too, is through -- ...
+            if (la && last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
+            hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt, nla)), dim3(256), 0, st, s->newton_w, ld, K0, Kend - K0, Kend, nla, s->newton_fail, la ? 1 : 0);
             s->stats.launches++;
+            // ... then the bulk, beside the next block's chain.  (Launched BEFORE the look-ahead columns -- it needs only this block's
+            // panel -- it measured slower: 9.43-9.64 ms per Newton iteration against 9.34-9.41, three alternating runs; the chain of
+            // the next block then runs under contention from its first kernel on.)
+            if (nt > nla) {
+                HIPCHK(hipEventRecord(c->la_events[2 * b], st));
+                HIPCHK(hipStreamWaitEvent(c->stream2, c->la_events[2 * b], 0));
+                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt - nla, nt - nla)), dim3(256), bulk_lds, c->stream2, s->newton_w, ld, K0, Kend - K0,
+                                   Kend + nla * QN_NB, nt - nla, s->newton_fail, 0);
+                s->stats.launches++;
+            }
+            if (nt > nla) { HIPCHK(hipEventRecord(c->la_events[2 * b + 1], c->stream2)); last_f = b; }
         }
     }
+    if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
     HIPCHK(hipGetLastError());
     if (s->newton_big) QNCHK(newton_build_block_inverses(s));
     // d = -(H^-1 g) ; z = H^-1 d

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__
     __shared__ double xrow[2][QN_NB];
     __shared__ int bad_s;
     QN_DSTAMP(0);
+    __builtin_amdgcn_s_setprio(3); // (a link of the dependent chain: it may run beside the bulk of a trailing update, see enqueue_newton)
     if (*fail) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     qn_tile_to_lds<256, false>(a, W + (size_t)k0 * ld + k0, ld);
@@ -143,6 +144,7 @@ __device__ __forceinline__ void qn_mfma_64(const double (*PI)[QN_NB + 1], const 
 // ---- panel: rows r >= k0+NB: W[r, k0:k0+NB] <- W[r, k0:k0+NB] * invL'   (64 rows per workgroup, f64 MFMA) ----
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ W, size_t ld, int k0, const double* __restrict__ invL,
                                                          const int* __restrict__ fail) {
+    __builtin_amdgcn_s_setprio(3); // (a link of the dependent chain, see chol_syrk_kernel)
     if (*fail) return;
     __shared__ double PI[QN_NB][QN_NB + 1]; // PI[k][i] = W[r0 + i][k0 + k]
     __shared__ double PJ[QN_NB][QN_NB + 1]; // PJ[k][j] = invL[j][k]
@@ -189,7 +191,11 @@ __device__ __forceinline__ void qn_tri_tile(int t, int ncols, int& ti, int& tj) 
 static inline int qn_tri_tiles(int nrows_t, int ncols_t) { // number of tiles with tj < ncols_t, tj <= ti < nrows_t (ncols_t <= nrows_t)
     return ncols_t * (ncols_t + 1) / 2 + (nrows_t - ncols_t) * ncols_t;
 }
-__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, size_t ld, int kb, int klen, int c0, int ncols, const int* __restrict__ fail) {
+// (`chain`: the launch is a link of the factorisation's dependent chain and runs beside the bulk of a trailing update on another
+// stream: its waves ask the SIMD's arbiter for priority -- see the look-ahead in enqueue_newton)
+__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, size_t ld, int kb, int klen, int c0, int ncols, const int* __restrict__ fail,
+                                                        int chain = 0) {
+    if (chain) __builtin_amdgcn_s_setprio(3);
     int ti, tj;
     qn_tri_tile(blockIdx.x, ncols, ti, tj);
     if (*fail) return;
