@@ -109,6 +109,8 @@ static int rccl_load() {
 struct qn_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    int lu_bulk_cus = 256;
+    hipStream_t stream_lu = nullptr; // Newton's LU: the bulk of a trailing update on a stream whose CU mask leaves a quarter of the chip to the panel chain
     hipStream_t stream2 = nullptr; // Newton's Cholesky: the bulk of a trailing update, beside the next block's chain of small kernels (created on first use)
     std::vector<hipEvent_t> la_events; // ... and the events that order the two streams
     int rank = 0, world = 1;
@@ -206,6 +208,7 @@ extern "C" void qn_context_destroy(qn_context* c) {
     (void)hipSetDevice(c->device);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->stream_lu) { (void)hipStreamSynchronize(c->stream_lu); (void)hipStreamDestroy(c->stream_lu); }
     for (auto e : c->la_events) (void)hipEventDestroy(e);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->pin) (void)hipHostFree(c->pin);
@@ -839,6 +842,7 @@ struct qn_solver {
     bool newton_lu_percol = false;  // diagnostics: the panel factorisation with two launches per column (rounds 1-2)
     std::vector<int> newton_piv_host;
     uint64_t newton_lu_runs = 0, newton_chol_runs = 0;
+    int newton_lu_no_la = 0; // diagnostics (rows = -10): the LU without the look-ahead on a second stream
     int newton_force_lu = 0; // diagnostics (qn_solver_set_tiling rows = -5): skip the Cholesky attempt
     size_t newton_n64 = 0;
     std::vector<double> newton_hhost;
@@ -1220,6 +1224,7 @@ extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_sp
     if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; }
     if (rows_per_block == -3) { s->no_sym = 1; rows_per_block = 0; }   // diagnostics: fused row kernels on the full matrices
     if (rows_per_block == -5) { s->newton_force_lu = 1; return QN_OK; } // diagnostics: Newton by pivoted LU even for an SPD Hessian
+    if (rows_per_block == -10) { s->newton_lu_no_la = 1; return QN_OK; } // diagnostics: ... one stream, no look-ahead
     if (rows_per_block == -8) { s->newton_lu_percol = 1; return QN_OK; } // diagnostics: ... with the per-column panel kernels
     if (rows_per_block == -9) { s->no_pair = !s->no_pair; return QN_OK; }     // diagnostics: general evaluation kernel (toggles)
     if (rows_per_block == -7) { s->no_sliver = !s->no_sliver; return QN_OK; } // diagnostics: sym2 without row slivers (toggles)
@@ -2211,7 +2216,55 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, W, ld, n, n64, hsrc, ld_src); // both triangles
     uint64_t launches = 1;
     if (!s->newton_panel) HIPCHK(hipMalloc((void**)&s->newton_panel, (size_t)QN_NB * QN_LU_PT * QN_LU_RPT * sizeof(double)));
-    for (int p0 = 0; p0 < nlu; p0 += QN_NB) {
+    // LOOK-AHEAD (round 4, as in the Cholesky path: enqueue_newton).  A panel's factorisation is a chain of 17 small launches (one CU
+    // working through 64 pivot steps: 150-400 us); what it needs from the previous panel is its own 64 columns brought up to date.
+    // So after panel p: its swaps, U12 solve and update on the NEXT panel's columns on this stream, and everything else -- the swaps
+    // on the finished columns left of it, swaps / solve / MFMA update on the columns right of the next panel -- on the context's
+    // second stream beside panel p + 1's chain (events E_p: panel p and its pivots are final; F_p: the bulk of panel p is done, awaited
+    // before the same columns are touched again).  The bulk update caps its occupancy as the Cholesky one does.
+    qn_context* c = s->ctx;
+    static const int lu_la_on = getenv("QN_LU_LOOKAHEAD") ? atoi(getenv("QN_LU_LOOKAHEAD")) : 1;
+    const int npanels = nlu / QN_NB;
+    const bool la = lu_la_on && !s->newton_lu_no_la && npanels >= 8;
+    size_t bulk_lds = 0;
+    if (la) {
+        if (!c->stream_lu) {
+            // A panel step's workgroups hold 8 waves of 232 registers -- a CU running even ONE workgroup of the update (4 waves of 196)
+            // has no room for them, and a grid of 16 k update workgroups never leaves a CU empty: without a mask the chain waits for the
+            // bulk to drain and nothing overlaps (measured: 65.6 ms with the second stream, 65.1 without).  So the bulk's stream may
+            // use only `QN_LU_BULK_CUS` of the 256 CUs (default 192: a panel step launches 58 workgroups at most).
+            static const int bulk_cus = getenv("QN_LU_BULK_CUS") ? atoi(getenv("QN_LU_BULK_CUS")) : 192;
+            static const int mask_mode = getenv("QN_LU_MASK_MODE") ? atoi(getenv("QN_LU_MASK_MODE")) : 0;
+            uint32_t mask[8];
+            for (int w = 0; w < 8; ++w) mask[w] = 0;
+            const int keep = std::max(32, std::min(256, bulk_cus));
+            for (int b = 0; b < 256; ++b) {
+                bool on;
+                if (mask_mode == 0) on = b < keep;                                // the low bits
+                else on = ((b * (256 - keep)) / 256) == (((b + 1) * (256 - keep)) / 256); // evenly spread gaps
+                if (on) mask[b >> 5] |= 1u << (b & 31);
+            }
+            c->lu_bulk_cus = keep;
+            if (keep >= 256 || hipExtStreamCreateWithCUMask(&c->stream_lu, 8, mask) != hipSuccess) {
+                (void)hipGetLastError();
+                c->lu_bulk_cus = 256;
+                HIPCHK(hipStreamCreateWithFlags(&c->stream_lu, hipStreamNonBlocking));
+            }
+        }
+        while ((int)c->la_events.size() < 2 * npanels) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->la_events.push_back(e); }
+        static std::atomic<int> attr_state[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        bulk_lds = (size_t)(80 * 1024 - 2 * QN_NB * (QN_NB + 1) * 8 - 1024); // (two workgroups per CU: room for the chain's on every CU)
+        if (dev >= 0 && dev < 64 && attr_state[dev].load() == 0) {
+            const bool ok = hipFuncSetAttribute((const void*)lu_gemm2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bulk_lds) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            attr_state[dev].store(ok ? 1 : 2);
+        }
+        if (dev < 0 || dev >= 64 || attr_state[dev].load() != 1) bulk_lds = 0;
+    }
+    int last_f = -1;
+    for (int p0 = 0, pi = 0; p0 < nlu; p0 += QN_NB, ++pi) {
         const int m = nlu - p0;
         if (m <= QN_LU_PT * QN_LU_RPT && !s->newton_lu_percol) {
             // the panel in a column-major buffer, four columns at a time (qn_lu.hip.h: 19 launches instead of 128)
@@ -2240,15 +2293,46 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
             }
         }
         const int right = nlu - p0 - QN_NB;
-        if (nlu > QN_NB)
-            hipLaunchKernelGGL(lu_swap_rows_kernel, dim3(std::min(256, (nlu + 255) / 256)), dim3(256), 0, st, W, ld, p0, nlu, s->newton_piv, flag);
-        if (right > 0) {
-            hipLaunchKernelGGL(lu_trsm_kernel, dim3((right + 255) / 256), dim3(256), 0, st, W, ld, p0, nlu, flag);
-            hipLaunchKernelGGL(lu_gemm_kernel, dim3(right / QN_NB, right / QN_NB), dim3(256), 0, st, W, ld, p0, flag);
-            launches += 2;
+        if (!la) {
+            if (nlu > QN_NB)
+                hipLaunchKernelGGL(lu_swap_rows_kernel, dim3(std::min(256, (nlu + 255) / 256)), dim3(256), 0, st, W, ld, p0, nlu, s->newton_piv, flag);
+            if (right > 0) {
+                hipLaunchKernelGGL(lu_trsm_kernel, dim3((right + 255) / 256), dim3(256), 0, st, W, ld, p0, nlu, flag);
+                hipLaunchKernelGGL(lu_gemm_kernel, dim3(right / QN_NB, right / QN_NB), dim3(256), 0, st, W, ld, p0, flag);
+                launches += 2;
+            }
+            launches++;
+            continue;
         }
+        const int la_lo = p0 + QN_NB, la_hi = std::min(la_lo + QN_NB, nlu); // the next panel's columns
+        const int below = nlu - la_lo;                                       // rows (and columns) right of / below this panel
+        // the next panel's columns on this stream -- once the previous panel's bulk, which wrote them too, is through
+        if (la_hi > la_lo) {
+            if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
+            hipLaunchKernelGGL(lu_swap_rows2_kernel, dim3(1), dim3(64), 0, st, W, ld, p0, la_lo, la_hi, s->newton_piv, flag);
+            hipLaunchKernelGGL(lu_trsm2_kernel<1>, dim3((la_hi - la_lo + 3) / 4), dim3(256), 0, st, W, ld, p0, la_lo, la_hi, flag);
+            hipLaunchKernelGGL(lu_gemm2_kernel, dim3(below / QN_NB), dim3(256), 0, st, W, ld, p0, la_lo, 1, below / QN_NB, flag, 1);
+            launches += 3;
+        }
+        // everything else beside the next panel's chain
+        HIPCHK(hipEventRecord(c->la_events[2 * pi], st));
+        HIPCHK(hipStreamWaitEvent(c->stream_lu, c->la_events[2 * pi], 0));
+        if (p0 > 0) hipLaunchKernelGGL(lu_swap_rows2_kernel, dim3(std::min(64, (p0 + 255) / 256)), dim3(256), 0, c->stream_lu, W, ld, p0, 0, p0, s->newton_piv, flag);
+        const int rest = nlu - la_hi;
+        if (rest > 0) {
+            hipLaunchKernelGGL(lu_swap_rows2_kernel, dim3(std::min(64, (rest + 255) / 256)), dim3(256), 0, c->stream_lu, W, ld, p0, la_hi, nlu, s->newton_piv, flag);
+            hipLaunchKernelGGL(lu_trsm2_kernel<2>, dim3((rest + 7) / 8), dim3(256), 0, c->stream_lu, W, ld, p0, la_hi, nlu, flag);
+            const int ncb = rest / QN_NB, ntiles = ncb * (below / QN_NB);
+            static const int persist = getenv("QN_LU_BULK_PERSIST") ? atoi(getenv("QN_LU_BULK_PERSIST")) : 0; // (a resident grid that loops: 54.1 ms against 53.5)
+            hipLaunchKernelGGL(lu_gemm2_kernel, dim3(persist ? std::min(ntiles, 2 * c->lu_bulk_cus) : ntiles), dim3(256), bulk_lds, c->stream_lu, W, ld, p0, la_hi, ncb,
+                               ntiles, flag, 0);
+            launches += 3;
+        }
+        HIPCHK(hipEventRecord(c->la_events[2 * pi + 1], c->stream_lu));
+        last_f = pi;
         launches++;
     }
+    if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
     HIPCHK(hipGetLastError());
     // row permutation: the swaps replayed on the identity (host; this path synchronises per Newton iteration anyway)
     int lu_failed = 0;

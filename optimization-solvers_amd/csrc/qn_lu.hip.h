@@ -437,6 +437,102 @@ __global__ __launch_bounds__(256) void lu_gemm_kernel(double* __restrict__ W, si
                 W[(size_t)(i0 + wi + a * 16 + l4 + 4 * reg) * ld + j0 + wj + b * 16 + l15] = -acc[a][b][reg];
 }
 
+// ---- the same three steps on a RANGE of columns (round 4: look-ahead, enqueue_newton_lu) ----
+// After a panel is factorised only the next panel's 64 columns are needed at once; everything right of them -- the bulk of the
+// trailing update, MFMA-bound -- and the swaps on the finished columns left of the panel can run on a second stream beside the
+// next panel's chain of step launches.  Same arithmetic per entry as lu_swap_rows / lu_trsm / lu_gemm: the factors are the same bits.
+__global__ __launch_bounds__(256) void lu_swap_rows2_kernel(double* __restrict__ W, size_t ld, int p0, int col_lo, int col_hi, const int* __restrict__ piv,
+                                                            const int* __restrict__ fail) {
+    if (*fail) return;
+    __shared__ int pv[64];
+    if (threadIdx.x < 64) pv[threadIdx.x] = piv[p0 + threadIdx.x];
+    __syncthreads();
+    for (int j = col_lo + blockIdx.x * blockDim.x + threadIdx.x; j < col_hi; j += gridDim.x * blockDim.x) {
+        for (int q = 0; q < 64; ++q) {
+            const int p = pv[q];
+            if (p != p0 + q) {
+                double* a = W + (size_t)(p0 + q) * ld + j;
+                double* b = W + (size_t)p * ld + j;
+                const double va = *a, vb = *b;
+                *a = vb; *b = va;
+            }
+        }
+    }
+}
+// U[p0 .. p0 + 63][j] = L11^-1 A[p0 ..][j] for the columns col_lo <= j < col_hi (unit lower L11 = the diagonal block at p0).
+// lu_trsm_kernel keeps a column in ONE thread's registers and walks L11 out of LDS: 412 registers, one wave per SIMD, 2016
+// multipliers each an LDS round trip nothing hides -- 35 us whatever the number of columns, and with the look-ahead that is 35 us
+// of the CHAIN per panel.  Here a column lives ACROSS a wave, lane r holding x[r]: step c broadcasts x[c] (v_readlane) and every lane
+// r > c subtracts L[r][c] x[c] -- per entry the same products subtracted in the same order, so the bits are lu_trsm_kernel's
+// (tests/test_gpu_newton.py) -- 63 short steps instead of 2016 dependent ones.  L11 sits transposed in LDS (lane r reads LT[c][r]:
+// contiguous), CPW columns per wave share each read.  (Also tried: a column per thread again but row by row with the multipliers
+// by scalar loads -- 60-75 us, the scalar loads' address arithmetic and latency in front of every row.)
+template <int CPW>
+__global__ __launch_bounds__(256) void lu_trsm2_kernel(double* __restrict__ W, size_t ld, int p0, int col_lo, int col_hi, const int* __restrict__ fail) {
+    if (*fail) return;
+    __shared__ double LT[QN_NB][QN_NB + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = col_lo + (blockIdx.x * 4 + wave) * CPW;
+    double x[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) x[q] = W[(size_t)(p0 + lane) * ld + min(j0 + q, col_hi - 1)];
+    qn_tile_to_lds<256, true>(LT, W + (size_t)p0 * ld + p0, ld); // LT[c][r] = L11[r][c]
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 63; ++c) {
+        const double l = LT[c][lane];
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            const double t = x[q] - l * qn_readlane_d(x[q], c);
+            x[q] = (lane > c) ? t : x[q];
+        }
+    }
+    if (lane >= 1) {
+#pragma unroll
+        for (int q = 0; q < CPW; ++q)
+            if (j0 + q < col_hi) W[(size_t)(p0 + lane) * ld + j0 + q] = x[q];
+    }
+}
+// C[p0 + 64 + 64 by ..][col_lo + 64 bx ..] -= L21 U12 of the panel at p0 (depth 64) on the f64 matrix cores: lu_gemm_kernel's tile, for
+// the tiles t = blockIdx.x, blockIdx.x + gridDim.x, ... < ntiles of an ncb-wide grid of tiles (t = by ncb + bx) from column col_lo on.
+// (The loop: a grid that is resident at once -- two workgroups per CU of the stream's mask -- instead of 16 k workgroups was tried for
+// the bulk, on the suspicion that a queue still placing workgroups holds up the other stream's launches.  With the CU mask the chain's
+// launches find their CUs either way: 54.1 ms looping, 53.5 ms as a plain grid, which is the default -- QN_LU_BULK_PERSIST.)
+__global__ __launch_bounds__(256) void lu_gemm2_kernel(double* __restrict__ W, size_t ld, int p0, int col_lo, int ncb, int ntiles, const int* __restrict__ fail,
+                                                       int chain) {
+    if (chain) __builtin_amdgcn_s_setprio(3); // (a link of the panel chain, beside the bulk on the other stream: see chol_syrk_kernel)
+    if (*fail) return;
+    __shared__ double PI[QN_NB][QN_NB + 1]; // PI[k][i] = L21[i0 + i][p0 + k]
+    __shared__ double PJ[QN_NB][QN_NB + 1]; // PJ[k][j] = U12[p0 + k][j0 + j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int by = t / ncb, bx = t - by * ncb;
+        const int i0 = p0 + 64 + by * 64, j0 = col_lo + bx * 64;
+        qn_tile_to_lds<256, true>(PI, W + (size_t)i0 * ld + p0, ld);
+        qn_tile_to_lds<256, false>(PJ, W + (size_t)p0 * ld + j0, ld);
+        v4d acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    acc[a][b][reg] = -W[(size_t)(i0 + wi + a * 16 + l4 + 4 * reg) * ld + j0 + wj + b * 16 + l15];
+        __syncthreads();
+        qn_mfma_64(PI, PJ, QN_NB, wi, wj, lane, acc);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    W[(size_t)(i0 + wi + a * 16 + l4 + 4 * reg) * ld + j0 + wj + b * 16 + l15] = -acc[a][b][reg];
+        __syncthreads(); // (the panels in LDS are refilled by the next tile)
+    }
+}
+
 // x[i] = sign * b[perm[i]] (zero past n_src): the row permutation of the factorisation applied to a right-hand side
 __global__ void lu_vec_perm_kernel(double* __restrict__ dst, const double* __restrict__ src, const int* __restrict__ perm, int n_src, int n_dst,
                                    double sign) {
