@@ -842,6 +842,9 @@ struct qn_solver {
     bool newton_lu_percol = false;  // diagnostics: the panel factorisation with two launches per column (rounds 1-2)
     std::vector<int> newton_piv_host;
     uint64_t newton_lu_runs = 0, newton_chol_runs = 0;
+    int newton_lu_no_persist = 0; // diagnostics (rows = -11), or set after a bounded wait of the one-launch panel gave up: one launch per sub-panel
+    int* newton_sync = nullptr;   // the one-launch panel's counters (qn_lu.hip.h, lu_panel_persist_kernel)
+    uint64_t newton_lu_sync_timeouts = 0;
     int newton_lu_no_la = 0; // diagnostics (rows = -10): the LU without the look-ahead on a second stream
     int newton_force_lu = 0; // diagnostics (qn_solver_set_tiling rows = -5): skip the Cholesky attempt
     size_t newton_n64 = 0;
@@ -1163,7 +1166,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     for (auto& e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : s->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
-    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->symsh_xg); (void)hipFree(s->symsh_gath); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm); (void)hipFree(s->newton_panel);
+    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->symsh_xg); (void)hipFree(s->symsh_gath); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm); (void)hipFree(s->newton_panel); (void)hipFree(s->newton_sync);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE); (void)hipFree(s->s2_ctl);
@@ -1224,6 +1227,7 @@ extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_sp
     if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; }
     if (rows_per_block == -3) { s->no_sym = 1; rows_per_block = 0; }   // diagnostics: fused row kernels on the full matrices
     if (rows_per_block == -5) { s->newton_force_lu = 1; return QN_OK; } // diagnostics: Newton by pivoted LU even for an SPD Hessian
+    if (rows_per_block == -11) { s->newton_lu_no_persist = 1; return QN_OK; } // diagnostics: ... the panel with one launch per sub-panel
     if (rows_per_block == -10) { s->newton_lu_no_la = 1; return QN_OK; } // diagnostics: ... one stream, no look-ahead
     if (rows_per_block == -8) { s->newton_lu_percol = 1; return QN_OK; } // diagnostics: ... with the per-column panel kernels
     if (rows_per_block == -9) { s->no_pair = !s->no_pair; return QN_OK; }     // diagnostics: general evaluation kernel (toggles)
@@ -2202,6 +2206,27 @@ static int enqueue_hpass_req(Run& r) {
     return QN_OK;
 }
 
+// The second stream of Newton's look-ahead (LU: the bulk of a trailing update beside the next panel's chain).  A panel step's
+// workgroups hold 8 waves of 232 registers -- a CU running even ONE workgroup of the update (4 waves of 196) has no room for them, and
+// a grid of 16 k update workgroups never leaves a CU empty: without a mask the chain waits for the bulk to drain and nothing overlaps
+// (measured: 65.6 ms with the second stream, 65.1 without).  So the bulk's stream may use only `QN_LU_BULK_CUS` of the 256 CUs
+// (default 192: the low mask bits -- 24 CUs of every XCD, tools/cu_mask_probe.hip; the panel's grid is 58 workgroups).
+static int ensure_masked_stream(qn_context* c) {
+    if (c->stream_lu) return QN_OK;
+    static const int bulk_cus = getenv("QN_LU_BULK_CUS") ? atoi(getenv("QN_LU_BULK_CUS")) : 192;
+    uint32_t mask[8];
+    for (int w = 0; w < 8; ++w) mask[w] = 0;
+    const int keep = std::max(32, std::min(256, bulk_cus));
+    for (int b = 0; b < keep; ++b) mask[b >> 5] |= 1u << (b & 31);
+    c->lu_bulk_cus = keep;
+    if (keep >= 256 || hipExtStreamCreateWithCUMask(&c->stream_lu, 8, mask) != hipSuccess) {
+        (void)hipGetLastError();
+        c->lu_bulk_cus = 256;
+        HIPCHK(hipStreamCreateWithFlags(&c->stream_lu, hipStreamNonBlocking));
+    }
+    return QN_OK;
+}
+
 // Pivoted LU of the staged Hessian and the two solves (qn_lu.hip.h); leaves d in V.d, z = H^-1 d in V.s, and newton_fail[0] = 1
 // when a pivot column is exactly zero (then QN_ST_AFTER_NEWTON takes -g, newton/mod.rs:43-46).
 static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
@@ -2216,6 +2241,10 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, W, ld, n, n64, hsrc, ld_src); // both triangles
     uint64_t launches = 1;
     if (!s->newton_panel) HIPCHK(hipMalloc((void**)&s->newton_panel, (size_t)QN_NB * QN_LU_PT * QN_LU_RPT * sizeof(double)));
+    if (!s->newton_sync) HIPCHK(hipMalloc((void**)&s->newton_sync, 128 * sizeof(int)));
+    HIPCHK(hipMemsetAsync(s->newton_sync, 0, 128 * sizeof(int), st));
+    static const int lu_persist_on = getenv("QN_LU_PERSIST") ? atoi(getenv("QN_LU_PERSIST")) : 1;
+    const bool persist = lu_persist_on && !s->newton_lu_no_persist;
     // LOOK-AHEAD (round 4, as in the Cholesky path: enqueue_newton).  A panel's factorisation is a chain of 17 small launches (one CU
     // working through 64 pivot steps: 150-400 us); what it needs from the previous panel is its own 64 columns brought up to date.
     // So after panel p: its swaps, U12 solve and update on the NEXT panel's columns on this stream, and everything else -- the swaps
@@ -2228,29 +2257,7 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     const bool la = lu_la_on && !s->newton_lu_no_la && npanels >= 8;
     size_t bulk_lds = 0;
     if (la) {
-        if (!c->stream_lu) {
-            // A panel step's workgroups hold 8 waves of 232 registers -- a CU running even ONE workgroup of the update (4 waves of 196)
-            // has no room for them, and a grid of 16 k update workgroups never leaves a CU empty: without a mask the chain waits for the
-            // bulk to drain and nothing overlaps (measured: 65.6 ms with the second stream, 65.1 without).  So the bulk's stream may
-            // use only `QN_LU_BULK_CUS` of the 256 CUs (default 192: a panel step launches 58 workgroups at most).
-            static const int bulk_cus = getenv("QN_LU_BULK_CUS") ? atoi(getenv("QN_LU_BULK_CUS")) : 192;
-            static const int mask_mode = getenv("QN_LU_MASK_MODE") ? atoi(getenv("QN_LU_MASK_MODE")) : 0;
-            uint32_t mask[8];
-            for (int w = 0; w < 8; ++w) mask[w] = 0;
-            const int keep = std::max(32, std::min(256, bulk_cus));
-            for (int b = 0; b < 256; ++b) {
-                bool on;
-                if (mask_mode == 0) on = b < keep;                                // the low bits
-                else on = ((b * (256 - keep)) / 256) == (((b + 1) * (256 - keep)) / 256); // evenly spread gaps
-                if (on) mask[b >> 5] |= 1u << (b & 31);
-            }
-            c->lu_bulk_cus = keep;
-            if (keep >= 256 || hipExtStreamCreateWithCUMask(&c->stream_lu, 8, mask) != hipSuccess) {
-                (void)hipGetLastError();
-                c->lu_bulk_cus = 256;
-                HIPCHK(hipStreamCreateWithFlags(&c->stream_lu, hipStreamNonBlocking));
-            }
-        }
+        QNCHK(ensure_masked_stream(c));
         while ((int)c->la_events.size() < 2 * npanels) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->la_events.push_back(e); }
         static std::atomic<int> attr_state[64];
         int dev = 0;
@@ -2271,6 +2278,17 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
             double* P = s->newton_panel;
             const size_t pld = (size_t)QN_LU_PT * QN_LU_RPT;
             hipLaunchKernelGGL(lu_panel_load_kernel, dim3(m / QN_NB), dim3(256), 0, st, W, ld, p0, P, pld, flag);
+            const int rpt_p = (m + QN_LU_PT - 1) / QN_LU_PT;
+            if (persist) { // the panel in one launch: 58 workgroups waiting for each other on counters (qn_lu.hip.h)
+                const dim3 pg(2 + QN_NB - 2 * QN_LU_SUB), pb(QN_LU_PT);
+                const int base = 32 * pi;
+                if (rpt_p <= 1) hipLaunchKernelGGL(lu_panel_persist_kernel<1>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base);
+                else if (rpt_p <= 2) hipLaunchKernelGGL(lu_panel_persist_kernel<2>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base);
+                else if (rpt_p <= 4) hipLaunchKernelGGL(lu_panel_persist_kernel<4>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base);
+                else if (rpt_p <= 8) hipLaunchKernelGGL(lu_panel_persist_kernel<8>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base);
+                else hipLaunchKernelGGL(lu_panel_persist_kernel<QN_LU_RPT>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base);
+                launches += 1;
+            } else
             for (int sp = 0; sp <= QN_NB / QN_LU_SUB; ++sp) {
                 const int ncol_b = sp >= 1 ? std::max(0, QN_NB - QN_LU_SUB * (sp + 1)) : 0; // role B: the columns right of sub-panel sp
                 const int grid = sp == 0 ? 1 : 2 + ncol_b;                                    // (workgroup 1: role C)
@@ -2282,7 +2300,7 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
                 else hipLaunchKernelGGL(lu_panel_step_kernel<QN_LU_RPT>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
             }
             hipLaunchKernelGGL(lu_panel_store_kernel, dim3(m / QN_NB), dim3(256), 0, st, W, ld, p0, P, pld, flag);
-            launches += 3 + QN_NB / QN_LU_SUB;
+            launches += 2 + (persist ? 0 : 1 + QN_NB / QN_LU_SUB);
         } else {
             for (int k = p0; k < p0 + QN_NB; ++k) {
                 hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(1024), 0, st, W, ld, k, p0, nlu, s->newton_piv, flag);
@@ -2341,6 +2359,12 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     HIPCHK(hipStreamSynchronize(st));
     s->stats.host_syncs++;
     s->stats.launches += launches;
+    if (lu_failed == 2) { // a bounded wait of the one-launch panel gave up (its workgroups were not placed together): one launch per sub-panel from now on
+        s->newton_lu_no_persist = 1;
+        s->newton_lu_sync_timeouts++;
+        s->newton_lu_runs--;
+        return enqueue_newton_lu(s, hsrc, ld_src);
+    }
     if (lu_failed) return QN_OK; // singular: the control kernel falls back to -g
     std::vector<int> perm((size_t)nlu);
     for (int i = 0; i < nlu; ++i) perm[i] = i;
@@ -2349,7 +2373,15 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     double* x1 = s->newton_x;
     double* x2 = s->newton_x + n64;
     const dim3 vg(std::min(1024, (n64 + 255) / 256)), vb(256);
+    int sweeps = 0;
     auto solve = [&](double* x, double* tmp) { // x <- U^-1 L^-1 x (x already permuted); tmp: scratch
+        if (persist) { // a sweep in one launch: workgroups taking each other's solution blocks as they are published (qn_lu.hip.h)
+            const int nb = nlu / QN_NB; // (`tmp` holds sentinels: lu_vec_perm_kernel; the forward sweep leaves them in `x`, the backward one in `tmp`)
+            hipLaunchKernelGGL(lu_sweep_kernel<false>, dim3(nb), dim3(256), 0, st, W, ld, nb, x, tmp, flag);
+            hipLaunchKernelGGL(lu_sweep_kernel<true>, dim3(nb), dim3(256), 0, st, W, ld, nb, tmp, x, flag);
+            sweeps += 2;
+            return;
+        }
         for (int k0 = 0; k0 < nlu; k0 += QN_NB) {
             const int below = nlu - k0 - QN_NB;
             hipLaunchKernelGGL(lu_fwd_step_kernel, dim3(std::max(1, std::min(256, (below + 3) / 4))), dim3(256), 0, st, W, ld, k0, nlu, x, tmp);
@@ -2357,15 +2389,22 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
         for (int k0 = nlu - QN_NB; k0 >= 0; k0 -= QN_NB)
             hipLaunchKernelGGL(lu_bwd_step_kernel, dim3(std::max(1, std::min(256, (k0 + 3) / 4))), dim3(256), 0, st, W, ld, k0, tmp, x);
     };
-    hipLaunchKernelGGL(lu_vec_perm_kernel, vg, vb, 0, st, x1, s->V.g, s->newton_perm, n, nlu, -1.0); // P (-g)
+    hipLaunchKernelGGL(lu_vec_perm_kernel, vg, vb, 0, st, x1, s->V.g, s->newton_perm, n, nlu, -1.0, persist ? x2 : nullptr); // P (-g)
     solve(x1, x2);
     hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.d, x1, n, s->T.n_pad, 1.0); // d = -(H^-1 g)
-    hipLaunchKernelGGL(lu_vec_perm_kernel, vg, vb, 0, st, x2, s->V.d, s->newton_perm, n, nlu, 1.0); // P d
+    hipLaunchKernelGGL(lu_vec_perm_kernel, vg, vb, 0, st, x2, s->V.d, s->newton_perm, n, nlu, 1.0, persist ? x1 : nullptr); // P d
     solve(x2, x1);
     hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.s, x2, n, s->T.n_pad, 1.0); // z = H^-1 d
     HIPCHK(hipGetLastError());
-    s->stats.launches += 4 + 4 * (uint64_t)(nlu / QN_NB);
+    s->stats.launches += 4 + (persist ? 4 : 4 * (uint64_t)(nlu / QN_NB));
+    if (persist) HIPCHK(hipMemcpyAsync(&lu_failed, flag, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st)); // `perm` is a local
+    if (persist && lu_failed == 2) { // a bounded wait of a one-launch sweep gave up: the whole factorisation again, launch by launch
+        s->newton_lu_no_persist = 1;
+        s->newton_lu_sync_timeouts++;
+        s->newton_lu_runs--;
+        return enqueue_newton_lu(s, hsrc, ld_src);
+    }
     return QN_OK;
 }
 
@@ -2428,12 +2467,14 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
     static const int bulk_wgs = getenv("QN_CHOL_BULK_WGS") ? std::max(1, atoi(getenv("QN_CHOL_BULK_WGS"))) : 2;
     const int nblocks = (n64 + KB - 1) / KB;
     const bool la = la_on && nblocks >= 4;
+    static const int chol_masked = getenv("QN_CHOL_BULK_MASKED") ? atoi(getenv("QN_CHOL_BULK_MASKED")) : 0;
     if (la) {
         if (!c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        if (chol_masked) QNCHK(ensure_masked_stream(c));
         while ((int)c->la_events.size() < 2 * nblocks) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->la_events.push_back(e); }
     }
-    // (static LDS of chol_syrk_kernel: 2 x 32 x 65 doubles = 33 KB; the CU has 160 KB: the dynamic part tops a workgroup up to 160 / bulk_wgs)
-    size_t bulk_lds = (size_t)std::max(0, (160 * 1024) / bulk_wgs - 34 * 1024);
+    // (static LDS of chol_syrk_kernel: 2 x 32 x 65 doubles + the diagonal step's vectors = 35 KB; the CU has 160 KB: the dynamic part tops a workgroup up to 160 / bulk_wgs)
+    size_t bulk_lds = (size_t)std::max(0, (160 * 1024) / bulk_wgs - 36 * 1024);
     if (la && bulk_lds > 0) { // (more than the default 64 KB per workgroup needs the attribute; refused: run the bulk without the cap)
         static std::atomic<int> attr_state[64];
         int dev = 0;
@@ -2446,36 +2487,77 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
         if (dev < 0 || dev >= 64 || attr_state[dev].load() != 1) bulk_lds = 0;
     }
     int last_f = -1;
+    static const int chol_fuse = getenv("QN_CHOL_FUSE_DIAG") ? atoi(getenv("QN_CHOL_FUSE_DIAG")) : 1;
+    static const int chol_left = getenv("QN_CHOL_LEFT") ? atoi(getenv("QN_CHOL_LEFT")) : 0;
+    bool diag_done = false;
+    hipStream_t bulk_st = (la && chol_masked) ? c->stream_lu : c->stream2;
     for (int K0 = 0, b = 0; K0 < n64; K0 += KB, ++b) {
         const int Kend = std::min(K0 + KB, n64);
         for (int k0 = K0; k0 < Kend; k0 += QN_NB) {
             double* invl = s->newton_invl + (size_t)(k0 / QN_NB) * QN_NB * QN_NB;
-            hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(256), 0, st, s->newton_w, ld, k0, invl, s->newton_fail);
+            // (the diagonal block's factor and inverse: a launch of its own for the first block only -- afterwards the update that
+            // produced the block went on to factorise it, chol_syrk_kernel's invL_next)
+            if (!diag_done) { hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(256), 0, st, s->newton_w, ld, k0, invl, s->newton_fail); s->stats.launches++; }
+            diag_done = false;
             const int nrt = (n64 - k0 - QN_NB) / QN_NB; // row tiles below the diagonal block
             if (nrt > 0) hipLaunchKernelGGL(chol_panel_kernel, dim3(nrt), dim3(256), 0, st, s->newton_w, ld, k0, invl, s->newton_fail);
             const int nct = (Kend - k0 - QN_NB) / QN_NB; // column tiles left in this outer block
-            if (nrt > 0 && nct > 0)
-                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nrt, nct)), dim3(256), 0, st, s->newton_w, ld, k0, QN_NB, k0 + QN_NB, nct, s->newton_fail, 1);
-            s->stats.launches += 3;
+            if (nrt > 0 && nct > 0) {
+                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nrt, nct)), dim3(256), 0, st, s->newton_w, ld, k0, QN_NB, k0 + QN_NB, nct, s->newton_fail, 1,
+                                   chol_fuse ? invl + QN_NB * QN_NB : nullptr);
+                diag_done = chol_fuse;
+            }
+            s->stats.launches += 2;
         }
         const int nt = (n64 - Kend) / QN_NB;
-        if (nt > 0) {
+        if (nt > 0 && la && chol_left) {
+            // LEFT-LOOKING second stream (round 4; measured, NOT the default: QN_CHOL_LEFT=1).  With the right-looking bulk -- block b's panel
+            // applied to everything right of the next block, beside chain b + 1 -- the first ten outer blocks are bound by the bulk (345 us
+            // of MFMA work against a 240 us chain) and the last twenty by the chain with the second stream nearly idle: 9.1 ms where the
+            // chain alone is ~5.5.  The same flops in another order: what block column b + 2 owes to ALL the panels so far (0 .. b) as ONE
+            // update of depth 256 (b + 1), launched on the second stream as soon as chain b is through and awaited a whole chain period
+            // later, before this stream adds panel b + 1's part.  Every tile is then read and written once, and the chain never waits for
+            // more than four tile columns.  Measured: 10.7 ms against 9.1 -- the deep, narrow updates of the last third (10-150 tiles of
+            // depth 5000-7700: one workgroup per CU, each 32-deep chunk a global-load round trip nothing hides: 1.2 us against 0.43 us of
+            // MFMA work) take 220-380 us where a chain period is 170, and in the middle third a panel kernel of the chain was seen
+            // waiting 150 us for CUs beside them (profiles/r04_j_*).  What it needs is an update kernel that is efficient at one workgroup
+            // per CU (deeper prefetch, 64 x 128 tiles: a 64 x 64 tile at full MFMA rate asks a CU for 77 KB/us, more than it takes in).
+            const int nla = std::min(KB / QN_NB, nt);
+            if (nt > nla) { // J_{b+2}: block column b + 2 (tile columns nla .. 2 nla - 1 right of Kend) -= panels [0, Kend) ...
+                const int ncj = std::min(KB / QN_NB, nt - nla);
+                HIPCHK(hipEventRecord(c->la_events[2 * b], st));
+                HIPCHK(hipStreamWaitEvent(bulk_st, c->la_events[2 * b], 0));
+                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt - nla, ncj)), dim3(256), bulk_lds, bulk_st, s->newton_w, ld, 0, Kend, Kend + nla * QN_NB, ncj,
+                                   s->newton_fail, 0);
+                HIPCHK(hipEventRecord(c->la_events[2 * b + 1], bulk_st));
+                s->stats.launches++;
+            }
+            // ... and block column b + 1 -= panel b on this stream, once J_{b+1} (launched a chain period ago) has brought it up to panel b - 1
+            if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
+            last_f = nt > nla ? b : -1;
+            hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt, nla)), dim3(256), 0, st, s->newton_w, ld, K0, Kend - K0, Kend, nla, s->newton_fail, 1,
+                               chol_fuse ? s->newton_invl + (size_t)(Kend / QN_NB) * QN_NB * QN_NB : nullptr);
+            diag_done = chol_fuse;
+            s->stats.launches++;
+        } else if (nt > 0) {
             const int nla = la ? std::min(KB / QN_NB, nt) : nt; // tile columns of the next outer block
             // the next block's columns on this stream -- once the PREVIOUS bulk, which wrote them too, is through -- ...
             if (la && last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
-            hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt, nla)), dim3(256), 0, st, s->newton_w, ld, K0, Kend - K0, Kend, nla, s->newton_fail, la ? 1 : 0);
+            hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt, nla)), dim3(256), 0, st, s->newton_w, ld, K0, Kend - K0, Kend, nla, s->newton_fail, la ? 1 : 0,
+                               chol_fuse ? s->newton_invl + (size_t)(Kend / QN_NB) * QN_NB * QN_NB : nullptr);
+            diag_done = chol_fuse;
             s->stats.launches++;
             // ... then the bulk, beside the next block's chain.  (Launched BEFORE the look-ahead columns -- it needs only this block's
             // panel -- it measured slower: 9.43-9.64 ms per Newton iteration against 9.34-9.41, three alternating runs; the chain of
             // the next block then runs under contention from its first kernel on.)
             if (nt > nla) {
                 HIPCHK(hipEventRecord(c->la_events[2 * b], st));
-                HIPCHK(hipStreamWaitEvent(c->stream2, c->la_events[2 * b], 0));
-                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt - nla, nt - nla)), dim3(256), bulk_lds, c->stream2, s->newton_w, ld, K0, Kend - K0,
+                HIPCHK(hipStreamWaitEvent(bulk_st, c->la_events[2 * b], 0));
+                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt - nla, nt - nla)), dim3(256), bulk_lds, bulk_st, s->newton_w, ld, K0, Kend - K0,
                                    Kend + nla * QN_NB, nt - nla, s->newton_fail, 0);
                 s->stats.launches++;
             }
-            if (nt > nla) { HIPCHK(hipEventRecord(c->la_events[2 * b + 1], c->stream2)); last_f = b; }
+            if (nt > nla) { HIPCHK(hipEventRecord(c->la_events[2 * b + 1], bulk_st)); last_f = b; }
         }
     }
     if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));

@@ -138,64 +138,79 @@ __global__ __launch_bounds__(256) void lu_panel_store_kernel(double* __restrict_
 
 #ifdef QN_LU_STAMPS
 __device__ unsigned long long qn_lu_dbg[64 * 16];
-#define QN_LU_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && s < 64) qn_lu_dbg[s * 16 + (k)] = wall_clock64(); } while (0)
+#ifndef QN_LU_STAMP_P0
+#define QN_LU_STAMP_P0 640 // the panel whose role A is stamped (p0: its first column)
+#endif
+#define QN_LU_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && s < 64 && p0 == QN_LU_STAMP_P0) qn_lu_dbg[s * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define QN_LU_STAMP(k) do { } while (0)
 #endif
 // RPT: rows per thread -- 16 for the first panels of an 8192-row matrix, fewer as the panels get shorter (the loops over a thread's
 // rows are unrolled, registers: a short panel must not pay for sixteen predicated copies of every step)
-template <int RPT>
-__global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restrict__ P, size_t pld, int m, int s, int p0, int* __restrict__ piv,
-                                                                 int* __restrict__ fail) {
-    QN_LU_STAMP(0);
-    if (*fail) return;
-    QN_LU_STAMP(1);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    if (b == 1) { // role C: the swaps of sub-panel s - 1 on the columns left of it
-        const int r0 = QN_LU_SUB * (s - 1);
-        if (s >= 2 && tid < r0) {
-            double* col = P + (size_t)tid * pld;
-            int ix[2 * QN_LU_SUB];
+// The three roles as functions of (sub-panel, column): lu_panel_step_kernel runs them one launch per sub-panel, lu_panel_persist_kernel
+// (below) in ONE launch per panel, the workgroups waiting for each other on counters in memory.
+// COH: every access to the panel buffer and the pivots as a relaxed atomic at agent scope (loads and stores that go past the
+// non-coherent cache levels: what the one-launch panel needs between workgroups on different XCDs -- see lu_panel_persist_kernel)
+template <bool COH> __device__ __forceinline__ double lu_ld(const double* p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH> __device__ __forceinline__ int lu_ldi(const int* p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH> __device__ __forceinline__ void lu_st(double* p, const double v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COH> __device__ __forceinline__ void lu_sti(int* p, const int v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+struct QnLuLds {
+    double U[QN_LU_SUB][QN_LU_SUB]; // U[q][j]: row r0 + q of column c0 + j after the solve
+    double bv[QN_LU_SUB][16];
+    int bi[QN_LU_SUB][16];
+    double rowk[QN_LU_SUB][QN_LU_SUB], rowp[QN_LU_SUB][QN_LU_SUB];
+};
+// role C: the swaps of the sub-panel at r0 on the columns left of it (thread = column)
+template <bool COH>
+__device__ __forceinline__ void lu_role_c(double* __restrict__ P, const size_t pld, const int r0, const int p0, const int* __restrict__ piv, const int tid) {
+    if (tid < r0) {
+        double* col = P + (size_t)tid * pld;
+        int ix[2 * QN_LU_SUB];
 #pragma unroll
-            for (int q = 0; q < QN_LU_SUB; ++q) { ix[q] = r0 + q; ix[QN_LU_SUB + q] = piv[p0 + r0 + q] - p0; }
-            double v[2 * QN_LU_SUB];
+        for (int q = 0; q < QN_LU_SUB; ++q) { ix[q] = r0 + q; ix[QN_LU_SUB + q] = lu_ldi<COH>(piv + p0 + r0 + q) - p0; }
+        double v[2 * QN_LU_SUB];
 #pragma unroll
-            for (int e = 0; e < 2 * QN_LU_SUB; ++e) v[e] = col[ix[e]];
-            int canon[2 * QN_LU_SUB];
+        for (int e = 0; e < 2 * QN_LU_SUB; ++e) v[e] = lu_ld<COH>(col + ix[e]);
+        int canon[2 * QN_LU_SUB];
 #pragma unroll
-            for (int e = 0; e < 2 * QN_LU_SUB; ++e) {
-                canon[e] = e;
+        for (int e = 0; e < 2 * QN_LU_SUB; ++e) {
+            canon[e] = e;
 #pragma unroll
-                for (int f = 2 * QN_LU_SUB - 1; f >= 0; --f)
-                    if (f < e && ix[f] == ix[e]) canon[e] = f;
-            }
-#pragma unroll
-            for (int q = 0; q < QN_LU_SUB; ++q) {
-                const int sa = canon[q], sb = canon[QN_LU_SUB + q];
-                double va = 0.0, vb = 0.0;
-#pragma unroll
-                for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) va = v[e]; if (e == sb) vb = v[e]; }
-#pragma unroll
-                for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) v[e] = vb; else if (e == sb) v[e] = va; }
-            }
-#pragma unroll
-            for (int e = 0; e < 2 * QN_LU_SUB; ++e)
-                if (canon[e] == e) col[ix[e]] = v[e];
+            for (int f = 2 * QN_LU_SUB - 1; f >= 0; --f)
+                if (f < e && ix[f] == ix[e]) canon[e] = f;
         }
-        return;
+#pragma unroll
+        for (int q = 0; q < QN_LU_SUB; ++q) {
+            const int sa = canon[q], sb = canon[QN_LU_SUB + q];
+            double va = 0.0, vb = 0.0;
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) va = v[e]; if (e == sb) vb = v[e]; }
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) v[e] = vb; else if (e == sb) v[e] = va; }
+        }
+#pragma unroll
+        for (int e = 0; e < 2 * QN_LU_SUB; ++e)
+            if (canon[e] == e) lu_st<COH>(col + ix[e], v[e]);
     }
-    const bool isA = b == 0;
-    if (isA && s >= QN_NB / QN_LU_SUB) return;
-    const int c0 = isA ? QN_LU_SUB * s : QN_LU_SUB * (s + 1) + (b - 2); // first column of this workgroup
-    const int nc = isA ? QN_LU_SUB : 1;
-    __shared__ double U[QN_LU_SUB][QN_LU_SUB]; // U[q][j]: row r0 + q of column c0 + j after the solve
-    __shared__ double bv[QN_LU_SUB][16];
-    __shared__ int bi[QN_LU_SUB][16];
-    __shared__ double rowk[QN_LU_SUB][QN_LU_SUB], rowp[QN_LU_SUB][QN_LU_SUB];
-    // ---- bring the columns up to date with sub-panel s - 1 ----
-    const int r0 = QN_LU_SUB * (s - 1);
-    if (s >= 1) {
+}
+// roles A and B, first half: the nc columns from c0 on into registers, brought up to date with the sub-panel at r0 (prev: there is one)
+template <int RPT, bool COH, int LCH>
+__device__ __forceinline__ void lu_cols_update(double* __restrict__ P, const size_t pld, const int m, const int r0, const bool prev, const int c0, const int nc,
+                                               const int p0, const int* __restrict__ piv, QnLuLds& L, double (&a)[QN_LU_SUB][RPT], const int tid) {
+    if (prev) {
         if (tid < nc) { // thread j, column c0 + j: the four swaps, then the unit-lower 4 x 4 solve
             // Two memory round trips, not fourteen: the pivots first, then the eight entries the swaps can touch and the six
             // multipliers, all at once; the swaps are replayed on those eight in registers (two slots may name the same row: the
@@ -204,14 +219,14 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restr
             double* col = P + (size_t)(c0 + tid) * pld;
             int ix[2 * QN_LU_SUB];
 #pragma unroll
-            for (int q = 0; q < QN_LU_SUB; ++q) { ix[q] = r0 + q; ix[QN_LU_SUB + q] = piv[p0 + r0 + q] - p0; }
+            for (int q = 0; q < QN_LU_SUB; ++q) { ix[q] = r0 + q; ix[QN_LU_SUB + q] = lu_ldi<COH>(piv + p0 + r0 + q) - p0; }
             double v[2 * QN_LU_SUB], l11[QN_LU_SUB][QN_LU_SUB];
 #pragma unroll
-            for (int e = 0; e < 2 * QN_LU_SUB; ++e) v[e] = col[ix[e]];
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e) v[e] = lu_ld<COH>(col + ix[e]);
 #pragma unroll
             for (int c = 0; c < QN_LU_SUB - 1; ++c)
 #pragma unroll
-                for (int r = c + 1; r < QN_LU_SUB; ++r) l11[r][c] = P[(size_t)(r0 + c) * pld + r0 + r];
+                for (int r = c + 1; r < QN_LU_SUB; ++r) l11[r][c] = lu_ld<COH>(P + (size_t)(r0 + c) * pld + r0 + r);
             int canon[2 * QN_LU_SUB]; // the first slot that names the same row
 #pragma unroll
             for (int e = 0; e < 2 * QN_LU_SUB; ++e) {
@@ -236,47 +251,71 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restr
                 for (int r = c + 1; r < QN_LU_SUB; ++r) v[r] = v[r] - l11[r][c] * v[c];
 #pragma unroll
             for (int e = 0; e < 2 * QN_LU_SUB; ++e)
-                if (canon[e] == e) col[ix[e]] = v[e];
+                if (canon[e] == e) lu_st<COH>(col + ix[e], v[e]);
 #pragma unroll
-            for (int q = 0; q < QN_LU_SUB; ++q) U[q][tid] = v[q];
+            for (int q = 0; q < QN_LU_SUB; ++q) L.U[q][tid] = v[q];
         }
         __syncthreads(); // (the swapped entries are read below by other threads of this workgroup: same CU, same L1)
     }
-    double a[QN_LU_SUB][RPT];
 #pragma unroll
     for (int jr = 0; jr < RPT; ++jr) {
         const int i = tid + QN_LU_PT * jr;
 #pragma unroll
-        for (int j = 0; j < QN_LU_SUB; ++j) a[j][jr] = (i < m && j < nc) ? P[(size_t)(c0 + j) * pld + i] : 0.0;
+        for (int j = 0; j < QN_LU_SUB; ++j) a[j][jr] = (i < m && j < nc) ? lu_ld<COH>(P + (size_t)(c0 + j) * pld + i) : 0.0;
     }
-    if (s >= 1) {
+    if (prev) {
+        // the multipliers CH rows-per-thread at a time, requested together and OUTSIDE any branch (first version: four loads inside
+        // `if (row below the sub-panel)` per row of the thread: the compiler waits for memory at every such block).  Measured at
+        // n = 8192 (whole Newton iteration): role A with CH = 4 at up to 8 rows per thread and CH = 1 at 16 (at 16, CH = 2 and 4 were
+        // 2-3 ms SLOWER: 251-256 registers, and the update's arithmetic no longer interleaves with the requests), role B 16 / 4.
+        constexpr int CH = RPT < LCH ? RPT : LCH;
 #pragma unroll
-        for (int jr = 0; jr < RPT; ++jr) {
-            const int i = tid + QN_LU_PT * jr;
-            if (i >= r0 + QN_LU_SUB && i < m) {
-                double l[QN_LU_SUB];
+        for (int jc = 0; jc < RPT; jc += CH) {
+            double l[CH][QN_LU_SUB];
 #pragma unroll
-                for (int q = 0; q < QN_LU_SUB; ++q) l[q] = P[(size_t)(r0 + q) * pld + i];
+            for (int u = 0; u < CH; ++u) {
+                const int i = tid + QN_LU_PT * (jc + u);
+                const bool on = i >= r0 + QN_LU_SUB && i < m;
 #pragma unroll
-                for (int j = 0; j < QN_LU_SUB; ++j)
-                    if (j < nc) {
+                for (int q = 0; q < QN_LU_SUB; ++q) l[u][q] = on ? lu_ld<COH>(P + (size_t)(r0 + q) * pld + i) : 0.0;
+            }
 #pragma unroll
-                        for (int q = 0; q < QN_LU_SUB; ++q) a[j][jr] = a[j][jr] - l[q] * U[q][j]; // (column order: the per-column kernels' rounding)
-                    }
+            for (int u = 0; u < CH; ++u) {
+                const int i = tid + QN_LU_PT * (jc + u);
+                if (i >= r0 + QN_LU_SUB && i < m) {
+#pragma unroll
+                    for (int j = 0; j < QN_LU_SUB; ++j)
+                        if (j < nc) {
+#pragma unroll
+                            for (int q = 0; q < QN_LU_SUB; ++q) a[j][jc + u] = a[j][jc + u] - l[u][q] * L.U[q][j]; // (column order: the per-column kernels' rounding)
+                        }
+                }
             }
         }
     }
-    if (!isA) {
+}
+// role B, second half: the column back to the panel buffer
+template <int RPT, bool COH>
+__device__ __forceinline__ void lu_col_store(double* __restrict__ P, const size_t pld, const int m, const int r0, const int c0, const double (&a)[QN_LU_SUB][RPT],
+                                             const int tid) {
+    // Every row of the thread, no condition: rows the update did not touch get back the value that was loaded (nobody else writes
+    // this column meanwhile), rows past m lie in the buffer's unused tail (pld = 512 x 16 rows).  Stores under a condition each
+    // came with a wait for all memory operations before them: sixteen write-through round trips in a row.
+    (void)m; (void)r0;
 #pragma unroll
-        for (int jr = 0; jr < RPT; ++jr) {
-            const int i = tid + QN_LU_PT * jr;
-            if (i >= r0 + QN_LU_SUB && i < m) P[(size_t)c0 * pld + i] = a[0][jr];
-        }
-        return;
-    }
-    // ---- role A: the four pivot steps of sub-panel s, rows in registers ----
-    QN_LU_STAMP(2);
+    for (int jr = 0; jr < RPT; ++jr) lu_st<COH>(P + (size_t)c0 * pld + tid + QN_LU_PT * jr, a[0][jr]);
+}
+// role A, second half: the four pivot steps of sub-panel s on the rows in registers, and the columns back to the buffer.
+// Returns true when a pivot column holds no non-zero entry (then *fail = 1).
+template <int RPT, bool COH>
+__device__ __forceinline__ bool lu_sub_factor(double* __restrict__ P, const size_t pld, const int m, const int s, const int p0, int* __restrict__ piv,
+                                              int* __restrict__ fail, QnLuLds& L, double (&a)[QN_LU_SUB][RPT], const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int c0 = QN_LU_SUB * s;
     bool failed = false;
+    int pv[QN_LU_SUB];
+#pragma unroll
+    for (int j = 0; j < QN_LU_SUB; ++j) pv[j] = p0 + QN_LU_SUB * s + j;
 #pragma unroll
     for (int j = 0; j < QN_LU_SUB; ++j) {
         const int k = QN_LU_SUB * s + j; // pivot position (panel row = panel column)
@@ -294,20 +333,20 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restr
                                   if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; } }
         QN_LU_ARGMAX_LEVEL(32) QN_LU_ARGMAX_LEVEL(16) QN_LU_ARGMAX_LEVEL(8) QN_LU_ARGMAX_LEVEL(4) QN_LU_ARGMAX_LEVEL(2) QN_LU_ARGMAX_LEVEL(1)
 #undef QN_LU_ARGMAX_LEVEL
-        if (lane == 0) { bv[j][wave] = best; bi[j][wave] = idx; }
+        if (lane == 0) { L.bv[j][wave] = best; L.bi[j][wave] = idx; }
         if (j == 0) QN_LU_STAMP(3);
         __syncthreads();
         if (j == 0) QN_LU_STAMP(4);
-        best = bv[j][0]; idx = bi[j][0];
+        best = L.bv[j][0]; idx = L.bi[j][0];
 #pragma unroll
         for (int w = 1; w < QN_LU_PT / 64; ++w) {
-            const double ov = bv[j][w];
-            const int oi = bi[j][w];
+            const double ov = L.bv[j][w];
+            const int oi = L.bi[j][w];
             if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
         }
         if (!(best > 0.0) || idx >= m) { failed = true; idx = k; } // no non-zero entry in this column: singular (newton/mod.rs:43-46)
         const int p = idx;
-        if (tid == 0) { piv[p0 + k] = p0 + p; if (failed) *fail = 1; }
+        pv[j] = p0 + p; // (stored after the four steps: a store here put a wait for the PREVIOUS step's store -- a write-through round trip -- into every step of the chain)
         if (failed) break; // (uniform: every thread reduced the same sixteen candidates)
         // Rows k and p meet in LDS: their owners publish them, take each other's, and everybody reads the pivot row.  Row k
         // (k < 64) is thread k's first row; row p is found by its one owner under a branch the other waves skip (first version:
@@ -324,11 +363,11 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restr
             }
         if (tid == k) {
 #pragma unroll
-            for (int jj = 0; jj < QN_LU_SUB; ++jj) rowk[j][jj] = a[jj][0];
+            for (int jj = 0; jj < QN_LU_SUB; ++jj) L.rowk[j][jj] = a[jj][0];
         }
         if (tid == tp) {
 #pragma unroll
-            for (int jj = 0; jj < QN_LU_SUB; ++jj) rowp[j][jj] = cp[jj];
+            for (int jj = 0; jj < QN_LU_SUB; ++jj) L.rowp[j][jj] = cp[jj];
         }
         __syncthreads();
         {
@@ -337,14 +376,14 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restr
             for (int jr = 0; jr < RPT; ++jr) {
                 const bool hit = own_p && jr == jp;
 #pragma unroll
-                for (int jj = 0; jj < QN_LU_SUB; ++jj) a[jj][jr] = hit ? rowk[j][jj] : a[jj][jr];
+                for (int jj = 0; jj < QN_LU_SUB; ++jj) a[jj][jr] = hit ? L.rowk[j][jj] : a[jj][jr];
             }
             // (after the owner of p: when both rows are this thread's, row k ends up with the pivot row)
 #pragma unroll
-            for (int jj = 0; jj < QN_LU_SUB; ++jj) a[jj][0] = own_k ? rowp[j][jj] : a[jj][0];
+            for (int jj = 0; jj < QN_LU_SUB; ++jj) a[jj][0] = own_k ? L.rowp[j][jj] : a[jj][0];
         }
         if (j == 0) QN_LU_STAMP(5);
-        const double inv_ukk = 1.0 / rowp[j][j]; // (one division per step and thread: eight of them per thread made a step 3 us on this one CU)
+        const double inv_ukk = 1.0 / L.rowp[j][j]; // (one division per step and thread: eight of them per thread made a step 3 us on this one CU)
 #pragma unroll
         for (int jr = 0; jr < RPT; ++jr) {
             const int i = tid + QN_LU_PT * jr;
@@ -353,21 +392,138 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restr
                 a[j][jr] = l;
 #pragma unroll
                 for (int jj = 0; jj < QN_LU_SUB; ++jj)
-                    if (jj > j) a[jj][jr] = a[jj][jr] - l * rowp[j][jj];
+                    if (jj > j) a[jj][jr] = a[jj][jr] - l * L.rowp[j][jj];
             }
         }
         if (j == 0) QN_LU_STAMP(6);
         if (j == 3) QN_LU_STAMP(7);
     }
+    if (tid == 0) {
+#pragma unroll
+        for (int j = 0; j < QN_LU_SUB; ++j) lu_sti<COH>(piv + p0 + QN_LU_SUB * s + j, pv[j]);
+        if (failed) lu_sti<COH>(fail, 1);
+    }
+    // (every row of the thread, no condition: see lu_col_store)
 #pragma unroll
     for (int jr = 0; jr < RPT; ++jr) {
-        const int i = tid + QN_LU_PT * jr;
-        if (i >= QN_LU_SUB * s && i < m) {
 #pragma unroll
-            for (int j = 0; j < QN_LU_SUB; ++j) P[(size_t)(c0 + j) * pld + i] = a[j][jr];
-        }
+        for (int j = 0; j < QN_LU_SUB; ++j) lu_st<COH>(P + (size_t)(c0 + j) * pld + tid + QN_LU_PT * jr, a[j][jr]);
     }
+    return failed;
+}
+
+template <int RPT>
+__global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restrict__ P, size_t pld, int m, int s, int p0, int* __restrict__ piv,
+                                                                 int* __restrict__ fail) {
+    QN_LU_STAMP(0);
+    if (*fail) return;
+    QN_LU_STAMP(1);
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    if (b == 1) { // role C: the swaps of sub-panel s - 1 on the columns left of it
+        if (s >= 2) lu_role_c<false>(P, pld, QN_LU_SUB * (s - 1), p0, piv, tid);
+        return;
+    }
+    const bool isA = b == 0;
+    if (isA && s >= QN_NB / QN_LU_SUB) return;
+    const int c0 = isA ? QN_LU_SUB * s : QN_LU_SUB * (s + 1) + (b - 2); // first column of this workgroup
+    const int nc = isA ? QN_LU_SUB : 1;
+    __shared__ QnLuLds L;
+    const int r0 = QN_LU_SUB * (s - 1);
+    double a[QN_LU_SUB][RPT];
+    lu_cols_update<RPT, false, (RPT >= 16 ? 1 : 4)>(P, pld, m, r0, s >= 1, c0, nc, p0, piv, L, a, tid);
+    if (!isA) { lu_col_store<RPT, false>(P, pld, m, r0, c0, a, tid); return; }
+    QN_LU_STAMP(2);
+    (void)lu_sub_factor<RPT, false>(P, pld, m, s, p0, piv, fail, L, a, tid);
     QN_LU_STAMP(8);
+}
+
+// ---- the panel in ONE launch (round 4) ----
+// 17 launches per panel are 16 kernel boundaries inside a dependent chain: ~4.6 us each between the last store of one and the first
+// load of the next, 2176 of them per factorisation at n = 8192 (10 ms of the chain's 41).  Here the same roles on the same columns
+// in the same order -- workgroup 0 factors the sub-panels one after another, workgroup 2 + j keeps column 8 + j up to date until it
+// becomes part of a sub-panel, workgroup 1 replays the swaps on the finished columns -- but as ONE grid of 58 workgroups that wait
+// for each other on counters in memory instead of on kernel boundaries:
+//     sync[0]      = base + s + 1  once sub-panel s and its pivots are stored (workgroup 0)
+//     sync[1 + c]  = base + s      once column c carries the update of sub-panel s - 1 (its workgroup)
+// (base = 32 x panel index: the counters only grow, nothing is reset between panels).  The workgroups sit on different XCDs -- different
+// L2s -- so inside this kernel EVERY access to the panel buffer, the pivots and the counters is a relaxed atomic at agent scope (sc1
+// loads and write-through stores, coherent per location by the memory model), a producer waits for its stores (s_waitcnt vmcnt(0))
+// and the workgroup barrier before it raises its counter, and no cache is flushed or invalidated.  (First version: plain accesses
+// between agent-scope release / acquire fences -- correct, and 565 us per panel against 458 with 17 launches: every release writes
+// the whole L2 of its XCD back, the trailing update's dirty lines included, 870 times per panel.)  Who waits for whom: a column for workgroup 0 only; workgroup 0,
+// at sub-panel s, for the four columns it is about to take -- the lowest-numbered columns still alive; workgroup 1 for both, and
+// nobody for workgroup 1.  Workgroups are placed in index order, so whoever is waited for is resident or next in line: the grid needs
+// three free CUs to finish, 58 to run as intended (the look-ahead leaves the panel chain 64, qn_hip.hip).  Every wait is BOUNDED: after
+// QN_LU_SPIN_MAX polls it gives up with *fail = 2, everybody else leaves at the next poll, and the host runs the factorisation again
+// with one launch per sub-panel (two solvers' panels sharing the free CUs could otherwise wait for each other's unplaced workgroups).
+#define QN_LU_SPIN_MAX (1 << 20)
+__device__ __forceinline__ bool lu_wait_ge(const int* flag, const int target, int* fail) {
+    for (int spin = 0; spin < QN_LU_SPIN_MAX; ++spin) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+// release: this thread's stores have left for the coherence point; acquire: nothing to do -- every load that follows goes there itself
+__device__ __forceinline__ void lu_release_all() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+template <int RPT>
+__global__ __launch_bounds__(QN_LU_PT) void lu_panel_persist_kernel(double* __restrict__ P, size_t pld, int m, int p0, int* __restrict__ piv, int* __restrict__ fail,
+                                                                    int* __restrict__ sync, int base) {
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    constexpr int NSUB = QN_NB / QN_LU_SUB;
+    if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    __shared__ QnLuLds L;
+    if (b == 0) { // role A: sub-panels 0 .. 15
+        for (int s = 0; s < NSUB; ++s) {
+            QN_LU_STAMP(0);
+            if (s >= 2) { // its four columns carry sub-panel s - 2 (their workgroups' last step)
+                const bool ok = tid < QN_LU_SUB ? lu_wait_ge(sync + 1 + QN_LU_SUB * s + tid, base + s - 1, fail) : true;
+                if (!__syncthreads_and(ok)) return;
+            }
+            QN_LU_STAMP(1);
+            double a[QN_LU_SUB][RPT];
+            lu_cols_update<RPT, true, (RPT >= 16 ? 1 : 4)>(P, pld, m, QN_LU_SUB * (s - 1), s >= 1, QN_LU_SUB * s, QN_LU_SUB, p0, piv, L, a, tid);
+            QN_LU_STAMP(2);
+            const bool failed = lu_sub_factor<RPT, true>(P, pld, m, s, p0, piv, fail, L, a, tid);
+            if (failed) return; // (*fail = 1: the others leave at their next poll)
+            QN_LU_STAMP(8);
+            lu_release_all(); // (also: the next sub-panel's update reads what other threads of this workgroup stored)
+            QN_LU_STAMP(9);
+            if (tid == 0) __hip_atomic_store(sync, base + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if (b == 1) { // role C: sub-panel sg - 1's swaps on the columns left of it, once nobody reads those in the old row order
+        for (int sg = 2; sg <= NSUB; ++sg) {
+            bool ok = true;
+            if (tid == 0) ok = lu_wait_ge(sync, base + sg, fail);
+            else if (tid < 1 + QN_NB && tid - 1 >= QN_LU_SUB * sg && tid - 1 >= 2 * QN_LU_SUB) ok = lu_wait_ge(sync + tid, base + sg - 1, fail);
+            if (!__syncthreads_and(ok)) return;
+            lu_role_c<true>(P, pld, QN_LU_SUB * (sg - 1), p0, piv, tid);
+        }
+        return;
+    }
+    // role B: column c, sub-panels 0 .. c / 4 - 2
+    const int c = 2 * QN_LU_SUB + (b - 2);
+    const int last = c / QN_LU_SUB - 1;
+    for (int sg = 1; sg <= last; ++sg) {
+        const bool ok = tid == 0 ? lu_wait_ge(sync, base + sg, fail) : true;
+        if (!__syncthreads_and(ok)) return;
+        double a[QN_LU_SUB][RPT];
+        const int r0 = QN_LU_SUB * (sg - 1);
+        lu_cols_update<RPT, true, (RPT >= 16 ? 4 : 16)>(P, pld, m, r0, true, c, 1, p0, piv, L, a, tid);
+        lu_col_store<RPT, true>(P, pld, m, r0, c, a, tid);
+        lu_release_all();
+        if (tid == 0) __hip_atomic_store(sync + 1 + c, base + sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __global__ __launch_bounds__(256) void lu_swap_rows_kernel(double* __restrict__ W, size_t ld, int p0, int ncols, const int* __restrict__ piv,
@@ -534,11 +690,13 @@ __global__ __launch_bounds__(256) void lu_gemm2_kernel(double* __restrict__ W, s
 }
 
 // x[i] = sign * b[perm[i]] (zero past n_src): the row permutation of the factorisation applied to a right-hand side
+// (`fill`: the vector the one-launch sweep that follows will write -- set to the sentinel its consumers wait on, lu_sweep_kernel)
 __global__ void lu_vec_perm_kernel(double* __restrict__ dst, const double* __restrict__ src, const int* __restrict__ perm, int n_src, int n_dst,
-                                   double sign) {
+                                   double sign, double* __restrict__ fill) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_dst; i += gridDim.x * blockDim.x) {
         const int p = perm[i];
         dst[i] = (p < n_src) ? sign * src[p] : 0.0;
+        if (fill) fill[i] = __longlong_as_double((long long)0x7ff8c0de5eed1e55ull);
     }
 }
 
@@ -594,6 +752,101 @@ __global__ __launch_bounds__(256) void lu_bwd_step_kernel(const double* __restri
         double p = W[(size_t)r * ld + k0 + lane] * zl;
         p = qn_wave_sum(p); // (xor 32, 16, ... 1 on the VALU data path: the same order as the __shfl_xor loop it replaces)
         if (lane == 0) rhs[r] = rhs[r] - p;
+    }
+}
+
+// ---- a whole substitution sweep in ONE launch (round 4) ----
+// The 128 step launches of a sweep are a dependent chain of 10-13 us links (launch, the diagonal block into LDS, 63 readlane steps,
+// the update of the rows below), 512 of them per Newton iteration: 6 ms.  Here workgroup j owns block row w (forward: w = j, backward:
+// w = nb - 1 - j), keeps its 64 running right-hand-side entries in registers, takes the solution blocks x_k of its predecessors as
+// they appear, subtracts W[w, k] x_k in the SAME order and with the same wave sums as the step kernels (row r: blocks k in sweep
+// order, each a product per lane and qn_wave_sum), then solves its own diagonal block as they do: the same bits.
+// How a block "appears": the solution vector is filled with a SENTINEL (a quiet NaN with a payload no arithmetic produces) before
+// the sweep, a solution entry is ONE 8-byte store, and a consumer's lane simply re-reads its entry (sc1: past the non-coherent cache
+// levels) until it is not the sentinel -- the datum is its own flag: no counter, no fence, one memory round trip per link instead of
+// two (first version: a counter raised after the block was stored -- 7.8 us per link, 4 ms per Newton iteration for the four sweeps).
+// The waves of a workgroup poll independently (no barrier inside the loop); the matrix rows of the next predecessor are requested
+// before the poll.  Who fills: the kernel that writes the right-hand side fills the sweep's output with sentinels
+// (lu_vec_perm_kernel), and a sweep workgroup that has taken its 64 right-hand-side entries puts sentinels in their place -- the
+// vector it read is the NEXT sweep's output.  A workgroup waits for lower-numbered workgroups only (placed before it); every wait
+// is bounded as in the panel kernel (*fail = 2, the host runs the factorisation again with step launches).
+#define QN_LU_SENTINEL 0x7ff8c0de5eed1e55ull
+__device__ __forceinline__ double lu_sentinel() { return __longlong_as_double((long long)QN_LU_SENTINEL); }
+__device__ __forceinline__ bool lu_is_sentinel(const double v) { return (unsigned long long)__double_as_longlong(v) == QN_LU_SENTINEL; }
+template <bool BWD>
+__global__ __launch_bounds__(256) void lu_sweep_kernel(const double* __restrict__ W, size_t ld, int nb, double* __restrict__ rhs, double* __restrict__ sol,
+                                                       int* __restrict__ fail) {
+    __shared__ double D[QN_NB][QN_NB + 1];
+    __shared__ double accs[QN_NB];
+    __shared__ int bail_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = blockIdx.x, w = BWD ? nb - 1 - j : j;
+    if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if (tid == 0) bail_s = 0;
+    qn_tile_to_lds<256, false>(D, W + (size_t)w * QN_NB * ld + (size_t)w * QN_NB, ld);
+    double acc[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) acc[jj] = rhs[w * QN_NB + wave + 4 * jj];
+    const double* __restrict__ rowp = W + (size_t)(w * QN_NB + wave) * ld + lane; // row wave + 4 jj: + 4 jj ld
+    double m[16];
+    if (j > 0) {
+        const int k = BWD ? nb - 1 : 0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) m[jj] = rowp[(size_t)(4 * jj) * ld + (size_t)k * QN_NB];
+    }
+    __syncthreads(); // (every wave has its right-hand-side entries: their places can take the sentinel; bail_s is set)
+    if (tid < QN_NB) lu_st<true>(rhs + w * QN_NB + tid, lu_sentinel());
+    bool bail = false;
+    for (int q = 0; q < j; ++q) {
+        const int k = BWD ? nb - 1 - q : q;
+        double xl = lu_ld<true>(sol + k * QN_NB + lane);
+        for (int spin = 0; __any(lu_is_sentinel(xl)); ++spin) {
+            if (spin >= QN_LU_SPIN_MAX) { if (lane == 0) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bail = true; break; }
+            if ((spin & 15) == 15 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bail = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+            xl = lu_ld<true>(sol + k * QN_NB + lane);
+        }
+        if (bail) break;
+        double mc[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) mc[jj] = m[jj];
+        if (q + 1 < j) { // the next predecessor's part of this wave's rows: in flight during the products and the next poll
+            const int kn = BWD ? k - 1 : k + 1;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) m[jj] = rowp[(size_t)(4 * jj) * ld + (size_t)kn * QN_NB];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            double p = mc[jj] * xl;
+            p = qn_wave_sum(p);
+            acc[jj] = acc[jj] - p;
+        }
+    }
+    if (bail && lane == 0) bail_s = 1;
+    if (lane == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) accs[wave + 4 * jj] = acc[jj];
+    }
+    __syncthreads();
+    if (bail_s) return; // (nothing is published: the successors give up at their own bound or see *fail)
+    if (wave == 0) {
+        double v = accs[lane];
+        if (!BWD) {
+#pragma unroll
+            for (int c = 0; c < 63; ++c) {
+                const double xc = qn_readlane_d(v, c);
+                if (lane > c) v = v - D[lane][c] * xc;
+            }
+        } else {
+#pragma unroll
+            for (int c = 63; c >= 0; --c) {
+                const double zc = qn_readlane_d(v, c) / D[c][c];
+                if (lane == c) v = zc;
+                if (lane < c) v = v - D[lane][c] * zc;
+            }
+        }
+        if (lu_is_sentinel(v)) v = __longlong_as_double(0x7ff8000000000000ll); // (cannot come out of arithmetic; if it ever did, it must not read as "not yet")
+        lu_st<true>(sol + w * QN_NB + lane, v);
     }
 }
 

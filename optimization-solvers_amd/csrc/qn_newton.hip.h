@@ -60,20 +60,13 @@ __device__ __forceinline__ double qn_readlane_d(double v, int l) { // wave-unifo
 #else
 #define QN_DSTAMP(i)
 #endif
-__global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__ W, size_t ld, int k0, double* __restrict__ invL,
-                                                            int* __restrict__ fail) {
-    __shared__ double a[QN_NB][QN_NB + 1];
-    __shared__ double col[2][QN_NB];
-    __shared__ double xrow[2][QN_NB];
-    __shared__ int bad_s;
-    QN_DSTAMP(0);
-    __builtin_amdgcn_s_setprio(3); // (a link of the dependent chain: it may run beside the bulk of a trailing update, see enqueue_newton)
-    if (*fail) return;
+// (the body: the tile is in `a`, *bad_s == 0, the workgroup has met at a barrier.  chol_diag_inv_kernel runs it on a tile it loads;
+// chol_syrk_kernel's first workgroup runs it on the diagonal tile it has just updated -- one launch and one kernel boundary less in
+// every link of the chain)
+__device__ __forceinline__ void chol_diag_inv_body(double (*a)[QN_NB + 1], double (*col)[QN_NB], double (*xrow)[QN_NB], int* bad_sp, double* __restrict__ W,
+                                                   const size_t ld, const int k0, double* __restrict__ invL, int* __restrict__ fail) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    qn_tile_to_lds<256, false>(a, W + (size_t)k0 * ld + k0, ld);
-    if (tid == 0) bad_s = 0;
-    __syncthreads();
-    QN_DSTAMP(1);
+    int& bad_s = *bad_sp;
     double r[16], x[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) { r[c] = a[lane][16 * wave + c]; x[c] = (16 * wave + c == lane) ? 1.0 : 0.0; }
@@ -123,6 +116,22 @@ __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__
     for (int ii = 0; ii < 16; ++ii) { const int i = 16 * wave + ii; invL[i * QN_NB + lane] = (lane <= i) ? x[ii] : 0.0; }
     QN_DSTAMP(4);
     QN_DSTAMP(5);
+}
+__global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__ W, size_t ld, int k0, double* __restrict__ invL,
+                                                            int* __restrict__ fail) {
+    __shared__ double a[QN_NB][QN_NB + 1];
+    __shared__ double col[2][QN_NB];
+    __shared__ double xrow[2][QN_NB];
+    __shared__ int bad_s;
+    QN_DSTAMP(0);
+    __builtin_amdgcn_s_setprio(3); // (a link of the dependent chain: it may run beside the bulk of a trailing update, see enqueue_newton)
+    if (*fail) return;
+    const int tid = threadIdx.x;
+    qn_tile_to_lds<256, false>(a, W + (size_t)k0 * ld + k0, ld);
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
+    QN_DSTAMP(1);
+    chol_diag_inv_body(a, col, xrow, &bad_s, W, ld, k0, invL, fail);
 }
 
 // 64 x 64 x 64 product on the f64 matrix cores from two k-major LDS panels: acc[a][b] += PI[:, wi+16a ..]' PJ[:, wj+16b ..]
@@ -193,14 +202,21 @@ static inline int qn_tri_tiles(int nrows_t, int ncols_t) { // number of tiles wi
 }
 // (`chain`: the launch is a link of the factorisation's dependent chain and runs beside the bulk of a trailing update on another
 // stream: its waves ask the SIMD's arbiter for priority -- see the look-ahead in enqueue_newton)
-__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, size_t ld, int kb, int klen, int c0, int ncols, const int* __restrict__ fail,
-                                                        int chain = 0) {
+// (`invL_next`: when given, the workgroup of the first tile -- the diagonal tile at c0, the next link's -- goes on to factorise and
+// invert it (chol_diag_inv_body) instead of handing it to a launch of its own: the tile goes from the accumulators to LDS, not through
+// memory, and the chain loses a kernel boundary per 64 columns.)
+__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, size_t ld, int kb, int klen, int c0, int ncols, int* __restrict__ fail,
+                                                        int chain = 0, double* __restrict__ invL_next = nullptr) {
     if (chain) __builtin_amdgcn_s_setprio(3);
     int ti, tj;
     qn_tri_tile(blockIdx.x, ncols, ti, tj);
     if (*fail) return;
-    __shared__ double PI[QN_KC][QN_NB + 1];
-    __shared__ double PJ[QN_KC][QN_NB + 1];
+    __shared__ double PP[2][QN_KC][QN_NB + 1]; // the two panels' chunks; afterwards (first workgroup) the 64 x 65 tile of the diagonal block
+    __shared__ double dcol[2][QN_NB];
+    __shared__ double dxrow[2][QN_NB];
+    __shared__ int dbad;
+    double (*PI)[QN_NB + 1] = PP[0];
+    double (*PJ)[QN_NB + 1] = PP[1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = c0 + ti * QN_NB, j0 = c0 + tj * QN_NB;
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
@@ -247,6 +263,19 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, 
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
                 W[(size_t)(i0 + wi + a * 16 + l4 + 4 * reg) * ld + j0 + wj + b * 16 + l15] = -acc[a][b][reg];
+    if (invL_next != nullptr && blockIdx.x == 0) { // (uniform per workgroup; tile (0, 0): i0 = j0 = c0)
+        double (*T)[QN_NB + 1] = reinterpret_cast<double (*)[QN_NB + 1]>(&PP[0][0][0]);
+        __syncthreads(); // (the last chunk's reads of the panels)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) T[wi + a * 16 + l4 + 4 * reg][wj + b * 16 + l15] = -acc[a][b][reg];
+        if (tid == 0) dbad = 0;
+        __syncthreads();
+        chol_diag_inv_body(T, dcol, dxrow, &dbad, W, ld, c0, invL_next, fail);
+    }
 }
 
 // ---- triangular solves with a vector right-hand side, one launch per 64-block ----

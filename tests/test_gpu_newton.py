@@ -281,19 +281,22 @@ def test_panel_lu_equals_the_per_column_lu_bit_for_bit(qn, qo, n):
     which are the ones config 4 (n = 8192) runs.
     Round 4: from 8 panels on the default path also runs the LOOK-AHEAD (the trailing update split between the solver's stream and a
     CU-masked second stream, the U12 solve row by row with scalar multipliers, the update as a resident grid that loops);
-    set_tiling(-10, 0) is the single-stream path with rounds 1-3's kernels -- the same bits again."""
+    set_tiling(-10, 0) is the single-stream path with rounds 1-3's kernels -- the same bits again.  And the panel itself is ONE launch
+    (58 workgroups waiting for each other on counters, lu_panel_persist_kernel); set_tiling(-11, 0) is round 3's launch per sub-panel."""
     fn, hess0, x0 = _double_well_chain(n)
     iters = 3 if n <= 2000 else 1
     rng = np.random.default_rng(8)
     k = 0.2 * np.triu(rng.standard_normal((n, n)), 1) / np.sqrt(n)
     hess = lambda x: hess0(x) + k - k.T  # noqa: E731
     runs = []
-    for percol, no_la in ((False, False), (True, True), (False, True)):
+    for percol, no_la, no_persist in ((False, False, False), (True, True, True), (False, True, False), (False, False, True)):
         s = qn.Newton(1e-10, x0)
         if percol:
             s.set_tiling(-8, 0)
         if no_la:
             s.set_tiling(-10, 0)
+        if no_persist:
+            s.set_tiling(-11, 0)
         s.set_trace(iters, with_x=True)
         try:
             s.minimize(qn.MoreThuente(), lambda x: qn.FuncEvalMultivariate(*fn(x)).with_hessian(hess(x)), iters, 20)
@@ -304,6 +307,7 @@ def test_panel_lu_equals_the_per_column_lu_bit_for_bit(qn, qo, n):
     key = lambda tr: [(r["f"], r["gnorm"], r["t"], r["n_evals"], r["ls_cases"]) for r in tr]  # noqa: E731  (s_norm / y_norm are NaN: Newton has none)
     assert key(runs[0][0]) == key(runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
     assert key(runs[0][0]) == key(runs[2][0]) and np.array_equal(runs[0][1], runs[2][1])
+    assert key(runs[0][0]) == key(runs[3][0]) and np.array_equal(runs[0][1], runs[3][1])
     assert runs[0][2] < runs[1][2]
     # and the direction is the Newton direction of the matrix as given
     f0, g0 = fn(x0)

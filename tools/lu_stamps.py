@@ -1,5 +1,6 @@
-"""Diagnostic: in-kernel time stamps of lu_panel_step_kernel's role A (build csrc/qn_hip.hip with -DQN_LU_STAMPS into
-optimization-solvers_amd/lib/libqn_hip_lustamps.so); prints, for the step launches of the last panel, ns since kernel entry."""
+"""Diagnostic: in-kernel time stamps of role A of the LU panel (lu_panel_persist_kernel, or lu_panel_step_kernel with QN_LU_PERSIST=0):
+build csrc/qn_hip.hip with -DQN_LU_STAMPS [-DQN_LU_STAMP_P0=<first column of the panel to stamp, default 640>] into
+optimization-solvers_amd/lib/libqn_hip_lustamps.so; prints, per sub-panel of that panel, ns since the sub-panel's first stamp."""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,9 +25,9 @@ L = A.lib()
 L.qn_debug_lu_stamps.argtypes = [C.c_void_p]
 L.qn_debug_lu_stamps(buf.ctypes.data_as(C.c_void_p))
 st = buf.reshape(64, 16).astype(np.int64)
-names = ["entry", "flag read", "columns loaded/updated", "search done", "after barrier", "rows exchanged", "step 0 done", "step 3 done", "stored"]
+names = ["entry", "flag read / waited", "columns loaded/updated", "search done", "after barrier", "rows exchanged", "step 0 done", "step 3 done", "stores issued", "stores complete"]
 for s_ in range(17):
     t = st[s_]
     if t[0] == 0:
         continue
-    print("launch s=%2d:" % s_, ", ".join("%s %d" % (names[k], (t[k] - t[0]) * 10) for k in range(1, 9) if t[k] > 0))
+    print("launch s=%2d:" % s_, ", ".join("%s %d" % (names[k], (t[k] - t[0]) * 10) for k in range(1, 10) if t[k] > 0))
