@@ -619,21 +619,28 @@ template <int R>
 static void launch_hpass(hipStream_t st, const QnHPassArgs& a);
 
 // enqueue one evaluation of the log-sum-exp objective at x_dev (n_pad entries): f -> f_dev, g -> g_dev
-template <int KCH>
-static int lse_launch_onepass(hipStream_t st, int G, const QnLseArgs& a, double* wgms, double* wgg) {
+template <int KCH, bool NTA>
+static int lse_launch_onepass_nt(hipStream_t st, int G, const QnLseArgs& a, double* wgms, double* wgg) {
     static std::atomic<bool> attr_set[64]; // per device: hipFuncSetAttribute applies to the current device only (atomic: ranks may be threads)
     int dev = 0;
     (void)hipGetDevice(&dev);
     const size_t lds = (size_t)KCH * 1024 * sizeof(double);
     if ((dev < 0 || dev >= 64 || !attr_set[dev].load()) && lds > 48 * 1024) { // x in LDS: up to 128 KB of the CU's 160 KB
-        if (hipFuncSetAttribute((const void*)lse_onepass_kernel<KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)lse_onepass_kernel<KCH, NTA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             return -1; // this device does not grant the LDS: the caller keeps the two-pass evaluation
         }
         if (dev >= 0 && dev < 64) attr_set[dev].store(true);
     }
-    hipLaunchKernelGGL((lse_onepass_kernel<KCH>), dim3(G), dim3(512), lds, st, a, wgms, wgg);
+    hipLaunchKernelGGL((lse_onepass_kernel<KCH, NTA>), dim3(G), dim3(512), lds, st, a, wgms, wgg);
     return QN_OK;
+}
+template <int KCH>
+static int lse_launch_onepass(hipStream_t st, int G, const QnLseArgs& a, double* wgms, double* wgg) {
+    // rows of A that cannot stay in the 256 MB Infinity Cache between evaluations are requested as non-temporal (QN_LSE_NT = 0 / 1 overrides)
+    static const int nt_env = getenv("QN_LSE_NT") ? atoi(getenv("QN_LSE_NT")) : -1;
+    const bool nt = nt_env >= 0 ? nt_env != 0 : (size_t)a.mrpr * (size_t)a.n_pad * sizeof(double) > ((size_t)230 << 20);
+    return nt ? lse_launch_onepass_nt<KCH, true>(st, G, a, wgms, wgg) : lse_launch_onepass_nt<KCH, false>(st, G, a, wgms, wgg);
 }
 
 static int lse_enqueue_eval(qn_objective* o, const double* x_dev, double* f_dev, double* g_dev) {

@@ -769,7 +769,9 @@ __global__ void lse_finish_kernel(const QnLseArgs a) {
 // butterfly, eight partials through LDS, ONE barrier per row -- a row is 128 KB, 5 us of HBM time per CU, the barrier hides in it).
 // lse_combine_kernel folds the workgroups' (m, S, G) in workgroup order, the ranks' results are exchanged once, lse_finish1_kernel
 // folds them in rank order: f = M + log S + mu/2 ||x||^2, g = G / S + mu x.  Every order is fixed: reproducible bit for bit.
-template <int KCH>
+// NTA: the rows of A as non-temporal loads -- A is read once per evaluation and, at the sizes this kernel is for, does not fit the
+// Infinity Cache (n = m = 16384: 2.1 GB): nothing of it is worth keeping (tools/stream_shape_probe.hip: 6.5-6.85 TB/s against 6.1-6.3)
+template <int KCH, bool NTA>
 __global__ __launch_bounds__(512) void lse_onepass_kernel(const QnLseArgs a, double* __restrict__ wgms, double* __restrict__ wgg) {
     extern __shared__ __attribute__((aligned(16))) double lse_x[]; // KCH * 1024 entries of x, zero past n_pad
     __shared__ double red[2][8];
@@ -795,12 +797,12 @@ __global__ __launch_bounds__(512) void lse_onepass_kernel(const QnLseArgs a, dou
     double m_run = -INFINITY, s_run = 0.0;
     if (r_lo < r_hi) {
 #pragma unroll
-        for (int k = 0; k < KCH; ++k) cur[k] = ld2(a.A + (size_t)r_lo * np + QN_LSE_JC(k));
+        for (int k = 0; k < KCH; ++k) cur[k] = NTA ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(a.A + (size_t)r_lo * np + QN_LSE_JC(k))) : ld2(a.A + (size_t)r_lo * np + QN_LSE_JC(k));
     }
     for (int r = r_lo; r < r_hi; ++r) {
         const double* nrow = a.A + (size_t)((r + 1 < r_hi) ? r + 1 : r) * np; // (last row: a harmless re-read, no branch)
 #pragma unroll
-        for (int k = 0; k < KCH; ++k) nxt[k] = ld2(nrow + QN_LSE_JC(k));
+        for (int k = 0; k < KCH; ++k) nxt[k] = NTA ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(nrow + QN_LSE_JC(k))) : ld2(nrow + QN_LSE_JC(k));
         double p = 0.0;
 #pragma unroll
         for (int k = 0; k < KCH; ++k) {
