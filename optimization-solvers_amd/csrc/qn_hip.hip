@@ -2247,7 +2247,8 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     HIPCHK(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
     hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, W, ld, n, n64, hsrc, ld_src); // both triangles
     uint64_t launches = 1;
-    if (!s->newton_panel) HIPCHK(hipMalloc((void**)&s->newton_panel, (size_t)QN_NB * QN_LU_PT * QN_LU_RPT * sizeof(double)));
+    const size_t panel_doubles = (size_t)QN_NB * QN_LU_PT * QN_LU_RPT; // (two buffers: the look-ahead writes the next panel's while this one's is still read)
+    if (!s->newton_panel) HIPCHK(hipMalloc((void**)&s->newton_panel, 2 * panel_doubles * sizeof(double)));
     if (!s->newton_sync) HIPCHK(hipMalloc((void**)&s->newton_sync, 128 * sizeof(int)));
     HIPCHK(hipMemsetAsync(s->newton_sync, 0, 128 * sizeof(int), st));
     static const int lu_persist_on = getenv("QN_LU_PERSIST") ? atoi(getenv("QN_LU_PERSIST")) : 1;
@@ -2278,13 +2279,18 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
         if (dev < 0 || dev >= 64 || attr_state[dev].load() != 1) bulk_lds = 0;
     }
     int last_f = -1;
+    static const int la_fused = getenv("QN_LU_LA_FUSED") ? atoi(getenv("QN_LU_LA_FUSED")) : 1;
+    bool p_ready = false; // the look-ahead update of the previous panel has already written this panel's buffer
     for (int p0 = 0, pi = 0; p0 < nlu; p0 += QN_NB, ++pi) {
         const int m = nlu - p0;
+        bool in_p = false; // this panel was factorised in its column-major buffer (and, with the fused look-ahead, is not yet back in W)
         if (m <= QN_LU_PT * QN_LU_RPT && !s->newton_lu_percol) {
             // the panel in a column-major buffer, four columns at a time (qn_lu.hip.h: 19 launches instead of 128)
-            double* P = s->newton_panel;
+            double* P = s->newton_panel + (size_t)(pi & 1) * panel_doubles;
             const size_t pld = (size_t)QN_LU_PT * QN_LU_RPT;
-            hipLaunchKernelGGL(lu_panel_load_kernel, dim3(m / QN_NB), dim3(256), 0, st, W, ld, p0, P, pld, flag);
+            if (!p_ready) { hipLaunchKernelGGL(lu_panel_load_kernel, dim3(m / QN_NB), dim3(256), 0, st, W, ld, p0, P, pld, flag); launches++; }
+            p_ready = false;
+            in_p = true;
             const int rpt_p = (m + QN_LU_PT - 1) / QN_LU_PT;
             if (persist) { // the panel in one launch: 58 workgroups waiting for each other on counters (qn_lu.hip.h)
                 const dim3 pg(2 + QN_NB - 2 * QN_LU_SUB), pb(QN_LU_PT);
@@ -2306,8 +2312,8 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
                 else if (rpt <= 8) hipLaunchKernelGGL(lu_panel_step_kernel<8>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
                 else hipLaunchKernelGGL(lu_panel_step_kernel<QN_LU_RPT>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
             }
-            hipLaunchKernelGGL(lu_panel_store_kernel, dim3(m / QN_NB), dim3(256), 0, st, W, ld, p0, P, pld, flag);
-            launches += 2 + (persist ? 0 : 1 + QN_NB / QN_LU_SUB);
+            if (!(la && la_fused)) hipLaunchKernelGGL(lu_panel_store_kernel, dim3(m / QN_NB), dim3(256), 0, st, W, ld, p0, P, pld, flag); // (else: on the second stream, below)
+            launches += 1 + (persist ? 0 : 1 + QN_NB / QN_LU_SUB);
         } else {
             for (int k = p0; k < p0 + QN_NB; ++k) {
                 hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(1024), 0, st, W, ld, k, p0, nlu, s->newton_piv, flag);
@@ -2331,17 +2337,34 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
         }
         const int la_lo = p0 + QN_NB, la_hi = std::min(la_lo + QN_NB, nlu); // the next panel's columns
         const int below = nlu - la_lo;                                       // rows (and columns) right of / below this panel
+        const bool fused = la_fused && in_p; // the chain's part reads the panel from its buffer; the copy back into W goes to the second stream
+        double* Pc = s->newton_panel + (size_t)(pi & 1) * panel_doubles;
+        double* Pn = s->newton_panel + (size_t)((pi + 1) & 1) * panel_doubles;
+        const size_t pld_c = (size_t)QN_LU_PT * QN_LU_RPT;
         // the next panel's columns on this stream -- once the previous panel's bulk, which wrote them too, is through
         if (la_hi > la_lo) {
             if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
-            hipLaunchKernelGGL(lu_swap_rows2_kernel, dim3(1), dim3(64), 0, st, W, ld, p0, la_lo, la_hi, s->newton_piv, flag);
-            hipLaunchKernelGGL(lu_trsm2_kernel<1>, dim3((la_hi - la_lo + 3) / 4), dim3(256), 0, st, W, ld, p0, la_lo, la_hi, flag);
-            hipLaunchKernelGGL(lu_gemm2_kernel, dim3(below / QN_NB), dim3(256), 0, st, W, ld, p0, la_lo, 1, below / QN_NB, flag, 1);
-            launches += 3;
+            if (fused) { // two launches, the second one leaving the next panel in its buffer (qn_lu.hip.h; the next panel is shorter: it fits)
+                hipLaunchKernelGGL(lu_la_swap_trsm_kernel, dim3((la_hi - la_lo + 3) / 4), dim3(256), 0, st, W, ld, p0, la_lo, la_hi, Pc, pld_c, s->newton_piv, flag);
+                hipLaunchKernelGGL(lu_la_gemm_kernel, dim3(below / QN_NB), dim3(256), 0, st, W, ld, p0, la_lo, Pc, pld_c, Pn, flag);
+                p_ready = true;
+                launches += 2;
+            } else {
+                hipLaunchKernelGGL(lu_swap_rows2_kernel, dim3(1), dim3(64), 0, st, W, ld, p0, la_lo, la_hi, s->newton_piv, flag);
+                hipLaunchKernelGGL(lu_trsm2_kernel<1>, dim3((la_hi - la_lo + 3) / 4), dim3(256), 0, st, W, ld, p0, la_lo, la_hi, flag);
+                hipLaunchKernelGGL(lu_gemm2_kernel, dim3(below / QN_NB), dim3(256), 0, st, W, ld, p0, la_lo, 1, below / QN_NB, flag, 1);
+                launches += 3;
+            }
         }
-        // everything else beside the next panel's chain
+        // everything else beside the next panel's chain (the event behind the look-ahead launches, not in front of them: its packet and
+        // the wait's were 13 us between the panel and the first look-ahead kernel.  For the tall panels, whose bulk is as long as the
+        // next panel's chain, in front measured the same: 45.5 against 45.2 ms)
         HIPCHK(hipEventRecord(c->la_events[2 * pi], st));
         HIPCHK(hipStreamWaitEvent(c->stream_lu, c->la_events[2 * pi], 0));
+        if (fused) { // the panel back into W, in front of the bulk that reads it there
+            hipLaunchKernelGGL(lu_panel_store_kernel, dim3(m / QN_NB), dim3(256), 0, c->stream_lu, W, ld, p0, Pc, pld_c, flag);
+            launches++;
+        }
         if (p0 > 0) hipLaunchKernelGGL(lu_swap_rows2_kernel, dim3(std::min(64, (p0 + 255) / 256)), dim3(256), 0, c->stream_lu, W, ld, p0, 0, p0, s->newton_piv, flag);
         const int rest = nlu - la_hi;
         if (rest > 0) {

@@ -689,6 +689,102 @@ __global__ __launch_bounds__(256) void lu_gemm2_kernel(double* __restrict__ W, s
     }
 }
 
+// ---- the look-ahead columns in TWO launches that read the panel from its column-major buffer (round 4) ----
+// Between two panels the chain ran: store the panel back (P -> W), swaps / U12 solve / update on the next panel's 64 columns, load
+// them into the buffer -- five launches, 46 us.  Now the factorised panel STAYS in its buffer for the chain's purposes (the copy back
+// into W moves to the second stream, in front of the bulk that needs it there):
+//   lu_la_swap_trsm_kernel  one wave per look-ahead column: the panel's 64 row swaps replayed on the column in registers (the block
+//                           row in the wave's lanes, the rows further down in one slot per pivot), then lu_trsm2_kernel's 63 steps
+//                           with L11 taken from the buffer;
+//   lu_la_gemm_kernel       lu_gemm2_kernel's tile with L21 taken from the buffer, the result written to W AND, transposed through
+//                           LDS, into the OTHER buffer as the next panel's columns (lu_panel_load_kernel's job).
+// Same operations in the same order on every entry: the bits of the five launches.
+__global__ __launch_bounds__(256) void lu_la_swap_trsm_kernel(double* __restrict__ W, size_t ld, int p0, int col_lo, int col_hi, const double* __restrict__ P, size_t pld,
+                                                              const int* __restrict__ piv, const int* __restrict__ fail) {
+    __builtin_amdgcn_s_setprio(3);
+    if (*fail) return;
+    __shared__ double LT[QN_NB][QN_NB + 1]; // LT[c][r] = L11[r][c] = P[c][r]
+    __shared__ int pv[QN_NB], canon[QN_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < QN_NB * QN_NB; e += 256) LT[e >> 6][e & 63] = P[(size_t)(e >> 6) * pld + (e & 63)];
+    if (tid < QN_NB) pv[tid] = piv[p0 + tid];
+    __syncthreads();
+    if (tid < QN_NB) { // the first pivot step that names the same row (outside the block row: that step's slot holds the row's value)
+        int cq = tid;
+        for (int q = tid - 1; q >= 0; --q)
+            if (pv[q] == pv[tid]) cq = q;
+        canon[tid] = cq;
+    }
+    __syncthreads();
+    const int j = col_lo + blockIdx.x * 4 + wave;
+    if (j >= col_hi) return; // (uniform per wave; no barrier below)
+    const int myp = pv[lane], mycanon = canon[lane];
+    const bool outside = myp >= p0 + QN_NB;
+    double x = W[(size_t)(p0 + lane) * ld + j];                 // row p0 + lane
+    double y = outside ? W[(size_t)myp * ld + j] : 0.0;          // slot `lane`: row piv[lane] when it lies below the block row
+#pragma unroll
+    for (int q = 0; q < QN_NB; ++q) {                            // (uniform: step q's pivot and slot by v_readlane from the lanes that hold them)
+        const int p = __builtin_amdgcn_readlane(myp, q);
+        if (p != p0 + q) {
+            const double a = qn_readlane_d(x, q);
+            if (p < p0 + QN_NB) {
+                const double b = qn_readlane_d(x, p - p0);
+                x = (lane == q) ? b : ((lane == p - p0) ? a : x);
+            } else {
+                const int cq = __builtin_amdgcn_readlane(mycanon, q);
+                const double b = qn_readlane_d(y, cq);
+                x = (lane == q) ? b : x;
+                y = (lane == cq) ? a : y;
+            }
+        }
+    }
+    if (outside && mycanon == lane) W[(size_t)myp * ld + j] = y;
+#pragma unroll
+    for (int c = 0; c < 63; ++c) {
+        const double l = LT[c][lane];
+        const double t = x - l * qn_readlane_d(x, c);
+        x = (lane > c) ? t : x;
+    }
+    W[(size_t)(p0 + lane) * ld + j] = x;
+}
+__global__ __launch_bounds__(256) void lu_la_gemm_kernel(double* __restrict__ W, size_t ld, int p0, int col_lo, const double* __restrict__ P, size_t pld,
+                                                         double* __restrict__ Pn, const int* __restrict__ fail) {
+    __builtin_amdgcn_s_setprio(3);
+    if (*fail) return;
+    __shared__ double PI[QN_NB][QN_NB + 1]; // PI[k][i] = L21[i0 + i][p0 + k] = P[k][i0 - p0 + i]
+    __shared__ double PJ[QN_NB][QN_NB + 1]; // PJ[k][j] = U12[p0 + k][col_lo + j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int i0 = p0 + 64 + blockIdx.x * 64, j0 = col_lo;
+    for (int e = tid; e < QN_NB * QN_NB; e += 256) PI[e >> 6][e & 63] = P[(size_t)(e >> 6) * pld + (i0 - p0) + (e & 63)];
+    qn_tile_to_lds<256, false>(PJ, W + (size_t)p0 * ld + j0, ld);
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                acc[a][b][reg] = -W[(size_t)(i0 + wi + a * 16 + l4 + 4 * reg) * ld + j0 + wj + b * 16 + l15];
+    __syncthreads();
+    qn_mfma_64(PI, PJ, QN_NB, wi, wj, lane, acc);
+    __syncthreads(); // (PI is reused for the transposed result)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const double v = -acc[a][b][reg];
+                W[(size_t)(i0 + wi + a * 16 + l4 + 4 * reg) * ld + j0 + wj + b * 16 + l15] = v;
+                PI[wj + b * 16 + l15][wi + a * 16 + l4 + 4 * reg] = v; // [column][row]
+            }
+    __syncthreads();
+    // the next panel starts at row and column p0 + 64: its buffer row of global row i is i - (p0 + 64)
+    for (int e = tid; e < QN_NB * QN_NB; e += 256) Pn[(size_t)(e >> 6) * pld + (size_t)(i0 - p0 - 64) + (e & 63)] = PI[e >> 6][e & 63];
+}
+
 // x[i] = sign * b[perm[i]] (zero past n_src): the row permutation of the factorisation applied to a right-hand side
 // (`fill`: the vector the one-launch sweep that follows will write -- set to the sentinel its consumers wait on, lu_sweep_kernel)
 __global__ void lu_vec_perm_kernel(double* __restrict__ dst, const double* __restrict__ src, const int* __restrict__ perm, int n_src, int n_dst,

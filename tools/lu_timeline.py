@@ -1,10 +1,12 @@
 """Timeline of the last LU factorisation in a rocprofv3 kernel trace (gpurun_out/lu_prof): per-kernel totals by queue, and for a few
-panels the start / end of every launch relative to the panel's load kernel -- does the bulk (second stream) run beside the chain?"""
+panels the start / end of every launch relative to the panel's first kernel -- does the bulk (second stream) run beside the chain?"""
 import csv, glob, sys
 f = glob.glob("gpurun_out/lu_prof/**/p_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-loads = [i for i, r in enumerate(rows) if "lu_panel_load" in r["Kernel_Name"]]
+loads = [i for i, r in enumerate(rows) if "lu_panel_persist" in r["Kernel_Name"]]  # one per panel (the one-launch panel)
+if len(loads) < 128:
+    loads = [i for i, r in enumerate(rows) if "lu_panel_load" in r["Kernel_Name"]]
 start = loads[-128]
 t0 = int(rows[start]["Start_Timestamp"])
 d = {}
