@@ -849,6 +849,7 @@ struct qn_solver {
     bool newton_lu_percol = false;  // diagnostics: the panel factorisation with two launches per column (rounds 1-2)
     std::vector<int> newton_piv_host;
     uint64_t newton_lu_runs = 0, newton_chol_runs = 0;
+    int newton_lu_force_timeout = 0; // diagnostics (rows = -12): the one-launch kernels' waits give up at once (exercises the fallback)
     int newton_lu_no_persist = 0; // diagnostics (rows = -11), or set after a bounded wait of the one-launch panel gave up: one launch per sub-panel
     int* newton_sync = nullptr;   // the one-launch panel's counters (qn_lu.hip.h, lu_panel_persist_kernel)
     uint64_t newton_lu_sync_timeouts = 0;
@@ -1234,6 +1235,7 @@ extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_sp
     if (rows_per_block == -1) { s->no_fused = 1; rows_per_block = 0; }
     if (rows_per_block == -3) { s->no_sym = 1; rows_per_block = 0; }   // diagnostics: fused row kernels on the full matrices
     if (rows_per_block == -5) { s->newton_force_lu = 1; return QN_OK; } // diagnostics: Newton by pivoted LU even for an SPD Hessian
+    if (rows_per_block == -12) { s->newton_lu_force_timeout = 1; return QN_OK; } // diagnostics: the one-launch kernels' bounded waits expire at once
     if (rows_per_block == -11) { s->newton_lu_no_persist = 1; return QN_OK; } // diagnostics: ... the panel with one launch per sub-panel
     if (rows_per_block == -10) { s->newton_lu_no_la = 1; return QN_OK; } // diagnostics: ... one stream, no look-ahead
     if (rows_per_block == -8) { s->newton_lu_percol = 1; return QN_OK; } // diagnostics: ... with the per-column panel kernels
@@ -2253,6 +2255,7 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     HIPCHK(hipMemsetAsync(s->newton_sync, 0, 128 * sizeof(int), st));
     static const int lu_persist_on = getenv("QN_LU_PERSIST") ? atoi(getenv("QN_LU_PERSIST")) : 1;
     const bool persist = lu_persist_on && !s->newton_lu_no_persist;
+    const int spin_max = s->newton_lu_force_timeout ? 0 : QN_LU_SPIN_MAX; // (diagnostics: every wait that is not satisfied at once gives up -> the fallback below)
     // LOOK-AHEAD (round 4, as in the Cholesky path: enqueue_newton).  A panel's factorisation is a chain of 17 small launches (one CU
     // working through 64 pivot steps: 150-400 us); what it needs from the previous panel is its own 64 columns brought up to date.
     // So after panel p: its swaps, U12 solve and update on the NEXT panel's columns on this stream, and everything else -- the swaps
@@ -2295,11 +2298,11 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
             if (persist) { // the panel in one launch: 58 workgroups waiting for each other on counters (qn_lu.hip.h)
                 const dim3 pg(2 + QN_NB - 2 * QN_LU_SUB), pb(QN_LU_PT);
                 const int base = 32 * pi;
-                if (rpt_p <= 1) hipLaunchKernelGGL(lu_panel_persist_kernel<1>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base);
-                else if (rpt_p <= 2) hipLaunchKernelGGL(lu_panel_persist_kernel<2>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base);
-                else if (rpt_p <= 4) hipLaunchKernelGGL(lu_panel_persist_kernel<4>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base);
-                else if (rpt_p <= 8) hipLaunchKernelGGL(lu_panel_persist_kernel<8>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base);
-                else hipLaunchKernelGGL(lu_panel_persist_kernel<QN_LU_RPT>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base);
+                if (rpt_p <= 1) hipLaunchKernelGGL(lu_panel_persist_kernel<1>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max);
+                else if (rpt_p <= 2) hipLaunchKernelGGL(lu_panel_persist_kernel<2>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max);
+                else if (rpt_p <= 4) hipLaunchKernelGGL(lu_panel_persist_kernel<4>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max);
+                else if (rpt_p <= 8) hipLaunchKernelGGL(lu_panel_persist_kernel<8>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max);
+                else hipLaunchKernelGGL(lu_panel_persist_kernel<QN_LU_RPT>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max);
                 launches += 1;
             } else
             for (int sp = 0; sp <= QN_NB / QN_LU_SUB; ++sp) {
@@ -2407,8 +2410,8 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     auto solve = [&](double* x, double* tmp) { // x <- U^-1 L^-1 x (x already permuted); tmp: scratch
         if (persist) { // a sweep in one launch: workgroups taking each other's solution blocks as they are published (qn_lu.hip.h)
             const int nb = nlu / QN_NB; // (`tmp` holds sentinels: lu_vec_perm_kernel; the forward sweep leaves them in `x`, the backward one in `tmp`)
-            hipLaunchKernelGGL(lu_sweep_kernel<false>, dim3(nb), dim3(256), 0, st, W, ld, nb, x, tmp, flag);
-            hipLaunchKernelGGL(lu_sweep_kernel<true>, dim3(nb), dim3(256), 0, st, W, ld, nb, tmp, x, flag);
+            hipLaunchKernelGGL(lu_sweep_kernel<false>, dim3(nb), dim3(256), 0, st, W, ld, nb, x, tmp, flag, spin_max);
+            hipLaunchKernelGGL(lu_sweep_kernel<true>, dim3(nb), dim3(256), 0, st, W, ld, nb, tmp, x, flag, spin_max);
             sweeps += 2;
             return;
         }

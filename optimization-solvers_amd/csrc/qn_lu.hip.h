@@ -458,8 +458,8 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restr
 // QN_LU_SPIN_MAX polls it gives up with *fail = 2, everybody else leaves at the next poll, and the host runs the factorisation again
 // with one launch per sub-panel (two solvers' panels sharing the free CUs could otherwise wait for each other's unplaced workgroups).
 #define QN_LU_SPIN_MAX (1 << 20)
-__device__ __forceinline__ bool lu_wait_ge(const int* flag, const int target, int* fail) {
-    for (int spin = 0; spin < QN_LU_SPIN_MAX; ++spin) {
+__device__ __forceinline__ bool lu_wait_ge(const int* flag, const int target, int* fail, const int spin_max) {
+    for (int spin = 0; spin < spin_max; ++spin) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
         if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
         __builtin_amdgcn_s_sleep(4);
@@ -475,7 +475,7 @@ __device__ __forceinline__ void lu_release_all() {
 }
 template <int RPT>
 __global__ __launch_bounds__(QN_LU_PT) void lu_panel_persist_kernel(double* __restrict__ P, size_t pld, int m, int p0, int* __restrict__ piv, int* __restrict__ fail,
-                                                                    int* __restrict__ sync, int base) {
+                                                                    int* __restrict__ sync, int base, int spin_max) { // (spin_max: QN_LU_SPIN_MAX; 0 in the test of the fallback)
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     constexpr int NSUB = QN_NB / QN_LU_SUB;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_persist_kernel(double* __re
         for (int s = 0; s < NSUB; ++s) {
             QN_LU_STAMP(0);
             if (s >= 2) { // its four columns carry sub-panel s - 2 (their workgroups' last step)
-                const bool ok = tid < QN_LU_SUB ? lu_wait_ge(sync + 1 + QN_LU_SUB * s + tid, base + s - 1, fail) : true;
+                const bool ok = tid < QN_LU_SUB ? lu_wait_ge(sync + 1 + QN_LU_SUB * s + tid, base + s - 1, fail, spin_max) : true;
                 if (!__syncthreads_and(ok)) return;
             }
             QN_LU_STAMP(1);
@@ -504,8 +504,8 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_persist_kernel(double* __re
     if (b == 1) { // role C: sub-panel sg - 1's swaps on the columns left of it, once nobody reads those in the old row order
         for (int sg = 2; sg <= NSUB; ++sg) {
             bool ok = true;
-            if (tid == 0) ok = lu_wait_ge(sync, base + sg, fail);
-            else if (tid < 1 + QN_NB && tid - 1 >= QN_LU_SUB * sg && tid - 1 >= 2 * QN_LU_SUB) ok = lu_wait_ge(sync + tid, base + sg - 1, fail);
+            if (tid == 0) ok = lu_wait_ge(sync, base + sg, fail, spin_max);
+            else if (tid < 1 + QN_NB && tid - 1 >= QN_LU_SUB * sg && tid - 1 >= 2 * QN_LU_SUB) ok = lu_wait_ge(sync + tid, base + sg - 1, fail, spin_max);
             if (!__syncthreads_and(ok)) return;
             lu_role_c<true>(P, pld, QN_LU_SUB * (sg - 1), p0, piv, tid);
         }
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_persist_kernel(double* __re
     const int c = 2 * QN_LU_SUB + (b - 2);
     const int last = c / QN_LU_SUB - 1;
     for (int sg = 1; sg <= last; ++sg) {
-        const bool ok = tid == 0 ? lu_wait_ge(sync, base + sg, fail) : true;
+        const bool ok = tid == 0 ? lu_wait_ge(sync, base + sg, fail, spin_max) : true;
         if (!__syncthreads_and(ok)) return;
         double a[QN_LU_SUB][RPT];
         const int r0 = QN_LU_SUB * (sg - 1);
@@ -871,7 +871,7 @@ __device__ __forceinline__ double lu_sentinel() { return __longlong_as_double((l
 __device__ __forceinline__ bool lu_is_sentinel(const double v) { return (unsigned long long)__double_as_longlong(v) == QN_LU_SENTINEL; }
 template <bool BWD>
 __global__ __launch_bounds__(256) void lu_sweep_kernel(const double* __restrict__ W, size_t ld, int nb, double* __restrict__ rhs, double* __restrict__ sol,
-                                                       int* __restrict__ fail) {
+                                                       int* __restrict__ fail, int spin_max) {
     __shared__ double D[QN_NB][QN_NB + 1];
     __shared__ double accs[QN_NB];
     __shared__ int bail_s;
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void lu_sweep_kernel(const double* __restrict_
         const int k = BWD ? nb - 1 - q : q;
         double xl = lu_ld<true>(sol + k * QN_NB + lane);
         for (int spin = 0; __any(lu_is_sentinel(xl)); ++spin) {
-            if (spin >= QN_LU_SPIN_MAX) { if (lane == 0) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bail = true; break; }
+            if (spin >= spin_max) { if (lane == 0) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bail = true; break; }
             if ((spin & 15) == 15 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bail = true; break; }
             __builtin_amdgcn_s_sleep(1);
             xl = lu_ld<true>(sol + k * QN_NB + lane);

@@ -257,6 +257,32 @@ def test_newton_exactly_singular_large_hessian_takes_the_gradient_direction(qn, 
     assert np.linalg.norm(xs[-1] - ref.trace_x[-1]) <= 1e-9 * max(1.0, np.linalg.norm(ref.trace_x[-1]))
 
 
+def test_one_launch_panel_whose_waits_expire_falls_back_to_step_launches(qn, qo):
+    """qn_lu.hip.h: the one-launch panel / sweep kernels wait for each other on counters with BOUNDED waits; when one expires (their
+    workgroups were not placed together) the kernel sets *fail = 2, everybody leaves, and the host runs the factorisation again with one
+    launch per sub-panel -- for good.  set_tiling(-12, 0) makes every wait that is not satisfied at once expire: same iterates, bit
+    for bit, and more launches (the abandoned attempt plus 17 per panel)."""
+    n = 700
+    fn, hess0, x0 = _double_well_chain(n)
+    rng = np.random.default_rng(8)
+    k = 0.2 * np.triu(rng.standard_normal((n, n)), 1) / np.sqrt(n)
+    hess = lambda x: hess0(x) + k - k.T  # noqa: E731
+    runs = []
+    for forced in (False, True):
+        s = qn.Newton(1e-10, x0)
+        if forced:
+            s.set_tiling(-12, 0)
+        s.set_trace(2, with_x=True)
+        try:
+            s.minimize(qn.MoreThuente(), lambda x: qn.FuncEvalMultivariate(*fn(x)).with_hessian(hess(x)), 2, 20)
+        except qn.MaxIterReached:
+            pass
+        tr, xs = s.trace()
+        runs.append((tr, xs, s.stats()["launches"]))
+    assert np.array_equal(runs[0][1], runs[1][1]) and [r["f"] for r in runs[0][0]] == [r["f"] for r in runs[1][0]]
+    assert runs[1][2] > runs[0][2] + 100
+
+
 @pytest.mark.parametrize("n", [64, 130, 777, 1500])
 def test_pivoted_lu_path_agrees_with_the_cholesky_path_on_spd(qn, qo, n):
     """diagnostics knob rows = -5: the same convex problem through both factorisations"""
