@@ -20,6 +20,14 @@
 //                          v_readlane broadcasts), then updates its rows of the running right-hand side
 //     lu_bwd_step_kernel   the same from the bottom with U (both sweeps read W by rows: contiguous)
 //
+// Round 4 (n = 8192: 65 -> 45 ms per Newton iteration, every path the same bits):
+//     lu_panel_persist_kernel   the panel's 17 launches as ONE grid of 58 workgroups that wait for each other on counters in memory
+//     lu_swap_rows2 / lu_trsm2 / lu_gemm2_kernel   the per-panel steps on a RANGE of columns: the look-ahead (qn_hip.hip) keeps the next
+//                               panel's 64 columns on the solver's stream and sends everything else to a CU-masked second stream
+//     lu_la_swap_trsm / lu_la_gemm_kernel   the look-ahead columns in two launches that read the panel from its column-major buffer and
+//                               leave the next panel in the second buffer
+//     lu_sweep_kernel           a whole substitution sweep in one launch (the solution entry is its own flag: sentinel NaN)
+//
 // Rounds 1-2 ran the panel with these two launches per column (~16 000 small launches at n = 8192: 146-196 ms per Newton
 // iteration, rocprofv3 r03_a); they remain the path for panels of more than 8192 rows and the reference the panel kernels below
 // are pinned against bit for bit (tests/test_gpu_newton.py).  Round 3: lu_panel_step_kernel -- 19 launches per panel, 65 ms.
