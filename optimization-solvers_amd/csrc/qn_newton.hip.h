@@ -278,6 +278,14 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ W, 
     }
 }
 
+// Round 4, built, measured and dropped: ONE launch per 64-column step, left-looking inside the outer block (`chol_step_kernel`:
+// workgroup b gives tile (k + b, k) what it owes to the outer block's earlier panels -- the tile in the accumulators throughout --,
+// workgroup 0 then factorises and inverts the diagonal tile and raises a counter, the others take the inverse as write-through stores /
+// sc1 loads and multiply; no in-block update launches).  Correct (32 Newton tests), and 9.49 ms against 9.20 at n = 8192 (3.52 / 3.34
+// at 4096): a step took 40 us alone and 62-70 us beside the bulk, against 27-47 + 7 with the two launches -- the left-looking update
+// in front of the diagonal block (depth up to 192: six 32-deep chunks, each a global-load round trip of ONE workgroup that nothing
+// hides) and the inverse's trip through memory behind it are both on the chain, where the right-looking in-block update is a 6 us
+// launch of many workgroups and the panel a 7 us one.
 // ---- triangular solves with a vector right-hand side, one launch per 64-block ----
 // Every workgroup first forms the block's solution from the stored inverse (a 64 x 64 product: cheaper than waiting for
 // a separate launch), workgroup 0 stores it into `sol`, then all update their rows of the running right-hand side `rhs`.
