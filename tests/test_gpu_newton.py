@@ -283,6 +283,29 @@ def test_one_launch_panel_whose_waits_expire_falls_back_to_step_launches(qn, qo)
     assert runs[1][2] > runs[0][2] + 100
 
 
+def test_pivoted_lu_with_a_panel_taller_than_the_panel_buffer(qn, qo):
+    """n = 8256: the first panel has 8256 rows -- more than the column-major panel buffer holds (8192) -- and is factorised by the
+    per-column kernels in W itself, the other 128 panels in the buffer with round 4's one-launch panel and two-launch look-ahead: the
+    hand-over between the two (look-ahead through W, the next panel loaded into the buffer) against the Cholesky path on the same
+    SPD matrix."""
+    n = 8256
+    diag = P.synth_diag(n)
+    b, x0 = P.synth_vectors(n)
+    obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
+    out = []
+    for force in (False, True):
+        s = qn.Newton(1e-8, x0)
+        if force:
+            s.set_tiling(-5, 0)
+        s.set_trace(3, with_x=True)
+        s.minimize(qn.MoreThuente(), obj, 10, 20)
+        out.append((s.k(), s.trace()[1][0]))
+    assert out[0][0] == out[1][0] == 2
+    assert np.linalg.norm(out[0][1] - out[1][1]) <= 1e-9 * np.linalg.norm(out[0][1])
+    g1 = obj(out[1][1]).g()
+    assert np.linalg.norm(g1) <= 1e-10 * np.linalg.norm(obj(x0).g())
+
+
 @pytest.mark.parametrize("n", [64, 130, 777, 1500])
 def test_pivoted_lu_path_agrees_with_the_cholesky_path_on_spd(qn, qo, n):
     """diagnostics knob rows = -5: the same convex problem through both factorisations"""
