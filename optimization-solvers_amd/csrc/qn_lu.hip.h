@@ -180,6 +180,7 @@ struct QnLuLds {
     double bv[QN_LU_SUB][16];
     int bi[QN_LU_SUB][16];
     double rowk[QN_LU_SUB][QN_LU_SUB], rowp[QN_LU_SUB][QN_LU_SUB];
+    double l11[QN_LU_SUB][QN_LU_SUB]; // the unit-lower 4 x 4 block of the sub-panel just factorised (l11[r][c], r > c), for lu_cols_update_keep
 };
 // role C: the swaps of the sub-panel at r0 on the columns left of it (thread = column)
 template <bool COH>
@@ -302,6 +303,73 @@ __device__ __forceinline__ void lu_cols_update(double* __restrict__ P, const siz
         }
     }
 }
+// role A of the one-launch panel at up to 8 rows per thread: the update from the PREVIOUS sub-panel's multipliers where they still are --
+// this thread's own registers (lprev: the rows a thread holds are the same in every sub-panel), the 4 x 4 block in LDS (L.l11), the
+// pivots in registers (pvprev) -- instead of reading back what the workgroup has just stored.  Nothing here depends on those stores
+// having completed: the wait for them moves behind this function (lu_panel_persist_kernel), beside the loads of the new columns.
+// Same products subtracted in the same order: the same bits.
+template <int RPT>
+__device__ __forceinline__ void lu_cols_update_keep(double* __restrict__ P, const size_t pld, const int m, const int r0, const bool prev, const int c0, const int p0,
+                                                    const int (&pvprev)[QN_LU_SUB], QnLuLds& L, const double (&lprev)[QN_LU_SUB][RPT], double (&a)[QN_LU_SUB][RPT],
+                                                    const int tid) {
+    if (prev) {
+        if (tid < QN_LU_SUB) { // thread j, column c0 + j: the four swaps, then the unit-lower 4 x 4 solve (as lu_cols_update)
+            double* col = P + (size_t)(c0 + tid) * pld;
+            int ix[2 * QN_LU_SUB];
+#pragma unroll
+            for (int q = 0; q < QN_LU_SUB; ++q) { ix[q] = r0 + q; ix[QN_LU_SUB + q] = pvprev[q] - p0; }
+            double v[2 * QN_LU_SUB];
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e) v[e] = lu_ld<true>(col + ix[e]);
+            int canon[2 * QN_LU_SUB];
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e) {
+                canon[e] = e;
+#pragma unroll
+                for (int f = 2 * QN_LU_SUB - 1; f >= 0; --f)
+                    if (f < e && ix[f] == ix[e]) canon[e] = f;
+            }
+#pragma unroll
+            for (int q = 0; q < QN_LU_SUB; ++q) {
+                const int sa = canon[q], sb = canon[QN_LU_SUB + q];
+                double va = 0.0, vb = 0.0;
+#pragma unroll
+                for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) va = v[e]; if (e == sb) vb = v[e]; }
+#pragma unroll
+                for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) v[e] = vb; else if (e == sb) v[e] = va; }
+            }
+#pragma unroll
+            for (int c = 0; c < QN_LU_SUB - 1; ++c)
+#pragma unroll
+                for (int r = c + 1; r < QN_LU_SUB; ++r) v[r] = v[r] - L.l11[r][c] * v[c];
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e)
+                if (canon[e] == e) lu_st<true>(col + ix[e], v[e]);
+#pragma unroll
+            for (int q = 0; q < QN_LU_SUB; ++q) L.U[q][tid] = v[q];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the entries are read back below by their rows' threads)
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int jr = 0; jr < RPT; ++jr) {
+        const int i = tid + QN_LU_PT * jr;
+#pragma unroll
+        for (int j = 0; j < QN_LU_SUB; ++j) a[j][jr] = (i < m) ? lu_ld<true>(P + (size_t)(c0 + j) * pld + i) : 0.0;
+    }
+    if (prev) {
+#pragma unroll
+        for (int jr = 0; jr < RPT; ++jr) {
+            const int i = tid + QN_LU_PT * jr;
+            if (i >= r0 + QN_LU_SUB && i < m) {
+#pragma unroll
+                for (int j = 0; j < QN_LU_SUB; ++j)
+#pragma unroll
+                    for (int q = 0; q < QN_LU_SUB; ++q) a[j][jr] = a[j][jr] - lprev[q][jr] * L.U[q][j]; // (column order: the per-column kernels' rounding)
+            }
+        }
+    }
+}
 // role B, second half: the column back to the panel buffer
 template <int RPT, bool COH>
 __device__ __forceinline__ void lu_col_store(double* __restrict__ P, const size_t pld, const int m, const int r0, const int c0, const double (&a)[QN_LU_SUB][RPT],
@@ -317,11 +385,10 @@ __device__ __forceinline__ void lu_col_store(double* __restrict__ P, const size_
 // Returns true when a pivot column holds no non-zero entry (then *fail = 1).
 template <int RPT, bool COH>
 __device__ __forceinline__ bool lu_sub_factor(double* __restrict__ P, const size_t pld, const int m, const int s, const int p0, int* __restrict__ piv,
-                                              int* __restrict__ fail, QnLuLds& L, double (&a)[QN_LU_SUB][RPT], const int tid) {
+                                              int* __restrict__ fail, QnLuLds& L, double (&a)[QN_LU_SUB][RPT], const int tid, int (&pv)[QN_LU_SUB]) {
     const int lane = tid & 63, wave = tid >> 6;
     const int c0 = QN_LU_SUB * s;
     bool failed = false;
-    int pv[QN_LU_SUB];
 #pragma unroll
     for (int j = 0; j < QN_LU_SUB; ++j) pv[j] = p0 + QN_LU_SUB * s + j;
 #pragma unroll
@@ -411,6 +478,10 @@ __device__ __forceinline__ bool lu_sub_factor(double* __restrict__ P, const size
         for (int j = 0; j < QN_LU_SUB; ++j) lu_sti<COH>(piv + p0 + QN_LU_SUB * s + j, pv[j]);
         if (failed) lu_sti<COH>(fail, 1);
     }
+    if (tid >= c0 && tid < c0 + QN_LU_SUB) { // rows c0 .. c0 + 3 are these threads' first rows: the sub-panel's own 4 x 4 block
+#pragma unroll
+        for (int c = 0; c < QN_LU_SUB; ++c) L.l11[tid - c0][c] = a[c][0];
+    }
     // (every row of the thread, no condition: see lu_col_store)
 #pragma unroll
     for (int jr = 0; jr < RPT; ++jr) {
@@ -442,7 +513,8 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_step_kernel(double* __restr
     lu_cols_update<RPT, false, (RPT >= 16 ? 1 : 4)>(P, pld, m, r0, s >= 1, c0, nc, p0, piv, L, a, tid);
     if (!isA) { lu_col_store<RPT, false>(P, pld, m, r0, c0, a, tid); return; }
     QN_LU_STAMP(2);
-    (void)lu_sub_factor<RPT, false>(P, pld, m, s, p0, piv, fail, L, a, tid);
+    int pv_unused[QN_LU_SUB];
+    (void)lu_sub_factor<RPT, false>(P, pld, m, s, p0, piv, fail, L, a, tid, pv_unused);
     QN_LU_STAMP(8);
 }
 
@@ -490,22 +562,44 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_persist_kernel(double* __re
     if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     __shared__ QnLuLds L;
     if (b == 0) { // role A: sub-panels 0 .. 15
+        constexpr bool KEEP = RPT <= 8; // the previous sub-panel's multipliers stay in registers (at 16 rows per thread there is no room)
+        double lprev[QN_LU_SUB][KEEP ? RPT : 1];
+        int pvprev[QN_LU_SUB] = {0, 0, 0, 0};
         for (int s = 0; s < NSUB; ++s) {
             QN_LU_STAMP(0);
             if (s >= 2) { // its four columns carry sub-panel s - 2 (their workgroups' last step)
                 const bool ok = tid < QN_LU_SUB ? lu_wait_ge(sync + 1 + QN_LU_SUB * s + tid, base + s - 1, fail, spin_max) : true;
                 if (!__syncthreads_and(ok)) return;
-            }
+            } else if (KEEP) __syncthreads(); // (L.l11 of the previous sub-panel is complete)
             QN_LU_STAMP(1);
             double a[QN_LU_SUB][RPT];
-            lu_cols_update<RPT, true, (RPT >= 16 ? 1 : 4)>(P, pld, m, QN_LU_SUB * (s - 1), s >= 1, QN_LU_SUB * s, QN_LU_SUB, p0, piv, L, a, tid);
+            if constexpr (KEEP) {
+                lu_cols_update_keep<RPT>(P, pld, m, QN_LU_SUB * (s - 1), s >= 1, QN_LU_SUB * s, p0, pvprev, L, lprev, a, tid);
+                if (s >= 1) { // sub-panel s - 1 is announced only now: its stores completed while the new columns came in
+                    lu_release_all();
+                    if (tid == 0) __hip_atomic_store(sync, base + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                lu_cols_update<RPT, true, 1>(P, pld, m, QN_LU_SUB * (s - 1), s >= 1, QN_LU_SUB * s, QN_LU_SUB, p0, piv, L, a, tid);
+            }
             QN_LU_STAMP(2);
-            const bool failed = lu_sub_factor<RPT, true>(P, pld, m, s, p0, piv, fail, L, a, tid);
+            const bool failed = lu_sub_factor<RPT, true>(P, pld, m, s, p0, piv, fail, L, a, tid, pvprev);
             if (failed) return; // (*fail = 1: the others leave at their next poll)
             QN_LU_STAMP(8);
-            lu_release_all(); // (also: the next sub-panel's update reads what other threads of this workgroup stored)
-            QN_LU_STAMP(9);
-            if (tid == 0) __hip_atomic_store(sync, base + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (KEEP) {
+#pragma unroll
+                for (int q = 0; q < QN_LU_SUB; ++q)
+#pragma unroll
+                    for (int jr = 0; jr < RPT; ++jr) lprev[q][jr] = a[q][jr];
+                if (s == NSUB - 1) {
+                    lu_release_all();
+                    if (tid == 0) __hip_atomic_store(sync, base + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                lu_release_all(); // (also: the next sub-panel's update reads what other threads of this workgroup stored)
+                QN_LU_STAMP(9);
+                if (tid == 0) __hip_atomic_store(sync, base + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         return;
     }
