@@ -423,6 +423,10 @@ __device__ __forceinline__ bool lu_sub_factor(double* __restrict__ P, const size
         const int p = idx;
         pv[j] = p0 + p; // (stored after the four steps: a store here put a wait for the PREVIOUS step's store -- a write-through round trip -- into every step of the chain)
         if (failed) break; // (uniform: every thread reduced the same sixteen candidates)
+        // (Round 4, measured and dropped: ONE barrier per pivot step -- every wave's candidate publishes its row and the reciprocal of
+        // its pivot entry together with the candidate, behind the barrier everybody picks the winner and reads the winner's row.  Same
+        // bits; 48.2-50.0 ms per Newton iteration at n = 8192 against 44.9: pulling the candidate's row out of sixteen rows per thread
+        // in EVERY wave, the dependent LDS read of the winner's row and eight more live registers cost more than the barrier saved.)
         // Rows k and p meet in LDS: their owners publish them, take each other's, and everybody reads the pivot row.  Row k
         // (k < 64) is thread k's first row; row p is found by its one owner under a branch the other waves skip (first version:
         // every thread compared every one of its rows with k and p, twice -- a third of the step).
