@@ -638,6 +638,18 @@ __device__ __forceinline__ double qn_s2_eval_sliver(const QnS2SliverVec& v, cons
 // body decides at run time whether there is a second item, a third one, a list to read, a sliver, a parked window; with those
 // five flags known the compiler drops the variants they select between and the register copies at their joins -- the phase
 // behind the workgroup barrier is instruction issue.
+// Round 4, built, measured and dropped: THE LAUNCH THAT STAYS for a whole line search (the two-items-and-a-sliver instance).  At
+// n = 4096 a workgroup's share of Q -- two tiles and a sliver, 256 KB -- is exactly what its CU holds after the first evaluation (one
+// tile parked in LDS, one in the register window), and the second trial point needs the same tiles against other vectors: the
+// workgroups published their six sums (write-through), met at a grid barrier, read the table back (sc1), ran the machine again from
+// the control block each had kept in LDS and took the next evaluation from the tiles they held -- no matrix traffic.  Correct (smoke,
+// bench), and SLOWER: 47.5 us for a launch of two evaluations against 2 x 15.5 (profiles/r04_q_staying_eval_launch_stamps.txt).
+// Per seam: the grid barrier 5 us (a counter took 30-40: 256 read-modify-writes of one word; a generation word per table row, polled
+// by every workgroup, 5), the table and the machine again 4.5 us -- 9.5 us against the 11 us of streaming it saves -- and ONE SEAM
+// MORE than evaluations, because only the machine's next run knows that the line search is over (with a launch per evaluation that
+// run sits in the next kernel's prologue, behind its launch latency).  On top, a second inlined copy of the machine and the
+// window held across it cost the row loops their registers (256 + scratch: the two evaluations' arithmetic took 10-12 us instead of
+// 4.5).  Even with a 2.8 us hierarchical barrier (tools/seam_probe.hip) and no spills the sum comes out level with three launches.
 template <bool PAIR, bool SHARD = false, bool NTQ = false>
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a) {
     static_assert(!(PAIR && SHARD), "the two-items-and-a-sliver instance is the single-rank n = 4096 one");
