@@ -2247,7 +2247,7 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     int* flag = s->newton_fail;
     s->newton_lu_runs++;
     HIPCHK(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
-    hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, W, ld, n, n64, hsrc, ld_src); // both triangles
+    hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, W, ld, n, n64, hsrc, ld_src, 0); // both triangles
     uint64_t launches = 1;
     const size_t panel_doubles = (size_t)QN_NB * QN_LU_PT * QN_LU_RPT; // (two buffers: the look-ahead writes the next panel's while this one's is still read)
     if (!s->newton_panel) HIPCHK(hipMalloc((void**)&s->newton_panel, 2 * panel_doubles * sizeof(double)));
@@ -2476,7 +2476,7 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
     }
     if (!symmetric || s->newton_force_lu) return enqueue_newton_lu(s, hsrc, ld_src);
     s->newton_chol_runs++;
-    hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, s->newton_w, ld, n, n64, hsrc, ld_src);
+    hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, s->newton_w, ld, n, n64, hsrc, ld_src, 1); // (the lower block triangle)
     // blocked right-looking Cholesky, lower triangle in place.  Outer blocks of 256 columns: each 64-column panel is
     // factorised and applied to the REST OF ITS OUTER BLOCK only; the trailing matrix then takes one depth-256 update.
     // (Look-ahead -- the next block's diag/panel chain on this stream beside the bulk update on a second, low-priority

@@ -469,10 +469,13 @@ __global__ __launch_bounds__(256) void tri_coldot512_kernel(const double* __rest
 }
 
 // Hessian staging: W (row-major, ld = n_pad64) <- src rows (ld_src), identity on the padding diagonal
-__global__ void newton_stage_kernel(double* __restrict__ W, size_t ld, int n, int n_pad64, const double* __restrict__ src, size_t ld_src) {
+// (lower_only: the Cholesky path reads the lower block triangle only -- the 64 x 64 tiles on and below the diagonal: the rest of the
+// copy, half of its 1 GB at n = 8192, is left out)
+__global__ void newton_stage_kernel(double* __restrict__ W, size_t ld, int n, int n_pad64, const double* __restrict__ src, size_t ld_src, int lower_only) {
     const size_t total = (size_t)n_pad64 * ld;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const size_t i = e / ld, j = e % ld;
+        if (lower_only && j > (i | 63)) continue;
         double v = 0.0;
         if (i < (size_t)n && j < (size_t)n) v = src[i * ld_src + j];
         else if (i == j) v = 1.0;
