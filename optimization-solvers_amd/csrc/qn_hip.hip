@@ -1895,6 +1895,16 @@ static int place_h(Run& r) {
     memcpy(pc, s->hctl, sizeof(QnCtl));
     pc->phase = QN_PH_REQ_HPASS; pc->serviced = 0; pc->hp_nrhs = 1; pc->pending = 0; pc->after_state = QN_ST_AFTER_DIR; pc->sym2 = 1; pc->fused = 1;
     pc->spec_tiles = 0; pc->sc = 0; pc->xc = 0;
+    // ... and, in front of every timed pass, what an iteration has in front of it: two evaluations (Q's half streamed twice).  Timed
+    // alone on H the update kernel showed the same 24.4 us on allocations where, in the run, it then took 29.6-30.3 us (2-3 processes
+    // in 20, tools/modes_ab.sh): the slow mode is H sharing the Infinity Cache with Q, not H by itself.
+    QnCtl* pe = nullptr;
+    if (hipHostMalloc((void**)&pe, sizeof(QnCtl), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); pe = nullptr; }
+    if (pe) {
+        memcpy(pe, s->hctl, sizeof(QnCtl));
+        pe->phase = QN_PH_REQ_EVAL; pe->serviced = 0; pe->sym2 = 1; pe->fused = 1; pe->sc = 0; pe->xc = 0;
+        pe->ev_kind = QN_REQ_T; pe->t = 1.0; pe->status = -1;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -1903,6 +1913,15 @@ static int place_h(Run& r) {
         a.H = H; a.parity = 0; a.ctl_first = pc; a.rep_seq = 0;
         float t[6];
         for (int rep = 0; rep < 6; ++rep) {
+            if (pe) {
+                QnS2Args ae = a;
+                ae.ctl_first = pe;
+                for (int e = 0; e < 2; ++e) {
+                    if (ae.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(ae.G), dim3(QN_S2_TPB), 0, st, ae);
+                    else if (ae.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, false, true>), dim3(ae.G), dim3(QN_S2_TPB), 0, st, ae);
+                    else hipLaunchKernelGGL(s2_eval_kernel<false>, dim3(ae.G), dim3(QN_S2_TPB), 0, st, ae);
+                }
+            }
             HIPCHK(hipEventRecord(e0, st));
             if (s->method == QN_BFGS) hipLaunchKernelGGL((s2_hpass_kernel<false, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
             else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
@@ -1939,6 +1958,7 @@ static int place_h(Run& r) {
     r.s2.H = s->H;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (pe) (void)hipHostFree(pe);
     return status;
 }
 

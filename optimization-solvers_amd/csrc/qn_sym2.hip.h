@@ -1418,7 +1418,8 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
 // So the library measures the pattern itself: with the objective in hand (the first run on the fast path) it times the update
 // pass's bytes -- every workgroup its first two list items of H, read into the 16-row window and written back -- BEHIND two reads
 // of Q's half in the same shape, on the solver's H and on a second allocation, a third one when they differ, and moves H to the
-// best (qn_hip.hip, place_h).
+// best (qn_hip.hip, place_h).  (What place_h times today is the real thing: the update kernel itself behind two real evaluation
+// launches -- on H alone the kernel measured fast on allocations that were slow in the run; tools/modes_ab.sh, profiles/r04_s_*.)
 template <bool WRITE>
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_place_probe_kernel(double* __restrict__ M, const int nb, const int np_, const int G, double* __restrict__ sink) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
