@@ -1887,7 +1887,7 @@ static int place_h(Run& r) {
     s->h_placed = true;
     const size_t np = s->T.n_pad, bytes = (size_t)s->T.rpr * np * sizeof(double);
     const char* sw = getenv("QN_H_PLACEMENT");
-    if ((sw && atoi(sw) == 0) || s->ctx->world != 1 || bytes > ((size_t)160 << 20) || r.s2.fold) return QN_OK; // (larger H: streamed from HBM anyway)
+    if ((sw && atoi(sw) == 0) || s->ctx->world != 1 || bytes > ((size_t)330 << 20) || r.s2.fold) return QN_OK; // (n <= 6144: H's half is an Infinity Cache tenant; larger H is streamed from HBM anyway)
     hipStream_t st = s->ctx->stream;
     // the request: a direction pass (one right-hand side, g in both places), nothing pending; the vectors it multiplies are whatever
     // the fused buffers hold (zeros before the first run) -- only the duration matters, and H comes back as it was
