@@ -180,6 +180,7 @@ struct QnLuLds {
     double bv[QN_LU_SUB][16];
     int bi[QN_LU_SUB][16];
     double rowk[QN_LU_SUB][QN_LU_SUB], rowp[QN_LU_SUB][QN_LU_SUB];
+    double pat[QN_LU_SUB][2 * QN_LU_SUB]; // pat[j][e]: column c0 + j's entry in slot e after the swaps and the 4 x 4 solve (lu_cols_update_pre)
     double l11[QN_LU_SUB][QN_LU_SUB]; // the unit-lower 4 x 4 block of the sub-panel just factorised (l11[r][c], r > c), for lu_cols_update_keep
 };
 // role C: the swaps of the sub-panel at r0 on the columns left of it (thread = column)
@@ -303,53 +304,30 @@ __device__ __forceinline__ void lu_cols_update(double* __restrict__ P, const siz
         }
     }
 }
-// role A of the one-launch panel at up to 8 rows per thread: the update from the PREVIOUS sub-panel's multipliers where they still are --
-// this thread's own registers (lprev: the rows a thread holds are the same in every sub-panel), the 4 x 4 block in LDS (L.l11), the
-// pivots in registers (pvprev) -- instead of reading back what the workgroup has just stored.  Nothing here depends on those stores
-// having completed: the wait for them moves behind this function (lu_panel_persist_kernel), beside the loads of the new columns.
+// role A of the one-launch panel.  Two things differ from lu_cols_update:
+//   * KEEP (up to 8 rows per thread): the update takes the PREVIOUS sub-panel's multipliers from where they still are -- this thread's
+//     own registers (lprev: the rows a thread holds are the same in every sub-panel) -- instead of reading back what the workgroup has
+//     just stored; the 4 x 4 block comes from LDS (L.l11) and the pivots from registers (pvprev) in either case.  With KEEP nothing
+//     here depends on those stores having completed: the wait for them moves behind this function (lu_panel_persist_kernel);
+//   * LOAD FIRST, PATCH AFTER: the new columns are requested at once -- together with the eight entries per column the swaps can touch
+//     -- and the four threads that replay the swaps and solve the 4 x 4 system publish the (at most eight) changed entries per column
+//     in LDS, from where the rows' owners take them into their registers.  Before: those threads loaded, stored, waited, and only
+//     behind the barrier did the workgroup ask for its columns -- two memory round trips in front of every sub-panel's update.
+//     (The changed entries need not go back to memory here: the sub-panel's store at the end writes every row.)
 // Same products subtracted in the same order: the same bits.
-template <int RPT>
-__device__ __forceinline__ void lu_cols_update_keep(double* __restrict__ P, const size_t pld, const int m, const int r0, const bool prev, const int c0, const int p0,
-                                                    const int (&pvprev)[QN_LU_SUB], QnLuLds& L, const double (&lprev)[QN_LU_SUB][RPT], double (&a)[QN_LU_SUB][RPT],
-                                                    const int tid) {
-    if (prev) {
-        if (tid < QN_LU_SUB) { // thread j, column c0 + j: the four swaps, then the unit-lower 4 x 4 solve (as lu_cols_update)
-            double* col = P + (size_t)(c0 + tid) * pld;
-            int ix[2 * QN_LU_SUB];
+template <int RPT, bool KEEP>
+__device__ __forceinline__ void lu_cols_update_pre(double* __restrict__ P, const size_t pld, const int m, const int r0, const bool prev, const int c0, const int p0,
+                                                   const int (&pvprev)[QN_LU_SUB], QnLuLds& L, const double (&lprev)[QN_LU_SUB][KEEP ? RPT : 1],
+                                                   double (&a)[QN_LU_SUB][RPT], const int tid) {
+    int ix[2 * QN_LU_SUB];
+    double v[2 * QN_LU_SUB];
 #pragma unroll
-            for (int q = 0; q < QN_LU_SUB; ++q) { ix[q] = r0 + q; ix[QN_LU_SUB + q] = pvprev[q] - p0; }
-            double v[2 * QN_LU_SUB];
+    for (int q = 0; q < QN_LU_SUB; ++q) { ix[q] = r0 + q; ix[QN_LU_SUB + q] = pvprev[q] - p0; }
+    const bool solver = prev && tid < QN_LU_SUB; // thread j: column c0 + j
+    {
+        const double* col = P + (size_t)(c0 + (tid & (QN_LU_SUB - 1))) * pld;
 #pragma unroll
-            for (int e = 0; e < 2 * QN_LU_SUB; ++e) v[e] = lu_ld<true>(col + ix[e]);
-            int canon[2 * QN_LU_SUB];
-#pragma unroll
-            for (int e = 0; e < 2 * QN_LU_SUB; ++e) {
-                canon[e] = e;
-#pragma unroll
-                for (int f = 2 * QN_LU_SUB - 1; f >= 0; --f)
-                    if (f < e && ix[f] == ix[e]) canon[e] = f;
-            }
-#pragma unroll
-            for (int q = 0; q < QN_LU_SUB; ++q) {
-                const int sa = canon[q], sb = canon[QN_LU_SUB + q];
-                double va = 0.0, vb = 0.0;
-#pragma unroll
-                for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) va = v[e]; if (e == sb) vb = v[e]; }
-#pragma unroll
-                for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) v[e] = vb; else if (e == sb) v[e] = va; }
-            }
-#pragma unroll
-            for (int c = 0; c < QN_LU_SUB - 1; ++c)
-#pragma unroll
-                for (int r = c + 1; r < QN_LU_SUB; ++r) v[r] = v[r] - L.l11[r][c] * v[c];
-#pragma unroll
-            for (int e = 0; e < 2 * QN_LU_SUB; ++e)
-                if (canon[e] == e) lu_st<true>(col + ix[e], v[e]);
-#pragma unroll
-            for (int q = 0; q < QN_LU_SUB; ++q) L.U[q][tid] = v[q];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the entries are read back below by their rows' threads)
-        }
-        __syncthreads();
+        for (int e = 0; e < 2 * QN_LU_SUB; ++e) v[e] = solver ? lu_ld<true>(col + ix[e]) : 0.0; // (requested in front of the columns: a wave's loads return in order)
     }
 #pragma unroll
     for (int jr = 0; jr < RPT; ++jr) {
@@ -357,7 +335,58 @@ __device__ __forceinline__ void lu_cols_update_keep(double* __restrict__ P, cons
 #pragma unroll
         for (int j = 0; j < QN_LU_SUB; ++j) a[j][jr] = (i < m) ? lu_ld<true>(P + (size_t)(c0 + j) * pld + i) : 0.0;
     }
-    if (prev) {
+    if (!prev) return; // (uniform)
+    int canon[2 * QN_LU_SUB]; // the first slot that names the same row (the same for every column: it follows from the pivots alone)
+#pragma unroll
+    for (int e = 0; e < 2 * QN_LU_SUB; ++e) {
+        canon[e] = e;
+#pragma unroll
+        for (int f = 2 * QN_LU_SUB - 1; f >= 0; --f)
+            if (f < e && ix[f] == ix[e]) canon[e] = f;
+    }
+    if (solver) {
+#pragma unroll
+        for (int q = 0; q < QN_LU_SUB; ++q) { // swap rows r0 + q and piv[r0 + q] (slots q and 4 + q), in pivot order
+            const int sa = canon[q], sb = canon[QN_LU_SUB + q];
+            double va = 0.0, vb = 0.0;
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) va = v[e]; if (e == sb) vb = v[e]; }
+#pragma unroll
+            for (int e = 0; e < 2 * QN_LU_SUB; ++e) { if (e == sa) v[e] = vb; else if (e == sb) v[e] = va; }
+        }
+#pragma unroll
+        for (int c = 0; c < QN_LU_SUB - 1; ++c)
+#pragma unroll
+            for (int r = c + 1; r < QN_LU_SUB; ++r) v[r] = v[r] - L.l11[r][c] * v[c];
+#pragma unroll
+        for (int e = 0; e < 2 * QN_LU_SUB; ++e) L.pat[tid][e] = v[e];
+#pragma unroll
+        for (int q = 0; q < QN_LU_SUB; ++q) L.U[q][tid] = v[q];
+    }
+    __syncthreads();
+    // the changed entries into their rows' registers: slots 0..3 are rows r0 .. r0 + 3 (first rows of threads r0 .. r0 + 3), a slot
+    // 4 + q that is the first to name its row is row piv[r0 + q] -- thread (row mod 512), its (row / 512)-th row: a uniform index
+#pragma unroll
+    for (int q = 0; q < QN_LU_SUB; ++q)
+        if (tid == r0 + q) {
+#pragma unroll
+            for (int j = 0; j < QN_LU_SUB; ++j) a[j][0] = L.pat[j][q];
+        }
+#pragma unroll
+    for (int q = 0; q < QN_LU_SUB; ++q) {
+        const int e = QN_LU_SUB + q;
+        if (canon[e] == e) { // (uniform)
+            const int row = ix[e], tp = row & (QN_LU_PT - 1), jp = __builtin_amdgcn_readfirstlane(row / QN_LU_PT);
+            const bool mine = tid == tp;
+#pragma unroll
+            for (int jr = 0; jr < RPT; ++jr)
+                if (jr == jp) {
+#pragma unroll
+                    for (int j = 0; j < QN_LU_SUB; ++j) a[j][jr] = mine ? L.pat[j][e] : a[j][jr];
+                }
+        }
+    }
+    if constexpr (KEEP) {
 #pragma unroll
         for (int jr = 0; jr < RPT; ++jr) {
             const int i = tid + QN_LU_PT * jr;
@@ -366,6 +395,21 @@ __device__ __forceinline__ void lu_cols_update_keep(double* __restrict__ P, cons
                 for (int j = 0; j < QN_LU_SUB; ++j)
 #pragma unroll
                     for (int q = 0; q < QN_LU_SUB; ++q) a[j][jr] = a[j][jr] - lprev[q][jr] * L.U[q][j]; // (column order: the per-column kernels' rounding)
+            }
+        }
+    } else { // the multipliers from the panel buffer, one row-per-thread at a time (lu_cols_update: larger chunks were slower at 16 rows per thread)
+#pragma unroll
+        for (int jr = 0; jr < RPT; ++jr) {
+            const int i = tid + QN_LU_PT * jr;
+            const bool on = i >= r0 + QN_LU_SUB && i < m;
+            double l[QN_LU_SUB];
+#pragma unroll
+            for (int q = 0; q < QN_LU_SUB; ++q) l[q] = on ? lu_ld<true>(P + (size_t)(r0 + q) * pld + i) : 0.0;
+            if (on) {
+#pragma unroll
+                for (int j = 0; j < QN_LU_SUB; ++j)
+#pragma unroll
+                    for (int q = 0; q < QN_LU_SUB; ++q) a[j][jr] = a[j][jr] - l[q] * L.U[q][j];
             }
         }
     }
@@ -574,17 +618,15 @@ __global__ __launch_bounds__(QN_LU_PT) void lu_panel_persist_kernel(double* __re
             if (s >= 2) { // its four columns carry sub-panel s - 2 (their workgroups' last step)
                 const bool ok = tid < QN_LU_SUB ? lu_wait_ge(sync + 1 + QN_LU_SUB * s + tid, base + s - 1, fail, spin_max) : true;
                 if (!__syncthreads_and(ok)) return;
-            } else if (KEEP) __syncthreads(); // (L.l11 of the previous sub-panel is complete)
+            } else __syncthreads(); // (L.l11 of the previous sub-panel is complete)
             QN_LU_STAMP(1);
             double a[QN_LU_SUB][RPT];
+            lu_cols_update_pre<RPT, KEEP>(P, pld, m, QN_LU_SUB * (s - 1), s >= 1, QN_LU_SUB * s, p0, pvprev, L, lprev, a, tid);
             if constexpr (KEEP) {
-                lu_cols_update_keep<RPT>(P, pld, m, QN_LU_SUB * (s - 1), s >= 1, QN_LU_SUB * s, p0, pvprev, L, lprev, a, tid);
                 if (s >= 1) { // sub-panel s - 1 is announced only now: its stores completed while the new columns came in
                     lu_release_all();
                     if (tid == 0) __hip_atomic_store(sync, base + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            } else {
-                lu_cols_update<RPT, true, 1>(P, pld, m, QN_LU_SUB * (s - 1), s >= 1, QN_LU_SUB * s, QN_LU_SUB, p0, piv, L, a, tid);
             }
             QN_LU_STAMP(2);
             const bool failed = lu_sub_factor<RPT, true>(P, pld, m, s, p0, piv, fail, L, a, tid, pvprev);
