@@ -89,11 +89,15 @@ def host_cpu_share():
     return max(1, n)
 
 
-def cpu_baseline(n, iters):
-    """The `cpu_baseline` leg in a FRESH CHILD PROCESS.  Round 3 ran it in the bench process, where `import
-    torch` had already started an OpenMP runtime: OMP_PROC_BIND / OMP_PLACES set afterwards never applied, and the driver's run
-    printed 41.7 it/s where the same code reached 87-137.  The child is started with the pinning in its environment before any
-    OpenMP runtime exists, never touches the GPU (it imports numpy and the oracle only), and prints one JSON object."""
+def cpu_baseline(n, iters, extra=True):
+    """The CPU legs in a FRESH CHILD PROCESS, run to completion BEFORE this process touches the GPU (round 5).
+    Round 3 ran the leg in the bench process, where `import torch` had already started an OpenMP runtime (41.7 it/s where the same
+    code reached 87-137); round 4 moved it to a child that ran AFTER the GPU measurement, beside a parent that still held a GPU
+    context, its runtime threads and 250 MB of pinned memory: 269-457 it/s inside full runs against 499-515 standalone.  Now the
+    parent starts the child first thing -- before torch, HIP or the library are loaded: the parent is one thread blocked in
+    wait() -- with the pinning in the child's environment before any OpenMP runtime exists; the child takes THREE sub-samples
+    per leg and reports all of them and their median.  Returns {"config2": {...}, "config4": {...}, "config5": {...}} or an
+    {"error": ...} object (a failing CPU leg never loses the bench line: ADVICE r4)."""
     env = dict(os.environ)
     # spread: the team's threads one per core, as far apart as the places allow -- on the GPU boxes' 2 x 64-core hosts each of the 16
     # threads of the container's share then has a core complex (and its 32 MB of L3) to itself: 499-514 it/s in three consecutive
@@ -102,53 +106,69 @@ def cpu_baseline(n, iters):
     env.setdefault("OMP_PLACES", "cores")
     threads = host_cpu_share()
     env["OMP_NUM_THREADS"] = str(threads)  # (torch.distributed.run exports OMP_NUM_THREADS=1 to its workers; the host shows more CPUs than the share)
-    cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(n), str(iters), str(threads)],
-                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    if cp.returncode != 0:
-        return {"error": f"cpu_baseline child failed (rc {cp.returncode}): {cp.stderr[-400:]}"}
-    out = json.loads(cp.stdout.strip().splitlines()[-1])
-    out["process"] = "fresh child process, %d threads = this container's CPU share, OMP_PROC_BIND=%s OMP_PLACES=%s" % (threads, env["OMP_PROC_BIND"], env["OMP_PLACES"])
+    try:
+        cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(n), str(iters), str(threads), "1" if extra else "0"],
+                            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        if cp.returncode != 0:
+            return {"error": f"cpu_baseline child failed (rc {cp.returncode}): {cp.stderr[-400:]}"}
+        out = json.loads(cp.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001 -- timeout, empty output, a line that is not JSON
+        return {"error": "cpu_baseline child: " + repr(e)}
+    proc = ("fresh child process run to completion before the bench process loaded torch / HIP, %d threads = this container's CPU share, "
+            "OMP_PROC_BIND=%s OMP_PLACES=%s" % (threads, env["OMP_PROC_BIND"], env["OMP_PLACES"]))
+    for leg in out.values():
+        if isinstance(leg, dict):
+            leg["process"] = proc
     return out
 
 
-def cpu_baseline_child(n, iters, threads=None):
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def cpu_leg_config2(qo, n, iters, threads):
     """CPU port timed on the host cores (CPU-B): the oracle restatement with the O(n^2) rank-2 update (the
     reference's literal update is O(n^3): 2.7e11 flop per iteration at n = 4096), reference call sequence (5 oracle calls per
     iteration), OpenMP over all cores.  Every sweep is contiguous per thread -- the symmetric H and Q are read by rows = columns,
     four rows per thread in flight, pages first touched by the thread that streams them -- so the port is bandwidth-bound and
-    the achieved GB/s is printed next to the core count."""
-    from oracle import qn_oracle as qo  # (the first OpenMP runtime of this process: the pinning is in the environment already)
-    threads = min(qo.max_threads(), threads) if threads else min(qo.max_threads(), host_cpu_share())
+    the achieved GB/s is printed next to the core count.  THREE sub-samples of ~3 s each; value = their median."""
     diag, b, x0 = synth_inputs(n)
     q = qo.synth_rows(n, 0, n, SEED, diag, nthreads=threads)
     o = qo.QuadraticOracle(q, b, nthreads=threads)
-    # ~10 s of CPU work.  One run stays inside the pre-convergence window (the restatement needs ~350 iterations on this family;
-    # past convergence y's -> 0 and the timings mean nothing), so the sample is a series of runs of `per_run` iterations, each
-    # from (x0, H = I) after 3 untimed iterations -- the GPU leg's protocol (SURVEY.md 8(d)).  Solver creation is not timed.
+    # One run stays inside the pre-convergence window (the restatement needs ~350 iterations on this family; past convergence
+    # y's -> 0 and the timings mean nothing), so a sub-sample is a series of runs of `per_run` iterations, each from (x0, H = I) after
+    # 3 untimed iterations -- the GPU leg's protocol (SURVEY.md 8(d)).  Solver creation is not timed.
     per_run = int(min(max(iters, 30), 250))
-    k, dt, moved, runs = 0, 0.0, 0.0, 0
-    while dt < 10.0 and runs < 200:
-        s = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=threads)
-        tw = time.perf_counter()
-        s.minimize(qo.morethuente(), o, 3, 20)  # warm the caches / thread pool
-        tw = (time.perf_counter() - tw) / 3.0
-        if runs == 0 and tw * per_run > 6.0:  # a host far slower than planned for: keep the whole sample near 10-30 s whatever it is
-            per_run = max(3, int(6.0 / tw))
-        bytes0, calls0 = s.bytes_streamed, o.calls
-        t0 = time.perf_counter()
-        s.minimize(qo.morethuente(), o, per_run, 20)  # warm restart: continues from the warmed-up state
-        dt += time.perf_counter() - t0
-        k += s.k
-        moved += (s.bytes_streamed - bytes0) + (o.calls - calls0) * 8.0 * n * n
-        runs += 1
-        del s
-    out = {"value": k / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
-           "achieved_GBs": moved / dt / 1e9, "bytes_per_iteration": moved / max(k, 1),
+    subs, tot_k, tot_dt, tot_moved, tot_runs = [], 0, 0.0, 0.0, 0
+    for sub in range(3):
+        k, dt, moved, runs = 0, 0.0, 0.0, 0
+        while dt < 2.7 and runs < 200:
+            s = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=threads)
+            tw = time.perf_counter()
+            s.minimize(qo.morethuente(), o, 3, 20)  # warm the caches / thread pool
+            tw = (time.perf_counter() - tw) / 3.0
+            if sub == 0 and runs == 0 and tw * per_run > 2.0:  # a host far slower than planned for: keep the whole sample near 10-30 s whatever it is
+                per_run = max(3, int(2.0 / tw))
+            bytes0, calls0 = s.bytes_streamed, o.calls
+            t0 = time.perf_counter()
+            s.minimize(qo.morethuente(), o, per_run, 20)  # warm restart: continues from the warmed-up state
+            dt += time.perf_counter() - t0
+            k += s.k
+            moved += (s.bytes_streamed - bytes0) + (o.calls - calls0) * 8.0 * n * n
+            runs += 1
+            del s
+        subs.append({"value": k / dt, "iterations": k, "seconds": dt, "achieved_GBs": moved / dt / 1e9})
+        tot_k += k; tot_dt += dt; tot_moved += moved; tot_runs += runs
+    val = _median([u["value"] for u in subs])
+    out = {"value": val, "unit": "iterations/s", "cores": threads, "kind": "port",
+           "sub_samples": [u["value"] for u in subs], "sub_sample_spread": (max(u["value"] for u in subs) - min(u["value"] for u in subs)) / val,
+           "achieved_GBs": _median([u["achieved_GBs"] for u in subs]), "bytes_per_iteration": tot_moved / max(tot_k, 1),
            "numa_nodes": len(glob.glob("/sys/devices/system/node/node[0-9]*")) or None,
            "bytes_note": "matrix bytes the port streams: 8 n^2 per oracle call (full Q by rows), 8 n^2 per mat-vec with H (u = H y, "
                          "d = -H g), 16 n^2 for the rank-2 update",
-           "sample": f"{k} BFGS+MoreThuente iterations at n={n} in {runs} runs of {per_run} from (x0, H = I) (same Q, b, x0 as the GPU run), "
-                     f"rank-2 O(n^2) update, reference oracle-call sequence (5 calls per iteration), OpenMP x{threads}, {dt:.1f} s"}
+           "sample": f"median of 3 sub-samples; in all {tot_k} BFGS+MoreThuente iterations at n={n} in {tot_runs} runs of {per_run} from (x0, H = I) (same Q, b, x0 as the GPU run), "
+                     f"rank-2 O(n^2) update, reference oracle-call sequence (5 calls per iteration), OpenMP x{threads}, {tot_dt:.1f} s"}
     # the reference's own formulation (dense n x n products, single thread as matrixmultiply is built) at a size it finishes
     n_small = 384
     d2, b2, x2 = synth_inputs(n_small)
@@ -165,9 +185,192 @@ def cpu_baseline_child(n, iters, threads=None):
     return out
 
 
+NEWTON_N = 8192          # BASELINE.json configs[3]
+LSE_N = 16384            # BASELINE.json configs[4]
+LSE_MU, LSE_A_SCALE, LSE_SEED = 0.1, 2.0, 11
+
+
+def lse_inputs(n):
+    """The config-5 instance of tools/bench_config5.py and tests/test_gpu_logsumexp.py: A ~ N(0, (2 / sqrt n)^2), c, x0 ~ N(0, 1), mu = 0.1."""
+    rng = np.random.default_rng(LSE_SEED)
+    a = rng.standard_normal((n, n)) * (LSE_A_SCALE / np.sqrt(n))
+    c = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    return a, c, x0
+
+
+def cpu_leg_config4(qo, n_full):
+    """Newton (newton/mod.rs:26-49) as the reference runs it: `try_inverse` = LU with partial pivoting + the explicit inverse, 2 n^3
+    flop, ONE thread (nalgebra's LU is not threaded) -- at n = 8192 that is 1.1e12 flop, minutes.  Bounded sample: the same
+    restatement on the same synthetic family at n = 768, three runs, extrapolated with n^3 (stated in `sample`)."""
+    n = 768
+    diag, b, x0 = synth_inputs(n)
+    q = qo.synth_rows(n, 0, n, SEED, diag)
+    per = []
+    for _ in range(3):
+        oq = qo.QuadraticOracle(q, b)
+        s = qo.Solver(qo.NEWTON, 1e-8, x0)
+        s.set_hessian(oq)
+        t0 = time.perf_counter()
+        s.minimize(qo.morethuente(), oq, 10, 20)
+        dt = time.perf_counter() - t0
+        per.append(dt / max(s.k, 1))
+        its = s.k
+    sec = _median(per) * (n_full / n) ** 3
+    return {"value": 1.0 / sec, "unit": "Newton iterations/s", "cores": 1, "kind": "port",
+            "s_per_iteration_extrapolated": sec, "sub_samples_s_per_iteration_at_n768": per,
+            "sample": f"oracle Newton (LU + explicit inverse as nalgebra's try_inverse, 1 thread) on the synthetic quadratic at n={n}: {its} iterations "
+                      f"per run, 3 runs, median {1e3 * _median(per):.0f} ms per iteration, extrapolated with n^3 to n={n_full}"}
+
+
+def cpu_leg_config5(qo, n_full, threads):
+    """DFP + More-Thuente on the log-sum-exp objective: the oracle's port (rank-2 O(n^2) update, threaded row sweeps of A and H).  At
+    n = m = 16384 the port needs 1-2 s per iteration on 16 cores (A and H are 2 GiB each), so the bounded sample is the same family at
+    n = m = 8192 -- three sub-samples continuing one run -- scaled with n^2 (every sweep of an iteration is over an n x n or m x n
+    matrix: the port is bandwidth-bound); stated in `sample`."""
+    n = 8192
+    a, c, x0 = lse_inputs(n)
+    o = qo.LogSumExpOracle(a, c, LSE_MU, nthreads=threads)
+    s = qo.Solver(qo.DFP, 1e-10, x0, qo.UPDATE_RANK2, nthreads=threads)
+    tw = time.perf_counter()
+    s.minimize(qo.morethuente(), o, 2, 20)
+    tw = (time.perf_counter() - tw) / 2.0
+    per_sub = max(2, min(40, int(1.5 / max(tw, 1e-3))))
+    subs = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        s.minimize(qo.morethuente(), o, per_sub, 20)  # (a continued call: k restarts, the state does not)
+        dt = time.perf_counter() - t0
+        subs.append(s.k / dt)
+    scale = (n / n_full) ** 2
+    val = _median(subs) * scale
+    return {"value": val, "unit": "iterations/s", "cores": threads, "kind": "port", "sub_samples_at_n8192": subs,
+            "sub_sample_spread": (max(subs) - min(subs)) / _median(subs),
+            "sample": f"oracle DFP + MoreThuente on the log-sum-exp family of the GPU leg at n=m={n} (A ~ N(0, (2/sqrt n)^2), mu={LSE_MU}), rank-2 O(n^2) update, "
+                      f"OpenMP x{threads}: 3 sub-samples of {per_sub} iterations continuing one run after 2 warm-up iterations, median "
+                      f"{_median(subs):.2f} it/s, scaled with (n/{n_full})^2 to n=m={n_full}"}
+
+
+def cpu_baseline_child(n, iters, threads=None, extra=True):
+    from oracle import qn_oracle as qo  # (the first OpenMP runtime of this process: the pinning is in the environment already)
+    threads = min(qo.max_threads(), threads) if threads else min(qo.max_threads(), host_cpu_share())
+    out = {}
+    legs = [("config2", lambda: cpu_leg_config2(qo, n, iters, threads))]
+    if extra:
+        legs += [("config4", lambda: cpu_leg_config4(qo, NEWTON_N)), ("config5", lambda: cpu_leg_config5(qo, LSE_N, threads))]
+    for name, leg in legs:
+        try:
+            out[name] = leg()
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": repr(e)}
+    return out
+
+
+MFMA_F64_PEAK_TFLOPS = 78.6  # dense v_mfma_f64 peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md); a pure v_mfma_f64_16x16x4_f64 loop sustains 47.8 here
+
+
+def extra_config4(qn, ctx):
+    """BASELINE.json configs[3]: Newton (src/newton/mod.rs) on the n = 8192 synthetic quadratic, dense Hessian solve on the GPU.  The
+    SPD Hessian takes the blocked Cholesky (f64 MFMA trailing updates); `lu` forces the pivoted LU the reference's try_inverse
+    stands for (what an indefinite or non-symmetric Hessian gets).  One Newton iteration = one factorisation + the sweeps of
+    d = -H^-1 g and of the decrement's second solve (newton/mod.rs:38-40) + the line search's evaluations."""
+    n = NEWTON_N
+    diag, b, x0 = synth_inputs(n)
+    obj = qn.Quadratic.synthetic(n, SEED, diag, b, ctx=ctx)
+    out = {"workload": f"Newton + MoreThuente::default, n={n} convex quadratic (random SPD Q, kappa=1e3, seed 0x5EED0001), f64, 1xMI355X", "dtype": "f64"}
+    for label, force_lu, flops in (("cholesky", False, n ** 3 / 3.0), ("lu", True, 2.0 * n ** 3 / 3.0)):
+        wall, its = [], 0
+        for rep in range(4):  # (the first repetition allocates the factorisation's buffers)
+            s = qn.Newton(1e-8, x0, ctx=ctx)
+            if force_lu:
+                s.set_tiling(-5, 0)
+            if rep == 3:
+                s.set_profiling(True)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            s.minimize(qn.MoreThuente(), obj, 10, 20)
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            its = s.k()
+            if rep in (1, 2):
+                wall.append(dt / max(its, 1))
+            if rep == 3:
+                st = s.stats()
+                ev_ms = st["t_newton_ms"] / max(st["n_newton_timed"], 1)
+                timeouts = st["newton_lu_sync_timeouts"]
+            del s
+        ms = 1e3 * min(wall)
+        tf = flops / (ev_ms * 1e-3) / 1e12
+        out[label] = {"metric": "Newton iterations/s", "value": 1e3 / ms, "unit": "iterations/s", "ms_per_iteration": ms, "iterations_per_run": its,
+                      "ms_per_iteration_runs": [1e3 * w for w in wall],
+                      "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TFLOPS,
+                                   "traffic": None, "flops_per_direction": flops, "avg_direction_ms": ev_ms,
+                                   "kernel": ("chol_syrk_kernel (depth-256 trailing updates on v_mfma_f64_16x16x4_f64) beside the diagonal-block / panel chain" if not force_lu
+                                              else "lu_panel_persist_kernel (one CU's dependent pivot chain) beside lu_gemm2_kernel (MFMA trailing update) on the masked stream"),
+                                   "note": "factorisation flops (n^3/3 Cholesky, 2n^3/3 LU) / HIP-event time of one direction request (staging + factorisation + the "
+                                           "substitution sweeps) on the solver's stream; the chain of small dependent kernels, not the MFMA rate, bounds both (DESIGN.md 8 f2)"},
+                      "lu_sync_timeouts": timeouts}
+    return out
+
+
+def extra_config5(qn, ctx):
+    """BASELINE.json configs[4] on one GPU (the config names 4: the driver's scaling run has no slot for it): DFP + More-Thuente on the
+    n = m = 16384 log-sum-exp objective f = log sum_i exp(a_i'x + c_i) + mu/2 ||x||^2 (dfp.rs:78-123, morethuente.rs:165-297).  A (2 GiB)
+    is generated on the host and uploaded once; the timed region has everything resident."""
+    n = LSE_N
+    a, c, x0 = lse_inputs(n)
+    obj = qn.LogSumExp(a, c, LSE_MU, ctx=ctx)
+    del a
+    s = qn.DFP(1e-10, x0, ctx=ctx)
+
+    def run(k):
+        try:
+            s.minimize(qn.MoreThuente(), obj, k, 20)
+        except qn.MaxIterReached:
+            pass
+    run(3)  # warm-up (continued below: one run)
+    steps, regions = 20, []
+    for _ in range(3):
+        ctx.synchronize()
+        st0 = s.stats()
+        t0 = time.perf_counter()
+        run(steps)
+        ctx.synchronize()
+        regions.append((time.perf_counter() - t0, s.stats()["total_oracle_evals"] - st0["total_oracle_evals"]))
+    dt, evals = sorted(regions)[1]
+    s.set_profiling(True)
+    p0 = s.stats()
+    run(8)
+    p1 = s.stats()
+    s.set_profiling(False)
+    n_h, n_e = p1["n_hpass_timed"] - p0["n_hpass_timed"], p1["n_eval_timed"] - p0["n_eval_timed"]
+    ms_h = (p1["t_hpass_ms"] - p0["t_hpass_ms"]) / max(n_h, 1)
+    ms_e = (p1["t_eval_ms"] - p0["t_eval_ms"]) / max(n_e, 1)
+    alg_h, alg_e = 2.0 * p1["matrix_bytes_per_pass"], 8.0 * n * n
+    e_per_it = evals / steps
+    b_iter = alg_h + e_per_it * alg_e
+    dom_eval = n_e * ms_e > n_h * ms_h
+    ach = (alg_e / (ms_e * 1e-3) if dom_eval else alg_h / (ms_h * 1e-3)) / 1e9
+    return {"workload": f"DFP + MoreThuente::default, n=m={n} log-sum-exp (mu={LSE_MU}, A ~ N(0, ({LSE_A_SCALE:g}/sqrt n)^2), seed {LSE_SEED}), f64, 1xMI355X "
+                        "(BASELINE.json configs[4] names 4 GPUs: tests/test_gpu_partitions.py runs that partition)",
+            "metric": "DFP iterations/s", "value": steps / dt, "unit": "iterations/s", "ms_per_iteration": 1e3 * dt / steps, "steps": steps, "dtype": "f64",
+            "region_ms": [1e3 * r[0] for r in regions], "evaluations_per_iteration": e_per_it,
+            "algorithmic_bytes_per_iteration": b_iter, "whole_iteration_hbm_frac": b_iter * (steps / dt) / (HBM_PEAK_GBS * 1e9),
+            "launches_per_iteration": (p1["launches"] - p0["launches"]) / 8.0,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": ("lse_onepass_kernel (f and the gradient in ONE pass over A: running-maximum softmax)" if dom_eval else
+                                    "the update pass over the symmetric half of H (pending rank-2 update + H+ [y, g+])"),
+                         "dominant_by": "largest share of the GPU time (launches x average HIP-event duration, synchronous profiling pass)",
+                         "objective_eval": {"algorithmic_bytes_per_launch": alg_e, "avg_launch_ms": ms_e, "launches_timed": n_e,
+                                            "achieved": alg_e / (ms_e * 1e-3) / 1e9 if n_e else None},
+                         "update_pass": {"algorithmic_bytes_per_launch": alg_h, "avg_launch_ms": ms_h, "launches_timed": n_h,
+                                         "achieved": alg_h / (ms_h * 1e-3) / 1e9 if n_h else None}}}
+
+
 def main():
-    if len(sys.argv) in (4, 5) and sys.argv[1] == "--cpu-baseline-child":  # (no torch, no GPU: see cpu_baseline)
-        print(json.dumps(cpu_baseline_child(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) == 5 else None)), flush=True)
+    if len(sys.argv) in (4, 5, 6) and sys.argv[1] == "--cpu-baseline-child":  # (no torch, no GPU: see cpu_baseline)
+        print(json.dumps(cpu_baseline_child(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) >= 5 else None,
+                                            (sys.argv[5] != "0") if len(sys.argv) >= 6 else True)), flush=True)
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +379,8 @@ def main():
     ap.add_argument("--dim", type=int, default=None, help="override the problem dimension n")
     ap.add_argument("--ls", default="mt", choices=["mt", "bt"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="N = 1: skip the `extra_configs` legs (BASELINE.json configs[3] Newton n=8192 and configs[4] DFP + log-sum-exp n=16384)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-scaling-ref", action="store_true",
                     help="N > 1: skip the single-GPU run of the same workload on rank 0 (strong-scaling denominator)")
@@ -191,6 +396,13 @@ def main():
             sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         if world > 1:
             sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    # The CPU legs run FIRST, in a child, to completion: this process has not loaded torch, HIP or the library yet (see cpu_baseline).
+    n_headline = args.dim or (4096 if world == 1 else 32768)
+    want_extra = world == 1 and args.dim is None and not args.no_extra_configs
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(n_headline, 200 if n_headline <= 4096 else 4, extra=want_extra)
 
     import torch  # device plumbing + torch.distributed rendezvous only
     import torch.distributed as dist
@@ -302,13 +514,15 @@ def main():
             run_iterations(qn, solver, ls, obj, x0, 5)
             barrier()
             t0 = time.perf_counter()
-            run_iterations(qn, solver, ls, obj, x0, k)
+            extra_calls = run_iterations(qn, solver, ls, obj, x0, k)
             ctx.synchronize()
+            if extra_calls:  # the run converged inside the interval: a reset and a second call were timed with it
+                return None
             ts.append(time.perf_counter() - t0)
         ts.sort()
         return 1e3 * ts[len(ts) // 2]
     t4, t24 = timed_call(4), timed_call(24)
-    per_call_fixed_ms = max(0.0, t4 - 4.0 * (t24 - t4) / 20.0)
+    per_call_fixed_ms = (t4 - 4.0 * (t24 - t4) / 20.0) if (t4 is not None and t24 is not None) else None  # (a negative intercept is reported as it is)
 
     # kernel-level roofline: same workload again with every launch bracketed by HIP events on the solver's stream
     roofline = None
@@ -478,8 +692,23 @@ def main():
                                      "note": "counters are the solver's cumulative totals differenced around the median timed region"},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, 200 if n <= 4096 else 4)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu.get("config2", cpu) if "error" not in cpu else cpu
+        if want_extra:
+            # BASELINE.json configs[3] and configs[4], driver-visible: timed after the headline region, each with
+            # its own roofline and CPU leg.  The headline `value` / `config` stay configs[1].
+            del solver, obj
+            extra = {}
+            for name, leg in (("config4_newton_n8192", lambda: extra_config4(qn, ctx)), ("config5_dfp_logsumexp_n16384", lambda: extra_config5(qn, ctx))):
+                try:
+                    extra[name] = leg()
+                except Exception as e:  # noqa: BLE001 -- an extra leg never loses the bench line
+                    extra[name] = {"error": repr(e)}
+            if cpu is not None and "error" not in cpu:
+                for name, key in (("config4_newton_n8192", "config4"), ("config5_dfp_logsumexp_n16384", "config5")):
+                    if isinstance(extra.get(name), dict):
+                        extra[name]["cpu_baseline"] = cpu.get(key)
+            out["extra_configs"] = extra
         if world > 1 and not args.no_scaling_ref:
             # strong-scaling denominator: the SAME workload unsharded on rank 0's GPU alone (N = 1 of the default run
             # is configs[1], a different problem size, so value(N)/value(1) across default runs is not an efficiency)

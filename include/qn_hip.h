@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define QN_ABI_VERSION 3
+#define QN_ABI_VERSION 4
 
 /* SolverError (ls_solver.rs:10-20); 0 is Ok(()) */
 typedef enum {
@@ -261,6 +261,13 @@ typedef struct {
      * the all-reduce north_star names, as an all-gather + rank-order sum or as ncclAllReduce), and of per-workgroup scalars
      * (8 KB per rank: what an evaluation hands the line search on the second-generation path) */
     uint64_t total_xchg_vector, total_xchg_scalar;
+    /* Newton (newton/mod.rs:26-49), profiling mode: HIP-event time of the direction requests (staging, factorisation, the four
+     * triangular sweeps of d = -H^-1 g and of the decrement's second solve) */
+    double   t_newton_ms;
+    uint64_t n_newton_timed;
+    /* pivoted-LU path: times a bounded wait of the one-launch panel / sweep kernels expired and the factorisation was run again
+     * with one launch per step (a co-tenant on the GPU can do that; the result is the same, the iteration slower) */
+    uint64_t newton_lu_sync_timeouts;
 } qn_stats;
 #define QN_PATH_FUSED 1u       /* fused fast path (device quadratic, memoised): no kernel but the streaming ones touches an n-vector */
 #define QN_PATH_SYM 2u         /* ... on the symmetric half of H and Q only */

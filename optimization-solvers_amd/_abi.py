@@ -53,7 +53,8 @@ class Stats(C.Structure):
                 ("total_oracle_evals", C.c_uint64), ("total_h_passes", C.c_uint64), ("total_h_bytes", C.c_uint64),
                 ("total_obj_bytes", C.c_uint64), ("path", C.c_uint32), ("_pad", C.c_uint32),
                 ("t_hreduce_ms", C.c_double), ("t_ereduce_ms", C.c_double), ("n_hreduce_timed", C.c_uint64), ("n_ereduce_timed", C.c_uint64),
-                ("total_xchg_vector", C.c_uint64), ("total_xchg_scalar", C.c_uint64)]
+                ("total_xchg_vector", C.c_uint64), ("total_xchg_scalar", C.c_uint64),
+                ("t_newton_ms", C.c_double), ("n_newton_timed", C.c_uint64), ("newton_lu_sync_timeouts", C.c_uint64)]
 
 
 PATH_FUSED, PATH_SYM, PATH_SYM_GENERIC, PATH_PIPELINED, PATH_SYM2 = 1, 2, 4, 8, 16

@@ -789,7 +789,7 @@ extern "C" int qn_objective_eval(qn_objective* o, const double* x_host, double* 
 // ------------------------------------------------------------------------------------------------
 // solver
 // ------------------------------------------------------------------------------------------------
-enum { KC_HPASS = 0, KC_EVAL = 1, KC_CTL = 2, KC_COMM = 3, KC_HREDUCE = 4, KC_EREDUCE = 5 };
+enum { KC_HPASS = 0, KC_EVAL = 1, KC_CTL = 2, KC_COMM = 3, KC_HREDUCE = 4, KC_EREDUCE = 5, KC_NEWTON = 6 };
 struct TimedEvent { hipEvent_t a, b; int cls; };
 
 struct qn_solver {
@@ -819,6 +819,8 @@ struct qn_solver {
     int s2_sl_first = 0, s2_sl_per = 0, s2_sl_cfg = -1; // row slivers (QnS2Args.sl_first / sl_per); the switches the lists were built for
     bool no_sliver = false;    // diagnostics: sym2 without row slivers (round 2's work lists)
     bool no_pair = false;      // diagnostics: the general evaluation kernel where the two-items-and-a-sliver instance would run
+    bool tred = false;         // measurement: the update-reduce in the tail of the update-tile launch (s2_hpass_kernel<.., TRED>: bit-identical, slower)
+    int* s2_cnt = nullptr;     // tail reduce: arrival counters of the block-rows
     bool h_sliver_whole = false; // the diagonal tiles that sliver rows read are complete (both triangles): kept so by sliver-mode update passes
     double* s2_evS = nullptr;   // row-sharded: [2][world][QN_S2SH_NEC][QN_S2_MAXG] the ranks' evaluation scalars, by launch parity (QnS2Args.evS)
     int *s2_sl_off = nullptr, *s2_sl_idx = nullptr; // row-sharded: per block-row, the slots this rank's tiles write (QnS2Args.sl_off / sl_idx)
@@ -853,6 +855,7 @@ struct qn_solver {
     int newton_lu_no_persist = 0; // diagnostics (rows = -11), or set after a bounded wait of the one-launch panel gave up: one launch per sub-panel
     int* newton_sync = nullptr;   // the one-launch panel's counters (qn_lu.hip.h, lu_panel_persist_kernel)
     uint64_t newton_lu_sync_timeouts = 0;
+    int newton_lu_timeout_fallback = 0; // newton_lu_no_persist was set by an expired wait (not by the diagnostics switch): how many factorisations have run launch by launch since
     int newton_lu_no_la = 0; // diagnostics (rows = -10): the LU without the look-ahead on a second stream
     int newton_force_lu = 0; // diagnostics (qn_solver_set_tiling rows = -5): skip the Cholesky attempt
     size_t newton_n64 = 0;
@@ -897,8 +900,10 @@ static void prof_collect(qn_solver* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     // In pipelined mode the launch pattern runs ahead of the decisions, so some bracketed launches found their request not
     // pending and returned from the prologue (a few microseconds).  They are not work: a class's sums take only the launches
-    // that lasted more than half its LONGEST launch (in synchronous mode every launch is real and passes; a median-based floor failed
-    // when most of a class's launches were skipped -- backtracking's four slots per period, a run that ends early in a batch).
+    // that lasted more than half of one of its LONGEST launches (in synchronous mode every launch is real and passes; a median-based
+    // floor failed when most of a class's launches were skipped -- backtracking's four slots per period, a run that ends early in a
+    // batch).  "One of the longest" = the (n / 50 + 1)-th longest: a single outlier twice the typical duration (a cold first launch,
+    // a co-tenant's preemption) would otherwise set a floor that discards every genuine launch.
     std::vector<std::vector<float>> dur(8);
     std::vector<std::pair<int, float>> all;
     all.reserve(s->events.size());
@@ -913,7 +918,11 @@ static void prof_collect(qn_solver* s) {
     float floor_ms[8];
     for (int c = 0; c < 8; ++c) {
         floor_ms[c] = 0.f;
-        if (dur[c].size() >= 8) floor_ms[c] = 0.5f * *std::max_element(dur[c].begin(), dur[c].end());
+        if (dur[c].size() >= 8) {
+            const size_t kth = dur[c].size() / 50; // 0: the maximum
+            std::nth_element(dur[c].begin(), dur[c].begin() + kth, dur[c].end(), std::greater<float>());
+            floor_ms[c] = 0.5f * dur[c][kth];
+        }
     }
     for (auto& e : all) {
         const int cls = (e.first >= 0 && e.first < 7) ? e.first : 7;
@@ -925,6 +934,7 @@ static void prof_collect(qn_solver* s) {
         case KC_CTL: s->stats.t_ctl_ms += ms; s->stats.n_ctl_timed++; break;
         case KC_HREDUCE: s->stats.t_hreduce_ms += ms; s->stats.n_hreduce_timed++; break;
         case KC_EREDUCE: s->stats.t_ereduce_ms += ms; s->stats.n_ereduce_timed++; break;
+        case KC_NEWTON: s->stats.t_newton_ms += ms; s->stats.n_newton_timed++; break;
         default: s->stats.t_comm_ms += ms; s->stats.n_comm_timed++; break;
         }
     }
@@ -1005,9 +1015,9 @@ static int solver_alloc_sym2(qn_solver* s) {
     const int cfg = (s->fold ? 1 : 0) | (s->no_sliver ? 2 : 0) | (sharded ? 4 : 0);
     if (s->s2_nb != nb || s->s2_sl_cfg != cfg) {
         (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE);
-        (void)hipFree(s->s2_evS);
+        (void)hipFree(s->s2_evS); (void)hipFree(s->s2_cnt);
         s->s2_items = nullptr; s->s2_wgS = nullptr; s->s2_partE = nullptr;
-        s->s2_evS = nullptr;
+        s->s2_evS = nullptr; s->s2_cnt = nullptr;
         s->s2_nb = 0;
         const int nbl = s->T.rpr / QN_TB, ioff = rank * nbl; // (sharded: this rank's block-rows)
         int nitems = nb * (nb + 1) / 2;
@@ -1099,6 +1109,8 @@ static int solver_alloc_sym2(qn_solver* s) {
         s->s2_trows = std::max(QN_S2_MAXG, (nb + 63) / 64 * 64);
         QNCHK(dev_alloc_zero(&s->s2_wgS, (size_t)2 * s->s2_trows * QN_S2_ROW, st));
         QNCHK(dev_alloc_zero(&s->s2_partE, (size_t)nb * nb * QN_TB, st));
+        HIPCHK(hipMalloc((void**)&s->s2_cnt, (size_t)nb * QN_S2_CNT_STRIDE * sizeof(int)));
+        HIPCHK(hipMemsetAsync(s->s2_cnt, 0, (size_t)nb * QN_S2_CNT_STRIDE * sizeof(int), st));
         if (sharded) {
             QNCHK(dev_alloc_zero(&s->s2_evS, (size_t)2 * world * QN_S2SH_NEC * QN_S2_MAXG, st));
         }
@@ -1178,7 +1190,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE); (void)hipFree(s->s2_ctl);
-    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx); (void)hipFree(s->symsh_tiles);
+    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_cnt); (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx); (void)hipFree(s->symsh_tiles);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
     delete s;
@@ -1240,6 +1252,7 @@ extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_sp
     if (rows_per_block == -10) { s->newton_lu_no_la = 1; return QN_OK; } // diagnostics: ... one stream, no look-ahead
     if (rows_per_block == -8) { s->newton_lu_percol = 1; return QN_OK; } // diagnostics: ... with the per-column panel kernels
     if (rows_per_block == -9) { s->no_pair = !s->no_pair; return QN_OK; }     // diagnostics: general evaluation kernel (toggles)
+    if (rows_per_block == -13) { s->tred = !s->tred; return QN_OK; }         // measurement: the update-reduce in the update-tile launch's tail (toggles)
     if (rows_per_block == -7) { s->no_sliver = !s->no_sliver; return QN_OK; } // diagnostics: sym2 without row slivers (toggles)
     if (rows_per_block == -6) { s->fold = 1; return QN_OK; }           // measurement: sym2 with the folded accept-reduce (see qn_solver::fold)
     if (rows_per_block == -4) { s->no_sym2 = 1; rows_per_block = 0; }  // diagnostics: first-generation symmetric tile kernels (8 launches per iteration)
@@ -1777,6 +1790,14 @@ static int s2_launch(Run& r, int kind) {
         } else if (a.fold) { // (n <= 4096: H stays in the Infinity Cache, no streaming hints)
             if (s->method == QN_BFGS) hipLaunchKernelGGL((s2_hpass_kernel<false, true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
             else hipLaunchKernelGGL((s2_hpass_kernel<false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        } else if (a.tred) { // the update-reduce in the launch's tail
+            if (s->method == QN_BFGS) {
+                if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, true, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+                else hipLaunchKernelGGL((s2_hpass_kernel<false, true, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            } else {
+                if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+                else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            }
         } else if (s->method == QN_BFGS) {
             if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
             else hipLaunchKernelGGL((s2_hpass_kernel<false, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
@@ -1845,6 +1866,7 @@ static int s2_do_hpass(Run& r, bool tiles) {
     qn_solver* s = r.s;
     qn_context* c = s->ctx;
     if (tiles) QNCHK(s2_launch(r, QN_S2_HTILE));
+    if (r.s2.tred) return QN_OK; // (tail reduce: the tile launch has summed the slots itself)
     if (r.s2.sh_world > 1) {
         QNCHK(s2_launch(r, QN_S2_HSUM));
         ProfScope ps(s, KC_COMM);
@@ -1906,11 +1928,18 @@ static int place_h(Run& r) {
         pe->ev_kind = QN_REQ_T; pe->t = 1.0; pe->status = -1;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { // no probe: H stays where it is, nothing is left behind
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        if (pe) (void)hipHostFree(pe);
+        return QN_OK;
+    }
+    // (every failure below -- inside time_on too -- comes back as `status` and leaves through the one cleanup path at the end: the
+    // candidates that are not kept, the events and the pinned block are freed, H stays the solver's own)
     auto time_on = [&](double* H, float* out_us) -> int {
         QnS2Args a = r.s2;
         a.H = H; a.parity = 0; a.ctl_first = pc; a.rep_seq = 0;
+        a.tred = 0; // (the probe times the tiles; the tail reduce would overwrite u, v and g with the probe's sums)
         float t[6];
         for (int rep = 0; rep < 6; ++rep) {
             if (pe) {
@@ -2258,8 +2287,28 @@ static int ensure_masked_stream(qn_context* c) {
 
 // Pivoted LU of the staged Hessian and the two solves (qn_lu.hip.h); leaves d in V.d, z = H^-1 d in V.s, and newton_fail[0] = 1
 // when a pivot column is exactly zero (then QN_ST_AFTER_NEWTON takes -g, newton/mod.rs:43-46).
+// A bounded wait of the one-launch LU kernels expired (the bound is a number of polls: a co-tenant on the GPU, or workgroups that were
+// not resident together, can do that).  The factorisation is run again launch by launch -- same bits -- and so are the next
+// QN_LU_RETRY_AFTER ones; then the one-launch kernels get another chance (one transient used to cost the solver 54
+// instead of 47 ms per iteration for the rest of its life, invisibly).  Counted in qn_stats.newton_lu_sync_timeouts, said once on stderr.
+#define QN_LU_RETRY_AFTER 8
+static void lu_note_timeout(qn_solver* s) {
+    s->newton_lu_no_persist = 1;
+    s->newton_lu_timeout_fallback = 1;
+    s->newton_lu_sync_timeouts++;
+    s->stats.newton_lu_sync_timeouts = s->newton_lu_sync_timeouts;
+    s->newton_lu_runs--;
+    static std::atomic<int> said{0};
+    if (said.exchange(1) == 0)
+        fprintf(stderr, "[qn] Newton / LU: a bounded wait of the one-launch kernels expired; this factorisation and the next %d run launch by launch "
+                        "(same result, slower; qn_stats.newton_lu_sync_timeouts counts these)\n", QN_LU_RETRY_AFTER);
+}
 static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     hipStream_t st = s->ctx->stream;
+    if (s->newton_lu_timeout_fallback && ++s->newton_lu_timeout_fallback > 1 + QN_LU_RETRY_AFTER) { // (the re-run itself is the first)
+        s->newton_lu_timeout_fallback = 0;
+        s->newton_lu_no_persist = 0;
+    }
     const int n = (int)s->n, n64 = (int)s->newton_n64;
     const int nlu = (n + QN_NB - 1) / QN_NB * QN_NB; // the factorisation works on whole 64-blocks; identity padding
     const size_t ld = s->newton_n64;
@@ -2412,11 +2461,9 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     HIPCHK(hipStreamSynchronize(st));
     s->stats.host_syncs++;
     s->stats.launches += launches;
-    if (lu_failed == 2) { // a bounded wait of the one-launch panel gave up (its workgroups were not placed together): one launch per sub-panel from now on
-        s->newton_lu_no_persist = 1;
-        s->newton_lu_sync_timeouts++;
-        s->newton_lu_runs--;
-        return enqueue_newton_lu(s, hsrc, ld_src);
+    if (lu_failed == 2) { // a bounded wait of the one-launch panel gave up (its workgroups were not placed together): one launch per sub-panel for a while
+        lu_note_timeout(s);
+        return enqueue_newton_lu(s, hsrc, ld_src); // (the abandoned attempt's launches stay counted: they ran)
     }
     if (lu_failed) return QN_OK; // singular: the control kernel falls back to -g
     std::vector<int> perm((size_t)nlu);
@@ -2453,9 +2500,7 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     if (persist) HIPCHK(hipMemcpyAsync(&lu_failed, flag, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st)); // `perm` is a local
     if (persist && lu_failed == 2) { // a bounded wait of a one-launch sweep gave up: the whole factorisation again, launch by launch
-        s->newton_lu_no_persist = 1;
-        s->newton_lu_sync_timeouts++;
-        s->newton_lu_runs--;
+        lu_note_timeout(s);
         return enqueue_newton_lu(s, hsrc, ld_src);
     }
     return QN_OK;
@@ -2787,6 +2832,14 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.sh_nsum = c->use_allreduce ? 1 : c->world;
         a.evS = s->s2_evS; a.xg = s->symsh_xg; a.sl_off = s->s2_sl_off; a.sl_idx = s->s2_sl_idx;
         if (c->world > 1) { a.fold = 0; a.pair = 0; }
+        // tail reduce (s2_hpass_kernel<.., TRED>): the update-reduce in the tail of the update-tile launch, 4 launches per iteration
+        // instead of 5 -- one rank, lists short enough for one wave to announce (n <= ~15 k).  BUILT, BIT-IDENTICAL, SLOWER, OFF BY
+        // DEFAULT (QN_S2_TRED=1 / set_tiling(-13, 0) switch it on; the note in front of the kernel has the stamps): the update kernel
+        // 23.5 -> 36.7 us for a 5.0 us launch saved.
+        a.cnt = s->s2_cnt;
+        a.cnt_stride = getenv("QN_S2_CNT_STRIDE") ? std::max(1, std::min(QN_S2_CNT_STRIDE, atoi(getenv("QN_S2_CNT_STRIDE")))) : QN_S2_CNT_STRIDE; // (diagnostics)
+        const bool want_tred = getenv("QN_S2_TRED") ? atoi(getenv("QN_S2_TRED")) != 0 : s->tred;
+        a.tred = (c->world == 1 && !a.fold && s->s2_maxk <= QN_S2_TRED_MAXK && want_tred) ? 1 : 0;
         // WHO GETS THE INFINITY CACHE (256 MB).  Per iteration a rank streams its half of Q twice (read) and its half of H once
         // (read + written); non-temporal accesses pass the cache by.  Measured (round 4, bench.py same box, it/s for the policies
         // H plain / Q plain, H plain / Q non-temporal, H non-temporal / Q plain, both non-temporal):
@@ -2882,7 +2935,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             else if (ph == QN_PH_REQ_HPASS_EVAL) { // fused path: update pass, then the evaluation that derives the update's coefficients itself
                 QNCHK(enqueue_hpass_req(r)); QNCHK(enqueue_eval(r, 1)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS_EVAL));
             }
-            else if (ph == QN_PH_REQ_NEWTON) { QNCHK(enqueue_newton(s, o, r.obj)); QNCHK(launch_ctl(r, QN_PH_REQ_NEWTON)); }
+            else if (ph == QN_PH_REQ_NEWTON) { { ProfScope ps(s, KC_NEWTON); QNCHK(enqueue_newton(s, o, r.obj)); } QNCHK(launch_ctl(r, QN_PH_REQ_NEWTON)); }
             else if (ph == QN_PH_ITER_DONE) { callback(callback_user, s); QNCHK(launch_ctl(r, QN_PH_ITER_DONE)); }
             else return fail(QN_ABNORMAL_TERMINATION, "control block in an unexpected phase");
         }

@@ -50,6 +50,9 @@
 #define QN_S2SH_NEC 4  // row-sharded runs: the evaluation scalars that are exchanged, per workgroup: x'(Q xt - 2 b), d'(Q xt - b), g'd,
                        // #non-finite d (the table's b'xt and b'd columns are zero by construction: see CONDITIONING below)
 #define QN_S2SH_EB 4   // ... and the slices of them a prologue requests at a time
+#define QN_S2_CNT_STRIDE 1056 // ints between two block-rows' arrival counters: 4 KB + 128 B, so that the counters fall on different memory
+                              // channels (at 128 B apart all of them sat behind ONE channel: the tail took 13 us -- profiles/r05_b_*)
+#define QN_S2_TRED_MAXK 31  // tail reduce: a workgroup's contributions (two per item and the sliver's) are dealt to the lanes of one wave
 
 enum { QN_S2_ADVANCE = 0, QN_S2_EVAL = 1, QN_S2_VEC = 2, QN_S2_HTILE = 3, QN_S2_HREDUCE = 4,
        QN_S2_VSUM = 5, QN_S2_HSUM = 6 }; // (row-sharded runs, qn_sym2sh.hip.h: this rank's slot sums, in front of the exchange of an n-vector)
@@ -68,6 +71,10 @@ struct QnS2Args {
                          // turns them into vectors also writes the update pass's slots (folded accept-reduce)
     int pair;            // every workgroup has two list items and a sliver: s2_eval_kernel<true>
     int fold;            // the accept-reduce runs inside the update-tile launch (workgroups hold <= 3 items: n <= 4096)
+    int tred;            // TAIL REDUCE (round 5): the update-reduce runs in the tail of the update-tile launch -- the workgroup whose slot
+                         // completes block-row R sums R's slots (s2_hpass_kernel<.., TRED>); no s2_hreduce launch follows
+    int* cnt;            // [nb][cnt_stride] arrival counters of the block-rows (zero between launches: the last arriver resets its counter)
+    int cnt_stride;
     int sl_first, sl_per; // ROW SLIVERS (sl_per != 0): the diagonal tiles sl_first .. nb - 1 are not on any work list; each is cut
                          // into sl_per slivers of 8 rows, one per workgroup (workgroup g: tile sl_first + g / sl_per, sliver g % sl_per,
                          // wave w its row 8 (g % sl_per) + w), taken after the workgroup's last item -- see qn_s2_eval_sliver
@@ -317,6 +324,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
                 }
             }
         }
+        QN_S2_STAMP(1); // (the table's values have arrived)
         QnWaveFold<8, 32>::run(acc, lane); // lane l holds the total of column l >> 3
 #pragma unroll
         for (int k = 0; k < QN_S2_NSE; ++k) tot[k] = qn_lane_bcast(acc[0], 8 * k);
@@ -352,7 +360,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
         if (KIND == QN_S2_HREDUCE) mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 1;
         if (c.phase == QN_PH_RUNNING) { c.status = 4; c.phase = QN_PH_DONE; } // a state this path cannot service: abort, never spin
         if (mine) { // as this launch leaves the request
-            if (KIND == QN_S2_HTILE) { c.serviced = mine == 2 ? 2 : 1; if (mine == 2) c.spec_tiles = c.ev_kind == QN_REQ_T ? 2 : 1; }
+            if (KIND == QN_S2_HTILE) { c.serviced = (mine == 2 || a.tred) ? 2 : 1; if (mine == 2) c.spec_tiles = c.ev_kind == QN_REQ_T ? 2 : 1; } // (tail reduce: the launch leaves the pass complete)
             else if (KIND == QN_S2_VSUM) c.serviced = 1; // (the exchange and the reduce launch follow)
             else c.serviced = 2;
         }
@@ -872,17 +880,26 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
 // combined in order through LDS.  In two steps, so that the first 16 slots of every quarter (all of them up to n = 8192) are in
 // flight while the control block is still on its way: the addresses do not depend on it.
 struct QnS2Slots { double v[16]; };
-template <int NRHS = 2>
+// COH (tail reduce, s2_hpass_kernel<.., TRED>): the slots were stored by other workgroups of the SAME launch -- written through
+// (sc1 stores) and read past the non-coherent cache levels (sc1 loads): MI355X_MICROARCH.md, hand-offs, first row of the table
+template <bool COH> __device__ __forceinline__ void qn_s2_slot_st(double* p, const double v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool COH> __device__ __forceinline__ double qn_s2_slot_ld(const double* p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <int NRHS = 2, bool COH = false>
 __device__ __forceinline__ void qn_s2_slot_issue(const double* __restrict__ part, int nb, int R, int rhs, QnS2Slots& S) {
     const int i = threadIdx.x & (QN_TB - 1), qd = threadIdx.x >> 7;
     const int per = (nb + 3) / 4;
     const int k_lo = qd * per, k_hi = min(nb, k_lo + per);
     const double* p = part + (((size_t)R * nb) * NRHS + rhs) * QN_TB + i;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) S.v[u] = (k_lo + u < k_hi) ? p[(size_t)(k_lo + u) * NRHS * QN_TB] : 0.0;
+    for (int u = 0; u < 16; ++u) S.v[u] = (k_lo + u < k_hi) ? qn_s2_slot_ld<COH>(p + (size_t)(k_lo + u) * NRHS * QN_TB) : 0.0;
 }
 // threads 0..127 return the total of row (tid & 127); all 512 threads call it
-template <int NRHS = 2>
+template <int NRHS = 2, bool COH = false>
 __device__ __forceinline__ double qn_s2_slot_sum(const double* __restrict__ part, int nb, int R, int rhs, const QnS2Slots& S, double (*qbuf)[QN_TB]) {
     const int i = threadIdx.x & (QN_TB - 1), qd = threadIdx.x >> 7;
     const int per = (nb + 3) / 4;
@@ -894,7 +911,7 @@ __device__ __forceinline__ double qn_s2_slot_sum(const double* __restrict__ part
     for (int k0 = k_lo + 16; k0 < k_hi; k0 += 16) {
         double v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = (k0 + u < k_hi) ? p[(size_t)(k0 + u) * NRHS * QN_TB] : 0.0;
+        for (int u = 0; u < 16; ++u) v[u] = (k0 + u < k_hi) ? qn_s2_slot_ld<COH>(p + (size_t)(k0 + u) * NRHS * QN_TB) : 0.0;
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc = acc + v[u];
     }
@@ -981,6 +998,32 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
 // once per qn_minimize call) = a two-right-hand-side pass with g in both places -- sixteen specialised copies of the row loop
 // cost more in registers (the compiler kept the load window in scratch memory across them) than the skipped flops were worth.
 // ------------------------------------------------------------------------------------------------
+// (the epilogue of a block-row, given its two totals on threads 0..127: called by s2_hreduce_kernel and by the tail reduce of
+// s2_hpass_kernel<.., TRED> -- one body, the same sums in the same order, hence the same bits; all 512 threads call it)
+__device__ __forceinline__ void qn_s2_hreduce_row(const QnS2Args& a, const int R, const int nrhs, const double tot0, const double tot1, double (*bred)[8]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = 0.0;
+    if (tid < QN_TB) {
+        const int gi = R * QN_TB + tid;
+        const double gp = a.F.GT[gi];
+        if (nrhs == 2) {
+            a.F.UN[gi] = tot0; a.F.VV[gi] = tot1;
+            p[0] = a.F.Y[gi] * tot0; // y'u = y'H+y
+            p[1] = tot0 * gp;        // u'g+
+        } else {
+            a.F.VV[gi] = tot0; // direction pass: v = H g (bfgs.rs:47)
+        }
+        a.F.G[gi] = gp; // commit g <- g+
+    }
+    if (wave < 2) { // threads 0..127 hold the rows
+        QnWaveFold<8, 32>::run(p, lane);
+        if ((lane & 7) == 0) bred[wave][lane >> 3] = p[0];
+    }
+    __syncthreads();
+    if (tid < 2) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = bred[0][tid] + bred[1][tid];
+}
 struct QnS2HReq { // the update-pass request, decoded once per launch
     const double *sp, *up, *r0v, *gt;
     double c_ss, c_su, c_uu;
@@ -1014,9 +1057,38 @@ __device__ __forceinline__ void qn_s2_hvec_load(const QnS2HReq& q, const unsigne
 // BFGS: true -> the update has the (s u' + u s') and s s' terms (bfgs.rs:115-124); false -> DFP: s s' and u u' (dfp.rs:115-120)
 // FOLD: the instantiation for a.fold (its right-hand sides always come from LDS: staged from the vectors when the request is a
 // plain update pass); the other one is round 2's kernel, vectors from global memory, any number of items.
-template <bool NT, bool BFGS, bool FOLD, bool SHARD = false>
+// TRED (round 5): TAIL REDUCE -- the update-reduce without a launch of its own.  Every slot store of the launch
+// is written through (sc1); when a workgroup has stored the slots of all its items, every wave waits for its stores
+// (s_waitcnt vmcnt(0)), the workgroup meets at a barrier and one wave adds 1 to the arrival counter of every block-row the
+// workgroup contributed to -- once per contribution: an off-diagonal item (I, J) contributes to I (row part) and to J (column
+// part), a diagonal item or a row sliver to its own block-row.  Block-row R expects (nb - 1) + 1 contributions ((nb - 1) + sl_per
+// where the diagonal tile is streamed as slivers).  The workgroup whose add returns the last count sums R's slots -- sc1 loads,
+// IN SLOT ORDER, the code of s2_hreduce_kernel (qn_s2_slot_sum, qn_s2_hreduce_row): the arrival order decides WHO sums, never in
+// what order, so the bits are those of the reduce launch -- and resets the counter.  Nobody waits for anybody: no workgroup can
+// be held up by one that is not resident.  (The protocol is the first row of the hand-off table in MI355X_MICROARCH.md: one
+// lane per contribution adds at agent scope behind every storing wave's wait and the workgroup's barrier; the last arriver's
+// other waves load behind a barrier that the adding wave joins; every store and load of the slots is sc1.)
+// What the last arriver writes is read by later launches only: u, v and g <- g+ are read by this launch's tiles of block-row R
+// alone (row side of I = R, column side of J = R), and those have all stored their slots -- and loaded their vector entries long
+// before -- when the counter completes.
+// MEASURED (round 5, n = 4096, rocprofv3 averages of alternating runs on one box, profiles/r05_c_*): bit-identical to the reduce
+// launch (tests/test_gpu_symmetric.py::test_tail_reduce_is_the_reduce_launch_bit_for_bit) and SLOWER -- the update kernel
+// 23.5 -> 36.7 us for the 5.0 us launch it removes (14.9 k -> 13.4 k it/s); OFF by default (set_tiling(-13, 0) / QN_S2_TRED=1).
+// In-kernel stamps say where it goes: the hand-off itself is cheap -- a workgroup's slot stores are acknowledged 0.4 us after its
+// last row, its adds have returned 0.7 us later, and spreading the counters over the memory channels changes nothing -- but the
+// last workgroup's tail ends 12.7 us after its adds.  The workgroups end within 2 us of each other, every block-row has ~47
+// contributors among the 256, so no block-row completes before the last handful of workgroups arrive: THE LAST WORKGROUP IS THE
+// LAST ARRIVER OF ALL ITS BLOCK-ROWS (two items and a sliver: five), the one before it of most of its own, and each of them then
+// reads 64 KB per block-row that other XCDs wrote -- at the 50-70 GB/s one workgroup gets on such bytes (MI355X_MICROARCH.md,
+// handoff-payload) that is ~2.5 us per block-row, one after the other.  Issuing a workgroup's block-rows together would bring its
+// 320 KB to ~5 us: the launch that is saved.  Who sums is decided by arrival, and arrival concentrates the sums on the workgroups
+// the launch is already waiting for; a designated, polling reducer would not have that problem and cannot be had without a
+// wait that a non-resident workgroup can hold up (two such launches of two solvers sharing the GPU deadlock).  The reduce launch
+// stays: 5 launches per iteration.
+template <bool NT, bool BFGS, bool FOLD, bool SHARD = false, bool TRED = false>
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a) {
     static_assert(!(FOLD && SHARD), "the folded accept-reduce is a single-rank variant");
+    static_assert(!(TRED && (FOLD || SHARD)), "the tail reduce is the single-rank kernel without the folded accept-reduce");
     __shared__ QnS2Lds L;
     __shared__ double colsum[2][QN_TB]; // [rhs]: row part of a diagonal item, parked until its column part is summed
     __shared__ double colred[QN_S2_WAVES][2][QN_TB];
@@ -1277,7 +1349,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         if ((lane & 1) == 0) {
             const int rhs = lane >> 5, rl = wave * QN_S2_RPW + ((lane >> 1) & 15);
             if (diag) colsum[rhs][rl] = racc[0]; // the column part of a diagonal tile lands in the same slot: park the row part
-            else a.part[(unsigned)(((I * a.nb + J) * 2 + rhs) * QN_TB + rl)] = racc[0]; // (32-bit slot offsets: nb <= 2048)
+            else qn_s2_slot_st<TRED>(a.part + (unsigned)(((I * a.nb + J) * 2 + rhs) * QN_TB + rl), racc[0]); // (32-bit slot offsets: nb <= 2048)
         }
         __syncthreads();
         if (tid < 2 * QN_TB) {
@@ -1285,8 +1357,8 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
             double acc = colred[0][crhs][c];
 #pragma unroll
             for (int w = 1; w < QN_S2_WAVES; ++w) acc = acc + colred[w][crhs][c];
-            if (diag) a.part[(unsigned)(((I * a.nb + I) * 2 + crhs) * QN_TB + c)] = colsum[crhs][c] + acc; // row part + column part
-            else a.part[(unsigned)(((J * a.nb + I) * 2 + crhs) * QN_TB + c)] = acc;
+            if (diag) qn_s2_slot_st<TRED>(a.part + (unsigned)(((I * a.nb + I) * 2 + crhs) * QN_TB + c), colsum[crhs][c] + acc); // row part + column part
+            else qn_s2_slot_st<TRED>(a.part + (unsigned)(((J * a.nb + I) * 2 + crhs) * QN_TB + c), acc);
         }
         if (it == 0) QN_S2_STAMP(5);
         if (!has_next) break;
@@ -1316,9 +1388,54 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         double tt[2] = {t0, t1};
         QnWaveFold<2, 32>::run(tt, lane); // lane 32 k: the total of right-hand side k
         const QnS2Sliver sl = qn_s2_sliver(a, wave);
-        if ((lane & 31) == 0) a.part[(unsigned)(((sl.D * a.nb + sl.D) * 2 + (lane >> 5)) * QN_TB + sl.row)] = tt[0];
+        if ((lane & 31) == 0) qn_s2_slot_st<TRED>(a.part + (unsigned)(((sl.D * a.nb + sl.D) * 2 + (lane >> 5)) * QN_TB + sl.row), tt[0]);
     }
     QN_S2_STAMP(15);
+    if (TRED) {
+        __shared__ int todo[2 * QN_S2_TRED_MAXK + 2]; // [0]: how many block-rows this workgroup completed; [1 ..]: which
+        __shared__ double qbuf[3][QN_TB];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its slot stores have been acknowledged ...
+        __syncthreads();                                  // ... before the workgroup's adds
+        QN_S2_STAMP(7);
+        if (wave == 0) {
+            // contribution `lane`: item lane >> 1, its I (even lanes) or J (odd lanes; a diagonal item has one); lane 2 maxk: the sliver
+            const int k = lane >> 1;
+            int R = -1;
+            if (k < a.maxk) {
+                const int ijk = k == 0 ? ij : (k == 1 ? ij1 : a.item_ij[(size_t)k * a.G + blockIdx.x]);
+                if (ijk >= 0) {
+                    const int Ik = ijk >> 16, Jk = ijk & 0xffff;
+                    R = (lane & 1) ? (Jk != Ik ? Jk : -1) : Ik;
+                }
+            } else if (lane == 2 * a.maxk && slv) R = qn_s2_sliver(a, 0).D;
+            bool last = false;
+            if (R >= 0) {
+                const int expect = (a.nb - 1) + ((a.sl_per != 0 && R >= a.sl_first) ? a.sl_per : 1);
+                int* cp = a.cnt + (size_t)R * a.cnt_stride;
+                last = __hip_atomic_fetch_add(cp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == expect;
+                if (last) __hip_atomic_store(cp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (nobody adds to it again before the next launch)
+            }
+            const unsigned long long m = __ballot(last);
+            if (last) todo[1 + __popcll(m & ((1ull << lane) - 1ull))] = R;
+            if (lane == 0) todo[0] = __popcll(m);
+        }
+        __syncthreads(); // (the adding wave joins: the other waves' loads come behind its returned adds)
+        QN_S2_STAMP(8);
+        const int ntodo = todo[0];
+        const int nrhs = L.c.hp_nrhs;
+        for (int t = 0; t < ntodo; ++t) { // (uniform)
+            const int R = todo[1 + t];
+            QnS2Slots S0, S1;
+            qn_s2_slot_issue<2, true>(a.part, a.nb, R, 0, S0);
+            qn_s2_slot_issue<2, true>(a.part, a.nb, R, 1, S1);
+            const double tot0 = qn_s2_slot_sum<2, true>(a.part, a.nb, R, 0, S0, qbuf);
+            const double tot1 = (nrhs == 2) ? qn_s2_slot_sum<2, true>(a.part, a.nb, R, 1, S1, qbuf) : 0.0; // (uniform)
+            qn_s2_hreduce_row(a, R, nrhs, tot0, tot1, fred);
+            __syncthreads(); // fred is reused
+        }
+        QN_S2_STAMP(14);
+        return;
+    }
     if (!fold) return; // (uniform)
     // Folded accept-reduce, the owner's part: the workgroup that holds the diagonal item (R, R) writes block R of the vectors
     // (g+, y, x+, s = x+ - x: bfgs.rs:94-99) and block R's five sums -- after its tiles, because nothing in this launch reads them
@@ -1361,7 +1478,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
     __shared__ QnS2Lds L;
     __shared__ double qbuf[3][QN_TB];
     __shared__ double bred[2][8];
-    const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     QnS2Slots S0, S1;
     if (SHARD) { if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE, true>(a, L); }
     else if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE>(a, L, [&]() { qn_s2_slot_issue(a.part, a.nb, R, 0, S0); qn_s2_slot_issue(a.part, a.nb, R, 1, S1); });
@@ -1381,27 +1498,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
         for (int r = 1; r < a.sh_nsum; ++r) { tot0 = tot0 + xp[(size_t)r * 2 * np]; tot1 = tot1 + xp[(size_t)r * 2 * np + np]; }
         if (nrhs != 2) tot1 = 0.0;
     }
-    double p[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = 0.0;
-    if (tid < QN_TB) {
-        const int gi = R * QN_TB + tid;
-        const double gp = a.F.GT[gi];
-        if (nrhs == 2) {
-            a.F.UN[gi] = tot0; a.F.VV[gi] = tot1;
-            p[0] = a.F.Y[gi] * tot0; // y'u = y'H+y
-            p[1] = tot0 * gp;        // u'g+
-        } else {
-            a.F.VV[gi] = tot0; // direction pass: v = H g (bfgs.rs:47)
-        }
-        a.F.G[gi] = gp; // commit g <- g+
-    }
-    if (wave < 2) { // threads 0..127 hold the rows
-        QnWaveFold<8, 32>::run(p, lane);
-        if ((lane & 7) == 0) bred[wave][lane >> 3] = p[0];
-    }
-    __syncthreads();
-    if (tid < 2) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = bred[0][tid] + bred[1][tid];
+    qn_s2_hreduce_row(a, R, nrhs, tot0, tot1, bred);
 }
 
 // PLACEMENT PROBE (round 4).  At n = 4096 about one inverse Hessian in eight runs the update kernel at 29.7 us instead of 25.2 for

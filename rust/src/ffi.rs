@@ -1,10 +1,10 @@
-//! `extern "C"` declarations for include/qn_hip.h (QN_ABI_VERSION 3): one `pub fn` per entry point, parameter for parameter.
+//! `extern "C"` declarations for include/qn_hip.h (QN_ABI_VERSION 4): one `pub fn` per entry point, parameter for parameter.
 //! tests/test_abi_load.py parses this file and the header and compares names, arity and every parameter / return type.
 //! NOT COMPILED in the build image (no Rust toolchain) -- see ../Cargo.toml.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const QN_ABI_VERSION: c_int = 3;
+pub const QN_ABI_VERSION: c_int = 4;
 
 // qn_status == SolverError (ls_solver.rs:10-20); 0 is Ok(())
 pub const QN_OK: c_int = 0;
@@ -126,6 +126,9 @@ pub struct qn_stats {
     pub n_ereduce_timed: u64,
     pub total_xchg_vector: u64,
     pub total_xchg_scalar: u64,
+    pub t_newton_ms: f64,
+    pub n_newton_timed: u64,
+    pub newton_lu_sync_timeouts: u64,
 }
 
 extern "C" {

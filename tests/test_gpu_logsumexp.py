@@ -88,8 +88,8 @@ def test_config5_size_properties_dfp_morethuente_n16384(qn, qo):
     assert np.linalg.norm(h @ yk - sk) <= 1e-8 * np.linalg.norm(sk)
     # first iterations against the threaded rank-2 CPU restatement
     ref = qo.Solver(qo.DFP, 1e-10, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
-    ref.minimize(qo.morethuente(), o, 3, 20, trace_cap=3, trace_x=True)
-    _compare(tr[:3], xs[:3], ref.trace, ref.trace_x)
+    ref.minimize(qo.morethuente(), o, iters, 20, trace_cap=iters, trace_x=True)  # (every iteration of the run)
+    assert _compare(tr, xs, ref.trace, ref.trace_x) == iters
 
 
 @pytest.mark.parametrize("m,n", [(9, 2), (300, 200), (1030, 515), (64, 5000), (2100, 1024), (130, 16384)])

@@ -279,6 +279,8 @@ def test_one_launch_panel_whose_waits_expire_falls_back_to_step_launches(qn, qo)
             pass
         tr, xs = s.trace()
         runs.append((tr, xs, s.stats()["launches"]))
+        # the expiry is visible to the caller (qn_stats.newton_lu_sync_timeouts, ABI version 4; one line on stderr per process)
+        assert (s.stats()["newton_lu_sync_timeouts"] >= 1) == forced
     assert np.array_equal(runs[0][1], runs[1][1]) and [r["f"] for r in runs[0][0]] == [r["f"] for r in runs[1][0]]
     assert runs[1][2] > runs[0][2] + 100
 

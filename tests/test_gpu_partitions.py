@@ -98,7 +98,8 @@ def _check_partition(res, world, n, first_generation=False):
 def test_config3_partition_8_ranks_n4096_vs_single_rank_and_oracle(qn, qo, allreduce, first_generation):
     """P = 8, rpr / 128 = 4 block-rows per rank, nb = 32 even (cnt(I) split at I < nb / 2): config 3's shape at a size the oracle
     follows.  Both generations of the sharded kernels: the default (qn_sym2sh.hip.h) and rounds 1-3's (set_tiling(-4))."""
-    n, world, iters = 4096, 8, 12
+    n, world = 4096, 8
+    iters = 50 if (not first_generation and not allreduce) else 12  # (the default partition: the whole stated window -- VERDICT r4 item 6)
     res, inputs = _sharded_quadratic(qn, n, world, iters, allreduce, want_h=not allreduce, first_generation=first_generation)
     _check_partition(res, world, n, first_generation)
     s1, obj1, tr1, xs1 = _single_rank_quadratic(qn, n, iters, inputs, first_generation)
@@ -109,12 +110,15 @@ def test_config3_partition_8_ranks_n4096_vs_single_rank_and_oracle(qn, qo, allre
         assert np.linalg.norm(h - h1) <= 1e-8 * np.linalg.norm(h1)
         for r in res[1:]:
             assert np.array_equal(r["h"], h)
-    # the first 6 iterations against the oracle's rank-2 mode (threaded: it is the CPU baseline of bench.py)
+    # against the oracle's rank-2 mode (threaded: it is the CPU baseline of bench.py): the whole stated window -- 50 iterations, all of
+    # them with ||g_k|| >= 1e-6 ||g_0|| -- for the default partition, the first 6 iterations for the other three variants
+    k = 50 if iters == 50 else 6
     diag, b, x0 = inputs
-    q = qo.synth_rows(n, 0, n, P.SEED, diag)
+    q = qo.synth_rows(n, 0, n, P.SEED, diag, nthreads=qo.max_threads())
     ref = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
-    ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b, nthreads=qo.max_threads()), 6, 20, trace_cap=6, trace_x=True)
-    _trace_close(res[0]["tr"][:6], res[0]["xs"][:6], ref.trace, ref.trace_x)
+    ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b, nthreads=qo.max_threads()), k, 20, trace_cap=k, trace_x=True)
+    assert len(ref.trace) == k and ref.trace[-1]["gnorm"] >= 1e-6 * ref.trace[0]["gnorm"]
+    _trace_close(res[0]["tr"][:k], res[0]["xs"][:k], ref.trace, ref.trace_x)
 
 
 def test_config3_partition_8_ranks_n32768(qn, qo):
@@ -128,6 +132,18 @@ def test_config3_partition_8_ranks_n32768(qn, qo):
     f = np.array([r["f"] for r in res[0]["tr"]])
     assert np.all(np.diff(f) < 0)
     s1.close(); obj1.close()
+    # ... and against the ORACLE at full size (round 5): the threaded rank-2 restatement on the same Q (8 GiB on the
+    # host, H another 8) -- every iteration of the 8-rank run, to the stated tolerance
+    import psutil
+    if psutil.virtual_memory().available < (40 << 30):
+        pytest.skip("the n = 32768 oracle run needs ~20 GiB of host memory (Q and H, 8 GiB each); the GPU-vs-GPU part above has passed")
+    diag, b, x0 = inputs
+    nt = qo.max_threads()
+    q = qo.synth_rows(n, 0, n, P.SEED, diag, nthreads=nt)
+    ref = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=nt)
+    ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b, nthreads=nt), iters, 20, trace_cap=iters, trace_x=True)
+    _trace_close(res[0]["tr"], res[0]["xs"], ref.trace, ref.trace_x)
+    del q, ref
     # ... and the literal all-reduce stand-in at full size: the same bits as the all-gather + rank-order sum (host-staged: it IS
     # gathered and added in rank order; RCCL's own order is tolerance-level, tests/test_gpu_sharded.py on a multi-GPU box)
     res_ar, _ = _sharded_quadratic(qn, n, world, iters, allreduce=True, want_h=False)
@@ -176,5 +192,5 @@ def test_config5_partition_4_ranks_dfp_logsumexp_n16384(qn, qo):
     assert abs(res[0]["f"] - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
     assert np.linalg.norm(res[0]["g"] - g_ref) <= 1e-11 * np.linalg.norm(g_ref)
     ref = qo.Solver(qo.DFP, 1e-10, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
-    ref.minimize(qo.morethuente(), o, 3, 20, trace_cap=3, trace_x=True)
-    _trace_close(res[0]["tr"][:3], res[0]["xs"][:3], ref.trace, ref.trace_x)
+    ref.minimize(qo.morethuente(), o, iters, 20, trace_cap=iters, trace_x=True)  # (every iteration of the run: 1-2 s each on the host)
+    _trace_close(res[0]["tr"], res[0]["xs"], ref.trace, ref.trace_x)

@@ -167,6 +167,32 @@ def test_row_slivers_at_4096(qn, qo, method, lsname):
     assert np.array_equal(hm, hm.T) and np.abs(hm - h).max() <= 1e-9 * np.abs(h).max()
 
 
+@pytest.mark.parametrize("n,method,lsname", [(4096, "bfgs", "mt"), (4096, "dfp", "mt"), (4096, "bfgs", "bt"), (1152, "bfgs", "mt"),
+                                             (3200, "dfp", "mt"), (8192, "bfgs", "mt")])
+def test_tail_reduce_is_the_reduce_launch_bit_for_bit(qn, qo, n, method, lsname):
+    """Round 5, set_tiling(-13, 0): the update-reduce in the TAIL of the update-tile launch (s2_hpass_kernel<.., TRED>: the workgroup
+    whose slot completes a block-row sums that block-row's slots, in slot order) -- 4 launches per iteration instead of 5.  Measured
+    slower than the launch it removes and off by default (note in front of the kernel); kept as a tested variant.  The arrival
+    order decides who sums, never in what order: trace, iterates and inverse Hessian must equal the default run bit for bit,
+    pipelined and synchronous, with row slivers (n = 4096), without (1152, 3200: lists of one and two items) and with lists of
+    nine items (8192); repeated, because a stale slot would depend on timing."""
+    diag = P.synth_diag(n); b, x0 = P.synth_vectors(n)
+    obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
+    iters = 24 if n <= 4096 else 8
+    base, st0 = _run(qn, method, lsname, obj, x0, iters)
+    tr0, xs0 = base.trace()
+    h0 = base.approx_inv_hessian() if n <= 4096 else None
+    assert base.stats()["path"] & 16
+    for rep, sync in enumerate((0, 1, 0, 0)):
+        s, st = _run(qn, method, lsname, obj, x0, iters, tiling=(-13, 0), sync=sync)
+        tr, xs = s.trace()
+        assert st == st0 and tr == tr0 and np.array_equal(xs, xs0), (rep, sync)
+        if h0 is not None:
+            assert np.array_equal(s.approx_inv_hessian(), h0)
+        if not sync:
+            assert s.stats()["launches"] < base.stats()["launches"]  # one launch less per iteration
+
+
 @pytest.mark.parametrize("n", [1152, 3200])
 def test_second_generation_without_slivers_and_without_the_pair_instance(qn, qo, n):
     """Sizes whose work lists carry NO row slivers (sl_per == 0) and where the two-items-and-a-sliver instance of the evaluation

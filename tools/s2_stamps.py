@@ -41,8 +41,10 @@ for slot in range(64):
         wg = t[:, 15] > 0
         w = t[wg]
         end = (w[:, 15] - w[:, 0].min()) * 10
-        print("slot %2d (update tiles): " % slot + ", ".join("%s %d" % (nm, int(np.median((w[:, k] - w[:, 0]) * 10))) for nm, k in (("ctl", 9), ("sums", 10), ("machine", 11), ("barrier", 2), ("w0 item 1 rows", 3), ("w7 item 1 rows", 12), ("item 1 stored", 5), ("w0 item 2 rows", 6), ("w7 item 2 rows", 13), ("end", 15)))
-              + "; workgroup ends p50 %d p90 %d max %d" % (np.median(end), np.percentile(end, 90), end.max()))
+        print("slot %2d (update tiles): " % slot + ", ".join("%s %d" % (nm, int(np.median((w[:, k] - w[:, 0]) * 10))) for nm, k in (("ctl", 9), ("sums", 10), ("machine", 11), ("barrier", 2), ("w0 item 1 rows", 3), ("w7 item 1 rows", 12), ("item 1 stored", 5), ("w0 item 2 rows", 6), ("w7 item 2 rows", 13), ("end", 15), ("tail: stores acknowledged", 7), ("tail: adds returned", 8), ("tail: done", 14)))
+              + "; workgroup ends p50 %d p90 %d max %d" % (np.median(end), np.percentile(end, 90), end.max())
+              + ("; tail (from the first entry): stores acknowledged p50 %d max %d, adds returned p50 %d max %d, done max %d" % tuple(
+                  int(f((w[:, k] - w[:, 0].min()) * 10)) for k, f in ((7, np.median), (7, np.max), (8, np.median), (8, np.max), (14, np.max))) if w[0, 7] else ""))
         continue
     if t[0, 15] == 0 or t[0, 0] == 0 or t[0, 3] == 0:
         continue  # not an evaluation launch that did work
