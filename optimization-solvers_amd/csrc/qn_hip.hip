@@ -1742,10 +1742,84 @@ struct Run {
     bool sym = false; // fused path on the upper block triangle of H and Q (qn_sym.hip.h)
     bool sym_generic = false; // generic path: the H pass alone on the upper block triangle
     bool sym2 = false;        // second-generation symmetric path (qn_sym2.hip.h)
+    bool gobj = false;        // ... in its form for a device objective that is not the quadratic (qn_sym2g.hip.h: the log-sum-exp objective)
     QnS2Args s2{};
     uint64_t s2_launches = 0; // parity of the control-block double buffer = launches so far & 1
     unsigned long long report_seq = 0; // != 0: the next launch reports its control block to the host (s2_wait_report)
 };
+
+// ---- generic objectives on the second-generation structure (qn_sym2g.hip.h) ----
+static QnS2GArgs s2g_args(const Run& r) {
+    qn_solver* s = r.s;
+    qn_objective* o = r.obj;
+    qn_context* c = s->ctx;
+    QnS2GArgs g{};
+    g.L.A = o->Q; g.L.c = o->b; g.L.mu = o->mu;
+    g.L.m = (int)o->m; g.L.m_pad = o->TA.n_pad; g.L.mrpr = o->TA.rpr; g.L.n = (int)o->n; g.L.n_pad = o->T.n_pad;
+    g.L.world = c->world; g.L.rank = c->rank; g.L.rs = 1;
+    g.wgms = o->lwgms; g.wgg = o->lwgg; g.G = o->lse_G;
+    g.ctl = s->s2_ctl + (r.s2_launches & 1); // what the last prologue launch has written
+    g.F = s->V.F;
+    g.wgS = nullptr; g.trows = s->s2_trows;
+    return g;
+}
+template <int KCH, bool NTA>
+static int s2g_launch_onepass_nt(hipStream_t st, const QnS2GArgs& g) {
+    static std::atomic<bool> attr_set[64]; // per device: hipFuncSetAttribute applies to the current device only (atomic: ranks may be threads)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t lds = (size_t)KCH * 1024 * sizeof(double);
+    if ((dev < 0 || dev >= 64 || !attr_set[dev].load()) && lds > 48 * 1024) { // the trial point in LDS: up to 128 KB of the CU's 160 KB
+        if (hipFuncSetAttribute((const void*)s2g_onepass_kernel<KCH, NTA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(QN_ABNORMAL_TERMINATION, "log-sum-exp: the device does not grant the evaluation kernel its LDS");
+        }
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true);
+    }
+    hipLaunchKernelGGL((s2g_onepass_kernel<KCH, NTA>), dim3(g.G), dim3(512), lds, st, g);
+    return QN_OK;
+}
+template <int KCH>
+static int s2g_launch_onepass(hipStream_t st, const QnS2GArgs& g) {
+    static const int nt_env = getenv("QN_LSE_NT") ? atoi(getenv("QN_LSE_NT")) : -1; // (as lse_launch_onepass)
+    const bool nt = nt_env >= 0 ? nt_env != 0 : (size_t)g.L.mrpr * (size_t)g.L.n_pad * sizeof(double) > ((size_t)230 << 20);
+    return nt ? s2g_launch_onepass_nt<KCH, true>(st, g) : s2g_launch_onepass_nt<KCH, false>(st, g);
+}
+static int s2g_enqueue_onepass(Run& r) {
+    qn_solver* s = r.s;
+    hipStream_t st = s->ctx->stream;
+    const QnS2GArgs g = s2g_args(r);
+    ProfScope ps(s, KC_EVAL);
+    switch (r.obj->lse_kch) {
+    case 1: QNCHK(s2g_launch_onepass<1>(st, g)); break;
+    case 2: QNCHK(s2g_launch_onepass<2>(st, g)); break;
+    case 4: QNCHK(s2g_launch_onepass<4>(st, g)); break;
+    case 8: QNCHK(s2g_launch_onepass<8>(st, g)); break;
+    default: QNCHK(s2g_launch_onepass<16>(st, g)); break;
+    }
+    s->stats.launches++;
+    HIPCHK(hipGetLastError());
+    return QN_OK;
+}
+// the update pass's tiles: the first-generation tile kernel (qn_sym.hip.h: one workgroup per tile, two per CU -- 6.2 TB/s on H's half at
+// n = 16384 where the one-workgroup-per-CU kernel of qn_sym2.hip.h reaches 5.4), reading the control block the launch in front wrote
+static int s2g_enqueue_tiles(Run& r) {
+    qn_solver* s = r.s;
+    qn_context* c = s->ctx;
+    QnSymHPassArgs y{};
+    y.H = s->H; y.T = s->T; y.T.cs = 1; y.F = s->V.F; y.F.UP = y.F.UN; // (no kernel of this path writes u while another reads it)
+    y.ctl = s->s2_ctl + (r.s2_launches & 1); y.expect_phase = QN_PH_REQ_HPASS; y.need_serviced = 1;
+    y.nb = s->sym_nb; y.part = s->sym_part;
+    y.nt = s->T.n_pad >= 8192; // past the Infinity Cache (same-box A/B, round 1: +7 % at n = 32768, +3 % at 8192, -1 % at 4096)
+    {
+        ProfScope ps(s, KC_HPASS);
+        hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
+    }
+    s->h_lower_stale = true;
+    s->stats.launches++;
+    HIPCHK(hipGetLastError());
+    return QN_OK;
+}
 
 static int s2_launch(Run& r, int kind) {
     qn_solver* s = r.s;
@@ -1759,7 +1833,7 @@ static int s2_launch(Run& r, int kind) {
     a.dbg = s->V.dbg; a.slot = (int)r.s2_launches;
 #endif
     r.s2_launches++;
-    const int cls = kind == QN_S2_EVAL ? KC_EVAL : (kind == QN_S2_VEC || kind == QN_S2_VSUM) ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS
+    const int cls = kind == QN_S2_EVAL ? KC_EVAL : (kind == QN_S2_VEC || kind == QN_S2_VSUM || kind == QN_S2_GCOMB) ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS
                   : (kind == QN_S2_HREDUCE || kind == QN_S2_HSUM) ? KC_HREDUCE : KC_CTL;
     ProfScope ps(s, cls);
     const bool sh = a.sh_world > 1; // row-sharded: the SHARD instantiations (qn_sym2sh.hip.h)
@@ -1812,8 +1886,17 @@ static int s2_launch(Run& r, int kind) {
         if (sh) hipLaunchKernelGGL(s2_hreduce_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
         else hipLaunchKernelGGL(s2_hreduce_kernel<false>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
         break;
+    case QN_S2_GEVAL_A: hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_GEVAL_A>), dim3(1), dim3(128), 0, st, a); break;
+    case QN_S2_GHT_A: hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_GHT_A>), dim3(1), dim3(128), 0, st, a); break;
+    case QN_S2_GCOMB: {
+        QnS2GArgs g = s2g_args(r);
+        g.wgS = a.wgS + (size_t)a.parity * (size_t)a.trows * QN_S2_ROW; // the half this launch writes (the next prologue reads it)
+        hipLaunchKernelGGL(s2g_combine_kernel, dim3(a.gw), dim3(256), 0, st, a, g);
+        break;
+    }
     default:
-        if (sh) hipLaunchKernelGGL(s2_advance_kernel<true>, dim3(1), dim3(128), 0, st, a);
+        if (r.gobj) hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_ADVANCE>), dim3(1), dim3(128), 0, st, a);
+        else if (sh) hipLaunchKernelGGL(s2_advance_kernel<true>, dim3(1), dim3(128), 0, st, a);
         else hipLaunchKernelGGL(s2_advance_kernel<false>, dim3(1), dim3(128), 0, st, a);
         break;
     }
@@ -1831,7 +1914,14 @@ static int s2_peek(Run& r) { // the control block the last enqueued launch write
 
 // ---- one request of the sym2 machine = its launches and, row-sharded, the collectives between them ----
 // An evaluation: the tiles, then (sharded) ONE exchange of the ranks' per-workgroup scalars -- 8 KB per rank, whatever n is.
-static int s2_do_eval(Run& r) {
+static int s2_do_eval(Run& r, unsigned long long report_seq = 0) {
+    if (r.gobj) { // the machine in a one-workgroup launch, the pass over A, the combine launch (which also stages the vectors of this point)
+        QNCHK(s2_launch(r, QN_S2_GEVAL_A));
+        QNCHK(s2g_enqueue_onepass(r));
+        r.report_seq = report_seq; // (the batch's last launch reports: only the combine launch leaves the request as the host may see it)
+        return s2_launch(r, QN_S2_GCOMB);
+    }
+    if (report_seq) r.report_seq = report_seq;
     QNCHK(s2_launch(r, QN_S2_EVAL));
     qn_solver* s = r.s;
     qn_context* c = s->ctx;
@@ -1865,6 +1955,12 @@ static int s2_do_vec(Run& r) {
 static int s2_do_hpass(Run& r, bool tiles) {
     qn_solver* s = r.s;
     qn_context* c = s->ctx;
+    if (r.gobj) {
+        if (!tiles) return fail(QN_ABNORMAL_TERMINATION, "sym2 (generic objective): tiles marked done without their launch");
+        QNCHK(s2_launch(r, QN_S2_GHT_A));
+        QNCHK(s2g_enqueue_tiles(r));
+        return s2_launch(r, QN_S2_HREDUCE);
+    }
     if (tiles) QNCHK(s2_launch(r, QN_S2_HTILE));
     if (r.s2.tred) return QN_OK; // (tail reduce: the tile launch has summed the slots itself)
     if (r.s2.sh_world > 1) {
@@ -2765,13 +2861,20 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     // fused fast path: device quadratic, memoised, BFGS/DFP, no callback, one column split, n > 5
     r.fused = r.oracle_tpl == QN_ORACLE_QUAD && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP) && !callback && s->hcs == 1 &&
               s->qcs == 1 && !h->small_n && !s->no_fused && !s->bounded && !ls_bounded; // bounded variants (row f4): generic path
+    // ... and the log-sum-exp objective in the structure of the second-generation path (qn_sym2g.hip.h; round 5): one rank, its one-pass
+    // evaluation (n <= 16384), whole 128-blocks without padding, a bitwise symmetric H.  Everything else keeps the generic path.
+    r.gobj = r.obj && r.obj->kind == OBJ_LOGSUMEXP && r.obj->lse_kch && !r.obj->lse_two_pass && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP) &&
+             !callback && s->hcs == 1 && !h->small_n && !s->no_fused && !s->bounded && !ls_bounded && !ls_only && c->world == 1 &&
+             (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && (size_t)s->T.n_pad == s->n && !s->no_sym && !s->no_sym2 && !s->h_nonsym &&
+             !(getenv("QN_S2G") && atoi(getenv("QN_S2G")) == 0);
+    if (r.gobj) r.fused = true;
     h->fused = r.fused ? 1 : 0;
     s->V.fused_hint = h->fused;
     // ... and on the upper block triangle only (half the bytes) when H and Q are whole 128-tiles on one rank
     const bool sym_ok = c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
     // ... row-sharded: every rank streams the circulant half of its own block-rows (whole 128-row blocks per rank)
     const bool symsh_ok = c->world > 1 && (s->T.rpr % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
-    r.sym = r.fused && (sym_ok || symsh_ok) && r.obj && r.obj->q_symmetric;
+    r.sym = r.fused && (sym_ok || symsh_ok) && r.obj && (r.obj->q_symmetric || r.gobj);
     // the generic path's H pass alone (closures, log-sum-exp objective, SR1, bounded variants): same tiles, sums into V.hp
     r.sym_generic = !r.fused && (sym_ok || symsh_ok) && s->H && s->hcs == 1 && (s->method == QN_BFGS || s->method == QN_DFP || s->method == QN_SR1);
     if ((r.sym || r.sym_generic) && c->world > 1) QNCHK(solver_alloc_symsh_lists(s));
@@ -2791,12 +2894,12 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     h->defer_u = 0;
     h->no_defer = s->no_defer;
     if (!r.fused) QNCHK(fused_export(s)); // another path takes over: it works on the canonical buffers
-    if (!(r.sym || r.sym_generic) || (s->h_diag_stale && !r.sym2)) QNCHK(ensure_full_h(s)); // ... and on whole rows of H (or whole diagonal tiles)
+    if (!(r.sym || r.sym_generic) || (s->h_diag_stale && (!r.sym2 || r.gobj))) QNCHK(ensure_full_h(s)); // ... and on whole rows of H (or whole diagonal tiles: the first-generation tile kernel, which the generic-objective path runs too, reads them whole)
     if (r.fused) {
         QNCHK(solver_alloc_fused(s, r.sym));
         s->V.F.pworld = r.sym ? 1 : c->world; // symmetric storage: every rank forms all the per-block partial sums itself
         if (r.sym && c->world > 1 && !s->symsh_xg) QNCHK(dev_alloc_zero(&s->symsh_xg, (size_t)c->world * 2 * s->T.n_pad, c->stream));
-        s->V.F.b = r.obj->b;
+        s->V.F.b = r.gobj ? nullptr : r.obj->b; // (the quadratic's linear term; the log-sum-exp path's kernels do not read it)
         if (!s->fused_live) { // import the canonical state (x, pending s and u) into the fused buffers
             const size_t vb = (size_t)s->T.n_pad * sizeof(double);
             HIPCHK(hipMemcpyAsync(s->V.F.X0, s->V.x, vb, hipMemcpyDeviceToDevice, c->stream));
@@ -2819,6 +2922,8 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.Q = r.obj->Q; a.H = s->H; a.n = (int)s->n; a.np = s->T.n_pad; a.nb = s->s2_nb; a.G = s->s2_G;
         a.item_ij = s->s2_items; a.maxk = s->s2_maxk; a.inorder = s->s2_inorder; a.F = s->V.F; a.part = s->sym_part;
         a.wgS = s->s2_wgS; a.trows = s->s2_trows; a.ctl2 = s->s2_ctl; a.partE = s->s2_partE;
+        a.gw = r.gobj ? s->T.n_pad / 64 : 0;
+        if (r.gobj && a.gw > s->s2_trows) return fail(QN_ABNORMAL_TERMINATION, "sym2 (generic objective): more combine workgroups than table rows");
         // folded accept-reduce (s2_hpass_kernel): every workgroup holds at most three items, so the blocks whose slots it sums fit
         // its LDS staging area -- n <= 4096 with 256 workgroups; larger n keeps the accept-reduce launch (7 us of 250+)
         a.fold = (s->s2_maxk <= 3 && s->s2_nb <= 32 && s->fold) ? 1 : 0;
@@ -2831,7 +2936,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.sh_world = c->world; a.sh_rank = c->rank; a.sh_ioff = c->rank * (s->T.rpr / QN_TB);
         a.sh_nsum = c->use_allreduce ? 1 : c->world;
         a.evS = s->s2_evS; a.xg = s->symsh_xg; a.sl_off = s->s2_sl_off; a.sl_idx = s->s2_sl_idx;
-        if (c->world > 1) { a.fold = 0; a.pair = 0; }
+        if (c->world > 1 || r.gobj) { a.fold = 0; a.pair = 0; }
         // tail reduce (s2_hpass_kernel<.., TRED>): the update-reduce in the tail of the update-tile launch, 4 launches per iteration
         // instead of 5 -- one rank, lists short enough for one wave to announce (n <= ~15 k).  BUILT, BIT-IDENTICAL, SLOWER, OFF BY
         // DEFAULT (QN_S2_TRED=1 / set_tiling(-13, 0) switch it on; the note in front of the kernel has the stamps): the update kernel
@@ -2839,7 +2944,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.cnt = s->s2_cnt;
         a.cnt_stride = getenv("QN_S2_CNT_STRIDE") ? std::max(1, std::min(QN_S2_CNT_STRIDE, atoi(getenv("QN_S2_CNT_STRIDE")))) : QN_S2_CNT_STRIDE; // (diagnostics)
         const bool want_tred = getenv("QN_S2_TRED") ? atoi(getenv("QN_S2_TRED")) != 0 : s->tred;
-        a.tred = (c->world == 1 && !a.fold && s->s2_maxk <= QN_S2_TRED_MAXK && want_tred) ? 1 : 0;
+        a.tred = (c->world == 1 && !a.fold && !r.gobj && s->s2_maxk <= QN_S2_TRED_MAXK && want_tred) ? 1 : 0;
         // WHO GETS THE INFINITY CACHE (256 MB).  Per iteration a rank streams its half of Q twice (read) and its half of H once
         // (read + written); non-temporal accesses pass the cache by.  Measured (round 4, bench.py same box, it/s for the policies
         // H plain / Q plain, H plain / Q non-temporal, H non-temporal / Q plain, both non-temporal):
@@ -2864,11 +2969,11 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     }
 
     // only the quadratic objective's kernels are predicated on the control block; everything else is serviced synchronously
-    const bool can_pipeline = (r.oracle_tpl == QN_ORACLE_QUAD) && !callback && !(c->world > 1 && !c->comm && !c->host_async);
+    const bool can_pipeline = (r.oracle_tpl == QN_ORACLE_QUAD || r.gobj) && !callback && !(c->world > 1 && !c->comm && !c->host_async);
     const bool sync = s->method == QN_NEWTON || s->sync_mode == 1 || (s->sync_mode == -1 && !(can_pipeline && o->memoize)) || !can_pipeline;
 
     int status = QN_ABNORMAL_TERMINATION;
-    if (r.sym2) QNCHK(place_h(r)); // (once per solver: H where the update kernel runs fastest)
+    if (r.sym2 && !r.gobj) QNCHK(place_h(r)); // (once per solver: H where the update kernel runs fastest)
     if (r.sym2) {
         if (sync) { // one request at a time: [service launch(es), advance], the host reads the control block in between
             QNCHK(s2_launch(r, QN_S2_ADVANCE));
@@ -2891,14 +2996,17 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             // the second batch on what the run has needed so far -- the counters are replicated, every rank sizes alike.  An
             // iteration that needs more evaluations than a period holds rolls over into the next one: only time is lost.
             int slots = (ls->kind == QN_LS_MORETHUENTE) ? 2 : 4;
-            if (r.s2.sh_world > 1) slots = s->s2_slots_hint ? s->s2_slots_hint : 2;
+            // (generic objective: an unused evaluation slot is three launches that find nothing to do, and on such objectives More-Thuente
+            // takes t = 1 almost every time -- the pattern is sized like the sharded one: one slot to start with, then what the run has needed)
+            const bool adaptive = r.s2.sh_world > 1 || r.gobj;
+            if (adaptive) slots = s->s2_slots_hint ? s->s2_slots_hint : (r.gobj ? 1 : 2);
             bool first = true;
             uint64_t ev0 = 0, it0 = 0;
             unsigned long long seq = 0;
             for (;;) {
                 if (!first) {
                     QNCHK(s2_wait_report(r, seq));
-                    if (r.s2.sh_world > 1 && h->n_iterations > it0) { // evaluations per iteration of the batch just run, rounded up
+                    if (adaptive && h->n_iterations > it0) { // evaluations per iteration of the batch just run, rounded up
                         const uint64_t di = h->n_iterations - it0;
                         uint64_t de = h->n_oracle_evals - ev0;
                         if (it0 == 0 && !h->warm && de > 0) de -= 1; // (the evaluation at x0 that opens a run had a period of its own)
@@ -2916,11 +3024,11 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 first = false;
                 for (int64_t p = 0; p < periods; ++p) {
                     for (int e = 0; e < slots; ++e) QNCHK(s2_do_eval(r));
-                    if (!r.s2.fold) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise)
+                    if (!r.s2.fold && !r.gobj) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise; generic objective: staged by every evaluation's combine launch)
                     QNCHK(s2_do_hpass(r, true));
                 }
-                seq = r.report_seq = ++s->rep_seq; // (the batch's last launch reports: the evaluation launch below)
-                QNCHK(s2_do_eval(r));
+                seq = ++s->rep_seq; // (the batch's last launch reports: the evaluation launch below)
+                QNCHK(s2_do_eval(r, seq));
             }
         }
     } else {
@@ -2980,7 +3088,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     const uint64_t full_shard = shard;
     if (r.sym || r.sym_generic) shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb + 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull; // the streamed tiles
     if ((r.sym || r.sym_generic) && c->world > 1) shard = (uint64_t)qn_symsh_ntiles(s->sym_nb, s->T.rpr / QN_TB, c->rank * (s->T.rpr / QN_TB)) * (uint64_t)QN_TB * QN_TB * 8ull;
-    if (r.sym2) // diagonal tiles: wave w (rows 16 w ...) reads 64 - 8 w lanes of 16 bytes per row = 73 728 of the 131 072 bytes
+    if (r.sym2 && !r.gobj) // diagonal tiles: wave w (rows 16 w ...) reads 64 - 8 w lanes of 16 bytes per row = 73 728 of the 131 072 bytes
         shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb - 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull + (uint64_t)s->sym_nb * 73728ull;
     if (r.sym2 && c->world > 1) { // this rank's windows: one diagonal tile per local block-row, the rest whole tiles
         const uint64_t nbl = (uint64_t)(s->T.rpr / QN_TB);
@@ -2990,6 +3098,8 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     s->stats.h_bytes = (h->n_hpasses + h->n_hpass_rw) * shard;
     if (r.sym2) s->stats.h_bytes = 2 * h->n_hpasses * shard; // (its one branch-free body writes every pass back, pending update or not)
     s->stats.obj_bytes = (r.oracle_tpl == QN_ORACLE_QUAD) ? h->n_oracle_evals * (r.sym ? shard : full_shard) : 0;
+    if (r.obj && r.obj->kind == OBJ_LOGSUMEXP) // one pass over this rank's rows of A per evaluation (two for n > 16384)
+        s->stats.obj_bytes = h->n_oracle_evals * (uint64_t)r.obj->TA.rpr * (uint64_t)r.obj->T.n_pad * 8ull * ((r.obj->lse_kch && !r.obj->lse_two_pass) ? 1ull : 2ull);
     s->stats.matrix_bytes_per_pass = shard;
     s->stats.total_minimize_calls++;
     s->stats.total_iterations += s->stats.iterations;

@@ -93,6 +93,8 @@ struct QnSymHPassArgs {
     double* ghp;
     int nt; // non-temporal tile loads and stores
     QnSymShard sh;
+    int need_serviced; // != 0 (generic objectives on the second-generation structure, qn_sym2g.hip.h): run only if the control block says
+                       // `serviced == need_serviced` -- the one-workgroup launch in front has marked the request as this kernel's
 };
 
 // launch-linear index t -> upper-triangle tile (I, J >= I), row-major over I
@@ -459,6 +461,7 @@ __global__ __launch_bounds__(QN_SYM_TPB) void sym_hpass_tile_kernel(const QnSymH
     const QnCtl* __restrict__ ctl = a.ctl;
     const int phase = ctl->phase;
     if (phase != a.expect_phase && !(phase == QN_PH_REQ_HPASS_EVAL && !a.generic)) return;
+    if (a.need_serviced && ctl->serviced != a.need_serviced) return; // (uniform)
     const int nrhs = ctl->hp_nrhs; // generic path: 0 = apply the pending update only (the sums are then not used)
     const int pending = ctl->pending;
     const double c_ss = ctl->c_ss, c_su = ctl->c_su, c_uu = ctl->c_uu;

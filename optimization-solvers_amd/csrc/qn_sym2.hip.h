@@ -46,7 +46,9 @@
 #define QN_S2_MAXG 256 // workgroups of a tile launch: one 8-wave workgroup per CU (see the note on registers below)
 #define QN_S2_NSE 6    // evaluation scalars per workgroup: xt'Q xt, b'xt, d'Q xt, b'd, g'd, #non-finite d
 #define QN_S2_NR 5     // accept-reduce partials per block-row: y'y, y's, g+'g+, s's, s'g+
-#define QN_S2_ROW 8    // doubles per partial row in memory (64 B: loaded as 16-byte pieces)
+#define QN_S2_ROW 16   // columns of the table of per-workgroup sums (QnS2Args.wgS): 0..5 what an evaluation / 0..4 an accept-reduce / 0..1 an
+                       // update-reduce leaves; 8..12 (QN_S2_VCOL): the accepted-point sums a generic objective's combine launch stages with every evaluation
+#define QN_S2_VCOL 8
 #define QN_S2SH_NEC 4  // row-sharded runs: the evaluation scalars that are exchanged, per workgroup: x'(Q xt - 2 b), d'(Q xt - b), g'd,
                        // #non-finite d (the table's b'xt and b'd columns are zero by construction: see CONDITIONING below)
 #define QN_S2SH_EB 4   // ... and the slices of them a prologue requests at a time
@@ -55,7 +57,9 @@
 #define QN_S2_TRED_MAXK 31  // tail reduce: a workgroup's contributions (two per item and the sliver's) are dealt to the lanes of one wave
 
 enum { QN_S2_ADVANCE = 0, QN_S2_EVAL = 1, QN_S2_VEC = 2, QN_S2_HTILE = 3, QN_S2_HREDUCE = 4,
-       QN_S2_VSUM = 5, QN_S2_HSUM = 6 }; // (row-sharded runs, qn_sym2sh.hip.h: this rank's slot sums, in front of the exchange of an n-vector)
+       QN_S2_VSUM = 5, QN_S2_HSUM = 6, // (row-sharded runs, qn_sym2sh.hip.h: this rank's slot sums, in front of the exchange of an n-vector)
+       QN_S2_GEVAL_A = 7, QN_S2_GCOMB = 8, QN_S2_GHT_A = 9 }; // (generic objectives, qn_sym2g.hip.h: the machine in a one-workgroup launch in
+                                                                // front of many-workgroup kernels that only READ the control block)
 
 struct QnS2Args {
     const double* Q;
@@ -85,6 +89,7 @@ struct QnS2Args {
                          // Column-major: every CU reads the whole table at kernel entry, all at once; as 64-byte rows that was
                          // 768 line requests per CU on the same 16 KB (a chip-wide hot spot: 2 us), as columns it is 96.
     int trows;           // rows per half: max(256, nb rounded up to 64)
+    int gw;              // generic objectives (qn_sym2g.hip.h): rows of the table an evaluation's combine launch leaves (its workgroups: n / 64)
     QnCtl* ctl2;         // [2]
     QnTraceRec* trace;
     double* xtrace;
@@ -221,7 +226,10 @@ struct QnS2NoEarly { __device__ __forceinline__ void operator()() const {} };
 // launch has brought in the other ranks' slices: this prologue adds them all up, ranks in order, so every rank has the same
 // bits -- and that a request for vectors takes two launches with an exchange of n-vectors in between (serviced: 0 pending,
 // 1 tiles / partial sums done, 3 partial sums of an update pass done, 2 complete).
-template <int KIND, bool SHARD = false, class Early = QnS2NoEarly>
+// GOBJ (generic objectives, qn_sym2g.hip.h): an evaluation's sums come from its combine launch -- a.gw rows -- which has ALSO staged the
+// vectors of the evaluated point (g+, y, x+, s) and their five sums (table columns QN_S2_VCOL ..): when the machine accepts the point
+// and asks for them (QN_PH_REQ_VEC), this prologue hands them over at once and lets the machine go on -- no launch in between.
+template <int KIND, bool SHARD = false, class Early = QnS2NoEarly, bool GOBJ = false>
 __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L, Early&& early = Early()) {
     const int lane = threadIdx.x; // (wave 0)
     const bool leader = blockIdx.x == 0;
@@ -236,13 +244,24 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     double tr[QN_S2_PCH][QN_S2_NSE];
     const double* T = a.wgS + (size_t)(a.parity ^ 1) * (size_t)a.trows * QN_S2_ROW;
     // launches with nothing to decide in front of them: the second (and third) launch of a request pass the control block on
-    constexpr bool kPass = KIND == QN_S2_HSUM || (SHARD && (KIND == QN_S2_VEC || KIND == QN_S2_HREDUCE));
+    constexpr bool kPass = KIND == QN_S2_HSUM || KIND == QN_S2_GCOMB || (SHARD && (KIND == QN_S2_VEC || KIND == QN_S2_HREDUCE));
     const bool no_decision = kPass || (KIND == QN_S2_HREDUCE && !a.fold); // (uniform) nothing to decide between the update tiles and their reduction
     if (!no_decision) {
 #pragma unroll
         for (int k = 0; k < QN_S2_NSE; ++k)
 #pragma unroll
             for (int j = 0; j < QN_S2_PCH; ++j) tr[j][k] = T[(size_t)k * a.trows + j * 64 + lane]; // (trows >= 256)
+    }
+    // (Measured and dropped, round 5: the first 64 rows of every column requested FIRST and only those waited for when the table has
+    // at most 64 rows -- the two small kernels' tables at n = 4096; in-kernel stamps had shown the table 1.3-1.5 us behind the control
+    // block in the update kernel.  rocprofv3 averages, alternating runs on one box (profiles/r05_f_*): evaluation -0.1 us, update tiles
+    // -0.05 us, and the update-reduce -- which does not run this code -- +0.4 us: no gain.)
+    double tv[GOBJ ? QN_S2_PCH : 1][QN_S2_NR]; // GOBJ: the staged accepted-point sums of the last evaluation
+    if constexpr (GOBJ) if (!no_decision) {
+#pragma unroll
+        for (int k = 0; k < QN_S2_NR; ++k)
+#pragma unroll
+            for (int j = 0; j < QN_S2_PCH; ++j) tv[j][k] = T[(size_t)(QN_S2_VCOL + k) * a.trows + j * 64 + lane];
     }
     // SHARD: the evaluation scalars of the first QN_S2SH_EB ranks go out now as well (every entry of evS is valid at all times --
     // rows past the grid stay zero -- so nothing about them depends on the control block; lane l takes rows 2 l, 2 l + 1 and
@@ -267,7 +286,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     QnCtl& c = L.c; // (in LDS: a private register copy of all ~150 words does not fit beside the machine's own temporaries -- 255 spills)
     int mine = 0;
     if (no_decision) { // pass the control block on (with the folded accept-reduce this prologue is where the machine sees the accepted point)
-        constexpr int want_ph = (KIND == QN_S2_VEC) ? QN_PH_REQ_VEC : QN_PH_REQ_HPASS;
+        constexpr int want_ph = (KIND == QN_S2_VEC) ? QN_PH_REQ_VEC : (KIND == QN_S2_GCOMB ? QN_PH_REQ_EVAL : QN_PH_REQ_HPASS);
         constexpr int from = (SHARD && KIND == QN_S2_HREDUCE) ? 3 : 1; // (sharded update pass: tiles 0 -> 1, partial sums 1 -> 3, reduce 3 -> 2)
         constexpr int to = (KIND == QN_S2_HSUM) ? 3 : 2;
         mine = c.phase == want_ph && c.serviced == from;
@@ -282,10 +301,13 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
         return;
     }
     double tot[QN_S2_NSE];
+    double totv[GOBJ ? QN_S2_NSE : 1];
 #pragma unroll
     for (int k = 0; k < QN_S2_NSE; ++k) tot[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < (GOBJ ? QN_S2_NSE : 1); ++k) totv[k] = 0.0;
     if (c.serviced == 2 && (ph == QN_PH_REQ_EVAL || ph == QN_PH_REQ_VEC || ph == QN_PH_REQ_HPASS)) { // (uniform)
-        const int nrows = ph == QN_PH_REQ_EVAL ? a.G : a.nb;
+        const int nrows = ph == QN_PH_REQ_EVAL ? (GOBJ ? a.gw : a.G) : a.nb;
         const int ncol = ph == QN_PH_REQ_EVAL ? QN_S2_NSE : (ph == QN_PH_REQ_VEC ? QN_S2_NR : 2);
         // The lane's rows in row order, then ONE halving butterfly over all columns at once (QnWaveFold: 17 exchanges instead of
         // six 6-step butterflies).  It pairs lanes l and l ^ 32, then ^ 16, ... ^ 1 for every column exactly as qn_wave_sum
@@ -328,26 +350,66 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
         QnWaveFold<8, 32>::run(acc, lane); // lane l holds the total of column l >> 3
 #pragma unroll
         for (int k = 0; k < QN_S2_NSE; ++k) tot[k] = qn_lane_bcast(acc[0], 8 * k);
+        if constexpr (GOBJ) if (ph == QN_PH_REQ_EVAL) { // (uniform) ... and the staged accepted-point sums, the same way
+            double av[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                av[k] = 0.0;
+                if (k < QN_S2_NR) {
+#pragma unroll
+                    for (int j = 0; j < QN_S2_PCH; ++j) av[k] = av[k] + ((j * 64 + lane < nrows) ? tv[j][k] : 0.0);
+                }
+            }
+            QnWaveFold<8, 32>::run(av, lane);
+#pragma unroll
+            for (int k = 0; k < QN_S2_NR; ++k) totv[k] = qn_lane_bcast(av[0], 8 * k);
+        }
     }
     QN_S2_STAMP(10);
     QnVecs V{};
     V.n = a.n; V.n_pad = a.np; V.trace = a.trace;
-    for (int guard = 0; guard < 64; ++guard) { // (the n <= 5 reference-order code of the machine is never reached on this path: no scratch)
-        int need_x = 0;
-        if (lane == 0) {
-            qn_s2_advance(c, tot, V, leader, &L.red[0][0], guard > 0);
-            need_x = c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END;
+    // (two copies of the loop on purpose: the generic-objective one -- a second entry into the machine with the staged sums -- runs in
+    // one-workgroup launches only; written as one loop with run-time flags it changed the code of EVERY kernel's prologue, and the two
+    // small kernels of the benchmark iteration, whose critical path is the machine, measured 0.3-0.65 us slower: profiles/r05_f_*)
+    if constexpr (!GOBJ) {
+        for (int guard = 0; guard < 64; ++guard) { // (the n <= 5 reference-order code of the machine is never reached on this path: no scratch)
+            int need_x = 0;
+            if (lane == 0) {
+                qn_s2_advance(c, tot, V, leader, &L.red[0][0], guard > 0);
+                need_x = c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END;
+            }
+            need_x = __builtin_amdgcn_readfirstlane(need_x);
+            if (!need_x) break;
+            // the machine stopped because the iterate has to be recorded (trace with x): workgroup 0 copies it, all go on
+            __builtin_amdgcn_wave_barrier();
+            if (leader) {
+                double* row = a.xtrace + (size_t)L.c.k * (size_t)a.n;
+                const double* xs = a.F.X0 + (size_t)L.c.xc * (size_t)a.np;
+                for (int i = lane; i < a.n; i += 64) row[i] = xs[i];
+            }
+            if (lane == 0) c.xtrace_done = 1;
         }
-        need_x = __builtin_amdgcn_readfirstlane(need_x);
-        if (!need_x) break;
-        // the machine stopped because the iterate has to be recorded (trace with x): workgroup 0 copies it, all go on
-        __builtin_amdgcn_wave_barrier();
-        if (leader) {
-            double* row = a.xtrace + (size_t)L.c.k * (size_t)a.n;
-            const double* xs = a.F.X0 + (size_t)L.c.xc * (size_t)a.np;
-            for (int i = lane; i < a.n; i += 64) row[i] = xs[i];
+    } else {
+        bool resume = false, use_v = false; // (uniform)
+        for (int guard = 0; guard < 64; ++guard) {
+            int need_x = 0;
+            if (lane == 0) {
+                qn_s2_advance(c, use_v ? totv : tot, V, leader, &L.red[0][0], resume);
+                need_x = c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END;
+                if (!need_x && c.phase == QN_PH_REQ_VEC && c.serviced == 0) { c.serviced = 2; need_x = 2; } // the vectors are staged: go on
+            }
+            need_x = __builtin_amdgcn_readfirstlane(need_x);
+            if (!need_x) break;
+            if (need_x == 2) { use_v = true; resume = false; continue; }
+            resume = true;
+            __builtin_amdgcn_wave_barrier();
+            if (leader) {
+                double* row = a.xtrace + (size_t)L.c.k * (size_t)a.n;
+                const double* xs = a.F.X0 + (size_t)L.c.xc * (size_t)a.np;
+                for (int i = lane; i < a.n; i += 64) row[i] = xs[i];
+            }
+            if (lane == 0) c.xtrace_done = 1;
         }
-        if (lane == 0) c.xtrace_done = 1;
     }
     QN_S2_STAMP(11);
     if (lane == 0) {
@@ -358,10 +420,12 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
             else if (c.phase == QN_PH_REQ_HPASS && c.serviced == 0) mine = 1;
         }
         if (KIND == QN_S2_HREDUCE) mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 1;
+        if (KIND == QN_S2_GEVAL_A) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == 0;  // (generic objectives: the kernels that follow
+        if (KIND == QN_S2_GHT_A) mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 0;   //  read `serviced == 1` as "yours")
         if (c.phase == QN_PH_RUNNING) { c.status = 4; c.phase = QN_PH_DONE; } // a state this path cannot service: abort, never spin
         if (mine) { // as this launch leaves the request
             if (KIND == QN_S2_HTILE) { c.serviced = (mine == 2 || a.tred) ? 2 : 1; if (mine == 2) c.spec_tiles = c.ev_kind == QN_REQ_T ? 2 : 1; } // (tail reduce: the launch leaves the pass complete)
-            else if (KIND == QN_S2_VSUM) c.serviced = 1; // (the exchange and the reduce launch follow)
+            else if (KIND == QN_S2_VSUM || KIND == QN_S2_GEVAL_A || KIND == QN_S2_GHT_A) c.serviced = 1; // (the exchange / the kernels that do the work follow)
             else c.serviced = 2;
         }
         L.mine = mine;
@@ -1545,10 +1609,11 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_place_probe_kernel(double* __
 }
 
 // synchronous mode: the prologue alone (one workgroup)
-template <bool SHARD = false>
+// (GOBJ / KIND: generic objectives -- the prologue-only launch in front of an evaluation's or an update pass's many-workgroup kernels)
+template <bool SHARD = false, bool GOBJ = false, int KIND = QN_S2_ADVANCE>
 __global__ __launch_bounds__(128) void s2_advance_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
-    if (threadIdx.x < 64) qn_s2_prologue_w0<QN_S2_ADVANCE, SHARD>(a, L);
+    if (threadIdx.x < 64) qn_s2_prologue_w0<KIND, SHARD, QnS2NoEarly, GOBJ>(a, L);
     __syncthreads();
     qn_s2_ctl_out(a, L);
 }

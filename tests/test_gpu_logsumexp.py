@@ -58,6 +58,60 @@ def test_quasi_newton_on_logsumexp_vs_oracle(qn, qo, method, lsname):
     assert st_["oracle_evals"] < st_["oracle_calls"]  # memoised: loop-top and bfgs.rs:98 calls are not re-evaluated
 
 
+@pytest.mark.parametrize("method", ["dfp", "bfgs"])
+@pytest.mark.parametrize("lsname", ["mt", "bt"])
+@pytest.mark.parametrize("m,n", [(600, 1024), (3000, 2176)])
+def test_second_generation_structure_for_logsumexp_vs_oracle_and_generic_path(qn, qo, method, lsname, m, n):
+    """Round 5 (qn_sym2g.hip.h): n a multiple of 128, >= 1024, one rank -- the objective runs in the structure of the second-generation
+    path: the state machine in one-workgroup launches on the device (pipelined: no host round trip per request), the trial point formed
+    by the pass over A from the lazy direction, an evaluation's combine launch staging g+, y, x+, s and their sums, the update pass on
+    the symmetric tiles.  Against the oracle (decisions exact, steps / iterates / f to the parity tolerance), pipelined = synchronous
+    bit for bit, against the generic path (set_tiling(-4, 0)), the launch contract counted, and a continued call."""
+    a, c, x0 = _problem(m, n, scale=3.0)
+    mu, iters = 0.1, 25
+    ref = qo.Solver(qo.DFP if method == "dfp" else qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=4)
+    o = qo.LogSumExpOracle(a, c, mu, nthreads=4)
+    st_ref = ref.minimize(_ls(qo, lsname), o, iters, 20, trace_cap=iters, trace_x=True)
+    obj = qn.LogSumExp(a, c, mu)
+    runs = []
+    for tiling, sync in ((None, 0), (None, 1), ((-4, 0), None)):
+        s = (qn.DFP if method == "dfp" else qn.BFGS)(1e-10, x0)
+        s.set_trace(iters, with_x=True)
+        if tiling:
+            s.set_tiling(*tiling)
+        if sync is not None:
+            s.set_sync_mode(sync)
+        try:
+            s.minimize(_ls(qn, lsname), obj, iters, 20)
+            st = 0
+        except qn.MaxIterReached:
+            st = 1
+        runs.append((s, st, *s.trace()))
+    (s0, st0, tr0, xs0), (s1, st1, tr1, xs1), (sg, stg, trg, xsg) = runs
+    p0, pg = s0.stats()["path"], sg.stats()["path"]
+    assert p0 & 16 and p0 & 8 and p0 & 2 and not pg & 16 and pg & 4  # second-generation structure, pipelined / the generic path on the tiles
+    assert st0 == st1 == stg == st_ref and tr0 == tr1 and np.array_equal(xs0, xs1)  # pipelined = synchronous, bit for bit
+    assert _compare(tr0, xs0, ref.trace, ref.trace_x) == min(len(ref.trace), 25)
+    _compare(tr0, xs0, trg, xsg)
+    h = s0.approx_inv_hessian()
+    assert np.array_equal(h, h.T) and np.abs(h - sg.approx_inv_hessian()).max() <= 1e-9 * np.abs(h).max()
+    # the launch contract: per evaluation 3 (machine, pass over A, combine), per update pass 3 (machine, tiles, reduce); a period of the
+    # pipelined pattern carries one evaluation slot, more once the run has needed more; the host reads the control block once per batch
+    st = s0.stats()
+    assert st["host_syncs"] <= 3 and sg.stats()["host_syncs"] > iters  # (the generic path: at least one round trip per request)
+    assert st["launches"] <= 3 * st["oracle_evals"] + 3 * (st["h_passes"] + 1) + 6 * (st["oracle_evals"] - iters) + 8
+    assert st["oracle_evals"] == sg.stats()["oracle_evals"]
+    # a continued call is the same run (the memo and the lazy direction stay on the device)
+    two = (qn.DFP if method == "dfp" else qn.BFGS)(1e-10, x0)
+    two.set_trace(iters, with_x=True)
+    for k in (10, iters - 10):
+        try:
+            two.minimize(_ls(qn, lsname), obj, k, 20)
+        except qn.MaxIterReached:
+            pass
+    assert np.array_equal(two.x(), s0.x()) and np.array_equal(two.approx_inv_hessian(), h)
+
+
 def test_config5_size_properties_dfp_morethuente_n16384(qn, qo):
     """BASELINE.json config 5: DFP + More-Thuente, n = 16384 log-sum-exp, f64 (one GPU here; rows shard across ranks)."""
     n = m = 16384

@@ -407,8 +407,21 @@ def test_generic_path_logsumexp_dfp_on_tiles(qn, qo):
     c = rng.standard_normal(m)
     x0 = rng.standard_normal(n)
     obj = qn.LogSumExp(amat, c, 0.1)
-    a, b_ = _generic_pair(lambda: qn.DFP(1e-10, x0), lambda s: s.minimize(qn.MoreThuente(), obj, 15, 20))
+
+    def generic_dfp():  # (round 5: the default for this objective is the second-generation structure, qn_sym2g.hip.h; -4 keeps the generic path)
+        s = qn.DFP(1e-10, x0)
+        s.set_tiling(-4, 0)
+        return s
+    a, b_ = _generic_pair(generic_dfp, lambda s: s.minimize(qn.MoreThuente(), obj, 15, 20))
+    assert a[0].stats()["path"] & 4 and not a[0].stats()["path"] & 16  # generic path, H pass on the symmetric tiles
     _assert_same_run(a, b_, n)
+    # ... and the default path against both
+    d = qn.DFP(1e-10, x0)
+    d.set_trace(40, with_x=True)
+    with pytest.raises(qn.MaxIterReached):
+        d.minimize(qn.MoreThuente(), obj, 15, 20)
+    assert d.stats()["path"] & 16 and d.stats()["path"] & 8  # second-generation structure, pipelined
+    _assert_same_run((d, "MaxIterReached"), b_, n)
 
 
 def test_generic_path_sr1b_bounded_on_tiles(qn, qo):

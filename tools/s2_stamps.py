@@ -34,14 +34,14 @@ for slot in range(64):
     t = st[slot]
     if t[0, 14] != 0 and t[0, 0] != 0 and t[0, 3] == 0:  # an accept-reduce launch that did work (32 workgroups; stamp 3 is the evaluation's)
         w = t[:32]
-        print("slot %2d (accept-reduce): ctl %d, sums %d, machine %d, barrier %d, end %d; last workgroup's end %d" % (
-            slot, *[int(np.median((w[:, k] - w[:, 0]) * 10)) for k in (9, 10, 11, 2, 14)], int((w[:, 14].max() - w[:, 0].min()) * 10)))
+        print("slot %2d (accept-reduce): ctl %d, table %d, sums %d, machine %d, barrier %d, end %d; last workgroup's end %d" % (
+            slot, *[int(np.median((w[:, k] - w[:, 0]) * 10)) for k in (9, 1, 10, 11, 2, 14)], int((w[:, 14].max() - w[:, 0].min()) * 10)))
         continue
     if t[0, 6] != 0 and t[0, 15] != 0 and t[0, 0] != 0 and t[0, 4] == 0:  # an update-tile launch (stamps 3 / 6: rows of item 1 / 2 consumed by wave 0, 12 / 13: by wave 7)
         wg = t[:, 15] > 0
         w = t[wg]
         end = (w[:, 15] - w[:, 0].min()) * 10
-        print("slot %2d (update tiles): " % slot + ", ".join("%s %d" % (nm, int(np.median((w[:, k] - w[:, 0]) * 10))) for nm, k in (("ctl", 9), ("sums", 10), ("machine", 11), ("barrier", 2), ("w0 item 1 rows", 3), ("w7 item 1 rows", 12), ("item 1 stored", 5), ("w0 item 2 rows", 6), ("w7 item 2 rows", 13), ("end", 15), ("tail: stores acknowledged", 7), ("tail: adds returned", 8), ("tail: done", 14)))
+        print("slot %2d (update tiles): " % slot + ", ".join("%s %d" % (nm, int(np.median((w[:, k] - w[:, 0]) * 10))) for nm, k in (("ctl", 9), ("table", 1), ("sums", 10), ("machine", 11), ("barrier", 2), ("w0 item 1 rows", 3), ("w7 item 1 rows", 12), ("item 1 stored", 5), ("w0 item 2 rows", 6), ("w7 item 2 rows", 13), ("end", 15), ("tail: stores acknowledged", 7), ("tail: adds returned", 8), ("tail: done", 14)))
               + "; workgroup ends p50 %d p90 %d max %d" % (np.median(end), np.percentile(end, 90), end.max())
               + ("; tail (from the first entry): stores acknowledged p50 %d max %d, adds returned p50 %d max %d, done max %d" % tuple(
                   int(f((w[:, k] - w[:, 0].min()) * 10)) for k, f in ((7, np.median), (7, np.max), (8, np.median), (8, np.max), (14, np.max))) if w[0, 7] else ""))
