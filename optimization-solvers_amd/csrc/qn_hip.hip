@@ -821,6 +821,7 @@ struct qn_solver {
     bool no_pair = false;      // diagnostics: the general evaluation kernel where the two-items-and-a-sliver instance would run
     bool tred = false;         // measurement: the update-reduce in the tail of the update-tile launch (s2_hpass_kernel<.., TRED>: bit-identical, slower)
     int* s2_cnt = nullptr;     // tail reduce: arrival counters of the block-rows
+    double* s2_gws = nullptr;  // row-sharded log-sum-exp (qn_sym2g.hip.h): the ranks' weights and S of the last evaluation consumed
     bool h_sliver_whole = false; // the diagonal tiles that sliver rows read are complete (both triangles): kept so by sliver-mode update passes
     double* s2_evS = nullptr;   // row-sharded: [2][world][QN_S2SH_NEC][QN_S2_MAXG] the ranks' evaluation scalars, by launch parity (QnS2Args.evS)
     int *s2_sl_off = nullptr, *s2_sl_idx = nullptr; // row-sharded: per block-row, the slots this rank's tiles write (QnS2Args.sl_off / sl_idx)
@@ -1114,6 +1115,7 @@ static int solver_alloc_sym2(qn_solver* s) {
         if (sharded) {
             QNCHK(dev_alloc_zero(&s->s2_evS, (size_t)2 * world * QN_S2SH_NEC * QN_S2_MAXG, st));
         }
+        if (!s->s2_gws) QNCHK(dev_alloc_zero(&s->s2_gws, 80, st)); // (row-sharded log-sum-exp: the ranks' weights and S, world <= 64)
         s->s2_G = G;
         s->s2_nb = nb;
     }
@@ -1190,7 +1192,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE); (void)hipFree(s->s2_ctl);
-    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_cnt); (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx); (void)hipFree(s->symsh_tiles);
+    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_cnt); (void)hipFree(s->s2_gws); (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx); (void)hipFree(s->symsh_tiles);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
     delete s;
@@ -1761,6 +1763,7 @@ static QnS2GArgs s2g_args(const Run& r) {
     g.ctl = s->s2_ctl + (r.s2_launches & 1); // what the last prologue launch has written
     g.F = s->V.F;
     g.wgS = nullptr; g.trows = s->s2_trows;
+    g.gall = o->lgall; g.ev_slice = nullptr;
     return g;
 }
 template <int KCH, bool NTA>
@@ -1846,10 +1849,14 @@ static int s2_launch(Run& r, int kind) {
         else if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         else hipLaunchKernelGGL(s2_eval_kernel<false>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         break;
-    case QN_S2_VSUM: hipLaunchKernelGGL(s2sh_vsum_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
+    case QN_S2_VSUM:
+        if (r.gobj) hipLaunchKernelGGL((s2_advance_kernel<true, true, QN_S2_VSUM>), dim3(1), dim3(128), 0, st, a); // (the machine sees the accepted point; the gather follows)
+        else hipLaunchKernelGGL(s2sh_vsum_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
+        break;
     case QN_S2_HSUM: hipLaunchKernelGGL(s2sh_hsum_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
     case QN_S2_VEC:
-        if (sh) hipLaunchKernelGGL(s2_vec_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
+        if (r.gobj) { const QnS2GArgs g = s2g_args(r); hipLaunchKernelGGL(s2g_vec_kernel, dim3(a.nb), dim3(QN_TB), 0, st, a, g); }
+        else if (sh) hipLaunchKernelGGL(s2_vec_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
         else hipLaunchKernelGGL(s2_vec_kernel<false>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
         break;
     case QN_S2_HTILE:
@@ -1886,16 +1893,23 @@ static int s2_launch(Run& r, int kind) {
         if (sh) hipLaunchKernelGGL(s2_hreduce_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
         else hipLaunchKernelGGL(s2_hreduce_kernel<false>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
         break;
-    case QN_S2_GEVAL_A: hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_GEVAL_A>), dim3(1), dim3(128), 0, st, a); break;
+    case QN_S2_GEVAL_A:
+        if (sh) hipLaunchKernelGGL((s2_advance_kernel<true, true, QN_S2_GEVAL_A>), dim3(1), dim3(128), 0, st, a);
+        else hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_GEVAL_A>), dim3(1), dim3(128), 0, st, a);
+        break;
     case QN_S2_GHT_A: hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_GHT_A>), dim3(1), dim3(128), 0, st, a); break;
     case QN_S2_GCOMB: {
         QnS2GArgs g = s2g_args(r);
         g.wgS = a.wgS + (size_t)a.parity * (size_t)a.trows * QN_S2_ROW; // the half this launch writes (the next prologue reads it)
-        hipLaunchKernelGGL(s2g_combine_kernel, dim3(a.gw), dim3(256), 0, st, a, g);
+        if (sh) {
+            g.ev_slice = a.evS + ((size_t)a.parity * (size_t)a.sh_world + (size_t)a.sh_rank) * (QN_S2SH_NEC * QN_S2_MAXG);
+            hipLaunchKernelGGL(s2g_combine_kernel<true>, dim3(a.gw), dim3(256), 0, st, a, g);
+        } else hipLaunchKernelGGL(s2g_combine_kernel<false>, dim3(a.gw), dim3(256), 0, st, a, g);
         break;
     }
     default:
-        if (r.gobj) hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_ADVANCE>), dim3(1), dim3(128), 0, st, a);
+        if (r.gobj && sh) hipLaunchKernelGGL((s2_advance_kernel<true, true, QN_S2_ADVANCE>), dim3(1), dim3(128), 0, st, a);
+        else if (r.gobj) hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_ADVANCE>), dim3(1), dim3(128), 0, st, a);
         else if (sh) hipLaunchKernelGGL(s2_advance_kernel<true>, dim3(1), dim3(128), 0, st, a);
         else hipLaunchKernelGGL(s2_advance_kernel<false>, dim3(1), dim3(128), 0, st, a);
         break;
@@ -1919,7 +1933,16 @@ static int s2_do_eval(Run& r, unsigned long long report_seq = 0) {
         QNCHK(s2_launch(r, QN_S2_GEVAL_A));
         QNCHK(s2g_enqueue_onepass(r));
         r.report_seq = report_seq; // (the batch's last launch reports: only the combine launch leaves the request as the host may see it)
-        return s2_launch(r, QN_S2_GCOMB);
+        QNCHK(s2_launch(r, QN_S2_GCOMB));
+        if (r.s2.sh_world > 1) { // row-sharded: the ranks' (m_r, S_r) and G_r'd per workgroup -- 8 KB per rank; an all-gather whatever the
+            qn_solver* s = r.s;  // context's exchange mode is (the ranks are weighed with exp(m_r - M) before they are added)
+            qn_context* c = s->ctx;
+            ProfScope ps(s, KC_COMM);
+            const size_t cnt = (size_t)QN_S2SH_NEC * QN_S2_MAXG;
+            c->n_xchg_scalar++;
+            QNCHK(exchange(c, s->s2_evS + (size_t)((r.s2_launches - 1) & 1) * (size_t)c->world * cnt, cnt));
+        }
+        return QN_OK;
     }
     if (report_seq) r.report_seq = report_seq;
     QNCHK(s2_launch(r, QN_S2_EVAL));
@@ -1944,7 +1967,8 @@ static int s2_do_vec(Run& r) {
         {
             ProfScope ps(s, KC_COMM);
             c->n_xchg_vector++;
-            if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, (size_t)s->T.n_pad));
+            if (r.gobj) QNCHK(exchange(c, r.obj->lgall, (size_t)s->T.n_pad)); // the ranks' G_r of the accepted point (weighed and added in rank order by s2g_vec_kernel)
+            else if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, (size_t)s->T.n_pad));
             else QNCHK(exchange(c, s->symsh_xg, (size_t)s->T.n_pad));
         }
         return s2_launch(r, QN_S2_VEC);
@@ -1955,7 +1979,7 @@ static int s2_do_vec(Run& r) {
 static int s2_do_hpass(Run& r, bool tiles) {
     qn_solver* s = r.s;
     qn_context* c = s->ctx;
-    if (r.gobj) {
+    if (r.gobj && r.s2.sh_world == 1) {
         if (!tiles) return fail(QN_ABNORMAL_TERMINATION, "sym2 (generic objective): tiles marked done without their launch");
         QNCHK(s2_launch(r, QN_S2_GHT_A));
         QNCHK(s2g_enqueue_tiles(r));
@@ -2864,8 +2888,9 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     // ... and the log-sum-exp objective in the structure of the second-generation path (qn_sym2g.hip.h; round 5): one rank, its one-pass
     // evaluation (n <= 16384), whole 128-blocks without padding, a bitwise symmetric H.  Everything else keeps the generic path.
     r.gobj = r.obj && r.obj->kind == OBJ_LOGSUMEXP && r.obj->lse_kch && !r.obj->lse_two_pass && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP) &&
-             !callback && s->hcs == 1 && !h->small_n && !s->no_fused && !s->bounded && !ls_bounded && !ls_only && c->world == 1 &&
-             (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && (size_t)s->T.n_pad == s->n && !s->no_sym && !s->no_sym2 && !s->h_nonsym &&
+             !callback && s->hcs == 1 && !h->small_n && !s->no_fused && !s->bounded && !ls_bounded && !ls_only &&
+             (c->world == 1 ? (s->T.n_pad % QN_TB) == 0 : ((s->T.rpr % QN_TB) == 0 && c->world <= 64 && (c->comm || c->host_xchg || c->host_async))) &&
+             s->T.n_pad >= 8 * QN_TB && (size_t)s->T.n_pad == s->n && !s->no_sym && !s->no_sym2 && !s->h_nonsym &&
              !(getenv("QN_S2G") && atoi(getenv("QN_S2G")) == 0);
     if (r.gobj) r.fused = true;
     h->fused = r.fused ? 1 : 0;
@@ -2894,7 +2919,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     h->defer_u = 0;
     h->no_defer = s->no_defer;
     if (!r.fused) QNCHK(fused_export(s)); // another path takes over: it works on the canonical buffers
-    if (!(r.sym || r.sym_generic) || (s->h_diag_stale && (!r.sym2 || r.gobj))) QNCHK(ensure_full_h(s)); // ... and on whole rows of H (or whole diagonal tiles: the first-generation tile kernel, which the generic-objective path runs too, reads them whole)
+    if (!(r.sym || r.sym_generic) || (s->h_diag_stale && (!r.sym2 || (r.gobj && c->world == 1)))) QNCHK(ensure_full_h(s)); // ... and on whole rows of H (or whole diagonal tiles: the first-generation tile kernel, which the generic-objective path runs too, reads them whole)
     if (r.fused) {
         QNCHK(solver_alloc_fused(s, r.sym));
         s->V.F.pworld = r.sym ? 1 : c->world; // symmetric storage: every rank forms all the per-block partial sums itself
@@ -2923,6 +2948,8 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.item_ij = s->s2_items; a.maxk = s->s2_maxk; a.inorder = s->s2_inorder; a.F = s->V.F; a.part = s->sym_part;
         a.wgS = s->s2_wgS; a.trows = s->s2_trows; a.ctl2 = s->s2_ctl; a.partE = s->s2_partE;
         a.gw = r.gobj ? s->T.n_pad / 64 : 0;
+        a.gmu = r.gobj ? r.obj->mu : 0.0;
+        a.gws = s->s2_gws;
         if (r.gobj && a.gw > s->s2_trows) return fail(QN_ABNORMAL_TERMINATION, "sym2 (generic objective): more combine workgroups than table rows");
         // folded accept-reduce (s2_hpass_kernel): every workgroup holds at most three items, so the blocks whose slots it sums fit
         // its LDS staging area -- n <= 4096 with 256 workgroups; larger n keeps the accept-reduce launch (7 us of 250+)
@@ -3024,7 +3051,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 first = false;
                 for (int64_t p = 0; p < periods; ++p) {
                     for (int e = 0; e < slots; ++e) QNCHK(s2_do_eval(r));
-                    if (!r.s2.fold && !r.gobj) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise; generic objective: staged by every evaluation's combine launch)
+                    if (!r.s2.fold && !(r.gobj && r.s2.sh_world == 1)) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise; generic objective: staged by every evaluation's combine launch)
                     QNCHK(s2_do_hpass(r, true));
                 }
                 seq = ++s->rep_seq; // (the batch's last launch reports: the evaluation launch below)

@@ -90,6 +90,9 @@ struct QnS2Args {
                          // 768 line requests per CU on the same 16 KB (a chip-wide hot spot: 2 us), as columns it is 96.
     int trows;           // rows per half: max(256, nb rounded up to 64)
     int gw;              // generic objectives (qn_sym2g.hip.h): rows of the table an evaluation's combine launch leaves (its workgroups: n / 64)
+    double gmu;          // ... log-sum-exp: mu (row-sharded runs: the prologue puts the ranks' (m, S, G'd) together itself)
+    double* gws;         // ... [sh_world + 1]: the ranks' weights w_r = exp(m_r - M) and S of the LAST evaluation the machine consumed (written
+                         //     by that prologue, read by s2g_vec_kernel when the point is accepted)
     QnCtl* ctl2;         // [2]
     QnTraceRec* trace;
     double* xtrace;
@@ -277,7 +280,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
                 for (int hh = 0; hh < 2; ++hh)
                     es[rr][cc][hh] = (r0 + rr < a.sh_nsum) ? ld2(E + ((size_t)(r0 + rr) * QN_S2SH_NEC + cc) * QN_S2_MAXG + hh * 128 + 2 * lane) : (v2d){0.0, 0.0};
     };
-    if (SHARD && !no_decision) es_load(0);
+    if (SHARD && !GOBJ && !no_decision) es_load(0);
     early();
     if (lane < NW) lc[lane] = cw0;
     if (64 + lane < NW) lc[64 + lane] = cw1;
@@ -313,7 +316,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
         // six 6-step butterflies).  It pairs lanes l and l ^ 32, then ^ 16, ... ^ 1 for every column exactly as qn_wave_sum
         // does, and floating-point addition commutes: the totals have round 2's bits.
         double acc[8];
-        if (SHARD && ph == QN_PH_REQ_EVAL) { // (uniform)
+        if (SHARD && !GOBJ && ph == QN_PH_REQ_EVAL) { // (uniform)
             // Entry by entry the ranks in rank order FIRST (what an all-reduce would have left in slice 0: with sh_nsum == 1 this
             // loop is empty, and the host-staged stand-in of the tests then gives the very bits of the all-gather), then the lane's
             // four rows of a column in row order, then the butterfly over the lanes.
@@ -350,6 +353,33 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
         QnWaveFold<8, 32>::run(acc, lane); // lane l holds the total of column l >> 3
 #pragma unroll
         for (int k = 0; k < QN_S2_NSE; ++k) tot[k] = qn_lane_bcast(acc[0], 8 * k);
+        if constexpr (GOBJ && SHARD) if (ph == QN_PH_REQ_EVAL) { // (uniform)
+            // Row-sharded log-sum-exp (qn_sym2g.hip.h): rank r's combine launch left in its slice of evS -- exchanged behind it -- the
+            // partial sums of G_r'd per workgroup (column 0) and its running maximum m_r and S_r = sum exp(z - m_r) (column 1, rows 0
+            // and 1); the table's own columns hold what every rank computes alike from the replicated vectors: mu xt'xt, xt'd, g'd and
+            // the non-finite count.  With M = max m_r, w_r = exp(m_r - M), S = sum S_r w_r (ranks in rank order, as lse_finish1_kernel):
+            //     f = M + log S + mu/2 xt'xt        g(xt)'d = (sum_r w_r G_r'd) / S + mu xt'd
+            const double* E = a.evS + (size_t)(a.parity ^ 1) * (size_t)a.sh_world * (QN_S2SH_NEC * QN_S2_MAXG);
+            double M = -INFINITY;
+            for (int r = 0; r < a.sh_world; ++r) M = fmax(M, E[((size_t)r * QN_S2SH_NEC + 1) * QN_S2_MAXG]);
+            double S = 0.0, gdA = 0.0;
+            for (int r = 0; r < a.sh_world; ++r) {
+                const double* Er = E + (size_t)r * QN_S2SH_NEC * QN_S2_MAXG;
+                const double mr = Er[QN_S2_MAXG], sr = Er[QN_S2_MAXG + 1];
+                const double w = mr != -INFINITY ? exp(mr - M) : 0.0; // (a rank that owns no real row contributes nothing)
+                S = __builtin_fma(sr, w, S);
+                double dp = 0.0;
+#pragma unroll
+                for (int j = 0; j < QN_S2_PCH; ++j) dp = dp + Er[j * 64 + lane]; // (rows past the combine launch's grid stay zero)
+                dp = qn_wave_sum(dp);
+                gdA = __builtin_fma(dp, w, gdA);
+                if (leader && lane == 0) a.gws[r] = w;
+            }
+            if (leader && lane == 0) a.gws[a.sh_world] = S;
+            tot[0] = 2.0 * (M + log(S)) + tot[0];
+            tot[2] = gdA / S + a.gmu * tot[1];
+            tot[1] = 0.0; tot[3] = 0.0;
+        }
         if constexpr (GOBJ) if (ph == QN_PH_REQ_EVAL) { // (uniform) ... and the staged accepted-point sums, the same way
             double av[8];
 #pragma unroll
@@ -396,7 +426,8 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
             if (lane == 0) {
                 qn_s2_advance(c, use_v ? totv : tot, V, leader, &L.red[0][0], resume);
                 need_x = c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END;
-                if (!need_x && c.phase == QN_PH_REQ_VEC && c.serviced == 0) { c.serviced = 2; need_x = 2; } // the vectors are staged: go on
+                if (!SHARD && !need_x && c.phase == QN_PH_REQ_VEC && c.serviced == 0) { c.serviced = 2; need_x = 2; } // the vectors are staged: go on
+                // (row-sharded: the gradient of the accepted point has to be gathered first -- s2g_vec_kernel, behind an exchange)
             }
             need_x = __builtin_amdgcn_readfirstlane(need_x);
             if (!need_x) break;

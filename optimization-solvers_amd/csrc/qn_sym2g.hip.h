@@ -33,6 +33,10 @@ struct QnS2GArgs {
     QnFused F;               // X0[2], S0[2], G, GT, Y, UN, VV
     double* wgS;             // the table half this evaluation's combine launch writes: [QN_S2_ROW][trows]
     int trows;
+    // row-sharded runs (rows of A and of H sharded, vectors replicated):
+    double* gall;            // [world][n_pad]: the ranks' G_r = sum_w exp(m_w - m_r) G_w, rank r's slice written by its combine launch;
+                             // all-gathered only for the point the line search accepts
+    double* ev_slice;        // this rank's slice of evS for this launch: [QN_S2SH_NEC][QN_S2_MAXG] -- column 0: G_r'd per workgroup, column 1: m_r, S_r
 };
 
 // the request as the two kernels decode it (qn_s2_eval_req without the scalar-register pinning: these kernels have registers to spare)
@@ -125,6 +129,12 @@ __global__ __launch_bounds__(512) void s2g_onepass_kernel(const QnS2GArgs g) {
 //         mu sum xt^2 (+ 2 (M + log S) in workgroup 0's row), 0, sum g+ d, 0, sum g d, #non-finite d
 //     columns QN_S2_VCOL .. + 4 (what it reads for an accepted point): y'y, y's, g+'g+, s's, s'g+
 // The launch's prologue passes the control block on (serviced 1 -> 2): nothing is decided between the pass over A and this.
+// SHARD (row-sharded runs): the rank folds ITS workgroups -- rows of A it owns -- into (m_r, S_r, G_r) and hands the line search what it
+// can: G_r'd per workgroup and (m_r, S_r) into its slice of evS (one 8 KB exchange follows; the next prologue weighs the ranks with
+// exp(m_r - M) in rank order), mu xt'xt, xt'd, g'd and the non-finite count -- the same on every rank, the vectors are replicated --
+// into the table.  G_r stays in the rank's slice of `gall`: it crosses the links only if the point is accepted (s2g_vec_kernel).  A
+// trial point that is rejected never moves an n-vector between GPUs.
+template <bool SHARD>
 __global__ __launch_bounds__(256) void s2g_combine_kernel(const QnS2Args a, const QnS2GArgs g) {
     __shared__ QnS2Lds L;
     __shared__ double fac[256];
@@ -173,6 +183,22 @@ __global__ __launch_bounds__(256) void s2g_combine_kernel(const QnS2Args a, cons
     double di;
     const double xi = x[j];
     const double xti = qn_s2_trial(q, xi, g.F.VV[j], spv[j], g.F.UN[j], di);
+    if (SHARD) {
+        const double go = g.F.G[j];
+        g.gall[(size_t)la.rank * np + j] = gs;
+        double p[8] = {la.mu * (xti * xti), xti * di, go * di, isfinite(di) ? 0.0 : 1.0, gs * di, 0.0, 0.0, 0.0};
+        QnWaveFold<8, 32>::run(p, c);
+        double* T = g.wgS;
+        const size_t tr = (size_t)g.trows;
+        if ((c & 7) == 0) {
+            const int k = c >> 3;
+            if (k < 4) { const int col = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 4 : 5)); T[(size_t)col * tr + blockIdx.x] = p[0]; }
+            else if (k == 4) g.ev_slice[blockIdx.x] = p[0];                       // column 0 of the slice: G_r'd of this workgroup's columns
+            else if (k == 5) { T[(size_t)2 * tr + blockIdx.x] = 0.0; T[(size_t)3 * tr + blockIdx.x] = 0.0; }
+            if (k == 6 && blockIdx.x == 0) { g.ev_slice[QN_S2_MAXG] = mr; g.ev_slice[QN_S2_MAXG + 1] = S; } // column 1, rows 0 and 1
+        }
+        return;
+    }
     const double gti = gs / S + la.mu * xti;
     const double go = g.F.G[j];
     const double yi = gti - go;
@@ -196,4 +222,44 @@ __global__ __launch_bounds__(256) void s2g_combine_kernel(const QnS2Args a, cons
         else if (k == 5) T[(size_t)3 * tr + blockIdx.x] = 0.0;
         if (k < QN_S2_NR) T[(size_t)(QN_S2_VCOL + k) * tr + blockIdx.x] = pv[0];
     }
+}
+
+// Row-sharded runs, the point the line search accepted: block-row R of g+ = (sum_r w_r G_r) / S + mu x+ (the ranks' G_r gathered by the
+// exchange in front, the weights and S as the prologue that consumed the evaluation left them), y = g+ - g, x+, s = x+ - x and the five
+// sums of bfgs.rs:94-102 -- on every rank, from the same inputs in the same order: the same bits.  What s2_vec_kernel<true> is for the
+// quadratic; the launch's prologue passes the control block on (serviced 1 -> 2).
+__global__ __launch_bounds__(QN_TB) void s2g_vec_kernel(const QnS2Args a, const QnS2GArgs g) {
+    __shared__ QnS2Lds L;
+    __shared__ double bred[2][8];
+    const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC, true>(a, L);
+    __syncthreads();
+    qn_s2_ctl_out(a, L);
+    if (!L.mine) return;
+    const QnLseArgs& la = g.L;
+    const QnEvalReq q = qn_s2_eval_req<false>(L.c, true);
+    const size_t np = (size_t)la.n_pad;
+    const int j = R * QN_TB + tid;
+    const double* __restrict__ x = g.F.X0 + (size_t)q.xc * np;
+    double* __restrict__ xstage = g.F.X0 + (size_t)(1 - q.xc) * np;
+    const double* __restrict__ spv = g.F.S0 + (size_t)q.sc * np;
+    double* __restrict__ sstage = g.F.S0 + (size_t)(1 - q.sc) * np;
+    double gs = 0.0;
+    for (int r = 0; r < la.world; ++r) gs = __builtin_fma(g.gall[(size_t)r * np + j], a.gws[r], gs); // ranks in rank order (lse_finish1_kernel)
+    const double S = a.gws[la.world];
+    double di;
+    const double xi = x[j];
+    const double xti = qn_s2_trial(q, xi, g.F.VV[j], spv[j], g.F.UN[j], di);
+    const double gti = gs / S + la.mu * xti;
+    const double yi = gti - g.F.G[j];
+    const double si = xti - xi; // s = x+ - x, not t d (bfgs.rs:96)
+    g.F.GT[j] = gti;
+    g.F.Y[j] = yi;
+    xstage[j] = xti;
+    sstage[j] = si;
+    double p[8] = {yi * yi, yi * si, gti * gti, si * si, si * gti, 0.0, 0.0, 0.0};
+    QnWaveFold<8, 32>::run(p, lane);
+    if ((lane & 7) == 0) bred[wave][lane >> 3] = p[0];
+    __syncthreads();
+    if (tid < QN_S2_NR) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = bred[0][tid] + bred[1][tid]; // (as s2_vec_kernel)
 }

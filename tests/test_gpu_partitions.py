@@ -153,8 +153,10 @@ def test_config3_partition_8_ranks_n32768(qn, qo):
 
 def test_config5_partition_4_ranks_dfp_logsumexp_n16384(qn, qo):
     """BASELINE.json config 5: DFP + More-Thuente on the n = m = 16384 log-sum-exp objective, rows of A (and of H) sharded 4 ways.
-    The H pass runs on the sharded symmetric tiles (generic path), the objective's gradient is summed over the ranks in rank
-    order."""
+    Round 5: the partition runs in the second-generation structure (qn_sym2g.hip.h) -- the state machine on the device on every rank, a
+    trial point exchanged as SCALARS (each rank's (m_r, S_r) and G_r'd per workgroup: 8 KB), the gradient's n-vector gathered only for
+    the point the line search accepts, the update pass on the rank's circulant windows of H: per iteration E scalar + 2 n-vector
+    collectives, counted below as _check_partition counts the quadratic's."""
     n = m = 16384
     world, iters, mu = 4, 6, 0.1
     rng = np.random.default_rng(11)
@@ -169,7 +171,8 @@ def test_config5_partition_4_ranks_dfp_logsumexp_n16384(qn, qo):
         tr, xs = _run(qn, s, qn.MoreThuente(), obj, iters)
         st = s.stats()
         ev = obj(xs[-1])
-        out = {"tr": tr, "xs": xs, "path": st["path"], "bytes": st["matrix_bytes_per_pass"], "f": ev.f(), "g": ev.g()}
+        out = {"tr": tr, "xs": xs, "path": st["path"], "bytes": st["matrix_bytes_per_pass"], "f": ev.f(), "g": ev.g(), "launches": st["launches"],
+               "iters": st["iterations"], "evals": st["oracle_evals"], "xchg": (st["total_xchg_vector"], st["total_xchg_scalar"])}
         group.sync()
         s.close(); obj.close(); ctx.close()
         return out
@@ -177,9 +180,18 @@ def test_config5_partition_4_ranks_dfp_logsumexp_n16384(qn, qo):
     res = run_ranks(world, body)
     nb = n // 128
     for r in res:
-        assert r["path"] & 4 and not r["path"] & 1  # generic path, H pass on the (sharded) symmetric tiles
+        assert r["path"] & 1 and r["path"] & 2 and r["path"] & 16  # the second-generation structure on the rank's share of the symmetric half
         assert np.array_equal(r["xs"], res[0]["xs"]) and r["tr"] == res[0]["tr"] and r["f"] == res[0]["f"] and np.array_equal(r["g"], res[0]["g"])
-    assert sum(r["bytes"] for r in res) == nb * (nb + 1) // 2 * 131072
+        # the launch / collective contract (synchronous pump of this harness: one prologue-only launch per request):
+        #   an evaluation  = machine, pass over A, combine (3 launches) + ONE exchange of 8 KB of scalars per rank
+        #   an acceptance  = machine, [gather of the ranks' G_r: n doubles each], vectors (2 launches)
+        #   an update pass = tiles, partial sums, [gather of 2 n doubles], reduce (3 launches)
+        it, ev = r["iters"], r["evals"]
+        xv, xs_ = r["xchg"]
+        assert xs_ == ev and xv == 2 * it + 2, (xv, xs_, it, ev)
+        requests = ev + (it + 1) + (it + 1)
+        assert r["launches"] == 3 * ev + 2 * (it + 1) + 3 * (it + 1) + requests + 1, (r["launches"], it, ev)
+    assert sum(r["bytes"] for r in res) == nb * (nb - 1) // 2 * 131072 + nb * 73728  # (diagonal tiles as their upper triangle: s2_hpass_kernel<.., SHARD>)
     obj1 = qn.LogSumExp(a, c, mu)
     s1 = qn.DFP(1e-10, x0)
     tr1, xs1 = _run(qn, s1, qn.MoreThuente(), obj1, iters)
@@ -193,4 +205,48 @@ def test_config5_partition_4_ranks_dfp_logsumexp_n16384(qn, qo):
     assert np.linalg.norm(res[0]["g"] - g_ref) <= 1e-11 * np.linalg.norm(g_ref)
     ref = qo.Solver(qo.DFP, 1e-10, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
     ref.minimize(qo.morethuente(), o, iters, 20, trace_cap=iters, trace_x=True)  # (every iteration of the run: 1-2 s each on the host)
+    _trace_close(res[0]["tr"], res[0]["xs"], ref.trace, ref.trace_x)
+
+
+@pytest.mark.parametrize("world,m,n,method,lsname", [(2, 777, 1024, "dfp", "mt"), (4, 1500, 1024, "bfgs", "mt"), (4, 900, 2048, "dfp", "bt"), (3, 640, 1152, "dfp", "mt")])
+def test_logsumexp_partition_second_generation_structure(qn, qo, world, m, n, method, lsname):
+    """The row-sharded log-sum-exp path of qn_sym2g.hip.h at sizes the oracle follows in seconds: 2, 3 and 4 ranks (rows of A not a
+    multiple of the rank count: a short last shard), DFP and BFGS, More-Thuente and backtracking (several rejected trial points per
+    iteration -- each exchanged as 8 KB of scalars, never as an n-vector).  Every rank the same bits; the single-rank run and the
+    oracle to the parity tolerance; the collective contract counted."""
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((m, n)) * (3.0 / np.sqrt(n))
+    c = rng.standard_normal(m)
+    x0 = rng.standard_normal(n)
+    mu, iters = 0.1, 14
+    mk = (lambda mod: mod.MoreThuente() if hasattr(mod, "MoreThuente") else mod.morethuente()) if lsname == "mt" else \
+         (lambda mod: mod.BackTracking(1e-4, 0.5) if hasattr(mod, "BackTracking") else mod.backtracking(1e-4, 0.5))
+
+    def body(rank, world_, group):
+        ctx = qn.Context(0, rank=rank, world=world_, host_allgather=group.allgather_fn(rank))
+        obj = qn.LogSumExp(a, c, mu, ctx=ctx)
+        s = (qn.DFP if method == "dfp" else qn.BFGS)(1e-10, x0, ctx=ctx)
+        tr, xs = _run(qn, s, mk(qn), obj, iters)
+        st = s.stats()
+        out = {"tr": tr, "xs": xs, "path": st["path"], "iters": st["iterations"], "evals": st["oracle_evals"],
+               "xchg": (st["total_xchg_vector"], st["total_xchg_scalar"]), "h": s.approx_inv_hessian()}
+        group.sync()
+        s.close(); obj.close(); ctx.close()
+        return out
+
+    res = run_ranks(world, body)
+    for r in res:
+        assert r["path"] & 1 and r["path"] & 2 and r["path"] & 16
+        assert np.array_equal(r["xs"], res[0]["xs"]) and r["tr"] == res[0]["tr"] and np.array_equal(r["h"], res[0]["h"])
+        it, ev = r["iters"], r["evals"]
+        assert r["xchg"][1] == ev and r["xchg"][0] >= 2 * it + 2  # (+ what the getter's mirror of H gathers afterwards)
+    assert np.array_equal(res[0]["h"], res[0]["h"].T)
+    obj1 = qn.LogSumExp(a, c, mu)
+    s1 = (qn.DFP if method == "dfp" else qn.BFGS)(1e-10, x0)
+    tr1, xs1 = _run(qn, s1, mk(qn), obj1, iters)
+    _trace_close(res[0]["tr"], res[0]["xs"], tr1, xs1)
+    assert np.abs(res[0]["h"] - s1.approx_inv_hessian()).max() <= 1e-9 * np.abs(res[0]["h"]).max()
+    o = qo.LogSumExpOracle(a, c, mu, nthreads=4)
+    ref = qo.Solver(qo.DFP if method == "dfp" else qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=4)
+    ref.minimize(mk(qo), o, iters, 20, trace_cap=iters, trace_x=True)
     _trace_close(res[0]["tr"], res[0]["xs"], ref.trace, ref.trace_x)
