@@ -344,19 +344,28 @@ def extra_config5(qn, ctx):
     p1 = s.stats()
     s.set_profiling(False)
     n_h, n_e = p1["n_hpass_timed"] - p0["n_hpass_timed"], p1["n_eval_timed"] - p0["n_eval_timed"]
-    ms_h = (p1["t_hpass_ms"] - p0["t_hpass_ms"]) / max(n_h, 1)
-    ms_e = (p1["t_eval_ms"] - p0["t_eval_ms"]) / max(n_e, 1)
+    ms_h = (p1["t_hpass_ms"] - p0["t_hpass_ms"]) / n_h if n_h else None
+    ms_e = (p1["t_eval_ms"] - p0["t_eval_ms"]) / n_e if n_e else None
+    n_c, n_r = p1["n_ereduce_timed"] - p0["n_ereduce_timed"], p1["n_hreduce_timed"] - p0["n_hreduce_timed"]
+    ms_c = (p1["t_ereduce_ms"] - p0["t_ereduce_ms"]) / n_c if n_c else None
+    ms_r = (p1["t_hreduce_ms"] - p0["t_hreduce_ms"]) / n_r if n_r else None
     alg_h, alg_e = 2.0 * p1["matrix_bytes_per_pass"], 8.0 * n * n
     e_per_it = evals / steps
     b_iter = alg_h + e_per_it * alg_e
+    if not (ms_h and ms_e):
+        raise RuntimeError("the profiling pass timed no launch of the pass over A or of the update pass")
     dom_eval = n_e * ms_e > n_h * ms_h
     ach = (alg_e / (ms_e * 1e-3) if dom_eval else alg_h / (ms_h * 1e-3)) / 1e9
+    path = p1["path"]
     return {"workload": f"DFP + MoreThuente::default, n=m={n} log-sum-exp (mu={LSE_MU}, A ~ N(0, ({LSE_A_SCALE:g}/sqrt n)^2), seed {LSE_SEED}), f64, 1xMI355X "
                         "(BASELINE.json configs[4] names 4 GPUs: tests/test_gpu_partitions.py runs that partition)",
             "metric": "DFP iterations/s", "value": steps / dt, "unit": "iterations/s", "ms_per_iteration": 1e3 * dt / steps, "steps": steps, "dtype": "f64",
             "region_ms": [1e3 * r[0] for r in regions], "evaluations_per_iteration": e_per_it,
             "algorithmic_bytes_per_iteration": b_iter, "whole_iteration_hbm_frac": b_iter * (steps / dt) / (HBM_PEAK_GBS * 1e9),
             "launches_per_iteration": (p1["launches"] - p0["launches"]) / 8.0,
+            "kernels": ("second-generation structure (qn_sym2g.hip.h): the state machine in one-workgroup launches on the device, pipelined; per iteration "
+                        "E x (machine, pass over A, combine + staged vectors) + (machine, update tiles, reduce)" if path & 16 else "generic path (synchronous)"),
+            "combine_avg_launch_ms": ms_c, "update_reduce_avg_launch_ms": ms_r,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "kernel": ("lse_onepass_kernel (f and the gradient in ONE pass over A: running-maximum softmax)" if dom_eval else
                                     "the update pass over the symmetric half of H (pending rank-2 update + H+ [y, g+])"),

@@ -262,18 +262,36 @@ def main():
                 c_ = rng.standard_normal(300)
                 xs0 = rng.standard_normal(n)
                 outs_l = []
-                for cx in (ctx, ctx1):
+                # sharded / one rank on the default path (round 5: the second-generation structure, qn_sym2g.hip.h -- trial points
+                # exchanged as scalars), then the sharded run on the generic path (set_tiling(-4, 0)), then -- host exchange only --
+                # the default path again with the exchange in stream order: pipelined, the same bits as the synchronous pump
+                variants = [(ctx, None, False), (ctx1, None, False), (ctx, (-4, 0), False)] + ([] if rccl else [(ctx, None, True)])
+                for cx, tiling, asyn in variants:
+                    if asyn:
+                        ctx.set_host_exchange_async(True)
                     lse = qn.LogSumExp(a_, c_, 0.1, ctx=cx)
                     sl = qn.DFP(1e-10, xs0, ctx=cx)
+                    if tiling:
+                        sl.set_tiling(*tiling)
                     sl.set_trace(10, with_x=True)
                     try:
                         sl.minimize(qn.MoreThuente(), lse, 10, 20)
                     except qn.MaxIterReached:
                         pass
-                    outs_l.append((sl.trace(), sl.stats()["path"]))
-                (tl, xl), (tl1, xl1) = outs_l[0][0], outs_l[1][0]
-                case["lse_close"] = bool(len(tl) == len(tl1) and np.linalg.norm(xl - xl1) <= 1e-9 * np.linalg.norm(xl1))
+                    stl = sl.stats()
+                    outs_l.append((sl.trace(), stl["path"], stl["oracle_evals"], stl["total_xchg_scalar"], stl["total_xchg_vector"]))
+                    if asyn:
+                        ctx.set_host_exchange_async(False)
+                (tl, xl), (tl1, xl1), (tlg, xlg) = outs_l[0][0], outs_l[1][0], outs_l[2][0]
+                case["lse_close"] = bool(len(tl) == len(tl1) and [r_["ls_cases"] for r_ in tl] == [r_["ls_cases"] for r_ in tl1]
+                                         and np.linalg.norm(xl - xl1) <= 1e-9 * np.linalg.norm(xl1))
                 case["lse_path"] = [outs_l[0][1], outs_l[1][1]]
+                case["lse_xchg"] = [outs_l[0][2], outs_l[0][3], outs_l[0][4], len(tl)]  # evaluations, scalar and n-vector collectives, iterations
+                case["lse_generic_close"] = bool(len(tlg) == len(tl1) and np.linalg.norm(xlg - xl1) <= 1e-9 * np.linalg.norm(xl1))
+                case["lse_generic_path"] = outs_l[2][1]
+                if not rccl:
+                    case["lse_pipelined_equal"] = bool(outs_l[3][0][0] == tl and np.array_equal(outs_l[3][0][1], xl))
+                    case["lse_pipelined_path"] = outs_l[3][1]
             # the same exchange in STREAM ORDER (no synchronisation per exchange): the run is then pipelined -- every kernel and
             # every exchange of an iteration enqueued ahead of the device-side decisions, as with RCCL -- and must give the same bits
             ctx.comm_check()

@@ -50,7 +50,15 @@ def _check_sharded_symmetric(res, nproc):
         for case in r["cases"]:
             assert case["generic_close"] and case["generic_path"][0] & 4 and not case["generic_path"][0] & 1, case
             if "lse_close" in case:
-                assert case["lse_close"] and case["lse_path"][0] & 4, case
+                # the log-sum-exp objective, rows of A sharded: the second-generation structure (round 5) on the ranks and on one rank --
+                # one scalar collective per evaluation, two n-vector collectives per iteration (+ the run's opening pair) --, the generic
+                # path still reachable, and the stream-ordered exchange (pipelined) bit for bit the synchronous pump
+                assert case["lse_close"] and case["lse_path"][0] & 16 and case["lse_path"][0] & 2 and case["lse_path"][1] & 16, case
+                ev, xs_, xv, it = case["lse_xchg"]
+                assert xs_ == ev and xv == 2 * it + 2, case["lse_xchg"]
+                assert case["lse_generic_close"] and case["lse_generic_path"] & 4 and not case["lse_generic_path"] & 16, case
+                if "lse_pipelined_equal" in case:
+                    assert case["lse_pipelined_equal"] and case["lse_pipelined_path"] & 8 and case["lse_pipelined_path"] & 16, case
             if "mt_cases_ok" in case:  # cases 2, 3 and 4 really occurred on the sharded tiles, and matched the single-rank run
                 assert case["mt_cases_ok"] and min(case["mt_digits"][1:]) >= 3, case
     nbs = {case["n"]: (case["n"] + 127) // 128 for case in res[0]["cases"]}
