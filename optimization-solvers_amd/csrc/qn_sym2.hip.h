@@ -138,7 +138,8 @@ struct QnS2Lds {
 // (Measured again and dropped, round 3: the machine as ONE out-of-line function, now called from wave 0's prologue where no tile
 // window is live -- one copy of its code for the five kernels instead of five.  The call frame lives in scratch memory (400 bytes
 // per lane) and the machine then takes 8.4 us instead of 4-5: 11.0 k it/s against 12.3 k inlined, same box.)
-__device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const QnVecs& V, const bool leader, double* scratch, const bool resume) {
+template <class C> // (C: QnCtl in LDS, or its register view QnCtlLanes)
+__device__ __forceinline__ void qn_s2_advance(C& c, const double* tot, const QnVecs& V, const bool leader, double* scratch, const bool resume) {
     const int ph = c.phase;
     bool run = resume; // (resume: the machine had stopped for the x-trace copy)
     if (!resume) {
@@ -286,14 +287,37 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     if (64 + lane < NW) lc[64 + lane] = cw1;
     __builtin_amdgcn_wave_barrier(); // (one wave: its LDS accesses execute in program order; this only pins the compiler's order)
     QN_S2_STAMP(9);
-    QnCtl& c = L.c; // (in LDS: a private register copy of all ~150 words does not fit beside the machine's own temporaries -- 255 spills)
+    // THE MACHINE ON REGISTERS (round 5): built, bit-identical, SLOWER, compiled out by default (-DQN_S2_CTL_LANES=1 builds it).  Rounds 2-4
+    // run the machine on the copy in LDS, one lane's dependent chain, and in-kernel stamps show 2.0 us between the sums and the
+    // machine's end in the two small kernels and the update tiles alike -- which looked like a few dozen ~100-cycle LDS round trips.
+    // A private register copy does not fit (~150 words: 255 spills, rounds 3-4), but the block IS in registers when it arrives,
+    // spread over the wave: word W in lane W & 63 of (cw0, cw1).  QnCtlLanes (qn_ctl_lanes.h, generated from qn_ctl.h) is a view of
+    // exactly that -- a field read is two v_readlane, a write two v_writelane -- and the machine, templated on the control type, runs
+    // on all 64 lanes alike (every value the same in every lane, every branch uniform); the block goes back to LDS once, at the end.
+    // Measured (tools/trace_cmp.py: the same bits in every run; tools/prof_ab.sh, alternating runs on one box, profiles/r05_j_*):
+    // the accept-reduce 6.42 -> 7.6 us, the update-reduce 5.1 -> 5.45, the evaluation +0.1, the update tiles +-0: 66.3 -> 68.0 us per
+    // iteration.  No scratch, FEWER vector registers (222 -> 171 in the evaluation kernel) -- and 10 KB MORE CODE per kernel (26 -> 36
+    // KB in the accept-reduce).  The machine is ONE wave's instruction stream, and one wave issues an instruction every ~5 cycles --
+    // tools/icache_probe.hip: 3072 eight-byte instructions of straight-line code take 15 380 cycles, the same right behind itself,
+    // behind another kernel of the same size or behind a 64 MB fill (so it is not instruction FETCH either: cold or warm alike).  2 us
+    // are ~700 instructions on the machine's path at that rate; the LDS latencies hide under them, and two readlanes and a move per
+    // field are simply more instructions than one ds_read.  What makes the machine faster is fewer instructions on its path (the
+    // LEAN instantiation of round 3), not where its block lives.
+#ifndef QN_S2_CTL_LANES
+#define QN_S2_CTL_LANES 0
+#endif
+    constexpr bool kLanes = QN_S2_CTL_LANES != 0;
+    QnLaneRegs creg{{(int)(unsigned)cw0, (int)(unsigned)(cw0 >> 32), (int)(unsigned)cw1, (int)(unsigned)(cw1 >> 32)}};
+    QnCtlLanes clanes(creg);
+    auto& c = [&]() -> auto& { if constexpr (kLanes) return clanes; else return L.c; }();
+    const bool every = kLanes; // (the deciding code below runs on lane 0 of the LDS copy, or on every lane of the register view)
     int mine = 0;
     if (no_decision) { // pass the control block on (with the folded accept-reduce this prologue is where the machine sees the accepted point)
         constexpr int want_ph = (KIND == QN_S2_VEC) ? QN_PH_REQ_VEC : (KIND == QN_S2_GCOMB ? QN_PH_REQ_EVAL : QN_PH_REQ_HPASS);
         constexpr int from = (SHARD && KIND == QN_S2_HREDUCE) ? 3 : 1; // (sharded update pass: tiles 0 -> 1, partial sums 1 -> 3, reduce 3 -> 2)
         constexpr int to = (KIND == QN_S2_HSUM) ? 3 : 2;
-        mine = c.phase == want_ph && c.serviced == from;
-        if (lane == 0) { if (mine) c.serviced = to; L.mine = mine; }
+        mine = L.c.phase == want_ph && L.c.serviced == from;
+        if (lane == 0) { if (mine) L.c.serviced = to; L.mine = mine; }
         __builtin_amdgcn_s_setprio(0);
         return;
     }
@@ -404,7 +428,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     if constexpr (!GOBJ) {
         for (int guard = 0; guard < 64; ++guard) { // (the n <= 5 reference-order code of the machine is never reached on this path: no scratch)
             int need_x = 0;
-            if (lane == 0) {
+            if (every || lane == 0) {
                 qn_s2_advance(c, tot, V, leader, &L.red[0][0], guard > 0);
                 need_x = c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END;
             }
@@ -412,18 +436,20 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
             if (!need_x) break;
             // the machine stopped because the iterate has to be recorded (trace with x): workgroup 0 copies it, all go on
             __builtin_amdgcn_wave_barrier();
+            const long long kx = __builtin_amdgcn_readfirstlane((int)c.k);
+            const int xcx = __builtin_amdgcn_readfirstlane((int)c.xc);
             if (leader) {
-                double* row = a.xtrace + (size_t)L.c.k * (size_t)a.n;
-                const double* xs = a.F.X0 + (size_t)L.c.xc * (size_t)a.np;
+                double* row = a.xtrace + (size_t)kx * (size_t)a.n;
+                const double* xs = a.F.X0 + (size_t)xcx * (size_t)a.np;
                 for (int i = lane; i < a.n; i += 64) row[i] = xs[i];
             }
-            if (lane == 0) c.xtrace_done = 1;
+            if (every || lane == 0) c.xtrace_done = 1;
         }
     } else {
         bool resume = false, use_v = false; // (uniform)
         for (int guard = 0; guard < 64; ++guard) {
             int need_x = 0;
-            if (lane == 0) {
+            if (every || lane == 0) {
                 qn_s2_advance(c, use_v ? totv : tot, V, leader, &L.red[0][0], resume);
                 need_x = c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END;
                 if (!SHARD && !need_x && c.phase == QN_PH_REQ_VEC && c.serviced == 0) { c.serviced = 2; need_x = 2; } // the vectors are staged: go on
@@ -434,16 +460,18 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
             if (need_x == 2) { use_v = true; resume = false; continue; }
             resume = true;
             __builtin_amdgcn_wave_barrier();
+            const long long kx = __builtin_amdgcn_readfirstlane((int)c.k);
+            const int xcx = __builtin_amdgcn_readfirstlane((int)c.xc);
             if (leader) {
-                double* row = a.xtrace + (size_t)L.c.k * (size_t)a.n;
-                const double* xs = a.F.X0 + (size_t)L.c.xc * (size_t)a.np;
+                double* row = a.xtrace + (size_t)kx * (size_t)a.n;
+                const double* xs = a.F.X0 + (size_t)xcx * (size_t)a.np;
                 for (int i = lane; i < a.n; i += 64) row[i] = xs[i];
             }
-            if (lane == 0) c.xtrace_done = 1;
+            if (every || lane == 0) c.xtrace_done = 1;
         }
     }
     QN_S2_STAMP(11);
-    if (lane == 0) {
+    if (every || lane == 0) {
         if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == 0;
         if (KIND == QN_S2_VEC || KIND == QN_S2_VSUM) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
         if (KIND == QN_S2_HTILE) { // 2: the accepted point's slots -> vectors AND the update tiles (folded accept-reduce); 1: the tiles of a pending pass
@@ -460,6 +488,11 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
             else c.serviced = 2;
         }
         L.mine = mine;
+    }
+    if constexpr (kLanes) { // the block as the machine left it -> LDS: the workgroup's other waves and qn_s2_ctl_out read it there
+        if (lane < NW) lc[lane] = ((uint64_t)(unsigned)creg.w[1] << 32) | (unsigned)creg.w[0];
+        if (64 + lane < NW) lc[64 + lane] = ((uint64_t)(unsigned)creg.w[3] << 32) | (unsigned)creg.w[2];
+        __builtin_amdgcn_wave_barrier();
     }
     __builtin_amdgcn_s_setprio(0);
 }
