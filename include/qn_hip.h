@@ -274,6 +274,8 @@ typedef struct {
 #define QN_PATH_SYM_GENERIC 4u /* generic path whose H pass runs on the symmetric half */
 #define QN_PATH_PIPELINED 8u   /* predicated kernels enqueued ahead of the device-side decisions (no host sync per step) */
 #define QN_PATH_SYM2 16u       /* QN_PATH_SYM with the solver's decisions taken in every kernel's prologue (5 launches per iteration) */
+#define QN_PATH_TILES1 32u     /* QN_PATH_SYM2 whose update pass streams H through the first-generation tile kernel (one workgroup per tile) behind a
+                                  one-workgroup launch that runs the state machine: H's share past the Infinity Cache, and the log-sum-exp objective */
 int qn_solver_get_stats(qn_solver* s, qn_stats* out);
 /* profiling != 0: bracket every launch with HIP events on the solver's stream (slower; for roofline reports) */
 int qn_solver_set_profiling(qn_solver* s, int on);

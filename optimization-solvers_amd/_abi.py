@@ -57,7 +57,7 @@ class Stats(C.Structure):
                 ("t_newton_ms", C.c_double), ("n_newton_timed", C.c_uint64), ("newton_lu_sync_timeouts", C.c_uint64)]
 
 
-PATH_FUSED, PATH_SYM, PATH_SYM_GENERIC, PATH_PIPELINED, PATH_SYM2 = 1, 2, 4, 8, 16
+PATH_FUSED, PATH_SYM, PATH_SYM_GENERIC, PATH_PIPELINED, PATH_SYM2, PATH_TILES1 = 1, 2, 4, 8, 16, 32
 
 
 # every symbol include/qn_hip.h declares: (name, restype, argtypes)

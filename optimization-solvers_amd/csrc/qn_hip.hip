@@ -1745,6 +1745,8 @@ struct Run {
     bool sym_generic = false; // generic path: the H pass alone on the upper block triangle
     bool sym2 = false;        // second-generation symmetric path (qn_sym2.hip.h)
     bool gobj = false;        // ... in its form for a device objective that is not the quadratic (qn_sym2g.hip.h: the log-sum-exp objective)
+    bool tiles1 = false;      // the update pass's tiles through the first-generation tile kernel (one workgroup per tile, two per CU) behind a
+                              // one-workgroup launch that runs the machine: H's share past the Infinity Cache (see minimize_impl)
     QnS2Args s2{};
     uint64_t s2_launches = 0; // parity of the control-block double buffer = launches so far & 1
     unsigned long long report_seq = 0; // != 0: the next launch reports its control block to the host (s2_wait_report)
@@ -1814,9 +1816,11 @@ static int s2g_enqueue_tiles(Run& r) {
     y.ctl = s->s2_ctl + (r.s2_launches & 1); y.expect_phase = QN_PH_REQ_HPASS; y.need_serviced = 1;
     y.nb = s->sym_nb; y.part = s->sym_part;
     y.nt = s->T.n_pad >= 8192; // past the Infinity Cache (same-box A/B, round 1: +7 % at n = 32768, +3 % at 8192, -1 % at 4096)
+    int grid = y.nb * (y.nb + 1) / 2;
+    if (c->world > 1) { y.sh = sym_shard(s); grid = qn_symsh_ntiles(y.nb, y.sh.nbl, y.sh.ioff); } // row-sharded: the rank's circulant windows
     {
         ProfScope ps(s, KC_HPASS);
-        hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
+        hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(grid), dim3(QN_SYM_TPB), 0, c->stream, y);
     }
     s->h_lower_stale = true;
     s->stats.launches++;
@@ -1897,7 +1901,11 @@ static int s2_launch(Run& r, int kind) {
         if (sh) hipLaunchKernelGGL((s2_advance_kernel<true, true, QN_S2_GEVAL_A>), dim3(1), dim3(128), 0, st, a);
         else hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_GEVAL_A>), dim3(1), dim3(128), 0, st, a);
         break;
-    case QN_S2_GHT_A: hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_GHT_A>), dim3(1), dim3(128), 0, st, a); break;
+    case QN_S2_GHT_A:
+        if (r.gobj) hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_GHT_A>), dim3(1), dim3(128), 0, st, a);
+        else if (sh) hipLaunchKernelGGL((s2_advance_kernel<true, false, QN_S2_GHT_A>), dim3(1), dim3(128), 0, st, a); // (measurement: QN_S2SH_GEN1_TILES)
+        else hipLaunchKernelGGL((s2_advance_kernel<false, false, QN_S2_GHT_A>), dim3(1), dim3(128), 0, st, a);
+        break;
     case QN_S2_GCOMB: {
         QnS2GArgs g = s2g_args(r);
         g.wgS = a.wgS + (size_t)a.parity * (size_t)a.trows * QN_S2_ROW; // the half this launch writes (the next prologue reads it)
@@ -1985,7 +1993,10 @@ static int s2_do_hpass(Run& r, bool tiles) {
         QNCHK(s2g_enqueue_tiles(r));
         return s2_launch(r, QN_S2_HREDUCE);
     }
-    if (tiles) QNCHK(s2_launch(r, QN_S2_HTILE));
+    if (tiles && r.tiles1) { // H past the Infinity Cache: the machine in a one-workgroup launch, then the first-generation tile kernel
+        QNCHK(s2_launch(r, QN_S2_GHT_A));
+        QNCHK(s2g_enqueue_tiles(r));
+    } else if (tiles) QNCHK(s2_launch(r, QN_S2_HTILE));
     if (r.s2.tred) return QN_OK; // (tail reduce: the tile launch has summed the slots itself)
     if (r.s2.sh_world > 1) {
         QNCHK(s2_launch(r, QN_S2_HSUM));
@@ -2915,11 +2926,28 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     // (the second-generation kernels keep no padding entries at zero; row-sharded: the SHARD instantiations, qn_sym2sh.hip.h)
     r.sym2 = r.sym && !s->no_sym2 && (size_t)s->T.n_pad == s->n && (c->world == 1 || c->world <= 64);
     h->sym2 = r.sym2 ? 1 : 0;
+    // WHICH KERNEL STREAMS THE UPDATE PASS OF A ROW-SHARDED RUN (round 5).  The one-workgroup-per-CU kernel of
+    // qn_sym2.hip.h (16-row register windows, the machine in its prologue) was built for n = 4096, where a launch is a twelfth of the
+    // iteration.  On one rank of the P = 8, n = 32768 partition -- 4112 tiles, 16 per workgroup, 1074 MB read and written back -- it takes
+    // 222 us (4.85 TB/s); the first-generation tile kernel (one workgroup per tile, two per CU, 8-row windows: nothing to balance, no
+    // prologue, no per-workgroup ramp) streams the same tiles in 166 us = 6.47 TB/s = 0.81 of the roofline, and the one-workgroup
+    // launch that then runs the machine in front of it costs 7.6 us: 459.6 -> 413.4 us of kernels per iteration on that rank
+    // (profiles/r05_l_*; one rank replayed alone with the other ranks' recorded data, the replay reproducing the recorded bits).
+    // On ONE GPU the choice does not matter past the cache -- the lists are long, the fixed parts amortised: n = 16384 404 -> 382 us per
+    // pass but 1249 -> 1241 it/s with the extra launch, n = 32768 1.575 -> 1.562 ms, 320 -> 324 it/s (profiles/r05_m_*) -- and inside the
+    // cache the second-generation kernel is the faster one.  So: a row-sharded run whose share of H's half is beyond 320 MB (the size
+    // from which both matrices are streamed non-temporally anyway) -> first-generation tiles; everything else -> the second-
+    // generation kernel.  QN_S2_GEN1_TILES=0 / 1 overrides (any rank count).
+    {
+        const size_t hhalf = c->world > 1 ? (size_t)s->T.rpr * s->T.n_pad * 8 / 2 : (size_t)s->T.n_pad * s->T.n_pad * 8 / 2;
+        r.tiles1 = r.sym2 && !r.gobj && c->world > 1 && hhalf > ((size_t)320 << 20);
+        if (r.sym2 && !r.gobj && getenv("QN_S2_GEN1_TILES")) r.tiles1 = atoi(getenv("QN_S2_GEN1_TILES")) != 0;
+    }
     h->serviced = 0; h->ev_par = 0; h->ev_kind = QN_REQ_X; h->ev_t = 0.0; h->spec_tiles = 0;
     h->defer_u = 0;
     h->no_defer = s->no_defer;
     if (!r.fused) QNCHK(fused_export(s)); // another path takes over: it works on the canonical buffers
-    if (!(r.sym || r.sym_generic) || (s->h_diag_stale && (!r.sym2 || (r.gobj && c->world == 1)))) QNCHK(ensure_full_h(s)); // ... and on whole rows of H (or whole diagonal tiles: the first-generation tile kernel, which the generic-objective path runs too, reads them whole)
+    if (!(r.sym || r.sym_generic) || (s->h_diag_stale && (!r.sym2 || (r.gobj && c->world == 1) || r.tiles1))) QNCHK(ensure_full_h(s)); // ... and on whole rows of H (or whole diagonal tiles: the first-generation tile kernel, which the generic-objective path runs too, reads them whole)
     if (r.fused) {
         QNCHK(solver_alloc_fused(s, r.sym));
         s->V.F.pworld = r.sym ? 1 : c->world; // symmetric storage: every rank forms all the per-block partial sums itself
@@ -2964,6 +2992,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.sh_nsum = c->use_allreduce ? 1 : c->world;
         a.evS = s->s2_evS; a.xg = s->symsh_xg; a.sl_off = s->s2_sl_off; a.sl_idx = s->s2_sl_idx;
         if (c->world > 1 || r.gobj) { a.fold = 0; a.pair = 0; }
+        if (r.tiles1) a.fold = 0;
         // tail reduce (s2_hpass_kernel<.., TRED>): the update-reduce in the tail of the update-tile launch, 4 launches per iteration
         // instead of 5 -- one rank, lists short enough for one wave to announce (n <= ~15 k).  BUILT, BIT-IDENTICAL, SLOWER, OFF BY
         // DEFAULT (QN_S2_TRED=1 / set_tiling(-13, 0) switch it on; the note in front of the kernel has the stamps): the update kernel
@@ -2971,7 +3000,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.cnt = s->s2_cnt;
         a.cnt_stride = getenv("QN_S2_CNT_STRIDE") ? std::max(1, std::min(QN_S2_CNT_STRIDE, atoi(getenv("QN_S2_CNT_STRIDE")))) : QN_S2_CNT_STRIDE; // (diagnostics)
         const bool want_tred = getenv("QN_S2_TRED") ? atoi(getenv("QN_S2_TRED")) != 0 : s->tred;
-        a.tred = (c->world == 1 && !a.fold && !r.gobj && s->s2_maxk <= QN_S2_TRED_MAXK && want_tred) ? 1 : 0;
+        a.tred = (c->world == 1 && !a.fold && !r.gobj && !r.tiles1 && s->s2_maxk <= QN_S2_TRED_MAXK && want_tred) ? 1 : 0;
         // WHO GETS THE INFINITY CACHE (256 MB).  Per iteration a rank streams its half of Q twice (read) and its half of H once
         // (read + written); non-temporal accesses pass the cache by.  Measured (round 4, bench.py same box, it/s for the policies
         // H plain / Q plain, H plain / Q non-temporal, H non-temporal / Q plain, both non-temporal):
@@ -3115,9 +3144,9 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     const uint64_t full_shard = shard;
     if (r.sym || r.sym_generic) shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb + 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull; // the streamed tiles
     if ((r.sym || r.sym_generic) && c->world > 1) shard = (uint64_t)qn_symsh_ntiles(s->sym_nb, s->T.rpr / QN_TB, c->rank * (s->T.rpr / QN_TB)) * (uint64_t)QN_TB * QN_TB * 8ull;
-    if (r.sym2 && !r.gobj) // diagonal tiles: wave w (rows 16 w ...) reads 64 - 8 w lanes of 16 bytes per row = 73 728 of the 131 072 bytes
+    if (r.sym2 && !r.gobj && !r.tiles1) // diagonal tiles: wave w (rows 16 w ...) reads 64 - 8 w lanes of 16 bytes per row = 73 728 of the 131 072 bytes
         shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb - 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull + (uint64_t)s->sym_nb * 73728ull;
-    if (r.sym2 && c->world > 1) { // this rank's windows: one diagonal tile per local block-row, the rest whole tiles
+    if (r.sym2 && c->world > 1 && !r.tiles1) { // this rank's windows: one diagonal tile per local block-row, the rest whole tiles
         const uint64_t nbl = (uint64_t)(s->T.rpr / QN_TB);
         const uint64_t nt = (uint64_t)qn_symsh_ntiles(s->sym_nb, (int)nbl, c->rank * (int)nbl);
         shard = (nt - nbl) * (uint64_t)QN_TB * QN_TB * 8ull + nbl * 73728ull;
@@ -3138,7 +3167,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     s->stats.total_xchg_vector += c->n_xchg_vector - xv0;
     s->stats.total_xchg_scalar += c->n_xchg_scalar - xs0;
     s->stats.path = (r.fused ? QN_PATH_FUSED : 0u) | (r.sym ? QN_PATH_SYM : 0u) | (r.sym_generic ? QN_PATH_SYM_GENERIC : 0u) |
-                    (sync ? 0u : QN_PATH_PIPELINED) | (r.sym2 ? QN_PATH_SYM2 : 0u);
+                    (sync ? 0u : QN_PATH_PIPELINED) | (r.sym2 ? QN_PATH_SYM2 : 0u) | ((r.tiles1 || (r.gobj && c->world == 1)) ? QN_PATH_TILES1 : 0u);
     if (c->host_async_failed) { c->host_async_failed = 0; return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed"); }
     if (status == QN_ABNORMAL_TERMINATION) return fail(status, "solver state machine aborted");
     return status;

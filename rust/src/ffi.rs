@@ -35,6 +35,7 @@ pub const QN_PATH_SYM: u32 = 2;
 pub const QN_PATH_SYM_GENERIC: u32 = 4;
 pub const QN_PATH_PIPELINED: u32 = 8;
 pub const QN_PATH_SYM2: u32 = 16;
+pub const QN_PATH_TILES1: u32 = 32;
 
 #[repr(C)] pub struct qn_context { _p: [u8; 0] }
 #[repr(C)] pub struct qn_solver { _p: [u8; 0] }
