@@ -60,3 +60,18 @@ for slot in range(64):
     late = np.argsort(end)[-8:]
     print(f"slot {slot:2d}: span {span} ns, start spread {start_spread}; " + ", ".join(parts)
           + "; workgroup ends p50 %d p90 %d max %d, last: %s" % (np.median(end), np.percentile(end, 90), end.max(), " ".join("%d@%d" % (g, end[g]) for g in late)))
+
+# which workgroups end late?  mean end (ns after the launch's first entry) by blockIdx.x % 8 -- the XCD under round-robin placement
+if os.environ.get("QN_STAMPS_BY_XCD"):
+    for name, sel in (("evaluation", lambda t: t[0, 15] != 0 and t[0, 0] != 0 and t[0, 3] != 0), ("update tiles", lambda t: t[0, 6] != 0 and t[0, 15] != 0 and t[0, 0] != 0 and t[0, 4] == 0)):
+        acc = np.zeros(8); cnt = 0
+        for slot in range(64):
+            t = st[slot]
+            if not sel(t):
+                continue
+            end = (t[:, 15] - t[:, 0].min()) * 10.0
+            acc += np.array([end[x::8].mean() for x in range(8)]); cnt += 1
+        if cnt:
+            m = acc / cnt
+            print("%s: mean workgroup end by blockIdx %% 8 over %d launches: %s  (spread %.0f ns)" % (name, cnt, " ".join("%.0f" % v for v in m), m.max() - m.min()))
+
