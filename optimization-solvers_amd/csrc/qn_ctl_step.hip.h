@@ -42,8 +42,7 @@ __device__ __forceinline__ void qn_keepalive(double v) { asm volatile("" ::"v"(v
 // ------------------------------------------------------------------------------------------------
 // scalar states (thread 0 only).  Runs until the machine yields or reaches a state that needs all threads.
 // ------------------------------------------------------------------------------------------------
-template <class C>
-__device__ __forceinline__ bool qn_check_is_scalar(const C& c) {
+__device__ __forceinline__ bool qn_check_is_scalar(const QnCtl& c) {
     return c.method != 2 && (c.small_n || c.gg_valid || c.method == 3);
 }
 
@@ -61,8 +60,8 @@ __device__ __forceinline__ bool qn_check_is_scalar(const C& c) {
 // gradient descent, bounded solvers / line searches, callbacks and qn_compute_step_len (minimize_impl: `r.fused`): the branches for
 // those are compiled out.  Same decisions on that path by construction; about half the code -- and the machine is inlined into
 // every kernel of an iteration, where code size is instruction-fetch time behind the kernel's data burst.
-template <bool LEAN, class C>
-__device__ __forceinline__ void qn_st_begin(C& c) { // ls_solver.rs:74-76: only k is reset
+template <bool LEAN>
+__device__ __forceinline__ void qn_st_begin(QnCtl& c) { // ls_solver.rs:74-76: only k is reset
     c.k = 0;
     // A fresh call evaluates the oracle at x_k and forms d = -H g from scratch (ls_solver.rs:79, bfgs.rs:47).  When it
     // continues the previous call -- same immutable device objective, memoised oracle, state untouched -- both are already
@@ -74,8 +73,8 @@ __device__ __forceinline__ void qn_st_begin(C& c) { // ls_solver.rs:74-76: only 
     c.state = QN_ST_LOOP_TOP;
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ void qn_st_loop_top(C& c) { // ls_solver.rs:78-79
+template <bool LEAN>
+__device__ __forceinline__ void qn_st_loop_top(QnCtl& c) { // ls_solver.rs:78-79
     if (!(c.max_iter > c.k)) {
         c.status = 1; // MaxIterReached, ls_solver.rs:109-110
         c.phase = QN_PH_DONE;
@@ -94,8 +93,8 @@ __device__ __forceinline__ void qn_st_loop_top(C& c) { // ls_solver.rs:78-79
     }
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ bool qn_st_after_evalx(C& c) {
+template <bool LEAN>
+__device__ __forceinline__ bool qn_st_after_evalx(QnCtl& c) {
     if (!LEAN && !c.fused) return false;
     c.f_k = c.f_e; // g <- gt is committed by the direction pass (h_pass row-block 0)
     c.gg = c.st_gg; c.gg_valid = 1;
@@ -105,8 +104,8 @@ __device__ __forceinline__ bool qn_st_after_evalx(C& c) {
     return true;
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ bool qn_st_after_dir(C& c) {
+template <bool LEAN>
+__device__ __forceinline__ bool qn_st_after_dir(QnCtl& c) {
     if (!LEAN && !c.fused) return false;
     c.n_hpasses++;
     if (c.pending) c.n_hpass_rw++;
@@ -117,8 +116,8 @@ __device__ __forceinline__ bool qn_st_after_dir(C& c) {
     return true;
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ bool qn_st_after_next(C& c) { // bfgs.rs:94-102 from the sums staged by the accepted evaluation
+template <bool LEAN>
+__device__ __forceinline__ bool qn_st_after_next(QnCtl& c) { // bfgs.rs:94-102 from the sums staged by the accepted evaluation
     if (!LEAN && !c.fused) return false;
     c.s_norm = sqrt(c.st_ss); c.has_s_norm = 1;
     c.y_norm = sqrt(c.st_yy); c.has_y_norm = 1;
@@ -152,8 +151,8 @@ __device__ __forceinline__ bool qn_st_after_next(C& c) { // bfgs.rs:94-102 from 
     return true;
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ bool qn_st_after_u(C& c) { // coefficients of bfgs.rs:115-124 / dfp.rs:115-120 in rank-2 form
+template <bool LEAN>
+__device__ __forceinline__ bool qn_st_after_u(QnCtl& c) { // coefficients of bfgs.rs:115-124 / dfp.rs:115-120 in rank-2 form
     if (!LEAN && !c.fused) return false;
     const double yu = c.hp_yu;
     double c_ss, c_su, c_uu;
@@ -171,12 +170,12 @@ __device__ __forceinline__ bool qn_st_after_u(C& c) { // coefficients of bfgs.rs
     return true;
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ bool qn_st_check(C& c, const QnVecs& V, double* small_scratch) { // ls_solver.rs:37-40 (OutOfDomain), has_converged (bfgs.rs:64-76)
+template <bool LEAN>
+__device__ __forceinline__ bool qn_st_check(QnCtl& c, const QnVecs& V, double* small_scratch) { // ls_solver.rs:37-40 (OutOfDomain), has_converged (bfgs.rs:64-76)
     const int n = V.n, n_pad = V.n_pad;
     if (!LEAN && !qn_check_is_scalar(c)) return false; // gradient descent / unknown ||g||: all threads needed
     if (!LEAN && c.method == 3) { // Newton: has_converged is the decrement test (newton/mod.rs:64-69)
-        c.gnorm = c.gg_valid ? sqrt((double)c.gg) : (double)NAN; c.tr_f = c.f_k; c.tr_gnorm = c.gnorm;
+        c.gnorm = c.gg_valid ? sqrt(c.gg) : NAN; c.tr_f = c.f_k; c.tr_gnorm = c.gnorm;
         const double f = c.f_k;
         if (isnan(f) || isinf(f)) { c.status = 2; c.phase = QN_PH_DONE; }
         else if (c.has_dec && c.dec * 0.5 < c.tol) { c.status = 0; c.phase = QN_PH_DONE; }
@@ -223,8 +222,8 @@ __device__ __forceinline__ bool qn_st_check(C& c, const QnVecs& V, double* small
     return true;
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ void qn_st_ls_begin(C& c) {
+template <bool LEAN>
+__device__ __forceinline__ void qn_st_ls_begin(QnCtl& c) {
     c.ls_i = 0;
     if (!LEAN && c.ls_kind == 2) c.mt_tmax = fmin(c.mt_tmax, c.mtb_cand); // morethuente_b.rs:201: self.t_max = self.t_max.min(candidate) -- persists
     if (c.ls_kind == 0 || (!LEAN && c.ls_kind == 2)) { // morethuente.rs:173-178
@@ -238,14 +237,14 @@ __device__ __forceinline__ void qn_st_ls_begin(C& c) {
     }
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ void qn_st_mt_loop(C& c) { // morethuente.rs:181-182
+template <bool LEAN>
+__device__ __forceinline__ void qn_st_mt_loop(QnCtl& c) { // morethuente.rs:181-182
     if (!(c.ls_i < c.max_iter_ls)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :295-296
     else { c.tr_ls_iters++; req_eval_t<LEAN>(c, c.t, QN_ST_MT_AFTER_T, 0); }
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ void qn_st_mt_after_t(C& c) { // morethuente.rs:184-217
+template <bool LEAN>
+__device__ __forceinline__ void qn_st_mt_after_t(QnCtl& c) { // morethuente.rs:184-217
     const double f_et = c.f_e, gd_t = c.gd_e, t = c.t;
     const bool wolfe = (f_et - c.f_k <= c.mt_c1 * t * c.gd0) && (fabs(gd_t) <= c.mt_c2 * fabs(c.gd0));
     if (wolfe || c.conv || t == c.tl || t == c.tu) {
@@ -260,8 +259,8 @@ __device__ __forceinline__ void qn_st_mt_after_t(C& c) { // morethuente.rs:184-2
     }
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ void qn_st_mt_after_tl(C& c) { // morethuente.rs:218-287
+template <bool LEAN>
+__device__ __forceinline__ void qn_st_mt_after_tl(QnCtl& c) { // morethuente.rs:218-287
     const double phi_tl_f = c.f_e, phi_tl_g = c.gd_e;
     double f_tl, g_tl, f_t, g_t;
     if (c.use_mod) { f_tl = phi_tl_f; g_tl = phi_tl_g; f_t = c.phi_t_f; g_t = c.phi_t_g; }
@@ -297,8 +296,8 @@ __device__ __forceinline__ void qn_st_mt_after_tl(C& c) { // morethuente.rs:218-
     }
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ void qn_st_mt_after_tu(C& c) {
+template <bool LEAN>
+__device__ __forceinline__ void qn_st_mt_after_tu(QnCtl& c) {
     double f_tu, g_tu;
     if (c.use_mod) { f_tu = c.f_e; g_tu = c.gd_e; }
     else { f_tu = c.f_e - c.f_k - c.mt_c1 * c.tu * c.gd0; g_tu = c.gd_e - c.mt_c1 * c.gd0; }
@@ -307,8 +306,8 @@ __device__ __forceinline__ void qn_st_mt_after_tu(C& c) {
     c.state = QN_ST_MT_FINISH;
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ void qn_st_mt_finish(C& c) { // morethuente.rs:290-293: the NEW t with the OLD trial's f_t, g_t
+template <bool LEAN>
+__device__ __forceinline__ void qn_st_mt_finish(QnCtl& c) { // morethuente.rs:290-293: the NEW t with the OLD trial's f_t, g_t
     c.t = fmin(fmax(c.t, c.mt_tmin), c.mt_tmax);
     double tl = c.tl, tu = c.tu;
     c.conv = mt_update_interval(c.sel_f_tl, c.sel_f_t, c.sel_g_t, tl, c.t, tu);
@@ -317,14 +316,14 @@ __device__ __forceinline__ void qn_st_mt_finish(C& c) { // morethuente.rs:290-29
     c.state = QN_ST_MT_LOOP;
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ void qn_st_bt_loop(C& c) { // backtracking.rs:31-34
+template <bool LEAN>
+__device__ __forceinline__ void qn_st_bt_loop(QnCtl& c) { // backtracking.rs:31-34
     if (!(c.max_iter_ls > c.ls_i)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :54
     else { c.tr_ls_iters++; req_eval_t<LEAN>(c, c.t, QN_ST_BT_AFTER, 0, (!LEAN && c.ls_kind == 3) ? 1 : 0); }
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ void qn_st_bt_after(C& c) { // backtracking.rs:37-51
+template <bool LEAN>
+__device__ __forceinline__ void qn_st_bt_after(QnCtl& c) { // backtracking.rs:37-51
     const double f1 = c.f_e;
     if (isnan(f1) || isinf(f1)) { c.t *= c.bt_beta; c.state = QN_ST_BT_LOOP; } // shrink, iteration not counted
     else if ((!LEAN && c.ls_kind == 3) ? (f1 - c.f_k <= (-c.bt_c1 / c.t) * c.bt_diff2) // backtracking_b.rs:24-34
@@ -332,23 +331,23 @@ __device__ __forceinline__ void qn_st_bt_after(C& c) { // backtracking.rs:37-51
     else { c.t *= c.bt_beta; c.ls_i++; c.state = QN_ST_BT_LOOP; }
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ bool qn_st_after_ls(C& c) {
+template <bool LEAN>
+__device__ __forceinline__ bool qn_st_after_ls(QnCtl& c) {
     if (!LEAN && c.ls_only) { c.status = 0; c.phase = QN_PH_DONE; return true; } // compute_step_len returns the step, nothing else
     if (!LEAN && (c.method == 2 || c.method == 3)) return false; // gradient descent / Newton: the default hook x += step*d needs all threads
     req_eval_t<LEAN>(c, c.ls_result, QN_ST_AFTER_NEXT, 1); // bfgs.rs:94,98: oracle(x + step*d)
     return true;
 }
 
-template <bool LEAN, class C>
-__device__ __forceinline__ bool qn_st_iter_end(C& c, const QnVecs& V, const bool side_effects) { // ls_solver.rs:104-107
+template <bool LEAN>
+__device__ __forceinline__ bool qn_st_iter_end(QnCtl& c, const QnVecs& V, const bool side_effects) { // ls_solver.rs:104-107
     const bool rec = c.k < c.trace_cap;
     if (rec && c.trace_x && !c.xtrace_done) return false; // the iterate has to be copied by all threads first
     if (rec) {
         QnTraceRec r;
         r.f = c.tr_f; r.gnorm = c.tr_gnorm; r.t = c.ls_result;
-        r.s_norm = c.has_s_norm ? (double)c.s_norm : (double)NAN;
-        r.y_norm = c.has_y_norm ? (double)c.y_norm : (double)NAN;
+        r.s_norm = c.has_s_norm ? c.s_norm : NAN;
+        r.y_norm = c.has_y_norm ? c.y_norm : NAN;
         r.n_evals = c.tr_n_evals; r.ls_iters = c.tr_ls_iters; r.ls_cases = c.tr_ls_cases; r.updated = c.tr_updated;
         if (side_effects) V.trace[c.k] = r;
     }
@@ -368,8 +367,8 @@ __device__ __forceinline__ bool qn_st_iter_end(C& c, const QnVecs& V, const bool
     if (!(c.phase == QN_PH_RUNNING && c.state == (ST))) break;          \
     if (!(CALL)) return;
 
-template <bool LEAN = false, class C>
-__device__ __forceinline__ void ctl_scalar_run(C& c, const QnVecs& V, double* small_scratch, const bool side_effects = true) {
+template <bool LEAN = false>
+__device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double* small_scratch, const bool side_effects = true) {
     for (int guard = 0; guard < (1 << 22); ++guard) {
         if (c.phase != QN_PH_RUNNING) return;
         switch (c.state) {

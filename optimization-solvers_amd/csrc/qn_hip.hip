@@ -1108,14 +1108,12 @@ static int solver_alloc_sym2(qn_solver* s) {
         s->s2_maxk = (int)maxk;
         s->s2_inorder = inorder;
         s->s2_trows = std::max(QN_S2_MAXG, (nb + 63) / 64 * 64);
-        QNCHK(dev_alloc_zero(&s->s2_wgS, (size_t)2 * s->s2_trows * QN_S2_ROW, st));
+        QNCHK(dev_alloc_zero(&s->s2_wgS, (size_t)4 * s->s2_trows * QN_S2_ROW, st)); // (two tables of two halves: the second one is the generic objectives')
         QNCHK(dev_alloc_zero(&s->s2_partE, (size_t)nb * nb * QN_TB, st));
-        HIPCHK(hipMalloc((void**)&s->s2_cnt, (size_t)nb * QN_S2_CNT_STRIDE * sizeof(int)));
-        HIPCHK(hipMemsetAsync(s->s2_cnt, 0, (size_t)nb * QN_S2_CNT_STRIDE * sizeof(int), st));
         if (sharded) {
             QNCHK(dev_alloc_zero(&s->s2_evS, (size_t)2 * world * QN_S2SH_NEC * QN_S2_MAXG, st));
         }
-        if (!s->s2_gws) QNCHK(dev_alloc_zero(&s->s2_gws, 80, st)); // (row-sharded log-sum-exp: the ranks' weights and S, world <= 64)
+
         s->s2_G = G;
         s->s2_nb = nb;
     }
@@ -2977,6 +2975,8 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.wgS = s->s2_wgS; a.trows = s->s2_trows; a.ctl2 = s->s2_ctl; a.partE = s->s2_partE;
         a.gw = r.gobj ? s->T.n_pad / 64 : 0;
         a.gmu = r.gobj ? r.obj->mu : 0.0;
+        // (allocated only for the runs that use them: the tail reduce's counters, the sharded log-sum-exp path's weights)
+        if (r.gobj && c->world > 1 && !s->s2_gws) QNCHK(dev_alloc_zero(&s->s2_gws, 80, c->stream)); // the ranks' weights and S, world <= 64
         a.gws = s->s2_gws;
         if (r.gobj && a.gw > s->s2_trows) return fail(QN_ABNORMAL_TERMINATION, "sym2 (generic objective): more combine workgroups than table rows");
         // folded accept-reduce (s2_hpass_kernel): every workgroup holds at most three items, so the blocks whose slots it sums fit
@@ -3000,6 +3000,11 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.cnt = s->s2_cnt;
         a.cnt_stride = getenv("QN_S2_CNT_STRIDE") ? std::max(1, std::min(QN_S2_CNT_STRIDE, atoi(getenv("QN_S2_CNT_STRIDE")))) : QN_S2_CNT_STRIDE; // (diagnostics)
         const bool want_tred = getenv("QN_S2_TRED") ? atoi(getenv("QN_S2_TRED")) != 0 : s->tred;
+        if (want_tred && !s->s2_cnt) {
+            HIPCHK(hipMalloc((void**)&s->s2_cnt, (size_t)a.nb * QN_S2_CNT_STRIDE * sizeof(int)));
+            HIPCHK(hipMemsetAsync(s->s2_cnt, 0, (size_t)a.nb * QN_S2_CNT_STRIDE * sizeof(int), c->stream));
+        }
+        a.cnt = s->s2_cnt;
         a.tred = (c->world == 1 && !a.fold && !r.gobj && !r.tiles1 && s->s2_maxk <= QN_S2_TRED_MAXK && want_tred) ? 1 : 0;
         // WHO GETS THE INFINITY CACHE (256 MB).  Per iteration a rank streams its half of Q twice (read) and its half of H once
         // (read + written); non-temporal accesses pass the cache by.  Measured (round 4, bench.py same box, it/s for the policies

@@ -532,22 +532,19 @@ __device__ __forceinline__ double mt_quad2(double ta, double tb, double g_ta, do
     return ta - g_ta * ((ta - tb) / (g_ta - g_tb));
 }
 
-// (C: the control block -- QnCtl in LDS, or its register view QnCtlLanes, qn_ctl_lanes.h: the state machine is templated on it)
-template <class C>
-__device__ __forceinline__ void tr_push_case(C& c, int digit) {
-    const int32_t nd = c.tr_ndigits;
-    if (nd < 10) {
+__device__ __forceinline__ void tr_push_case(QnCtl& c, int digit) {
+    if (c.tr_ndigits < 10) {
         int32_t mul = 1;
-        for (int i = 0; i < nd; ++i) mul *= 8;
+        for (int i = 0; i < c.tr_ndigits; ++i) mul *= 8;
         c.tr_ls_cases += mul * digit;
     }
-    c.tr_ndigits = nd + 1;
+    c.tr_ndigits++;
 }
 
 // One oracle call of the reference's sequence at x + t d.  With memoisation a call whose point was already
 // evaluated is answered from the memo (the values are identical; see include/qn_hip.h qn_oracle.memoize).
-template <bool LEAN = false, class C>
-__device__ __forceinline__ void req_eval_t(C& c, double t, int after_state, int need_vectors, int project = 0) {
+template <bool LEAN = false>
+__device__ __forceinline__ void req_eval_t(QnCtl& c, double t, int after_state, int need_vectors, int project = 0) {
     c.n_oracle_calls++;
     c.tr_n_evals++;
     if (LEAN || (c.memoize && !project && !c.last_projected)) {
@@ -908,7 +905,6 @@ __global__ __launch_bounds__(256) void lse_finish1_kernel(const QnLseArgs a, con
 #include "qn_sym.hip.h"
 #include "qn_newton.hip.h"
 #include "qn_lu.hip.h"
-#include "qn_ctl_lanes.h"
 #include "qn_ctl_step.hip.h"
 #include "qn_sym2.hip.h"
 #include "qn_sym2sh.hip.h"

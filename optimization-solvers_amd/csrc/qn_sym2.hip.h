@@ -46,9 +46,9 @@
 #define QN_S2_MAXG 256 // workgroups of a tile launch: one 8-wave workgroup per CU (see the note on registers below)
 #define QN_S2_NSE 6    // evaluation scalars per workgroup: xt'Q xt, b'xt, d'Q xt, b'd, g'd, #non-finite d
 #define QN_S2_NR 5     // accept-reduce partials per block-row: y'y, y's, g+'g+, s's, s'g+
-#define QN_S2_ROW 16   // columns of the table of per-workgroup sums (QnS2Args.wgS): 0..5 what an evaluation / 0..4 an accept-reduce / 0..1 an
-                       // update-reduce leaves; 8..12 (QN_S2_VCOL): the accepted-point sums a generic objective's combine launch stages with every evaluation
-#define QN_S2_VCOL 8
+#define QN_S2_ROW 8    // doubles per partial row in memory (64 B: loaded as 16-byte pieces)
+                       // (generic objectives, qn_sym2g.hip.h: the accepted-point sums a combine launch stages with every evaluation live in a
+                       // SECOND table of the same shape behind the first -- wgS + 2 trows QN_S2_ROW -- so that this one keeps its layout)
 #define QN_S2SH_NEC 4  // row-sharded runs: the evaluation scalars that are exchanged, per workgroup: x'(Q xt - 2 b), d'(Q xt - b), g'd,
                        // #non-finite d (the table's b'xt and b'd columns are zero by construction: see CONDITIONING below)
 #define QN_S2SH_EB 4   // ... and the slices of them a prologue requests at a time
@@ -78,7 +78,6 @@ struct QnS2Args {
     int tred;            // TAIL REDUCE (round 5): the update-reduce runs in the tail of the update-tile launch -- the workgroup whose slot
                          // completes block-row R sums R's slots (s2_hpass_kernel<.., TRED>); no s2_hreduce launch follows
     int* cnt;            // [nb][cnt_stride] arrival counters of the block-rows (zero between launches: the last arriver resets its counter)
-    int cnt_stride;
     int sl_first, sl_per; // ROW SLIVERS (sl_per != 0): the diagonal tiles sl_first .. nb - 1 are not on any work list; each is cut
                          // into sl_per slivers of 8 rows, one per workgroup (workgroup g: tile sl_first + g / sl_per, sliver g % sl_per,
                          // wave w its row 8 (g % sl_per) + w), taken after the workgroup's last item -- see qn_s2_eval_sliver
@@ -89,10 +88,6 @@ struct QnS2Args {
                          // Column-major: every CU reads the whole table at kernel entry, all at once; as 64-byte rows that was
                          // 768 line requests per CU on the same 16 KB (a chip-wide hot spot: 2 us), as columns it is 96.
     int trows;           // rows per half: max(256, nb rounded up to 64)
-    int gw;              // generic objectives (qn_sym2g.hip.h): rows of the table an evaluation's combine launch leaves (its workgroups: n / 64)
-    double gmu;          // ... log-sum-exp: mu (row-sharded runs: the prologue puts the ranks' (m, S, G'd) together itself)
-    double* gws;         // ... [sh_world + 1]: the ranks' weights w_r = exp(m_r - M) and S of the LAST evaluation the machine consumed (written
-                         //     by that prologue, read by s2g_vec_kernel when the point is accepted)
     QnCtl* ctl2;         // [2]
     QnTraceRec* trace;
     double* xtrace;
@@ -113,6 +108,12 @@ struct QnS2Args {
     double* xg;            // [sh_world][2][np]: the ranks' partial n-vectors (q of the accepted evaluation; [u, v] of the update pass)
     const int* sl_off;     // [nb + 1] the slots of block-row R that THIS rank's tiles write are sl_idx[sl_off[R] .. sl_off[R + 1]), ascending
     const int* sl_idx;
+    // ---- round 5 additions (kept behind everything the benchmark path's kernels read: the struct is the kernel argument) ----
+    int cnt_stride;      // tail reduce: ints between two block-rows' arrival counters
+    int gw;              // generic objectives (qn_sym2g.hip.h): rows of the table an evaluation's combine launch leaves (its workgroups: n / 64)
+    double gmu;          // ... log-sum-exp: mu (row-sharded runs: the prologue puts the ranks' (m, S, G'd) together itself)
+    double* gws;         // ... [sh_world + 1]: the ranks' weights w_r = exp(m_r - M) and S of the LAST evaluation the machine consumed (written
+                         //     by that prologue, read by s2g_vec_kernel when the point is accepted)
 #ifdef QN_S2_STAMPS
     unsigned long long* dbg; // diagnostic build: dbg[((slot % 64) * 256 + workgroup) * 16 + k] = wall clock (10 ns) at stamp k
     int slot;
@@ -138,8 +139,7 @@ struct QnS2Lds {
 // (Measured again and dropped, round 3: the machine as ONE out-of-line function, now called from wave 0's prologue where no tile
 // window is live -- one copy of its code for the five kernels instead of five.  The call frame lives in scratch memory (400 bytes
 // per lane) and the machine then takes 8.4 us instead of 4-5: 11.0 k it/s against 12.3 k inlined, same box.)
-template <class C> // (C: QnCtl in LDS, or its register view QnCtlLanes)
-__device__ __forceinline__ void qn_s2_advance(C& c, const double* tot, const QnVecs& V, const bool leader, double* scratch, const bool resume) {
+__device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const QnVecs& V, const bool leader, double* scratch, const bool resume) {
     const int ph = c.phase;
     bool run = resume; // (resume: the machine had stopped for the x-trace copy)
     if (!resume) {
@@ -222,6 +222,18 @@ __device__ __forceinline__ double qn_lane_bcast(const double v, const int l) {
 // (Measured and dropped, same-box A/B: waves 1..7 sleeping 1-2 us before their 112 KB burst so that wave 0's control block and
 // table come back from an idle memory system -- 12.2 k it/s without, 11.3-11.9 k with: the burst itself is on the critical path.)
 
+// Measured and dropped, round 5 (tools/experiments/r05_machine_on_lane_registers.patch rebuilds it): THE MACHINE ON REGISTERS.  The
+// block is in registers when it arrives, spread over the wave -- word W in lane W & 63 of (cw0, cw1); a view of exactly that
+// (QnCtlLanes, generated from qn_ctl.h: a field read = two v_readlane, a write = two v_writelane) and the state machine templated
+// on the control type, run on all 64 lanes alike, the block back to LDS once at the end.  The same bits in every run
+// (tools/trace_cmp.py), no scratch, 50 vector registers fewer -- and SLOWER: the accept-reduce 6.4 -> 7.6 us, the update-reduce
+// 5.1 -> 5.45, 66.3 -> 68.0 us per iteration (profiles/r05_j_*), with 10 KB more code per kernel.  tools/icache_probe.hip says what
+// the machine's time is: one wave issues an instruction every ~5 cycles, cold or warm, right behind itself or behind another kernel --
+// neither instruction fetch nor LDS latency: ~700 instructions on the machine's path are its 2 us, and two readlanes and a move per
+// field are more instructions than one ds_read.  Fewer instructions on the path (the LEAN instantiation) is what makes it faster.
+// (The experiment lives in a patch, not behind a switch: the launches of 32 workgroups are sensitive to where their code lies -- round 5's
+// new kernels grew the code object from 2.25 to 2.54 MB and the accept-reduce went 6.45 -> 7.1 us with an IDENTICAL instruction stream,
+// profiles/r05_o_* -- so nothing that is not used stays in the tree.)
 struct QnS2NoEarly { __device__ __forceinline__ void operator()() const {} };
 // `early`: requests the caller wants in flight while the machine runs (issued right behind the control block and the table, so
 // that those two still come back first: a wave's loads return in order)
@@ -265,7 +277,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
 #pragma unroll
         for (int k = 0; k < QN_S2_NR; ++k)
 #pragma unroll
-            for (int j = 0; j < QN_S2_PCH; ++j) tv[j][k] = T[(size_t)(QN_S2_VCOL + k) * a.trows + j * 64 + lane];
+            for (int j = 0; j < QN_S2_PCH; ++j) tv[j][k] = T[(size_t)(2 * QN_S2_ROW + k) * a.trows + j * 64 + lane]; // (the second table's same half)
     }
     // SHARD: the evaluation scalars of the first QN_S2SH_EB ranks go out now as well (every entry of evS is valid at all times --
     // rows past the grid stay zero -- so nothing about them depends on the control block; lane l takes rows 2 l, 2 l + 1 and
@@ -287,37 +299,14 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     if (64 + lane < NW) lc[64 + lane] = cw1;
     __builtin_amdgcn_wave_barrier(); // (one wave: its LDS accesses execute in program order; this only pins the compiler's order)
     QN_S2_STAMP(9);
-    // THE MACHINE ON REGISTERS (round 5): built, bit-identical, SLOWER, compiled out by default (-DQN_S2_CTL_LANES=1 builds it).  Rounds 2-4
-    // run the machine on the copy in LDS, one lane's dependent chain, and in-kernel stamps show 2.0 us between the sums and the
-    // machine's end in the two small kernels and the update tiles alike -- which looked like a few dozen ~100-cycle LDS round trips.
-    // A private register copy does not fit (~150 words: 255 spills, rounds 3-4), but the block IS in registers when it arrives,
-    // spread over the wave: word W in lane W & 63 of (cw0, cw1).  QnCtlLanes (qn_ctl_lanes.h, generated from qn_ctl.h) is a view of
-    // exactly that -- a field read is two v_readlane, a write two v_writelane -- and the machine, templated on the control type, runs
-    // on all 64 lanes alike (every value the same in every lane, every branch uniform); the block goes back to LDS once, at the end.
-    // Measured (tools/trace_cmp.py: the same bits in every run; tools/prof_ab.sh, alternating runs on one box, profiles/r05_j_*):
-    // the accept-reduce 6.42 -> 7.6 us, the update-reduce 5.1 -> 5.45, the evaluation +0.1, the update tiles +-0: 66.3 -> 68.0 us per
-    // iteration.  No scratch, FEWER vector registers (222 -> 171 in the evaluation kernel) -- and 10 KB MORE CODE per kernel (26 -> 36
-    // KB in the accept-reduce).  The machine is ONE wave's instruction stream, and one wave issues an instruction every ~5 cycles --
-    // tools/icache_probe.hip: 3072 eight-byte instructions of straight-line code take 15 380 cycles, the same right behind itself,
-    // behind another kernel of the same size or behind a 64 MB fill (so it is not instruction FETCH either: cold or warm alike).  2 us
-    // are ~700 instructions on the machine's path at that rate; the LDS latencies hide under them, and two readlanes and a move per
-    // field are simply more instructions than one ds_read.  What makes the machine faster is fewer instructions on its path (the
-    // LEAN instantiation of round 3), not where its block lives.
-#ifndef QN_S2_CTL_LANES
-#define QN_S2_CTL_LANES 0
-#endif
-    constexpr bool kLanes = QN_S2_CTL_LANES != 0;
-    QnLaneRegs creg{{(int)(unsigned)cw0, (int)(unsigned)(cw0 >> 32), (int)(unsigned)cw1, (int)(unsigned)(cw1 >> 32)}};
-    QnCtlLanes clanes(creg);
-    auto& c = [&]() -> auto& { if constexpr (kLanes) return clanes; else return L.c; }();
-    const bool every = kLanes; // (the deciding code below runs on lane 0 of the LDS copy, or on every lane of the register view)
+    QnCtl& c = L.c; // (in LDS: a private register copy of all ~150 words does not fit beside the machine's own temporaries -- 255 spills)
     int mine = 0;
     if (no_decision) { // pass the control block on (with the folded accept-reduce this prologue is where the machine sees the accepted point)
         constexpr int want_ph = (KIND == QN_S2_VEC) ? QN_PH_REQ_VEC : (KIND == QN_S2_GCOMB ? QN_PH_REQ_EVAL : QN_PH_REQ_HPASS);
         constexpr int from = (SHARD && KIND == QN_S2_HREDUCE) ? 3 : 1; // (sharded update pass: tiles 0 -> 1, partial sums 1 -> 3, reduce 3 -> 2)
         constexpr int to = (KIND == QN_S2_HSUM) ? 3 : 2;
-        mine = L.c.phase == want_ph && L.c.serviced == from;
-        if (lane == 0) { if (mine) L.c.serviced = to; L.mine = mine; }
+        mine = c.phase == want_ph && c.serviced == from;
+        if (lane == 0) { if (mine) c.serviced = to; L.mine = mine; }
         __builtin_amdgcn_s_setprio(0);
         return;
     }
@@ -428,7 +417,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     if constexpr (!GOBJ) {
         for (int guard = 0; guard < 64; ++guard) { // (the n <= 5 reference-order code of the machine is never reached on this path: no scratch)
             int need_x = 0;
-            if (every || lane == 0) {
+            if (lane == 0) {
                 qn_s2_advance(c, tot, V, leader, &L.red[0][0], guard > 0);
                 need_x = c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END;
             }
@@ -436,20 +425,18 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
             if (!need_x) break;
             // the machine stopped because the iterate has to be recorded (trace with x): workgroup 0 copies it, all go on
             __builtin_amdgcn_wave_barrier();
-            const long long kx = __builtin_amdgcn_readfirstlane((int)c.k);
-            const int xcx = __builtin_amdgcn_readfirstlane((int)c.xc);
             if (leader) {
-                double* row = a.xtrace + (size_t)kx * (size_t)a.n;
-                const double* xs = a.F.X0 + (size_t)xcx * (size_t)a.np;
+                double* row = a.xtrace + (size_t)L.c.k * (size_t)a.n;
+                const double* xs = a.F.X0 + (size_t)L.c.xc * (size_t)a.np;
                 for (int i = lane; i < a.n; i += 64) row[i] = xs[i];
             }
-            if (every || lane == 0) c.xtrace_done = 1;
+            if (lane == 0) c.xtrace_done = 1;
         }
     } else {
         bool resume = false, use_v = false; // (uniform)
         for (int guard = 0; guard < 64; ++guard) {
             int need_x = 0;
-            if (every || lane == 0) {
+            if (lane == 0) {
                 qn_s2_advance(c, use_v ? totv : tot, V, leader, &L.red[0][0], resume);
                 need_x = c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END;
                 if (!SHARD && !need_x && c.phase == QN_PH_REQ_VEC && c.serviced == 0) { c.serviced = 2; need_x = 2; } // the vectors are staged: go on
@@ -460,18 +447,16 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
             if (need_x == 2) { use_v = true; resume = false; continue; }
             resume = true;
             __builtin_amdgcn_wave_barrier();
-            const long long kx = __builtin_amdgcn_readfirstlane((int)c.k);
-            const int xcx = __builtin_amdgcn_readfirstlane((int)c.xc);
             if (leader) {
-                double* row = a.xtrace + (size_t)kx * (size_t)a.n;
-                const double* xs = a.F.X0 + (size_t)xcx * (size_t)a.np;
+                double* row = a.xtrace + (size_t)L.c.k * (size_t)a.n;
+                const double* xs = a.F.X0 + (size_t)L.c.xc * (size_t)a.np;
                 for (int i = lane; i < a.n; i += 64) row[i] = xs[i];
             }
-            if (every || lane == 0) c.xtrace_done = 1;
+            if (lane == 0) c.xtrace_done = 1;
         }
     }
     QN_S2_STAMP(11);
-    if (every || lane == 0) {
+    if (lane == 0) {
         if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == 0;
         if (KIND == QN_S2_VEC || KIND == QN_S2_VSUM) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
         if (KIND == QN_S2_HTILE) { // 2: the accepted point's slots -> vectors AND the update tiles (folded accept-reduce); 1: the tiles of a pending pass
@@ -488,11 +473,6 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
             else c.serviced = 2;
         }
         L.mine = mine;
-    }
-    if constexpr (kLanes) { // the block as the machine left it -> LDS: the workgroup's other waves and qn_s2_ctl_out read it there
-        if (lane < NW) lc[lane] = ((uint64_t)(unsigned)creg.w[1] << 32) | (unsigned)creg.w[0];
-        if (64 + lane < NW) lc[64 + lane] = ((uint64_t)(unsigned)creg.w[3] << 32) | (unsigned)creg.w[2];
-        __builtin_amdgcn_wave_barrier();
     }
     __builtin_amdgcn_s_setprio(0);
 }

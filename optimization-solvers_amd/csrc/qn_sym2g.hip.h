@@ -19,7 +19,7 @@
 // s2g_combine folds the workgroups' (m, S, G) -- and, because it then holds g(x + t d) entry by entry, does at once what the
 // line search AND an acceptance need: g+'d for the Wolfe test, and -- staged, in case the machine accepts this point -- g+, y = g+ - g,
 // x+ = x + t d, s = x+ - x and the five sums of bfgs.rs:94-102 / dfp.rs:94-102.  The next prologue finds them in the table (columns
-// QN_S2_VCOL ..) and goes from "accepted" to "update pass requested" without a launch (qn_s2_prologue_w0<.., GOBJ>).  A rejected
+// the second table) and goes from "accepted" to "update pass requested" without a launch (qn_s2_prologue_w0<.., GOBJ>).  A rejected
 // trial point costs its staging writes (5 n doubles), never a launch.
 // Reference lines served: dfp.rs:78-123, bfgs.rs:78-127, morethuente.rs:165-297, backtracking.rs:20-58, ls_solver.rs:66-111.
 #pragma once
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512) void s2g_onepass_kernel(const QnS2GArgs g) {
 // staged in the buffers the update pass reads, and this workgroup's row of the table:
 //     columns 0..5 (what qn_s2_advance reads for an evaluation: f = 1/2 tot0 - tot1, g(xt)'d = tot2 - tot3, g'd = tot4, #non-finite d):
 //         mu sum xt^2 (+ 2 (M + log S) in workgroup 0's row), 0, sum g+ d, 0, sum g d, #non-finite d
-//     columns QN_S2_VCOL .. + 4 (what it reads for an accepted point): y'y, y's, g+'g+, s's, s'g+
+//     columns the second table + 4 (what it reads for an accepted point): y'y, y's, g+'g+, s's, s'g+
 // The launch's prologue passes the control block on (serviced 1 -> 2): nothing is decided between the pass over A and this.
 // SHARD (row-sharded runs): the rank folds ITS workgroups -- rows of A it owns -- into (m_r, S_r, G_r) and hands the line search what it
 // can: G_r'd per workgroup and (m_r, S_r) into its slice of evS (one 8 KB exchange follows; the next prologue weighs the ranks with
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void s2g_combine_kernel(const QnS2Args a, cons
         if (k < 4) { const int col = k == 0 ? 0 : (k == 1 ? 2 : (k == 2 ? 4 : 5)); T[(size_t)col * tr + blockIdx.x] = v; }
         else if (k == 4) T[(size_t)1 * tr + blockIdx.x] = 0.0;
         else if (k == 5) T[(size_t)3 * tr + blockIdx.x] = 0.0;
-        if (k < QN_S2_NR) T[(size_t)(QN_S2_VCOL + k) * tr + blockIdx.x] = pv[0];
+        if (k < QN_S2_NR) T[(size_t)(2 * QN_S2_ROW + k) * tr + blockIdx.x] = pv[0]; // (the second table: wgS + 2 trows QN_S2_ROW, the same half)
     }
 }
 
