@@ -1836,6 +1836,7 @@ static int s2_launch(Run& r, int kind) {
     r.report_seq = 0;
 #ifdef QN_S2_STAMPS
     a.dbg = s->V.dbg; a.slot = (int)r.s2_launches;
+    a.swz = (getenv("QN_S2_SWZ") && a.pair) ? atoi(getenv("QN_S2_SWZ")) : 0; // (only where both items follow from the workgroup index: n = 4096)
 #endif
     r.s2_launches++;
     const int cls = kind == QN_S2_EVAL ? KC_EVAL : (kind == QN_S2_VEC || kind == QN_S2_VSUM || kind == QN_S2_GCOMB) ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS

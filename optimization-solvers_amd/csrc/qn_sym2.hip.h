@@ -117,8 +117,14 @@ struct QnS2Args {
 #ifdef QN_S2_STAMPS
     unsigned long long* dbg; // diagnostic build: dbg[((slot % 64) * 256 + workgroup) * 16 + k] = wall clock (10 ns) at stamp k
     int slot;
+    int swz;                 // diagnostic build: workgroup g takes the items of workgroup g ^ swz (which XCD streams which tiles: QN_S2_SWZ)
 #endif
 };
+#ifdef QN_S2_STAMPS
+#define QN_S2_WG(a) ((int)blockIdx.x ^ (a).swz)
+#else
+#define QN_S2_WG(a) ((int)blockIdx.x)
+#endif
 #ifdef QN_S2_STAMPS
 #define QN_S2_STAMP(k) do { if (threadIdx.x == 0 && a.dbg && blockIdx.x < 256) a.dbg[(((size_t)(a.slot & 63)) * 256 + blockIdx.x) * 16 + (k)] = wall_clock64(); } while (0)
 #define QN_S2_STAMP_T(k, t) do { if (threadIdx.x == (t) && a.dbg && blockIdx.x < 256) a.dbg[(((size_t)(a.slot & 63)) * 256 + blockIdx.x) * 16 + (k)] = wall_clock64(); } while (0)
@@ -551,12 +557,12 @@ __device__ __forceinline__ int qn_s2_first_item(int g, int nb) { return qn_s2_it
 // occurs), dealt by the host like any other list -- the first item is read, not computed: one scalar load in front of a launch
 // that streams ~16 tiles per workgroup -- and tile (I, J) lives at the rank's local block-row I - sh_ioff.
 template <bool SHARD>
-__device__ __forceinline__ int qn_s2_first_item_of(const QnS2Args& a) { return SHARD ? a.item_ij[blockIdx.x] : qn_s2_first_item(blockIdx.x, a.nb); }
+__device__ __forceinline__ int qn_s2_first_item_of(const QnS2Args& a) { return SHARD ? a.item_ij[blockIdx.x] : qn_s2_first_item(QN_S2_WG(a), a.nb); }
 template <bool SHARD>
 __device__ __forceinline__ int qn_s2_lrow(const QnS2Args& a, const int I) { return SHARD ? I - a.sh_ioff : I; }
 // the workgroup's second item (-1: none): in closed form when the host dealt it in order (a.inorder), from the list otherwise
 __device__ __forceinline__ int qn_s2_second_item(const QnS2Args& a) {
-    const int t = a.G + (int)blockIdx.x;
+    const int t = a.G + QN_S2_WG(a);
     if (t < a.inorder) return qn_s2_item_of_index(t, a.nb);
     return (a.maxk > 1) ? a.item_ij[(size_t)a.G + blockIdx.x] : -1;
 }
