@@ -821,6 +821,7 @@ struct qn_solver {
     bool no_pair = false;      // diagnostics: the general evaluation kernel where the two-items-and-a-sliver instance would run
     bool tred = false;         // measurement: the update-reduce in the tail of the update-tile launch (s2_hpass_kernel<.., TRED>: bit-identical, slower)
     int* s2_cnt = nullptr;     // tail reduce: arrival counters of the block-rows
+    int gen_slots_hint = 0;    // generic pipelined path: evaluation slots per period the last batch needed (0: none run yet)
     double* s2_gws = nullptr;  // row-sharded log-sum-exp (qn_sym2g.hip.h): the ranks' weights and S of the last evaluation consumed
     bool h_sliver_whole = false; // the diagonal tiles that sliver rows read are complete (both triangles): kept so by sliver-mode update passes
     double* s2_evS = nullptr;   // row-sharded: [2][world][QN_S2SH_NEC][QN_S2_MAXG] the ranks' evaluation scalars, by launch parity (QnS2Args.evS)
@@ -3112,10 +3113,29 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     } else {
         // pipelined: every kernel is predicated on the control block, so a fixed pattern can be enqueued ahead
         // of the decisions; one period = [eval, step] x slots, [h_pass, step], and advances at most one iteration.
-        const int slots = (ls->kind == QN_LS_MORETHUENTE || ls->kind == QN_LS_MORETHUENTE_B) ? 2 : 4;
+        const int slots_max = (ls->kind == QN_LS_MORETHUENTE || ls->kind == QN_LS_MORETHUENTE_B) ? 2 : 4;
+        int slots = slots_max;
+        // The generic path (closures excluded: they are synchronous) sizes its periods like the sharded second-generation path does:
+        // an evaluation slot the line search does not use is two launches that find nothing to do (5.2 + 4.8 us at n = 4096 -- a tenth of a
+        // bounded iteration, where MoreThuenteB accepts t = 1: profiles/r05_q_*); from the second batch on a period carries what the run
+        // has needed per iteration so far, rounded up, and an iteration that needs more rolls over into the next period (every launch
+        // is predicated: only time is lost).  The counters are the control block's: the same on every rank.
+        const bool adaptive = !r.fused;
+        if (adaptive && s->gen_slots_hint) slots = std::min(slots_max, s->gen_slots_hint);
+        uint64_t ev0 = 0, it0 = 0;
+        bool first_batch = true;
         const int gd = s->method == QN_GRADIENT_DESCENT;
         for (;;) {
             QNCHK(peek_ctl(s));
+            if (adaptive && !first_batch && h->n_iterations > it0) {
+                const uint64_t di = h->n_iterations - it0;
+                uint64_t de = h->n_oracle_evals - ev0;
+                if (it0 == 0 && de > 0) de -= 1; // (the evaluation at x0 that opens a run)
+                slots = (int)std::min<uint64_t>((uint64_t)slots_max, std::max<uint64_t>(1, (de + di - 1) / di));
+                s->gen_slots_hint = slots;
+            }
+            ev0 = h->n_oracle_evals; it0 = h->n_iterations;
+            first_batch = false;
             if (h->phase == QN_PH_DONE) { status = h->status; break; }
             int64_t remaining = h->max_iter - h->k;
             if (remaining < 1) remaining = 1;
