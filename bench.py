@@ -649,6 +649,7 @@ def main():
         mat_bytes = float(solver.stats()["matrix_bytes_per_pass"])  # per rank: the row shard, or the symmetric half (symmetric storage)
         symmetric = bool(solver.stats()["path"] & 2)
         second_gen = bool(solver.stats()["path"] & 16)
+        tiles1 = bool(solver.stats()["path"] & 32)  # (round 5) a rank's share of H past the Infinity Cache: first-generation tile kernel behind a machine launch
         # what the default layout of this shape is, and whether the run fell back from it (nothing in the line said so)
         layout_fallback = None
         if not symmetric:
@@ -673,7 +674,9 @@ def main():
                                          "blocks (every pair of blocks once across the ranks), per-rank partial n-vectors all-gathered and "
                                          "summed in rank order" if symmetric else "full row-major, row-sharded"),
                        "kernels": ("second generation: the state machine in every kernel's prologue; per iteration E evaluation launches + "
-                                   + ("5 (partial sums, vectors, update tiles, partial sums, reduce), E scalar + 2 n-vector collectives" if world > 1
+                                   + (("6 (partial sums, vectors, machine, update tiles [one workgroup per tile: the rank's share of H is past the Infinity Cache], "
+                                       "partial sums, reduce), E scalar + 2 n-vector collectives") if (world > 1 and tiles1) else
+                                      "5 (partial sums, vectors, update tiles, partial sums, reduce), E scalar + 2 n-vector collectives" if world > 1
                                       else "3 (vectors, update tiles, reduce)")) if second_gen else "first generation",
                        "layout_fallback": layout_fallback,
                        "n": n, "line_search": args.ls, "tol": 1e-10, "parallelism": f"row-shard x{world}",
