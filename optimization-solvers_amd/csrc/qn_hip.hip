@@ -823,6 +823,7 @@ struct qn_solver {
     int* s2_cnt = nullptr;     // tail reduce: arrival counters of the block-rows
     int gen_slots_hint = 0;    // generic pipelined path: evaluation slots per period the last batch needed (0: none run yet)
     double* s2_gws = nullptr;  // row-sharded log-sum-exp (qn_sym2g.hip.h): the ranks' weights and S of the last evaluation consumed
+    double* s2_wgV = nullptr;  // generic objectives: the second table of per-workgroup sums (QnS2Args.wgV)
     bool h_sliver_whole = false; // the diagonal tiles that sliver rows read are complete (both triangles): kept so by sliver-mode update passes
     double* s2_evS = nullptr;   // row-sharded: [2][world][QN_S2SH_NEC][QN_S2_MAXG] the ranks' evaluation scalars, by launch parity (QnS2Args.evS)
     int *s2_sl_off = nullptr, *s2_sl_idx = nullptr; // row-sharded: per block-row, the slots this rank's tiles write (QnS2Args.sl_off / sl_idx)
@@ -1109,7 +1110,8 @@ static int solver_alloc_sym2(qn_solver* s) {
         s->s2_maxk = (int)maxk;
         s->s2_inorder = inorder;
         s->s2_trows = std::max(QN_S2_MAXG, (nb + 63) / 64 * 64);
-        QNCHK(dev_alloc_zero(&s->s2_wgS, (size_t)4 * s->s2_trows * QN_S2_ROW, st)); // (two tables of two halves: the second one is the generic objectives')
+        QNCHK(dev_alloc_zero(&s->s2_wgS, (size_t)2 * s->s2_trows * QN_S2_ROW, st));
+        (void)hipFree(s->s2_wgV); s->s2_wgV = nullptr; // (the generic objectives' second table: allocated by the runs that use it)
         QNCHK(dev_alloc_zero(&s->s2_partE, (size_t)nb * nb * QN_TB, st));
         if (sharded) {
             QNCHK(dev_alloc_zero(&s->s2_evS, (size_t)2 * world * QN_S2SH_NEC * QN_S2_MAXG, st));
@@ -1191,7 +1193,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE); (void)hipFree(s->s2_ctl);
-    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_cnt); (void)hipFree(s->s2_gws); (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx); (void)hipFree(s->symsh_tiles);
+    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_cnt); (void)hipFree(s->s2_gws); (void)hipFree(s->s2_wgV); (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx); (void)hipFree(s->symsh_tiles);
     (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
     (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
     delete s;
@@ -1909,6 +1911,7 @@ static int s2_launch(Run& r, int kind) {
     case QN_S2_GCOMB: {
         QnS2GArgs g = s2g_args(r);
         g.wgS = a.wgS + (size_t)a.parity * (size_t)a.trows * QN_S2_ROW; // the half this launch writes (the next prologue reads it)
+        g.wgV = a.wgV + (size_t)a.parity * (size_t)a.trows * QN_S2_ROW;
         if (sh) {
             g.ev_slice = a.evS + ((size_t)a.parity * (size_t)a.sh_world + (size_t)a.sh_rank) * (QN_S2SH_NEC * QN_S2_MAXG);
             hipLaunchKernelGGL(s2g_combine_kernel<true>, dim3(a.gw), dim3(256), 0, st, a, g);
@@ -2980,6 +2983,8 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         // (allocated only for the runs that use them: the tail reduce's counters, the sharded log-sum-exp path's weights)
         if (r.gobj && c->world > 1 && !s->s2_gws) QNCHK(dev_alloc_zero(&s->s2_gws, 80, c->stream)); // the ranks' weights and S, world <= 64
         a.gws = s->s2_gws;
+        if (r.gobj && !s->s2_wgV) QNCHK(dev_alloc_zero(&s->s2_wgV, (size_t)2 * s->s2_trows * QN_S2_ROW, c->stream));
+        a.wgV = s->s2_wgV;
         if (r.gobj && a.gw > s->s2_trows) return fail(QN_ABNORMAL_TERMINATION, "sym2 (generic objective): more combine workgroups than table rows");
         // folded accept-reduce (s2_hpass_kernel): every workgroup holds at most three items, so the blocks whose slots it sums fit
         // its LDS staging area -- n <= 4096 with 256 workgroups; larger n keeps the accept-reduce launch (7 us of 250+)

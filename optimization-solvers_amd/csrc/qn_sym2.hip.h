@@ -48,7 +48,7 @@
 #define QN_S2_NR 5     // accept-reduce partials per block-row: y'y, y's, g+'g+, s's, s'g+
 #define QN_S2_ROW 8    // doubles per partial row in memory (64 B: loaded as 16-byte pieces)
                        // (generic objectives, qn_sym2g.hip.h: the accepted-point sums a combine launch stages with every evaluation live in a
-                       // SECOND table of the same shape behind the first -- wgS + 2 trows QN_S2_ROW -- so that this one keeps its layout)
+                       // SECOND table of the same shape, QnS2Args.wgV, so that this one keeps its layout and its size)
 #define QN_S2SH_NEC 4  // row-sharded runs: the evaluation scalars that are exchanged, per workgroup: x'(Q xt - 2 b), d'(Q xt - b), g'd,
                        // #non-finite d (the table's b'xt and b'd columns are zero by construction: see CONDITIONING below)
 #define QN_S2SH_EB 4   // ... and the slices of them a prologue requests at a time
@@ -110,6 +110,8 @@ struct QnS2Args {
     const int* sl_idx;
     // ---- round 5 additions (kept behind everything the benchmark path's kernels read: the struct is the kernel argument) ----
     int cnt_stride;      // tail reduce: ints between two block-rows' arrival counters
+    double* wgV;         // generic objectives: the SECOND table ([2][QN_S2_ROW][trows], an allocation of its own): the accepted-point sums a combine
+                         // launch stages with every evaluation, by launch parity like wgS
     int gw;              // generic objectives (qn_sym2g.hip.h): rows of the table an evaluation's combine launch leaves (its workgroups: n / 64)
     double gmu;          // ... log-sum-exp: mu (row-sharded runs: the prologue puts the ranks' (m, S, G'd) together itself)
     double* gws;         // ... [sh_world + 1]: the ranks' weights w_r = exp(m_r - M) and S of the LAST evaluation the machine consumed (written
@@ -283,7 +285,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
 #pragma unroll
         for (int k = 0; k < QN_S2_NR; ++k)
 #pragma unroll
-            for (int j = 0; j < QN_S2_PCH; ++j) tv[j][k] = T[(size_t)(2 * QN_S2_ROW + k) * a.trows + j * 64 + lane]; // (the second table's same half)
+            for (int j = 0; j < QN_S2_PCH; ++j) tv[j][k] = a.wgV[((size_t)(a.parity ^ 1) * QN_S2_ROW + k) * a.trows + j * 64 + lane]; // (the second table's same half)
     }
     // SHARD: the evaluation scalars of the first QN_S2SH_EB ranks go out now as well (every entry of evS is valid at all times --
     // rows past the grid stay zero -- so nothing about them depends on the control block; lane l takes rows 2 l, 2 l + 1 and
@@ -810,9 +812,11 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
 #pragma unroll
         for (int r = 0; r < QN_S2_RPW; ++r) h[r] = qn_sym_ld<NTQ>(qb + (size_t)r * np);
     };
+    unsigned cw = 0u;
     if (wave == 0) {
         qn_s2_prologue_w0<QN_S2_EVAL, SHARD>(a, L, vec_spec);
     } else {
+        if (wave <= 4) cw = qn_code_warm_issue((wave - 1) * 64 + lane); // (qn_kernels.hip.h, CODE WARM-UP: 32 KB)
         window_load(ij0);
         vec_spec();
     }
@@ -852,6 +856,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     QN_S2_STAMP(1);
     __syncthreads();
     qn_s2_ctl_out(a, L);
+    qn_code_warm_done(cw, a.n < 0, a.wgS);
     if (!L.mine) return;
     QN_S2_STAMP(2);
     if (wave == 0) window_load(parked ? ij1 : ij0); // (parked: its rows of the first item are in LDS)
@@ -1047,6 +1052,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     __shared__ double bred[2][8];
     const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QnS2Slots S0;
+    unsigned cw[4] = {0u, 0u, 0u, 0u};
     QN_S2_STAMP(0);
     // (wave 0 requests its share of the slots behind the control block and the table, BEFORE it runs the machine: requested after
     // it -- 3.5 us into a 6 us kernel -- they were what the slot sums waited for)
@@ -1062,12 +1068,17 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
             e_u = a.F.UN[gi]; e_b = a.F.b[gi]; e_g = a.F.G[gi];
         }
     };
+    if (wave == 7) { // (qn_kernels.hip.h, CODE WARM-UP: 32 KB, the whole kernel -- 7.1 -> 5.8 us, profiles/r05_o_*)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cw[k] = qn_code_warm_issue(k * 64 + lane);
+    }
     if (SHARD) { if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC, true>(a, L, entries); else entries(); }
     else if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC>(a, L, [&]() { qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0); entries(); });
     else { qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0); entries(); }
     __syncthreads();
     QN_S2_STAMP(2);
     qn_s2_ctl_out(a, L);
+    qn_code_warm_done(cw[0] ^ cw[1] ^ cw[2] ^ cw[3], a.n < 0, a.wgS);
     if (!L.mine) return;
     const QnEvalReq q = qn_s2_eval_req<false>(L.c, true);
     double* __restrict__ xt = a.F.X0 + (size_t)(1 - q.xc) * np;

@@ -32,6 +32,7 @@ struct QnS2GArgs {
     const QnCtl* ctl;        // the control block the advance launch in front has written (read only)
     QnFused F;               // X0[2], S0[2], G, GT, Y, UN, VV
     double* wgS;             // the table half this evaluation's combine launch writes: [QN_S2_ROW][trows]
+    double* wgV;             // ... and the same half of the second table (the staged accepted-point sums)
     int trows;
     // row-sharded runs (rows of A and of H sharded, vectors replicated):
     double* gall;            // [world][n_pad]: the ranks' G_r = sum_w exp(m_w - m_r) G_w, rank r's slice written by its combine launch;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void s2g_combine_kernel(const QnS2Args a, cons
         if (k < 4) { const int col = k == 0 ? 0 : (k == 1 ? 2 : (k == 2 ? 4 : 5)); T[(size_t)col * tr + blockIdx.x] = v; }
         else if (k == 4) T[(size_t)1 * tr + blockIdx.x] = 0.0;
         else if (k == 5) T[(size_t)3 * tr + blockIdx.x] = 0.0;
-        if (k < QN_S2_NR) T[(size_t)(2 * QN_S2_ROW + k) * tr + blockIdx.x] = pv[0]; // (the second table: wgS + 2 trows QN_S2_ROW, the same half)
+        if (k < QN_S2_NR) g.wgV[(size_t)k * tr + blockIdx.x] = pv[0]; // (the second table, the same half)
     }
 }
 
