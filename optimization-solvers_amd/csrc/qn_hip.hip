@@ -1897,7 +1897,7 @@ static int s2_launch(Run& r, int kind) {
         break;
     case QN_S2_HREDUCE:
         if (sh) hipLaunchKernelGGL(s2_hreduce_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
-        else hipLaunchKernelGGL(s2_hreduce_kernel<false>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
+        else hipLaunchKernelGGL(s2_hreduce_kernel<false>, dim3(2 * a.nb), dim3(QN_S2_TPB), 0, st, a); // (a workgroup per block-row and right-hand side)
         break;
     case QN_S2_GEVAL_A:
         if (sh) hipLaunchKernelGGL((s2_advance_kernel<true, true, QN_S2_GEVAL_A>), dim3(1), dim3(128), 0, st, a);

@@ -276,6 +276,9 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
 #pragma unroll
             for (int j = 0; j < QN_S2_PCH; ++j) tr[j][k] = T[(size_t)k * a.trows + j * 64 + lane]; // (trows >= 256)
     }
+    // (Measured and dropped, round 5: the control block's and the table's addresses as LEADING SCALAR kernel arguments, preloaded into SGPRs by the
+    // dispatcher -- -mllvm -amdgpu-kernarg-preload-count=16, .amdhsa_user_sgpr_kernarg_preload_length 4 on the accept-reduce -- so that the first
+    // requests need no kernel-argument fetch in front of them: 5.93 -> 6.03 us, nothing.  HIP_FORCE_DEV_KERNARG=0, for scale: +2 us on EVERY kernel.)
     // (Measured and dropped, round 5: the first 64 rows of every column requested FIRST and only those waited for when the table has
     // at most 64 rows -- the two small kernels' tables at n = 4096; in-kernel stamps had shown the table 1.3-1.5 us behind the control
     // block in the update kernel.  rocprofv3 averages, alternating runs on one box (profiles/r05_f_*): evaluation -0.1 us, update tiles
@@ -1125,17 +1128,26 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
 // ------------------------------------------------------------------------------------------------
 // (the epilogue of a block-row, given its two totals on threads 0..127: called by s2_hreduce_kernel and by the tail reduce of
 // s2_hpass_kernel<.., TRED> -- one body, the same sums in the same order, hence the same bits; all 512 threads call it)
-__device__ __forceinline__ void qn_s2_hreduce_row(const QnS2Args& a, const int R, const int nrhs, const double tot0, const double tot1, double (*bred)[8]) {
+// (gp, yv: the block-row's entries of g+ and y on threads 0..127 -- the accept-reduce wrote them a launch earlier, so s2_hreduce_kernel requests them
+// at entry, with its slots: behind the totals they were one more memory round trip at the end of a 5 us kernel)
+// (half: s2_hreduce_kernel gives a block-row's two right-hand sides to TWO workgroups -- 0: u, the sums and the commit of g; 1: v, passed as tot1,
+// and nothing else; -1: both, the tail reduce)
+__device__ __forceinline__ void qn_s2_hreduce_row(const QnS2Args& a, const int R, const int nrhs, const double tot0, const double tot1, double (*bred)[8],
+                                                  const double gp, const double yv, const int half = -1) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (half == 1) { // (uniform)
+        if (tid < QN_TB && nrhs == 2) a.F.VV[R * QN_TB + tid] = tot1;
+        return;
+    }
     double p[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = 0.0;
     if (tid < QN_TB) {
         const int gi = R * QN_TB + tid;
-        const double gp = a.F.GT[gi];
         if (nrhs == 2) {
-            a.F.UN[gi] = tot0; a.F.VV[gi] = tot1;
-            p[0] = a.F.Y[gi] * tot0; // y'u = y'H+y
+            a.F.UN[gi] = tot0;
+            if (half < 0) a.F.VV[gi] = tot1;
+            p[0] = yv * tot0; // y'u = y'H+y
             p[1] = tot0 * gp;        // u'g+
         } else {
             a.F.VV[gi] = tot0; // direction pass: v = H g (bfgs.rs:47)
@@ -1555,7 +1567,9 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
             qn_s2_slot_issue<2, true>(a.part, a.nb, R, 1, S1);
             const double tot0 = qn_s2_slot_sum<2, true>(a.part, a.nb, R, 0, S0, qbuf);
             const double tot1 = (nrhs == 2) ? qn_s2_slot_sum<2, true>(a.part, a.nb, R, 1, S1, qbuf) : 0.0; // (uniform)
-            qn_s2_hreduce_row(a, R, nrhs, tot0, tot1, fred);
+            double gp = 0.0, yv = 0.0;
+            if (tid < QN_TB) { gp = a.F.GT[R * QN_TB + tid]; yv = a.F.Y[R * QN_TB + tid]; }
+            qn_s2_hreduce_row(a, R, nrhs, tot0, tot1, fred, gp, yv);
             __syncthreads(); // fred is reused
         }
         QN_S2_STAMP(14);
@@ -1598,24 +1612,34 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
 
 // update-reduce: u_i, v_i = sums of block-row R's slots, the partials of y'u and u'g+ (the update's coefficients and the next
 // direction need them); commits g <- g+ (the evaluation kernels read g for g'd)
+// Single rank: TWO workgroups per block-row, one per right-hand side (grid 2 nb).  A workgroup's slots were 2 x nb KB behind one CU's
+// memory pipeline -- in-kernel stamps at n = 4096: control block 1.45 us after entry, barrier 2.0, totals 2.75: the slots, not the machine, were
+// what the epilogue waited for -- and nothing in the epilogue needs both totals: u goes with the two sums and the commit of g, v is stored and
+// that is all.  The same sums in the same order.
 template <bool SHARD = false> // (row-sharded: the totals are the rank-order sums of the gathered partial [u, v]: see s2_vec_kernel)
 __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
     __shared__ double qbuf[3][QN_TB];
     __shared__ double bred[2][8];
-    const int R = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
-    QnS2Slots S0, S1;
-    if (SHARD) { if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE, true>(a, L); }
-    else if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE>(a, L, [&]() { qn_s2_slot_issue(a.part, a.nb, R, 0, S0); qn_s2_slot_issue(a.part, a.nb, R, 1, S1); });
-    else { qn_s2_slot_issue(a.part, a.nb, R, 0, S0); qn_s2_slot_issue(a.part, a.nb, R, 1, S1); }
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int R = SHARD ? (int)blockIdx.x : (int)(blockIdx.x >> 1), half = SHARD ? -1 : (int)(blockIdx.x & 1);
+    QnS2Slots S0;
+    QN_S2_STAMP(0);
+    double gp = 0.0, yv = 0.0;
+    auto entries = [&]() { if (half != 1 && tid < QN_TB) { gp = a.F.GT[R * QN_TB + tid]; yv = a.F.Y[R * QN_TB + tid]; } };
+    if (SHARD) { if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE, true>(a, L, entries); else entries(); }
+    else if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE>(a, L, [&]() { qn_s2_slot_issue(a.part, a.nb, R, half, S0); entries(); });
+    else { qn_s2_slot_issue(a.part, a.nb, R, half, S0); entries(); }
     __syncthreads();
+    QN_S2_STAMP(2);
     qn_s2_ctl_out(a, L);
     if (!L.mine) return;
     const int nrhs = L.c.hp_nrhs;
     double tot0 = 0.0, tot1 = 0.0;
     if (!SHARD) {
-        tot0 = qn_s2_slot_sum(a.part, a.nb, R, 0, S0, qbuf);
-        tot1 = (nrhs == 2) ? qn_s2_slot_sum(a.part, a.nb, R, 1, S1, qbuf) : 0.0; // (uniform)
+        if (half == 1 && nrhs != 2) return; // (uniform) a direction pass has one right-hand side
+        const double t = qn_s2_slot_sum(a.part, a.nb, R, half, S0, qbuf);
+        if (half == 0) tot0 = t; else tot1 = t;
     } else if (tid < QN_TB) { // xg: [rank][rhs][np]
         const size_t np = (size_t)a.np;
         const double* xp = a.xg + (size_t)R * QN_TB + tid;
@@ -1623,7 +1647,9 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
         for (int r = 1; r < a.sh_nsum; ++r) { tot0 = tot0 + xp[(size_t)r * 2 * np]; tot1 = tot1 + xp[(size_t)r * 2 * np + np]; }
         if (nrhs != 2) tot1 = 0.0;
     }
-    qn_s2_hreduce_row(a, R, nrhs, tot0, tot1, bred);
+    QN_S2_STAMP(13); // (the totals)
+    qn_s2_hreduce_row(a, R, nrhs, tot0, tot1, bred, gp, yv, half);
+    QN_S2_STAMP(12);
 }
 
 // PLACEMENT PROBE (round 4).  At n = 4096 about one inverse Hessian in eight runs the update kernel at 29.7 us instead of 25.2 for

@@ -37,6 +37,11 @@ for slot in range(64):
         print("slot %2d (accept-reduce): ctl %d, table %d, sums %d, machine %d, barrier %d, end %d; last workgroup's end %d" % (
             slot, *[int(np.median((w[:, k] - w[:, 0]) * 10)) for k in (9, 1, 10, 11, 2, 14)], int((w[:, 14].max() - w[:, 0].min()) * 10)))
         continue
+    if t[0, 12] != 0 and t[0, 0] != 0 and t[0, 3] == 0 and t[0, 14] == 0 and t[0, 15] == 0:  # an update-reduce launch that did work (32 workgroups)
+        w = t[:32]
+        print("slot %2d (update-reduce): ctl %d, table %d, sums %d, machine %d, barrier %d, totals %d, end %d; last workgroup's end %d" % (
+            slot, *[int(np.median((w[:, k] - w[:, 0]) * 10)) for k in (9, 1, 10, 11, 2, 13, 12)], int((w[:, 12].max() - w[:, 0].min()) * 10)))
+        continue
     if t[0, 6] != 0 and t[0, 15] != 0 and t[0, 0] != 0 and t[0, 4] == 0:  # an update-tile launch (stamps 3 / 6: rows of item 1 / 2 consumed by wave 0, 12 / 13: by wave 7)
         wg = t[:, 15] > 0
         w = t[wg]
