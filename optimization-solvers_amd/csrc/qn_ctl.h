@@ -18,7 +18,9 @@ enum QnPhase : int32_t {
     QN_PH_REQ_HPASS_EVAL = 7, // fused path: run h_pass, then the evaluation at (req_kind, req_t) whose direction uses the
                               // coefficients of the update this pass completes (derived from the pass's partial sums)
     QN_PH_REQ_VEC = 8,   // sym2: turn the slots of the last evaluation into vectors (g+, y, x+, s) and their sums
-    QN_PH_REQ_NEWTON = 6 // Newton: factorise the Hessian at x_k and solve for d and H^-1 d (5 is the in-kernel RUNNING marker)
+    QN_PH_REQ_NEWTON = 6, // Newton: factorise the Hessian at x_k and solve for d and H^-1 d (5 is the in-kernel RUNNING marker)
+    QN_PH_REQ_DIR = 9    // sym2, bounded variants: turn the lazy direction into a stored one -- projected onto the solver's box (bfgs_b.rs:72-75)
+                         // -- and find the step at which it leaves the line search's box (morethuente_b.rs:185-198): s2_dir_kernel
 };
 
 enum QnReqKind : int32_t { QN_REQ_X = 0 /* at x_k itself */, QN_REQ_T = 1 /* at x_k + t d_k */ };
@@ -99,7 +101,9 @@ struct QnCtl {
     double bt_diff2; // ||P(x + t d) - x||^2 of the last projected trial (backtracking_b.rs:33-34)
 
     // ---- Newton (newton/mod.rs:8-13) ----
-    int32_t has_dec, _padn;
+    int32_t has_dec;
+    int32_t s2_dir; // sym2, bounded variants (qn_sym2.hip.h, s2_dir_kernel): a new direction goes through QN_PH_REQ_DIR before the line search
+                    // starts -- bit 0: it is projected onto the solver's box, bit 1: MoreThuenteB, t_max is clipped by the step to the box
     double dec; // decrement_squared: Option<f64>
 
     // ---- request ----
@@ -128,7 +132,8 @@ struct QnCtl {
 
     // ---- per-iteration trace scratch ----
     double tr_f, tr_gnorm;
-    int32_t tr_n_evals, tr_ls_iters, tr_ls_cases, tr_ndigits, tr_updated, _pad2;
+    int32_t tr_n_evals, tr_ls_iters, tr_ls_cases, tr_ndigits, tr_updated;
+    int32_t dir_ready; // s2_dir: the direction of the current x has been through its QN_PH_REQ_DIR (VV holds -d, mtb_cand its step to the box)
 
     // ---- counters ----
     uint64_t n_oracle_calls, n_oracle_evals, n_hpasses, n_hpass_rw, n_iterations;

@@ -60,7 +60,10 @@ __device__ __forceinline__ bool qn_check_is_scalar(const QnCtl& c) {
 // gradient descent, bounded solvers / line searches, callbacks and qn_compute_step_len (minimize_impl: `r.fused`): the branches for
 // those are compiled out.  Same decisions on that path by construction; about half the code -- and the machine is inlined into
 // every kernel of an iteration, where code size is instruction-fetch time behind the kernel's data burst.
-template <bool LEAN>
+// LEAN == 2: the lean machine of the second-generation path's BOUNDED runs (BFGSB / DFPB, MoreThuenteB; QnCtl.s2_dir): a new direction is
+// not searched along before it has been through QN_PH_REQ_DIR -- s2_dir_kernel stores it, projected, and reduces the step to the line
+// search's box, which clips t_max (morethuente_b.rs:201; from there on MoreThuenteB IS More-Thuente: the host hands this machine ls_kind 0).
+template <int LEAN>
 __device__ __forceinline__ void qn_st_begin(QnCtl& c) { // ls_solver.rs:74-76: only k is reset
     c.k = 0;
     // A fresh call evaluates the oracle at x_k and forms d = -H g from scratch (ls_solver.rs:79, bfgs.rs:47).  When it
@@ -73,7 +76,7 @@ __device__ __forceinline__ void qn_st_begin(QnCtl& c) { // ls_solver.rs:74-76: o
     c.state = QN_ST_LOOP_TOP;
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ void qn_st_loop_top(QnCtl& c) { // ls_solver.rs:78-79
     if (!(c.max_iter > c.k)) {
         c.status = 1; // MaxIterReached, ls_solver.rs:109-110
@@ -93,7 +96,7 @@ __device__ __forceinline__ void qn_st_loop_top(QnCtl& c) { // ls_solver.rs:78-79
     }
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ bool qn_st_after_evalx(QnCtl& c) {
     if (!LEAN && !c.fused) return false;
     c.f_k = c.f_e; // g <- gt is committed by the direction pass (h_pass row-block 0)
@@ -104,7 +107,7 @@ __device__ __forceinline__ bool qn_st_after_evalx(QnCtl& c) {
     return true;
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ bool qn_st_after_dir(QnCtl& c) {
     if (!LEAN && !c.fused) return false;
     c.n_hpasses++;
@@ -113,10 +116,11 @@ __device__ __forceinline__ bool qn_st_after_dir(QnCtl& c) {
     c.dir_mode = 0; // d = -v
     c.gd0_valid = 0; c.d_finite = 0; c.last_valid = 0;
     c.state = QN_ST_LS_BEGIN;
+    if (LEAN == 2 && c.s2_dir) { c.dir_ready = 0; c.after_state = QN_ST_LS_BEGIN; c.phase = QN_PH_REQ_DIR; }
     return true;
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ bool qn_st_after_next(QnCtl& c) { // bfgs.rs:94-102 from the sums staged by the accepted evaluation
     if (!LEAN && !c.fused) return false;
     c.s_norm = sqrt(c.st_ss); c.has_s_norm = 1;
@@ -151,7 +155,7 @@ __device__ __forceinline__ bool qn_st_after_next(QnCtl& c) { // bfgs.rs:94-102 f
     return true;
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ bool qn_st_after_u(QnCtl& c) { // coefficients of bfgs.rs:115-124 / dfp.rs:115-120 in rank-2 form
     if (!LEAN && !c.fused) return false;
     const double yu = c.hp_yu;
@@ -165,12 +169,13 @@ __device__ __forceinline__ bool qn_st_after_u(QnCtl& c) { // coefficients of bfg
     c.dir_mode = 1; c.dir_ug = c.hp_ug; c.dir_sg = c.hp_sg; // next direction formed on the fly by the evaluations
     c.gd0_valid = 0; c.d_finite = 0;
     c.have_dir = 1;
+    if (LEAN == 2) c.dir_ready = 0;
     c.tr_updated = 1;
     c.state = QN_ST_ITER_END;
     return true;
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ bool qn_st_check(QnCtl& c, const QnVecs& V, double* small_scratch) { // ls_solver.rs:37-40 (OutOfDomain), has_converged (bfgs.rs:64-76)
     const int n = V.n, n_pad = V.n_pad;
     if (!LEAN && !qn_check_is_scalar(c)) return false; // gradient descent / unknown ||g||: all threads needed
@@ -214,6 +219,10 @@ __device__ __forceinline__ bool qn_st_check(QnCtl& c, const QnVecs& V, double* s
         c.state = QN_ST_LS_BEGIN;
     } else if (c.have_dir) {
         c.state = QN_ST_LS_BEGIN;
+        if (LEAN == 2 && c.s2_dir) {
+            if (!c.dir_ready) { c.after_state = QN_ST_LS_BEGIN; c.phase = QN_PH_REQ_DIR; }
+            else if (c.s2_dir & 2) c.mt_tmax = fmin(c.mt_tmax, c.mtb_cand); // (a call that continues behind a served request: the clip is the line search's)
+        }
     } else { // bfgs.rs:47 d = -(H g): one pass over H (applies a pending update on the way)
         c.hp_nrhs = 1; c.hp_lazy = 0;
         c.after_state = QN_ST_AFTER_DIR;
@@ -222,7 +231,7 @@ __device__ __forceinline__ bool qn_st_check(QnCtl& c, const QnVecs& V, double* s
     return true;
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ void qn_st_ls_begin(QnCtl& c) {
     c.ls_i = 0;
     if (!LEAN && c.ls_kind == 2) c.mt_tmax = fmin(c.mt_tmax, c.mtb_cand); // morethuente_b.rs:201: self.t_max = self.t_max.min(candidate) -- persists
@@ -237,13 +246,13 @@ __device__ __forceinline__ void qn_st_ls_begin(QnCtl& c) {
     }
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ void qn_st_mt_loop(QnCtl& c) { // morethuente.rs:181-182
     if (!(c.ls_i < c.max_iter_ls)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :295-296
     else { c.tr_ls_iters++; req_eval_t<LEAN>(c, c.t, QN_ST_MT_AFTER_T, 0); }
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ void qn_st_mt_after_t(QnCtl& c) { // morethuente.rs:184-217
     const double f_et = c.f_e, gd_t = c.gd_e, t = c.t;
     const bool wolfe = (f_et - c.f_k <= c.mt_c1 * t * c.gd0) && (fabs(gd_t) <= c.mt_c2 * fabs(c.gd0));
@@ -259,7 +268,7 @@ __device__ __forceinline__ void qn_st_mt_after_t(QnCtl& c) { // morethuente.rs:1
     }
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ void qn_st_mt_after_tl(QnCtl& c) { // morethuente.rs:218-287
     const double phi_tl_f = c.f_e, phi_tl_g = c.gd_e;
     double f_tl, g_tl, f_t, g_t;
@@ -296,7 +305,7 @@ __device__ __forceinline__ void qn_st_mt_after_tl(QnCtl& c) { // morethuente.rs:
     }
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ void qn_st_mt_after_tu(QnCtl& c) {
     double f_tu, g_tu;
     if (c.use_mod) { f_tu = c.f_e; g_tu = c.gd_e; }
@@ -306,7 +315,7 @@ __device__ __forceinline__ void qn_st_mt_after_tu(QnCtl& c) {
     c.state = QN_ST_MT_FINISH;
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ void qn_st_mt_finish(QnCtl& c) { // morethuente.rs:290-293: the NEW t with the OLD trial's f_t, g_t
     c.t = fmin(fmax(c.t, c.mt_tmin), c.mt_tmax);
     double tl = c.tl, tu = c.tu;
@@ -316,13 +325,13 @@ __device__ __forceinline__ void qn_st_mt_finish(QnCtl& c) { // morethuente.rs:29
     c.state = QN_ST_MT_LOOP;
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ void qn_st_bt_loop(QnCtl& c) { // backtracking.rs:31-34
     if (!(c.max_iter_ls > c.ls_i)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :54
     else { c.tr_ls_iters++; req_eval_t<LEAN>(c, c.t, QN_ST_BT_AFTER, 0, (!LEAN && c.ls_kind == 3) ? 1 : 0); }
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ void qn_st_bt_after(QnCtl& c) { // backtracking.rs:37-51
     const double f1 = c.f_e;
     if (isnan(f1) || isinf(f1)) { c.t *= c.bt_beta; c.state = QN_ST_BT_LOOP; } // shrink, iteration not counted
@@ -331,7 +340,7 @@ __device__ __forceinline__ void qn_st_bt_after(QnCtl& c) { // backtracking.rs:37
     else { c.t *= c.bt_beta; c.ls_i++; c.state = QN_ST_BT_LOOP; }
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ bool qn_st_after_ls(QnCtl& c) {
     if (!LEAN && c.ls_only) { c.status = 0; c.phase = QN_PH_DONE; return true; } // compute_step_len returns the step, nothing else
     if (!LEAN && (c.method == 2 || c.method == 3)) return false; // gradient descent / Newton: the default hook x += step*d needs all threads
@@ -339,7 +348,7 @@ __device__ __forceinline__ bool qn_st_after_ls(QnCtl& c) {
     return true;
 }
 
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ bool qn_st_iter_end(QnCtl& c, const QnVecs& V, const bool side_effects) { // ls_solver.rs:104-107
     const bool rec = c.k < c.trace_cap;
     if (rec && c.trace_x && !c.xtrace_done) return false; // the iterate has to be copied by all threads first
@@ -367,7 +376,7 @@ __device__ __forceinline__ bool qn_st_iter_end(QnCtl& c, const QnVecs& V, const 
     if (!(c.phase == QN_PH_RUNNING && c.state == (ST))) break;          \
     if (!(CALL)) return;
 
-template <bool LEAN = false>
+template <int LEAN = 0>
 __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double* small_scratch, const bool side_effects = true) {
     for (int guard = 0; guard < (1 << 22); ++guard) {
         if (c.phase != QN_PH_RUNNING) return;
@@ -387,6 +396,7 @@ __device__ __forceinline__ void ctl_scalar_run(QnCtl& c, const QnVecs& V, double
 
         case QN_ST_AFTER_DIR:
             if (!qn_st_after_dir<LEAN>(c)) return;
+            if (LEAN == 2 && c.phase != QN_PH_RUNNING) break; // (the direction goes through QN_PH_REQ_DIR first)
             qn_st_ls_begin<LEAN>(c);
             QN_RUN_NEXT(QN_ST_MT_LOOP, qn_st_mt_loop<LEAN>(c))
             break;
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
             }
         }
         QN_STAMP(1);
-        ctl_block_sum<3>(p, lds);
+        ctl_block_sum<3, true>(p, lds);
         cons_f = (ORACLE == QN_ORACLE_QUAD) ? (0.5 * p[0] - p[1]) : *V.f_dev;
         cons_gd = p[2];
     }
@@ -561,7 +571,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
     if (!fused && expect_phase == QN_PH_REQ_EVAL && c.req_project) { // BackTrackingB: ||P(x + t d) - x||^2
         double p[1] = {0.0};
         for (int i = tid; i < n_pad; i += tpb) { const double df = vxt[i] - vx[i]; p[0] = __builtin_fma(df, df, p[0]); }
-        ctl_block_sum<1>(p, lds);
+        ctl_block_sum<1, true>(p, lds);
         if (c.small_n) {
             __syncthreads();
             if (tid == 0) { double acc8[QN_SMALL_N]; for (int i = 0; i < n; ++i) acc8[i] = V.xt[i] - V.x[i]; p[0] = ref_dot(acc8, acc8, n); }
@@ -623,7 +633,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                 for (int u = 0; u < 4; ++u)
                     if (ok[u]) { vg[idx[u]] = gv[u]; p[0] = __builtin_fma(gv[u], gv[u], p[0]); }
             }
-            ctl_block_sum<1>(p, lds);
+            ctl_block_sum<1, true>(p, lds);
             if (tid == 0) {
                 c.f_k = c.f_e;
                 c.gg = p[0]; c.gg_valid = 1;
@@ -646,15 +656,15 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                     p[0] = __builtin_fma(gi, di, p[0]);
                     p[1] += isfinite(di) ? 0.0 : 1.0;
                 }
-                gnorm = ctl_block_fmax(m, lds);
-                ctl_block_sum<2>(p, lds);
+                gnorm = ctl_block_fmax<true>(m, lds);
+                ctl_block_sum<2, true>(p, lds);
                 if (c.small_n) {
                     __syncthreads();
                     if (tid == 0) p[0] = ref_dot(V.g, V.d, n);
                 }
             } else {
                 for (int i = tid; i < n_pad; i += tpb) { const double gi = vg[i]; p[0] = __builtin_fma(gi, gi, p[0]); }
-                ctl_block_sum<2>(p, lds);
+                ctl_block_sum<2, true>(p, lds);
                 gnorm = sqrt(p[0]);
             }
             if (tid == 0) {
@@ -695,8 +705,8 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                         }
                     }
             }
-            ctl_block_sum<2>(p, lds);
-            if (want_cand) cand = -ctl_block_fmax(-cand, lds);
+            ctl_block_sum<2, true>(p, lds);
+            if (want_cand) cand = -ctl_block_fmax<true>(-cand, lds);
             if (tid == 0) {
                 c.mtb_cand = cand;
                 c.n_hpasses++;
@@ -722,8 +732,8 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                     cand = fmin(v, cand);
                 }
             }
-            ctl_block_sum<2>(p, lds);
-            if (want_cand) cand = -ctl_block_fmax(-cand, lds);
+            ctl_block_sum<2, true>(p, lds);
+            if (want_cand) cand = -ctl_block_fmax<true>(-cand, lds);
             if (c.small_n) {
                 __threadfence_block();
                 __syncthreads();
@@ -752,7 +762,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                 p[1] += isfinite(di) ? 0.0 : 1.0;
                 if (!failed) p[2] = __builtin_fma(vs[i], di, p[2]); // (hessian_inv * direction).dot(direction)
             }
-            ctl_block_sum<3>(p, lds);
+            ctl_block_sum<3, true>(p, lds);
             if (c.small_n) {
                 __threadfence_block();
                 __syncthreads();
@@ -779,7 +789,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                     vx[i] = vx[i] + td;
                 }
             }
-            ctl_block_sum<1>(p, lds);
+            ctl_block_sum<1, true>(p, lds);
             if (tid == 0) {
                 if (hit && memo) { c.f_k = c.f_last; c.have_cur_eval = 1; } else c.have_cur_eval = 0;
                 c.gg_valid = 0;
@@ -807,7 +817,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                         p[3] = __builtin_fma(gn[u], gn[u], p[3]);
                     }
             }
-            ctl_block_sum<4>(p, lds);
+            ctl_block_sum<4, true>(p, lds);
             if (c.small_n) {
                 __threadfence_block();
                 __syncthreads();
@@ -861,7 +871,7 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                         p[3] = __builtin_fma(sv[u] - uv[u], yv[u], p[3]); // SR1: (s - H y).y, sr1_b.rs:145
                     }
             }
-            ctl_block_sum<4>(p, lds);
+            ctl_block_sum<4, true>(p, lds);
             const double yu = p[0], ug = p[1], sg = p[2];
             double c_ss, c_su, c_uu;
             if (method == 0) { const double rho = 1.0 / ys; c_su = -rho; c_ss = rho * rho * yu + rho; c_uu = 0.0; }
@@ -895,8 +905,8 @@ __global__ __launch_bounds__(QN_CTL_TPB) void ctl_step_kernel(QnCtl* __restrict_
                             }
                         }
                 }
-                ctl_block_sum<2>(q, lds);
-                if (c.ls_kind == 2) lazy_cand = -ctl_block_fmax(-lazy_cand, lds);
+                ctl_block_sum<2, true>(q, lds);
+                if (c.ls_kind == 2) lazy_cand = -ctl_block_fmax<true>(-lazy_cand, lds);
             }
             if (tid == 0) {
                 c.n_hpasses++;

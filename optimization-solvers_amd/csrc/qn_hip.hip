@@ -824,6 +824,8 @@ struct qn_solver {
     int gen_slots_hint = 0;    // generic pipelined path: evaluation slots per period the last batch needed (0: none run yet)
     double* s2_gws = nullptr;  // row-sharded log-sum-exp (qn_sym2g.hip.h): the ranks' weights and S of the last evaluation consumed
     double* s2_wgV = nullptr;  // generic objectives: the second table of per-workgroup sums (QnS2Args.wgV)
+    double mtb_cand_keep = INFINITY; // bounded second-generation runs: the step to the box of the direction a warm call continues with
+    bool no_s2bnd = false;     // tests: bounded runs keep the generic path (qn_solver_set_tiling(-14, ..))
     bool h_sliver_whole = false; // the diagonal tiles that sliver rows read are complete (both triangles): kept so by sliver-mode update passes
     double* s2_evS = nullptr;   // row-sharded: [2][world][QN_S2SH_NEC][QN_S2_MAXG] the ranks' evaluation scalars, by launch parity (QnS2Args.evS)
     int *s2_sl_off = nullptr, *s2_sl_idx = nullptr; // row-sharded: per block-row, the slots this rank's tiles write (QnS2Args.sl_off / sl_idx)
@@ -1255,6 +1257,7 @@ extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_sp
     if (rows_per_block == -10) { s->newton_lu_no_la = 1; return QN_OK; } // diagnostics: ... one stream, no look-ahead
     if (rows_per_block == -8) { s->newton_lu_percol = 1; return QN_OK; } // diagnostics: ... with the per-column panel kernels
     if (rows_per_block == -9) { s->no_pair = !s->no_pair; return QN_OK; }     // diagnostics: general evaluation kernel (toggles)
+    if (rows_per_block == -14) { s->no_s2bnd = !s->no_s2bnd; return QN_OK; }   // tests: bounded runs on the generic path (toggles)
     if (rows_per_block == -13) { s->tred = !s->tred; return QN_OK; }         // measurement: the update-reduce in the update-tile launch's tail (toggles)
     if (rows_per_block == -7) { s->no_sliver = !s->no_sliver; return QN_OK; } // diagnostics: sym2 without row slivers (toggles)
     if (rows_per_block == -6) { s->fold = 1; return QN_OK; }           // measurement: sym2 with the folded accept-reduce (see qn_solver::fold)
@@ -1746,6 +1749,7 @@ struct Run {
     bool sym_generic = false; // generic path: the H pass alone on the upper block triangle
     bool sym2 = false;        // second-generation symmetric path (qn_sym2.hip.h)
     bool gobj = false;        // ... in its form for a device objective that is not the quadratic (qn_sym2g.hip.h: the log-sum-exp objective)
+    bool bnd = false;         // ... a bounded run on it (BFGSB / DFPB, MoreThuenteB): one more launch per iteration, s2_dir_kernel (qn_sym2.hip.h)
     bool tiles1 = false;      // the update pass's tiles through the first-generation tile kernel (one workgroup per tile, two per CU) behind a
                               // one-workgroup launch that runs the machine: H's share past the Infinity Cache (see minimize_impl)
     QnS2Args s2{};
@@ -1842,7 +1846,7 @@ static int s2_launch(Run& r, int kind) {
     a.swz = (getenv("QN_S2_SWZ") && a.pair) ? atoi(getenv("QN_S2_SWZ")) : 0; // (only where both items follow from the workgroup index: n = 4096)
 #endif
     r.s2_launches++;
-    const int cls = kind == QN_S2_EVAL ? KC_EVAL : (kind == QN_S2_VEC || kind == QN_S2_VSUM || kind == QN_S2_GCOMB) ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS
+    const int cls = kind == QN_S2_EVAL ? KC_EVAL : (kind == QN_S2_VEC || kind == QN_S2_VSUM || kind == QN_S2_GCOMB || kind == QN_S2_DIR) ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS
                   : (kind == QN_S2_HREDUCE || kind == QN_S2_HSUM) ? KC_HREDUCE : KC_CTL;
     ProfScope ps(s, cls);
     const bool sh = a.sh_world > 1; // row-sharded: the SHARD instantiations (qn_sym2sh.hip.h)
@@ -1851,10 +1855,15 @@ static int s2_launch(Run& r, int kind) {
         if (sh) {
             if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
             else hipLaunchKernelGGL((s2_eval_kernel<false, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        } else if (r.bnd) { // (bounded variants: the same kernels behind the bounded runs' prologue)
+            if (a.pair) hipLaunchKernelGGL((s2_eval_kernel<true, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            else if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, false, true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            else hipLaunchKernelGGL((s2_eval_kernel<false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         } else if (a.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         else if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         else hipLaunchKernelGGL(s2_eval_kernel<false>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         break;
+    case QN_S2_DIR: hipLaunchKernelGGL(s2_dir_kernel, dim3(a.nb), dim3(QN_TB), 0, st, a); break;
     case QN_S2_VSUM:
         if (r.gobj) hipLaunchKernelGGL((s2_advance_kernel<true, true, QN_S2_VSUM>), dim3(1), dim3(128), 0, st, a); // (the machine sees the accepted point; the gather follows)
         else hipLaunchKernelGGL(s2sh_vsum_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
@@ -1922,6 +1931,7 @@ static int s2_launch(Run& r, int kind) {
         if (r.gobj && sh) hipLaunchKernelGGL((s2_advance_kernel<true, true, QN_S2_ADVANCE>), dim3(1), dim3(128), 0, st, a);
         else if (r.gobj) hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_ADVANCE>), dim3(1), dim3(128), 0, st, a);
         else if (sh) hipLaunchKernelGGL(s2_advance_kernel<true>, dim3(1), dim3(128), 0, st, a);
+        else if (r.bnd) hipLaunchKernelGGL((s2_advance_kernel<false, false, QN_S2_ADVANCE, true>), dim3(1), dim3(128), 0, st, a);
         else hipLaunchKernelGGL(s2_advance_kernel<false>, dim3(1), dim3(128), 0, st, a);
         break;
     }
@@ -2891,14 +2901,20 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     h->trace_cap = (int64_t)s->trace_cap;
     h->trace_x = s->trace_x;
     h->bounded = s->bounded;
-    h->req_project = 0; h->last_projected = 0; h->mtb_cand = INFINITY;
+    h->req_project = 0; h->last_projected = 0; s->mtb_cand_keep = h->mtb_cand; h->mtb_cand = INFINITY;
     h->ls_only = ls_only;
     if (ls_only) { h->f_k = ls_f0; h->have_cur_eval = 0; h->have_dir = 0; h->last_valid = 0; }
     h->small_n = (s->n <= QN_SMALL_N && c->world == 1) ? 1 : 0;
     if (h->small_n && h->pending) QNCHK(flush_pending(s));
     // fused fast path: device quadratic, memoised, BFGS/DFP, no callback, one column split, n > 5
+    // Bounded variants (row f4): BFGSB / DFPB and MoreThuenteB run on the second-generation symmetric path when everything that path needs
+    // holds (one rank, whole 128-blocks without padding, a symmetric Q, bitwise symmetric H) -- s2_dir_kernel, qn_sym2.hip.h; BackTrackingB
+    // (projected trial points), SR1B and everything else bounded keep the generic path.  QN_S2_BND=0 switches it off (tests: generic path).
+    const bool s2b = (s->bounded || ls_bounded) && ls->kind != QN_LS_BACKTRACKING_B && !ls_only && c->world == 1 && (s->T.n_pad % QN_TB) == 0 &&
+                     s->T.n_pad >= 8 * QN_TB && (size_t)s->T.n_pad == s->n && !s->no_sym && !s->no_sym2 && !s->h_nonsym && r.obj && r.obj->q_symmetric &&
+                     !s->no_s2bnd && !(getenv("QN_S2_BND") && atoi(getenv("QN_S2_BND")) == 0);
     r.fused = r.oracle_tpl == QN_ORACLE_QUAD && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP) && !callback && s->hcs == 1 &&
-              s->qcs == 1 && !h->small_n && !s->no_fused && !s->bounded && !ls_bounded; // bounded variants (row f4): generic path
+              s->qcs == 1 && !h->small_n && !s->no_fused && (!(s->bounded || ls_bounded) || s2b);
     // ... and the log-sum-exp objective in the structure of the second-generation path (qn_sym2g.hip.h; round 5): one rank, its one-pass
     // evaluation (n <= 16384), whole 128-blocks without padding, a bitwise symmetric H.  Everything else keeps the generic path.
     r.gobj = r.obj && r.obj->kind == OBJ_LOGSUMEXP && r.obj->lse_kch && !r.obj->lse_two_pass && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP) &&
@@ -2929,6 +2945,10 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     // (the second-generation kernels keep no padding entries at zero; row-sharded: the SHARD instantiations, qn_sym2sh.hip.h)
     r.sym2 = r.sym && !s->no_sym2 && (size_t)s->T.n_pad == s->n && (c->world == 1 || c->world <= 64);
     h->sym2 = r.sym2 ? 1 : 0;
+    r.bnd = r.sym2 && (s->bounded || ls_bounded);
+    if ((s->bounded || ls_bounded) && r.fused && !r.bnd) return fail(QN_ABNORMAL_TERMINATION, "bounded run on a fused path that is not the second-generation one");
+    h->s2_dir = r.bnd ? ((s->bounded ? 1 : 0) | (ls->kind == QN_LS_MORETHUENTE_B ? 2 : 0)) : 0;
+    if (r.bnd && ls->kind == QN_LS_MORETHUENTE_B) h->ls_kind = QN_LS_MORETHUENTE; // (the clip of t_max is applied where the direction's request is consumed: from there on it IS More-Thuente)
     // WHICH KERNEL STREAMS THE UPDATE PASS OF A ROW-SHARDED RUN (round 5).  The one-workgroup-per-CU kernel of
     // qn_sym2.hip.h (16-row register windows, the machine in its prologue) was built for n = 4096, where a launch is a twelfth of the
     // iteration.  On one rank of the P = 8, n = 32768 partition -- 4112 tiles, 16 per workgroup, 1074 MB read and written back -- it takes
@@ -2966,7 +2986,10 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             h->xc = 0; h->sc = 0;
         } // (else: a fused run left them there; xc / sc in the control block say which halves are current)
         h->warm = (s->fused_live && s->warm_obj != 0 && s->warm_obj == r.obj->serial && h->memoize && h->pending && !ls_only) ? 1 : 0;
-        if (!h->warm) { h->dir_mode = 0; h->gd0_valid = 0; }
+        if (!h->warm) { h->dir_mode = 0; h->gd0_valid = 0; h->dir_ready = 0; }
+        if (!r.bnd) h->dir_ready = 0;
+        // (a warm bounded call whose direction has been through its request keeps mtb_cand: the machine clips this call's t_max with it)
+        if (r.bnd && h->dir_ready) h->mtb_cand = s->mtb_cand_keep;
     } else {
         h->warm = 0;
     }
@@ -2999,6 +3022,9 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.sh_nsum = c->use_allreduce ? 1 : c->world;
         a.evS = s->s2_evS; a.xg = s->symsh_xg; a.sl_off = s->s2_sl_off; a.sl_idx = s->s2_sl_idx;
         if (c->world > 1 || r.gobj) { a.fold = 0; a.pair = 0; }
+        if (r.bnd) a.fold = 0;
+        a.lb = (r.bnd && s->bounded) ? s->V.lb : nullptr; a.ub = (r.bnd && s->bounded) ? s->V.ub : nullptr;
+        a.llb = (r.bnd && ls_bounded) ? s->V.llb : nullptr; a.lub = (r.bnd && ls_bounded) ? s->V.lub : nullptr;
         if (r.tiles1) a.fold = 0;
         // tail reduce (s2_hpass_kernel<.., TRED>): the update-reduce in the tail of the update-tile launch, 4 launches per iteration
         // instead of 5 -- one rank, lists short enough for one wave to announce (n <= ~15 k).  BUILT, BIT-IDENTICAL, SLOWER, OFF BY
@@ -3053,6 +3079,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 if (h->serviced != 0 && !tiles_done) return fail(QN_ABNORMAL_TERMINATION, "sym2: request in an unexpected service state");
                 if (ph == QN_PH_REQ_EVAL) QNCHK(s2_do_eval(r));
                 else if (ph == QN_PH_REQ_VEC) QNCHK(s2_do_vec(r));
+                else if (ph == QN_PH_REQ_DIR && r.bnd) QNCHK(s2_launch(r, QN_S2_DIR));
                 else if (ph == QN_PH_REQ_HPASS) QNCHK(s2_do_hpass(r, !tiles_done));
                 else return fail(QN_ABNORMAL_TERMINATION, "sym2: control block in an unexpected phase");
                 QNCHK(s2_launch(r, QN_S2_ADVANCE));
@@ -3066,7 +3093,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             int slots = (ls->kind == QN_LS_MORETHUENTE) ? 2 : 4;
             // (generic objective: an unused evaluation slot is three launches that find nothing to do, and on such objectives More-Thuente
             // takes t = 1 almost every time -- the pattern is sized like the sharded one: one slot to start with, then what the run has needed)
-            const bool adaptive = r.s2.sh_world > 1 || r.gobj;
+            const bool adaptive = r.s2.sh_world > 1 || r.gobj || r.bnd; // (bounded: MoreThuenteB's clipped first step is often the accepted one)
             if (adaptive) slots = s->s2_slots_hint ? s->s2_slots_hint : (r.gobj ? 1 : 2);
             bool first = true;
             uint64_t ev0 = 0, it0 = 0;
@@ -3091,6 +3118,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 const int64_t periods = std::min<int64_t>(remaining + ((first && !h->warm) ? 1 : 0), 256);
                 first = false;
                 for (int64_t p = 0; p < periods; ++p) {
+                    if (r.bnd) QNCHK(s2_launch(r, QN_S2_DIR)); // (the direction the period's evaluations search along: stored, projected)
                     for (int e = 0; e < slots; ++e) QNCHK(s2_do_eval(r));
                     if (!r.s2.fold && !(r.gobj && r.s2.sh_world == 1)) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise; generic objective: staged by every evaluation's combine launch)
                     QNCHK(s2_do_hpass(r, true));

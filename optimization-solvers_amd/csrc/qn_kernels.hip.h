@@ -471,19 +471,25 @@ __global__ void identity_fill_kernel(double* __restrict__ H, const QnTile T) {
 // ------------------------------------------------------------------------------------------------
 // control workgroup helpers
 // ------------------------------------------------------------------------------------------------
-template <int K>
+// LDS_ONLY (ctl_step_kernel): the two barriers order the workgroup's LDS traffic and nothing else.  __syncthreads() also waits for every
+// global store of the wave to be acknowledged -- a memory round trip (1.5-2 us on bytes another XCD's kernel has just written) in front of each
+// of a vector state's sums, which the control kernel does not need: inside one launch an entry of an n-vector is only ever touched by thread
+// (i mod blockDim) -- program order -- and the states are separated by the loop's own __syncthreads().  In-kernel stamps at n = 4096,
+// bounded run: the two-sweep state behind an update pass 15.6 us, the one-sweep state behind an evaluation 7.3 us (tools/ctl_stamps_bounded.py).
+__device__ __forceinline__ void qn_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int K, bool LDS_ONLY = false>
 __device__ __forceinline__ void ctl_block_sum(double (&v)[K], double* lds /* 16*K */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         v[k] = qn_wave_sum(v[k]);
     }
-    __syncthreads();
+    if (LDS_ONLY) qn_lds_barrier(); else __syncthreads();
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
     }
-    __syncthreads();
+    if (LDS_ONLY) qn_lds_barrier(); else __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         double t = 0.0;
@@ -492,13 +498,14 @@ __device__ __forceinline__ void ctl_block_sum(double (&v)[K], double* lds /* 16*
     }
 }
 
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ double ctl_block_fmax(double v, double* lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    __syncthreads();
+    if (LDS_ONLY) qn_lds_barrier(); else __syncthreads();
     if (lane == 0) lds[wave] = v;
-    __syncthreads();
+    if (LDS_ONLY) qn_lds_barrier(); else __syncthreads();
     double t = -INFINITY;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, lds[w]);
     return t;
@@ -561,7 +568,7 @@ __device__ __forceinline__ void tr_push_case(QnCtl& c, int digit) {
 
 // One oracle call of the reference's sequence at x + t d.  With memoisation a call whose point was already
 // evaluated is answered from the memo (the values are identical; see include/qn_hip.h qn_oracle.memoize).
-template <bool LEAN = false>
+template <int LEAN = 0>
 __device__ __forceinline__ void req_eval_t(QnCtl& c, double t, int after_state, int need_vectors, int project = 0) {
     c.n_oracle_calls++;
     c.tr_n_evals++;

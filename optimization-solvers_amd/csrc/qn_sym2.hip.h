@@ -58,8 +58,9 @@
 
 enum { QN_S2_ADVANCE = 0, QN_S2_EVAL = 1, QN_S2_VEC = 2, QN_S2_HTILE = 3, QN_S2_HREDUCE = 4,
        QN_S2_VSUM = 5, QN_S2_HSUM = 6, // (row-sharded runs, qn_sym2sh.hip.h: this rank's slot sums, in front of the exchange of an n-vector)
-       QN_S2_GEVAL_A = 7, QN_S2_GCOMB = 8, QN_S2_GHT_A = 9 }; // (generic objectives, qn_sym2g.hip.h: the machine in a one-workgroup launch in
-                                                                // front of many-workgroup kernels that only READ the control block)
+       QN_S2_GEVAL_A = 7, QN_S2_GCOMB = 8, QN_S2_GHT_A = 9, // (generic objectives, qn_sym2g.hip.h: the machine in a one-workgroup launch in
+                                                             // front of many-workgroup kernels that only READ the control block)
+       QN_S2_DIR = 10 }; // (bounded variants: s2_dir_kernel)
 
 struct QnS2Args {
     const double* Q;
@@ -116,6 +117,8 @@ struct QnS2Args {
     double gmu;          // ... log-sum-exp: mu (row-sharded runs: the prologue puts the ranks' (m, S, G'd) together itself)
     double* gws;         // ... [sh_world + 1]: the ranks' weights w_r = exp(m_r - M) and S of the LAST evaluation the machine consumed (written
                          //     by that prologue, read by s2g_vec_kernel when the point is accepted)
+    const double *lb, *ub;   // bounded variants (s2_dir_kernel): the solver's box (BFGSB / DFPB; null: none) ...
+    const double *llb, *lub; // ... and the line search's (MoreThuenteB; null: none)
 #ifdef QN_S2_STAMPS
     unsigned long long* dbg; // diagnostic build: dbg[((slot % 64) * 256 + workgroup) * 16 + k] = wall clock (10 ns) at stamp k
     int slot;
@@ -147,6 +150,7 @@ struct QnS2Lds {
 // (Measured again and dropped, round 3: the machine as ONE out-of-line function, now called from wave 0's prologue where no tile
 // window is live -- one copy of its code for the five kernels instead of five.  The call frame lives in scratch memory (400 bytes
 // per lane) and the machine then takes 8.4 us instead of 4-5: 11.0 k it/s against 12.3 k inlined, same box.)
+template <bool BND = false> // (BND: the bounded variants' machine -- LEAN == 2, qn_ctl_step.hip.h -- and their QN_PH_REQ_DIR)
 __device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const QnVecs& V, const bool leader, double* scratch, const bool resume) {
     const int ph = c.phase;
     bool run = resume; // (resume: the machine had stopped for the x-trace copy)
@@ -178,6 +182,11 @@ __device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const
             } else if (ph == QN_PH_REQ_HPASS) {
                 if (c.hp_nrhs == 2) { c.hp_yu = tot[0]; c.hp_ug = tot[1]; }
                 c.state = c.after_state;
+            } else if (BND && ph == QN_PH_REQ_DIR) { // VV holds -d (stored, projected): the evaluations form x + t d as they do for a first direction
+                c.mtb_cand = tot[0];                // (the MINIMUM over the block-rows: the prologue folds this request's column that way)
+                if (c.s2_dir & 2) c.mt_tmax = fmin(c.mt_tmax, c.mtb_cand); // morethuente_b.rs:201: self.t_max = self.t_max.min(candidate) -- persists
+                c.dir_mode = 0; c.dir_ready = 1;
+                c.state = c.after_state;
             } else {
                 return;
             }
@@ -185,7 +194,7 @@ __device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const
             run = true;
         }
     }
-    if (run) ctl_scalar_run<true>(c, V, scratch, leader); // (ONE call site: the machine is inlined, and it is large; LEAN: qn_ctl_step.hip.h)
+    if (run) ctl_scalar_run<BND ? 2 : 1>(c, V, scratch, leader); // (ONE call site: the machine is inlined, and it is large; LEAN: qn_ctl_step.hip.h)
     // Folded accept-reduce: the launch that formed g+, y, s of the accepted point ran the update tiles as well, BEFORE the machine
     // had seen ||s||, ||y|| (the tiles only need the vectors and the coefficients of the PENDING update, all known then).  Now that
     // the machine has consumed those sums: if it asks for exactly that pass, its tiles are done (the reduce launch is what is left);
@@ -253,8 +262,9 @@ struct QnS2NoEarly { __device__ __forceinline__ void operator()() const {} };
 // GOBJ (generic objectives, qn_sym2g.hip.h): an evaluation's sums come from its combine launch -- a.gw rows -- which has ALSO staged the
 // vectors of the evaluated point (g+, y, x+, s) and their five sums (table columns QN_S2_VCOL ..): when the machine accepts the point
 // and asks for them (QN_PH_REQ_VEC), this prologue hands them over at once and lets the machine go on -- no launch in between.
-template <int KIND, bool SHARD = false, class Early = QnS2NoEarly, bool GOBJ = false>
+template <int KIND, bool SHARD = false, class Early = QnS2NoEarly, bool GOBJ = false, bool BND = false>
 __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L, Early&& early = Early()) {
+    static_assert(!(BND && (SHARD || GOBJ)), "the bounded variants run on one rank, on the quadratic");
     const int lane = threadIdx.x; // (wave 0)
     const bool leader = blockIdx.x == 0;
     constexpr int NW = (int)(sizeof(QnCtl) / 8);
@@ -419,6 +429,15 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
             for (int k = 0; k < QN_S2_NR; ++k) totv[k] = qn_lane_bcast(av[0], 8 * k);
         }
     }
+    if constexpr (BND) if (c.serviced == 2 && ph == QN_PH_REQ_DIR) { // (uniform) column 0 of s2_dir_kernel's rows: the MINIMUM (morethuente_b.rs:198)
+        double m = INFINITY;
+#pragma unroll
+        for (int j = 0; j < QN_S2_PCH; ++j) m = fmin(m, (j * 64 + lane < a.nb) ? tr[j][0] : INFINITY);
+        for (int b = QN_S2_MAXG + lane; b < a.nb; b += 64) m = fmin(m, T[b]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+        tot[0] = m;
+    }
     QN_S2_STAMP(10);
     QnVecs V{};
     V.n = a.n; V.n_pad = a.np; V.trace = a.trace;
@@ -429,7 +448,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
         for (int guard = 0; guard < 64; ++guard) { // (the n <= 5 reference-order code of the machine is never reached on this path: no scratch)
             int need_x = 0;
             if (lane == 0) {
-                qn_s2_advance(c, tot, V, leader, &L.red[0][0], guard > 0);
+                qn_s2_advance<BND>(c, tot, V, leader, &L.red[0][0], guard > 0);
                 need_x = c.phase == QN_PH_RUNNING && c.state == QN_ST_ITER_END;
             }
             need_x = __builtin_amdgcn_readfirstlane(need_x);
@@ -475,6 +494,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
             else if (c.phase == QN_PH_REQ_HPASS && c.serviced == 0) mine = 1;
         }
         if (KIND == QN_S2_HREDUCE) mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 1;
+        if (KIND == QN_S2_DIR) mine = c.phase == QN_PH_REQ_DIR && c.serviced == 0;
         if (KIND == QN_S2_GEVAL_A) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == 0;  // (generic objectives: the kernels that follow
         if (KIND == QN_S2_GHT_A) mine = c.phase == QN_PH_REQ_HPASS && c.serviced == 0;   //  read `serviced == 1` as "yours")
         if (c.phase == QN_PH_RUNNING) { c.status = 4; c.phase = QN_PH_DONE; } // a state this path cannot service: abort, never spin
@@ -777,7 +797,9 @@ __device__ __forceinline__ double qn_s2_eval_sliver(const QnS2SliverVec& v, cons
 // run sits in the next kernel's prologue, behind its launch latency).  On top, a second inlined copy of the machine and the
 // window held across it cost the row loops their registers (256 + scratch: the two evaluations' arithmetic took 10-12 us instead of
 // 4.5).  Even with a 2.8 us hierarchical barrier (tools/seam_probe.hip) and no spills the sum comes out level with three launches.
-template <bool PAIR, bool SHARD = false, bool NTQ = false>
+// BND (bounded variants): the same kernel behind the bounded runs' prologue -- their machine and the request that stores the direction
+// (s2_dir_kernel); the evaluation itself is the unbounded one's with a stored direction (dir_mode 0).
+template <bool PAIR, bool SHARD = false, bool NTQ = false, bool BND = false>
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a) {
     static_assert(!(PAIR && SHARD), "the two-items-and-a-sliver instance is the single-rank n = 4096 one");
     __shared__ QnS2Lds L;
@@ -817,7 +839,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     };
     unsigned cw = 0u;
     if (wave == 0) {
-        qn_s2_prologue_w0<QN_S2_EVAL, SHARD>(a, L, vec_spec);
+        qn_s2_prologue_w0<QN_S2_EVAL, SHARD, decltype(vec_spec)&, false, BND>(a, L, vec_spec);
     } else {
         if (wave <= 4) cw = qn_code_warm_issue((wave - 1) * 64 + lane); // (qn_kernels.hip.h, CODE WARM-UP: 32 KB)
         window_load(ij0);
@@ -1697,12 +1719,57 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_place_probe_kernel(double* __
 
 // synchronous mode: the prologue alone (one workgroup)
 // (GOBJ / KIND: generic objectives -- the prologue-only launch in front of an evaluation's or an update pass's many-workgroup kernels)
-template <bool SHARD = false, bool GOBJ = false, int KIND = QN_S2_ADVANCE>
+template <bool SHARD = false, bool GOBJ = false, int KIND = QN_S2_ADVANCE, bool BND = false>
 __global__ __launch_bounds__(128) void s2_advance_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
-    if (threadIdx.x < 64) qn_s2_prologue_w0<KIND, SHARD, QnS2NoEarly, GOBJ>(a, L);
+    if (threadIdx.x < 64) qn_s2_prologue_w0<KIND, SHARD, QnS2NoEarly, GOBJ, BND>(a, L);
     __syncthreads();
     qn_s2_ctl_out(a, L);
+}
+
+// BOUNDED VARIANTS (round 5): BFGSB / DFPB and MoreThuenteB in this structure.
+// What a bounded run does differently from the unbounded one (bfgs_b.rs:66-77, morethuente_b.rs:185-201): its direction is
+// P(x - H g) - x, not -H g, and MoreThuenteB clips t_max by the step at which x + t d leaves its box -- a minimum over the entries --
+// before it starts; after that it IS More-Thuente.  Both are O(n) work on the direction, which this path otherwise never stores (the
+// evaluations form -H+ g+ on the fly from v, s, u and five scalars).  So a bounded run gets ONE more launch per iteration, this one, in front
+// of its evaluations: its prologue runs the machine up to the new direction (QN_PH_REQ_DIR, qn_ctl_step.hip.h LEAN == 2), block-row R forms
+// the lazy direction at its 128 entries, projects it, stores VV <- -d -- from here on the direction is a STORED one, which is what
+// dir_mode 0 means to every other kernel: they run unchanged -- and leaves the block-row's minimal step to the box in the table; the next
+// prologue folds that column with fmin and clips t_max.  (The generic path did this in its one-workgroup control kernel, which streams
+// 1 MB of n-vectors per iteration through ONE CU: 39 of a bounded iteration's 95 us at n = 4096, tools/ctl_stamps_bounded.py.)
+__global__ __launch_bounds__(QN_TB) void s2_dir_kernel(const QnS2Args a) {
+    __shared__ QnS2Lds L;
+    __shared__ double red[2];
+    const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gi = R * QN_TB + tid;
+    const size_t np = (size_t)a.np;
+    // (requested before the machine runs, for both settings of the two buffer toggles: see s2_vec_kernel)
+    double x0 = 0.0, x1 = 0.0, s0 = 0.0, s1 = 0.0, vv = 0.0, un = 0.0, lbi = -INFINITY, ubi = INFINITY, llbi = -INFINITY, lubi = INFINITY;
+    auto entries = [&]() {
+        x0 = a.F.X0[gi]; x1 = a.F.X0[np + gi]; s0 = a.F.S0[gi]; s1 = a.F.S0[np + gi]; vv = a.F.VV[gi]; un = a.F.UN[gi];
+        if (a.lb) { lbi = a.lb[gi]; ubi = a.ub[gi]; }
+        if (a.llb) { llbi = a.llb[gi]; lubi = a.lub[gi]; }
+    };
+    if (wave == 0) qn_s2_prologue_w0<QN_S2_DIR, false, decltype(entries)&, false, true>(a, L, entries);
+    else entries();
+    __syncthreads();
+    qn_s2_ctl_out(a, L);
+    if (!L.mine) return;
+    const QnCtl& c = L.c;
+    const double xi = c.xc ? x1 : x0, si = c.sc ? s1 : s0;
+    // the lazy direction as the evaluations would have formed it (qn_s2_trial, qn_s2_eval_req) ...
+    const double al = c.c_su * c.dir_ug + c.c_ss * c.dir_sg, be = c.c_su * c.dir_sg + c.c_uu * c.dir_ug;
+    const double w = c.dir_mode ? (vv + __builtin_fma(be, un, al * si)) : vv; // H g
+    double di = -w;
+    if (c.s2_dir & 1) { double t = xi - w; t = fmin(fmax(t, lbi), ubi); di = t - xi; } // bfgs_b.rs:72-75: P(x - H g) - x
+    a.F.VV[gi] = -di;
+    double cand = INFINITY; // morethuente_b.rs:185-198
+    if (c.s2_dir & 2) { if (di > 0.0) cand = (lubi - xi) / di; else if (di < 0.0) cand = (llbi - xi) / di; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cand = fmin(cand, __shfl_xor(cand, off, 64));
+    if (lane == 0) red[wave] = cand;
+    __syncthreads();
+    if (tid == 0) a.wgS[((size_t)a.parity * QN_S2_ROW + 0) * a.trows + R] = fmin(red[0], red[1]);
 }
 
 // lower triangle <- transpose of the maintained upper one, 32 x 32 blocks through LDS; inside the diagonal blocks too

@@ -117,3 +117,70 @@ def test_bounded_run_to_termination_matches_oracle(qn, qo, method):
     active = np.isclose(x, lb) | np.isclose(x, ub)
     active_ref = np.isclose(ref.x, lb) | np.isclose(ref.x, ub)
     assert active.sum() >= n // 4 and np.array_equal(active, active_ref)
+
+
+@pytest.mark.parametrize("method", ["bfgsb", "dfpb"])
+@pytest.mark.parametrize("lsname", ["mt", "mtb"])
+@pytest.mark.parametrize("n", [1024, 1408])
+def test_bounded_second_generation_path_vs_oracle_and_generic(qn, qo, method, lsname, n):
+    """BFGSB / DFPB with More-Thuente(B) on the second-generation symmetric path (s2_dir_kernel, qn_sym2.hip.h: the direction stored and
+    projected by one more launch per iteration, t_max clipped where that request is consumed): against the oracle's restatement, against the
+    generic path (qn_solver_set_tiling(-14, 0)), and pipelined against synchronous bit for bit."""
+    q, b, x0, lb, ub = _box(qo, n)
+    iters = 25
+    ref = qo.Solver({"bfgsb": qo.BFGS, "dfpb": qo.DFP}[method], 1e-9, x0)
+    ref.set_bounds(lb, ub)
+    ls_ref = _make_ls(qo, lsname, n, lb, ub)
+    ref.minimize(ls_ref, qo.QuadraticOracle(q, b), iters, 30, trace_cap=iters, trace_x=True)
+    cls = {"bfgsb": qn.BFGSB, "dfpb": qn.DFPB}[method]
+    obj = qn.Quadratic(q, b)
+    runs = {}
+    for mode in ("pipelined", "sync", "generic"):
+        s = cls.new(1e-9, x0, lb, ub)
+        s.set_trace(iters, with_x=True)
+        if mode == "sync":
+            s.set_sync_mode(1)
+        if mode == "generic":
+            s.set_tiling(-14, 0)
+        ls = _make_ls(qn, lsname, n, lb, ub)
+        try:
+            s.minimize(ls, obj, iters, 30)
+        except qn.MaxIterReached:
+            pass
+        tr, xs = s.trace()
+        st = s.stats()
+        runs[mode] = (tr, xs, s.x(), ls.t_max() if lsname == "mtb" else None, st)
+        assert bool(st["path"] & 16) == (mode != "generic"), (mode, st["path"])  # QN_PATH_SYM2
+        x = s.x()
+        assert np.all(x >= lb - 1e-12) and np.all(x <= ub + 1e-12)
+        w = min(len(tr), len(ref.trace), 20)
+        assert w >= min(10, len(ref.trace))
+        for k in range(w):
+            assert tr[k]["n_evals"] == ref.trace[k]["n_evals"], (mode, k)
+            assert abs(tr[k]["t"] - ref.trace[k]["t"]) <= 1e-8 * abs(ref.trace[k]["t"]), (mode, k)
+            assert np.linalg.norm(xs[k] - ref.trace_x[k]) <= 1e-8 * max(1.0, np.linalg.norm(ref.trace_x[k])), (mode, k)
+        if lsname == "mtb":
+            assert abs(ls.t_max() - ls_ref.t_max) <= 1e-8 * max(1.0, abs(ls_ref.t_max)), mode
+    assert np.array_equal(runs["pipelined"][2], runs["sync"][2]) and np.array_equal(runs["pipelined"][1], runs["sync"][1])
+    assert runs["pipelined"][3] == runs["sync"][3]
+    # one launch more per iteration than the unbounded pattern, and no host round trip per request
+    st = runs["pipelined"][4]
+    assert st["host_syncs"] <= 6
+
+
+def test_bounded_second_generation_path_continues_across_calls(qn, qo):
+    """Two calls of 8 iterations = one of 16 (the second call continues warm: the stored direction and its step to the box carry over)."""
+    n = 1024
+    q, b, x0, lb, ub = _box(qo, n)
+    obj = qn.Quadratic(q, b)
+    outs = []
+    for split in (False, True):
+        s = qn.BFGSB.new(1e-9, x0, lb, ub)
+        ls = _make_ls(qn, "mtb", n, lb, ub)
+        for k in ((8, 8) if split else (16,)):
+            try:
+                s.minimize(ls, obj, k, 30)
+            except qn.MaxIterReached:
+                pass
+        outs.append((s.x(), ls.t_max()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
