@@ -824,6 +824,8 @@ struct qn_solver {
     int gen_slots_hint = 0;    // generic pipelined path: evaluation slots per period the last batch needed (0: none run yet)
     double* s2_gws = nullptr;  // row-sharded log-sum-exp (qn_sym2g.hip.h): the ranks' weights and S of the last evaluation consumed
     double* s2_wgV = nullptr;  // generic objectives: the second table of per-workgroup sums (QnS2Args.wgV)
+    hipGraphExec_t s2_graph_exec = nullptr; // measurement (QN_S2_GRAPH): two periods of the pipelined pattern as one graph, and what it was captured for
+    QnS2Args s2_graph_args{}; int s2_graph_slots = 0, s2_graph_bnd = 0; uint64_t s2_graph_len = 0, s2_graph_stat = 0;
     double mtb_cand_keep = INFINITY; // bounded second-generation runs: the step to the box of the direction a warm call continues with
     bool no_s2bnd = false;     // tests: bounded runs keep the generic path (qn_solver_set_tiling(-14, ..))
     bool h_sliver_whole = false; // the diagonal tiles that sliver rows read are complete (both triangles): kept so by sliver-mode update passes
@@ -1020,7 +1022,8 @@ static int solver_alloc_sym2(qn_solver* s) {
     const int cfg = (s->fold ? 1 : 0) | (s->no_sliver ? 2 : 0) | (sharded ? 4 : 0);
     if (s->s2_nb != nb || s->s2_sl_cfg != cfg) {
         (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE);
-        (void)hipFree(s->s2_evS); (void)hipFree(s->s2_cnt);
+        if (s->s2_graph_exec) (void)hipGraphExecDestroy(s->s2_graph_exec);
+    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_cnt);
         s->s2_items = nullptr; s->s2_wgS = nullptr; s->s2_partE = nullptr;
         s->s2_evS = nullptr; s->s2_cnt = nullptr;
         s->s2_nb = 0;
@@ -3117,12 +3120,48 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 // a last evaluation launch whose prologue finds the iteration cap reached and writes DONE
                 const int64_t periods = std::min<int64_t>(remaining + ((first && !h->warm) ? 1 : 0), 256);
                 first = false;
-                for (int64_t p = 0; p < periods; ++p) {
+                auto one_period = [&]() -> int {
                     if (r.bnd) QNCHK(s2_launch(r, QN_S2_DIR)); // (the direction the period's evaluations search along: stored, projected)
                     for (int e = 0; e < slots; ++e) QNCHK(s2_do_eval(r));
                     if (!r.s2.fold && !(r.gobj && r.s2.sh_world == 1)) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise; generic objective: staged by every evaluation's combine launch)
                     QNCHK(s2_do_hpass(r, true));
+                    return QN_OK;
+                };
+                int64_t p = 0;
+                // MEASUREMENT (QN_S2_GRAPH=1; tools/README.md): the periods behind the first one as launches of ONE captured hipGraph of two
+                // periods (an even number of launches, so the control block's parity repeats; the first period carries ctl_first, the
+                // reporting launch stays outside).  Single rank, quadratic objective, profiling off.
+                static const bool want_graph = getenv("QN_S2_GRAPH") && atoi(getenv("QN_S2_GRAPH")) != 0;
+                if (want_graph && c->world == 1 && !r.gobj && !s->profiling && periods >= 3) {
+                    QNCHK(one_period()); ++p;
+                    const uint64_t l0 = r.s2_launches;
+                    if ((l0 & 1) != 0) { QNCHK(one_period()); ++p; } // (start the captured pair on an even launch count)
+                    if (periods - p >= 2) {
+                        const uint64_t lbase = r.s2_launches, stat0 = s->stats.launches;
+                        const bool reuse = s->s2_graph_exec && memcmp(&s->s2_graph_args, &r.s2, sizeof(QnS2Args)) == 0 && s->s2_graph_slots == slots && s->s2_graph_bnd == (int)r.bnd;
+                        if (!reuse) {
+                            if (s->s2_graph_exec) { (void)hipGraphExecDestroy(s->s2_graph_exec); s->s2_graph_exec = nullptr; }
+                            hipGraph_t g = nullptr;
+                            HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                            int rc = one_period(); if (rc == QN_OK) rc = one_period();
+                            const hipError_t e = hipStreamEndCapture(c->stream, &g);
+                            if (rc != QN_OK) return rc;
+                            HIPCHK(e);
+                            HIPCHK(hipGraphInstantiate(&s->s2_graph_exec, g, nullptr, nullptr, 0));
+                            (void)hipGraphDestroy(g);
+                            s->s2_graph_args = r.s2; s->s2_graph_slots = slots; s->s2_graph_bnd = (int)r.bnd;
+                            s->s2_graph_len = r.s2_launches - lbase; s->s2_graph_stat = s->stats.launches - stat0;
+                            r.s2_launches = lbase; s->stats.launches = stat0; // (captured, not run)
+                        }
+                        if ((s->s2_graph_len & 1) == 0) {
+                            for (; periods - p >= 2; p += 2) {
+                                HIPCHK(hipGraphLaunch(s->s2_graph_exec, c->stream));
+                                r.s2_launches += s->s2_graph_len; s->stats.launches += s->s2_graph_stat;
+                            }
+                        }
+                    }
                 }
+                for (; p < periods; ++p) QNCHK(one_period());
                 seq = ++s->rep_seq; // (the batch's last launch reports: the evaluation launch below)
                 QNCHK(s2_do_eval(r, seq));
             }
