@@ -1,4 +1,4 @@
-"""Diagnostic: in-kernel time stamps of ctl_step on a BOUNDED run (BFGSB + MoreThuenteB, the box of tools/bench_bounded.py); needs
+"""Diagnostic: in-kernel time stamps of ctl_step on a BOUNDED run of the GENERIC path (BFGSB + MoreThuenteB, the box of tools/bench_bounded.py); needs
 optimization-solvers_amd/lib/libqn_hip_ctlstamps.so built with -DQN_CTL_STAMPS.  usage: ctl_stamps_bounded.py [n]"""
 import ctypes as C, os, sys
 import numpy as np
@@ -21,6 +21,7 @@ k4 = max(1, n // 4)
 lb[:k4] = xs[:k4] + 0.2
 ub[:k4] = xs[:k4] + 1.0
 s = qn.BFGSB.new(1e-10, x0, lb, ub)
+s.set_tiling(-14, 0)  # the generic path (bounded runs of this shape default to the second-generation one since round 5)
 ls = qn.MoreThuenteB.new(n).with_lower_bound(lb).with_upper_bound(ub)
 L = A.lib()
 L.qn_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
