@@ -128,10 +128,12 @@ def test_bounded_second_generation_path_vs_oracle_and_generic(qn, qo, method, ls
     generic path (qn_solver_set_tiling(-14, 0)), and pipelined against synchronous bit for bit."""
     q, b, x0, lb, ub = _box(qo, n)
     iters = 25
-    ref = qo.Solver({"bfgsb": qo.BFGS, "dfpb": qo.DFP}[method], 1e-9, x0)
+    # (the oracle's rank-2 form of the update -- pinned against the as-written one by the CPU tests -- on all host threads: the as-written
+    # update is five n x n products per iteration)
+    ref = qo.Solver({"bfgsb": qo.BFGS, "dfpb": qo.DFP}[method], 1e-9, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
     ref.set_bounds(lb, ub)
     ls_ref = _make_ls(qo, lsname, n, lb, ub)
-    ref.minimize(ls_ref, qo.QuadraticOracle(q, b), iters, 30, trace_cap=iters, trace_x=True)
+    ref.minimize(ls_ref, qo.QuadraticOracle(q, b, nthreads=qo.max_threads()), iters, 30, trace_cap=iters, trace_x=True)
     cls = {"bfgsb": qn.BFGSB, "dfpb": qn.DFPB}[method]
     obj = qn.Quadratic(q, b)
     runs = {}
