@@ -639,6 +639,12 @@ __device__ __forceinline__ void qn_s2_eval_vec_load(const QnS2Args& a, const dou
     v.x_c = ld2(x + jc); v.v_c = ld2(a.F.VV + jc); v.s_c = ld2(sp + jc); v.u_c = ld2(a.F.UN + jc);
 }
 
+__device__ __forceinline__ void qn_s2_evalvec_touch(const QnS2EvalVec& v) { // (a use of every entry: the compiler waits for their loads here)
+    qn_keepalive(v.x_r); qn_keepalive(v.v_r); qn_keepalive(v.s_r); qn_keepalive(v.u_r); qn_keepalive(v.b_r); qn_keepalive(v.g_r);
+    qn_keepalive(v.x_c.x); qn_keepalive(v.x_c.y); qn_keepalive(v.v_c.x); qn_keepalive(v.v_c.y);
+    qn_keepalive(v.s_c.x); qn_keepalive(v.s_c.y); qn_keepalive(v.u_c.x); qn_keepalive(v.u_c.y);
+}
+
 // One item of the evaluation: the wave's 16 rows against the trial point, folded.
 // CONDITIONING (round 3).  f = 1/2 xt'Q xt - b'xt and g(xt)'d = d'Q xt - b'd are what the line search reads.  Round 2 summed
 // xt'Q xt, b'xt, d'Q xt and b'd separately and subtracted the totals: each pair is a difference of two sums of size ~ ||b|| ||d||
@@ -838,15 +844,8 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         for (int r = 0; r < QN_S2_RPW; ++r) h[r] = qn_sym_ld<NTQ>(qb + (size_t)r * np);
     };
     unsigned cw = 0u;
-    if (wave == 0) {
-        qn_s2_prologue_w0<QN_S2_EVAL, SHARD, decltype(vec_spec)&, false, BND>(a, L, vec_spec);
-    } else {
-        if (wave <= 4) cw = qn_code_warm_issue((wave - 1) * 64 + lane); // (qn_kernels.hip.h, CODE WARM-UP: 32 KB)
-        window_load(ij0);
-        vec_spec();
-    }
-    const int ij1 = qn_s2_second_item(a); // the second item: what the parked window is refilled from (after the first requests: nothing in front of them)
-    const bool parked = PAIR || ij1 >= 0; // (uniform) a workgroup with one item parks nothing
+    int ij1;     // the second item: what the parked window is refilled from (looked up after the first requests: nothing in front of them)
+    bool parked; // (uniform) a workgroup with one item parks nothing
     // PARKING.  The prologue of wave 0 -- one memory round trip, the sums of 256 rows, the state machine on one lane -- takes
     // 6-9 us, and the 128 KB register window lands in 5.  Round 2 let the memory system idle until the decision was there.
     // Now waves 1..7 move each row of the first item into LDS the moment it arrives and request the same row of the SECOND item
@@ -854,29 +853,62 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     // item is then consumed from LDS and the second from registers.  Wave 0's sixteen rows of the first item are fetched and
     // parked by the other waves too (three rows each, behind their own): a wave that asked for its rows only after the
     // prologue was 3 us behind the rest at the pair's barrier (in-kernel time stamps).
-    if (parked && wave != 0) {
-        const int I1 = ij1 >> 16, J1 = ij1 & 0xffff;
-        const double* q1 = a.Q + (size_t)(qn_s2_lrow<SHARD>(a, I1) * QN_TB + wave * QN_S2_RPW) * np + (size_t)J1 * QN_TB + qn_s2_col(I1 == J1, lane, wave);
-        // (wave 0's rows are requested BEFORE the second item's: a wave's loads return in order, and behind the refills these three
-        // -- which the barrier below waits for -- arrived with the last byte of the second window, 9.5 us into the kernel: the
-        // workgroup then started on the first item when both had landed, however early the machine was done)
-        const int I0 = ij0 >> 16, J0 = ij0 & 0xffff;
-        const double* q0 = a.Q + (size_t)(qn_s2_lrow<SHARD>(a, I0) * QN_TB) * np + (size_t)J0 * QN_TB + 2 * lane; // wave 0's rows: no clone lanes (qn_s2_col(., ., 0) = 2 lane)
-        const int r0 = (wave - 1) * 3;
-        v2d t3[3];
+    // Measured and dropped, round 5 (tools/experiments/r05_eval_first_item_by_lds_dma.patch): THE FIRST ITEM STRAIGHT INTO LDS --
+    // global_load_lds_dwordx4, lane l's 16 bytes land at row + 16 l, which is the park's layout: no registers, no copy -- and the second item into
+    // the register window right behind it, 245 KB per CU requested from entry on.  Bit-identical, and 15.3 us against 15.0-15.1: a wave that has
+    // filled its share of the CU's memory queue is held at its next request until the queue drains, so "requested from entry on" is not what
+    // happens -- in-kernel stamps: the first item's nineteen requests per wave are out 3.9 us after entry, the second item's sixteen 7.9 us
+    // after entry (the CU takes requests at the rate it delivers: 31 KB/us) -- and a wave that is held at a request cannot multiply: the
+    // workgroup barrier moved from 8.5 to 9.3 us.  What would overlap the first item's arithmetic with the second item's bytes is a second
+    // set of waves that does nothing but request (16 waves per CU at 128 registers each): a different kernel.
+    // (The parking lives INSIDE the branch of the waves that do it.  As a second `if (wave != 0)` behind the first one it left the compiler a
+    // path that exists in no wave -- this branch's vector-entry loads, then around the parking -- on which those loads are still pending
+    // behind the workgroup barrier; s_waitcnt is per wave, so EVERY wave then waited with vmcnt(0) in front of the first item's rows, which
+    // are in LDS, for the last row of the SECOND item.  Both branches now leave the vector entries waited for: qn_s2_evalvec_touch.)
+    if (wave == 0) {
+        qn_s2_prologue_w0<QN_S2_EVAL, SHARD, decltype(vec_spec)&, false, BND>(a, L, vec_spec);
+        qn_s2_evalvec_touch(va);
+        qn_keepalive(v1.x_r); qn_keepalive(v1.s_r); qn_keepalive(v1.x_c.x); qn_keepalive(v1.x_c.y); qn_keepalive(v1.s_c.x); qn_keepalive(v1.s_c.y);
+        ij1 = qn_s2_second_item(a);
+        parked = PAIR || ij1 >= 0;
+    } else {
+        if (wave <= 4) cw = qn_code_warm_issue((wave - 1) * 64 + lane); // (qn_kernels.hip.h, CODE WARM-UP: 32 KB.  All seven waves -- 56 KB, the
+        window_load(ij0);                                               // whole two-item instance -- in front of their rows: 15.2 -> 15.55 us;
+        vec_spec();                                                     // the last 24 KB behind the rows instead: 15.25 -> 15.35)
+        ij1 = qn_s2_second_item(a);
+        parked = PAIR || ij1 >= 0;
+        if (parked) {
+            const int I1 = ij1 >> 16, J1 = ij1 & 0xffff;
+            const double* q1 = a.Q + (size_t)(qn_s2_lrow<SHARD>(a, I1) * QN_TB + wave * QN_S2_RPW) * np + (size_t)J1 * QN_TB + qn_s2_col(I1 == J1, lane, wave);
+            // (wave 0's rows are requested BEFORE the second item's: a wave's loads return in order, and behind the refills these three
+            // -- which the barrier below waits for -- arrived with the last byte of the second window, 9.5 us into the kernel: the
+            // workgroup then started on the first item when both had landed, however early the machine was done)
+            const int I0 = ij0 >> 16, J0 = ij0 & 0xffff;
+            const double* q0 = a.Q + (size_t)(qn_s2_lrow<SHARD>(a, I0) * QN_TB) * np + (size_t)J0 * QN_TB + 2 * lane; // wave 0's rows: no clone lanes (qn_s2_col(., ., 0) = 2 lane)
+            const int r0 = (wave - 1) * 3;
+            v2d t3[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) t3[k] = qn_sym_ld<NTQ>(q0 + (size_t)min(r0 + k, QN_S2_RPW - 1) * np);
-        QN_S2_STAMP_T(6, 448); // (wave 7: everything requested)
+            for (int k = 0; k < 3; ++k) t3[k] = qn_sym_ld<NTQ>(q0 + (size_t)min(r0 + k, QN_S2_RPW - 1) * np);
+            // The vector entries are waited for HERE, in front of the second item's requests (they arrive right behind the first item's rows):
+            // see the note above.
+            qn_s2_evalvec_touch(va);
+            qn_keepalive(v1.x_r); qn_keepalive(v1.s_r); qn_keepalive(v1.x_c.x); qn_keepalive(v1.x_c.y); qn_keepalive(v1.s_c.x); qn_keepalive(v1.s_c.y);
+            QN_S2_STAMP_T(6, 448); // (wave 7: the first item has landed)
 #pragma unroll
-        for (int r = 0; r < QN_S2_RPW; ++r) {
-            park[wave][r][lane] = h[r];
-            h[r] = qn_sym_ld<NTQ>(q1 + (size_t)r * np);
+            for (int r = 0; r < QN_S2_RPW; ++r) {
+                park[wave][r][lane] = h[r];
+                h[r] = qn_sym_ld<NTQ>(q1 + (size_t)r * np);
+            }
+            QN_S2_STAMP_T(7, 448); // (its sixteen rows parked, the second item requested)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (r0 + k < QN_S2_RPW) park[0][r0 + k][lane] = t3[k]; // (they came in right behind the wave's own sixteen)
+            QN_S2_STAMP_T(8, 448);
         }
-        QN_S2_STAMP_T(7, 448); // (its sixteen rows parked)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (r0 + k < QN_S2_RPW) park[0][r0 + k][lane] = t3[k]; // (they came in right behind the wave's own sixteen)
-        QN_S2_STAMP_T(8, 448);
+        else { // (nothing is parked: the entries are waited for all the same -- both branches leave them so)
+            qn_s2_evalvec_touch(va);
+            qn_keepalive(v1.x_r); qn_keepalive(v1.s_r); qn_keepalive(v1.x_c.x); qn_keepalive(v1.x_c.y); qn_keepalive(v1.s_c.x); qn_keepalive(v1.s_c.y);
+        }
     }
     QN_S2_STAMP(1);
     __syncthreads();
