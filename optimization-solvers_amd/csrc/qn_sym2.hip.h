@@ -875,6 +875,9 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
         if (wave <= 4) cw = qn_code_warm_issue((wave - 1) * 64 + lane); // (qn_kernels.hip.h, CODE WARM-UP: 32 KB.  All seven waves -- 56 KB, the
         window_load(ij0);                                               // whole two-item instance -- in front of their rows: 15.2 -> 15.55 us;
         vec_spec();                                                     // the last 24 KB behind the rows instead: 15.25 -> 15.35)
+        // (Measured and dropped: the vector entries requested IN FRONT of the window.  The compiler then gives the second item a register window of
+        // its own and requests it right behind the first -- everything in flight 1.6 us after entry, every parked row waited for exactly -- and the
+        // kernel takes 16.05 us instead of 15.25: the second item's bytes delay the first item's, whose arithmetic is what the barrier waits for.)
         ij1 = qn_s2_second_item(a);
         parked = PAIR || ij1 >= 0;
         if (parked) {
