@@ -121,7 +121,7 @@ def test_bounded_run_to_termination_matches_oracle(qn, qo, method):
 
 @pytest.mark.parametrize("method", ["bfgsb", "dfpb"])
 @pytest.mark.parametrize("lsname", ["mt", "mtb"])
-@pytest.mark.parametrize("n", [1024, 1408])
+@pytest.mark.parametrize("n", [1024, 1408])  # (work lists read from memory; the two-items-and-a-sliver instance: the test below)
 def test_bounded_second_generation_path_vs_oracle_and_generic(qn, qo, method, lsname, n):
     """BFGSB / DFPB with More-Thuente(B) on the second-generation symmetric path (s2_dir_kernel, qn_sym2.hip.h: the direction stored and
     projected by one more launch per iteration, t_max clipped where that request is consumed): against the oracle's restatement, against the
@@ -186,3 +186,46 @@ def test_bounded_second_generation_path_continues_across_calls(qn, qo):
                 pass
         outs.append((s.x(), ls.t_max()))
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+
+
+def test_bounded_second_generation_path_at_the_benchmark_size(qn, qo):
+    """n = 4096 -- every workgroup two tiles and a sliver: s2_eval_kernel<true, .., BND> -- BFGSB + MoreThuenteB against the oracle and the
+    generic path, the launch count of the pattern (one stored-direction launch per iteration on top of evaluation, accept-reduce, update
+    tiles, update-reduce), and no host round trip per request."""
+    n = 4096
+    q, b, x0, lb, ub = _box(qo, n)
+    iters = 20
+    ref = qo.Solver(qo.BFGS, 1e-9, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
+    ref.set_bounds(lb, ub)
+    ls_ref = _make_ls(qo, "mtb", n, lb, ub)
+    ref.minimize(ls_ref, qo.QuadraticOracle(q, b, nthreads=qo.max_threads()), iters, 30, trace_cap=iters, trace_x=True)
+    obj = qn.Quadratic(q, b)
+    xs_by_mode = {}
+    for mode in ("second generation", "generic"):
+        s = qn.BFGSB.new(1e-9, x0, lb, ub)
+        s.set_trace(iters, with_x=True)
+        if mode == "generic":
+            s.set_tiling(-14, 0)
+        ls = _make_ls(qn, "mtb", n, lb, ub)
+        try:
+            s.minimize(ls, obj, iters, 30)
+        except qn.MaxIterReached:
+            pass
+        tr, xs = s.trace()
+        st = s.stats()
+        assert bool(st["path"] & 16) == (mode != "generic")
+        w = min(len(tr), len(ref.trace))
+        assert w >= 15
+        for k in range(w):
+            assert tr[k]["n_evals"] == ref.trace[k]["n_evals"], (mode, k)
+            assert abs(tr[k]["t"] - ref.trace[k]["t"]) <= 1e-8 * abs(ref.trace[k]["t"]), (mode, k)
+            assert np.linalg.norm(xs[k] - ref.trace_x[k]) <= 1e-8 * max(1.0, np.linalg.norm(ref.trace_x[k])), (mode, k)
+        assert abs(ls.t_max() - ls_ref.t_max) <= 1e-8 * max(1.0, abs(ls_ref.t_max))
+        x = s.x()
+        assert np.all(x >= lb - 1e-12) and np.all(x <= ub + 1e-12)
+        xs_by_mode[mode] = x
+        if mode == "second generation":
+            evals = sum(r["n_evals"] for r in tr)
+            assert st["host_syncs"] <= 4
+            assert st["launches"] <= 2 * (len(tr) * 4 + evals) + 16  # (dir + vec + tiles + reduce per iteration, the evaluations; slack for unused slots)
+    assert np.linalg.norm(xs_by_mode["second generation"] - xs_by_mode["generic"]) <= 1e-8 * max(1.0, np.linalg.norm(xs_by_mode["generic"]))
