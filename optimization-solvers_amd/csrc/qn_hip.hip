@@ -2786,6 +2786,21 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
             s->stats.launches++;
         } else if (nt > 0) {
             const int nla = la ? std::min(KB / QN_NB, nt) : nt; // tile columns of the next outer block
+            // Round 5: in the FIRST THIRD of the outer blocks -- where the bulk, not the chain, sets the pace (tools/chol_timeline.py: periods of
+            // 470 ... 250 us against a chain of 240) -- the bulk may start as soon as this block's panels are final, BESIDE the look-ahead
+            // columns' update instead of behind it: the two touch different columns.  The second stream then never idles there.  Not later:
+            // where the chain is the pace, the look-ahead update is a link of it and runs slower beside a bulk.  Measured at n = 8192, alternating:
+            // 9.00-9.14 -> 8.92-8.98 ms per Newton iteration (QN_CHOL_EARLY_BULK = 0 / 6 / 10 / 14 / 32 blocks: 9.05 / 8.96 / 8.95 / 8.96 / 9.05).
+            // The gain is small because the first third does MFMA work back to back either way: what would shorten it is moving flops into the last
+            // two thirds, where the second stream is mostly idle -- the left-looking order, which needs an update kernel that is efficient on
+            // deep, narrow updates (see above).
+            static const int chol_early_env = getenv("QN_CHOL_EARLY_BULK") ? atoi(getenv("QN_CHOL_EARLY_BULK")) : -1;
+            const int chol_early = chol_early_env >= 0 ? chol_early_env : nblocks / 3;
+            const bool early = la && nt > nla && b < chol_early;
+            if (early) {
+                HIPCHK(hipEventRecord(c->la_events[2 * b], st));
+                HIPCHK(hipStreamWaitEvent(bulk_st, c->la_events[2 * b], 0));
+            }
             // the next block's columns on this stream -- once the PREVIOUS bulk, which wrote them too, is through -- ...
             if (la && last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
             hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt, nla)), dim3(256), 0, st, s->newton_w, ld, K0, Kend - K0, Kend, nla, s->newton_fail, la ? 1 : 0,
@@ -2796,8 +2811,10 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
             // panel -- it measured slower: 9.43-9.64 ms per Newton iteration against 9.34-9.41, three alternating runs; the chain of
             // the next block then runs under contention from its first kernel on.)
             if (nt > nla) {
-                HIPCHK(hipEventRecord(c->la_events[2 * b], st));
-                HIPCHK(hipStreamWaitEvent(bulk_st, c->la_events[2 * b], 0));
+                if (!early) {
+                    HIPCHK(hipEventRecord(c->la_events[2 * b], st));
+                    HIPCHK(hipStreamWaitEvent(bulk_st, c->la_events[2 * b], 0));
+                }
                 hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt - nla, nt - nla)), dim3(256), bulk_lds, bulk_st, s->newton_w, ld, K0, Kend - K0,
                                    Kend + nla * QN_NB, nt - nla, s->newton_fail, 0);
                 s->stats.launches++;
