@@ -2794,6 +2794,11 @@ static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
             // The gain is small because the first third does MFMA work back to back either way: what would shorten it is moving flops into the last
             // two thirds, where the second stream is mostly idle -- the left-looking order, which needs an update kernel that is efficient on
             // deep, narrow updates (see above).
+            // Also measured and dropped in round 5 (same tool, alternating): the look-ahead columns in TWO launches -- the first 64-column strip,
+            // which the chain's next link needs, on this stream, strips 1..3 on a third stream beside it, awaited in front of the next block's first
+            // in-block update: the strip-0 launch is 42 us instead of 60, but two more event pairs sit in the chain (7-8 us each) and the first
+            // in-block update still runs beside the freshly started bulk at twice its solo time: 8.9-9.0 -> 9.2-9.4 ms; and the bulk at ONE
+            // workgroup per CU in the chain-paced blocks: 9.03-9.06 ms either way.
             static const int chol_early_env = getenv("QN_CHOL_EARLY_BULK") ? atoi(getenv("QN_CHOL_EARLY_BULK")) : -1;
             const int chol_early = chol_early_env >= 0 ? chol_early_env : nblocks / 3;
             const bool early = la && nt > nla && b < chol_early;
