@@ -313,6 +313,55 @@ def extra_config4(qn, ctx):
     return out
 
 
+def extra_bounded(qn, ctx):
+    """SURVEY 8 row f4, driver-visible: BFGSB + MoreThuenteB (bfgs_b.rs, morethuente_b.rs) against BFGS + MoreThuente on the
+    headline workload -- n = 4096, a box of which a quarter of the bounds is active at the constrained optimum (the box of tools/bench_bounded.py
+    and tests/test_gpu_bounded.py; the unconstrained optimum it is built around comes from two Newton iterations on the GPU, not from the oracle).
+    Wall time per iteration of 200 iterations each, after 5 untimed ones, and their ratio."""
+    n = 4096
+    diag, b, x0 = synth_inputs(n)
+    obj = qn.Quadratic.synthetic(n, SEED, diag, b, ctx=ctx)
+    nt = qn.Newton(1e-12, x0, ctx=ctx)
+    try:
+        nt.minimize(qn.MoreThuente(), obj, 3, 20)
+    except qn.MaxIterReached:
+        pass
+    xs = np.array(nt.x(), dtype=np.float64)
+    del nt
+    lb = xs - 0.3 * np.abs(xs) - 0.05
+    ub = xs + 0.1
+    k4 = max(1, n // 4)
+    lb[:k4] = xs[:k4] + 0.2
+    ub[:k4] = xs[:k4] + 1.0
+    out = {"workload": f"BFGSB + MoreThuenteB against BFGS + MoreThuente, n={n} convex quadratic (the headline's), a quarter of the box active at the constrained optimum, f64, 1xMI355X"}
+    iters = 200
+    for name, mk, mkls in (("unbounded", lambda: qn.BFGS(1e-10, x0, ctx=ctx), lambda: qn.MoreThuente()),
+                           ("bounded", lambda: qn.BFGSB.new(1e-10, x0, lb, ub, ctx=ctx), lambda: qn.MoreThuenteB.new(n).with_lower_bound(lb).with_upper_bound(ub))):
+        s = mk()
+        ls = mkls()
+
+        def run(k):
+            try:
+                s.minimize(ls, obj, k, 20)
+            except qn.MaxIterReached:
+                pass
+        run(5)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        run(iters)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        st = s.stats()
+        its = max(int(st["iterations"]), 1)
+        out[name] = {"iterations_per_s": its / dt, "us_per_iteration": 1e6 * dt / its, "iterations": its, "path": st["path"],
+                     "second_generation_path": bool(st["path"] & 16), "launches_per_iteration": st["launches"] / its, "host_syncs": st["host_syncs"]}
+        del s
+    out["ratio_bounded_over_unbounded_time"] = out["bounded"]["us_per_iteration"] / out["unbounded"]["us_per_iteration"]
+    out["value"] = out["bounded"]["iterations_per_s"]
+    out["unit"] = "iterations/s"
+    return out
+
+
 def extra_config5(qn, ctx):
     """BASELINE.json configs[4] on one GPU (the config names 4: the driver's scaling run has no slot for it): DFP + More-Thuente on the
     n = m = 16384 log-sum-exp objective f = log sum_i exp(a_i'x + c_i) + mu/2 ||x||^2 (dfp.rs:78-123, morethuente.rs:165-297).  A (2 GiB)
@@ -711,7 +760,8 @@ def main():
             # its own roofline and CPU leg.  The headline `value` / `config` stay configs[1].
             del solver, obj
             extra = {}
-            for name, leg in (("config4_newton_n8192", lambda: extra_config4(qn, ctx)), ("config5_dfp_logsumexp_n16384", lambda: extra_config5(qn, ctx))):
+            for name, leg in (("config4_newton_n8192", lambda: extra_config4(qn, ctx)), ("config5_dfp_logsumexp_n16384", lambda: extra_config5(qn, ctx)),
+                              ("bounded_bfgsb_morethuenteb_n4096", lambda: extra_bounded(qn, ctx))):
                 try:
                     extra[name] = leg()
                 except Exception as e:  # noqa: BLE001 -- an extra leg never loses the bench line
