@@ -93,6 +93,7 @@ struct QnCtl {
     double dir_ug, dir_sg;
     double st_gd0, st_yy, st_ys, st_gg, st_ss, st_dnf;
     double hp_yu, hp_ug, hp_sg;
+    double hp_den; // SR1 on the second-generation path: (s - u).y, the update's denominator (sr1_b.rs:143-146), summed by the update-reduce
 
     // ---- bounded variants (row f4) ----
     int32_t bounded, req_project, last_projected;

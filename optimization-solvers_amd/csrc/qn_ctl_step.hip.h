@@ -160,7 +160,7 @@ __device__ __forceinline__ bool qn_st_after_u(QnCtl& c) { // coefficients of bfg
     if (!LEAN && !c.fused) return false;
     const double yu = c.hp_yu;
     double c_ss, c_su, c_uu;
-    qn_update_coeffs(c.method, c.ys, yu, c_ss, c_su, c_uu);
+    qn_update_coeffs(c.method, c.ys, yu, c_ss, c_su, c_uu, c.hp_den);
     c.c_ss = c_ss; c.c_su = c_su; c.c_uu = c_uu;
     c.n_hpasses++;
     if (c.pending) c.n_hpass_rw++;

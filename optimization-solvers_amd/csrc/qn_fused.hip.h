@@ -56,8 +56,10 @@ __device__ __forceinline__ double qn_partial_col_sum(const double* __restrict__ 
 }
 
 // coefficients of the symmetric rank-2 form of bfgs.rs:115-124 (method 0) / dfp.rs:115-120 (method 1)
-__device__ __forceinline__ void qn_update_coeffs(int method, double ys, double yu, double& c_ss, double& c_su, double& c_uu) {
+// (method 4, SR1 -- second-generation path only: (s - u)(s - u)'/((s - u).y) = c (s s' - (s u' + u s') + u u'), c = 1 / den, sr1_b.rs:143-146)
+__device__ __forceinline__ void qn_update_coeffs(int method, double ys, double yu, double& c_ss, double& c_su, double& c_uu, double den = 0.0) {
     if (method == 0) { const double rho = 1.0 / ys; c_su = -rho; c_ss = rho * rho * yu + rho; c_uu = 0.0; }
+    else if (method == 4) { c_ss = 1.0 / den; c_su = -c_ss; c_uu = c_ss; }
     else { c_ss = 1.0 / ys; c_su = 0.0; c_uu = -1.0 / yu; }
 }
 

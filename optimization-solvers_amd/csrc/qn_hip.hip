@@ -1752,6 +1752,7 @@ struct Run {
     bool sym_generic = false; // generic path: the H pass alone on the upper block triangle
     bool sym2 = false;        // second-generation symmetric path (qn_sym2.hip.h)
     bool gobj = false;        // ... in its form for a device objective that is not the quadratic (qn_sym2g.hip.h: the log-sum-exp objective)
+    bool dirq = false;        // ... whose pattern has the stored-direction launch (QnCtl.s2_dir != 0)
     bool bnd = false;         // ... a bounded run on it (BFGSB / DFPB, MoreThuenteB): one more launch per iteration, s2_dir_kernel (qn_sym2.hip.h)
     bool tiles1 = false;      // the update pass's tiles through the first-generation tile kernel (one workgroup per tile, two per CU) behind a
                               // one-workgroup launch that runs the machine: H's share past the Infinity Cache (see minimize_impl)
@@ -1878,7 +1879,10 @@ static int s2_launch(Run& r, int kind) {
         else hipLaunchKernelGGL(s2_vec_kernel<false>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
         break;
     case QN_S2_HTILE:
-        if (sh) {
+        if (s->method == QN_SR1) { // (one rank, no fold, no tail reduce: minimize_impl)
+            if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, false, false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        } else if (sh) {
             if (s->method == QN_BFGS) {
                 if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, true, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
                 else hipLaunchKernelGGL((s2_hpass_kernel<false, true, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
@@ -1909,6 +1913,7 @@ static int s2_launch(Run& r, int kind) {
         break;
     case QN_S2_HREDUCE:
         if (sh) hipLaunchKernelGGL(s2_hreduce_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
+        else if (s->method == QN_SR1) hipLaunchKernelGGL((s2_hreduce_kernel<false, true>), dim3(2 * a.nb), dim3(QN_S2_TPB), 0, st, a);
         else hipLaunchKernelGGL(s2_hreduce_kernel<false>, dim3(2 * a.nb), dim3(QN_S2_TPB), 0, st, a); // (a workgroup per block-row and right-hand side)
         break;
     case QN_S2_GEVAL_A:
@@ -2938,7 +2943,12 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     const bool s2b = (s->bounded || ls_bounded) && ls->kind != QN_LS_BACKTRACKING_B && !ls_only && c->world == 1 && (s->T.n_pad % QN_TB) == 0 &&
                      s->T.n_pad >= 8 * QN_TB && (size_t)s->T.n_pad == s->n && !s->no_sym && !s->no_sym2 && !s->h_nonsym && r.obj && r.obj->q_symmetric &&
                      !s->no_s2bnd && !(getenv("QN_S2_BND") && atoi(getenv("QN_S2_BND")) == 0);
-    r.fused = r.oracle_tpl == QN_ORACLE_QUAD && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP) && !callback && s->hcs == 1 &&
+    // SR1 (sr1_b.rs; row f4) has its three-term update only in the second-generation kernels (s2_hpass_kernel<.., SR1>): it takes the fused path
+    // exactly when that path will be taken -- the same structural conditions as the bounded variants'.
+    const bool s2_struct = !ls_only && c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && (size_t)s->T.n_pad == s->n && !s->no_sym &&
+                           !s->no_sym2 && !s->h_nonsym && r.obj && r.obj->q_symmetric && !s->no_s2bnd && !(getenv("QN_S2_BND") && atoi(getenv("QN_S2_BND")) == 0);
+    const bool sr1_s2 = s->method == QN_SR1 && s2_struct && ls->kind != QN_LS_BACKTRACKING_B;
+    r.fused = r.oracle_tpl == QN_ORACLE_QUAD && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP || sr1_s2) && !callback && s->hcs == 1 &&
               s->qcs == 1 && !h->small_n && !s->no_fused && (!(s->bounded || ls_bounded) || s2b);
     // ... and the log-sum-exp objective in the structure of the second-generation path (qn_sym2g.hip.h; round 5): one rank, its one-pass
     // evaluation (n <= 16384), whole 128-blocks without padding, a bitwise symmetric H.  Everything else keeps the generic path.
@@ -2970,9 +2980,11 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     // (the second-generation kernels keep no padding entries at zero; row-sharded: the SHARD instantiations, qn_sym2sh.hip.h)
     r.sym2 = r.sym && !s->no_sym2 && (size_t)s->T.n_pad == s->n && (c->world == 1 || c->world <= 64);
     h->sym2 = r.sym2 ? 1 : 0;
-    r.bnd = r.sym2 && (s->bounded || ls_bounded);
+    r.bnd = r.sym2 && (s->bounded || ls_bounded || s->method == QN_SR1); // (SR1: the BND prologues also carry its third update-reduce column)
     if ((s->bounded || ls_bounded) && r.fused && !r.bnd) return fail(QN_ABNORMAL_TERMINATION, "bounded run on a fused path that is not the second-generation one");
+    if (s->method == QN_SR1 && r.fused && !r.sym2) return fail(QN_ABNORMAL_TERMINATION, "SR1 on a fused path that is not the second-generation one");
     h->s2_dir = r.bnd ? ((s->bounded ? 1 : 0) | (ls->kind == QN_LS_MORETHUENTE_B ? 2 : 0)) : 0;
+    r.dirq = h->s2_dir != 0; // (the stored-direction launch is part of the pattern only where a direction asks for it)
     if (r.bnd && ls->kind == QN_LS_MORETHUENTE_B) h->ls_kind = QN_LS_MORETHUENTE; // (the clip of t_max is applied where the direction's request is consumed: from there on it IS More-Thuente)
     // WHICH KERNEL STREAMS THE UPDATE PASS OF A ROW-SHARDED RUN (round 5).  The one-workgroup-per-CU kernel of
     // qn_sym2.hip.h (16-row register windows, the machine in its prologue) was built for n = 4096, where a launch is a twelfth of the
@@ -3048,8 +3060,10 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.evS = s->s2_evS; a.xg = s->symsh_xg; a.sl_off = s->s2_sl_off; a.sl_idx = s->s2_sl_idx;
         if (c->world > 1 || r.gobj) { a.fold = 0; a.pair = 0; }
         if (r.bnd) a.fold = 0;
+        a.method = s->method;
+        if (s->method == QN_SR1) a.fold = 0;
         a.lb = (r.bnd && s->bounded) ? s->V.lb : nullptr; a.ub = (r.bnd && s->bounded) ? s->V.ub : nullptr;
-        a.llb = (r.bnd && ls_bounded) ? s->V.llb : nullptr; a.lub = (r.bnd && ls_bounded) ? s->V.lub : nullptr;
+        a.llb = (r.bnd && ls->kind == QN_LS_MORETHUENTE_B) ? s->V.llb : nullptr; a.lub = (r.bnd && ls->kind == QN_LS_MORETHUENTE_B) ? s->V.lub : nullptr;
         if (r.tiles1) a.fold = 0;
         // tail reduce (s2_hpass_kernel<.., TRED>): the update-reduce in the tail of the update-tile launch, 4 launches per iteration
         // instead of 5 -- one rank, lists short enough for one wave to announce (n <= ~15 k).  BUILT, BIT-IDENTICAL, SLOWER, OFF BY
@@ -3063,7 +3077,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             HIPCHK(hipMemsetAsync(s->s2_cnt, 0, (size_t)a.nb * QN_S2_CNT_STRIDE * sizeof(int), c->stream));
         }
         a.cnt = s->s2_cnt;
-        a.tred = (c->world == 1 && !a.fold && !r.gobj && !r.tiles1 && s->s2_maxk <= QN_S2_TRED_MAXK && want_tred) ? 1 : 0;
+        a.tred = (c->world == 1 && !a.fold && !r.gobj && !r.tiles1 && s->s2_maxk <= QN_S2_TRED_MAXK && want_tred && s->method != QN_SR1) ? 1 : 0;
         // WHO GETS THE INFINITY CACHE (256 MB).  Per iteration a rank streams its half of Q twice (read) and its half of H once
         // (read + written); non-temporal accesses pass the cache by.  Measured (round 4, bench.py same box, it/s for the policies
         // H plain / Q plain, H plain / Q non-temporal, H non-temporal / Q plain, both non-temporal):
@@ -3143,7 +3157,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 const int64_t periods = std::min<int64_t>(remaining + ((first && !h->warm) ? 1 : 0), 256);
                 first = false;
                 auto one_period = [&]() -> int {
-                    if (r.bnd) QNCHK(s2_launch(r, QN_S2_DIR)); // (the direction the period's evaluations search along: stored, projected)
+                    if (r.dirq) QNCHK(s2_launch(r, QN_S2_DIR)); // (the direction the period's evaluations search along: stored, projected)
                     for (int e = 0; e < slots; ++e) QNCHK(s2_do_eval(r));
                     if (!r.s2.fold && !(r.gobj && r.s2.sh_world == 1)) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise; generic objective: staged by every evaluation's combine launch)
                     QNCHK(s2_do_hpass(r, true));

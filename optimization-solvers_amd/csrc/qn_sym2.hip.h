@@ -78,6 +78,11 @@ struct QnS2Args {
     int fold;            // the accept-reduce runs inside the update-tile launch (workgroups hold <= 3 items: n <= 4096)
     int tred;            // TAIL REDUCE (round 5): the update-reduce runs in the tail of the update-tile launch -- the workgroup whose slot
                          // completes block-row R sums R's slots (s2_hpass_kernel<.., TRED>); no s2_hreduce launch follows
+    int method;          // the solver's method (QN_SR1 = 4: its runs use the BND prologues, which read it).  In the four bytes of padding in front of
+                         // the pointer: nothing moves.  (SR1's extra sum and column count are compiled into instantiations of their own -- s2_hreduce_kernel
+                         // <false, true>, the BND prologues: as run-time branches in the kernels of every run they cost the benchmark iteration
+                         // 1-2 us -- update tiles 23.5 -> 24.4, update-reduce 4.9 -> 5.5 us, alternating A/Bs on one box -- for reasons that are not the
+                         // argument's cache line, not the code's size and not cold code)
     int* cnt;            // [nb][cnt_stride] arrival counters of the block-rows (zero between launches: the last arriver resets its counter)
     int sl_first, sl_per; // ROW SLIVERS (sl_per != 0): the diagonal tiles sl_first .. nb - 1 are not on any work list; each is cut
                          // into sl_per slivers of 8 rows, one per workgroup (workgroup g: tile sl_first + g / sl_per, sliver g % sl_per,
@@ -180,7 +185,7 @@ __device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const
                 c.st_yy = tot[0]; c.st_ys = tot[1]; c.st_gg = tot[2]; c.st_ss = tot[3]; c.hp_sg = tot[4];
                 c.state = c.after_state;
             } else if (ph == QN_PH_REQ_HPASS) {
-                if (c.hp_nrhs == 2) { c.hp_yu = tot[0]; c.hp_ug = tot[1]; }
+                if (c.hp_nrhs == 2) { c.hp_yu = tot[0]; c.hp_ug = tot[1]; if (BND) c.hp_den = tot[2]; } // (hp_den: SR1's denominator, third column of its update-reduce)
                 c.state = c.after_state;
             } else if (BND && ph == QN_PH_REQ_DIR) { // VV holds -d (stored, projected): the evaluations form x + t d as they do for a first direction
                 c.mtb_cand = tot[0];                // (the MINIMUM over the block-rows: the prologue folds this request's column that way)
@@ -345,7 +350,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     for (int k = 0; k < (GOBJ ? QN_S2_NSE : 1); ++k) totv[k] = 0.0;
     if (c.serviced == 2 && (ph == QN_PH_REQ_EVAL || ph == QN_PH_REQ_VEC || ph == QN_PH_REQ_HPASS)) { // (uniform)
         const int nrows = ph == QN_PH_REQ_EVAL ? (GOBJ ? a.gw : a.G) : a.nb;
-        const int ncol = ph == QN_PH_REQ_EVAL ? QN_S2_NSE : (ph == QN_PH_REQ_VEC ? QN_S2_NR : 2);
+        const int ncol = ph == QN_PH_REQ_EVAL ? QN_S2_NSE : (ph == QN_PH_REQ_VEC ? QN_S2_NR : ((BND && a.method == 4) ? 3 : 2)); // (SR1 -- its runs use the BND instantiations --: y'u, u'g+ and (s - u)'y)
         // The lane's rows in row order, then ONE halving butterfly over all columns at once (QnWaveFold: 17 exchanges instead of
         // six 6-step butterflies).  It pairs lanes l and l ^ 32, then ^ 16, ... ^ 1 for every column exactly as qn_wave_sum
         // does, and floating-point addition commutes: the totals have round 2's bits.
@@ -1189,8 +1194,9 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
 // at entry, with its slots: behind the totals they were one more memory round trip at the end of a 5 us kernel)
 // (half: s2_hreduce_kernel gives a block-row's two right-hand sides to TWO workgroups -- 0: u, the sums and the commit of g; 1: v, passed as tot1,
 // and nothing else; -1: both, the tail reduce)
+template <bool SR1 = false> // (SR1: also (s - u)'y, the update's denominator, as a third sum -- snew is the staged s)
 __device__ __forceinline__ void qn_s2_hreduce_row(const QnS2Args& a, const int R, const int nrhs, const double tot0, const double tot1, double (*bred)[8],
-                                                  const double gp, const double yv, const int half = -1) {
+                                                  const double gp, const double yv, const int half = -1, const double snew = 0.0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (half == 1) { // (uniform)
         if (tid < QN_TB && nrhs == 2) a.F.VV[R * QN_TB + tid] = tot1;
@@ -1205,6 +1211,7 @@ __device__ __forceinline__ void qn_s2_hreduce_row(const QnS2Args& a, const int R
             a.F.UN[gi] = tot0;
             if (half < 0) a.F.VV[gi] = tot1;
             p[0] = yv * tot0; // y'u = y'H+y
+            if (SR1) p[2] = (snew - tot0) * yv; // (s - u)'y, the update's denominator (sr1_b.rs:145)
             p[1] = tot0 * gp;        // u'g+
         } else {
             a.F.VV[gi] = tot0; // direction pass: v = H g (bfgs.rs:47)
@@ -1216,7 +1223,7 @@ __device__ __forceinline__ void qn_s2_hreduce_row(const QnS2Args& a, const int R
         if ((lane & 7) == 0) bred[wave][lane >> 3] = p[0];
     }
     __syncthreads();
-    if (tid < 2) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = bred[0][tid] + bred[1][tid];
+    if (tid < (SR1 ? 3 : 2)) a.wgS[((size_t)a.parity * QN_S2_ROW + tid) * a.trows + R] = bred[0][tid] + bred[1][tid];
 }
 struct QnS2HReq { // the update-pass request, decoded once per launch
     const double *sp, *up, *r0v, *gt;
@@ -1279,10 +1286,11 @@ __device__ __forceinline__ void qn_s2_hvec_load(const QnS2HReq& q, const unsigne
 // the launch is already waiting for; a designated, polling reducer would not have that problem and cannot be had without a
 // wait that a non-resident workgroup can hold up (two such launches of two solvers sharing the GPU deadlock).  The reduce launch
 // stays: 5 launches per iteration.
-template <bool NT, bool BFGS, bool FOLD, bool SHARD = false, bool TRED = false>
+template <bool NT, bool BFGS, bool FOLD, bool SHARD = false, bool TRED = false, bool SR1 = false> // (SR1: s u' + u s', s s' AND u u' -- sr1_b.rs)
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a) {
     static_assert(!(FOLD && SHARD), "the folded accept-reduce is a single-rank variant");
     static_assert(!(TRED && (FOLD || SHARD)), "the tail reduce is the single-rank kernel without the folded accept-reduce");
+    static_assert(!(SR1 && (FOLD || SHARD || TRED || BFGS)), "SR1: the plain single-rank instance");
     __shared__ QnS2Lds L;
     __shared__ double colsum[2][QN_TB]; // [rhs]: row part of a diagonal item, parked until its column part is summed
     __shared__ double colred[QN_S2_WAVES][2][QN_TB];
@@ -1488,13 +1496,13 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
             v2d hn = h[r];
             h[r] = qn_sym_ld<NT>(hnext + (size_t)r * rstride); // the register this row frees takes the same row of the next item at once
             const double si = qn_lane_bcast(sr, r), ui = qn_lane_bcast(ur, r);
-            if (BFGS) {
+            if (BFGS || SR1) {
                 hn.x = hn.x + c_su * (si * uj.x + ui * sj.x);
                 hn.y = hn.y + c_su * (si * uj.y + ui * sj.y);
             }
             hn.x = hn.x + c_ss * (si * sj.x);
             hn.y = hn.y + c_ss * (si * sj.y);
-            if (!BFGS) {
+            if (!BFGS || SR1) {
                 hn.x = hn.x + c_uu * (ui * uj.x);
                 hn.y = hn.y + c_uu * (ui * uj.y);
             }
@@ -1564,13 +1572,13 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
         const double si = pend ? v0.s_r : 0.0, ui = pend ? v0.u_r : 0.0;
         v2d sj = {0.0, 0.0}, uj = {0.0, 0.0};
         if (pend) { sj = v0.s_c; uj = v0.u_c; }
-        if (BFGS) {
+        if (BFGS || SR1) {
             hn.x = hn.x + c_su * (si * uj.x + ui * sj.x);
             hn.y = hn.y + c_su * (si * uj.y + ui * sj.y);
         }
         hn.x = hn.x + c_ss * (si * sj.x);
         hn.y = hn.y + c_ss * (si * sj.y);
-        if (!BFGS) {
+        if (!BFGS || SR1) {
             hn.x = hn.x + c_uu * (ui * uj.x);
             hn.y = hn.y + c_uu * (ui * uj.y);
         }
@@ -1673,8 +1681,9 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
 // memory pipeline -- in-kernel stamps at n = 4096: control block 1.45 us after entry, barrier 2.0, totals 2.75: the slots, not the machine, were
 // what the epilogue waited for -- and nothing in the epilogue needs both totals: u goes with the two sums and the commit of g, v is stored and
 // that is all.  The same sums in the same order.
-template <bool SHARD = false> // (row-sharded: the totals are the rank-order sums of the gathered partial [u, v]: see s2_vec_kernel)
+template <bool SHARD = false, bool SR1 = false> // (row-sharded: the totals are the rank-order sums of the gathered partial [u, v]: see s2_vec_kernel)
 __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a) {
+    static_assert(!(SHARD && SR1), "SR1 runs on one rank");
     __shared__ QnS2Lds L;
     __shared__ double qbuf[3][QN_TB];
     __shared__ double bred[2][8];
@@ -1682,8 +1691,13 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
     const int R = SHARD ? (int)blockIdx.x : (int)(blockIdx.x >> 1), half = SHARD ? -1 : (int)(blockIdx.x & 1);
     QnS2Slots S0;
     QN_S2_STAMP(0);
-    double gp = 0.0, yv = 0.0;
-    auto entries = [&]() { if (half != 1 && tid < QN_TB) { gp = a.F.GT[R * QN_TB + tid]; yv = a.F.Y[R * QN_TB + tid]; } };
+    double gp = 0.0, yv = 0.0, s0e = 0.0, s1e = 0.0;
+    auto entries = [&]() {
+        if (half != 1 && tid < QN_TB) {
+            gp = a.F.GT[R * QN_TB + tid]; yv = a.F.Y[R * QN_TB + tid];
+            if (SR1) { s0e = a.F.S0[R * QN_TB + tid]; s1e = a.F.S0[(size_t)a.np + R * QN_TB + tid]; } // (the staged s, either half)
+        }
+    };
     if (SHARD) { if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE, true>(a, L, entries); else entries(); }
     else if (wave == 0) qn_s2_prologue_w0<QN_S2_HREDUCE>(a, L, [&]() { qn_s2_slot_issue(a.part, a.nb, R, half, S0); entries(); });
     else { qn_s2_slot_issue(a.part, a.nb, R, half, S0); entries(); }
@@ -1705,7 +1719,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
         if (nrhs != 2) tot1 = 0.0;
     }
     QN_S2_STAMP(13); // (the totals)
-    qn_s2_hreduce_row(a, R, nrhs, tot0, tot1, bred, gp, yv, half);
+    qn_s2_hreduce_row<SR1>(a, R, nrhs, tot0, tot1, bred, gp, yv, half, L.c.sc ? s0e : s1e); // (the STAGED s: the half the pending one does not occupy)
     QN_S2_STAMP(12);
 }
 

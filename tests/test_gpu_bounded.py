@@ -119,22 +119,22 @@ def test_bounded_run_to_termination_matches_oracle(qn, qo, method):
     assert active.sum() >= n // 4 and np.array_equal(active, active_ref)
 
 
-@pytest.mark.parametrize("method", ["bfgsb", "dfpb"])
+@pytest.mark.parametrize("method", ["bfgsb", "dfpb", "sr1b"])
 @pytest.mark.parametrize("lsname", ["mt", "mtb"])
 @pytest.mark.parametrize("n", [1024, 1408])  # (work lists read from memory; the two-items-and-a-sliver instance: the test below)
 def test_bounded_second_generation_path_vs_oracle_and_generic(qn, qo, method, lsname, n):
-    """BFGSB / DFPB with More-Thuente(B) on the second-generation symmetric path (s2_dir_kernel, qn_sym2.hip.h: the direction stored and
+    """BFGSB / DFPB / SR1B with More-Thuente(B) on the second-generation symmetric path (s2_dir_kernel, qn_sym2.hip.h: the direction stored and
     projected by one more launch per iteration, t_max clipped where that request is consumed): against the oracle's restatement, against the
     generic path (qn_solver_set_tiling(-14, 0)), and pipelined against synchronous bit for bit."""
     q, b, x0, lb, ub = _box(qo, n)
     iters = 25
     # (the oracle's rank-2 form of the update -- pinned against the as-written one by the CPU tests -- on all host threads: the as-written
     # update is five n x n products per iteration)
-    ref = qo.Solver({"bfgsb": qo.BFGS, "dfpb": qo.DFP}[method], 1e-9, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
+    ref = qo.Solver({"bfgsb": qo.BFGS, "dfpb": qo.DFP, "sr1b": qo.SR1}[method], 1e-9, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
     ref.set_bounds(lb, ub)
     ls_ref = _make_ls(qo, lsname, n, lb, ub)
     ref.minimize(ls_ref, qo.QuadraticOracle(q, b, nthreads=qo.max_threads()), iters, 30, trace_cap=iters, trace_x=True)
-    cls = {"bfgsb": qn.BFGSB, "dfpb": qn.DFPB}[method]
+    cls = {"bfgsb": qn.BFGSB, "dfpb": qn.DFPB, "sr1b": qn.SR1B}[method]
     obj = qn.Quadratic(q, b)
     runs = {}
     for mode in ("pipelined", "sync", "generic"):

@@ -432,7 +432,11 @@ def test_generic_path_sr1b_bounded_on_tiles(qn, qo):
     lb = np.where(rng.random(n) < 0.3, xs + 0.05, -np.inf)
     ub = np.where(rng.random(n) < 0.3, np.maximum(xs - 0.05, lb + 0.1), np.inf)
     obj = qn.Quadratic(q, b)
-    a, b_ = _generic_pair(lambda: qn.SR1B.new(1e-10, x0, lb, ub), lambda s: s.minimize(qn.MoreThuente(), obj, 20, 20))
+    def mk():  # (SR1B of this shape takes the second-generation path since round 5: this test is about the GENERIC path's tiles)
+        s = qn.SR1B.new(1e-10, x0, lb, ub)
+        s.set_tiling(-14, 0)
+        return s
+    a, b_ = _generic_pair(mk, lambda s: s.minimize(qn.MoreThuente(), obj, 20, 20))
     _assert_same_run(a, b_, n)
     x = a[0].x()
     assert np.all(x >= lb - 1e-12) and np.all(x <= ub + 1e-12)
