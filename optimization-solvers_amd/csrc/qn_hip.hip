@@ -3198,8 +3198,14 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                     }
                 }
                 for (; p < periods; ++p) QNCHK(one_period());
-                seq = ++s->rep_seq; // (the batch's last launch reports: the evaluation launch below)
-                QNCHK(s2_do_eval(r, seq));
+                seq = ++s->rep_seq; // (the batch's last launch reports)
+                // One rank, quadratic objective: the reporting launch is the ONE-WORKGROUP machine launch, not an evaluation launch.  The
+                // evaluation kernel requests its first item before it knows whether there is anything to evaluate -- at the end of a call
+                // there is not: the machine finds the iteration cap and writes DONE -- which made the last launch of every call 10.7 us
+                // (kernel trace of the driver's 20-step call); the machine launch is 3-4.  Whatever request the machine leaves pending is
+                // served by the next batch's first launches.
+                if (r.s2.sh_world == 1 && !r.gobj) { r.report_seq = seq; QNCHK(s2_launch(r, QN_S2_ADVANCE)); }
+                else QNCHK(s2_do_eval(r, seq));
             }
         }
     } else {
