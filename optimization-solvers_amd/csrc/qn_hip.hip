@@ -819,6 +819,7 @@ struct qn_solver {
     int s2_sl_first = 0, s2_sl_per = 0, s2_sl_cfg = -1; // row slivers (QnS2Args.sl_first / sl_per); the switches the lists were built for
     bool no_sliver = false;    // diagnostics: sym2 without row slivers (round 2's work lists)
     bool no_pair = false;      // diagnostics: the general evaluation kernel where the two-items-and-a-sliver instance would run
+    bool no_ring = false;      // diagnostics: round 5's two-items-and-a-sliver instance where the mover / multiplier kernel (qn_sym2r.hip.h) would run
     bool tred = false;         // measurement: the update-reduce in the tail of the update-tile launch (s2_hpass_kernel<.., TRED>: bit-identical, slower)
     int* s2_cnt = nullptr;     // tail reduce: arrival counters of the block-rows
     int gen_slots_hint = 0;    // generic pipelined path: evaluation slots per period the last batch needed (0: none run yet)
@@ -1260,6 +1261,7 @@ extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_sp
     if (rows_per_block == -10) { s->newton_lu_no_la = 1; return QN_OK; } // diagnostics: ... one stream, no look-ahead
     if (rows_per_block == -8) { s->newton_lu_percol = 1; return QN_OK; } // diagnostics: ... with the per-column panel kernels
     if (rows_per_block == -9) { s->no_pair = !s->no_pair; return QN_OK; }     // diagnostics: general evaluation kernel (toggles)
+    if (rows_per_block == -15) { s->no_ring = !s->no_ring; return QN_OK; }    // diagnostics: round 5's pair instance instead of the mover / multiplier kernel (toggles)
     if (rows_per_block == -14) { s->no_s2bnd = !s->no_s2bnd; return QN_OK; }   // tests: bounded runs on the generic path (toggles)
     if (rows_per_block == -13) { s->tred = !s->tred; return QN_OK; }         // measurement: the update-reduce in the update-tile launch's tail (toggles)
     if (rows_per_block == -7) { s->no_sliver = !s->no_sliver; return QN_OK; } // diagnostics: sym2 without row slivers (toggles)
@@ -1860,10 +1862,12 @@ static int s2_launch(Run& r, int kind) {
             if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
             else hipLaunchKernelGGL((s2_eval_kernel<false, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         } else if (r.bnd) { // (bounded variants: the same kernels behind the bounded runs' prologue)
-            if (a.pair) hipLaunchKernelGGL((s2_eval_kernel<true, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+            if (a.pair && a.ring) hipLaunchKernelGGL(s2_evalr_kernel<true>, dim3(a.G), dim3(QN_S2R_TPB), 0, st, a);
+            else if (a.pair) hipLaunchKernelGGL((s2_eval_kernel<true, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
             else if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, false, true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
             else hipLaunchKernelGGL((s2_eval_kernel<false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-        } else if (a.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
+        } else if (a.pair && a.ring) hipLaunchKernelGGL(s2_evalr_kernel<false>, dim3(a.G), dim3(QN_S2R_TPB), 0, st, a);
+        else if (a.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         else if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         else hipLaunchKernelGGL(s2_eval_kernel<false>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         break;
@@ -2098,7 +2102,8 @@ static int place_h(Run& r) {
                 QnS2Args ae = a;
                 ae.ctl_first = pe;
                 for (int e = 0; e < 2; ++e) {
-                    if (ae.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(ae.G), dim3(QN_S2_TPB), 0, st, ae);
+                    if (ae.pair && ae.ring) hipLaunchKernelGGL(s2_evalr_kernel<false>, dim3(ae.G), dim3(QN_S2R_TPB), 0, st, ae);
+                    else if (ae.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(ae.G), dim3(QN_S2_TPB), 0, st, ae);
                     else if (ae.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, false, true>), dim3(ae.G), dim3(QN_S2_TPB), 0, st, ae);
                     else hipLaunchKernelGGL(s2_eval_kernel<false>, dim3(ae.G), dim3(QN_S2_TPB), 0, st, ae);
                 }
@@ -3059,6 +3064,10 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.sh_nsum = c->use_allreduce ? 1 : c->world;
         a.evS = s->s2_evS; a.xg = s->symsh_xg; a.sl_off = s->s2_sl_off; a.sl_idx = s->s2_sl_idx;
         if (c->world > 1 || r.gobj) { a.fold = 0; a.pair = 0; }
+        { // the pair instance's evaluation as movers + multipliers (qn_sym2r.hip.h); QN_S2_RING=0 / set_tiling(-15): round 5's kernel, same bits
+            static const bool ring_env = !(getenv("QN_S2_RING") && atoi(getenv("QN_S2_RING")) == 0);
+            a.ring = (a.pair && ring_env && !s->no_ring) ? 1 : 0;
+        }
         if (r.bnd) a.fold = 0;
         a.method = s->method;
         if (s->method == QN_SR1) a.fold = 0;

@@ -124,6 +124,7 @@ struct QnS2Args {
                          //     by that prologue, read by s2g_vec_kernel when the point is accepted)
     const double *lb, *ub;   // bounded variants (s2_dir_kernel): the solver's box (BFGSB / DFPB; null: none) ...
     const double *llb, *lub; // ... and the line search's (MoreThuenteB; null: none)
+    int ring;                // round 6: the pair instance's evaluation runs as s2_evalr_kernel (qn_sym2r.hip.h: mover waves + multiplier waves)
 #ifdef QN_S2_STAMPS
     unsigned long long* dbg; // diagnostic build: dbg[((slot % 64) * 256 + workgroup) * 16 + k] = wall clock (10 ns) at stamp k
     int slot;

@@ -193,6 +193,30 @@ def test_tail_reduce_is_the_reduce_launch_bit_for_bit(qn, qo, n, method, lsname)
             assert s.stats()["launches"] < base.stats()["launches"]  # one launch less per iteration
 
 
+@pytest.mark.parametrize("method,lsname", [("bfgs", "mt"), ("dfp", "mt"), ("bfgs", "bt")])
+def test_ring_evaluation_is_the_pair_instance_bit_for_bit(qn, qo, method, lsname):
+    """Round 6: at n = 4096 the evaluation tiles run as s2_evalr_kernel (csrc/qn_sym2r.hip.h): eight mover waves stream the workgroup's two
+    tiles and its sliver through a ring of LDS slots, eight multiplier waves do -- instruction for instruction -- what the waves of round 5's
+    two-items-and-a-sliver instance did behind their barrier, as the rows arrive.  Same sums in the same order: trace, iterates and inverse
+    Hessian must equal round 5's kernel (set_tiling(-15, 0)) bit for bit, pipelined and synchronous; repeated, because a row consumed before
+    it was parked (or overwritten before it was read) would depend on timing.  Backtracking evaluates at points it rejects more often than
+    More-Thuente does: launches whose request is not an evaluation's leave through the ring's early exit."""
+    n = 4096
+    diag = P.synth_diag(n); b, x0 = P.synth_vectors(n)
+    obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
+    iters = 30
+    base, st0 = _run(qn, method, lsname, obj, x0, iters, tiling=(-15, 0))
+    tr0, xs0 = base.trace()
+    h0 = base.approx_inv_hessian()
+    assert base.stats()["path"] & 16 and len(tr0) == iters
+    assert all(np.isfinite(r["f"]) for r in tr0)
+    for rep, sync in enumerate((0, 1, 0, 0, 1, 0)):
+        s, st = _run(qn, method, lsname, obj, x0, iters, sync=sync)
+        tr, xs = s.trace()
+        assert st == st0 and tr == tr0 and np.array_equal(xs, xs0), (rep, sync)
+        assert np.array_equal(s.approx_inv_hessian(), h0)
+
+
 @pytest.mark.parametrize("n", [1152, 3200])
 def test_second_generation_without_slivers_and_without_the_pair_instance(qn, qo, n):
     """Sizes whose work lists carry NO row slivers (sl_per == 0) and where the two-items-and-a-sliver instance of the evaluation
