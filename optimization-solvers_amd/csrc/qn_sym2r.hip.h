@@ -28,7 +28,7 @@
 
 struct QnS2RSync {
     unsigned prod[QN_S2_WAVES]; // rows of its sequence mover w has parked (wave 0's first-item rows are parked by the others: cnt0)
-    unsigned cons[QN_S2_WAVES]; // rows multiplier w has read
+    unsigned adone[QN_S2_WAVES]; // multiplier w has finished the first item: its lanes' shares of the two scalar sums lie in park[w][0]
     unsigned cnt0;              // rows of wave 0's share of the first item parked so far (16 when complete)
     unsigned eready;            // blocks of the trial point staged so far (5 when complete)
     unsigned mdone;             // the machine has run: L.c and L.mine are final
@@ -50,8 +50,10 @@ __device__ __forceinline__ unsigned qn_s2r_wait_ge(const unsigned* p, const unsi
     return v;
 }
 // publish: every LDS access this wave has issued is complete before the word changes
+template <bool WAIT = true>
 __device__ __forceinline__ void qn_s2r_publish(unsigned* p, const unsigned v) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (WAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("" ::: "memory"); // (a wave's LDS instructions execute in the order it issued them: the count lands behind the rows it counts)
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void qn_s2r_publish_add(unsigned* p, const unsigned v) {
@@ -88,9 +90,13 @@ struct QnS2RTrial {
     double xr, dr, b_r, g_r; // row 16 w + (lane & 15) of block I
     v2d xtj, dj;             // this lane's two columns of block J
 };
-template <class WaitRow>
-__device__ __forceinline__ double qn_s2r_item(const QnS2RTrial& v, const bool diag, const int lane, const int wave, const v2d* parkw,
-                                              double* __restrict__ colred_w, double (&sacc)[4], WaitRow&& wait_row) {
+struct QnS2RNoWait { __device__ __forceinline__ void operator()(int) const {} };
+struct QnS2RSums { double pf, pg, p4, p5; }; // an item's share of x'(Q xt - 2b), d'(Q xt - b), g'd, #non-finite d on this lane
+// PARK: the rows come from the park (a multiplier; wait_row(r) is called in front of rows r .. r + 3, r = 0, 4, 8, 12); otherwise from the
+// register window h (a mover: its own sixteen rows of the second item), whose first register takes the sliver's row once its row is consumed.
+template <bool PARK, class WaitRow>
+__device__ __forceinline__ double qn_s2r_item(const QnS2RTrial& v, const bool diag, const int lane, const int wave, const v2d* parkw, v2d (&h)[QN_S2_RPW],
+                                              const double* __restrict__ refill0, double* __restrict__ colred_w, QnS2RSums& o, WaitRow&& wait_row) {
     const double xr = v.xr, dr = v.dr;
     double p4 = 0.0, p5 = 0.0; // diagonal items: g'd, #non-finite d over block I (lanes 0..15 of every wave)
     if (diag && lane < 16) { p4 = v.g_r * dr; p5 = isfinite(dr) ? 0.0 : 1.0; }
@@ -98,21 +104,27 @@ __device__ __forceinline__ double qn_s2r_item(const QnS2RTrial& v, const bool di
     if (!qn_s2_row_on(diag, lane, wave)) { xtj = (v2d){0.0, 0.0}; dj = (v2d){0.0, 0.0}; }
     double cx = 0.0, cy = 0.0;
     double racc[QN_S2_RPW / 2];
-    v2d hq[8]; // a rolling window of eight rows: while rows r .. r + 3 are multiplied, rows r + 4 .. r + 7 are on their way out of the park
+    v2d hq[8]; // PARK: a rolling window of eight rows -- while rows r .. r + 3 are multiplied, rows r + 4 .. r + 7 are on their way out of the park
 #pragma unroll
     for (int r = 0; r < QN_S2_RPW; ++r) {
-        wait_row(r); // (at r = 0, 4, 8, 12: the hook has seen rows up to r + 7 parked)
-        if ((r & 3) == 0) {
-            if (r == 0) {
+        v2d hv;
+        if (PARK) {
+            wait_row(r); // (at r = 0, 4, 8, 12: the hook has seen rows up to r + 7 parked)
+            if ((r & 3) == 0) {
+                if (r == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) hq[k] = parkw[k * 64 + lane];
-            }
-            if (r + 4 < QN_S2_RPW) {
+                    for (int k = 0; k < 4; ++k) hq[k] = parkw[k * 64 + lane];
+                }
+                if (r + 4 < QN_S2_RPW) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) hq[(r + 4 + k) & 7] = parkw[(r + 4 + k) * 64 + lane];
+                    for (int k = 0; k < 4; ++k) hq[(r + 4 + k) & 7] = parkw[(r + 4 + k) * 64 + lane];
+                }
             }
+            hv = hq[r & 7];
+        } else {
+            hv = h[r];
+            if (r == 0) h[0] = ld2(refill0);
         }
-        const v2d hv = hq[r & 7];
         const double xi = qn_lane_bcast(xr, r);
         double t0 = hv.x * xtj.x;
         t0 = __builtin_fma(hv.y, xtj.y, t0);
@@ -124,8 +136,9 @@ __device__ __forceinline__ double qn_s2r_item(const QnS2RTrial& v, const bool di
         } else racc[r] = t0;
         cx = __builtin_fma(hv.x, xi, cx);
         cy = __builtin_fma(hv.y, xi, cy);
-        // (a use per row: without it the compiler sinks every row's arithmetic below the last wait -- see qn_s2_eval_item)
-        qn_keepalive(cx); qn_keepalive(cy); qn_keepalive(racc[r & (QN_S2_RPW / 2 - 1)]);
+        // (a use per row: without it the compiler sinks every row's arithmetic below the last wait -- eight rows held in registers, and nothing
+        // multiplied while the next row is on its way)
+        if (PARK) { qn_keepalive(cx); qn_keepalive(cy); qn_keepalive(racc[r & (QN_S2_RPW / 2 - 1)]); }
     }
     if (!qn_s2_col_on(diag, lane, wave)) { cx = 0.0; cy = 0.0; }
     colred_w[2 * lane] = cx;
@@ -143,12 +156,12 @@ __device__ __forceinline__ double qn_s2r_item(const QnS2RTrial& v, const bool di
             pg = __builtin_fma(dq, racc[0] - bq, pg);
         }
     }
-    sacc[0] = sacc[0] + pf; sacc[1] = sacc[1] + pg; sacc[2] = sacc[2] + p4; sacc[3] = sacc[3] + p5;
+    o.pf = pf; o.pg = pg; o.p4 = p4; o.p5 = p5;
     return racc[0];
 }
 
 #ifdef QN_S2_STAMPS
-#define QN_S2R_STAMP(k, t) do { if (threadIdx.x == (t)) SH.stamps[k] = wall_clock64(); } while (0)
+#define QN_S2R_STAMP(k, t) do { if (ltid == (t)) SH.stamps[k] = wall_clock64(); } while (0)
 #else
 #define QN_S2R_STAMP(k, t) do { } while (0)
 #endif
@@ -169,8 +182,19 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
     const int tid = threadIdx.x, lane = tid & 63;
     // (the wave index as a SCALAR: with `tid >> 6` the compiler takes every `if (wave ...)` for a divergent branch, lays both sides out in one
     // stream and keeps the movers' 16-row windows allocated across wave 0's run of the state machine -- 180 registers instead of 88 + 80)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ROLES BY A CHECKERBOARD over (wave / 4, wave % 4): whichever of the two the hardware takes for a wave's SIMD, every SIMD gets two movers and two
+    // multipliers.  (First version: waves 0..7 moved, 8..15 multiplied -- and in-kernel stamps had the multipliers of ONE workgroup finish the same
+    // sixteen rows 8.3, 9.9 and 11.3 us after entry: four of them on one SIMD, behind one another.)  `wave` below is the LOGICAL index: 0..7 movers
+    // (0 = physical wave 0: the prologue addresses its lanes by threadIdx.x), 8..15 multipliers; 8 + w takes the rows mover w parks.
+    const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = (pwave >> 2) * 2 + ((pwave & 3) >> 1) + ((((pwave >> 2) + (pwave & 3)) & 1) ? QN_S2_WAVES : 0);
+    const int ltid = wave * 64 + lane; // (the logical thread index: what the diagnostic stamps and the ring's clearing address)
     const size_t np = (size_t)a.np;
+    // (the kernel's own first 32 KB -- the prologue and the movers' code -- are read as DATA by four multipliers at entry: qn_kernels.hip.h, CODE WARM-UP.
+    // Round 5's kernel let waves 1..4 do it in front of their rows; a wave's loads return in order, so those four movers' rows -- and the
+    // multipliers behind them -- ran 1.5-3 us behind the other three's: in-kernel stamps.)
+    unsigned long long pc0;
+    asm volatile("s_getpc_b64 %0" : "=s"(pc0));
     QN_S2R_STAMP(0, 0);
     // ONE barrier in front of the exchange: the ring's words are zero (wave 8 clears them first thing) before anybody reads or counts them.
     // Wave 0 and the multipliers execute it BEHIND their first requests (registers only): the control block, the table and the trial point's
@@ -179,6 +203,11 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
     const int wg = QN_S2_WG(a);
     const int ij0 = qn_s2_item_of_index(wg, a.nb), ij1 = qn_s2_item_of_index(a.G + wg, a.nb); // (the host deals the pair instance's lists in order)
     bool bad = false;
+    const int Ia = ij0 >> 16, Ja = ij0 & 0xffff, Ib = ij1 >> 16, Jb = ij1 & 0xffff;
+    constexpr bool diag_a = false; // (the host runs this kernel only where every workgroup's FIRST item is an off-diagonal tile: minimize_impl)
+    const bool diag_b = Ib == Jb;
+    double row_b = 0.0, row_c = 0.0; // (movers) the second item's row totals, the sliver row's total
+    QnS2Sliver sl{};
     if (wave < QN_S2_WAVES) {
         // ------------------------------------------------------------------ movers
         v2d h[QN_S2_RPW];
@@ -222,9 +251,7 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
             // (the movers' barrier comes FIRST: behind their nineteen requests it fell 5-6 us after entry -- a wave is held at a request while the
             // CU's memory queue is full -- and wave 0, waiting in its own, had the state machine done at 8-10 us instead of 4.4)
             entry_barrier();
-            QN_S2R_STAMP(5, 64); // (wave 1 behind the entry barrier)
-            unsigned cw = 0u;
-            if (wave <= 4) cw = qn_code_warm_issue((wave - 1) * 64 + lane); // (qn_kernels.hip.h, CODE WARM-UP)
+            __builtin_amdgcn_s_setprio(2); // (the movers keep the CU's memory queue full: their few instructions go in front of the multipliers' many)
             // wave 0's rows of the first item, three per mover, go out FIRST and are parked first: they come back in front of the wave's own
             const int r0 = (wave - 1) * 3;
             const double* q0 = tile_base(ij0, 0, lane); // (wave 0 has no clone lanes: qn_s2_col(., ., 0) = 2 lane)
@@ -240,52 +267,60 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
             for (int k = 0; k < 3; ++k)
                 if (r0 + k < QN_S2_RPW) { park[0][r0 + k][lane] = t3[k]; ++n0; }
             qn_s2r_publish_add(&Y.cnt0, n0);
-            QN_S2R_STAMP(6, 448);
 #pragma unroll
             for (int r = 0; r < QN_S2_RPW; ++r) {
                 park[wave][r][lane] = h[r];
                 h[r] = ld2(q1 + (size_t)r * np);
-                if ((r & 3) == 3) qn_s2r_publish(&Y.prod[wave], (unsigned)r + 1u);
+                if ((r & 3) == 3) qn_s2r_publish<false>(&Y.prod[wave], (unsigned)r + 1u);
             }
+            __builtin_amdgcn_s_setprio(0);
             QN_S2R_STAMP(7, 448); // (wave 7: its sixteen rows parked, the second item requested)
-            qn_code_warm_done(cw, a.n < 0, a.wgS);
             qn_s2r_wait_ge<8>(&Y.mdone, 1u, bad); // (long naps: the machine's wave shares its SIMD with three of the waiting ones)
         }
         if (!L.mine) return; // (every wave of the workgroup leaves here, or none does)
-        // second item: row r into slot r once the multiplier has read the first item's row r; the register of row 0 takes the sliver's row
-        const QnS2Sliver sl = qn_s2_sliver(a, opaque(wave));
-        const double* slp = a.Q + (size_t)(sl.D * QN_TB + sl.row) * np + (size_t)sl.D * QN_TB + 2 * opaque(lane);
-        unsigned freed = 0u;
-#pragma unroll
-        for (int r = 0; r < QN_S2_RPW; ++r) {
-            if (freed < (unsigned)r + 1u) freed = qn_s2r_wait_ge(&Y.cons[wave], (unsigned)r + 1u, bad);
-            park[wave][r][lane] = h[r];
-            if (r == 0) h[0] = ld2(slp);
-            if ((r & 3) == 3) qn_s2r_publish(&Y.prod[wave], 17u + (unsigned)r);
+        // ---- the SECOND item is multiplied by the wave that holds it, out of its register window (round 5's from-register item): by now the
+        // multipliers have been at the first item for 2-3 us, and nothing of the second item has to go through LDS
+        const int ln = opaque(lane);
+        sl = qn_s2_sliver(a, wave);
+        const double* slp = a.Q + (size_t)(sl.D * QN_TB + sl.row) * np + (size_t)sl.D * QN_TB + 2 * ln;
+        qn_s2r_wait_ge(&Y.eready, 5u, bad); // the trial point is staged (multipliers 0..4, right behind the machine)
+        const int rr = wave * QN_S2_RPW + (ln & 15);
+        QnS2RTrial tb;
+        tb.xr = SH.xb_r[rr]; tb.dr = SH.db_r[rr]; tb.b_r = SH.bb_r[rr]; tb.g_r = SH.gb_r[rr];
+        tb.xtj = *reinterpret_cast<const v2d*>(SH.xb_c + 2 * ln); tb.dj = *reinterpret_cast<const v2d*>(SH.db_c + 2 * ln);
+        QnS2SliverVec slv; // (qn_s2_sliver_prep's values; the wave's sliver row is ONE row: its row-side values are the same in every lane -- scalar registers)
+        slv.xtj = *reinterpret_cast<const v2d*>(SH.xs_c + 2 * ln);
+        slv.xr = qn_uniform(SH.ss[wave][0]); slv.dr = qn_uniform(SH.ss[wave][1]); slv.b = qn_uniform(SH.ss[wave][2]);
+        slv.gd = qn_uniform(SH.ss[wave][3] * slv.dr); slv.nf = isfinite(slv.dr) ? 0.0 : 1.0;
+        QnS2RSums sb;
+        row_b = qn_s2r_item<false>(tb, diag_b, ln, wave, nullptr, h, slp, colred[1][wave], sb, QnS2RNoWait());
+        QN_S2R_STAMP(14, 448); // (wave 7: the second item done)
+        // the lane's shares of the group's scalars in round 5's order: ((0 + first item) + second item) + sliver -- the first item's from its multiplier
+        qn_s2r_wait_ge(&Y.adone[wave], 1u, bad);
+        const v2d fa = park[wave][0][ln]; // (pf, pg of the first item on this lane; it is never a diagonal tile: its g'd and non-finite shares are zero)
+        double sacc[4] = {(0.0 + fa.x) + sb.pf, (0.0 + fa.y) + sb.pg, (0.0 + 0.0) + sb.p4, (0.0 + 0.0) + sb.p5};
+        const double t0s = qn_s2_eval_sliver(slv, h[0], sl.row, ln, sacc);
+        { // ONE fold for the pair: the four scalars and the sliver's row total (value 6: lane 48 holds it)
+            double sv[8] = {sacc[0], sacc[1], 0.0, 0.0, sacc[2], sacc[3], t0s, 0.0};
+            QnWaveFold<8, 32, true>::run(sv, ln);
+            if ((ln & 7) == 0 && ln < 48) sred[wave][ln >> 3] = sv[0];
+            row_c = sv[0];
         }
-        QN_S2R_STAMP(8, 448); // (wave 7: the second item parked)
-        if (freed < 17u) freed = qn_s2r_wait_ge(&Y.cons[wave], 17u, bad);
-        park[wave][0][lane] = h[0];
-        qn_s2r_publish(&Y.prod[wave], 33u);
-        QN_S2R_STAMP(3, 0); // (wave 0: its second item and its sliver row parked)
+        QN_S2R_STAMP(12, 448); // (wave 7: folded)
+        QN_S2R_STAMP(3, 0);    // (wave 0: folded)
     }
-    // ---------------------------------------------------------------------- multipliers (wave 8 + w is the old kernel's wave w)
-    const int mw = wave - QN_S2_WAVES; // (movers: negative, and nothing below the exchange uses it)
-    const int Ia = ij0 >> 16, Ja = ij0 & 0xffff, Ib = ij1 >> 16, Jb = ij1 & 0xffff;
-    constexpr bool diag_a = false; // (the host runs this kernel only where every workgroup's FIRST item is an off-diagonal tile: minimize_impl)
-    const bool diag_b = Ib == Jb;
-    double row_b = 0.0, row_c = 0.0;
-    QnS2Sliver sl{};
+    // ---------------------------------------------------------------------- multipliers: wave 8 + w takes the FIRST item's rows of wave w out of the park
+    const int mw = wave - QN_S2_WAVES; // (movers: negative, and nothing below uses it for them)
     if (wave >= QN_S2_WAVES) {
-        if (tid - QN_S2_WAVES * 64 < (int)(sizeof(QnS2RSync) / 4)) reinterpret_cast<unsigned*>(&Y)[tid - QN_S2_WAVES * 64] = 0u; // (wave 8)
+        if (wave == QN_S2_WAVES && lane < (int)(sizeof(QnS2RSync) / 4)) reinterpret_cast<unsigned*>(&Y)[lane] = 0u; // (wave 8)
 #ifdef QN_S2_STAMPS
-        if (tid - QN_S2_WAVES * 64 < 16 && tid - QN_S2_WAVES * 64 > 0) SH.stamps[tid - QN_S2_WAVES * 64] = 0ull;
+        if (wave == QN_S2_WAVES && lane < 16 && lane > 0) SH.stamps[lane] = 0ull;
 #endif
-        sl = qn_s2_sliver(a, mw);
+        const QnS2Sliver slm = qn_s2_sliver(a, mw);
         // Multipliers 0..4 request, for ONE of the workgroup's five blocks each (first item: I, J; second item: I, J; the sliver's diagonal block),
         // the entries the trial point is made of -- x for both settings of the buffer toggle the control block holds, v, s likewise, u, and b, g
         // where a diagonal tile or the sliver needs them: two consecutive entries per lane, eight 1 KB requests per wave, BEFORE the movers' burst.
-        const int blk = mw == 0 ? Ia : (mw == 1 ? Ja : (mw == 2 ? Ib : (mw == 3 ? Jb : sl.D))); // (uniform)
+        const int blk = mw == 0 ? Ia : (mw == 1 ? Ja : (mw == 2 ? Ib : (mw == 3 ? Jb : slm.D))); // (uniform)
         v2d e_x0, e_x1, e_v, e_s0, e_s1, e_u, e_b, e_g;
         if (mw < 5) {
             const unsigned ei = (unsigned)blk * QN_TB + 2u * (unsigned)lane;
@@ -293,11 +328,12 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
             e_s0 = ld2(a.F.S0 + ei); e_s1 = ld2(a.F.S0 + np + ei); e_u = ld2(a.F.UN + ei);
             if (mw == 2 || mw == 4) { e_b = ld2(a.F.b + ei); e_g = ld2(a.F.G + ei); }
         }
+        unsigned cw = 0u;
+        if (mw >= 4) cw = ((const volatile unsigned*)(pc0 & ~127ull))[(size_t)((mw - 4) * 64 + lane) * 32];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (wave 8: the ring's words are cleared)
         entry_barrier();
         qn_s2r_wait_ge<8>(&Y.mdone, 1u, bad); // (long naps: the machine's wave shares its SIMD with three of the waiting ones)
         if (!L.mine) return;
-        QN_S2R_STAMP(2, 512);
         const QnEvalReq q = qn_s2_eval_req<true>(L.c, false);
         if (mw < 5) { // the trial point at this wave's block: qn_s2_trial, entry by entry -- what every wave of round 5's kernel formed for itself
             const v2d ex = q.xc ? e_x1 : e_x0, es = q.sc ? e_s1 : e_s0;
@@ -311,7 +347,7 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
             }
             if (mw == 2) { *reinterpret_cast<v2d*>(SH.bb_r + 2 * lane) = e_b; *reinterpret_cast<v2d*>(SH.gb_r + 2 * lane) = e_g; }
             if (mw == 4) { // the sliver's eight rows of block D: xt, d, b, g per row (rows 8 s .. 8 s + 7: lanes 4 s .. 4 s + 3)
-                const int j = 2 * lane - (sl.row - mw); // (sl.row - mw = 8 s: the first of the workgroup's eight rows)
+                const int j = 2 * lane - (slm.row - mw); // (slm.row - mw = 8 s: the first of the workgroup's eight rows)
                 if (j >= 0 && j < 8) {
                     SH.ss[j][0] = xt.x; SH.ss[j][1] = dd.x; SH.ss[j][2] = e_b.x; SH.ss[j][3] = e_g.x;
                     SH.ss[j + 1][0] = xt.y; SH.ss[j + 1][1] = dd.y; SH.ss[j + 1][2] = e_b.y; SH.ss[j + 1][3] = e_g.y;
@@ -320,48 +356,30 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
             qn_s2r_publish_add(&Y.eready, 1u);
         }
         qn_s2r_wait_ge(&Y.eready, 5u, bad);
-        QN_S2R_STAMP(9, 960); // (wave 15: the trial point is staged)
+        QN_S2R_STAMP(9, 960); // (multiplier 7: the trial point is staged)
         const int rr = mw * QN_S2_RPW + (lane & 15);
-        QnS2RTrial ta, tb;
+        QnS2RTrial ta;
         ta.xr = SH.xa_r[rr]; ta.dr = SH.da_r[rr]; ta.b_r = 0.0; ta.g_r = 0.0;
         ta.xtj = *reinterpret_cast<const v2d*>(SH.xa_c + 2 * lane); ta.dj = *reinterpret_cast<const v2d*>(SH.da_c + 2 * lane);
-        tb.xr = SH.xb_r[rr]; tb.dr = SH.db_r[rr]; tb.b_r = SH.bb_r[rr]; tb.g_r = SH.gb_r[rr];
-        tb.xtj = *reinterpret_cast<const v2d*>(SH.xb_c + 2 * lane); tb.dj = *reinterpret_cast<const v2d*>(SH.db_c + 2 * lane);
-        QnS2SliverVec slv; // (qn_s2_sliver_prep's values; the wave's sliver row is ONE row: its row-side values are the same in every lane -- scalar registers)
-        slv.xtj = *reinterpret_cast<const v2d*>(SH.xs_c + 2 * lane);
-        slv.xr = qn_uniform(SH.ss[mw][0]); slv.dr = qn_uniform(SH.ss[mw][1]); slv.b = qn_uniform(SH.ss[mw][2]);
-        slv.gd = qn_uniform(SH.ss[mw][3] * slv.dr); slv.nf = isfinite(slv.dr) ? 0.0 : 1.0;
-        unsigned have = 0u; // (uniform) the last count read from the mover: the word is polled only when it does not cover the row yet
+        unsigned have = 0u; // (uniform) the last count read from the mover: the word is polled only when it does not cover the rows yet
         if (mw == 0) { qn_s2r_wait_ge(&Y.cnt0, 16u, bad); have = 16u; } // (wave 0's share of the first item: parked by the other movers)
-        double sacc[4] = {0.0, 0.0, 0.0, 0.0};
-        const v2d* pw = &park[mw][0][0];
-        // in front of rows r .. r + 3 of an item whose first row is number `base` of the mover's sequence: hand back the slots of the four rows
-        // before (they are in registers by now), wait for these four and the next four if the last count read does not cover them
-        auto row_hook = [&](const unsigned base, const int r) __attribute__((always_inline)) {
+        // in front of rows r .. r + 3: wait for these four and the four that are read ahead, if the last count read does not cover them
+        auto row_hook = [&](const int r) __attribute__((always_inline)) {
             if (r & 3) return; // (rows are taken four at a time: one look at the mover's count, four reads in flight together)
-            if (r) qn_s2r_publish(&Y.cons[mw], base + (unsigned)r);
-            const unsigned want = base + (unsigned)(r + 8 < QN_S2_RPW ? r + 8 : QN_S2_RPW); // (the rows about to be multiplied AND the four to be read ahead)
+            const unsigned want = (unsigned)(r + 8 < QN_S2_RPW ? r + 8 : QN_S2_RPW);
             if (have < want) have = qn_s2r_wait_ge(&Y.prod[mw], want, bad);
         };
-        const double row_a = qn_s2r_item(ta, diag_a, lane, mw, pw, colred[0][mw], sacc, [&](const int r) __attribute__((always_inline)) { row_hook(0u, r); });
-        qn_s2r_publish(&Y.cons[mw], 16u);
+        v2d hnone[QN_S2_RPW]; // (the from-park instance never touches a window)
+        QnS2RSums sa;
+        const double row_a = qn_s2r_item<true>(ta, diag_a, lane, mw, &park[mw][0][0], hnone, nullptr, colred[0][mw], sa, row_hook);
         if ((lane & 3) == 0) a.partE[(unsigned)((Ia * a.nb + Ja) * QN_TB + mw * QN_S2_RPW + (lane >> 2))] = row_a; // (off-diagonal: its slot is its own)
-        QN_S2R_STAMP(13, 960);
-        row_b = qn_s2r_item(tb, diag_b, lane, mw, pw, colred[1][mw], sacc, [&](const int r) __attribute__((always_inline)) { row_hook(16u, r); });
-        qn_s2r_publish(&Y.cons[mw], 32u);
-        QN_S2R_STAMP(14, 960);
-        if (have < 33u) have = qn_s2r_wait_ge(&Y.prod[mw], 33u, bad);
-        const v2d hs = park[mw][0][lane];
-        const double t0s = qn_s2_eval_sliver(slv, hs, sl.row, lane, sacc);
-        { // ONE fold for the pair: the four scalars and the sliver's row total (value 6: lane 48 holds it)
-            double sv[8] = {sacc[0], sacc[1], 0.0, 0.0, sacc[2], sacc[3], t0s, 0.0};
-            QnWaveFold<8, 32, true>::run(sv, lane);
-            if ((lane & 7) == 0 && lane < 48) sred[mw][lane >> 3] = sv[0];
-            row_c = sv[0];
-        }
-        QN_S2R_STAMP(12, 960);
-        QN_S2R_STAMP(1, 512);  // (wave 8: folded)
-        QN_S2R_STAMP(10, 768); // (wave 12: folded)
+        // the lane's shares of the two scalar sums go to the mover that holds the second item, through the first slot of the park (all of it has been read)
+        park[mw][0][lane] = (v2d){sa.pf, sa.pg};
+        qn_s2r_publish(&Y.adone[mw], 1u);
+        qn_code_warm_done(cw, a.n < 0, a.wgS);
+        QN_S2R_STAMP(13, 960); // (multiplier 7: the first item done)
+        QN_S2R_STAMP(1, 512);  // (multiplier 0)
+        QN_S2R_STAMP(10, 768); // (multiplier 4)
     }
     __syncthreads();
     QN_S2R_STAMP(4, 0);
@@ -378,9 +396,9 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
     }
     if (tid < QN_S2_NSE) wgk = wgk + qn_s2_wave_total(sred, tid); // (waves in order; scalars 2..5 are zero off the diagonal items)
     if (diag_a || diag_b) __syncthreads(); // (uniform)
-    if (wave >= QN_S2_WAVES) {
+    if (wave < QN_S2_WAVES) {
         if ((lane & 3) == 0) {
-            const int rl = mw * QN_S2_RPW + (lane >> 2);
+            const int rl = wave * QN_S2_RPW + (lane >> 2);
             double v = row_b;
             if (diag_b) v = v + colsum[rl];
             a.partE[(unsigned)((Ib * a.nb + Jb) * QN_TB + rl)] = v;

@@ -30,9 +30,9 @@ st = buf.reshape(64, 256, 16).astype(np.int64)
 # folded, 4 after the pair's barrier, 5 pair's slots stored, 15 end
 order = [9, 10, 11, 1, 6, 7, 8, 2, 13, 14, 12, 3, 4, 5, 15]
 if os.environ.get("QN_STAMPS_RING"):  # the mover / multiplier kernel (qn_sym2r.hip.h) stamps other things under the same numbers
-    order = [5, 11, 2, 9, 6, 7, 8, 3, 13, 14, 12, 1, 10, 4, 15]
-    label = {5: "w1 past the entry barrier", 9: "w15 trial point staged", 11: "machine + flag", 2: "w8 starts", 6: "w7 parked wave 0's rows", 7: "w7 first item parked, second requested", 8: "w7 second item parked",
-             3: "w0 second item + sliver parked", 13: "w15 item a done", 14: "w15 item b done", 12: "w15 folded", 1: "w8 folded", 10: "w12 folded", 4: "exchange barrier", 15: "end"}
+    order = [11, 9, 7, 13, 1, 10, 14, 12, 3, 4, 15]
+    label = {11: "machine + flag", 9: "m7 trial point staged", 7: "w7 first item parked, second requested", 13: "first item done: m7", 1: "m0", 10: "m4",
+             14: "w7 second item done", 12: "w7 folded", 3: "w0 folded", 4: "exchange barrier", 15: "end"}
 else:
   label = {12: "w7 pair folded", 13: "w7 item a done", 14: "w7 item b done", 6: "w7 requested", 7: "w7 parked", 8: "w7 at barrier", 9: "ctl", 10: "sums", 11: "machine", 1: "w0 at barrier", 2: "barrier", 3: "w0 pair folded", 4: "pair barrier", 5: "pair stored", 15: "end"}
 for slot in range(64):
