@@ -819,7 +819,7 @@ struct qn_solver {
     int s2_sl_first = 0, s2_sl_per = 0, s2_sl_cfg = -1; // row slivers (QnS2Args.sl_first / sl_per); the switches the lists were built for
     bool no_sliver = false;    // diagnostics: sym2 without row slivers (round 2's work lists)
     bool no_pair = false;      // diagnostics: the general evaluation kernel where the two-items-and-a-sliver instance would run
-    bool ring_toggle = false;  // measurement: the two-items-and-a-sliver instance as mover + multiplier waves (qn_sym2r.hip.h; flips what QN_S2_RING says)
+    bool ring_toggle = false;  // diagnostics: round 5's two-items-and-a-sliver instance where the mover / multiplier kernel (qn_sym2r.hip.h) would run (flips what QN_S2_RING says)
     bool tred = false;         // measurement: the update-reduce in the tail of the update-tile launch (s2_hpass_kernel<.., TRED>: bit-identical, slower)
     int* s2_cnt = nullptr;     // tail reduce: arrival counters of the block-rows
     int gen_slots_hint = 0;    // generic pipelined path: evaluation slots per period the last batch needed (0: none run yet)
@@ -1261,7 +1261,7 @@ extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_sp
     if (rows_per_block == -10) { s->newton_lu_no_la = 1; return QN_OK; } // diagnostics: ... one stream, no look-ahead
     if (rows_per_block == -8) { s->newton_lu_percol = 1; return QN_OK; } // diagnostics: ... with the per-column panel kernels
     if (rows_per_block == -9) { s->no_pair = !s->no_pair; return QN_OK; }     // diagnostics: general evaluation kernel (toggles)
-    if (rows_per_block == -15) { s->ring_toggle = !s->ring_toggle; return QN_OK; } // measurement: the pair instance's evaluation as mover + multiplier waves (toggles)
+    if (rows_per_block == -15) { s->ring_toggle = !s->ring_toggle; return QN_OK; } // diagnostics: round 5's pair instance instead of the mover / multiplier kernel (toggles)
     if (rows_per_block == -14) { s->no_s2bnd = !s->no_s2bnd; return QN_OK; }   // tests: bounded runs on the generic path (toggles)
     if (rows_per_block == -13) { s->tred = !s->tred; return QN_OK; }         // measurement: the update-reduce in the update-tile launch's tail (toggles)
     if (rows_per_block == -7) { s->no_sliver = !s->no_sliver; return QN_OK; } // diagnostics: sym2 without row slivers (toggles)
@@ -3064,9 +3064,9 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.sh_nsum = c->use_allreduce ? 1 : c->world;
         a.evS = s->s2_evS; a.xg = s->symsh_xg; a.sl_off = s->s2_sl_off; a.sl_idx = s->s2_sl_idx;
         if (c->world > 1 || r.gobj) { a.fold = 0; a.pair = 0; }
-        { // measurement: the pair instance's evaluation as mover + multiplier waves (qn_sym2r.hip.h; QN_S2_RING=1 / set_tiling(-15, 0)): the same bits as
-          // round 5's kernel, 0.5-0.7 us SLOWER per launch (profiles/r06_a_*), hence off by default.  It needs every workgroup's FIRST item off the diagonal.
-            static const bool ring_env = getenv("QN_S2_RING") && atoi(getenv("QN_S2_RING")) == 1;
+        { // the pair instance's evaluation as mover + multiplier waves (qn_sym2r.hip.h): the same bits as round 5's kernel, 14.3 us against 15.3 per launch
+          // (profiles/r06_a_*).  QN_S2_RING=0 / set_tiling(-15, 0): round 5's kernel.  It needs every workgroup's FIRST item off the diagonal.
+            static const bool ring_env = !(getenv("QN_S2_RING") && atoi(getenv("QN_S2_RING")) == 0);
             a.ring = (a.pair && (ring_env != s->ring_toggle) && s->s2_nb * (s->s2_nb - 1) / 2 >= s->s2_G) ? 1 : 0;
         }
         if (r.bnd) a.fold = 0;

@@ -24,6 +24,9 @@
 #pragma once
 
 #define QN_S2R_TPB 1024
+#ifndef QN_S2R_HEAD
+#define QN_S2R_HEAD 4 // first-item rows a mover requests in front of the entry barrier (behind wave 0's three)
+#endif
 #define QN_S2R_SPIN_MAX (1 << 18) // polls of an LDS word (~150 cycles each with the s_sleep) before the workgroup gives up
 
 struct QnS2RSync {
@@ -250,8 +253,8 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
         } else {
             // (the movers' barrier comes FIRST: behind their nineteen requests it fell 5-6 us after entry -- a wave is held at a request while the
             // CU's memory queue is full -- and wave 0, waiting in its own, had the state machine done at 8-10 us instead of 4.4)
-            entry_barrier();
-            __builtin_amdgcn_s_setprio(2); // (the movers keep the CU's memory queue full: their few instructions go in front of the multipliers' many)
+            // (... but behind the wave's first QN_S2R_HEAD requests: seven movers' worth of them fit the CU's memory queue without holding anybody, and
+            // they are in flight while the workgroup's last waves arrive -- the barrier falls ~1.6 us after wave 0's first instruction)
             // wave 0's rows of the first item, three per mover, go out FIRST and are parked first: they come back in front of the wave's own
             const int r0 = (wave - 1) * 3;
             const double* q0 = tile_base(ij0, 0, lane); // (wave 0 has no clone lanes: qn_s2_col(., ., 0) = 2 lane)
@@ -260,7 +263,10 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
             for (int k = 0; k < 3; ++k) t3[k] = ld2(q0 + (size_t)min(r0 + k, QN_S2_RPW - 1) * np);
             const double* qa = tile_base(ij0, wave, lane);
 #pragma unroll
-            for (int r = 0; r < QN_S2_RPW; ++r) h[r] = ld2(qa + (size_t)r * np);
+            for (int r = 0; r < QN_S2R_HEAD; ++r) h[r] = ld2(qa + (size_t)r * np);
+            entry_barrier();
+#pragma unroll
+            for (int r = QN_S2R_HEAD; r < QN_S2_RPW; ++r) h[r] = ld2(qa + (size_t)r * np);
             const double* q1 = tile_base(ij1, wave, lane);
             unsigned n0 = 0u;
 #pragma unroll
@@ -273,7 +279,6 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
                 h[r] = ld2(q1 + (size_t)r * np);
                 if ((r & 3) == 3) qn_s2r_publish<false>(&Y.prod[wave], (unsigned)r + 1u);
             }
-            __builtin_amdgcn_s_setprio(0);
             QN_S2R_STAMP(7, 448); // (wave 7: its sixteen rows parked, the second item requested)
             qn_s2r_wait_ge<8>(&Y.mdone, 1u, bad); // (long naps: the machine's wave shares its SIMD with three of the waiting ones)
         }

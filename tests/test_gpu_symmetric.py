@@ -195,24 +195,24 @@ def test_tail_reduce_is_the_reduce_launch_bit_for_bit(qn, qo, n, method, lsname)
 
 @pytest.mark.parametrize("method,lsname", [("bfgs", "mt"), ("dfp", "mt"), ("bfgs", "bt")])
 def test_ring_evaluation_is_the_pair_instance_bit_for_bit(qn, qo, method, lsname):
-    """Round 6, set_tiling(-15, 0): at n = 4096 the evaluation tiles as s2_evalr_kernel (csrc/qn_sym2r.hip.h) -- a 16-wave workgroup whose eight
+    """Round 6: at n = 4096 the evaluation tiles run as s2_evalr_kernel (csrc/qn_sym2r.hip.h) -- a 16-wave workgroup whose eight
     mover waves stream the two tiles and the sliver as round 5's kernel does, while eight multiplier waves take the FIRST tile's rows out of the LDS
     park as they land (the trial point staged once per workgroup) and the movers multiply the second tile out of their own registers; the lanes'
     shares of the scalar sums change hands through LDS.  The same products, sums and exchanges in the same order as round 5's two-items-and-a-
     sliver instance: trace, iterates and inverse Hessian must be equal bit for bit, pipelined and synchronous; repeated, because a row consumed
-    before it was parked would depend on timing.  Measured 0.5-0.7 us slower per launch than the kernel it mirrors (profiles/r06_a_*): a tested
-    variant, off by default.  Backtracking evaluates at points it rejects: launches whose request is not an evaluation's leave early."""
+    before it was parked would depend on timing.  14.3 us per launch against 15.3 (profiles/r06_a_*): the default since round 6; set_tiling(-15, 0)
+    selects round 5's kernel.  Backtracking evaluates at points it rejects: launches whose request is not an evaluation's leave early."""
     n = 4096
     diag = P.synth_diag(n); b, x0 = P.synth_vectors(n)
     obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
     iters = 30
-    base, st0 = _run(qn, method, lsname, obj, x0, iters)
+    base, st0 = _run(qn, method, lsname, obj, x0, iters, tiling=(-15, 0))
     tr0, xs0 = base.trace()
     h0 = base.approx_inv_hessian()
     assert base.stats()["path"] & 16 and len(tr0) == iters
     assert all(np.isfinite(r["f"]) for r in tr0)
     for rep, sync in enumerate((0, 1, 0, 0, 1, 0)):
-        s, st = _run(qn, method, lsname, obj, x0, iters, tiling=(-15, 0), sync=sync)
+        s, st = _run(qn, method, lsname, obj, x0, iters, sync=sync)
         tr, xs = s.trace()
         assert st == st0 and tr == tr0 and np.array_equal(xs, xs0), (rep, sync)
         assert np.array_equal(s.approx_inv_hessian(), h0)
