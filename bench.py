@@ -60,6 +60,27 @@ def run_iterations(qn, solver, ls, obj, x0, iters):
     return restarts
 
 
+def timed_regions(run_exact, stats, synchronize, steps, nregions):
+    """`nregions` timed regions of exactly `steps` iterations each (run_exact(k) runs k iterations, restarting a run that converges, and
+    returns the number of restarts).  What a region did is DIFFERENCED from the solver's cumulative counters, not assumed: round 5's config-5
+    leg divided by `steps` while a converged run had done fewer.  Raises when a region's count is not `steps`."""
+    out = []
+    for _ in range(nregions):
+        synchronize()
+        st0 = stats()
+        t0 = time.perf_counter()
+        restarts = run_exact(steps)
+        synchronize()
+        dt = time.perf_counter() - t0
+        st1 = stats()
+        its = st1["total_iterations"] - st0["total_iterations"]
+        if its != steps:
+            raise RuntimeError(f"a timed region ran {its} iterations, not the {steps} it is quoted for")
+        out.append({"s": dt, "iterations": its, "s_per_iteration": dt / its, "restarts": restarts,
+                    "evaluations": st1["total_oracle_evals"] - st0["total_oracle_evals"]})
+    return out
+
+
 def totals(solver):
     """Counters that accumulate over every qn_minimize call of the solver (the per-call ones restart with k)."""
     st = solver.stats()
@@ -95,8 +116,8 @@ def cpu_baseline(n, iters, extra=True):
     code reached 87-137); round 4 moved it to a child that ran AFTER the GPU measurement, beside a parent that still held a GPU
     context, its runtime threads and 250 MB of pinned memory: 269-457 it/s inside full runs against 499-515 standalone.  Now the
     parent starts the child first thing -- before torch, HIP or the library are loaded: the parent is one thread blocked in
-    wait() -- with the pinning in the child's environment before any OpenMP runtime exists; the child takes THREE sub-samples
-    per leg and reports all of them and their median.  Returns {"config2": {...}, "config4": {...}, "config5": {...}} or an
+    wait() -- with the pinning in the child's environment before any OpenMP runtime exists; the child takes several sub-samples
+    per leg (five for the headline's, round 6) and reports all of them and their median.  Returns {"config2": {...}, "config4": {...}, "config5": {...}} or an
     {"error": ...} object (a failing CPU leg never loses the bench line: ADVICE r4)."""
     env = dict(os.environ)
     # spread: the team's threads one per core, as far apart as the places allow -- on the GPU boxes' 2 x 64-core hosts each of the 16
@@ -132,7 +153,9 @@ def cpu_leg_config2(qo, n, iters, threads):
     reference's literal update is O(n^3): 2.7e11 flop per iteration at n = 4096), reference call sequence (5 oracle calls per
     iteration), OpenMP over all cores.  Every sweep is contiguous per thread -- the symmetric H and Q are read by rows = columns,
     four rows per thread in flight, pages first touched by the thread that streams them -- so the port is bandwidth-bound and
-    the achieved GB/s is printed next to the core count.  THREE sub-samples of ~3 s each; value = their median."""
+    the achieved GB/s is printed next to the core count.  FIVE sub-samples of ~2 s each (round 6, VERDICT r5 item 9: three moved 18 % between
+    runs on a shared host); value = their median, with the minimum and the maximum beside it.  (Q's pages are first touched by the threads that
+    sweep them -- qo_synth_fill_rows follows the evaluation's partition --, H's by qo_solver_create.)"""
     diag, b, x0 = synth_inputs(n)
     q = qo.synth_rows(n, 0, n, SEED, diag, nthreads=threads)
     o = qo.QuadraticOracle(q, b, nthreads=threads)
@@ -141,9 +164,9 @@ def cpu_leg_config2(qo, n, iters, threads):
     # 3 untimed iterations -- the GPU leg's protocol.  Solver creation is not timed.
     per_run = int(min(max(iters, 30), 250))
     subs, tot_k, tot_dt, tot_moved, tot_runs = [], 0, 0.0, 0.0, 0
-    for sub in range(3):
+    for sub in range(5):
         k, dt, moved, runs = 0, 0.0, 0.0, 0
-        while dt < 2.7 and runs < 200:
+        while dt < 2.0 and runs < 200:
             s = qo.Solver(qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=threads)
             tw = time.perf_counter()
             s.minimize(qo.morethuente(), o, 3, 20)  # warm the caches / thread pool
@@ -163,11 +186,12 @@ def cpu_leg_config2(qo, n, iters, threads):
     val = _median([u["value"] for u in subs])
     out = {"value": val, "unit": "iterations/s", "cores": threads, "kind": "port",
            "sub_samples": [u["value"] for u in subs], "sub_sample_spread": (max(u["value"] for u in subs) - min(u["value"] for u in subs)) / val,
+           "sub_sample_min": min(u["value"] for u in subs), "sub_sample_median": val, "sub_sample_max": max(u["value"] for u in subs),
            "achieved_GBs": _median([u["achieved_GBs"] for u in subs]), "bytes_per_iteration": tot_moved / max(tot_k, 1),
            "numa_nodes": len(glob.glob("/sys/devices/system/node/node[0-9]*")) or None,
            "bytes_note": "matrix bytes the port streams: 8 n^2 per oracle call (full Q by rows), 8 n^2 per mat-vec with H (u = H y, "
                          "d = -H g), 16 n^2 for the rank-2 update",
-           "sample": f"median of 3 sub-samples; in all {tot_k} BFGS+MoreThuente iterations at n={n} in {tot_runs} runs of {per_run} from (x0, H = I) (same Q, b, x0 as the GPU run), "
+           "sample": f"median of 5 sub-samples; in all {tot_k} BFGS+MoreThuente iterations at n={n} in {tot_runs} runs of {per_run} from (x0, H = I) (same Q, b, x0 as the GPU run), "
                      f"rank-2 O(n^2) update, reference oracle-call sequence (5 calls per iteration), OpenMP x{threads}, {tot_dt:.1f} s"}
     # the reference's own formulation (dense n x n products, single thread as matrixmultiply is built) at a size it finishes
     n_small = 384
@@ -226,7 +250,7 @@ def cpu_leg_config4(qo, n_full):
 def cpu_leg_config5(qo, n_full, threads):
     """DFP + More-Thuente on the log-sum-exp objective: the oracle's port (rank-2 O(n^2) update, threaded row sweeps of A and H).  At
     n = m = 16384 the port needs 1-2 s per iteration on 16 cores (A and H are 2 GiB each), so the bounded sample is the same family at
-    n = m = 8192 -- three sub-samples continuing one run -- scaled with n^2 (every sweep of an iteration is over an n x n or m x n
+    n = m = 8192 -- five sub-samples continuing one run -- scaled with n^2 (every sweep of an iteration is over an n x n or m x n
     matrix: the port is bandwidth-bound); stated in `sample`."""
     n = 8192
     a, c, x0 = lse_inputs(n)
@@ -235,9 +259,9 @@ def cpu_leg_config5(qo, n_full, threads):
     tw = time.perf_counter()
     s.minimize(qo.morethuente(), o, 2, 20)
     tw = (time.perf_counter() - tw) / 2.0
-    per_sub = max(2, min(40, int(1.5 / max(tw, 1e-3))))
+    per_sub = max(2, min(40, int(1.0 / max(tw, 1e-3))))
     subs = []
-    for _ in range(3):
+    for _ in range(5):
         t0 = time.perf_counter()
         s.minimize(qo.morethuente(), o, per_sub, 20)  # (a continued call: k restarts, the state does not)
         dt = time.perf_counter() - t0
@@ -246,8 +270,9 @@ def cpu_leg_config5(qo, n_full, threads):
     val = _median(subs) * scale
     return {"value": val, "unit": "iterations/s", "cores": threads, "kind": "port", "sub_samples_at_n8192": subs,
             "sub_sample_spread": (max(subs) - min(subs)) / _median(subs),
+            "sub_sample_min_median_max_at_n8192": [min(subs), _median(subs), max(subs)],
             "sample": f"oracle DFP + MoreThuente on the log-sum-exp family of the GPU leg at n=m={n} (A ~ N(0, (2/sqrt n)^2), mu={LSE_MU}), rank-2 O(n^2) update, "
-                      f"OpenMP x{threads}: 3 sub-samples of {per_sub} iterations continuing one run after 2 warm-up iterations, median "
+                      f"OpenMP x{threads}: 5 sub-samples of {per_sub} iterations continuing one run after 2 warm-up iterations, median "
                       f"{_median(subs):.2f} it/s, scaled with (n/{n_full})^2 to n=m={n_full}"}
 
 
@@ -283,7 +308,7 @@ def extra_config4(qn, ctx):
         for rep in range(4):  # (the first repetition allocates the factorisation's buffers)
             s = qn.Newton(1e-8, x0, ctx=ctx)
             if force_lu:
-                s.set_tiling(-5, 0)
+                s.set_option("newton_pivoted_lu", 1)
             if rep == 3:
                 s.set_profiling(True)
             ctx.synchronize()
@@ -371,27 +396,21 @@ def extra_config5(qn, ctx):
     obj = qn.LogSumExp(a, c, LSE_MU, ctx=ctx)
     del a
     s = qn.DFP(1e-10, x0, ctx=ctx)
-
-    def run(k):
-        try:
-            s.minimize(qn.MoreThuente(), obj, k, 20)
-        except qn.MaxIterReached:
-            pass
-    run(3)  # warm-up (continued below: one run)
-    steps, regions = 20, []
-    for _ in range(3):
-        ctx.synchronize()
-        st0 = s.stats()
-        t0 = time.perf_counter()
-        run(steps)
-        ctx.synchronize()
-        regions.append((time.perf_counter() - t0, s.stats()["total_oracle_evals"] - st0["total_oracle_evals"]))
-    dt, evals = sorted(regions)[1]
+    ls = qn.MoreThuente()
+    run_iterations(qn, s, ls, obj, x0, 3)  # warm-up (the regions below continue this run; a run that converges restarts from (x0, H = I))
+    steps = 20
+    regions = timed_regions(lambda k: run_iterations(qn, s, ls, obj, x0, k), s.stats, ctx.synchronize, steps, 3)
+    med = sorted(regions, key=lambda r: r["s_per_iteration"])[1]
+    # the profiling pass: a LIVE solver -- reset, warmed up again, exactly 8 iterations with restarts as above -- so that every class of launch is timed
+    # (round 5 profiled a solver that had converged: one loop-top evaluation and nine predicated-off launches, a `frac` of 2.87)
+    s.reset(x0)
+    run_iterations(qn, s, ls, obj, x0, 3)
     s.set_profiling(True)
     p0 = s.stats()
-    run(8)
+    run_iterations(qn, s, ls, obj, x0, 8)
     p1 = s.stats()
     s.set_profiling(False)
+    prof_iters = p1["total_iterations"] - p0["total_iterations"]
     n_h, n_e = p1["n_hpass_timed"] - p0["n_hpass_timed"], p1["n_eval_timed"] - p0["n_eval_timed"]
     ms_h = (p1["t_hpass_ms"] - p0["t_hpass_ms"]) / n_h if n_h else None
     ms_e = (p1["t_eval_ms"] - p0["t_eval_ms"]) / n_e if n_e else None
@@ -399,19 +418,27 @@ def extra_config5(qn, ctx):
     ms_c = (p1["t_ereduce_ms"] - p0["t_ereduce_ms"]) / n_c if n_c else None
     ms_r = (p1["t_hreduce_ms"] - p0["t_hreduce_ms"]) / n_r if n_r else None
     alg_h, alg_e = 2.0 * p1["matrix_bytes_per_pass"], 8.0 * n * n
-    e_per_it = evals / steps
+    e_per_it = med["evaluations"] / med["iterations"]
     b_iter = alg_h + e_per_it * alg_e
     if not (ms_h and ms_e):
         raise RuntimeError("the profiling pass timed no launch of the pass over A or of the update pass")
+    if n_e < prof_iters or n_h < prof_iters - 1:
+        raise RuntimeError(f"the profiling pass timed {n_e} evaluation and {n_h} update-pass launches for {prof_iters} iterations: not a live run")
     dom_eval = n_e * ms_e > n_h * ms_h
     ach = (alg_e / (ms_e * 1e-3) if dom_eval else alg_h / (ms_h * 1e-3)) / 1e9
+    for what, v in (("roofline", ach), ("objective_eval", alg_e / (ms_e * 1e-3) / 1e9), ("update_pass", alg_h / (ms_h * 1e-3) / 1e9)):
+        if v > HBM_PEAK_GBS:
+            raise RuntimeError(f"config 5: {what} would read {v:.0f} GB/s, above the {HBM_PEAK_GBS:.0f} GB/s roofline -- the accounting is wrong, refusing to print it")
+    dt_it = med["s_per_iteration"]
     path = p1["path"]
     return {"workload": f"DFP + MoreThuente::default, n=m={n} log-sum-exp (mu={LSE_MU}, A ~ N(0, ({LSE_A_SCALE:g}/sqrt n)^2), seed {LSE_SEED}), f64, 1xMI355X "
                         "(BASELINE.json configs[4] names 4 GPUs: tests/test_gpu_partitions.py runs that partition)",
-            "metric": "DFP iterations/s", "value": steps / dt, "unit": "iterations/s", "ms_per_iteration": 1e3 * dt / steps, "steps": steps, "dtype": "f64",
-            "region_ms": [1e3 * r[0] for r in regions], "evaluations_per_iteration": e_per_it,
-            "algorithmic_bytes_per_iteration": b_iter, "whole_iteration_hbm_frac": b_iter * (steps / dt) / (HBM_PEAK_GBS * 1e9),
-            "launches_per_iteration": (p1["launches"] - p0["launches"]) / 8.0,
+            "metric": "DFP iterations/s", "value": 1.0 / dt_it, "unit": "iterations/s", "ms_per_iteration": 1e3 * dt_it, "steps": steps, "dtype": "f64",
+            "region_ms": [1e3 * r["s"] for r in regions], "region_iterations": [r["iterations"] for r in regions],
+            "region_ms_per_iteration": [1e3 * r["s_per_iteration"] for r in regions], "restarts_after_convergence": sum(r["restarts"] for r in regions),
+            "evaluations_per_iteration": e_per_it,
+            "algorithmic_bytes_per_iteration": b_iter, "whole_iteration_hbm_frac": b_iter / dt_it / (HBM_PEAK_GBS * 1e9),
+            "launches_per_iteration": (p1["launches"] - p0["launches"]) / max(prof_iters, 1), "profiled_iterations": prof_iters,
             "kernels": ("second-generation structure (qn_sym2g.hip.h): the state machine in one-workgroup launches on the device, pipelined; per iteration "
                         "E x (machine, pass over A, combine + staged vectors) + (machine, update tiles, reduce)" if path & 16 else "generic path (synchronous)"),
             "combine_avg_launch_ms": ms_c, "update_reduce_avg_launch_ms": ms_r,
@@ -779,9 +806,9 @@ def main():
                 obj1 = qn.Quadratic.synthetic(n, SEED, diag, b, ctx=ctx1)
                 s1 = qn.BFGS(1e-10, x0, ctx=ctx1)
                 if symmetric and not second_gen:
-                    s1.set_tiling(-4, 0)  # the same kernels as the N-rank run: first-generation symmetric-storage tiles
+                    s1.set_option("second_generation", 0)  # the same kernels as the N-rank run: first-generation symmetric-storage tiles
                 elif not symmetric:
-                    s1.set_tiling(-3, 0)  # the same kernels as the N-rank run: fused row kernels on the full matrices
+                    s1.set_option("symmetric_storage", 0)  # the same kernels as the N-rank run: fused row kernels on the full matrices
                 # (second generation: the single-GPU default path IS the N-rank run's kernels, unsharded)
                 ref_steps = min(steps, 50)
                 run_iterations(qn, s1, ls, obj1, x0, min(warmup, 5))

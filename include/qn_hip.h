@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define QN_ABI_VERSION 4
+#define QN_ABI_VERSION 5
 
 /* SolverError (ls_solver.rs:10-20); 0 is Ok(()) */
 typedef enum {
@@ -282,15 +282,31 @@ int qn_solver_set_profiling(qn_solver* s, int on);
 /* 0 = pipelined (device-resident control, no host sync per decision; default for memoised device objectives),
  * 1 = synchronous (host reads the control block after every step; always used with host oracles / callbacks) */
 int qn_solver_set_sync_mode(qn_solver* s, int sync);
-/* tuning: rows per workgroup tile (4, 8 or 16), column splits (>= 1); 0 keeps the default.  Diagnostics: rows = -1 selects the
- * generic (non-fused) kernels, -2 the fused kernels without the deferred update step, -3 the fused ROW kernels on the full
- * matrices instead of the symmetric-storage tiles, -4 the first-generation symmetric tile kernels (separate control
- * launches), -5 Newton by pivoted LU even for an SPD Hessian, -6 the second-generation path with the accept-reduce folded into
- * the update-tile launch (4 launches per iteration; measured neutral, off by default), -7 toggles the row slivers of that path
- * (n = 4096: whole tiles only, as in round 2), -8 the LU panel with two launches per column (rounds 1-2), -9 toggles the
- * evaluation kernel's two-items-and-a-sliver instance (off: the general body on the same work lists);
- * col_splits = 100 + U selects U column chunks per loop trip */
+/* tuning of the fused ROW kernels: rows per workgroup tile (2, 4, 8 or 16), column splits (1 .. 64); 0 keeps what is set.  (ABI <= 4 also took
+ * negative `rows_per_block` codes that selected diagnostic paths: those are the named options below since ABI 5.) */
 int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits);
+/* Named options (ABI 5).  None of them is needed to USE the library -- the reference has no counterpart: ls_solver.rs:66-111 takes a solver, a line
+ * search and a closure -- they select, for tests and measurements, a path the library would not take by itself, or switch a step of the default path
+ * off.  value != 0 switches the named thing ON, 0 OFF; [default] in brackets.  Unknown option: QN_ERROR_INPUT_PARAMS. */
+typedef enum {
+    QN_OPT_GENERIC_KERNELS = 1,            /* [0] the generic path: every O(n) vector operation in the one-workgroup control kernel, synchronous requests */
+    QN_OPT_DEFERRED_UPDATE_STEP = 2,       /* [1] fused row kernels: the accepting step also opens the next line search (one launch less per iteration) */
+    QN_OPT_SYMMETRIC_STORAGE = 3,          /* [1] stream only the upper block triangle of H and Q; 0: the fused ROW kernels on the full matrices */
+    QN_OPT_SECOND_GENERATION = 4,          /* [1] the state machine in every kernel's prologue (5 launches per iteration); 0: first-generation tile kernels */
+    QN_OPT_FOLDED_ACCEPT_REDUCE = 5,       /* [0] the accept-reduce inside the update-tile launch (n <= 4096; measured neutral) */
+    QN_OPT_ROW_SLIVERS = 6,                /* [1] left-over diagonal tiles cut into 8-row slivers, one per workgroup (n = 4096); 0: whole tiles only */
+    QN_OPT_EVAL_PAIR_INSTANCE = 7,         /* [1] the evaluation kernel's two-items-and-a-sliver instance where the work lists allow it; 0: the general body */
+    QN_OPT_EVAL_MOVER_MULTIPLIER = 8,      /* [1] ... as mover + multiplier waves (round 6, csrc/qn_sym2r.hip.h); 0: round 5's kernel -- the same bits */
+    QN_OPT_TAIL_REDUCE = 9,                /* [0] the update-reduce in the tail of the update-tile launch (bit-identical, measured slower) */
+    QN_OPT_BOUNDED_SECOND_GENERATION = 10, /* [1] BFGSB / DFPB / SR1B with More-Thuente(B) on the second-generation path; 0: the generic path */
+    QN_OPT_NEWTON_PIVOTED_LU = 11,         /* [0] Newton: the pivoted LU the reference's try_inverse stands for (newton/mod.rs:31-40) even for an SPD Hessian */
+    QN_OPT_LU_PER_COLUMN_PANEL = 12,       /* [0] ... its panel with two launches per column (rounds 1-2) */
+    QN_OPT_LU_LOOKAHEAD = 13,              /* [1] ... look-ahead on a second stream; 0: one stream */
+    QN_OPT_LU_ONE_LAUNCH_PANEL = 14,       /* [1] ... the panel and the substitution sweeps as one launch each; 0: one launch per sub-panel / block */
+    QN_OPT_LU_FORCE_WAIT_EXPIRY = 15,      /* [0] ... every bounded wait of the one-launch kernels expires at once (exercises the fallback) */
+    QN_OPT_CHUNKS_PER_TRIP = 16            /* [1] fused ROW kernels: column chunks per loop trip (1, 2 or 4) */
+} qn_option;
+int qn_solver_set_option(qn_solver* s, int option, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Thin kernel-level FFI (what a Rust host loop would bind if it keeps `minimize` in Rust):

@@ -126,6 +126,7 @@ SYMBOLS = [
     ("qn_solver_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
     ("qn_solver_set_sync_mode", C.c_int, [C.c_void_p, C.c_int]),
     ("qn_solver_set_tiling", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("qn_solver_set_option", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("qn_dev_alloc", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("qn_dev_free", C.c_int, [C.c_void_p, C.c_void_p]),
     ("qn_h2d", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

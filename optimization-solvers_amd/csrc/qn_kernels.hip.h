@@ -34,6 +34,8 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // nor a smaller object brought it back).  So an otherwise idle wave reads the kernel's own bytes as DATA at entry -- `line` counts 128-byte
 // lines from the program counter on, one request per lane, all in flight at once -- and the fetches of the wave that executes them hit:
 // 7.1 -> 5.8 us on that kernel wherever the code lies.  The value is consumed by a store that never happens (the loads must not be dropped).
+// The read is NOT bounded by the kernel's size: it must stay inside the code object's .text -- tools/check_code_warm.py, run by the Makefile after
+// every link, fails the build when a warmed kernel ends less than 32 KB in front of the end of .text.
 __device__ __forceinline__ unsigned qn_code_warm_issue(const int line) {
     unsigned long long pc;
     asm volatile("s_getpc_b64 %0" : "=s"(pc));

@@ -1275,7 +1275,7 @@ __device__ __forceinline__ void qn_s2_hvec_load(const QnS2HReq& q, const unsigne
 // before -- when the counter completes.
 // MEASURED (round 5, n = 4096, rocprofv3 averages of alternating runs on one box, profiles/r05_c_*): bit-identical to the reduce
 // launch (tests/test_gpu_symmetric.py::test_tail_reduce_is_the_reduce_launch_bit_for_bit) and SLOWER -- the update kernel
-// 23.5 -> 36.7 us for the 5.0 us launch it removes (14.9 k -> 13.4 k it/s); OFF by default (set_tiling(-13, 0) / QN_S2_TRED=1).
+// 23.5 -> 36.7 us for the 5.0 us launch it removes (14.9 k -> 13.4 k it/s); OFF by default (QN_OPT_TAIL_REDUCE / QN_S2_TRED=1).
 // In-kernel stamps say where it goes: the hand-off itself is cheap -- a workgroup's slot stores are acknowledged 0.4 us after its
 // last row, its adds have returned 0.7 us later, and spreading the counters over the memory channels changes nothing -- but the
 // last workgroup's tail ends 12.7 us after its adds.  The workgroups end within 2 us of each other, every block-row has ~47

@@ -36,6 +36,43 @@ def _close_all():
                 pass
 
 
+# qn_option (include/qn_hip.h, ABI 5)
+OPTIONS = {
+    "generic_kernels": 1,
+    "deferred_update_step": 2,
+    "symmetric_storage": 3,
+    "second_generation": 4,
+    "folded_accept_reduce": 5,
+    "row_slivers": 6,
+    "eval_pair_instance": 7,
+    "eval_mover_multiplier": 8,
+    "tail_reduce": 9,
+    "bounded_second_generation": 10,
+    "newton_pivoted_lu": 11,
+    "lu_per_column_panel": 12,
+    "lu_lookahead": 13,
+    "lu_one_launch_panel": 14,
+    "lu_force_wait_expiry": 15,
+    "chunks_per_trip": 16,
+}
+OPT_GENERIC_KERNELS = 1
+OPT_DEFERRED_UPDATE_STEP = 2
+OPT_SYMMETRIC_STORAGE = 3
+OPT_SECOND_GENERATION = 4
+OPT_FOLDED_ACCEPT_REDUCE = 5
+OPT_ROW_SLIVERS = 6
+OPT_EVAL_PAIR_INSTANCE = 7
+OPT_EVAL_MOVER_MULTIPLIER = 8
+OPT_TAIL_REDUCE = 9
+OPT_BOUNDED_SECOND_GENERATION = 10
+OPT_NEWTON_PIVOTED_LU = 11
+OPT_LU_PER_COLUMN_PANEL = 12
+OPT_LU_LOOKAHEAD = 13
+OPT_LU_ONE_LAUNCH_PANEL = 14
+OPT_LU_FORCE_WAIT_EXPIRY = 15
+OPT_CHUNKS_PER_TRIP = 16
+
+
 class SolverError(Exception):
     """ls_solver.rs:10-20"""
     code = A.ABNORMAL_TERMINATION
@@ -641,7 +678,23 @@ class _SolverBase:
         _check(A.lib().qn_solver_set_sync_mode(self.h, int(sync)))
 
     def set_tiling(self, rows_per_block=0, col_splits=0):
+        """tuning of the fused row kernels (rows per tile 2 / 4 / 8 / 16, column splits); diagnostics are named options: set_option"""
         _check(A.lib().qn_solver_set_tiling(self.h, rows_per_block, col_splits))
+
+    def set_option(self, option, value=1):
+        """qn_solver_set_option: `option` is a qn_option value (the OPT_* constants of this module) or its lower-case name without the prefix
+        ("second_generation", "newton_pivoted_lu", ...); value != 0 switches the named thing on, 0 off."""
+        if isinstance(option, str):
+            option = OPTIONS[option]
+        _check(A.lib().qn_solver_set_option(self.h, int(option), int(value)))
+
+    def configure(self, what, value=0):
+        """one entry point for parameter lists in tests and tools: configure(rows_per_block, col_splits) tunes, configure("option_name", v) sets a
+        named option"""
+        if isinstance(what, str):
+            self.set_option(what, value)
+        else:
+            self.set_tiling(what, value)
 
 
 class BFGS(_SolverBase):

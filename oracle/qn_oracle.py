@@ -11,7 +11,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libqn_oracle.so")
+# QN_ORACLE_LIB names another build of the same source: `make -C oracle asan` -> libqn_oracle_asan.so (gcc -fsanitize=address,undefined; the
+# process then needs the sanitizer runtime preloaded -- tests/test_oracle_sanitizers.py starts one that has it).  CPU only.
+_LIB_PATH = os.environ.get("QN_ORACLE_LIB") or os.path.join(_HERE, "libqn_oracle.so")
 
 OK, MAX_ITER_REACHED, OUT_OF_DOMAIN, ERROR_INPUT_PARAMS, ABNORMAL_TERMINATION = range(5)
 BFGS, DFP, GRADIENT_DESCENT, NEWTON, SR1 = 0, 1, 2, 3, 4
@@ -23,6 +25,8 @@ def build(force=False):
     """Compile the oracle with gcc (building the checker is not using it)."""
     src = os.path.join(_HERE, "qn_oracle.c")
     hdr = os.path.join(_HERE, "qn_oracle.h")
+    if os.environ.get("QN_ORACLE_LIB"):  # (a named build: whoever named it has built it)
+        return _LIB_PATH
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
         return _LIB_PATH

@@ -1,10 +1,10 @@
-//! `extern "C"` declarations for include/qn_hip.h (QN_ABI_VERSION 4): one `pub fn` per entry point, parameter for parameter.
+//! `extern "C"` declarations for include/qn_hip.h (QN_ABI_VERSION 5): one `pub fn` per entry point, parameter for parameter.
 //! tests/test_abi_load.py parses this file and the header and compares names, arity and every parameter / return type.
 //! NOT COMPILED in the build image (no Rust toolchain) -- see ../Cargo.toml.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const QN_ABI_VERSION: c_int = 4;
+pub const QN_ABI_VERSION: c_int = 5;
 
 // qn_status == SolverError (ls_solver.rs:10-20); 0 is Ok(())
 pub const QN_OK: c_int = 0;
@@ -27,6 +27,24 @@ pub const QN_DFP: c_int = 1;
 pub const QN_GRADIENT_DESCENT: c_int = 2;
 pub const QN_NEWTON: c_int = 3;
 pub const QN_SR1: c_int = 4;
+
+// qn_option (ABI 5): what rounds 1-5 selected through negative codes of qn_solver_set_tiling; value != 0 on, 0 off
+pub const QN_OPT_GENERIC_KERNELS: c_int = 1;
+pub const QN_OPT_DEFERRED_UPDATE_STEP: c_int = 2;
+pub const QN_OPT_SYMMETRIC_STORAGE: c_int = 3;
+pub const QN_OPT_SECOND_GENERATION: c_int = 4;
+pub const QN_OPT_FOLDED_ACCEPT_REDUCE: c_int = 5;
+pub const QN_OPT_ROW_SLIVERS: c_int = 6;
+pub const QN_OPT_EVAL_PAIR_INSTANCE: c_int = 7;
+pub const QN_OPT_EVAL_MOVER_MULTIPLIER: c_int = 8;
+pub const QN_OPT_TAIL_REDUCE: c_int = 9;
+pub const QN_OPT_BOUNDED_SECOND_GENERATION: c_int = 10;
+pub const QN_OPT_NEWTON_PIVOTED_LU: c_int = 11;
+pub const QN_OPT_LU_PER_COLUMN_PANEL: c_int = 12;
+pub const QN_OPT_LU_LOOKAHEAD: c_int = 13;
+pub const QN_OPT_LU_ONE_LAUNCH_PANEL: c_int = 14;
+pub const QN_OPT_LU_FORCE_WAIT_EXPIRY: c_int = 15;
+pub const QN_OPT_CHUNKS_PER_TRIP: c_int = 16;
 
 pub const QN_UNIQUE_ID_BYTES: usize = 128;
 pub const QN_TRACE_LS_MODIFIED: i32 = 1 << 30;
@@ -206,6 +224,7 @@ extern "C" {
     pub fn qn_solver_set_profiling(s: *mut qn_solver, on: c_int) -> c_int;
     pub fn qn_solver_set_sync_mode(s: *mut qn_solver, sync: c_int) -> c_int;
     pub fn qn_solver_set_tiling(s: *mut qn_solver, rows_per_block: c_int, col_splits: c_int) -> c_int;
+    pub fn qn_solver_set_option(s: *mut qn_solver, option: c_int, value: c_int) -> c_int;
 
     // ---- kernel-level primitives on device buffers ----
     pub fn qn_dev_alloc(ctx: *mut qn_context, bytes: usize, out_dev: *mut *mut c_void) -> c_int;

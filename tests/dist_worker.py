@@ -187,7 +187,7 @@ def main():
                 for rows in (False, True):
                     for sv, ob in ((s, obj), (s1, obj1)):
                         if rows:
-                            sv.set_tiling(-3, 0)
+                            sv.set_option("symmetric_storage", 0)
                         try:
                             sv.minimize(qn.MoreThuente(), ob, 4, 20)
                         except qn.MaxIterReached:
@@ -195,9 +195,9 @@ def main():
                     xa, xb = s.x(), s1.x()
                     case[method + ("_rows" if rows else "_again") + "_close"] = bool(np.linalg.norm(xa - xb) <= 1e-8 * np.linalg.norm(xb))
                     case[method + ("_rows" if rows else "_again") + "_path"] = s.stats()["path"]
-            # rounds 1-3's sharded kernels (tile, sum, exchange, epilogue, control step) stay reachable: set_tiling(-4)
+            # rounds 1-3's sharded kernels (tile, sum, exchange, epilogue, control step) stay reachable: set_option("second_generation", 0)
             sg1 = qn.BFGS(1e-10, x0, ctx=ctx)
-            sg1.set_tiling(-4, 0)
+            sg1.set_option("second_generation", 0)
             sg1.set_trace(iters, with_x=True)
             sr1 = qn.BFGS(1e-10, x0, ctx=ctx1)
             sr1.set_trace(iters, with_x=True)
@@ -244,7 +244,7 @@ def main():
             gen = {}
             for label, cx, ob in (("sh", ctx, obj), ("one", ctx1, obj1)):
                 sg = qn.DFP(1e-10, x0, ctx=cx)
-                sg.set_tiling(-1, 0)
+                sg.set_option("generic_kernels", 1)
                 sg.set_trace(8, with_x=True)
                 try:
                     sg.minimize(qn.MoreThuente(), ob, 8, 20)
@@ -263,16 +263,16 @@ def main():
                 xs0 = rng.standard_normal(n)
                 outs_l = []
                 # sharded / one rank on the default path (round 5: the second-generation structure, qn_sym2g.hip.h -- trial points
-                # exchanged as scalars), then the sharded run on the generic path (set_tiling(-4, 0)), then -- host exchange only --
+                # exchanged as scalars), then the sharded run on the generic path (set_option("second_generation", 0)), then -- host exchange only --
                 # the default path again with the exchange in stream order: pipelined, the same bits as the synchronous pump
-                variants = [(ctx, None, False), (ctx1, None, False), (ctx, (-4, 0), False)] + ([] if rccl else [(ctx, None, True)])
+                variants = [(ctx, None, False), (ctx1, None, False), (ctx, ("second_generation", 0), False)] + ([] if rccl else [(ctx, None, True)])
                 for cx, tiling, asyn in variants:
                     if asyn:
                         ctx.set_host_exchange_async(True)
                     lse = qn.LogSumExp(a_, c_, 0.1, ctx=cx)
                     sl = qn.DFP(1e-10, xs0, ctx=cx)
                     if tiling:
-                        sl.set_tiling(*tiling)
+                        sl.configure(*tiling)
                     sl.set_trace(10, with_x=True)
                     try:
                         sl.minimize(qn.MoreThuente(), lse, 10, 20)
@@ -328,7 +328,7 @@ def main():
                 outs = []
                 for sync in (1, 0):
                     sr = qn.BFGS(1e-10, x0, ctx=ctx)
-                    sr.set_tiling(-3, 0)
+                    sr.set_option("symmetric_storage", 0)
                     sr.set_sync_mode(sync)
                     sr.set_trace(iters, with_x=True)
                     try:
@@ -376,7 +376,7 @@ def main():
             for asyn in (False, True):
                 ctx.set_host_exchange_async(asyn)
                 sr = qn.BFGS(1e-10, x0, ctx=ctx)
-                sr.set_tiling(-3, 0)
+                sr.set_option("symmetric_storage", 0)
                 sr.set_trace(iters, with_x=True)
                 try:
                     sr.minimize(qn.MoreThuente(), obj, iters, 20)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(qn):
     assert set(declared) == bound, (set(declared) ^ bound)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.qn_abi_version() == 4
+    assert L.qn_abi_version() == 5
     assert L.qn_status_string(1) == b"Max iter reached"      # ls_solver.rs:12
     assert L.qn_status_string(2) == b"Out of domain"         # ls_solver.rs:14
     assert L.qn_status_string(3) == b"Error in input parameters"

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_cpu_baseline_child_runs_without_torch_and_reports_sub_samples():
-    """`bench.py --cpu-baseline-child n iters threads 0`: the config-2 leg alone at a small size -- three sub-samples, their median as the
+    """`bench.py --cpu-baseline-child n iters threads 0`: the config-2 leg alone at a small size -- five sub-samples, their median as the
     value, the spread, the bytes accounting; and the child must not have imported torch (its OpenMP runtime is what round 3 tripped over)."""
     code = ("import sys, json; sys.argv = ['bench.py']; sys.path.insert(0, %r); import bench; "
             "out = bench.cpu_baseline_child(256, 30, 2, extra=False); out['torch_loaded'] = 'torch' in sys.modules; print(json.dumps(out))" % ROOT)
@@ -20,7 +20,8 @@ def test_cpu_baseline_child_runs_without_torch_and_reports_sub_samples():
     assert out["torch_loaded"] is False
     leg = out["config2"]
     assert leg["kind"] == "port" and leg["cores"] == 2 and leg["unit"] == "iterations/s"
-    assert len(leg["sub_samples"]) == 3 and sorted(leg["sub_samples"])[1] == leg["value"] and leg["value"] > 0
+    assert len(leg["sub_samples"]) == 5 and sorted(leg["sub_samples"])[2] == leg["value"] and leg["value"] > 0
+    assert leg["sub_sample_min"] <= leg["sub_sample_median"] == leg["value"] <= leg["sub_sample_max"]
     assert "as_written_1thread" in leg and leg["bytes_per_iteration"] > 0
 
 
@@ -46,3 +47,46 @@ def test_experiments_kept_as_patches_still_apply():
     for f in patches:
         cp = subprocess.run(["git", "apply", "--check", os.path.join(pdir, f)], cwd=ROOT, capture_output=True, text=True)
         assert cp.returncode == 0, (f, cp.stderr[-1000:])
+
+
+def test_timed_regions_difference_the_counters_and_refuse_a_short_region():
+    """bench.timed_regions (the config-5 leg's accounting, VERDICT r5 item 2): what a region did comes from the solver's cumulative counters;
+    a region that ran fewer iterations than it is quoted for -- round 5: a converged run swallowed as Ok -- raises instead of printing."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Fake:
+        def __init__(self, converge_after=None):
+            self.tot = {"total_iterations": 0, "total_oracle_evals": 0}
+            self.converge_after = converge_after
+            self.restarts = 0
+
+        def stats(self):
+            return dict(self.tot)
+
+        def run_exact(self, k):  # the shape of bench.run_iterations: exactly k iterations, restarting a run that converges
+            done, restarts = 0, 0
+            while done < k:
+                step = k - done
+                if self.converge_after is not None and self.tot["total_iterations"] % self.converge_after + step > self.converge_after:
+                    step = self.converge_after - self.tot["total_iterations"] % self.converge_after
+                    restarts += 1
+                self.tot["total_iterations"] += step
+                self.tot["total_oracle_evals"] += 2 * step
+                done += step
+            return restarts
+
+        def run_swallowing_convergence(self, k):  # round 5's run(): stops at convergence and says nothing
+            step = min(k, 7)
+            self.tot["total_iterations"] += step
+            self.tot["total_oracle_evals"] += step
+            return 0
+
+    f = Fake(converge_after=33)
+    regs = bench.timed_regions(f.run_exact, f.stats, lambda: None, 20, 3)
+    assert [r["iterations"] for r in regs] == [20, 20, 20] and [r["evaluations"] for r in regs] == [40, 40, 40]
+    assert sum(r["restarts"] for r in regs) == 1 and all(r["s_per_iteration"] == r["s"] / 20 for r in regs)
+    g = Fake()
+    with pytest.raises(RuntimeError, match="ran 7 iterations"):
+        bench.timed_regions(g.run_swallowing_convergence, g.stats, lambda: None, 20, 3)

@@ -125,7 +125,7 @@ def test_bounded_run_to_termination_matches_oracle(qn, qo, method):
 def test_bounded_second_generation_path_vs_oracle_and_generic(qn, qo, method, lsname, n):
     """BFGSB / DFPB / SR1B with More-Thuente(B) on the second-generation symmetric path (s2_dir_kernel, qn_sym2.hip.h: the direction stored and
     projected by one more launch per iteration, t_max clipped where that request is consumed): against the oracle's restatement, against the
-    generic path (qn_solver_set_tiling(-14, 0)), and pipelined against synchronous bit for bit."""
+    generic path (set_option("bounded_second_generation", 0)), and pipelined against synchronous bit for bit."""
     q, b, x0, lb, ub = _box(qo, n)
     iters = 25
     # (the oracle's rank-2 form of the update -- pinned against the as-written one by the CPU tests -- on all host threads: the as-written
@@ -143,7 +143,7 @@ def test_bounded_second_generation_path_vs_oracle_and_generic(qn, qo, method, ls
         if mode == "sync":
             s.set_sync_mode(1)
         if mode == "generic":
-            s.set_tiling(-14, 0)
+            s.set_option("bounded_second_generation", 0)
         ls = _make_ls(qn, lsname, n, lb, ub)
         try:
             s.minimize(ls, obj, iters, 30)
@@ -188,6 +188,39 @@ def test_bounded_second_generation_path_continues_across_calls(qn, qo):
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
 
 
+def test_warm_call_with_another_line_search_box_forms_its_direction_again(qn, qo):
+    """a warm bounded call kept the stored direction and its step to the line search's box (QnCtl.dir_ready, mtb_cand) whatever line
+    search the call brought.  BFGSB + plain More-Thuente for 6 iterations, then the SAME solver with MoreThuenteB and a box of its own: the
+    second call must clip its first t_max by THAT box (morethuente_b.rs:185-201 recomputes the candidate in every compute_step_len) -- i.e.
+    equal, bit for bit on the second-generation path's own terms, a run whose second call is not warm -- and stay inside the box."""
+    n = 1024
+    q, b, x0, lb, ub = _box(qo, n)
+    obj = qn.Quadratic(q, b)
+    outs = {}
+    for mode in ("second generation", "generic"):
+        s = qn.BFGSB.new(1e-9, x0, lb, ub)
+        if mode == "generic":
+            s.set_option("bounded_second_generation", 0)
+        try:
+            s.minimize(qn.MoreThuente(), obj, 6, 30)
+        except qn.MaxIterReached:
+            pass
+        x6 = s.x()
+        # the second call's line search has a box of its own, tight around where the run stands: the very first step is clipped by it
+        llb, lub = x6 - 1e-3, x6 + 1e-3
+        ls = qn.MoreThuenteB.new(n).with_lower_bound(llb).with_upper_bound(lub)
+        try:
+            s.minimize(ls, obj, 1, 30)
+        except qn.MaxIterReached:
+            pass
+        x7 = s.x()
+        assert np.all(x7 >= llb - 1e-9) and np.all(x7 <= lub + 1e-9), mode  # (with the stale candidate -- +inf -- the step left the box)
+        assert np.any(np.abs(x7 - x6) > 0), mode
+        outs[mode] = (x7, ls.t_max())
+    assert np.linalg.norm(outs["second generation"][0] - outs["generic"][0]) <= 1e-7 * max(1.0, np.linalg.norm(outs["generic"][0]))
+    assert abs(outs["second generation"][1] - outs["generic"][1]) <= 1e-8 * max(1.0, abs(outs["generic"][1]))
+
+
 def test_bounded_second_generation_path_at_the_benchmark_size(qn, qo):
     """n = 4096 -- every workgroup two tiles and a sliver: s2_eval_kernel<true, .., BND> -- BFGSB + MoreThuenteB against the oracle and the
     generic path, the launch count of the pattern (one stored-direction launch per iteration on top of evaluation, accept-reduce, update
@@ -205,7 +238,7 @@ def test_bounded_second_generation_path_at_the_benchmark_size(qn, qo):
         s = qn.BFGSB.new(1e-9, x0, lb, ub)
         s.set_trace(iters, with_x=True)
         if mode == "generic":
-            s.set_tiling(-14, 0)
+            s.set_option("bounded_second_generation", 0)
         ls = _make_ls(qn, "mtb", n, lb, ub)
         try:
             s.minimize(ls, obj, iters, 30)

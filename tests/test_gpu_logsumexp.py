@@ -66,7 +66,7 @@ def test_second_generation_structure_for_logsumexp_vs_oracle_and_generic_path(qn
     path: the state machine in one-workgroup launches on the device (pipelined: no host round trip per request), the trial point formed
     by the pass over A from the lazy direction, an evaluation's combine launch staging g+, y, x+, s and their sums, the update pass on
     the symmetric tiles.  Against the oracle (decisions exact, steps / iterates / f to the parity tolerance), pipelined = synchronous
-    bit for bit, against the generic path (set_tiling(-4, 0)), the launch contract counted, and a continued call."""
+    bit for bit, against the generic path (set_option("second_generation", 0)), the launch contract counted, and a continued call."""
     a, c, x0 = _problem(m, n, scale=3.0)
     mu, iters = 0.1, 25
     ref = qo.Solver(qo.DFP if method == "dfp" else qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=4)
@@ -74,11 +74,11 @@ def test_second_generation_structure_for_logsumexp_vs_oracle_and_generic_path(qn
     st_ref = ref.minimize(_ls(qo, lsname), o, iters, 20, trace_cap=iters, trace_x=True)
     obj = qn.LogSumExp(a, c, mu)
     runs = []
-    for tiling, sync in ((None, 0), (None, 1), ((-4, 0), None)):
+    for tiling, sync in ((None, 0), (None, 1), (("second_generation", 0), None)):
         s = (qn.DFP if method == "dfp" else qn.BFGS)(1e-10, x0)
         s.set_trace(iters, with_x=True)
         if tiling:
-            s.set_tiling(*tiling)
+            s.configure(*tiling)
         if sync is not None:
             s.set_sync_mode(sync)
         try:

@@ -32,9 +32,9 @@ def _run_gpu(qn, n, name, method, tiling=None, sync=None, memoize=None, tiling2=
         s.set_approx_inv_hessian(w["h0"] * np.eye(n))
     s.set_trace(w["iters"], with_x=True)
     if tiling:
-        s.set_tiling(*tiling)
+        s.configure(*tiling)
     if tiling2:
-        s.set_tiling(*tiling2)
+        s.configure(*tiling2)
     if sync is not None:
         s.set_sync_mode(sync)
     if memoize is not None:
@@ -67,12 +67,12 @@ PATHS = {
     # name: (solver knobs, path flags the run must report: (fused, sym, sym_generic, pipelined))
     "sym": (dict(), (1, 1, 0, 1)),
     "sym_sync": (dict(sync=1), (1, 1, 0, 0)),
-    "sym_v1": (dict(tiling=(-4, 0)), (1, 1, 0, 1)),  # first-generation tile kernels (separate control launches, deferred update step)
-    "sym_v1_no_defer": (dict(tiling=(-2, 0), tiling2=(-4, 0)), (1, 1, 0, 1)),
-    "rows": (dict(tiling=(-3, 0)), (1, 0, 0, 1)),
-    "rows_sync": (dict(tiling=(-3, 0), sync=1), (1, 0, 0, 0)),
-    "generic": (dict(tiling=(-1, 0)), (0, 0, 1, 1)),
-    "generic_no_memo": (dict(tiling=(-1, 0), memoize=0), (0, 0, 1, 0)),
+    "sym_v1": (dict(tiling=("second_generation", 0)), (1, 1, 0, 1)),  # first-generation tile kernels (separate control launches, deferred update step)
+    "sym_v1_no_defer": (dict(tiling=("deferred_update_step", 0), tiling2=("second_generation", 0)), (1, 1, 0, 1)),
+    "rows": (dict(tiling=("symmetric_storage", 0)), (1, 0, 0, 1)),
+    "rows_sync": (dict(tiling=("symmetric_storage", 0), sync=1), (1, 0, 0, 0)),
+    "generic": (dict(tiling=("generic_kernels", 1)), (0, 0, 1, 1)),
+    "generic_no_memo": (dict(tiling=("generic_kernels", 1), memoize=0), (0, 0, 1, 0)),
 }
 
 
@@ -111,7 +111,7 @@ def test_morethuente_cases_2_3_4_and_modified_updating(qn, qo, n, path, methods)
 def test_cases_on_a_ragged_dimension(qn, qo, path):
     """n = 1100 is no multiple of 128: fused row kernels / h_pass_kernel (no symmetric tiles), ragged last column chunk"""
     n = 1100
-    knobs = dict(tiling=(-1, 0)) if path == "generic" else {}
+    knobs = dict(tiling=("generic_kernels", 1)) if path == "generic" else {}
     for name in ("case2_mod", "case3_tmax", "case4_inf", "case4_tmax2"):
         ref = _ref(qo, n, name, "bfgs")
         s, st, tr, xs = _run_gpu(qn, n, name, "bfgs", **knobs)

@@ -157,7 +157,7 @@ def _newton_pair(qn, qo, fn, hess, x0, ls_gpu, ls_ref, iters, tol=1e-10, force_l
     st_ref = ref.minimize(ls_ref, qo.PyOracle(fn), iters, 20, trace_cap=iters, trace_x=True)
     s = qn.Newton(tol, x0)
     if force_lu:
-        s.set_tiling(-5, 0)
+        s.set_option("newton_pivoted_lu", 1)
     s.set_trace(iters, with_x=True)
     st = qo.OK
     try:
@@ -260,7 +260,7 @@ def test_newton_exactly_singular_large_hessian_takes_the_gradient_direction(qn, 
 def test_one_launch_panel_whose_waits_expire_falls_back_to_step_launches(qn, qo):
     """qn_lu.hip.h: the one-launch panel / sweep kernels wait for each other on counters with BOUNDED waits; when one expires (their
     workgroups were not placed together) the kernel sets *fail = 2, everybody leaves, and the host runs the factorisation again with one
-    launch per sub-panel -- for good.  set_tiling(-12, 0) makes every wait that is not satisfied at once expire: same iterates, bit
+    launch per sub-panel -- for good.  set_option("lu_force_wait_expiry", 1) makes every wait that is not satisfied at once expire: same iterates, bit
     for bit, and more launches (the abandoned attempt plus 17 per panel)."""
     n = 700
     fn, hess0, x0 = _double_well_chain(n)
@@ -271,7 +271,7 @@ def test_one_launch_panel_whose_waits_expire_falls_back_to_step_launches(qn, qo)
     for forced in (False, True):
         s = qn.Newton(1e-10, x0)
         if forced:
-            s.set_tiling(-12, 0)
+            s.set_option("lu_force_wait_expiry", 1)
         s.set_trace(2, with_x=True)
         try:
             s.minimize(qn.MoreThuente(), lambda x: qn.FuncEvalMultivariate(*fn(x)).with_hessian(hess(x)), 2, 20)
@@ -298,7 +298,7 @@ def test_pivoted_lu_with_a_panel_taller_than_the_panel_buffer(qn, qo):
     for force in (False, True):
         s = qn.Newton(1e-8, x0)
         if force:
-            s.set_tiling(-5, 0)
+            s.set_option("newton_pivoted_lu", 1)
         s.set_trace(3, with_x=True)
         s.minimize(qn.MoreThuente(), obj, 10, 20)
         out.append((s.k(), s.trace()[1][0]))
@@ -316,7 +316,7 @@ def test_pivoted_lu_path_agrees_with_the_cholesky_path_on_spd(qn, qo, n):
     for force in (False, True):
         s = qn.Newton(1e-8, x0)
         if force:
-            s.set_tiling(-5, 0)
+            s.set_option("newton_pivoted_lu", 1)
         s.set_trace(5, with_x=True)
         s.minimize(qn.MoreThuente(), qn.Quadratic(q, b), 50, 20)
         out.append((s.k(), s.x(), s.decrement_squared(), s.trace()[1][0]))
@@ -329,14 +329,14 @@ def test_pivoted_lu_path_agrees_with_the_cholesky_path_on_spd(qn, qo, n):
 @pytest.mark.parametrize("n", [64, 200, 777, 1300, 4200])
 def test_panel_lu_equals_the_per_column_lu_bit_for_bit(qn, qo, n):
     """qn_lu.hip.h: the 64-column panel is factorised four columns at a time by one workgroup that holds the rows in registers
-    (19 launches per panel); set_tiling(-8, 0) selects rounds 1-2's two launches per column.  Same pivots (first maximum), same
+    (19 launches per panel); set_option("lu_per_column_panel", 1) selects rounds 1-2's two launches per column.  Same pivots (first maximum), same
     arithmetic in the same order: the iterates are the same bits.  Non-symmetric, indefinite Hessian (row swaps do occur).
     n = 4200: panels of more than 2048 and more than 4096 rows -- the 8- and 16-rows-per-thread instantiations of the step kernel,
     which are the ones config 4 (n = 8192) runs.
     Round 4: from 8 panels on the default path also runs the LOOK-AHEAD (the trailing update split between the solver's stream and a
     CU-masked second stream, the U12 solve row by row with scalar multipliers, the update as a resident grid that loops);
-    set_tiling(-10, 0) is the single-stream path with rounds 1-3's kernels -- the same bits again.  And the panel itself is ONE launch
-    (58 workgroups waiting for each other on counters, lu_panel_persist_kernel); set_tiling(-11, 0) is round 3's launch per sub-panel."""
+    set_option("lu_lookahead", 0) is the single-stream path with rounds 1-3's kernels -- the same bits again.  And the panel itself is ONE launch
+    (58 workgroups waiting for each other on counters, lu_panel_persist_kernel); set_option("lu_one_launch_panel", 0) is round 3's launch per sub-panel."""
     fn, hess0, x0 = _double_well_chain(n)
     iters = 3 if n <= 2000 else 1
     rng = np.random.default_rng(8)
@@ -346,11 +346,11 @@ def test_panel_lu_equals_the_per_column_lu_bit_for_bit(qn, qo, n):
     for percol, no_la, no_persist in ((False, False, False), (True, True, True), (False, True, False), (False, False, True)):
         s = qn.Newton(1e-10, x0)
         if percol:
-            s.set_tiling(-8, 0)
+            s.set_option("lu_per_column_panel", 1)
         if no_la:
-            s.set_tiling(-10, 0)
+            s.set_option("lu_lookahead", 0)
         if no_persist:
-            s.set_tiling(-11, 0)
+            s.set_option("lu_one_launch_panel", 0)
         s.set_trace(iters, with_x=True)
         try:
             s.minimize(qn.MoreThuente(), lambda x: qn.FuncEvalMultivariate(*fn(x)).with_hessian(hess(x)), iters, 20)

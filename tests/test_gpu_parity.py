@@ -68,7 +68,7 @@ def _run_gpu(qn, method, lsname, obj_or_fn, x0, iters, tol=1e-10, sync=None, mem
     if memoize is not None:
         s.memoize = memoize
     if tiling:
-        s.set_tiling(*tiling)
+        s.configure(*tiling)
     status = 0
     try:
         s.minimize(_ls(qn, lsname), obj_or_fn, iters, 20)
@@ -471,7 +471,7 @@ def test_fused_path_matches_generic_path_and_oracle(qn, qo):
     ref, _, _ = _run_ref(qo, "bfgs", "mt", q, b, x0, 30)
     obj = qn.Quadratic(q, b)
     fused, _ = _run_gpu(qn, "bfgs", "mt", obj, x0, 30)
-    generic, _ = _run_gpu(qn, "bfgs", "mt", obj, x0, 30, tiling=(-1, 0))
+    generic, _ = _run_gpu(qn, "bfgs", "mt", obj, x0, 30, tiling=("generic_kernels", 1))
     tf, xf = fused.trace()
     tg, xg = generic.trace()
     _compare(tf, xf, ref.trace, ref.trace_x)
@@ -482,8 +482,8 @@ def test_fused_path_matches_generic_path_and_oracle(qn, qo):
     assert np.array_equal(hf, hf.T)
     assert np.linalg.norm(hf - hg) <= 1e-9 * np.linalg.norm(hg)
     # warm restart across paths: continue the fused run on the generic path and vice versa
-    for a, bpath in ((fused, (-1, 0)), (generic, (8, 1))):
-        a.set_tiling(*bpath) if bpath[0] > 0 else a.set_tiling(-1, 0)
+    for a, bpath in ((fused, ("generic_kernels", 1)), (generic, (8, 1))):
+        a.configure(*bpath)
     cont_ref = qo.Solver(qo.BFGS, 1e-10, ref.x)
     cont_ref.set_inv_hessian(ref.approx_inv_hessian)
     cont_ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b), 10, 20, trace_cap=10, trace_x=True)
@@ -651,7 +651,7 @@ def test_deferred_update_step_is_bitwise_neutral(qn, qo):
     obj = qn.Quadratic(q, b)
     for method, lsname in (("bfgs", "mt"), ("dfp", "mt"), ("bfgs", "bt")):
         runs = []
-        for tiling, sync in (((0, 0), 0), ((-2, 0), 0), ((0, 0), 1), ((-2, 0), 1)):
+        for tiling, sync in (((0, 0), 0), (("deferred_update_step", 0), 0), ((0, 0), 1), (("deferred_update_step", 0), 1)):
             s, st = _run_gpu(qn, method, lsname, obj, x0, 35, sync=sync, tiling=tiling if tiling != (0, 0) else None)
             tr, xs = s.trace()
             runs.append((st, tr, xs, s.approx_inv_hessian(), s.stats()))
@@ -672,10 +672,10 @@ def test_element_offsets_beyond_int32_n49152(qn, qo):
     b, x0 = P.synth_vectors(n)
     obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
     runs = []
-    for tiling in (None, (-1, 0)):
+    for tiling in (None, ("generic_kernels", 1)):
         s = qn.BFGS(1e-10, x0)
         if tiling:
-            s.set_tiling(*tiling)
+            s.configure(*tiling)
         s.set_trace(iters, with_x=True)
         with pytest.raises(qn.MaxIterReached):
             s.minimize(qn.MoreThuente(), obj, iters, 20)

@@ -46,7 +46,7 @@ def _sharded_quadratic(qn, n, world, iters, allreduce, want_h, first_generation=
         obj = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx)
         s = qn.BFGS(1e-10, x0, ctx=ctx)
         if first_generation:
-            s.set_tiling(-4, 0)  # rounds 1-3: tile, sum, exchange, epilogue, control step per evaluation or pass
+            s.set_option("second_generation", 0)  # rounds 1-3: tile, sum, exchange, epilogue, control step per evaluation or pass
         tr, xs = _run(qn, s, qn.MoreThuente(), obj, iters)
         st = s.stats()
         out = {"tr": tr, "xs": xs, "path": st["path"], "bytes": st["matrix_bytes_per_pass"], "launches": st["launches"],
@@ -65,7 +65,7 @@ def _single_rank_quadratic(qn, n, iters, inputs, first_generation=False):
     obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
     s = qn.BFGS(1e-10, x0)
     if first_generation:
-        s.set_tiling(-4, 0)  # the first-generation tile kernels
+        s.set_option("second_generation", 0)  # the first-generation tile kernels
     tr, xs = _run(qn, s, qn.MoreThuente(), obj, iters)
     return s, obj, tr, xs
 
@@ -99,7 +99,7 @@ def _check_partition(res, world, n, first_generation=False):
 @pytest.mark.parametrize("allreduce", [False, True])
 def test_config3_partition_8_ranks_n4096_vs_single_rank_and_oracle(qn, qo, allreduce, first_generation):
     """P = 8, rpr / 128 = 4 block-rows per rank, nb = 32 even (cnt(I) split at I < nb / 2): config 3's shape at a size the oracle
-    follows.  Both generations of the sharded kernels: the default (qn_sym2sh.hip.h) and rounds 1-3's (set_tiling(-4))."""
+    follows.  Both generations of the sharded kernels: the default (qn_sym2sh.hip.h) and rounds 1-3's (set_option("second_generation", 0))."""
     n, world = 4096, 8
     iters = 50 if (not first_generation and not allreduce) else 12  # (the default partition: the whole stated window -- VERDICT r4 item 6)
     res, inputs = _sharded_quadratic(qn, n, world, iters, allreduce, want_h=not allreduce, first_generation=first_generation)

@@ -22,7 +22,7 @@ def _run(qn, method, lsname, obj, x0, iters, tiling=None, sync=None):
     s = (qn.BFGS if method == "bfgs" else qn.DFP)(1e-10, x0)
     s.set_trace(iters, with_x=True)
     if tiling:
-        s.set_tiling(*tiling)
+        s.configure(*tiling)
     if sync is not None:
         s.set_sync_mode(sync)
     ls = qn.MoreThuente() if lsname == "mt" else qn.BackTracking(1e-4, 0.5)
@@ -42,7 +42,7 @@ def test_symmetric_path_vs_row_kernels_and_oracle(qn, qo, n, method, lsname):
     iters = 30
     s, st = _run(qn, method, lsname, obj, x0, iters)
     assert s.stats()["matrix_bytes_per_pass"] == sym_bytes(n)  # the path under test did run
-    r, st_r = _run(qn, method, lsname, obj, x0, iters, tiling=(-3, 0))
+    r, st_r = _run(qn, method, lsname, obj, x0, iters, tiling=("symmetric_storage", 0))
     assert r.stats()["matrix_bytes_per_pass"] == n * n * 8
     (tr, xs), (tr_r, xs_r) = s.trace(), r.trace()
     assert st == st_r and len(tr) == len(tr_r)
@@ -69,7 +69,7 @@ def test_symmetric_path_is_bitwise_reproducible_across_modes(qn, qo):
     q, b, x0, _ = P.synth_problem(qo, n)
     obj = qn.Quadratic(q, b)
     runs = []
-    for tiling, sync in ((None, 0), (None, 1), ((-2, 0), 0), ((-2, 0), 1)):  # pipelined / synchronous, with / without the deferred step
+    for tiling, sync in ((None, 0), (None, 1), (("deferred_update_step", 0), 0), (("deferred_update_step", 0), 1)):  # pipelined / synchronous, with / without the deferred step
         s, st = _run(qn, "bfgs", "mt", obj, x0, 35, tiling=tiling, sync=sync)
         tr, xs = s.trace()
         runs.append((st, tr, xs, s.approx_inv_hessian()))
@@ -80,7 +80,7 @@ def test_symmetric_path_is_bitwise_reproducible_across_modes(qn, qo):
 
 @pytest.mark.parametrize("method,lsname", [("bfgs", "mt"), ("dfp", "mt"), ("bfgs", "bt")])
 def test_folded_accept_reduce_is_the_same_run_bit_for_bit(qn, qo, method, lsname):
-    """set_tiling(-6, 0): the launch that runs the update tiles also turns the accepted evaluation's slots into vectors (four
+    """set_option("folded_accept_reduce", 1): the launch that runs the update tiles also turns the accepted evaluation's slots into vectors (four
     launches per iteration; s2_hpass_kernel<.., FOLD>).  Same sums in the same order: the trace, the iterates and the inverse
     Hessian must equal the default five-launch pattern bit for bit, pipelined and synchronous, and across a continued call."""
     n = 1280
@@ -89,7 +89,7 @@ def test_folded_accept_reduce_is_the_same_run_bit_for_bit(qn, qo, method, lsname
     base, st0 = _run(qn, method, lsname, obj, x0, 35)
     tr0, xs0 = base.trace()
     for sync in (0, 1):
-        s, st = _run(qn, method, lsname, obj, x0, 35, tiling=(-6, 0), sync=sync)
+        s, st = _run(qn, method, lsname, obj, x0, 35, tiling=("folded_accept_reduce", 1), sync=sync)
         tr, xs = s.trace()
         assert st == st0 and tr == tr0
         assert np.array_equal(xs, xs0) and np.array_equal(s.approx_inv_hessian(), base.approx_inv_hessian())
@@ -97,10 +97,10 @@ def test_folded_accept_reduce_is_the_same_run_bit_for_bit(qn, qo, method, lsname
     # a run that converges (the speculative tiles of the last accepted point are not followed by a pass) and is then continued
     tol = 1e-3
     pair = []  # (tol 1e-3: converges in a few dozen iterations)
-    for tiling in (None, (-6, 0)):
+    for tiling in (None, ("folded_accept_reduce", 1)):
         s = (qn.BFGS if method == "bfgs" else qn.DFP)(tol, x0)
         if tiling:
-            s.set_tiling(*tiling)
+            s.configure(*tiling)
         ls = qn.MoreThuente() if lsname == "mt" else qn.BackTracking(1e-4, 0.5)
         try:
             s.minimize(ls, obj, 200, 20)
@@ -120,7 +120,7 @@ def test_folded_accept_reduce_is_the_same_run_bit_for_bit(qn, qo, method, lsname
 @pytest.mark.parametrize("method,lsname", [("bfgs", "mt"), ("dfp", "mt"), ("bfgs", "bt")])
 def test_row_slivers_at_4096(qn, qo, method, lsname):
     """n = 4096: 528 tiles on 256 workgroups.  The sixteen diagonal tiles left over after two rounds are cut into 8-row slivers, one
-    per workgroup (qn_sym2.hip.h, qn_s2_eval_sliver); set_tiling(-7, 0) switches back to whole tiles (round 2's work lists).  Other
+    per workgroup (qn_sym2.hip.h, qn_s2_eval_sliver); set_option("row_slivers", 0) switches back to whole tiles (round 2's work lists).  Other
     association of the sums, same run: decisions equal, steps and iterates to the parity tolerance, H complete and bitwise
     symmetric; pipelined and synchronous identical; and a solver may change between the two layouts from call to call."""
     n = 4096
@@ -128,7 +128,7 @@ def test_row_slivers_at_4096(qn, qo, method, lsname):
     obj = qn.Quadratic(q, b)
     iters = 24
     s, st = _run(qn, method, lsname, obj, x0, iters)
-    r, st_r = _run(qn, method, lsname, obj, x0, iters, tiling=(-7, 0))
+    r, st_r = _run(qn, method, lsname, obj, x0, iters, tiling=("row_slivers", 0))
     assert s.stats()["path"] & 16 and r.stats()["path"] & 16
     (tr, xs), (tr_r, xs_r) = s.trace(), r.trace()
     assert st == st_r and len(tr) == len(tr_r) >= 10
@@ -143,7 +143,7 @@ def test_row_slivers_at_4096(qn, qo, method, lsname):
     assert st_y == st and sy.trace()[0] == tr and np.array_equal(sy.approx_inv_hessian(), h)
     # the evaluation kernel's two-items-and-a-sliver instance (s2_eval_kernel<true>) against the general body on the same lists:
     # the same sums in the same order
-    g, st_g = _run(qn, method, lsname, obj, x0, iters, tiling=(-9, 0))
+    g, st_g = _run(qn, method, lsname, obj, x0, iters, tiling=("eval_pair_instance", 0))
     assert st_g == st and g.trace()[0] == tr and np.array_equal(g.approx_inv_hessian(), h)
     # against the oracle, as the parity sweep does
     ref = qo.Solver(qo.BFGS if method == "bfgs" else qo.DFP, 1e-10, x0, qo.UPDATE_RANK2)
@@ -161,7 +161,7 @@ def test_row_slivers_at_4096(qn, qo, method, lsname):
             m.minimize(ls, obj, 8, 20)
         except qn.MaxIterReached:
             pass
-        m.set_tiling(-7, 0)
+        m.set_option("row_slivers", 0)
     assert np.linalg.norm(m.x() - xs[-1]) <= 1e-9 * max(1.0, np.linalg.norm(xs[-1]))
     hm = m.approx_inv_hessian()
     assert np.array_equal(hm, hm.T) and np.abs(hm - h).max() <= 1e-9 * np.abs(h).max()
@@ -170,7 +170,7 @@ def test_row_slivers_at_4096(qn, qo, method, lsname):
 @pytest.mark.parametrize("n,method,lsname", [(4096, "bfgs", "mt"), (4096, "dfp", "mt"), (4096, "bfgs", "bt"), (1152, "bfgs", "mt"),
                                              (3200, "dfp", "mt"), (8192, "bfgs", "mt")])
 def test_tail_reduce_is_the_reduce_launch_bit_for_bit(qn, qo, n, method, lsname):
-    """Round 5, set_tiling(-13, 0): the update-reduce in the TAIL of the update-tile launch (s2_hpass_kernel<.., TRED>: the workgroup
+    """Round 5, set_option("tail_reduce", 1): the update-reduce in the TAIL of the update-tile launch (s2_hpass_kernel<.., TRED>: the workgroup
     whose slot completes a block-row sums that block-row's slots, in slot order) -- 4 launches per iteration instead of 5.  Measured
     slower than the launch it removes and off by default (note in front of the kernel); kept as a tested variant.  The arrival
     order decides who sums, never in what order: trace, iterates and inverse Hessian must equal the default run bit for bit,
@@ -184,7 +184,7 @@ def test_tail_reduce_is_the_reduce_launch_bit_for_bit(qn, qo, n, method, lsname)
     h0 = base.approx_inv_hessian() if n <= 4096 else None
     assert base.stats()["path"] & 16
     for rep, sync in enumerate((0, 1, 0, 0)):
-        s, st = _run(qn, method, lsname, obj, x0, iters, tiling=(-13, 0), sync=sync)
+        s, st = _run(qn, method, lsname, obj, x0, iters, tiling=("tail_reduce", 1), sync=sync)
         tr, xs = s.trace()
         assert st == st0 and tr == tr0 and np.array_equal(xs, xs0), (rep, sync)
         if h0 is not None:
@@ -200,13 +200,13 @@ def test_ring_evaluation_is_the_pair_instance_bit_for_bit(qn, qo, method, lsname
     park as they land (the trial point staged once per workgroup) and the movers multiply the second tile out of their own registers; the lanes'
     shares of the scalar sums change hands through LDS.  The same products, sums and exchanges in the same order as round 5's two-items-and-a-
     sliver instance: trace, iterates and inverse Hessian must be equal bit for bit, pipelined and synchronous; repeated, because a row consumed
-    before it was parked would depend on timing.  14.3 us per launch against 15.3 (profiles/r06_a_*): the default since round 6; set_tiling(-15, 0)
+    before it was parked would depend on timing.  14.3 us per launch against 15.3 (profiles/r06_a_*): the default since round 6; set_option("eval_mover_multiplier", 0)
     selects round 5's kernel.  Backtracking evaluates at points it rejects: launches whose request is not an evaluation's leave early."""
     n = 4096
     diag = P.synth_diag(n); b, x0 = P.synth_vectors(n)
     obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
     iters = 30
-    base, st0 = _run(qn, method, lsname, obj, x0, iters, tiling=(-15, 0))
+    base, st0 = _run(qn, method, lsname, obj, x0, iters, tiling=("eval_mover_multiplier", 0))
     tr0, xs0 = base.trace()
     h0 = base.approx_inv_hessian()
     assert base.stats()["path"] & 16 and len(tr0) == iters
@@ -230,7 +230,7 @@ def test_second_generation_without_slivers_and_without_the_pair_instance(qn, qo,
     iters = 16
     s, st = _run(qn, "bfgs", "mt", obj, x0, iters)
     assert s.stats()["path"] & 16 and s.stats()["matrix_bytes_per_pass"] == sym_bytes(n)
-    r, st_r = _run(qn, "bfgs", "mt", obj, x0, iters, tiling=(-3, 0))
+    r, st_r = _run(qn, "bfgs", "mt", obj, x0, iters, tiling=("symmetric_storage", 0))
     (tr, xs), (tr_r, xs_r) = s.trace(), r.trace()
     assert st == st_r and len(tr) == len(tr_r) == iters
     assert [(a["n_evals"], a["ls_cases"]) for a in tr] == [(a["n_evals"], a["ls_cases"]) for a in tr_r]
@@ -260,13 +260,13 @@ def test_warm_restart_continues_on_the_mirrored_hessian(qn, qo):
     three = qn.BFGS(1e-10, x0)
     with pytest.raises(qn.MaxIterReached):
         three.minimize(qn.MoreThuente(), obj, 10, 20)
-    three.set_tiling(-1, 0)
+    three.set_option("generic_kernels", 1)
     with pytest.raises(qn.MaxIterReached):
         three.minimize(qn.MoreThuente(), obj, 10, 20)
     assert np.linalg.norm(three.x() - one.x()) <= 1e-9 * np.linalg.norm(one.x())
 
 
-@pytest.mark.parametrize("tiling", [None, (-4, 0), (-3, 0)])
+@pytest.mark.parametrize("tiling", [None, ("second_generation", 0), ("symmetric_storage", 0)])
 def test_continued_calls_are_one_run_bit_for_bit(qn, qo, tiling):
     """minimize resets only k (ls_solver.rs:74): a second call on the same device objective, with nothing touched in between,
     continues the first one -- the memoised evaluation at x_k and the lazily formed direction carry over, so two calls of 10
@@ -278,7 +278,7 @@ def test_continued_calls_are_one_run_bit_for_bit(qn, qo, tiling):
     one, _ = _run(qn, "bfgs", "mt", obj, x0, 20, tiling=tiling)
     two = qn.BFGS(1e-10, x0)
     if tiling:
-        two.set_tiling(*tiling)
+        two.configure(*tiling)
     evals = passes = 0
     for _ in range(2):
         with pytest.raises(qn.MaxIterReached):
@@ -290,7 +290,7 @@ def test_continued_calls_are_one_run_bit_for_bit(qn, qo, tiling):
     assert np.array_equal(one.approx_inv_hessian(), two.approx_inv_hessian())
     three = qn.BFGS(1e-10, x0)
     if tiling:
-        three.set_tiling(*tiling)
+        three.configure(*tiling)
     with pytest.raises(qn.MaxIterReached):
         three.minimize(qn.MoreThuente(), obj, 10, 20)
     three.set_x(three.x())  # same values, but the solver cannot know that
@@ -300,7 +300,7 @@ def test_continued_calls_are_one_run_bit_for_bit(qn, qo, tiling):
     assert np.linalg.norm(three.x() - one.x()) <= 1e-9 * np.linalg.norm(one.x())
     four = qn.BFGS(1e-10, x0)
     if tiling:
-        four.set_tiling(*tiling)
+        four.configure(*tiling)
     with pytest.raises(qn.MaxIterReached):
         four.minimize(qn.MoreThuente(), obj, 10, 20)
     obj2 = qn.Quadratic(q, b)  # an equal objective is still another oracle
@@ -375,7 +375,7 @@ def _generic_pair(make_solver, minimize):
     for full in (False, True):
         s = make_solver()
         if full:
-            s.set_tiling(-3, 0)  # H pass on the full row-major matrix
+            s.set_option("symmetric_storage", 0)  # H pass on the full row-major matrix
         s.set_trace(40, with_x=True)
         st = 0
         try:
@@ -408,7 +408,7 @@ def test_generic_path_device_objective_on_tiles(qn, qo, method):
 
     def make():
         s = (qn.BFGS if method == "bfgs" else qn.DFP)(1e-10, x0)
-        s.set_tiling(-1, 0)  # generic kernels (the control step does the vector work)
+        s.set_option("generic_kernels", 1)  # generic kernels (the control step does the vector work)
         return s
     a, b_ = _generic_pair(make, lambda s: s.minimize(qn.MoreThuente(), obj, 25, 20))
     _assert_same_run(a, b_, n)
@@ -435,7 +435,7 @@ def test_generic_path_logsumexp_dfp_on_tiles(qn, qo):
 
     def generic_dfp():  # (round 5: the default for this objective is the second-generation structure, qn_sym2g.hip.h; -4 keeps the generic path)
         s = qn.DFP(1e-10, x0)
-        s.set_tiling(-4, 0)
+        s.set_option("second_generation", 0)
         return s
     a, b_ = _generic_pair(generic_dfp, lambda s: s.minimize(qn.MoreThuente(), obj, 15, 20))
     assert a[0].stats()["path"] & 4 and not a[0].stats()["path"] & 16  # generic path, H pass on the symmetric tiles
@@ -459,7 +459,7 @@ def test_generic_path_sr1b_bounded_on_tiles(qn, qo):
     obj = qn.Quadratic(q, b)
     def mk():  # (SR1B of this shape takes the second-generation path since round 5: this test is about the GENERIC path's tiles)
         s = qn.SR1B.new(1e-10, x0, lb, ub)
-        s.set_tiling(-14, 0)
+        s.set_option("bounded_second_generation", 0)
         return s
     a, b_ = _generic_pair(mk, lambda s: s.minimize(qn.MoreThuente(), obj, 20, 20))
     _assert_same_run(a, b_, n)

@@ -21,7 +21,7 @@ k4 = max(1, n // 4)
 lb[:k4] = xs[:k4] + 0.2
 ub[:k4] = xs[:k4] + 1.0
 s = qn.BFGSB.new(1e-10, x0, lb, ub)
-s.set_tiling(-14, 0)  # the generic path (bounded runs of this shape default to the second-generation one since round 5)
+s.set_option("bounded_second_generation", 0)  # the generic path (bounded runs of this shape default to the second-generation one since round 5)
 ls = qn.MoreThuenteB.new(n).with_lower_bound(lb).with_upper_bound(ub)
 L = A.lib()
 L.qn_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]

@@ -10,13 +10,13 @@ for n in [int(v) for v in sys.argv[1:]] or [1280, 4096]:
     diag = P.synth_diag(n); b, x0 = P.synth_vectors(n)
     obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
     for sync in (1, 0):
-        for tiling in (None, (-7, 0), (-6, 0)):
+        for tiling in (None, ("row_slivers", 0), ("folded_accept_reduce", 1)):
             print("n", n, "sync", sync, "tiling", tiling, file=sys.stderr, flush=True)
             s = qn.BFGS(1e-10, x0)
             s.set_trace(12, with_x=False)
             s.set_sync_mode(sync)
             if tiling:
-                s.set_tiling(*tiling)
+                s.configure(*tiling)
             try:
                 s.minimize(qn.MoreThuente(), obj, 12, 20)
             except qn.MaxIterReached:

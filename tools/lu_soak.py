@@ -1,5 +1,5 @@
 """Soak of the one-launch LU kernels (panel, sweeps) and the look-ahead: the same non-symmetric Newton step many times over through the
-default path and through round 3's launches (set_tiling(-10) no look-ahead, (-11) one launch per sub-panel / per block) -- every
+default path and through round 3's launches (set_option("lu_lookahead", 0), ("lu_one_launch_panel", 0): one launch per sub-panel / per block) -- every
 repetition must give the same bits.  A stale read between workgroups (the panel buffer and the solution vectors cross workgroups as
 write-through stores and sc1 loads, no cache flush) would show up here as a mismatch.
 usage: python tools/lu_soak.py [n] [reps] [synth]   (synth: the device-resident SPD benchmark matrix through the forced LU path -- n = 8192 without a host matrix)"""
@@ -25,16 +25,16 @@ else:
 def step(flags):
     s = qn.Newton(1e-12, x0)
     if synth:
-        s.set_tiling(-5, 0)
+        s.set_option("newton_pivoted_lu", 1)
     for f in flags:
-        s.set_tiling(f, 0)
+        s.set_option(f, 0)
     s.set_trace(1, with_x=True)
     try:
         s.minimize(qn.BackTracking(1e-4, 0.5), fn, 1, 5)
     except qn.MaxIterReached:
         pass
     return s.trace()[1][0].copy()
-ref = step((-10, -11))
+ref = step(("lu_lookahead", "lu_one_launch_panel"))
 bad = 0
 t0 = time.time()
 for r in range(reps):

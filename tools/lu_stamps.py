@@ -14,7 +14,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 diag = P.synth_diag(n); b, x0 = P.synth_vectors(n)
 obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
 s = qn.Newton(1e-8, x0)
-s.set_tiling(-5, 0)
+s.set_option("newton_pivoted_lu", 1)
 s.minimize(qn.MoreThuente(), obj, 1, 20) if False else None
 try:
     s.minimize(qn.MoreThuente(), obj, 1, 20)

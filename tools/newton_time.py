@@ -13,7 +13,7 @@ obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
 for rep in range(3):
     s = qn.Newton(1e-8, x0)
     if force_lu:
-        s.set_tiling(-5, 0)
+        s.set_option("newton_pivoted_lu", 1)
     qn.default_context().synchronize()
     t0 = time.perf_counter()
     s.minimize(qn.MoreThuente(), obj, 10, 20)

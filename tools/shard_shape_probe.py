@@ -24,7 +24,7 @@ obj = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx)
 for tiling in ((0, 0), (4, 101), (4, 102), (8, 101), (8, 102), (16, 101), (2, 102)):
     s = qn.BFGS(1e-10, x0, ctx=ctx)
     if tiling != (0, 0):
-        s.set_tiling(*tiling)
+        s.configure(*tiling)
     s.set_sync_mode(1)
     s.set_profiling(True)
     try:

@@ -44,7 +44,7 @@ def run(qn, ctx, n, iters, first_generation, warm=0):
     obj = qn.Quadratic.synthetic(n, SEED, diag, b, ctx=ctx)
     s = qn.BFGS(1e-10, x0, ctx=ctx)
     if first_generation:
-        s.set_tiling(-4, 0)
+        s.set_option("second_generation", 0)
     s.set_trace(iters + warm, with_x=False)
     t = []
     for k in ([warm, iters] if warm else [iters]):  # (a continued call: the warm-up is outside the timed call, the run is one run)
