@@ -81,6 +81,26 @@ def timed_regions(run_exact, stats, synchronize, steps, nregions):
     return out
 
 
+def collectives_share(xprobe, scalars_per_it, vectors_per_it, ms_per_step):
+    """What the probed exchange latencies and the COUNTED collectives of the timed region say about where an iteration's time goes (N > 1): the
+    n-vector collectives of an iteration alternate between n doubles (q of the accepted point) and 2 n doubles ([u, v] of the update pass).  An
+    estimate -- probed latencies x counts, slowest rank -- printed beside the measured ms_per_step; it answers DESIGN section 5's open question
+    (is a small RCCL collective ~20 us?) the first time the line is printed on a multi-GPU node."""
+    out = {"exchange_probe": xprobe, "collectives_per_iteration": {"scalars_8KB": scalars_per_it, "n_vectors": vectors_per_it}}
+    try:
+        ranks = [r for r in xprobe["per_rank"] if isinstance(r, dict) and "error" not in r]
+        if not ranks:
+            raise ValueError("no rank probed")
+        worst = {k: max(r[k]["median_us"] for r in ranks) for k in ("scalars_8KB", "n_vector", "two_n_vectors")}
+        est_us = scalars_per_it * worst["scalars_8KB"] + 0.5 * vectors_per_it * (worst["n_vector"] + worst["two_n_vectors"])
+        out.update({"slowest_rank_median_us": worst, "estimated_collective_us_per_iteration": est_us,
+                    "estimated_fraction_of_ms_per_step": est_us / (1e3 * ms_per_step) if ms_per_step else None,
+                    "design_budget_us_per_small_collective": 20.0})
+    except Exception as e:  # noqa: BLE001
+        out["error"] = repr(e)
+    return out
+
+
 def totals(solver):
     """Counters that accumulate over every qn_minimize call of the solver (the per-call ones restart with k)."""
     st = solver.stats()
@@ -540,6 +560,19 @@ def main():
     else:
         ctx = qn.Context(device=local_rank)
 
+    # N > 1, in front of everything that is timed (round 6): what ONE exchange of each size a row-sharded iteration makes costs
+    # on this node -- 8 KB of per-workgroup scalars (one per evaluation), n doubles (q of the accepted point), 2 n doubles ([u, v] of the update
+    # pass) per rank.  DESIGN section 5 budgets ~20 us for a small one without ever having run one between devices.
+    xprobe = None
+    if world > 1:
+        try:
+            xprobe = {"scalars_8KB": ctx.exchange_probe(1024), "n_vector": ctx.exchange_probe(n), "two_n_vectors": ctx.exchange_probe(2 * n)}
+        except Exception as e:  # noqa: BLE001 -- the probe never loses the bench line
+            xprobe = {"error": repr(e)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, xprobe)  # (every rank's own clock: a slow link shows on the ranks at its ends)
+        xprobe = {"ranks": world, "exchange": "host-staged" if host_exchange else "rccl", "per_rank": per_rank}
+
     diag, b, x0 = synth_inputs(n)
     obj = qn.Quadratic.synthetic(n, SEED, diag, b, ctx=ctx)  # Q is generated shard-locally on the device
     solver = qn.BFGS(1e-10, x0, ctx=ctx)
@@ -658,6 +691,9 @@ def main():
                  "h_pass_fused_kernel (fused rank-2 update + 2-RHS mat-vec over the rank's rows of H)")
         ename = ("s2_eval_kernel<.., SHARD> (this rank's share of f(x + t d) and g(x + t d)'d from its windows of Q: per-workgroup scalars, "
                  "exchanged as 8 KB per rank and summed in rank order by the next launch's prologue)" if (sym2 and world > 1) else
+                 "s2_evalr_kernel (f(x + t d) and g(x + t d)'d from the symmetric half of Q; round 6: mover waves stream the workgroup's two tiles and "
+                 "its sliver, multiplier waves take the first tile's rows out of the LDS park as they land while wave 0's state machine has long "
+                 "decided, the movers multiply the second tile out of their registers)" if (sym2 and n == 4096 and os.environ.get("QN_S2_RING", "1") != "0") else
                  "s2_eval_kernel (f(x + t d) and g(x + t d)'d from the symmetric half of Q: first tile parked in LDS while wave 0 runs the "
                  "solver's state machine, items in groups with one exchange)" if sym2 else
                  "sym_eval_tile_kernel (Q (x + t d) from the upper block triangle of Q)" if sym_pass else
@@ -780,6 +816,8 @@ def main():
                                      "note": "counters are the solver's cumulative totals differenced around the median timed region"},
             "roofline": roofline,
         }
+        if world > 1:
+            out["multi_gpu_readiness"] = collectives_share(xprobe, acc["total_xchg_scalar"] / steps, acc["total_xchg_vector"] / steps, 1e3 * elapsed / steps)
         if cpu is not None:
             out["cpu_baseline"] = cpu.get("config2", cpu) if "error" not in cpu else cpu
         if want_extra:

@@ -79,6 +79,11 @@ int qn_comm_selftest(qn_context* ctx);
 /* collective (every rank calls it): one rank-tagged all-gather through the context's own exchange, then three of different
  * sizes as ONE group (the form the row kernels' exchanges take), each verified on every rank */
 int qn_context_comm_check(qn_context* ctx);
+/* The latency of ONE exchange (all-gather) of `count` doubles per rank on this context's exchange, between other work on its stream: `reps` timed
+ * repetitions bracketed by HIP events; out_us[0] = median, [1] = minimum, [2] = maximum, in microseconds (zeros on a one-rank context).  Collective:
+ * call on every rank with the same arguments.  (No counterpart in the reference, which is one thread: bench.py --gpus N reports these in front
+ * of its timed region, for the three sizes a row-sharded BFGS iteration exchanges -- 8 KB of scalars, n and 2 n doubles.) */
+int qn_context_exchange_probe(qn_context* ctx, size_t count, int reps, double* out_us);
 /* measurement aid: the fixed part (ms) of what a hipEventRecord / launch / hipEventRecord bracket on the idle context stream
  * reports beyond the bracketed kernel's own duration: 2 * bracket(one empty kernel) - bracket(two empty kernels) */
 int qn_context_event_bracket_overhead(qn_context* ctx, int reps, double* out_ms);

@@ -74,6 +74,7 @@ SYMBOLS = [
     ("qn_partition", C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("qn_comm_selftest", C.c_int, [C.c_void_p]),
     ("qn_context_comm_check", C.c_int, [C.c_void_p]),
+    ("qn_context_exchange_probe", C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     ("qn_context_event_bracket_overhead", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     ("qn_context_synchronize", C.c_int, [C.c_void_p]),
     ("qn_context_rank", C.c_int, [C.c_void_p]),

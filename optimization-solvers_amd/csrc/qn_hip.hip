@@ -360,6 +360,42 @@ extern "C" int qn_comm_selftest(qn_context* c) {
     return QN_OK;
 }
 
+// How long does ONE exchange of `count` doubles per rank take on this context, launch to completion, between other work on the stream?  (Round 6,
+// DESIGN section 5 budgets ~20 us per small collective without ever having measured one between devices; bench.py --gpus N
+// prints these figures in front of its timed region so that the first run on a multi-GPU node answers the question.)  `reps` exchanges, each
+// bracketed by HIP events on the context's stream and each behind a small kernel-sized gap (the exchanges of a run sit between launches, not
+// back to back); out_us[0] = median, out_us[1] = minimum, out_us[2] = maximum.  Collective: call on every rank with the same arguments.
+extern "C" int qn_context_exchange_probe(qn_context* c, size_t count, int reps, double* out_us) {
+    if (!c || !out_us || count == 0 || reps < 1 || reps > 4096) return fail(QN_ERROR_INPUT_PARAMS, "exchange probe: bad arguments");
+    out_us[0] = out_us[1] = out_us[2] = 0.0;
+    if (c->world == 1) return QN_OK;
+    HIPCHK(hipSetDevice(c->device));
+    double* buf = nullptr;
+    HIPCHK(hipMalloc((void**)&buf, count * (size_t)c->world * sizeof(double)));
+    HIPCHK(hipMemsetAsync(buf, 0, count * (size_t)c->world * sizeof(double), c->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int st = QN_OK;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, "exchange probe: event creation failed");
+    std::vector<float> us;
+    for (int r = 0; r < reps + 2 && st == QN_OK; ++r) { // (two untimed ones first: connection set-up, first-touch)
+        if (hipEventRecord(e0, c->stream) != hipSuccess) { st = fail(QN_ABNORMAL_TERMINATION, "exchange probe: event record"); break; }
+        st = exchange(c, buf, count);
+        if (st != QN_OK) break;
+        if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { st = fail(QN_ABNORMAL_TERMINATION, "exchange probe: event"); break; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { st = fail(QN_ABNORMAL_TERMINATION, "exchange probe: elapsed time"); break; }
+        if (r >= 2) us.push_back(1e3f * ms);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    if (st != QN_OK) return st;
+    if (c->host_async_failed) { c->host_async_failed = 0; return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed"); }
+    std::sort(us.begin(), us.end());
+    out_us[0] = us[us.size() / 2]; out_us[1] = us.front(); out_us[2] = us.back();
+    return QN_OK;
+}
+
 // Cross-rank check of the context's own exchange (RCCL communicator or host callback): every rank contributes a
 // rank-tagged slice to one in-place all-gather and verifies all of them.  Collective: call on every rank.
 extern "C" int qn_context_comm_check(qn_context* c) {

@@ -191,6 +191,13 @@ class Context:
         """Collective: one verified rank-tagged all-gather through this context's exchange (RCCL or host-staged)."""
         _check(A.lib().qn_context_comm_check(self.h))
 
+    def exchange_probe(self, count, reps=20):
+        """Collective: the latency of one exchange of `count` doubles per rank on this context (qn_context_exchange_probe):
+        {"median_us", "min_us", "max_us", "bytes_per_rank"}."""
+        out = (C.c_double * 3)()
+        _check(A.lib().qn_context_exchange_probe(self.h, int(count), int(reps), out))
+        return {"bytes_per_rank": 8 * int(count), "median_us": out[0], "min_us": out[1], "max_us": out[2]}
+
     def set_allreduce(self, on=True):
         """Sharded symmetric storage: all-reduce the partial n-vectors (RCCL's order) instead of all-gather + rank-order sum."""
         _check(A.lib().qn_context_set_allreduce(self.h, 1 if on else 0))

@@ -167,6 +167,7 @@ extern "C" {
     pub fn qn_partition(n: usize, world: c_int, rows_per_rank: *mut usize, n_pad: *mut usize) -> c_int;
     pub fn qn_comm_selftest(ctx: *mut qn_context) -> c_int;
     pub fn qn_context_comm_check(ctx: *mut qn_context) -> c_int;
+    pub fn qn_context_exchange_probe(ctx: *mut qn_context, count: usize, reps: c_int, out_us: *mut f64) -> c_int;
     pub fn qn_context_event_bracket_overhead(ctx: *mut qn_context, reps: c_int, out_ms: *mut f64) -> c_int;
     pub fn qn_context_synchronize(ctx: *mut qn_context) -> c_int;
     pub fn qn_context_rank(ctx: *const qn_context) -> c_int;

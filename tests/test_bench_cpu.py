@@ -90,3 +90,16 @@ def test_timed_regions_difference_the_counters_and_refuse_a_short_region():
     g = Fake()
     with pytest.raises(RuntimeError, match="ran 7 iterations"):
         bench.timed_regions(g.run_swallowing_convergence, g.stats, lambda: None, 20, 3)
+
+
+def test_collectives_share_estimates_from_probe_and_counts():
+    """bench.collectives_share (N > 1): probed latencies x counted collectives, slowest rank; a failed probe is reported, not raised."""
+    sys.path.insert(0, ROOT)
+    import bench
+    pr = lambda a, b, c: {"scalars_8KB": {"median_us": a}, "n_vector": {"median_us": b}, "two_n_vectors": {"median_us": c}}  # noqa: E731
+    out = bench.collectives_share({"ranks": 2, "exchange": "rccl", "per_rank": [pr(10.0, 30.0, 50.0), pr(12.0, 28.0, 60.0)]}, 2.0, 2.0, 0.5)
+    assert out["slowest_rank_median_us"] == {"scalars_8KB": 12.0, "n_vector": 30.0, "two_n_vectors": 60.0}
+    assert abs(out["estimated_collective_us_per_iteration"] - (2 * 12.0 + 30.0 + 60.0)) < 1e-12
+    assert abs(out["estimated_fraction_of_ms_per_step"] - 114.0 / 500.0) < 1e-12
+    bad = bench.collectives_share({"ranks": 2, "exchange": "rccl", "per_rank": [{"error": "x"}, {"error": "y"}]}, 2.0, 2.0, 0.5)
+    assert "error" in bad and "estimated_fraction_of_ms_per_step" not in bad

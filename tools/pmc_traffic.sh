@@ -18,7 +18,7 @@ def med(path, counter, key):
 f = glob.glob(out + "/fetch/**/f_counter_collection.csv", recursive=True)[0]
 w = glob.glob(out + "/write/**/w_counter_collection.csv", recursive=True)[0]
 res = {}
-for key, name in (("s2_hpass_kernel", "h_pass"), ("s2_eval_kernel", "quad_eval")):
+for key, name in (("s2_hpass_kernel", "h_pass"), ("s2_eval", "quad_eval")):  # ("s2_eval": s2_eval_kernel and, at n = 4096 since round 6, s2_evalr_kernel)
     fk, nf = med(f, "FETCH_SIZE", key); wk, nw = med(w, "WRITE_SIZE", key)
     res[name + "_FETCH_SIZE_KB"] = fk; res[name + "_WRITE_SIZE_KB"] = wk
     res[name + "_bytes_per_launch"] = 2 * fk * 1024 + wk * 1024
