@@ -50,3392 +50,12 @@ extern "C" const char* qn_status_string(int status) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// RCCL, loaded lazily so the library itself has no link-time dependency on it
-// ------------------------------------------------------------------------------------------------
-struct RcclUniqueId { char internal[QN_UNIQUE_ID_BYTES]; };
-typedef void* RcclComm;
-struct RcclApi {
-    void* handle = nullptr;
-    int (*GetUniqueId)(RcclUniqueId*) = nullptr;
-    int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
-    int (*CommDestroy)(RcclComm) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
-    int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr; // optional (qn_context_set_allreduce)
-    const char* (*GetErrorString)(int) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-};
-static RcclApi g_rccl;
-static const int kRcclDouble = 8; // ncclFloat64 / ncclDouble (rccl.h)
-static const int kRcclSum = 0;    // ncclSum
-
-static int rccl_load() {
-    if (g_rccl.handle) return QN_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    void* h = nullptr;
-    const char* forced = getenv("QN_RCCL_LIB"); // the one library to load (deployments with their own build; rehearsals of a missing one)
-    if (forced && *forced) h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
-    else
-        for (const char* nm : names) {
-            h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-            if (h) break;
-        }
-    if (!h) return fail(QN_ABNORMAL_TERMINATION, std::string("cannot load librccl: ") + dlerror());
-    g_rccl.GetUniqueId = (int (*)(RcclUniqueId*))dlsym(h, "ncclGetUniqueId");
-    g_rccl.CommInitRank = (int (*)(RcclComm*, int, RcclUniqueId, int))dlsym(h, "ncclCommInitRank");
-    g_rccl.CommDestroy = (int (*)(RcclComm))dlsym(h, "ncclCommDestroy");
-    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t))dlsym(h, "ncclAllGather");
-    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t))dlsym(h, "ncclAllReduce");
-    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-    g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
-    g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather)
-        return fail(QN_ABNORMAL_TERMINATION, "librccl is missing a required symbol");
-    g_rccl.handle = h;
-    return QN_OK;
-}
-#define RCCLCHK(expr)                                                                                             \
-    do {                                                                                                          \
-        int _r = (expr);                                                                                          \
-        if (_r != 0)                                                                                              \
-            return fail(QN_ABNORMAL_TERMINATION,                                                                  \
-                        std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error")); \
-    } while (0)
-
-// ------------------------------------------------------------------------------------------------
-// context
-// ------------------------------------------------------------------------------------------------
-struct qn_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int lu_bulk_cus = 256;
-    hipStream_t stream_lu = nullptr; // Newton's LU: the bulk of a trailing update on a stream whose CU mask leaves a quarter of the chip to the panel chain
-    hipStream_t stream2 = nullptr; // Newton's Cholesky: the bulk of a trailing update, beside the next block's chain of small kernels (created on first use)
-    std::vector<hipEvent_t> la_events; // ... and the events that order the two streams
-    int rank = 0, world = 1;
-    RcclComm comm = nullptr;
-    qn_host_allgather_fn host_xchg = nullptr;
-    void* host_xchg_user = nullptr;
-    std::vector<double> xchg_send, xchg_recv;
-    uint64_t n_comm = 0;
-    uint64_t n_xchg_vector = 0, n_xchg_scalar = 0; // collectives a solver enqueued on this context: of n-vectors, of per-workgroup scalars
-    // host-staged exchange in STREAM ORDER (qn_context_set_host_exchange_async): pinned staging, the callback runs as a
-    // hipLaunchHostFunc node between the two copies, nothing synchronises -- the pipelined launch logic can then be rehearsed
-    // with several ranks on one GPU
-    int use_allreduce = 0; // symmetric-storage sharded runs: ncclAllReduce of the partial n-vectors instead of all-gather + rank-order sum
-    int host_async = 0;
-    double* pin = nullptr; // [send (cap) | recv (cap * world)]
-    size_t pin_cap = 0;
-    int host_async_failed = 0;
-};
-struct HostXchgNode { qn_context* c; size_t count; };
-static void host_xchg_node(void* p) {
-    HostXchgNode* nd = (HostXchgNode*)p;
-    qn_context* c = nd->c;
-    if (c->host_xchg(c->host_xchg_user, c->pin, c->pin + c->pin_cap, nd->count) != 0) c->host_async_failed = 1;
-    delete nd;
-}
-
-extern "C" int qn_device_count(int* out) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) { *out = 0; return fail(QN_ABNORMAL_TERMINATION, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
-    *out = n;
-    return QN_OK;
-}
-
-static int context_base(int device, qn_context** out) {
-    if (!out) return fail(QN_ERROR_INPUT_PARAMS, "out is null");
-    int ndev = 0;
-    HIPCHK(hipGetDeviceCount(&ndev));
-    if (ndev <= 0) return fail(QN_ABNORMAL_TERMINATION, "no HIP device visible: libqn_hip has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(QN_ERROR_INPUT_PARAMS, "device ordinal out of range");
-    HIPCHK(hipSetDevice(device));
-    qn_context* c = new qn_context();
-    c->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete c; return fail(QN_ABNORMAL_TERMINATION, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-    *out = c;
-    return QN_OK;
-}
-
-extern "C" int qn_context_create(int device, qn_context** out) { return context_base(device, out); }
-
-extern "C" int qn_comm_unique_id(void* out_128_bytes) {
-    QNCHK(rccl_load());
-    RcclUniqueId id;
-    RCCLCHK(g_rccl.GetUniqueId(&id));
-    memcpy(out_128_bytes, &id, sizeof(id));
-    return QN_OK;
-}
-
-extern "C" int qn_context_create_sharded(int device, int rank, int world, const void* unique_id, qn_context** out) {
-    if (world < 1 || rank < 0 || rank >= world) return fail(QN_ERROR_INPUT_PARAMS, "bad rank/world");
-    QNCHK(context_base(device, out));
-    qn_context* c = *out;
-    c->rank = rank;
-    c->world = world;
-    if (world > 1) {
-        if (!unique_id) { qn_context_destroy(c); *out = nullptr; return fail(QN_ERROR_INPUT_PARAMS, "unique_id is null"); }
-        int s = rccl_load();
-        if (s != QN_OK) { qn_context_destroy(c); *out = nullptr; return s; }
-        RcclUniqueId id;
-        memcpy(&id, unique_id, sizeof(id));
-        int r = g_rccl.CommInitRank(&c->comm, world, id, rank);
-        if (r != 0) {
-            qn_context_destroy(c); *out = nullptr;
-            return fail(QN_ABNORMAL_TERMINATION, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
-        }
-    }
-    return QN_OK;
-}
-
-extern "C" int qn_context_create_sharded_host_exchange(int device, int rank, int world, qn_host_allgather_fn fn, void* user,
-                                                       qn_context** out) {
-    if (world < 1 || rank < 0 || rank >= world) return fail(QN_ERROR_INPUT_PARAMS, "bad rank/world");
-    if (world > 1 && !fn) return fail(QN_ERROR_INPUT_PARAMS, "exchange function is null");
-    QNCHK(context_base(device, out));
-    (*out)->rank = rank;
-    (*out)->world = world;
-    (*out)->host_xchg = fn;
-    (*out)->host_xchg_user = user;
-    return QN_OK;
-}
-
-extern "C" void qn_context_destroy(qn_context* c) {
-    if (!c) return;
-    (void)hipSetDevice(c->device);
-    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-    if (c->stream_lu) { (void)hipStreamSynchronize(c->stream_lu); (void)hipStreamDestroy(c->stream_lu); }
-    for (auto e : c->la_events) (void)hipEventDestroy(e);
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    if (c->pin) (void)hipHostFree(c->pin);
-    delete c;
-}
-extern "C" int qn_context_synchronize(qn_context* c) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->host_async_failed) { c->host_async_failed = 0; return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed"); }
-    return QN_OK;
-}
-extern "C" int qn_context_set_allreduce(qn_context* c, int on) {
-    if (!c) return fail(QN_ERROR_INPUT_PARAMS, "context is null");
-    if (on && c->comm && !g_rccl.AllReduce) return fail(QN_ERROR_INPUT_PARAMS, "librccl has no ncclAllReduce");
-    c->use_allreduce = on ? 1 : 0;
-    return QN_OK;
-}
-extern "C" int qn_context_set_host_exchange_async(qn_context* c, int on) {
-    if (!c) return fail(QN_ERROR_INPUT_PARAMS, "context is null");
-    if (on && c->world > 1 && !c->host_xchg) return fail(QN_ERROR_INPUT_PARAMS, "not a host-exchange context");
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->host_async = on ? 1 : 0;
-    return QN_OK;
-}
-extern "C" int qn_context_rank(const qn_context* c) { return c->rank; }
-extern "C" int qn_context_world(const qn_context* c) { return c->world; }
-extern "C" void* qn_context_stream(qn_context* c) { return (void*)c->stream; }
-
-// All-gather of `count` doubles per rank, in place: rank r's slice lives at buf + r*count.
-static int exchange(qn_context* c, double* buf, size_t count) {
-    if (c->world == 1) return QN_OK;
-    c->n_comm++;
-    if (c->comm) {
-        RCCLCHK(g_rccl.AllGather(buf + (size_t)c->rank * count, buf, count, kRcclDouble, c->comm, c->stream));
-        return QN_OK;
-    }
-    if (c->host_async) { // stream-ordered: D2H copy, host node, H2D copy; the caller's next synchronisation covers all three
-        if (count > c->pin_cap) {
-            HIPCHK(hipStreamSynchronize(c->stream)); // earlier nodes may still use the old staging area
-            if (c->pin) HIPCHK(hipHostFree(c->pin));
-            c->pin = nullptr;
-            c->pin_cap = std::max(count, (size_t)1 << 16);
-            HIPCHK(hipHostMalloc((void**)&c->pin, c->pin_cap * (size_t)(c->world + 1) * sizeof(double), hipHostMallocDefault));
-        }
-        HIPCHK(hipMemcpyAsync(c->pin, buf + (size_t)c->rank * count, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipLaunchHostFunc(c->stream, host_xchg_node, new HostXchgNode{c, count}));
-        HIPCHK(hipMemcpyAsync(buf, c->pin + c->pin_cap, count * (size_t)c->world * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        return QN_OK;
-    }
-    // host-staged exchange (tests / bring-up)
-    c->xchg_send.resize(count);
-    c->xchg_recv.resize(count * (size_t)c->world);
-    HIPCHK(hipMemcpyAsync(c->xchg_send.data(), buf + (size_t)c->rank * count, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->host_xchg(c->host_xchg_user, c->xchg_send.data(), c->xchg_recv.data(), count) != 0)
-        return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed");
-    HIPCHK(hipMemcpyAsync(buf, c->xchg_recv.data(), count * (size_t)c->world * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return QN_OK;
-}
-
-// Several in-place all-gathers issued as ONE RCCL group (one fused collective launch).
-struct XchgItem { double* buf; size_t count; };
-static int exchange_group(qn_context* c, const XchgItem* items, int nitems) {
-    if (c->world == 1) return QN_OK;
-    if (c->comm && g_rccl.GroupStart && g_rccl.GroupEnd) {
-        c->n_comm++;
-        RCCLCHK(g_rccl.GroupStart());
-        for (int i = 0; i < nitems; ++i)
-            RCCLCHK(g_rccl.AllGather(items[i].buf + (size_t)c->rank * items[i].count, items[i].buf, items[i].count, kRcclDouble, c->comm, c->stream));
-        RCCLCHK(g_rccl.GroupEnd());
-        return QN_OK;
-    }
-    for (int i = 0; i < nitems; ++i) QNCHK(exchange(c, items[i].buf, items[i].count));
-    return QN_OK;
-}
-
-// Sum of `count` doubles per rank over the ranks: rank r's contribution lives at buf + r*count, the total lands in buf[0..count).
-// RCCL: ncclAllReduce(ncclSum) -- the operation north_star names; its summation order is RCCL's (ring / tree), identical on all
-// ranks but not the rank order of the default all-gather path.  Host exchange (tests): gathered and added in rank order.
-__global__ void xchg_rank_sum_kernel(double* __restrict__ buf, size_t count, int world) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
-        double acc = buf[i];
-        for (int r = 1; r < world; ++r) acc = acc + buf[(size_t)r * count + i];
-        buf[i] = acc;
-    }
-}
-static int exchange_sum(qn_context* c, double* buf, size_t count) {
-    if (c->world == 1) return QN_OK;
-    if (c->comm) {
-        if (!g_rccl.AllReduce) return fail(QN_ABNORMAL_TERMINATION, "librccl has no ncclAllReduce");
-        c->n_comm++;
-        RCCLCHK(g_rccl.AllReduce(buf + (size_t)c->rank * count, buf, count, kRcclDouble, kRcclSum, c->comm, c->stream));
-        return QN_OK;
-    }
-    QNCHK(exchange(c, buf, count));
-    hipLaunchKernelGGL(xchg_rank_sum_kernel, dim3((unsigned)std::min<size_t>((count + 255) / 256, 1024)), dim3(256), 0, c->stream, buf, count, c->world);
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// partition: rank p owns rows [p*rpr, (p+1)*rpr); rpr is a multiple of 16 so every row tile is full
-// ------------------------------------------------------------------------------------------------
-static int part_rpr(size_t n, int world) {
-    size_t per = (n + (size_t)world - 1) / (size_t)world;
-    per = (per + 15) / 16 * 16;
-    if (per == 0) per = 16;
-    return (int)per;
-}
-static QnTile make_tile(size_t n, const qn_context* c, int cs) {
-    QnTile T;
-    T.n = (int)n;
-    T.rpr = part_rpr(n, c->world);
-    T.n_pad = T.rpr * c->world;
-    T.row_off = T.rpr * c->rank;
-    T.cs = cs;
-    T.rank = c->rank;
-    return T;
-}
-
-extern "C" int qn_partition(size_t n, int world, size_t* rows_per_rank, size_t* n_pad) {
-    if (world < 1 || n == 0) return fail(QN_ERROR_INPUT_PARAMS, "bad n/world");
-    const int rpr = part_rpr(n, world);
-    if (rows_per_rank) *rows_per_rank = (size_t)rpr;
-    if (n_pad) *n_pad = (size_t)rpr * (size_t)world;
-    return QN_OK;
-}
-
-extern "C" int qn_comm_selftest(qn_context* c) {
-    HIPCHK(hipSetDevice(c->device));
-    QNCHK(rccl_load());
-    RcclUniqueId id;
-    RCCLCHK(g_rccl.GetUniqueId(&id));
-    RcclComm comm = nullptr;
-    RCCLCHK(g_rccl.CommInitRank(&comm, 1, id, 0));
-    const size_t count = 1024;
-    double* buf = nullptr;
-    HIPCHK(hipMalloc((void**)&buf, count * sizeof(double)));
-    std::vector<double> h(count), back(count, 0.0);
-    for (size_t i = 0; i < count; ++i) h[i] = 0.5 * (double)i - 3.0;
-    HIPCHK(hipMemcpyAsync(buf, h.data(), count * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    RCCLCHK(g_rccl.AllGather(buf, buf, count, kRcclDouble, comm, c->stream)); // in place, rank 0 of 1
-    HIPCHK(hipMemcpyAsync(back.data(), buf, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    g_rccl.CommDestroy(comm);
-    HIPCHK(hipFree(buf));
-    if (memcmp(h.data(), back.data(), count * sizeof(double)) != 0) return fail(QN_ABNORMAL_TERMINATION, "RCCL self-test: data mismatch");
-    return QN_OK;
-}
-
-// How long does ONE exchange of `count` doubles per rank take on this context, launch to completion, between other work on the stream?  (Round 6,
-// DESIGN section 5 budgets ~20 us per small collective without ever having measured one between devices; bench.py --gpus N
-// prints these figures in front of its timed region so that the first run on a multi-GPU node answers the question.)  `reps` exchanges, each
-// bracketed by HIP events on the context's stream and each behind a small kernel-sized gap (the exchanges of a run sit between launches, not
-// back to back); out_us[0] = median, out_us[1] = minimum, out_us[2] = maximum.  Collective: call on every rank with the same arguments.
-extern "C" int qn_context_exchange_probe(qn_context* c, size_t count, int reps, double* out_us) {
-    if (!c || !out_us || count == 0 || reps < 1 || reps > 4096) return fail(QN_ERROR_INPUT_PARAMS, "exchange probe: bad arguments");
-    out_us[0] = out_us[1] = out_us[2] = 0.0;
-    if (c->world == 1) return QN_OK;
-    HIPCHK(hipSetDevice(c->device));
-    double* buf = nullptr;
-    HIPCHK(hipMalloc((void**)&buf, count * (size_t)c->world * sizeof(double)));
-    HIPCHK(hipMemsetAsync(buf, 0, count * (size_t)c->world * sizeof(double), c->stream));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    int st = QN_OK;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, "exchange probe: event creation failed");
-    std::vector<float> us;
-    for (int r = 0; r < reps + 2 && st == QN_OK; ++r) { // (two untimed ones first: connection set-up, first-touch)
-        if (hipEventRecord(e0, c->stream) != hipSuccess) { st = fail(QN_ABNORMAL_TERMINATION, "exchange probe: event record"); break; }
-        st = exchange(c, buf, count);
-        if (st != QN_OK) break;
-        if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { st = fail(QN_ABNORMAL_TERMINATION, "exchange probe: event"); break; }
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { st = fail(QN_ABNORMAL_TERMINATION, "exchange probe: elapsed time"); break; }
-        if (r >= 2) us.push_back(1e3f * ms);
-    }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    (void)hipFree(buf);
-    if (st != QN_OK) return st;
-    if (c->host_async_failed) { c->host_async_failed = 0; return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed"); }
-    std::sort(us.begin(), us.end());
-    out_us[0] = us[us.size() / 2]; out_us[1] = us.front(); out_us[2] = us.back();
-    return QN_OK;
-}
-
-// Cross-rank check of the context's own exchange (RCCL communicator or host callback): every rank contributes a
-// rank-tagged slice to one in-place all-gather and verifies all of them.  Collective: call on every rank.
-extern "C" int qn_context_comm_check(qn_context* c) {
-    if (!c) return fail(QN_ERROR_INPUT_PARAMS, "context is null");
-    if (c->world == 1) return QN_OK;
-    HIPCHK(hipSetDevice(c->device));
-    const size_t count = 4096, total = count * (size_t)c->world;
-    double* buf = nullptr;
-    HIPCHK(hipMalloc((void**)&buf, total * sizeof(double)));
-    std::vector<double> h(total, -1.0);
-    for (size_t i = 0; i < count; ++i) h[(size_t)c->rank * count + i] = 1000.0 * (double)c->rank + 0.25 * (double)i;
-    HIPCHK(hipMemcpyAsync(buf, h.data(), total * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    int st = exchange(c, buf, count);
-    if (st == QN_OK) {
-        hipError_t e = hipMemcpyAsync(h.data(), buf, total * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, std::string("comm check: ") + hipGetErrorString(e));
-    }
-    (void)hipFree(buf);
-    if (st != QN_OK) return st;
-    for (int r = 0; r < c->world; ++r)
-        for (size_t i = 0; i < count; ++i)
-            if (h[(size_t)r * count + i] != 1000.0 * (double)r + 0.25 * (double)i)
-                return fail(QN_ABNORMAL_TERMINATION, "comm check: all-gather returned wrong data");
-    // ... and the GROUPED path the row kernels use (three all-gathers of different sizes between ncclGroupStart / ncclGroupEnd:
-    // vector slices and per-workgroup partial sums), verified the same way
-    const size_t counts[3] = {1024, 1024, 9 * 32};
-    double* gb[3] = {nullptr, nullptr, nullptr};
-    std::vector<double> gh[3];
-    for (int k = 0; k < 3 && st == QN_OK; ++k) {
-        const size_t tot = counts[k] * (size_t)c->world;
-        gh[k].assign(tot, -1.0);
-        for (size_t i = 0; i < counts[k]; ++i) gh[k][(size_t)c->rank * counts[k] + i] = 1e6 * (k + 1) + 1000.0 * (double)c->rank + 0.5 * (double)i;
-        hipError_t e = hipMalloc((void**)&gb[k], tot * sizeof(double));
-        if (e == hipSuccess) e = hipMemcpyAsync(gb[k], gh[k].data(), tot * sizeof(double), hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, std::string("comm check: ") + hipGetErrorString(e));
-    }
-    if (st == QN_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, "comm check: synchronize");
-    if (st == QN_OK) {
-        const XchgItem items[3] = {{gb[0], counts[0]}, {gb[1], counts[1]}, {gb[2], counts[2]}};
-        st = exchange_group(c, items, 3);
-    }
-    for (int k = 0; k < 3 && st == QN_OK; ++k) {
-        hipError_t e = hipMemcpyAsync(gh[k].data(), gb[k], gh[k].size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, std::string("comm check: ") + hipGetErrorString(e));
-    }
-    for (int k = 0; k < 3; ++k) (void)hipFree(gb[k]);
-    if (st != QN_OK) return st;
-    if (c->host_async_failed) { c->host_async_failed = 0; return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed"); }
-    for (int k = 0; k < 3; ++k)
-        for (int r = 0; r < c->world; ++r)
-            for (size_t i = 0; i < counts[k]; ++i)
-                if (gh[k][(size_t)r * counts[k] + i] != 1e6 * (k + 1) + 1000.0 * (double)r + 0.5 * (double)i)
-                    return fail(QN_ABNORMAL_TERMINATION, "comm check: grouped all-gather returned wrong data");
-    return QN_OK;
-}
-
-__global__ void qn_empty_kernel() {}
-extern "C" int qn_context_event_bracket_overhead(qn_context* c, int reps, double* out_ms) {
-    if (!c || !out_ms || reps < 1) return fail(QN_ERROR_INPUT_PARAMS, "bad arguments");
-    HIPCHK(hipSetDevice(c->device));
-    hipEvent_t a = nullptr, b = nullptr;
-    HIPCHK(hipEventCreate(&a));
-    HIPCHK(hipEventCreate(&b));
-    // A bracket around k empty kernels reports fixed + k * (one empty dispatch).  The fixed part -- what a bracket adds to the
-    // duration of the single kernel inside it -- is 2 * bracket(1) - bracket(2).
-    double total[2] = {0.0, 0.0};
-    for (int k = 1; k <= 2; ++k) {
-        for (int i = 0; i < reps + 5; ++i) {
-            HIPCHK(hipStreamSynchronize(c->stream)); // the launch meets an idle stream, as in synchronous mode
-            HIPCHK(hipEventRecord(a, c->stream));
-            for (int j = 0; j < k; ++j) hipLaunchKernelGGL(qn_empty_kernel, dim3(1), dim3(64), 0, c->stream);
-            HIPCHK(hipEventRecord(b, c->stream));
-            HIPCHK(hipEventSynchronize(b));
-            float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, a, b));
-            if (i >= 5) total[k - 1] += ms; // the first few carry one-off costs
-        }
-    }
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    const double b1 = total[0] / reps, b2 = total[1] / reps;
-    *out_ms = std::max(0.0, 2.0 * b1 - b2);
-    return QN_OK;
-}
-
-static int dev_alloc_zero(double** p, size_t count, hipStream_t st) {
-    HIPCHK(hipMalloc((void**)p, count * sizeof(double)));
-    HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(double), st));
-    return QN_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// line-search parameter structs
-// ------------------------------------------------------------------------------------------------
-extern "C" void qn_morethuente_default(qn_linesearch* ls) { // morethuente.rs:16-28
-    memset(ls, 0, sizeof(*ls));
-    ls->kind = QN_LS_MORETHUENTE;
-    ls->c1 = 1e-4; ls->c2 = 0.9; ls->t_min = 0.0; ls->t_max = INFINITY;
-    ls->delta_min = 0.58333333; ls->delta = 0.66; ls->delta_max = 1.1;
-}
-extern "C" int qn_morethuente_with_deltas(qn_linesearch* ls, double dmin, double d, double dmax) {
-    ls->delta_min = dmin; ls->delta = d; ls->delta_max = dmax; return QN_OK;
-}
-extern "C" int qn_morethuente_with_t_min(qn_linesearch* ls, double t_min) { ls->t_min = t_min; return QN_OK; }
-extern "C" int qn_morethuente_with_t_max(qn_linesearch* ls, double t_max) { ls->t_max = t_max; return QN_OK; }
-extern "C" int qn_morethuente_with_c1(qn_linesearch* ls, double c1) { // asserts of morethuente.rs:51-52
-    if (!(c1 > 0.0)) return fail(QN_ERROR_INPUT_PARAMS, "c1 must be positive");
-    if (!(c1 < ls->c2)) return fail(QN_ERROR_INPUT_PARAMS, "c1 must be less than c2");
-    ls->c1 = c1; return QN_OK;
-}
-extern "C" int qn_morethuente_with_c2(qn_linesearch* ls, double c2) { // asserts of morethuente.rs:57-59
-    if (!(c2 > 0.0)) return fail(QN_ERROR_INPUT_PARAMS, "c2 must be positive");
-    if (!(c2 < 1.0)) return fail(QN_ERROR_INPUT_PARAMS, "c2 must be less than 1");
-    if (!(c2 > ls->c1)) return fail(QN_ERROR_INPUT_PARAMS, "c2 must be greater than c1");
-    ls->c2 = c2; return QN_OK;
-}
-extern "C" void qn_morethuente_b_new(qn_linesearch* ls) { // MoreThuenteB::new(n), morethuente_b.rs:18-31
-    qn_morethuente_default(ls);
-    ls->kind = QN_LS_MORETHUENTE_B;
-}
-extern "C" void qn_backtracking_b_new(qn_linesearch* ls, double c1, double beta, const double* lb, const double* ub) { // backtracking_b.rs:10-23
-    memset(ls, 0, sizeof(*ls));
-    ls->kind = QN_LS_BACKTRACKING_B;
-    ls->bt_c1 = c1; ls->bt_beta = beta;
-    ls->lower_bound_host = lb; ls->upper_bound_host = ub;
-}
-extern "C" void qn_linesearch_with_lower_bound(qn_linesearch* ls, const double* lb) { ls->lower_bound_host = lb; }
-extern "C" void qn_linesearch_with_upper_bound(qn_linesearch* ls, const double* ub) { ls->upper_bound_host = ub; }
-extern "C" void qn_backtracking_new(qn_linesearch* ls, double c1, double beta) { // backtracking.rs:8-10
-    memset(ls, 0, sizeof(*ls));
-    ls->kind = QN_LS_BACKTRACKING;
-    ls->bt_c1 = c1; ls->bt_beta = beta;
-}
-
-// ------------------------------------------------------------------------------------------------
-// objectives
-// ------------------------------------------------------------------------------------------------
-enum { OBJ_QUADRATIC = 1, OBJ_LOGSUMEXP = 2 };
-static std::atomic<uint64_t> g_objective_serial{0}; // objectives are numbered at creation: an address can come back after a destroy, a serial cannot
-struct qn_objective {
-    uint64_t serial = ++g_objective_serial;
-    qn_context* ctx = nullptr;
-    int kind = 0;
-    size_t n = 0;
-    QnTile T{};
-    double* Q = nullptr; // this rank's rows, [rpr][n_pad]
-    double* b = nullptr; // n_pad
-    bool q_symmetric = true; // quadratic: Q == Q' bit for bit (checked at creation); the symmetric-storage evaluation needs it
-    // scratch for qn_objective_eval
-    double *ex = nullptr, *eq = nullptr, *eg = nullptr, *ef = nullptr;
-    // log-sum-exp: A rows are in Q ([mrpr][n_pad]), c in b (m_pad)
-    size_t m = 0;
-    QnTile TA{}; // row partition of A (m rows)
-    double mu = 0.0;
-    int lse_rs = 1;
-    int lse_two_pass = 0; // diagnostics (QN_LSE_TWO_PASS=1 in the environment at creation): the round-1 two-pass evaluation
-    double *lz = nullptr, *lw = nullptr, *lgpart = nullptr, *lgall = nullptr, *lscal = nullptr;
-    double *lwgms = nullptr, *lwgg = nullptr, *lms = nullptr; // one-pass evaluation: per-workgroup (m, S), G vectors; gathered per-rank (m, S)
-    int lse_G = 0, lse_kch = 0;                                 // its grid and column chunks per thread (0: two-pass evaluation)
-};
-
-static int objective_base(qn_context* ctx, size_t n, const double* b_host, qn_objective** out) {
-    if (!ctx || !out || !b_host || n == 0) return fail(QN_ERROR_INPUT_PARAMS, "null argument or n == 0");
-    if (n > (size_t)1 << 30) return fail(QN_ERROR_INPUT_PARAMS, "n too large");
-    HIPCHK(hipSetDevice(ctx->device));
-    qn_objective* o = new qn_objective();
-    o->ctx = ctx;
-    o->kind = OBJ_QUADRATIC;
-    o->n = n;
-    o->T = make_tile(n, ctx, 1);
-    *out = o;
-    QNCHK(dev_alloc_zero(&o->Q, (size_t)o->T.rpr * o->T.n_pad, ctx->stream));
-    QNCHK(dev_alloc_zero(&o->b, o->T.n_pad, ctx->stream));
-    HIPCHK(hipMemcpyAsync(o->b, b_host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return QN_OK;
-}
-
-extern "C" int qn_quadratic_create(qn_context* ctx, size_t n, const double* q_host, const double* b_host, qn_objective** out) {
-    if (!q_host) return fail(QN_ERROR_INPUT_PARAMS, "q is null");
-    QNCHK(objective_base(ctx, n, b_host, out));
-    qn_objective* o = *out;
-    const size_t r0 = (size_t)o->T.row_off;
-    if (r0 < n) {
-        const size_t nr = std::min((size_t)o->T.rpr, n - r0);
-        HIPCHK(hipMemcpy2D(o->Q, (size_t)o->T.n_pad * sizeof(double), q_host + r0 * n, n * sizeof(double), n * sizeof(double), nr,
-                           hipMemcpyHostToDevice));
-    }
-    // g = Q x - b is the gradient of f only for a symmetric Q, but nothing stops a caller from passing another matrix: the row
-    // kernels multiply by what was given, so the symmetric-storage evaluation is used only when Q is symmetric bit for bit
-    for (size_t i = 0; i < n && o->q_symmetric; ++i)
-        for (size_t j = i + 1; j < n; ++j)
-            if (q_host[i * n + j] != q_host[j * n + i]) { o->q_symmetric = false; break; }
-    return QN_OK;
-}
-
-extern "C" int qn_quadratic_create_synthetic(qn_context* ctx, size_t n, uint64_t seed, const double* diag_host,
-                                             const double* b_host, qn_objective** out) {
-    if (!diag_host) return fail(QN_ERROR_INPUT_PARAMS, "diag is null");
-    QNCHK(objective_base(ctx, n, b_host, out));
-    qn_objective* o = *out;
-    double* diag = nullptr;
-    HIPCHK(hipMalloc((void**)&diag, n * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(diag, diag_host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(synth_fill_kernel, dim3(2048), dim3(256), 0, ctx->stream, o->Q, o->T, seed, diag, 1.0 / (double)n);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipFree(diag));
-    return QN_OK;
-}
-
-extern "C" int qn_logsumexp_create(qn_context* ctx, size_t m, size_t n, const double* a_host, const double* c_host, double mu,
-                                   qn_objective** out) {
-    if (!ctx || !out || !a_host || !c_host || n == 0 || m == 0) return fail(QN_ERROR_INPUT_PARAMS, "null argument or empty shape");
-    if (n > (size_t)1 << 30 || m > (size_t)1 << 30) return fail(QN_ERROR_INPUT_PARAMS, "shape too large");
-    HIPCHK(hipSetDevice(ctx->device));
-    qn_objective* o = new qn_objective();
-    *out = o;
-    o->ctx = ctx; o->kind = OBJ_LOGSUMEXP; o->n = n; o->m = m; o->mu = mu;
-    o->T = make_tile(n, ctx, 1);  // column padding follows the solver's vectors
-    o->TA = make_tile(m, ctx, 1); // rows of A are sharded
-    const size_t np = o->T.n_pad, mp = o->TA.n_pad, mrpr = o->TA.rpr;
-    hipStream_t st = ctx->stream;
-    QNCHK(dev_alloc_zero(&o->Q, mrpr * np, st));
-    QNCHK(dev_alloc_zero(&o->b, mp, st));
-    HIPCHK(hipMemcpyAsync(o->b, c_host, m * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st)); // the zero-fill above must land before the (null-stream) 2-D upload below
-    const size_t r0 = (size_t)o->TA.row_off;
-    if (r0 < m) {
-        const size_t nr = std::min(mrpr, m - r0);
-        HIPCHK(hipMemcpy2D(o->Q, np * sizeof(double), a_host + r0 * n, n * sizeof(double), n * sizeof(double), nr, hipMemcpyHostToDevice));
-    }
-    o->lse_rs = (int)std::max<size_t>(1, std::min<size_t>(64, mrpr / 64));
-    QNCHK(dev_alloc_zero(&o->lz, (size_t)ctx->world * 2 * mrpr, st));
-    QNCHK(dev_alloc_zero(&o->lw, mp, st));
-    QNCHK(dev_alloc_zero(&o->lgpart, (size_t)o->lse_rs * np, st));
-    QNCHK(dev_alloc_zero(&o->lgall, (size_t)ctx->world * np, st));
-    QNCHK(dev_alloc_zero(&o->lscal, 2, st));
-    o->lse_two_pass = getenv("QN_LSE_TWO_PASS") && atoi(getenv("QN_LSE_TWO_PASS")) != 0;
-    if (np <= 16384 && np >= 2) { // the one-pass evaluation keeps a whole row per workgroup in registers
-        int kch = 1;
-        while ((size_t)kch * 1024 < np) kch *= 2;
-        o->lse_kch = kch;
-        o->lse_G = (int)std::max<size_t>(1, std::min<size_t>(256, (mrpr + 3) / 4));
-        QNCHK(dev_alloc_zero(&o->lwgms, 2 * (size_t)o->lse_G, st));
-        QNCHK(dev_alloc_zero(&o->lwgg, (size_t)o->lse_G * np, st));
-        QNCHK(dev_alloc_zero(&o->lms, 2 * (size_t)ctx->world, st));
-    }
-    HIPCHK(hipStreamSynchronize(st));
-    return QN_OK;
-}
-
-template <int R>
-static void launch_hpass(hipStream_t st, const QnHPassArgs& a);
-
-// enqueue one evaluation of the log-sum-exp objective at x_dev (n_pad entries): f -> f_dev, g -> g_dev
-template <int KCH, bool NTA>
-static int lse_launch_onepass_nt(hipStream_t st, int G, const QnLseArgs& a, double* wgms, double* wgg) {
-    static std::atomic<bool> attr_set[64]; // per device: hipFuncSetAttribute applies to the current device only (atomic: ranks may be threads)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const size_t lds = (size_t)KCH * 1024 * sizeof(double);
-    if ((dev < 0 || dev >= 64 || !attr_set[dev].load()) && lds > 48 * 1024) { // x in LDS: up to 128 KB of the CU's 160 KB
-        if (hipFuncSetAttribute((const void*)lse_onepass_kernel<KCH, NTA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return -1; // this device does not grant the LDS: the caller keeps the two-pass evaluation
-        }
-        if (dev >= 0 && dev < 64) attr_set[dev].store(true);
-    }
-    hipLaunchKernelGGL((lse_onepass_kernel<KCH, NTA>), dim3(G), dim3(512), lds, st, a, wgms, wgg);
-    return QN_OK;
-}
-template <int KCH>
-static int lse_launch_onepass(hipStream_t st, int G, const QnLseArgs& a, double* wgms, double* wgg) {
-    // rows of A that cannot stay in the 256 MB Infinity Cache between evaluations are requested as non-temporal (QN_LSE_NT = 0 / 1 overrides)
-    static const int nt_env = getenv("QN_LSE_NT") ? atoi(getenv("QN_LSE_NT")) : -1;
-    const bool nt = nt_env >= 0 ? nt_env != 0 : (size_t)a.mrpr * (size_t)a.n_pad * sizeof(double) > ((size_t)230 << 20);
-    return nt ? lse_launch_onepass_nt<KCH, true>(st, G, a, wgms, wgg) : lse_launch_onepass_nt<KCH, false>(st, G, a, wgms, wgg);
-}
-
-static int lse_enqueue_eval(qn_objective* o, const double* x_dev, double* f_dev, double* g_dev) {
-    qn_context* c = o->ctx;
-    hipStream_t st = c->stream;
-    if (o->lse_kch && !o->lse_two_pass) { // one pass over A (qn_kernels.hip.h): 8 m n / P bytes per evaluation instead of 16 m n / P
-        QnLseArgs a{};
-        a.A = o->Q; a.c = o->b; a.gall = o->lgall; a.x = x_dev; a.f_out = f_dev; a.g_out = g_dev; a.mu = o->mu;
-        a.m = (int)o->m; a.m_pad = o->TA.n_pad; a.mrpr = o->TA.rpr; a.n = (int)o->n; a.n_pad = o->T.n_pad;
-        a.world = c->world; a.rank = c->rank; a.rs = 1;
-        int lst;
-        switch (o->lse_kch) {
-        case 1: lst = lse_launch_onepass<1>(st, o->lse_G, a, o->lwgms, o->lwgg); break;
-        case 2: lst = lse_launch_onepass<2>(st, o->lse_G, a, o->lwgms, o->lwgg); break;
-        case 4: lst = lse_launch_onepass<4>(st, o->lse_G, a, o->lwgms, o->lwgg); break;
-        case 8: lst = lse_launch_onepass<8>(st, o->lse_G, a, o->lwgms, o->lwgg); break;
-        default: lst = lse_launch_onepass<16>(st, o->lse_G, a, o->lwgms, o->lwgg); break;
-        }
-        if (lst < 0) { o->lse_two_pass = 1; return lse_enqueue_eval(o, x_dev, f_dev, g_dev); }
-        hipLaunchKernelGGL(lse_combine_kernel, dim3((a.n_pad + 63) / 64), dim3(256), 0, st, a, o->lse_G, o->lwgms, o->lwgg, o->lms);
-        HIPCHK(hipGetLastError());
-        const XchgItem items[2] = {{o->lgall, (size_t)a.n_pad}, {o->lms, 2}};
-        c->n_xchg_vector++;
-        QNCHK(exchange_group(c, items, 2));
-        hipLaunchKernelGGL(lse_finish1_kernel, dim3(std::min(1024, (a.n_pad + 255) / 256)), dim3(256), 0, st, a, o->lms);
-        HIPCHK(hipGetLastError());
-        return QN_OK;
-    }
-    // pass 1: z = A_rows x (the H-pass kernel in plain mat-vec mode)
-    QnHPassArgs h{};
-    h.H = o->Q; h.T = o->TA; h.T.n_pad = o->T.n_pad; h.T.n = (int)o->n; h.T.cs = 1;
-    h.T.rpr = o->TA.rpr; h.T.row_off = 0; // row guards are not needed for a read-only pass
-    h.hp = o->lz; h.expect_phase = -1; h.force_nrhs = 1; h.force_pending = 0; h.r0 = x_dev; h.r1 = x_dev;
-    h.sp = x_dev; h.up = x_dev;
-    launch_hpass<8>(st, h);
-    HIPCHK(hipGetLastError());
-    c->n_xchg_vector++;
-    QNCHK(exchange(c, o->lz, 2 * (size_t)o->TA.rpr));
-    QnLseArgs a{};
-    a.A = o->Q; a.c = o->b; a.z = o->lz; a.w = o->lw; a.gpart = o->lgpart; a.gall = o->lgall; a.x = x_dev;
-    a.f_out = f_dev; a.g_out = g_dev; a.scal = o->lscal; a.mu = o->mu;
-    a.m = (int)o->m; a.m_pad = o->TA.n_pad; a.mrpr = o->TA.rpr; a.n = (int)o->n; a.n_pad = o->T.n_pad;
-    a.world = c->world; a.rank = c->rank; a.rs = o->lse_rs;
-    hipLaunchKernelGGL(lse_softmax_kernel, dim3(1), dim3(1024), 0, st, a);
-    // pass 2: column sums A'w over this rank's rows
-    hipLaunchKernelGGL(lse_colsum_kernel, dim3((a.n_pad + QN_CHUNK - 1) / QN_CHUNK, a.rs), dim3(QN_TPB), 0, st, a);
-    hipLaunchKernelGGL(lse_reduce_splits_kernel, dim3(std::min(1024, (a.n_pad + 255) / 256)), dim3(256), 0, st, a);
-    HIPCHK(hipGetLastError());
-    c->n_xchg_vector++;
-    QNCHK(exchange(c, o->lgall, (size_t)a.n_pad));
-    hipLaunchKernelGGL(lse_finish_kernel, dim3(std::min(1024, (a.n_pad + 255) / 256)), dim3(256), 0, st, a);
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-
-extern "C" void qn_objective_destroy(qn_objective* o) {
-    if (!o) return;
-    (void)hipSetDevice(o->ctx->device);
-    (void)hipFree(o->Q); (void)hipFree(o->b);
-    (void)hipFree(o->ex); (void)hipFree(o->eq); (void)hipFree(o->eg); (void)hipFree(o->ef);
-    (void)hipFree(o->lz); (void)hipFree(o->lw); (void)hipFree(o->lgpart); (void)hipFree(o->lgall); (void)hipFree(o->lscal);
-    (void)hipFree(o->lwgms); (void)hipFree(o->lwgg); (void)hipFree(o->lms);
-    delete o;
-}
-
-extern "C" int qn_objective_get_rows(qn_objective* o, size_t row0, size_t nrows, double* out_host) {
-    const bool lse = o->kind == OBJ_LOGSUMEXP;
-    const size_t lo = lse ? (size_t)o->TA.row_off : (size_t)o->T.row_off;
-    const size_t hi = lse ? std::min(o->m, lo + (size_t)o->TA.rpr) : std::min(o->n, lo + (size_t)o->T.rpr);
-    if (row0 < lo || row0 + nrows > hi) return fail(QN_ERROR_INPUT_PARAMS, "rows outside this rank's shard");
-    HIPCHK(hipSetDevice(o->ctx->device));
-    HIPCHK(hipMemcpy2D(out_host, o->n * sizeof(double), o->Q + (row0 - lo) * (size_t)o->T.n_pad, (size_t)o->T.n_pad * sizeof(double),
-                       o->n * sizeof(double), nrows, hipMemcpyDeviceToHost));
-    return QN_OK;
-}
-
-template <int R>
-static void launch_quad(hipStream_t st, const QnQuadArgs& a) {
-    dim3 grid(a.T.rpr / R, a.T.cs);
-    hipLaunchKernelGGL(quad_matvec_kernel<R>, grid, dim3(QN_TPB), 0, st, a);
-}
-static int launch_quad_R(int R, hipStream_t st, const QnQuadArgs& a) {
-    switch (R) {
-    case 4: launch_quad<4>(st, a); break;
-    case 16: launch_quad<16>(st, a); break;
-    default: launch_quad<8>(st, a); break;
-    }
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-
-__global__ __launch_bounds__(QN_CTL_TPB) void quad_finish_kernel(const QnVecs V, double* f_out, double* g_out) {
-    __shared__ double lds[32];
-    double p[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < V.n_pad; i += QN_CTL_TPB) {
-        const double qi = q_val(V, i), xi = V.xt[i], bi = V.b[i];
-        p[0] = __builtin_fma(xi, qi, p[0]);
-        p[1] = __builtin_fma(bi, xi, p[1]);
-        g_out[i] = qi - bi;
-    }
-    ctl_block_sum<2>(p, lds);
-    if (threadIdx.x == 0) *f_out = 0.5 * p[0] - p[1];
-}
-
-extern "C" int qn_objective_eval(qn_objective* o, const double* x_host, double* f, double* g_host) {
-    qn_context* c = o->ctx;
-    HIPCHK(hipSetDevice(c->device));
-    const size_t np = o->T.n_pad;
-    if (o->kind == OBJ_LOGSUMEXP) {
-        if (!o->ex) {
-            QNCHK(dev_alloc_zero(&o->ex, 2 * np, c->stream));
-            QNCHK(dev_alloc_zero(&o->eg, np, c->stream));
-            QNCHK(dev_alloc_zero(&o->ef, 2, c->stream));
-        }
-        HIPCHK(hipMemcpyAsync(o->ex, x_host, o->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        QNCHK(lse_enqueue_eval(o, o->ex, o->ef, o->eg));
-        HIPCHK(hipMemcpyAsync(f, o->ef, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(g_host, o->eg, o->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        return QN_OK;
-    }
-    if (o->kind != OBJ_QUADRATIC) return fail(QN_ERROR_INPUT_PARAMS, "unsupported objective");
-    if (!o->ex) {
-        QNCHK(dev_alloc_zero(&o->ex, 2 * np, c->stream)); // x and xt
-        QNCHK(dev_alloc_zero(&o->eq, np, c->stream));
-        QNCHK(dev_alloc_zero(&o->eg, np, c->stream));
-        QNCHK(dev_alloc_zero(&o->ef, 2, c->stream));
-    }
-    HIPCHK(hipMemcpyAsync(o->ex, x_host, o->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    QnQuadArgs a{};
-    a.Q = o->Q; a.T = o->T; a.x = o->ex; a.d = o->ex; a.xt = o->ex + np;
-    a.out = o->eq + (size_t)c->rank * o->T.rpr;
-    a.ctl = nullptr; a.expect_phase = -1; a.force_kind = QN_REQ_X; a.force_t = 0.0;
-    QNCHK(launch_quad_R(8, c->stream, a));
-    QNCHK(exchange(c, o->eq, (size_t)o->T.rpr));
-    QnVecs V{};
-    V.q = o->eq; V.xt = o->ex + np; V.b = o->b; V.n = (int)o->n; V.n_pad = (int)np; V.rpr = o->T.rpr; V.world = c->world; V.qcs = 1; V.hcs = 1;
-    hipLaunchKernelGGL(quad_finish_kernel, dim3(1), dim3(QN_CTL_TPB), 0, c->stream, V, o->ef, o->eg);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(f, o->ef, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(g_host, o->eg, o->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return QN_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// solver
-// ------------------------------------------------------------------------------------------------
-enum { KC_HPASS = 0, KC_EVAL = 1, KC_CTL = 2, KC_COMM = 3, KC_HREDUCE = 4, KC_EREDUCE = 5, KC_NEWTON = 6 };
-struct TimedEvent { hipEvent_t a, b; int cls; };
-
-struct qn_solver {
-    qn_context* ctx = nullptr;
-    int method = QN_BFGS;
-    size_t n = 0;
-    double tol = 0.0;
-    QnTile T{};
-    int R = 4, U = 1, hcs = 1, qcs = 1; // row tile, chunks per trip (fused kernels), column splits
-    double* H = nullptr;
-    double* vec_block = nullptr; // one allocation holding all n_pad vectors
-    QnVecs V{};
-    double* f_dev = nullptr;
-    // Newton: Hessian work matrix (row-major, ld = nw), right-hand sides, staging for host Hessians, failure flag
-    double *newton_w = nullptr, *newton_x = nullptr, *newton_hsrc = nullptr, *newton_invl = nullptr, *newton_inv2 = nullptr;
-    bool newton_big = false;
-    // symmetric-storage fast path (qn_sym.hip.h): slot buffer, tile count per side, opt-out, "user installed a non-symmetric H"
-    double* sym_part = nullptr;
-    int sym_nb = 0;
-    bool no_sym = false, h_nonsym = false;
-    bool h_lower_stale = false; // a symmetric-storage run is (or was) updating the upper block triangle only
-    double *symsh_xg = nullptr, *symsh_gath = nullptr; // row-sharded symmetric storage: gathered partial sums [world][2][n_pad]; mirror staging
-    bool h_diag_stale = false;  // ... and (second-generation kernels) only the upper triangle of 16 x 16 sub-blocks inside the diagonal tiles
-    // second-generation symmetric path (qn_sym2.hip.h): static work lists, per-workgroup scalars, double-buffered control block
-    int* s2_items = nullptr;
-    int s2_G = 0, s2_nb = 0, s2_maxk = 0, s2_inorder = 0;
-    int s2_sl_first = 0, s2_sl_per = 0, s2_sl_cfg = -1; // row slivers (QnS2Args.sl_first / sl_per); the switches the lists were built for
-    bool no_sliver = false;    // diagnostics: sym2 without row slivers (round 2's work lists)
-    bool no_pair = false;      // diagnostics: the general evaluation kernel where the two-items-and-a-sliver instance would run
-    int ring = (getenv("QN_S2_RING") && atoi(getenv("QN_S2_RING")) == 0) ? 0 : 1; // the pair instance's evaluation as mover + multiplier waves (qn_sym2r.hip.h); QN_OPT_EVAL_MOVER_MULTIPLIER
-    bool tred = false;         // measurement: the update-reduce in the tail of the update-tile launch (s2_hpass_kernel<.., TRED>: bit-identical, slower)
-    int* s2_cnt = nullptr;     // tail reduce: arrival counters of the block-rows
-    int gen_slots_hint = 0;    // generic pipelined path: evaluation slots per period the last batch needed (0: none run yet)
-    double* s2_gws = nullptr;  // row-sharded log-sum-exp (qn_sym2g.hip.h): the ranks' weights and S of the last evaluation consumed
-    double* s2_wgV = nullptr;  // generic objectives: the second table of per-workgroup sums (QnS2Args.wgV)
-    hipGraphExec_t s2_graph_exec = nullptr; // measurement (QN_S2_GRAPH): two periods of the pipelined pattern as one graph, and what it was captured for
-    QnS2Args s2_graph_args{}; int s2_graph_slots = 0, s2_graph_bnd = 0; uint64_t s2_graph_len = 0, s2_graph_stat = 0;
-    int last_ls_kind = -1; std::vector<double> last_ls_box; bool ls_box_changed = false; // the line search (kind, box) of the last qn_minimize call: see minimize_impl
-    double mtb_cand_keep = INFINITY; // bounded second-generation runs: the step to the box of the direction a warm call continues with
-    bool no_s2bnd = false;     // tests: bounded runs keep the generic path (QN_OPT_BOUNDED_SECOND_GENERATION 0)
-    bool h_sliver_whole = false; // the diagonal tiles that sliver rows read are complete (both triangles): kept so by sliver-mode update passes
-    double* s2_evS = nullptr;   // row-sharded: [2][world][QN_S2SH_NEC][QN_S2_MAXG] the ranks' evaluation scalars, by launch parity (QnS2Args.evS)
-    int *s2_sl_off = nullptr, *s2_sl_idx = nullptr; // row-sharded: per block-row, the slots this rank's tiles write (QnS2Args.sl_off / sl_idx)
-    int s2_sl_nb = 0;
-    bool h_placed = false;      // H's placement has been measured (place_h)
-    int* symsh_tiles = nullptr; // row-sharded, first-generation kernels: this rank's tiles in launch order (QnSymShard.tiles)
-    int s2_slots_hint = 0;      // row-sharded, pipelined: evaluation launches (each followed by a collective) enqueued per period
-    double* s2_partE = nullptr; // [nb][nb][128]: row / column slots of the last evaluation (QnS2Args.partE)
-    double* s2_wgS = nullptr; // [2][s2_trows][QN_S2_ROW]: the sums a servicing launch leaves for the next launch's prologue, by launch parity
-    int s2_trows = 0;
-    QnCtl* s2_ctl = nullptr;
-    bool no_sym2 = false; // diagnostics: the first-generation tile kernels (qn_sym.hip.h)
-    bool fold = false; // sym2 with the accept-reduce folded into the update-tile launch (four launches per iteration instead of five).
-                       // OFF by default -- measured, rocprofv3 averages, n = 4096, same box: the accept-reduce launch (6.7 us) goes, the
-                       // update-tile launch gets 5 us longer (every workgroup sums the slots of its own six blocks: 48 MB of L2 reads
-                       // instead of 1 MB, and the prologue there is the long run of the machine) and the update-reduce 2.4 us (its
-                       // prologue now runs the machine): 80.3 against 79.4 us per iteration.
-    // After a fused run the iterate and the pending update's vectors stay where the fused kernels keep them (X0[xc], S0[sc], UN);
-    // they are copied back to the canonical buffers only when something other than the next fused run wants them.
-    bool fused_live = false;
-    // the previous qn_minimize ended on the iteration cap of a fused, memoised run on the objective with this serial (0: none);
-    // nothing has touched the state since.  A serial, not the pointer: destroy A, create B of the same size and the allocator
-    // hands the address back -- the run on B would have inherited f, g and the lazy direction of A.
-    uint64_t warm_obj = 0;
-    int* newton_fail = nullptr; // [0]: the factorisation met a bad pivot, [1]: the staged Hessian is not symmetric bit for bit
-    int *newton_piv = nullptr, *newton_perm = nullptr; // LU fallback (qn_lu.hip.h): pivot rows, row permutation
-    double* newton_panel = nullptr; // ... and the column-major copy of the 64-column panel being factorised
-    bool newton_lu_percol = false;  // diagnostics: the panel factorisation with two launches per column (rounds 1-2)
-    std::vector<int> newton_piv_host;
-    uint64_t newton_lu_runs = 0, newton_chol_runs = 0;
-    int newton_lu_force_timeout = 0; // diagnostics (QN_OPT_LU_FORCE_WAIT_EXPIRY): the one-launch kernels' waits give up at once (exercises the fallback)
-    int newton_lu_no_persist = 0; // diagnostics (QN_OPT_LU_ONE_LAUNCH_PANEL 0), or set after a bounded wait of the one-launch panel gave up: one launch per sub-panel
-    int* newton_sync = nullptr;   // the one-launch panel's counters (qn_lu.hip.h, lu_panel_persist_kernel)
-    uint64_t newton_lu_sync_timeouts = 0;
-    int newton_lu_timeout_fallback = 0; // newton_lu_no_persist was set by an expired wait (not by the diagnostics switch): how many factorisations have run launch by launch since
-    int newton_lu_no_la = 0; // diagnostics (QN_OPT_LU_LOOKAHEAD 0): the LU without the look-ahead on a second stream
-    int newton_force_lu = 0; // diagnostics (QN_OPT_NEWTON_PIVOTED_LU): skip the Cholesky attempt
-    size_t newton_n64 = 0;
-    std::vector<double> newton_hhost;
-    double* bounds_block = nullptr; // lb, ub (solver), llb, lub (bounded line search): 4 n_pad vectors
-    int bounded = 0;
-    double* fused_block = nullptr; // X0[2], S0[2], G, GT, Y, UN, UP, VV (10 n_pad vectors)
-    double *fused_evp = nullptr, *fused_hpp = nullptr;
-    int fused_nblk = 0;
-    QnCtl* ctl = nullptr;  // device
-    QnCtl* hctl = nullptr; // pinned host mirror
-    QnCtl* hrep = nullptr; // pinned: the control block as the last launch of a sym2 batch left it (written by the device)
-    unsigned long long* hrep_flag = nullptr;
-    unsigned long long rep_seq = 0;
-    double *hx = nullptr, *hg = nullptr; // pinned staging for host oracles
-    size_t trace_cap = 0;
-    int trace_x = 0;
-    int sync_mode = -1; // -1 auto
-    int no_fused = 0;   // diagnostics: force the generic (non-fused) path
-    int no_defer = 0;   // diagnostics: fused path without the deferred update step
-    int profiling = 0;
-    std::vector<TimedEvent> events;
-    std::vector<hipEvent_t> event_pool;
-    qn_stats stats{};
-};
-
-static hipEvent_t ev_get(qn_solver* s) {
-    if (!s->event_pool.empty()) { hipEvent_t e = s->event_pool.back(); s->event_pool.pop_back(); return e; }
-    hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
-    return e;
-}
-struct ProfScope { // brackets one launch (or one exchange) with events when profiling is on
-    qn_solver* s; int cls; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(qn_solver* s_, int cls_) : s(s_), cls(cls_) {
-        if (s->profiling && s->events.size() < 200000) { a = ev_get(s); b = ev_get(s); (void)hipEventRecord(a, s->ctx->stream); }
-    }
-    ~ProfScope() { if (a) { (void)hipEventRecord(b, s->ctx->stream); s->events.push_back({a, b, cls}); } }
-};
-static void prof_collect(qn_solver* s) {
-    if (s->events.empty()) return;
-    (void)hipStreamSynchronize(s->ctx->stream);
-    // In pipelined mode the launch pattern runs ahead of the decisions, so some bracketed launches found their request not
-    // pending and returned from the prologue (a few microseconds).  They are not work: a class's sums take only the launches
-    // that lasted more than half of one of its LONGEST launches (in synchronous mode every launch is real and passes; a median-based
-    // floor failed when most of a class's launches were skipped -- backtracking's four slots per period, a run that ends early in a
-    // batch).  "One of the longest" = the (n / 50 + 1)-th longest: a single outlier twice the typical duration (a cold first launch,
-    // a co-tenant's preemption) would otherwise set a floor that discards every genuine launch.
-    std::vector<std::vector<float>> dur(8);
-    std::vector<std::pair<int, float>> all;
-    all.reserve(s->events.size());
-    for (auto& e : s->events) {
-        float ms = 0.f;
-        const bool ok = hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess;
-        const int cls = (e.cls >= 0 && e.cls < 7) ? e.cls : 7;
-        if (ok) { dur[cls].push_back(ms); all.push_back({e.cls, ms}); }
-        s->event_pool.push_back(e.a);
-        s->event_pool.push_back(e.b);
-    }
-    float floor_ms[8];
-    for (int c = 0; c < 8; ++c) {
-        floor_ms[c] = 0.f;
-        if (dur[c].size() >= 8) {
-            const size_t kth = dur[c].size() / 50; // 0: the maximum
-            std::nth_element(dur[c].begin(), dur[c].begin() + kth, dur[c].end(), std::greater<float>());
-            floor_ms[c] = 0.5f * dur[c][kth];
-        }
-    }
-    for (auto& e : all) {
-        const int cls = (e.first >= 0 && e.first < 7) ? e.first : 7;
-        const float ms = e.second;
-        if (ms < floor_ms[cls]) continue;
-        switch (e.first) {
-        case KC_HPASS: s->stats.t_hpass_ms += ms; s->stats.n_hpass_timed++; break;
-        case KC_EVAL: s->stats.t_eval_ms += ms; s->stats.n_eval_timed++; break;
-        case KC_CTL: s->stats.t_ctl_ms += ms; s->stats.n_ctl_timed++; break;
-        case KC_HREDUCE: s->stats.t_hreduce_ms += ms; s->stats.n_hreduce_timed++; break;
-        case KC_EREDUCE: s->stats.t_ereduce_ms += ms; s->stats.n_ereduce_timed++; break;
-        case KC_NEWTON: s->stats.t_newton_ms += ms; s->stats.n_newton_timed++; break;
-        default: s->stats.t_comm_ms += ms; s->stats.n_comm_timed++; break;
-        }
-    }
-    s->events.clear();
-}
-
-// buffers of the fused fast path (allocated on first use; partial buffers depend on the row tile R)
-static int solver_alloc_fused(qn_solver* s, bool sym) {
-    const size_t np = s->T.n_pad;
-    hipStream_t st = s->ctx->stream;
-    if (!s->fused_block) QNCHK(dev_alloc_zero(&s->fused_block, 10 * np, st));
-    const int nblk = sym ? (int)(np / QN_TB) : s->T.rpr / s->R; // partial-sum rows: 128-row blocks or R-row workgroups
-    if (sym && s->sym_nb != nblk) {
-        if (s->sym_part) { HIPCHK(hipFree(s->sym_part)); s->sym_part = nullptr; }
-        QNCHK(dev_alloc_zero(&s->sym_part, (size_t)nblk * nblk * 2 * QN_TB, st));
-        s->sym_nb = nblk;
-    }
-    if (nblk != s->fused_nblk) {
-        if (s->fused_evp) { HIPCHK(hipFree(s->fused_evp)); s->fused_evp = nullptr; }
-        if (s->fused_hpp) { HIPCHK(hipFree(s->fused_hpp)); s->fused_hpp = nullptr; }
-        QNCHK(dev_alloc_zero(&s->fused_evp, (size_t)s->ctx->world * QN_NEVP * nblk, st));
-        QNCHK(dev_alloc_zero(&s->fused_hpp, (size_t)s->ctx->world * QN_NHPP * nblk, st));
-        s->fused_nblk = nblk;
-    }
-    double* p = s->fused_block;
-    QnFused& F = s->V.F;
-    F.X0 = p; F.S0 = p + 2 * np; F.G = p + 4 * np; F.GT = p + 5 * np; F.Y = p + 6 * np;
-    F.UN = p + 7 * np; F.UP = p + 8 * np; F.VV = p + 9 * np;
-    F.evp = s->fused_evp; F.hpp = s->fused_hpp;
-    F.nblk = nblk;
-    return QN_OK;
-}
-
-// Row-sharded symmetric storage (both generations of kernels): per block-row R, the slots this rank's tiles write -- R's own
-// window (row parts; a diagonal tile's single slot) and the column parts of the local block-rows whose windows contain R.  Every
-// unordered pair of block-rows is owned once, so no slot appears twice; ascending order = the summation order of the rank's share.
-static int solver_alloc_symsh_lists(qn_solver* s) {
-    const int nb = s->T.n_pad / QN_TB;
-    if (s->s2_sl_off && s->s2_sl_nb == nb) return QN_OK;
-    (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx); (void)hipFree(s->symsh_tiles);
-    s->s2_sl_off = nullptr; s->s2_sl_idx = nullptr; s->symsh_tiles = nullptr;
-    const int nbl = s->T.rpr / QN_TB, ioff = s->ctx->rank * nbl;
-    {
-        std::vector<int> tiles;
-        for (int il = 0; il < nbl; ++il)
-            for (int k = 0, I = ioff + il; k < qn_symsh_cnt(I, nb); ++k) tiles.push_back((I << 16) | ((I + k) % nb));
-        if (tiles.empty()) tiles.push_back(0);
-        HIPCHK(hipMalloc((void**)&s->symsh_tiles, tiles.size() * sizeof(int)));
-        HIPCHK(hipMemcpy(s->symsh_tiles, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
-    }
-    std::vector<int> off(nb + 1, 0), idx;
-    for (int R = 0; R < nb; ++R) {
-        const bool r_local = R >= ioff && R < ioff + nbl;
-        for (int t = 0; t < nb; ++t) {
-            const bool t_local = t >= ioff && t < ioff + nbl;
-            if ((r_local && qn_symsh_owns(R, t, nb)) || (t_local && t != R && qn_symsh_owns(t, R, nb))) idx.push_back(t);
-        }
-        off[R + 1] = (int)idx.size();
-    }
-    if (idx.empty()) idx.push_back(0);
-    HIPCHK(hipMalloc((void**)&s->s2_sl_off, off.size() * sizeof(int)));
-    HIPCHK(hipMalloc((void**)&s->s2_sl_idx, idx.size() * sizeof(int)));
-    HIPCHK(hipMemcpy(s->s2_sl_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->s2_sl_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
-    s->s2_sl_nb = nb;
-    return QN_OK;
-}
-
-// sym2: work items (off-diagonal tiles cost 1, diagonal tiles -- upper triangle only -- 0.5625), assigned to min(items, 256)
-// workgroups by longest-processing-time-first so that every workgroup streams the same number of bytes to within one tile.
-// Row-sharded runs: the items are the tiles of the rank's circulant windows (qn_sym.hip.h), the grid is the same on every rank
-// (the ranks' per-workgroup scalars are exchanged as rows of one table), and the rank gets the list of slots its tiles write.
-static int solver_alloc_sym2(qn_solver* s) {
-    const int nb = s->T.n_pad / QN_TB;
-    hipStream_t st = s->ctx->stream;
-    const int world = s->ctx->world, rank = s->ctx->rank;
-    const bool sharded = world > 1;
-    const int cfg = (s->fold ? 1 : 0) | (s->no_sliver ? 2 : 0) | (sharded ? 4 : 0);
-    if (s->s2_nb != nb || s->s2_sl_cfg != cfg) {
-        (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE);
-        if (s->s2_graph_exec) { (void)hipGraphExecDestroy(s->s2_graph_exec); s->s2_graph_exec = nullptr; } // (the pointer dangled -- a matching memcmp launched it again)
-    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_cnt);
-        s->s2_items = nullptr; s->s2_wgS = nullptr; s->s2_partE = nullptr;
-        s->s2_evS = nullptr; s->s2_cnt = nullptr;
-        s->s2_nb = 0;
-        const int nbl = s->T.rpr / QN_TB, ioff = rank * nbl; // (sharded: this rank's block-rows)
-        int nitems = nb * (nb + 1) / 2;
-        int G = std::min(nitems, QN_S2_MAXG);
-        if (sharded) {
-            // every rank launches the same grid: the smallest share of tiles bounds it (each workgroup has at least one item)
-            nitems = qn_symsh_ntiles(nb, nbl, ioff);
-            int least = nitems;
-            for (int r = 0; r < world; ++r) least = std::min(least, qn_symsh_ntiles(nb, nbl, r * nbl));
-            G = std::min(least, QN_S2_MAXG);
-            if (G < 1) return fail(QN_ABNORMAL_TERMINATION, "sym2: a rank without tiles");
-        }
-        std::vector<std::vector<int>> lists;
-        int inorder = 0;
-        // deals the items to G lists; L: the last L diagonal tiles stay off the lists (row slivers)
-        auto deal = [&](int L) {
-            lists.assign(G, std::vector<int>());
-            std::vector<std::pair<double, int>> heap; // (-load, workgroup): max-heap on the least loaded
-            for (int g = 0; g < G; ++g) heap.push_back({0.0, -g});
-            std::make_heap(heap.begin(), heap.end());
-            auto give = [&](int I, int J, double cost) {
-                std::pop_heap(heap.begin(), heap.end());
-                auto e = heap.back();
-                lists[-e.second].push_back((I << 16) | J);
-                e.first -= cost;
-                heap.back() = e;
-                std::push_heap(heap.begin(), heap.end());
-            };
-            if (sharded) { // the windows' off-diagonal tiles in window order, then the diagonal ones (the cheap items last)
-                inorder = 0; // (the kernels read every item from the list: qn_s2_first_item_of)
-                for (int il = 0; il < nbl; ++il) {
-                    const int I = ioff + il, cnt = qn_symsh_cnt(I, nb);
-                    for (int k = 1; k < cnt; ++k) give(I, (I + k) % nb, 1.0);
-                }
-                for (int il = 0; il < nbl; ++il) give(ioff + il, ioff + il, 0.5625);
-                return;
-            }
-            // the first min(2 G, items) items go out in order -- item t to workgroup t mod G -- so the kernels compute a workgroup's
-            // first two items from its index (qn_s2_item_of_index); the rest to whoever has streamed least so far
-            inorder = std::min(nitems - L, 2 * G);
-            std::vector<double> load0(G, 0.0);
-            int handed = 0;
-            auto hand = [&](int I, int J, double cost) {
-                if (handed < inorder) {
-                    lists[handed % G].push_back((I << 16) | J);
-                    load0[handed % G] += cost;
-                    ++handed;
-                    if (handed == inorder) {
-                        for (auto& e : heap) e.first = -load0[-e.second];
-                        std::make_heap(heap.begin(), heap.end());
-                    }
-                } else {
-                    give(I, J, cost);
-                }
-            };
-            for (int I = 0; I < nb; ++I)
-                for (int J = I + 1; J < nb; ++J) hand(I, J, 1.0);
-            for (int I = 0; I < nb - L; ++I) hand(I, I, 0.5625);
-        };
-        // Row slivers (qn_sym2.hip.h, qn_s2_eval_sliver): when the tiles do not deal out evenly and the L left over can be cut into
-        // one 8-row sliver per workgroup (16 L = G: n = 4096 on 256 workgroups), the last L diagonal tiles leave the work lists.
-        // The kernels take the sliver in the place of a last, odd item: EVERY list must then have the same, even length -- true
-        // when all items go out in order (n = 4096), not in general once the heap deals a tail of mixed costs (nb = 991
-        // passed the arithmetic test with lists of different, odd lengths -- the sliver of such a workgroup was never evaluated).
-        // So the lists are checked after the deal, and dealt again without slivers if they are not uniform.
-        int L = (!sharded && nitems > G) ? nitems % G : 0;
-        if (!(L > 0 && 16 * L == G && L <= nb && ((nitems - L) / G) % 2 == 0 && !s->fold && !s->no_sliver)) L = 0;
-        deal(L);
-        if (L) {
-            bool uniform = true;
-            for (int g = 0; g < G; ++g) uniform = uniform && lists[g].size() == lists[0].size() && lists[g].size() % 2 == 0;
-            if (!uniform) { L = 0; deal(0); }
-        }
-        s->s2_sl_first = nb - L;
-        s->s2_sl_per = L ? G / L : 0;
-        if (s->s2_sl_per != 0 && (G % L != 0 || s->s2_sl_per != 16)) return fail(QN_ABNORMAL_TERMINATION, "sym2: row slivers do not tile the grid");
-        s->s2_sl_cfg = cfg;
-        size_t maxk = 0;
-        for (int g = 0; g < G; ++g) maxk = std::max(maxk, lists[g].size());
-        for (int g = 0; g < G; ++g)
-            if (lists[g].empty()) return fail(QN_ABNORMAL_TERMINATION, "sym2: a workgroup without items");
-        std::vector<int> items(maxk * (size_t)G, -1); // [k][g]: the workgroup's k-th item; -1 ends its list
-        for (int g = 0; g < G; ++g)
-            for (size_t k = 0; k < lists[g].size(); ++k) items[k * (size_t)G + g] = lists[g][k];
-        HIPCHK(hipMalloc((void**)&s->s2_items, items.size() * sizeof(int)));
-        HIPCHK(hipMemcpy(s->s2_items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
-        s->s2_maxk = (int)maxk;
-        s->s2_inorder = inorder;
-        s->s2_trows = std::max(QN_S2_MAXG, (nb + 63) / 64 * 64);
-        QNCHK(dev_alloc_zero(&s->s2_wgS, (size_t)2 * s->s2_trows * QN_S2_ROW, st));
-        (void)hipFree(s->s2_wgV); s->s2_wgV = nullptr; // (the generic objectives' second table: allocated by the runs that use it)
-        QNCHK(dev_alloc_zero(&s->s2_partE, (size_t)nb * nb * QN_TB, st));
-        if (sharded) {
-            QNCHK(dev_alloc_zero(&s->s2_evS, (size_t)2 * world * QN_S2SH_NEC * QN_S2_MAXG, st));
-        }
-
-        s->s2_G = G;
-        s->s2_nb = nb;
-    }
-    if (!s->s2_ctl) {
-        HIPCHK(hipMalloc((void**)&s->s2_ctl, 2 * sizeof(QnCtl)));
-        HIPCHK(hipMemsetAsync(s->s2_ctl, 0, 2 * sizeof(QnCtl), st));
-    }
-    return QN_OK;
-}
-
-static int solver_alloc_hp(qn_solver* s) {
-    if (s->V.hp) { HIPCHK(hipFree(s->V.hp)); s->V.hp = nullptr; }
-    if (s->V.q) { HIPCHK(hipFree(s->V.q)); s->V.q = nullptr; }
-    QNCHK(dev_alloc_zero(&s->V.hp, (size_t)s->ctx->world * s->hcs * 2 * s->T.rpr, s->ctx->stream));
-    QNCHK(dev_alloc_zero(&s->V.q, (size_t)s->ctx->world * s->qcs * s->T.rpr, s->ctx->stream));
-    s->V.hcs = s->hcs;
-    s->V.qcs = s->qcs;
-    return QN_OK;
-}
-
-extern "C" int qn_solver_create(qn_context* ctx, int method, double tol, const double* x0_host, size_t n, qn_solver** out) {
-    if (!ctx || !x0_host || !out || n == 0) return fail(QN_ERROR_INPUT_PARAMS, "null argument or n == 0");
-    if (method != QN_BFGS && method != QN_DFP && method != QN_GRADIENT_DESCENT && method != QN_NEWTON && method != QN_SR1)
-        return fail(QN_ERROR_INPUT_PARAMS, "unknown method");
-    if (n > (size_t)1 << 30) return fail(QN_ERROR_INPUT_PARAMS, "n too large");
-    HIPCHK(hipSetDevice(ctx->device));
-    qn_solver* s = new qn_solver();
-    *out = s;
-    s->ctx = ctx; s->method = method; s->n = n; s->tol = tol;
-    s->T = make_tile(n, ctx, 1);
-    // row tile: 4 rows per workgroup keeps 4 workgroups per CU busy at n = 4096; at large n the per-workgroup partial
-    // sums read by the control step dominate its latency, so use 8 (measured: profiles/r01_c_tiling_sweep.txt)
-    s->R = (s->T.rpr >= 16384 / ctx->world && n >= 16384) ? 8 : 4;
-    s->U = (n >= 16384) ? 2 : 1; // column chunks per loop trip of the fused kernels
-    const size_t np = s->T.n_pad;
-    hipStream_t st = ctx->stream;
-    if (method == QN_BFGS || method == QN_DFP || method == QN_SR1) {
-        QNCHK(dev_alloc_zero(&s->H, (size_t)s->T.rpr * np, st));
-        hipLaunchKernelGGL(identity_fill_kernel, dim3(2048), dim3(256), 0, st, s->H, s->T); // bfgs.rs:27-39: H = I
-        HIPCHK(hipGetLastError());
-    }
-    QNCHK(dev_alloc_zero(&s->vec_block, 9 * np, st));
-    double* p = s->vec_block;
-    s->V.x = p; s->V.g = p + np; s->V.d = p + 2 * np; s->V.xt = p + 3 * np; s->V.gt = p + 4 * np;
-    s->V.s = p + 5 * np; s->V.y = p + 6 * np; s->V.sp = p + 7 * np; s->V.up = p + 8 * np;
-    s->V.n = (int)n; s->V.n_pad = (int)np; s->V.rpr = s->T.rpr; s->V.world = ctx->world;
-    s->V.H = s->H;
-    QNCHK(solver_alloc_hp(s));
-    QNCHK(dev_alloc_zero(&s->f_dev, 2, st));
-    s->V.f_dev = s->f_dev;
-    HIPCHK(hipMalloc((void**)&s->ctl, sizeof(QnCtl)));
-    HIPCHK(hipMemsetAsync(s->ctl, 0, sizeof(QnCtl), st));
-    // (mapped + coherent, explicitly: s2_ctl_upload_kernel reads the mirror from the device, call after call -- with a non-coherent
-    // mapping the second call could be served a stale line from L2)
-    HIPCHK(hipHostMalloc((void**)&s->hctl, 2 * sizeof(QnCtl) + 64, hipHostMallocMapped | hipHostMallocCoherent));
-    memset(s->hctl, 0, 2 * sizeof(QnCtl) + 64);
-    s->hrep = s->hctl + 1;                                                    // what a batch's last launch reports (QnS2Args.rep)
-    s->hrep_flag = reinterpret_cast<unsigned long long*>(s->hctl + 2);        // ... and the sequence number it stores behind it
-    HIPCHK(hipHostMalloc((void**)&s->hx, n * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&s->hg, (n + 1) * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipMemcpyAsync(s->V.x, x0_host, n * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
-    return QN_OK;
-}
-
-extern "C" void qn_solver_destroy(qn_solver* s) {
-    if (!s) return;
-    (void)hipSetDevice(s->ctx->device);
-    (void)hipStreamSynchronize(s->ctx->stream);
-    for (auto& e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    for (auto& e : s->event_pool) (void)hipEventDestroy(e);
-    if (s->s2_graph_exec) (void)hipGraphExecDestroy(s->s2_graph_exec);
-    (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
-    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->symsh_xg); (void)hipFree(s->symsh_gath); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm); (void)hipFree(s->newton_panel); (void)hipFree(s->newton_sync);
-    (void)hipFree(s->bounds_block);
-    (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
-    (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE); (void)hipFree(s->s2_ctl);
-    (void)hipFree(s->s2_evS); (void)hipFree(s->s2_cnt); (void)hipFree(s->s2_gws); (void)hipFree(s->s2_wgV); (void)hipFree(s->s2_sl_off); (void)hipFree(s->s2_sl_idx); (void)hipFree(s->symsh_tiles);
-    (void)hipFree(s->f_dev); (void)hipFree(s->ctl); (void)hipFree(s->V.trace); (void)hipFree(s->V.xtrace);
-    (void)hipHostFree(s->hctl); (void)hipHostFree(s->hx); (void)hipHostFree(s->hg);
-    delete s;
-}
-
-extern "C" int qn_solver_set_trace(qn_solver* s, size_t cap, int with_x) {
-    HIPCHK(hipSetDevice(s->ctx->device));
-    if (s->V.trace) { HIPCHK(hipFree(s->V.trace)); s->V.trace = nullptr; }
-    if (s->V.xtrace) { HIPCHK(hipFree(s->V.xtrace)); s->V.xtrace = nullptr; }
-    s->trace_cap = cap;
-    s->trace_x = with_x && cap;
-    if (cap) {
-        HIPCHK(hipMalloc((void**)&s->V.trace, cap * sizeof(QnTraceRec)));
-        HIPCHK(hipMemset(s->V.trace, 0, cap * sizeof(QnTraceRec)));
-        if (with_x) QNCHK(dev_alloc_zero(&s->V.xtrace, cap * s->n, s->ctx->stream));
-    }
-    return QN_OK;
-}
-
-extern "C" int qn_solver_get_trace(qn_solver* s, qn_trace_rec* out_host, size_t cap, size_t* len, double* x_trace_host) {
-    HIPCHK(hipSetDevice(s->ctx->device));
-    size_t m = std::min<size_t>(std::min(cap, s->trace_cap), (size_t)s->hctl->n_iterations);
-    if (len) *len = m;
-    static_assert(sizeof(qn_trace_rec) == sizeof(QnTraceRec), "trace record layout");
-    if (m && out_host) HIPCHK(hipMemcpy(out_host, s->V.trace, m * sizeof(QnTraceRec), hipMemcpyDeviceToHost));
-    if (m && x_trace_host && s->V.xtrace) HIPCHK(hipMemcpy(x_trace_host, s->V.xtrace, m * s->n * sizeof(double), hipMemcpyDeviceToHost));
-    return QN_OK;
-}
-
-#if defined(QN_CTL_STAMPS) || defined(QN_S2_STAMPS)
-extern "C" int qn_debug_stamps(qn_solver* s, unsigned long long* out, size_t count) { // diagnostic build only
-    HIPCHK(hipSetDevice(s->ctx->device));
-    if (!s->V.dbg) {
-        HIPCHK(hipMalloc((void**)&s->V.dbg, (1 << 20) * 8));
-        HIPCHK(hipMemset(s->V.dbg, 0, (1 << 20) * 8));
-        return QN_OK;
-    }
-    HIPCHK(hipStreamSynchronize(s->ctx->stream));
-    HIPCHK(hipMemcpy(out, s->V.dbg, count * 8, hipMemcpyDeviceToHost));
-    return QN_OK;
-}
-#endif
-
-#ifdef QN_LU_STAMPS
-extern "C" int qn_debug_lu_stamps(unsigned long long* out) { // diagnostic build: the stamps of the LAST panel's step launches
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(qn_lu_dbg), sizeof(unsigned long long) * 64 * 16));
-    return QN_OK;
-}
-#endif
-extern "C" int qn_solver_set_profiling(qn_solver* s, int on) { s->profiling = on; return QN_OK; }
-extern "C" int qn_solver_set_sync_mode(qn_solver* s, int sync) { s->sync_mode = sync; return QN_OK; }
-// Named options (ABI 5): what rounds 1-5 selected through negative `rows_per_block` codes of qn_solver_set_tiling.  Every option
-// SETS a state (value != 0: on), none toggles; the defaults are in include/qn_hip.h.
-extern "C" int qn_solver_set_option(qn_solver* s, int option, int value) {
-    if (!s) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
-    const bool on = value != 0;
-    switch (option) {
-    case QN_OPT_GENERIC_KERNELS: s->no_fused = on ? 1 : 0; return QN_OK;
-    case QN_OPT_DEFERRED_UPDATE_STEP: s->no_defer = on ? 0 : 1; return QN_OK;
-    case QN_OPT_SYMMETRIC_STORAGE: s->no_sym = on ? 0 : 1; return QN_OK;
-    case QN_OPT_SECOND_GENERATION: s->no_sym2 = on ? 0 : 1; return QN_OK;
-    case QN_OPT_FOLDED_ACCEPT_REDUCE: s->fold = on ? 1 : 0; return QN_OK;
-    case QN_OPT_ROW_SLIVERS: s->no_sliver = !on; return QN_OK;
-    case QN_OPT_EVAL_PAIR_INSTANCE: s->no_pair = !on; return QN_OK;
-    case QN_OPT_EVAL_MOVER_MULTIPLIER: s->ring = on ? 1 : 0; return QN_OK;
-    case QN_OPT_TAIL_REDUCE: s->tred = on; return QN_OK;
-    case QN_OPT_BOUNDED_SECOND_GENERATION: s->no_s2bnd = !on; return QN_OK;
-    case QN_OPT_NEWTON_PIVOTED_LU: s->newton_force_lu = on ? 1 : 0; return QN_OK;
-    case QN_OPT_LU_PER_COLUMN_PANEL: s->newton_lu_percol = on ? 1 : 0; return QN_OK;
-    case QN_OPT_LU_LOOKAHEAD: s->newton_lu_no_la = on ? 0 : 1; return QN_OK;
-    case QN_OPT_LU_ONE_LAUNCH_PANEL: s->newton_lu_no_persist = on ? 0 : 1; return QN_OK;
-    case QN_OPT_LU_FORCE_WAIT_EXPIRY: s->newton_lu_force_timeout = on ? 1 : 0; return QN_OK;
-    case QN_OPT_CHUNKS_PER_TRIP:
-        if (value != 1 && value != 2 && value != 4) return fail(QN_ERROR_INPUT_PARAMS, "chunks per trip must be 1, 2 or 4");
-        s->U = value;
-        return QN_OK;
-    default: return fail(QN_ERROR_INPUT_PARAMS, "unknown option");
-    }
-}
-
-// tuning only: rows per workgroup tile of the fused ROW kernels (2, 4, 8 or 16) and column splits (1 .. 64); 0 keeps what is set
-extern "C" int qn_solver_set_tiling(qn_solver* s, int rows_per_block, int col_splits) {
-    if (!s) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
-    if (rows_per_block != 0 && rows_per_block != 2 && rows_per_block != 4 && rows_per_block != 8 && rows_per_block != 16)
-        return fail(QN_ERROR_INPUT_PARAMS, "rows_per_block must be 2, 4, 8 or 16 (diagnostics are named options: qn_solver_set_option)");
-    if (col_splits < 0 || col_splits > 64) return fail(QN_ERROR_INPUT_PARAMS, "col_splits out of range");
-    HIPCHK(hipSetDevice(s->ctx->device));
-    if (rows_per_block) s->R = rows_per_block;
-    if (col_splits) { s->hcs = col_splits; s->qcs = col_splits; }
-    return solver_alloc_hp(s);
-}
-
-extern "C" size_t qn_solver_n(const qn_solver* s) { return s->n; }
-extern "C" size_t qn_solver_k(const qn_solver* s) { return (size_t)s->hctl->k; }
-extern "C" double qn_solver_tol(const qn_solver* s) { return s->tol; }
-
-// canonical buffers <- fused buffers (the lazy half of qn_minimize's export)
-static int fused_export(qn_solver* s) {
-    s->warm_obj = 0; // whoever asks for the canonical buffers may change them: the next call starts from scratch
-    if (!s->fused_live) return QN_OK;
-    qn_context* c = s->ctx;
-    const QnCtl* h = s->hctl;
-    const size_t np = s->T.n_pad, vb = np * sizeof(double);
-    HIPCHK(hipMemcpyAsync(s->V.x, s->V.F.X0 + (size_t)h->xc * np, vb, hipMemcpyDeviceToDevice, c->stream));
-    if (h->pending) {
-        HIPCHK(hipMemcpyAsync(s->V.sp, s->V.F.S0 + (size_t)h->sc * np, vb, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(s->V.up, s->V.F.UN, vb, hipMemcpyDeviceToDevice, c->stream));
-    }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    s->fused_live = false;
-    return QN_OK;
-}
-
-extern "C" int qn_solver_get_x(qn_solver* s, double* out) {
-    HIPCHK(hipSetDevice(s->ctx->device));
-    // (a getter: read the iterate where it lives, do not disturb a run that may be continued)
-    const double* src = s->fused_live ? s->V.F.X0 + (size_t)s->hctl->xc * (size_t)s->T.n_pad : s->V.x;
-    HIPCHK(hipMemcpyAsync(out, src, s->n * sizeof(double), hipMemcpyDeviceToHost, s->ctx->stream));
-    HIPCHK(hipStreamSynchronize(s->ctx->stream));
-    return QN_OK;
-}
-
-static int poke_ctl(qn_solver* s) { // host mirror -> device
-    HIPCHK(hipMemcpyAsync(s->ctl, s->hctl, sizeof(QnCtl), hipMemcpyHostToDevice, s->ctx->stream));
-    HIPCHK(hipStreamSynchronize(s->ctx->stream));
-    return QN_OK;
-}
-static int peek_ctl(qn_solver* s) { // device -> host mirror
-    HIPCHK(hipMemcpyAsync(s->hctl, s->ctl, sizeof(QnCtl), hipMemcpyDeviceToHost, s->ctx->stream));
-    HIPCHK(hipStreamSynchronize(s->ctx->stream));
-    s->stats.host_syncs++;
-    return QN_OK;
-}
-
-// box vectors live in one allocation: [lb | ub | llb | lub], padding -inf / +inf so padded entries never move
-static int bounds_alloc(qn_solver* s) {
-    if (s->bounds_block) return QN_OK;
-    const size_t np = s->T.n_pad;
-    HIPCHK(hipMalloc((void**)&s->bounds_block, 4 * np * sizeof(double)));
-    std::vector<double> init(4 * np);
-    for (size_t i = 0; i < np; ++i) { init[i] = -INFINITY; init[np + i] = INFINITY; init[2 * np + i] = -INFINITY; init[3 * np + i] = INFINITY; }
-    HIPCHK(hipMemcpy(s->bounds_block, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice));
-    s->V.lb = s->bounds_block; s->V.ub = s->bounds_block + np; s->V.llb = s->bounds_block + 2 * np; s->V.lub = s->bounds_block + 3 * np;
-    return QN_OK;
-}
-static int bounds_upload(qn_solver* s, double* dst, const double* src_host, double fill) {
-    std::vector<double> v(s->T.n_pad, fill);
-    if (src_host) memcpy(v.data(), src_host, s->n * sizeof(double));
-    HIPCHK(hipMemcpy(dst, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
-    return QN_OK;
-}
-
-extern "C" int qn_solver_set_bounds(qn_solver* s, const double* lb_host, const double* ub_host) { // BFGSB::new, bfgs_b.rs:43-63
-    if (!s || !lb_host || !ub_host) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
-    if (s->method != QN_BFGS && s->method != QN_DFP && s->method != QN_SR1) return fail(QN_ERROR_INPUT_PARAMS, "bounds need a BFGS / DFP / SR1 solver");
-    HIPCHK(hipSetDevice(s->ctx->device));
-    QNCHK(bounds_alloc(s));
-    QNCHK(bounds_upload(s, s->bounds_block, lb_host, -INFINITY));
-    QNCHK(bounds_upload(s, s->bounds_block + s->T.n_pad, ub_host, INFINITY));
-    std::vector<double> x(s->n);
-    QNCHK(qn_solver_get_x(s, x.data()));
-    for (size_t i = 0; i < s->n; ++i) x[i] = std::fmin(std::fmax(x[i], lb_host[i]), ub_host[i]); // x0.box_projection(&lower, &upper), :49
-    s->bounded = 1;
-    return qn_solver_set_x(s, x.data());
-}
-
-extern "C" int qn_solver_reset(qn_solver* s, const double* x0_host) {
-    if (!s || !x0_host) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
-    HIPCHK(hipSetDevice(s->ctx->device));
-    hipStream_t st = s->ctx->stream;
-    if (s->H) {
-        hipLaunchKernelGGL(identity_fill_kernel, dim3(2048), dim3(256), 0, st, s->H, s->T);
-        HIPCHK(hipGetLastError());
-        s->h_lower_stale = false; s->h_diag_stale = false;
-        s->h_nonsym = false;
-    }
-    s->fused_live = false; s->warm_obj = 0; // (whatever the fused buffers hold is dropped with the rest of the state)
-    HIPCHK(hipMemsetAsync(s->vec_block, 0, 9 * (size_t)s->T.n_pad * sizeof(double), st));
-    HIPCHK(hipMemcpyAsync(s->V.x, x0_host, s->n * sizeof(double), hipMemcpyHostToDevice, st));
-    memset(s->hctl, 0, sizeof(QnCtl));
-    return poke_ctl(s);
-}
-
-extern "C" int qn_solver_set_k(qn_solver* s, size_t k) { // k_mut() (bfgs.rs:58-63); minimize() resets it to 0 itself (ls_solver.rs:74-76)
-    if (!s) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
-    s->hctl->k = (int64_t)k;
-    return poke_ctl(s);
-}
-extern "C" int qn_solver_set_x(qn_solver* s, const double* x_host) {
-    HIPCHK(hipSetDevice(s->ctx->device));
-    QNCHK(fused_export(s));
-    HIPCHK(hipMemcpyAsync(s->V.x, x_host, s->n * sizeof(double), hipMemcpyHostToDevice, s->ctx->stream));
-    s->hctl->have_cur_eval = 0; s->hctl->have_dir = 0; s->hctl->last_valid = 0;
-    return poke_ctl(s);
-}
-extern "C" int qn_solver_s_norm(qn_solver* s, double* out, int* is_some) {
-    if (is_some) *is_some = s->hctl->has_s_norm;
-    if (out) *out = s->hctl->s_norm;
-    return QN_OK;
-}
-extern "C" int qn_solver_y_norm(qn_solver* s, double* out, int* is_some) {
-    if (is_some) *is_some = s->hctl->has_y_norm;
-    if (out) *out = s->hctl->y_norm;
-    return QN_OK;
-}
-extern "C" int qn_solver_decrement_squared(qn_solver* s, double* out, int* is_some) { // newton/mod.rs:10
-    if (is_some) *is_some = s->hctl->has_dec;
-    if (out) *out = s->hctl->dec;
-    return QN_OK;
-}
-extern "C" int qn_solver_next_iterate_too_close(qn_solver* s, int* out) { // bfgs.rs:15-20
-    *out = s->hctl->has_s_norm && s->hctl->s_norm < s->tol;
-    return QN_OK;
-}
-extern "C" int qn_solver_gradient_next_iterate_too_close(qn_solver* s, int* out) { // bfgs.rs:21-26
-    *out = s->hctl->has_y_norm && s->hctl->y_norm < s->tol;
-    return QN_OK;
-}
-
-// ---- launches ----
-template <int R>
-static void launch_hpass(hipStream_t st, const QnHPassArgs& a) {
-    dim3 grid(a.T.rpr / R, a.T.cs);
-    hipLaunchKernelGGL(h_pass_kernel<R>, grid, dim3(QN_TPB), 0, st, a);
-}
-static int launch_hpass_R(qn_solver* s, const QnHPassArgs& a) {
-    ProfScope ps(s, KC_HPASS);
-    switch (s->R) {
-    case 4: launch_hpass<4>(s->ctx->stream, a); break;
-    case 16: launch_hpass<16>(s->ctx->stream, a); break;
-    default: launch_hpass<8>(s->ctx->stream, a); break;
-    }
-    s->stats.launches++;
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-
-static QnHPassArgs hpass_args(qn_solver* s, int expect_phase) {
-    QnHPassArgs a{};
-    a.H = s->H;
-    a.T = s->T; a.T.cs = s->hcs;
-    a.sp = s->V.sp; a.up = s->V.up;
-    a.vy = s->V.y; a.vg = s->V.g;
-    a.r0 = nullptr; a.r1 = nullptr;
-    a.hp = s->V.hp;
-    a.ctl = s->ctl;
-    a.expect_phase = expect_phase;
-    return a;
-}
-
-static QnSymShard sym_shard(const qn_solver* s) {
-    QnSymShard sh{};
-    sh.world = s->ctx->world; sh.rank = s->ctx->rank;
-    sh.nbl = s->T.rpr / QN_TB; sh.ioff = sh.rank * sh.nbl;
-    sh.xg = s->symsh_xg;
-    sh.sl_off = s->s2_sl_off; sh.sl_idx = s->s2_sl_idx; sh.tiles = s->symsh_tiles;
-    sh.nsum = s->ctx->use_allreduce ? 1 : sh.world; // all-reduce mode: the exchange already left the total in slice 0
-    return sh;
-}
-
-// the symmetric-storage paths maintain the upper block triangle only: restore the lower one before anything reads whole rows
-static int ensure_full_h(qn_solver* s) {
-    if (!s->H || !s->h_lower_stale) return QN_OK;
-    qn_context* c = s->ctx;
-    if (c->world > 1) { // row-sharded: the stale half of a block-row is maintained by other ranks (circulant windows, qn_sym.hip.h)
-        const size_t np = (size_t)s->T.n_pad, blk = (size_t)QN_TB * np;
-        const QnSymShard sh = sym_shard(s);
-        if (!s->symsh_gath) HIPCHK(hipMalloc((void**)&s->symsh_gath, (size_t)c->world * blk * sizeof(double)));
-        if (s->h_diag_stale) // (second-generation tiles: inside the local diagonal tiles only the upper 16 x 16 sub-blocks are current)
-            hipLaunchKernelGGL(s2sh_diag_mirror_kernel, dim3(QN_TB / 32, QN_TB / 32, sh.nbl), dim3(256), 0, c->stream, s->H, s->T.n_pad, sh.ioff);
-        for (int il = 0; il < sh.nbl; ++il) {
-            HIPCHK(hipMemcpyAsync(s->symsh_gath + (size_t)c->rank * blk, s->H + (size_t)il * blk, blk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-            QNCHK(exchange(c, s->symsh_gath, blk));
-            hipLaunchKernelGGL(symsh_mirror_kernel, dim3(sh.nbl, c->world), dim3(256), 0, c->stream, s->H, s->symsh_gath, s->T.n_pad,
-                               s->T.n_pad / QN_TB, il, sh);
-        }
-        HIPCHK(hipGetLastError());
-        s->h_lower_stale = false;
-        s->h_diag_stale = false;
-        return QN_OK;
-    }
-    const int b32 = s->T.n_pad / 32;
-    hipLaunchKernelGGL(sym2_mirror_kernel, dim3(b32, b32), dim3(256), 0, s->ctx->stream, s->H, s->T.n_pad); // (also inside the diagonal tiles)
-    HIPCHK(hipGetLastError());
-    s->h_lower_stale = false;
-    s->h_diag_stale = false;
-    return QN_OK;
-}
-
-static int flush_pending(qn_solver* s) { // H_stored <- H_true
-    QNCHK(fused_export(s));  // the pending update's vectors
-    QNCHK(ensure_full_h(s)); // (also from a callback in the middle of a symmetric-storage run)
-    if (!s->H || !s->hctl->pending) return QN_OK;
-    QnHPassArgs a = hpass_args(s, -1);
-    a.force_nrhs = 0; a.force_pending = 1;
-    a.c_ss = s->hctl->c_ss; a.c_su = s->hctl->c_su; a.c_uu = s->hctl->c_uu;
-    QNCHK(launch_hpass_R(s, a));
-    s->hctl->pending = 0;
-    return poke_ctl(s);
-}
-
-extern "C" int qn_solver_get_inv_hessian(qn_solver* s, double* out, int all_ranks) {
-    if (!s->H) return fail(QN_ERROR_INPUT_PARAMS, "gradient descent keeps no inverse Hessian");
-    qn_context* c = s->ctx;
-    HIPCHK(hipSetDevice(c->device));
-    QNCHK(flush_pending(s));
-    const size_t n = s->n, np = s->T.n_pad, rpr = s->T.rpr;
-    const size_t chunk = 16;
-    std::vector<double> rows(chunk * np * (all_ranks ? c->world : 1));
-    double* tmp = nullptr;
-    if (all_ranks && c->world > 1) HIPCHK(hipMalloc((void**)&tmp, (size_t)c->world * chunk * np * sizeof(double)));
-    for (size_t r0 = 0; r0 < rpr; r0 += chunk) {
-        if (all_ranks && c->world > 1) {
-            HIPCHK(hipMemcpyAsync(tmp + (size_t)c->rank * chunk * np, s->H + r0 * np, chunk * np * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-            QNCHK(exchange(c, tmp, chunk * np));
-            HIPCHK(hipMemcpyAsync(rows.data(), tmp, (size_t)c->world * chunk * np * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            for (int p = 0; p < c->world; ++p)
-                for (size_t r = 0; r < chunk; ++r) {
-                    const size_t i = (size_t)p * rpr + r0 + r;
-                    if (i >= n) continue;
-                    const double* row = rows.data() + ((size_t)p * chunk + r) * np;
-                    for (size_t j = 0; j < n; ++j) out[i + j * n] = row[j];
-                }
-        } else {
-            HIPCHK(hipMemcpyAsync(rows.data(), s->H + r0 * np, chunk * np * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            for (size_t r = 0; r < chunk; ++r) {
-                const size_t i = (size_t)s->T.row_off + r0 + r;
-                if (i >= n) continue;
-                const double* row = rows.data() + r * np;
-                for (size_t j = 0; j < n; ++j) out[i + j * n] = row[j];
-            }
-        }
-    }
-    if (tmp) HIPCHK(hipFree(tmp));
-    return QN_OK;
-}
-
-// ComputeDirection::compute_direction (bfgs.rs:42-49, dfp.rs:42-49: `-&self.approx_inv_hessian * eval.g()`;
-// gradient_descent.rs:24-30: `-eval.g()`) on its own, for a binding that implements the trait: g goes up, d comes down.
-extern "C" int qn_solver_compute_direction(qn_solver* s, const double* g_host, double* d_host) {
-    if (!s || !g_host || !d_host) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
-    if (s->method == QN_NEWTON) return fail(QN_ERROR_INPUT_PARAMS, "the Newton direction needs the oracle's Hessian: use qn_minimize");
-    const size_t n = s->n;
-    if (!s->H) { // gradient descent
-        for (size_t i = 0; i < n; ++i) d_host[i] = -g_host[i];
-        return QN_OK;
-    }
-    qn_context* c = s->ctx;
-    HIPCHK(hipSetDevice(c->device));
-    QNCHK(flush_pending(s)); // the lazy update of the last iteration, and whole rows of H
-    const size_t np = s->T.n_pad, rpr = s->T.rpr;
-    double* buf = nullptr; // [g (np) | H g (np)]
-    HIPCHK(hipMalloc((void**)&buf, 2 * np * sizeof(double)));
-    HIPCHK(hipMemsetAsync(buf, 0, 2 * np * sizeof(double), c->stream));
-    HIPCHK(hipMemcpyAsync(buf, g_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    int st = qn_gemv(c, s->H, np, rpr, n, buf, buf + np + (size_t)s->T.row_off);
-    if (st == QN_OK) st = exchange(c, buf + np, rpr);
-    if (st == QN_OK) {
-        hipError_t e = hipMemcpyAsync(d_host, buf + np, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, hipGetErrorString(e));
-    }
-    (void)hipFree(buf);
-    if (st != QN_OK) return st;
-    if (s->bounded) { // BFGSB / DFPB / SR1B: P(x - H g) - x with the solver's box (bfgs_b.rs:66-77), not -H g
-        std::vector<double> x(n), lb(n), ub(n);
-        QNCHK(qn_solver_get_x(s, x.data()));
-        HIPCHK(hipMemcpy(lb.data(), s->bounds_block, n * sizeof(double), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(ub.data(), s->bounds_block + np, n * sizeof(double), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) {
-            double t = x[i] - d_host[i];
-            t = std::fmin(std::fmax(t, lb[i]), ub[i]);
-            d_host[i] = t - x[i];
-        }
-        return QN_OK;
-    }
-    for (size_t i = 0; i < n; ++i) d_host[i] = -d_host[i];
-    return QN_OK;
-}
-
-// The second half of the `update_next_iterate` hook (bfgs.rs:92-130, dfp.rs:92-118) on its own, for a binding that implements
-// LineSearchSolver hook by hook: records ||s|| and ||y|| (s_norm / y_norm), returns early when either is below tol
-// (bfgs.rs:103-109), otherwise applies the secant update to the device-resident inverse Hessian as the rank-2 form of DESIGN.md 4
-// (u = H y; BFGS: rho = 1/y's, H += -rho (su' + us') + (rho^2 y'u + rho) ss'; DFP: H += ss'/y's - uu'/y'u).
-extern "C" int qn_solver_secant_update(qn_solver* s, const double* s_host, const double* y_host) {
-    if (!s || !s_host || !y_host) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
-    if ((s->method != QN_BFGS && s->method != QN_DFP) || s->bounded)
-        return fail(QN_ERROR_INPUT_PARAMS, "secant update: BFGS and DFP only");
-    qn_context* c = s->ctx;
-    HIPCHK(hipSetDevice(c->device));
-    QNCHK(flush_pending(s));
-    const size_t n = s->n, np = s->T.n_pad, rpr = s->T.rpr;
-    double ss = 0.0, yy = 0.0, ys = 0.0;
-    for (size_t i = 0; i < n; ++i) { ss += s_host[i] * s_host[i]; yy += y_host[i] * y_host[i]; ys += y_host[i] * s_host[i]; }
-    QnCtl* h = s->hctl;
-    h->has_s_norm = 1; h->s_norm = std::sqrt(ss);
-    h->has_y_norm = 1; h->y_norm = std::sqrt(yy);
-    h->have_dir = 0; h->have_cur_eval = 0;
-    QNCHK(poke_ctl(s));
-    if (h->s_norm < s->tol || h->y_norm < s->tol) return QN_OK;
-    double* buf = nullptr; // [s | y | u = H y], n_pad each
-    HIPCHK(hipMalloc((void**)&buf, 3 * np * sizeof(double)));
-    std::vector<double> u(n);
-    int st = QN_OK;
-    auto hip_ok = [&](hipError_t e) { if (e != hipSuccess && st == QN_OK) st = fail(QN_ABNORMAL_TERMINATION, hipGetErrorString(e)); return e == hipSuccess; };
-    hip_ok(hipMemsetAsync(buf, 0, 3 * np * sizeof(double), c->stream));
-    hip_ok(hipMemcpyAsync(buf, s_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    hip_ok(hipMemcpyAsync(buf + np, y_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (st == QN_OK) st = qn_gemv(c, s->H, np, rpr, n, buf + np, buf + 2 * np + (size_t)s->T.row_off);
-    if (st == QN_OK) st = exchange(c, buf + 2 * np, rpr);
-    if (st == QN_OK) {
-        hip_ok(hipMemcpyAsync(u.data(), buf + 2 * np, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        hip_ok(hipStreamSynchronize(c->stream));
-    }
-    if (st == QN_OK) {
-        double yu = 0.0;
-        for (size_t i = 0; i < n; ++i) yu += y_host[i] * u[i];
-        double c_ss, c_su, c_uu;
-        if (s->method == QN_BFGS) { const double rho = 1.0 / ys; c_su = -rho; c_ss = rho * rho * yu + rho; c_uu = 0.0; }
-        else { c_ss = 1.0 / ys; c_su = 0.0; c_uu = -1.0 / yu; }
-        st = qn_rank2_update(c, s->H, np, (size_t)s->T.row_off, rpr, n, buf, buf + 2 * np, c_ss, c_su, c_uu);
-        if (st == QN_OK) hip_ok(hipStreamSynchronize(c->stream));
-    }
-    (void)hipFree(buf);
-    return st;
-}
-
-extern "C" int qn_solver_set_inv_hessian(qn_solver* s, const double* h) {
-    if (!s->H) return fail(QN_ERROR_INPUT_PARAMS, "gradient descent keeps no inverse Hessian");
-    HIPCHK(hipSetDevice(s->ctx->device));
-    const size_t n = s->n, np = s->T.n_pad;
-    std::vector<double> rows((size_t)s->T.rpr * np, 0.0);
-    for (size_t r = 0; r < (size_t)s->T.rpr; ++r) {
-        const size_t i = (size_t)s->T.row_off + r;
-        if (i >= n) break;
-        for (size_t j = 0; j < n; ++j) rows[r * np + j] = h[i + j * n];
-    }
-    QNCHK(fused_export(s));
-    HIPCHK(hipMemcpy(s->H, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
-    s->h_lower_stale = false; s->h_diag_stale = false; // every entry was just replaced
-    s->h_nonsym = false; // the symmetric-storage path needs H == H' bit for bit (BFGS / DFP keep it so from a symmetric start)
-    for (size_t i = 0; i < n && !s->h_nonsym; ++i)
-        for (size_t j = i + 1; j < n; ++j)
-            if (h[i + j * n] != h[j + i * n]) { s->h_nonsym = true; break; }
-    s->hctl->pending = 0; s->hctl->have_dir = 0;
-    return poke_ctl(s);
-}
-
-extern "C" int qn_solver_get_stats(qn_solver* s, qn_stats* out) {
-    HIPCHK(hipSetDevice(s->ctx->device));
-    prof_collect(s);
-    *out = s->stats;
-    return QN_OK;
-}
-
-// ---- Newton direction (newton/mod.rs:26-49): Cholesky factorisation + four triangular solves, or the n <= 5 kernel ----
-static int newton_alloc(qn_solver* s) {
-    if (s->newton_w) return QN_OK;
-    size_t n64 = (s->n + QN_NB - 1) / QN_NB * QN_NB;
-    s->newton_big = n64 > QN_TS; // 512-wide triangular blocks (inverses doubled up from the 64-wide ones)
-    if (s->newton_big) n64 = (s->n + QN_TS - 1) / QN_TS * QN_TS;
-    s->newton_n64 = n64;
-    hipStream_t st = s->ctx->stream;
-    QNCHK(dev_alloc_zero(&s->newton_w, n64 * n64, st));
-    QNCHK(dev_alloc_zero(&s->newton_x, 2 * n64, st));
-    QNCHK(dev_alloc_zero(&s->newton_invl, n64 * QN_NB, st));
-    if (s->newton_big) { // inverse blocks of width 128, 256, 512, the transposed 512 ones, and the product scratch
-        QNCHK(dev_alloc_zero(&s->newton_inv2, n64 * (128 + 256 + 512 + 512 + 256), st));
-    }
-    HIPCHK(hipMalloc((void**)&s->newton_fail, 2 * sizeof(int)));
-    HIPCHK(hipMemsetAsync(s->newton_fail, 0, 2 * sizeof(int), st));
-    HIPCHK(hipMalloc((void**)&s->newton_piv, n64 * sizeof(int)));
-    HIPCHK(hipMalloc((void**)&s->newton_perm, n64 * sizeof(int)));
-    s->newton_piv_host.resize(n64);
-    s->V.nfail = s->newton_fail;
-    return QN_OK;
-}
-
-static inline int rowdot_grid(int nrows) { return std::max(1, std::min(1024, nrows <= 4096 ? (nrows + 3) / 4 : (nrows + 15) / 16)); }
-
-// inverses of the 512-wide diagonal blocks of L from the 64-wide ones: inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1, C^-1]
-static int newton_build_block_inverses(qn_solver* s) {
-    hipStream_t st = s->ctx->stream;
-    const size_t n64 = s->newton_n64, ld = n64;
-    double* lvl[4] = {s->newton_invl, s->newton_inv2, s->newton_inv2 + n64 * 128, s->newton_inv2 + n64 * (128 + 256)};
-    double* invT = s->newton_inv2 + n64 * (128 + 256 + 512);
-    double* T = s->newton_inv2 + n64 * (128 + 256 + 512 + 512);
-    for (int l = 0; l < 3; ++l) {
-        const int sz = QN_NB << l;
-        const int npairs = (int)(n64 / (2 * (size_t)sz));
-        const size_t ss = (size_t)sz * sz;
-        const dim3 grid(sz / QN_NB, sz / QN_NB, npairs);
-        QnBatchGemm g1{s->newton_w + (size_t)sz * ld, ld, 2 * (size_t)sz * ld + 2 * (size_t)sz, lvl[l], (size_t)sz, 2 * ss, T, (size_t)sz, ss, sz, 1.0};
-        hipLaunchKernelGGL(tri_batch_gemm_kernel, grid, dim3(256), 0, st, g1); // T = B A^-1
-        QnBatchGemm g2{lvl[l] + ss, (size_t)sz, 2 * ss, T, (size_t)sz, ss, lvl[l + 1] + (size_t)sz * 2 * sz, 2 * (size_t)sz, 4 * ss, sz, -1.0};
-        hipLaunchKernelGGL(tri_batch_gemm_kernel, grid, dim3(256), 0, st, g2); // lower-left = -C^-1 T
-        hipLaunchKernelGGL(tri_inv_assemble_kernel, dim3(1024), dim3(256), 0, st, lvl[l], lvl[l + 1], sz, npairs);
-    }
-    const int nb = (int)(n64 / QN_TS);
-    hipLaunchKernelGGL(tri_transpose_blocks_kernel, dim3(QN_TS / 32, QN_TS / 32, nb), dim3(256), 0, st, lvl[3], invT, (int)QN_TS, nb);
-    s->stats.launches += 10;
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-
-static int newton_tri_solve(qn_solver* s, double* x, double* tmp) { // x <- (L L')^-1 x ; tmp: n64 scratch
-    hipStream_t st = s->ctx->stream;
-    const int n64 = (int)s->newton_n64;
-    const size_t ld = s->newton_n64;
-    if (s->newton_big) {
-        const double* inv = s->newton_inv2 + (size_t)n64 * (128 + 256);
-        const double* invT = s->newton_inv2 + (size_t)n64 * (128 + 256 + 512);
-        const size_t bb = (size_t)QN_TS * QN_TS;
-        const int nb = n64 / QN_TS;
-        for (int K = 0; K < nb; ++K) { // L y = x : rhs x (consumed), solution tmp
-            const int K0 = K * QN_TS, below = n64 - K0 - QN_TS;
-            hipLaunchKernelGGL(tri_rowdot512_kernel, dim3(rowdot_grid(QN_TS)), dim3(256), 0, st, inv + K * bb, (size_t)QN_TS, (int)QN_TS, x + K0, tmp + K0, 0);
-            if (below > 0)
-                hipLaunchKernelGGL(tri_rowdot512_kernel, dim3(rowdot_grid(below)), dim3(256), 0, st, s->newton_w + (size_t)(K0 + QN_TS) * ld + K0, ld,
-                                   below, tmp + K0, x + K0 + QN_TS, 1);
-        }
-        for (int K = nb - 1; K >= 0; --K) { // L' z = y : rhs tmp (consumed), solution x
-            const int K0 = K * QN_TS;
-            hipLaunchKernelGGL(tri_rowdot512_kernel, dim3(rowdot_grid(QN_TS)), dim3(256), 0, st, invT + K * bb, (size_t)QN_TS, (int)QN_TS, tmp + K0, x + K0, 0);
-            if (K0 > 0)
-                hipLaunchKernelGGL(tri_coldot512_kernel, dim3((K0 + 63) / 64), dim3(256), 0, st, s->newton_w + (size_t)K0 * ld, ld, K0, x + K0, tmp);
-        }
-        s->stats.launches += 4 * (uint64_t)nb;
-        HIPCHK(hipGetLastError());
-        return QN_OK;
-    }
-    for (int k0 = 0; k0 < n64; k0 += QN_NB) { // L y = x : rhs x (consumed), solution tmp
-        const int below = n64 - k0 - QN_NB;
-        const int grid = std::max(1, std::min(256, (below + 3) / 4));
-        hipLaunchKernelGGL(tri_fwd_step_kernel, dim3(grid), dim3(256), 0, st, s->newton_w, ld, k0, n64,
-                           s->newton_invl + (size_t)(k0 / QN_NB) * QN_NB * QN_NB, x, tmp);
-    }
-    for (int k0 = n64 - QN_NB; k0 >= 0; k0 -= QN_NB) { // L' z = y : rhs tmp (consumed), solution x
-        const int grid = std::max(1, std::min(256, (k0 + 255) / 256));
-        hipLaunchKernelGGL(tri_bwd_step_kernel, dim3(grid), dim3(256), 0, st, s->newton_w, ld, k0,
-                           s->newton_invl + (size_t)(k0 / QN_NB) * QN_NB * QN_NB, tmp, x);
-    }
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-
-struct Run;
-static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj);
-
-// ---- the pump ----
-struct Run {
-    qn_solver* s;
-    const qn_oracle* o;
-    qn_objective* obj;
-    int oracle_tpl; // QN_ORACLE_GENERIC / QN_ORACLE_QUAD
-    bool fused;
-    bool sym = false; // fused path on the upper block triangle of H and Q (qn_sym.hip.h)
-    bool sym_generic = false; // generic path: the H pass alone on the upper block triangle
-    bool sym2 = false;        // second-generation symmetric path (qn_sym2.hip.h)
-    bool gobj = false;        // ... in its form for a device objective that is not the quadratic (qn_sym2g.hip.h: the log-sum-exp objective)
-    bool dirq = false;        // ... whose pattern has the stored-direction launch (QnCtl.s2_dir != 0)
-    bool bnd = false;         // ... a bounded run on it (BFGSB / DFPB, MoreThuenteB): one more launch per iteration, s2_dir_kernel (qn_sym2.hip.h)
-    bool tiles1 = false;      // the update pass's tiles through the first-generation tile kernel (one workgroup per tile, two per CU) behind a
-                              // one-workgroup launch that runs the machine: H's share past the Infinity Cache (see minimize_impl)
-    QnS2Args s2{};
-    uint64_t s2_launches = 0; // parity of the control-block double buffer = launches so far & 1
-    unsigned long long report_seq = 0; // != 0: the next launch reports its control block to the host (s2_wait_report)
-};
-
-// ---- generic objectives on the second-generation structure (qn_sym2g.hip.h) ----
-static QnS2GArgs s2g_args(const Run& r) {
-    qn_solver* s = r.s;
-    qn_objective* o = r.obj;
-    qn_context* c = s->ctx;
-    QnS2GArgs g{};
-    g.L.A = o->Q; g.L.c = o->b; g.L.mu = o->mu;
-    g.L.m = (int)o->m; g.L.m_pad = o->TA.n_pad; g.L.mrpr = o->TA.rpr; g.L.n = (int)o->n; g.L.n_pad = o->T.n_pad;
-    g.L.world = c->world; g.L.rank = c->rank; g.L.rs = 1;
-    g.wgms = o->lwgms; g.wgg = o->lwgg; g.G = o->lse_G;
-    g.ctl = s->s2_ctl + (r.s2_launches & 1); // what the last prologue launch has written
-    g.F = s->V.F;
-    g.wgS = nullptr; g.trows = s->s2_trows;
-    g.gall = o->lgall; g.ev_slice = nullptr;
-    return g;
-}
-template <int KCH, bool NTA>
-static int s2g_launch_onepass_nt(hipStream_t st, const QnS2GArgs& g) {
-    static std::atomic<bool> attr_set[64]; // per device: hipFuncSetAttribute applies to the current device only (atomic: ranks may be threads)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const size_t lds = (size_t)KCH * 1024 * sizeof(double);
-    if ((dev < 0 || dev >= 64 || !attr_set[dev].load()) && lds > 48 * 1024) { // the trial point in LDS: up to 128 KB of the CU's 160 KB
-        if (hipFuncSetAttribute((const void*)s2g_onepass_kernel<KCH, NTA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(QN_ABNORMAL_TERMINATION, "log-sum-exp: the device does not grant the evaluation kernel its LDS");
-        }
-        if (dev >= 0 && dev < 64) attr_set[dev].store(true);
-    }
-    hipLaunchKernelGGL((s2g_onepass_kernel<KCH, NTA>), dim3(g.G), dim3(512), lds, st, g);
-    return QN_OK;
-}
-template <int KCH>
-static int s2g_launch_onepass(hipStream_t st, const QnS2GArgs& g) {
-    static const int nt_env = getenv("QN_LSE_NT") ? atoi(getenv("QN_LSE_NT")) : -1; // (as lse_launch_onepass)
-    const bool nt = nt_env >= 0 ? nt_env != 0 : (size_t)g.L.mrpr * (size_t)g.L.n_pad * sizeof(double) > ((size_t)230 << 20);
-    return nt ? s2g_launch_onepass_nt<KCH, true>(st, g) : s2g_launch_onepass_nt<KCH, false>(st, g);
-}
-static int s2g_enqueue_onepass(Run& r) {
-    qn_solver* s = r.s;
-    hipStream_t st = s->ctx->stream;
-    const QnS2GArgs g = s2g_args(r);
-    ProfScope ps(s, KC_EVAL);
-    switch (r.obj->lse_kch) {
-    case 1: QNCHK(s2g_launch_onepass<1>(st, g)); break;
-    case 2: QNCHK(s2g_launch_onepass<2>(st, g)); break;
-    case 4: QNCHK(s2g_launch_onepass<4>(st, g)); break;
-    case 8: QNCHK(s2g_launch_onepass<8>(st, g)); break;
-    default: QNCHK(s2g_launch_onepass<16>(st, g)); break;
-    }
-    s->stats.launches++;
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-// the update pass's tiles: the first-generation tile kernel (qn_sym.hip.h: one workgroup per tile, two per CU -- 6.2 TB/s on H's half at
-// n = 16384 where the one-workgroup-per-CU kernel of qn_sym2.hip.h reaches 5.4), reading the control block the launch in front wrote
-static int s2g_enqueue_tiles(Run& r) {
-    qn_solver* s = r.s;
-    qn_context* c = s->ctx;
-    QnSymHPassArgs y{};
-    y.H = s->H; y.T = s->T; y.T.cs = 1; y.F = s->V.F; y.F.UP = y.F.UN; // (no kernel of this path writes u while another reads it)
-    y.ctl = s->s2_ctl + (r.s2_launches & 1); y.expect_phase = QN_PH_REQ_HPASS; y.need_serviced = 1;
-    y.nb = s->sym_nb; y.part = s->sym_part;
-    y.nt = s->T.n_pad >= 8192; // past the Infinity Cache (same-box A/B, round 1: +7 % at n = 32768, +3 % at 8192, -1 % at 4096)
-    int grid = y.nb * (y.nb + 1) / 2;
-    if (c->world > 1) { y.sh = sym_shard(s); grid = qn_symsh_ntiles(y.nb, y.sh.nbl, y.sh.ioff); } // row-sharded: the rank's circulant windows
-    {
-        ProfScope ps(s, KC_HPASS);
-        hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(grid), dim3(QN_SYM_TPB), 0, c->stream, y);
-    }
-    s->h_lower_stale = true;
-    s->stats.launches++;
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-
-static int s2_launch(Run& r, int kind) {
-    qn_solver* s = r.s;
-    hipStream_t st = s->ctx->stream;
-    QnS2Args a = r.s2;
-    a.parity = (int)(r.s2_launches & 1);
-    a.ctl_first = r.s2_launches == 0 ? s->hctl : nullptr; // (the first launch of a call takes the control block from the pinned mirror)
-    a.rep = s->hrep; a.rep_flag = s->hrep_flag; a.rep_seq = r.report_seq;
-    r.report_seq = 0;
-#ifdef QN_S2_STAMPS
-    a.dbg = s->V.dbg; a.slot = (int)r.s2_launches;
-    a.swz = (getenv("QN_S2_SWZ") && a.pair) ? atoi(getenv("QN_S2_SWZ")) : 0; // (only where both items follow from the workgroup index: n = 4096)
-#endif
-    r.s2_launches++;
-    const int cls = kind == QN_S2_EVAL ? KC_EVAL : (kind == QN_S2_VEC || kind == QN_S2_VSUM || kind == QN_S2_GCOMB || kind == QN_S2_DIR) ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS
-                  : (kind == QN_S2_HREDUCE || kind == QN_S2_HSUM) ? KC_HREDUCE : KC_CTL;
-    ProfScope ps(s, cls);
-    const bool sh = a.sh_world > 1; // row-sharded: the SHARD instantiations (qn_sym2sh.hip.h)
-    switch (kind) {
-    case QN_S2_EVAL:
-        if (sh) {
-            if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            else hipLaunchKernelGGL((s2_eval_kernel<false, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-        } else if (r.bnd) { // (bounded variants: the same kernels behind the bounded runs' prologue)
-            if (a.pair && a.ring) hipLaunchKernelGGL(s2_evalr_kernel<true>, dim3(a.G), dim3(QN_S2R_TPB), 0, st, a);
-            else if (a.pair) hipLaunchKernelGGL((s2_eval_kernel<true, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            else if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, false, true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            else hipLaunchKernelGGL((s2_eval_kernel<false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-        } else if (a.pair && a.ring) hipLaunchKernelGGL(s2_evalr_kernel<false>, dim3(a.G), dim3(QN_S2R_TPB), 0, st, a);
-        else if (a.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-        else if (a.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-        else hipLaunchKernelGGL(s2_eval_kernel<false>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-        break;
-    case QN_S2_DIR: hipLaunchKernelGGL(s2_dir_kernel, dim3(a.nb), dim3(QN_TB), 0, st, a); break;
-    case QN_S2_VSUM:
-        if (r.gobj) hipLaunchKernelGGL((s2_advance_kernel<true, true, QN_S2_VSUM>), dim3(1), dim3(128), 0, st, a); // (the machine sees the accepted point; the gather follows)
-        else hipLaunchKernelGGL(s2sh_vsum_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
-        break;
-    case QN_S2_HSUM: hipLaunchKernelGGL(s2sh_hsum_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break;
-    case QN_S2_VEC:
-        if (r.gobj) { const QnS2GArgs g = s2g_args(r); hipLaunchKernelGGL(s2g_vec_kernel, dim3(a.nb), dim3(QN_TB), 0, st, a, g); }
-        else if (sh) hipLaunchKernelGGL(s2_vec_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
-        else hipLaunchKernelGGL(s2_vec_kernel<false>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
-        break;
-    case QN_S2_HTILE:
-        if (s->method == QN_SR1) { // (one rank, no fold, no tail reduce: minimize_impl)
-            if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, false, false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-        } else if (sh) {
-            if (s->method == QN_BFGS) {
-                if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, true, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-                else hipLaunchKernelGGL((s2_hpass_kernel<false, true, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            } else {
-                if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-                else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            }
-        } else if (a.fold) { // (n <= 4096: H stays in the Infinity Cache, no streaming hints)
-            if (s->method == QN_BFGS) hipLaunchKernelGGL((s2_hpass_kernel<false, true, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            else hipLaunchKernelGGL((s2_hpass_kernel<false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-        } else if (a.tred) { // the update-reduce in the launch's tail
-            if (s->method == QN_BFGS) {
-                if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, true, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-                else hipLaunchKernelGGL((s2_hpass_kernel<false, true, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            } else {
-                if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-                else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            }
-        } else if (s->method == QN_BFGS) {
-            if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            else hipLaunchKernelGGL((s2_hpass_kernel<false, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-        } else {
-            if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, false, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-        }
-        s->h_lower_stale = true; s->h_diag_stale = true;
-        s->h_sliver_whole = a.sl_per != 0; // (sliver rows update every entry of their tiles; without them only the upper sub-blocks are kept)
-        break;
-    case QN_S2_HREDUCE:
-        if (sh) hipLaunchKernelGGL(s2_hreduce_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
-        else if (s->method == QN_SR1) hipLaunchKernelGGL((s2_hreduce_kernel<false, true>), dim3(2 * a.nb), dim3(QN_S2_TPB), 0, st, a);
-        else hipLaunchKernelGGL(s2_hreduce_kernel<false>, dim3(2 * a.nb), dim3(QN_S2_TPB), 0, st, a); // (a workgroup per block-row and right-hand side)
-        break;
-    case QN_S2_GEVAL_A:
-        if (sh) hipLaunchKernelGGL((s2_advance_kernel<true, true, QN_S2_GEVAL_A>), dim3(1), dim3(128), 0, st, a);
-        else hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_GEVAL_A>), dim3(1), dim3(128), 0, st, a);
-        break;
-    case QN_S2_GHT_A:
-        if (r.gobj) hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_GHT_A>), dim3(1), dim3(128), 0, st, a);
-        else if (sh) hipLaunchKernelGGL((s2_advance_kernel<true, false, QN_S2_GHT_A>), dim3(1), dim3(128), 0, st, a); // (measurement: QN_S2SH_GEN1_TILES)
-        else hipLaunchKernelGGL((s2_advance_kernel<false, false, QN_S2_GHT_A>), dim3(1), dim3(128), 0, st, a);
-        break;
-    case QN_S2_GCOMB: {
-        QnS2GArgs g = s2g_args(r);
-        g.wgS = a.wgS + (size_t)a.parity * (size_t)a.trows * QN_S2_ROW; // the half this launch writes (the next prologue reads it)
-        g.wgV = a.wgV + (size_t)a.parity * (size_t)a.trows * QN_S2_ROW;
-        if (sh) {
-            g.ev_slice = a.evS + ((size_t)a.parity * (size_t)a.sh_world + (size_t)a.sh_rank) * (QN_S2SH_NEC * QN_S2_MAXG);
-            hipLaunchKernelGGL(s2g_combine_kernel<true>, dim3(a.gw), dim3(256), 0, st, a, g);
-        } else hipLaunchKernelGGL(s2g_combine_kernel<false>, dim3(a.gw), dim3(256), 0, st, a, g);
-        break;
-    }
-    default:
-        if (r.gobj && sh) hipLaunchKernelGGL((s2_advance_kernel<true, true, QN_S2_ADVANCE>), dim3(1), dim3(128), 0, st, a);
-        else if (r.gobj) hipLaunchKernelGGL((s2_advance_kernel<false, true, QN_S2_ADVANCE>), dim3(1), dim3(128), 0, st, a);
-        else if (sh) hipLaunchKernelGGL(s2_advance_kernel<true>, dim3(1), dim3(128), 0, st, a);
-        else if (r.bnd) hipLaunchKernelGGL((s2_advance_kernel<false, false, QN_S2_ADVANCE, true>), dim3(1), dim3(128), 0, st, a);
-        else hipLaunchKernelGGL(s2_advance_kernel<false>, dim3(1), dim3(128), 0, st, a);
-        break;
-    }
-    s->stats.launches++;
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-static int s2_peek(Run& r) { // the control block the last enqueued launch writes -> host mirror
-    qn_solver* s = r.s;
-    HIPCHK(hipMemcpyAsync(s->hctl, s->s2_ctl + (r.s2_launches & 1), sizeof(QnCtl), hipMemcpyDeviceToHost, s->ctx->stream));
-    HIPCHK(hipStreamSynchronize(s->ctx->stream));
-    s->stats.host_syncs++;
-    return QN_OK;
-}
-
-// ---- one request of the sym2 machine = its launches and, row-sharded, the collectives between them ----
-// An evaluation: the tiles, then (sharded) ONE exchange of the ranks' per-workgroup scalars -- 8 KB per rank, whatever n is.
-static int s2_do_eval(Run& r, unsigned long long report_seq = 0) {
-    if (r.gobj) { // the machine in a one-workgroup launch, the pass over A, the combine launch (which also stages the vectors of this point)
-        QNCHK(s2_launch(r, QN_S2_GEVAL_A));
-        QNCHK(s2g_enqueue_onepass(r));
-        r.report_seq = report_seq; // (the batch's last launch reports: only the combine launch leaves the request as the host may see it)
-        QNCHK(s2_launch(r, QN_S2_GCOMB));
-        if (r.s2.sh_world > 1) { // row-sharded: the ranks' (m_r, S_r) and G_r'd per workgroup -- 8 KB per rank; an all-gather whatever the
-            qn_solver* s = r.s;  // context's exchange mode is (the ranks are weighed with exp(m_r - M) before they are added)
-            qn_context* c = s->ctx;
-            ProfScope ps(s, KC_COMM);
-            const size_t cnt = (size_t)QN_S2SH_NEC * QN_S2_MAXG;
-            c->n_xchg_scalar++;
-            QNCHK(exchange(c, s->s2_evS + (size_t)((r.s2_launches - 1) & 1) * (size_t)c->world * cnt, cnt));
-        }
-        return QN_OK;
-    }
-    if (report_seq) r.report_seq = report_seq;
-    QNCHK(s2_launch(r, QN_S2_EVAL));
-    qn_solver* s = r.s;
-    qn_context* c = s->ctx;
-    if (r.s2.sh_world > 1) {
-        ProfScope ps(s, KC_COMM);
-        const size_t cnt = (size_t)QN_S2SH_NEC * QN_S2_MAXG;
-        double* half = s->s2_evS + (size_t)((r.s2_launches - 1) & 1) * (size_t)c->world * cnt; // the half the launch above wrote
-        c->n_xchg_scalar++;
-        if (c->use_allreduce) QNCHK(exchange_sum(c, half, cnt));
-        else QNCHK(exchange(c, half, cnt));
-    }
-    return QN_OK;
-}
-// the accepted point's vectors: (sharded) this rank's slot sums, the exchange of ONE n-vector, the epilogue on every rank
-static int s2_do_vec(Run& r) {
-    qn_solver* s = r.s;
-    qn_context* c = s->ctx;
-    if (r.s2.sh_world > 1) {
-        QNCHK(s2_launch(r, QN_S2_VSUM));
-        {
-            ProfScope ps(s, KC_COMM);
-            c->n_xchg_vector++;
-            if (r.gobj) QNCHK(exchange(c, r.obj->lgall, (size_t)s->T.n_pad)); // the ranks' G_r of the accepted point (weighed and added in rank order by s2g_vec_kernel)
-            else if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, (size_t)s->T.n_pad));
-            else QNCHK(exchange(c, s->symsh_xg, (size_t)s->T.n_pad));
-        }
-        return s2_launch(r, QN_S2_VEC);
-    }
-    return s2_launch(r, r.s2.fold ? QN_S2_HTILE : QN_S2_VEC);
-}
-// the update pass: tiles (unless the folded accept-reduce ran them), (sharded) partial sums and the exchange of [u, v], the reduce
-static int s2_do_hpass(Run& r, bool tiles) {
-    qn_solver* s = r.s;
-    qn_context* c = s->ctx;
-    if (r.gobj && r.s2.sh_world == 1) {
-        if (!tiles) return fail(QN_ABNORMAL_TERMINATION, "sym2 (generic objective): tiles marked done without their launch");
-        QNCHK(s2_launch(r, QN_S2_GHT_A));
-        QNCHK(s2g_enqueue_tiles(r));
-        return s2_launch(r, QN_S2_HREDUCE);
-    }
-    if (tiles && r.tiles1) { // H past the Infinity Cache: the machine in a one-workgroup launch, then the first-generation tile kernel
-        QNCHK(s2_launch(r, QN_S2_GHT_A));
-        QNCHK(s2g_enqueue_tiles(r));
-    } else if (tiles) QNCHK(s2_launch(r, QN_S2_HTILE));
-    if (r.s2.tred) return QN_OK; // (tail reduce: the tile launch has summed the slots itself)
-    if (r.s2.sh_world > 1) {
-        QNCHK(s2_launch(r, QN_S2_HSUM));
-        ProfScope ps(s, KC_COMM);
-        c->n_xchg_vector++;
-        if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
-        else QNCHK(exchange(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
-    }
-    return s2_launch(r, QN_S2_HREDUCE);
-}
-
-// The control block of the launch that was told to report (Run.report_seq) -> host mirror, without synchronising the stream: the
-// launch stores the block and then the sequence number into pinned memory, the host spins on the number.  (Round 3 copied the block
-// back with hipMemcpyAsync + hipStreamSynchronize: a copy-engine transfer and an interrupt-driven wake-up at the end of every call,
-// ~25 us of the 64 us a call cost beyond its iterations.)
-static int s2_wait_report(Run& r, unsigned long long seq) {
-    qn_solver* s = r.s;
-    volatile unsigned long long* flag = s->hrep_flag;
-    for (uint64_t spins = 0;; ++spins) {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
-        if ((spins & 0xfff) == 0xfff) { // the stream has drained and nothing reported: a launch failed
-            hipError_t e = hipStreamQuery(s->ctx->stream);
-            if (e == hipSuccess) { if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break; return fail(QN_ABNORMAL_TERMINATION, "sym2: the batch ended without a report"); }
-            if (e != hipErrorNotReady) return fail(QN_ABNORMAL_TERMINATION, std::string("sym2 batch: ") + hipGetErrorString(e));
-        }
-    }
-    memcpy(s->hctl, s->hrep, sizeof(QnCtl));
-    s->stats.host_syncs++;
-    return QN_OK;
-}
-
-// Where the inverse Hessian lives decides how fast the update pass runs on it while it is Infinity-Cache resident (qn_sym2.hip.h,
-// PLACEMENT PROBE: one H in eight is 18 % slower for as long as it lives).  Probes that only move H's bytes do not see it, so the
-// probe is the update kernel ITSELF: a direction pass with no update pending (H + 0: every tile read, written back with the
-// values it had, slots into the scratch buffer) on the solver's H and on a second allocation -- a third one when the two differ,
-// to know which was the odd one -- and H moves to the best.  Once per solver, at its first run on the second-generation path;
-// ~1 ms, up to three times H's size for that long; QN_H_PLACEMENT=0 switches it off, =2 prints what it measured.
-static int place_h(Run& r) {
-    qn_solver* s = r.s;
-    if (s->h_placed) return QN_OK;
-    s->h_placed = true;
-    const size_t np = s->T.n_pad, bytes = (size_t)s->T.rpr * np * sizeof(double);
-    const char* sw = getenv("QN_H_PLACEMENT");
-    if ((sw && atoi(sw) == 0) || s->ctx->world != 1 || bytes > ((size_t)330 << 20) || r.s2.fold) return QN_OK; // (n <= 6144: H's half is an Infinity Cache tenant; larger H is streamed from HBM anyway)
-    hipStream_t st = s->ctx->stream;
-    // the request: a direction pass (one right-hand side, g in both places), nothing pending; the vectors it multiplies are whatever
-    // the fused buffers hold (zeros before the first run) -- only the duration matters, and H comes back as it was
-    QnCtl* pc = s->hrep; // (pinned, device-mapped; the report area is free between calls)
-    memcpy(pc, s->hctl, sizeof(QnCtl));
-    pc->phase = QN_PH_REQ_HPASS; pc->serviced = 0; pc->hp_nrhs = 1; pc->pending = 0; pc->after_state = QN_ST_AFTER_DIR; pc->sym2 = 1; pc->fused = 1;
-    pc->spec_tiles = 0; pc->sc = 0; pc->xc = 0;
-    // ... and, in front of every timed pass, what an iteration has in front of it: two evaluations (Q's half streamed twice).  Timed
-    // alone on H the update kernel showed the same 24.4 us on allocations where, in the run, it then took 29.6-30.3 us (2-3 processes
-    // in 20, tools/modes_ab.sh): the slow mode is H sharing the Infinity Cache with Q, not H by itself.
-    QnCtl* pe = nullptr;
-    if (hipHostMalloc((void**)&pe, sizeof(QnCtl), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); pe = nullptr; }
-    if (pe) {
-        memcpy(pe, s->hctl, sizeof(QnCtl));
-        pe->phase = QN_PH_REQ_EVAL; pe->serviced = 0; pe->sym2 = 1; pe->fused = 1; pe->sc = 0; pe->xc = 0;
-        pe->ev_kind = QN_REQ_T; pe->t = 1.0; pe->status = -1;
-    }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { // no probe: H stays where it is, nothing is left behind
-        (void)hipGetLastError();
-        if (e0) (void)hipEventDestroy(e0);
-        if (pe) (void)hipHostFree(pe);
-        return QN_OK;
-    }
-    // (every failure below -- inside time_on too -- comes back as `status` and leaves through the one cleanup path at the end: the
-    // candidates that are not kept, the events and the pinned block are freed, H stays the solver's own)
-    auto time_on = [&](double* H, float* out_us) -> int {
-        QnS2Args a = r.s2;
-        a.H = H; a.parity = 0; a.ctl_first = pc; a.rep_seq = 0;
-        a.tred = 0; // (the probe times the tiles; the tail reduce would overwrite u, v and g with the probe's sums)
-        float t[6];
-        for (int rep = 0; rep < 6; ++rep) {
-            if (pe) {
-                QnS2Args ae = a;
-                ae.ctl_first = pe;
-                for (int e = 0; e < 2; ++e) {
-                    if (ae.pair && ae.ring) hipLaunchKernelGGL(s2_evalr_kernel<false>, dim3(ae.G), dim3(QN_S2R_TPB), 0, st, ae);
-                    else if (ae.pair) hipLaunchKernelGGL(s2_eval_kernel<true>, dim3(ae.G), dim3(QN_S2_TPB), 0, st, ae);
-                    else if (ae.ntq) hipLaunchKernelGGL((s2_eval_kernel<false, false, true>), dim3(ae.G), dim3(QN_S2_TPB), 0, st, ae);
-                    else hipLaunchKernelGGL(s2_eval_kernel<false>, dim3(ae.G), dim3(QN_S2_TPB), 0, st, ae);
-                }
-            }
-            HIPCHK(hipEventRecord(e0, st));
-            if (s->method == QN_BFGS) hipLaunchKernelGGL((s2_hpass_kernel<false, true, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            else hipLaunchKernelGGL((s2_hpass_kernel<false, false, false>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
-            HIPCHK(hipEventRecord(e1, st));
-            HIPCHK(hipEventSynchronize(e1));
-            float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-            t[rep] = ms * 1e3f;
-        }
-        std::sort(t + 2, t + 6); // (the first two repetitions bring the tiles in)
-        *out_us = t[3];
-        return QN_OK;
-    };
-    double* cand[3] = {s->H, nullptr, nullptr};
-    float us[3] = {0.f, 0.f, 0.f};
-    int ncand = 1, keep = 0;
-    int status = time_on(cand[0], &us[0]);
-    for (int k = 1; k < 3 && status == QN_OK; ++k) {
-        if (k == 2 && std::fabs(us[0] - us[1]) <= 0.06f * std::min(us[0], us[1])) break; // the two agree: both are the common case
-        if (hipMalloc((void**)&cand[k], bytes) != hipSuccess) { (void)hipGetLastError(); cand[k] = nullptr; break; } // (no room: keep what there is)
-        ++ncand;
-        if (hipMemcpyAsync(cand[k], s->H, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { status = fail(QN_ABNORMAL_TERMINATION, "H placement: copy failed"); break; }
-        status = time_on(cand[k], &us[k]);
-    }
-    if (status == QN_OK)
-        for (int k = 1; k < ncand; ++k)
-            if (us[k] < 0.96f * us[keep]) keep = k; // (the one it has, unless another is clearly better)
-    if (sw && atoi(sw) == 2) fprintf(stderr, "[qn] H placement: %d candidates, update kernel %.2f %.2f %.2f us, kept %d\n", ncand, us[0], us[1], us[2], keep);
-    (void)hipStreamSynchronize(st);
-    for (int k = 0; k < ncand; ++k)
-        if (k != keep && cand[k]) (void)hipFree(cand[k]);
-    s->H = cand[keep];
-    s->V.H = s->H;
-    r.s2.H = s->H;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (pe) (void)hipHostFree(pe);
-    return status;
-}
-
-static int launch_ctl_mask(Run& r, int expect_mask) {
-    qn_solver* s = r.s;
-    ProfScope ps(s, KC_CTL);
-    // fused path: the step only sums per-workgroup partials, one wave per column (9 evaluation + 3 update-pass columns);
-    // generic path: it sweeps n-vectors with 1024 threads
-    const bool hp = (expect_mask & ((1 << QN_PH_REQ_HPASS) | (1 << QN_PH_REQ_HPASS_EVAL))) != 0;
-    const bool ev = (expect_mask & ((1 << QN_PH_REQ_EVAL) | (1 << QN_PH_REQ_HPASS_EVAL))) != 0;
-    const dim3 blk(r.fused ? ((hp && ev) ? 768 : 576) : QN_CTL_TPB);
-    if (r.oracle_tpl == QN_ORACLE_QUAD)
-        hipLaunchKernelGGL(ctl_step_kernel<QN_ORACLE_QUAD>, dim3(1), blk, 0, s->ctx->stream, s->ctl, s->V, expect_mask);
-    else
-        hipLaunchKernelGGL(ctl_step_kernel<QN_ORACLE_GENERIC>, dim3(1), blk, 0, s->ctx->stream, s->ctl, s->V, expect_mask);
-    s->stats.launches++;
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-static int launch_ctl(Run& r, int expect_phase) { return launch_ctl_mask(r, 1 << expect_phase); }
-
-template <int R, int U>
-static void launch_eval_fused(hipStream_t st, const QnEvalFusedArgs& a) {
-    hipLaunchKernelGGL((quad_eval_fused_kernel<R, U>), dim3(a.T.rpr / R), dim3(QN_TPB), 0, st, a);
-}
-template <int R, int U>
-static void launch_hpass_fused(hipStream_t st, const QnHPassFusedArgs& a) {
-    hipLaunchKernelGGL((h_pass_fused_kernel<R, U>), dim3(a.T.rpr / R), dim3(QN_TPB), 0, st, a);
-}
-#define QN_DISPATCH_RU(fn, R_, U_, ...)                                             \
-    do {                                                                            \
-        const int key_ = (R_) * 10 + (U_);                                          \
-        switch (key_) {                                                             \
-        case 21: fn<2, 1>(__VA_ARGS__); break;                                      \
-        case 22: fn<2, 2>(__VA_ARGS__); break;                                      \
-        case 24: fn<2, 4>(__VA_ARGS__); break;                                      \
-        case 41: fn<4, 1>(__VA_ARGS__); break;                                      \
-        case 42: fn<4, 2>(__VA_ARGS__); break;                                      \
-        case 44: fn<4, 4>(__VA_ARGS__); break;                                      \
-        case 82: fn<8, 2>(__VA_ARGS__); break;                                      \
-        case 161: fn<16, 1>(__VA_ARGS__); break;                                    \
-        default: fn<8, 1>(__VA_ARGS__); break;                                      \
-        }                                                                           \
-    } while (0)
-
-static int enqueue_eval_fused(Run& r, int after_h) {
-    qn_solver* s = r.s;
-    qn_context* c = s->ctx;
-    QnEvalFusedArgs a{};
-    a.Q = r.obj->Q; a.T = s->T; a.T.cs = 1; a.F = s->V.F; a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_EVAL;
-    a.after_h = after_h; a.world = c->world;
-    if (r.sym) {
-        QnSymEvalArgs y{};
-        y.Q = r.obj->Q; y.T = a.T; y.F = a.F; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_EVAL; y.after_h = after_h; y.nb = s->sym_nb; y.part = s->sym_part;
-        y.nt = 0; // Q is only read: non-temporal loads measured no gain at n = 32768 and -4 % at n = 16384
-        if (c->world > 1) { // row-sharded: this rank's circulant half, partial sums gathered, epilogue on every rank
-            y.sh = sym_shard(s);
-            {
-                ProfScope ps(s, KC_EVAL);
-                hipLaunchKernelGGL(sym_eval_tile_kernel, dim3(qn_symsh_ntiles(y.nb, y.sh.nbl, y.sh.ioff)), dim3(QN_SYM_TPB), 0, c->stream, y);
-            }
-            {
-                ProfScope ps(s, KC_EREDUCE);
-                hipLaunchKernelGGL(symsh_eval_sum_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
-            }
-            HIPCHK(hipGetLastError());
-            {
-                ProfScope ps(s, KC_COMM);
-                c->n_xchg_vector++;
-                if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, (size_t)s->T.n_pad));
-                else QNCHK(exchange(c, s->symsh_xg, (size_t)s->T.n_pad));
-            }
-            {
-                ProfScope ps(s, KC_EREDUCE);
-                hipLaunchKernelGGL(symsh_eval_epi_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
-            }
-            s->stats.launches += 3;
-            HIPCHK(hipGetLastError());
-            return QN_OK;
-        }
-        {
-            ProfScope ps(s, KC_EVAL);
-            hipLaunchKernelGGL(sym_eval_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
-        }
-        {
-            ProfScope ps(s, KC_EREDUCE);
-            hipLaunchKernelGGL(sym_eval_reduce_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
-        }
-        s->stats.launches += 2;
-        HIPCHK(hipGetLastError());
-        return QN_OK;
-    }
-    {
-        ProfScope ps(s, KC_EVAL);
-        QN_DISPATCH_RU(launch_eval_fused, s->R, s->U, c->stream, a);
-        s->stats.launches++;
-        HIPCHK(hipGetLastError());
-    }
-    if (c->world > 1) {
-        ProfScope ps(s, KC_COMM);
-        const XchgItem items[3] = {{s->V.F.GT, (size_t)s->T.rpr}, {s->V.F.Y, (size_t)s->T.rpr}, {s->V.F.evp, (size_t)QN_NEVP * s->V.F.nblk}};
-        c->n_xchg_vector++;
-        QNCHK(exchange_group(c, items, 3));
-    }
-    return QN_OK;
-}
-
-static int enqueue_hpass_fused(Run& r) {
-    qn_solver* s = r.s;
-    qn_context* c = s->ctx;
-    QnHPassFusedArgs a{};
-    a.H = s->H; a.T = s->T; a.T.cs = 1; a.F = s->V.F; a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_HPASS;
-    if (r.sym) {
-        QnSymHPassArgs y{};
-        y.H = s->H; y.T = a.T; y.F = a.F; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_HPASS; y.nb = s->sym_nb; y.part = s->sym_part;
-        y.nt = s->T.n_pad >= 8192; // past the Infinity Cache (same-box A/B: +7 % at n = 32768, +3 % at 8192, -1 % at 4096)
-        s->h_lower_stale = true;
-        if (c->world > 1) {
-            y.sh = sym_shard(s);
-            {
-                ProfScope ps(s, KC_HPASS);
-                hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(qn_symsh_ntiles(y.nb, y.sh.nbl, y.sh.ioff)), dim3(QN_SYM_TPB), 0, c->stream, y);
-            }
-            {
-                ProfScope ps(s, KC_HREDUCE);
-                hipLaunchKernelGGL(symsh_hpass_sum_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
-            }
-            HIPCHK(hipGetLastError());
-            {
-                ProfScope ps(s, KC_COMM);
-                c->n_xchg_vector++;
-                if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
-                else QNCHK(exchange(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
-            }
-            {
-                ProfScope ps(s, KC_HREDUCE);
-                hipLaunchKernelGGL(symsh_hpass_epi_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
-            }
-            s->stats.launches += 3;
-            HIPCHK(hipGetLastError());
-            return QN_OK;
-        }
-        {
-            ProfScope ps(s, KC_HPASS);
-            hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
-        }
-        {
-            ProfScope ps(s, KC_HREDUCE);
-            hipLaunchKernelGGL(sym_hpass_reduce_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
-        }
-        s->stats.launches += 2;
-        HIPCHK(hipGetLastError());
-        return QN_OK;
-    }
-    {
-        ProfScope ps(s, KC_HPASS);
-        QN_DISPATCH_RU(launch_hpass_fused, s->R, s->U, c->stream, a);
-        s->stats.launches++;
-        HIPCHK(hipGetLastError());
-    }
-    if (c->world > 1) {
-        ProfScope ps(s, KC_COMM);
-        const XchgItem items[3] = {{s->V.F.UN, (size_t)s->T.rpr}, {s->V.F.VV, (size_t)s->T.rpr}, {s->V.F.hpp, (size_t)QN_NHPP * s->V.F.nblk}};
-        c->n_xchg_vector++;
-        QNCHK(exchange_group(c, items, 3));
-    }
-    return QN_OK;
-}
-
-// enqueue the evaluation of the oracle at the requested point (predicated on phase == REQ_EVAL)
-static int enqueue_eval(Run& r, int after_h = 0) {
-    qn_solver* s = r.s;
-    qn_context* c = s->ctx;
-    if (r.fused) return enqueue_eval_fused(r, after_h);
-    if (r.oracle_tpl == QN_ORACLE_QUAD) {
-        QnQuadArgs a{};
-        a.Q = r.obj->Q; a.T = s->T; a.T.cs = s->qcs;
-        a.x = s->V.x; a.d = s->V.d; a.xt = s->V.xt;
-        a.llb = s->V.llb; a.lub = s->V.lub;
-        a.out = s->V.q + (size_t)c->rank * s->qcs * s->T.rpr;
-        a.ctl = s->ctl; a.expect_phase = QN_PH_REQ_EVAL;
-        {
-            ProfScope ps(s, KC_EVAL);
-            QNCHK(launch_quad_R(s->R, c->stream, a));
-            s->stats.launches++;
-        }
-        if (c->world > 1) {
-            ProfScope ps(s, KC_COMM);
-            c->n_xchg_vector++;
-            QNCHK(exchange(c, s->V.q, (size_t)s->qcs * s->T.rpr));
-        }
-        return QN_OK;
-    }
-    hipLaunchKernelGGL(trial_point_kernel, dim3(std::min(1024, (s->T.n_pad + 255) / 256)), dim3(256), 0, c->stream, s->V.x, s->V.d,
-                       s->V.xt, s->T.n_pad, s->ctl, (int)QN_PH_REQ_EVAL, s->V.llb, s->V.lub);
-    s->stats.launches++;
-    HIPCHK(hipGetLastError());
-    if (r.o->kind == QN_ORACLE_HOST) {
-        HIPCHK(hipMemcpyAsync(s->hx, s->V.xt, s->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        s->stats.host_syncs++;
-        double f = NAN;
-        if (r.o->host_fn(r.o->host_user, s->hx, s->n, &f, s->hg) != 0) return fail(QN_ABNORMAL_TERMINATION, "host oracle returned non-zero");
-        s->hg[s->n] = f; // pinned staging: g[0..n) then f
-        HIPCHK(hipMemcpyAsync(s->V.gt, s->hg, s->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(s->f_dev, s->hg + s->n, sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        return QN_OK;
-    }
-    if (r.o->kind == QN_ORACLE_OBJECTIVE) return lse_enqueue_eval(r.obj, s->V.xt, s->f_dev, s->V.gt); // log-sum-exp
-    // device closure
-    if (r.o->device_fn(r.o->device_user, (void*)c->stream, s->V.xt, s->n, s->f_dev, s->V.gt) != 0)
-        return fail(QN_ABNORMAL_TERMINATION, "device oracle returned non-zero");
-    return QN_OK;
-}
-
-static int enqueue_hpass_req(Run& r) {
-    qn_solver* s = r.s;
-    qn_context* c = s->ctx;
-    if (r.fused) return enqueue_hpass_fused(r);
-    if (r.sym_generic) {
-        QnSymHPassArgs y{};
-        y.H = s->H; y.T = s->T; y.T.cs = 1; y.ctl = s->ctl; y.expect_phase = QN_PH_REQ_HPASS; y.nb = s->sym_nb; y.part = s->sym_part;
-        y.generic = 1; y.gsp = s->V.sp; y.gup = s->V.up; y.gvy = s->V.y; y.gvg = s->V.g; y.ghp = s->V.hp;
-        y.nt = s->T.n_pad >= 8192; // past the Infinity Cache (same-box A/B: +7 % at n = 32768, +3 % at 8192, -1 % at 4096)
-        s->h_lower_stale = true;
-        if (c->world > 1) { // row-sharded: the circulant half of this rank's block-rows; partial sums gathered, totals on every rank
-            y.sh = sym_shard(s);
-            {
-                ProfScope ps(s, KC_HPASS);
-                hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(qn_symsh_ntiles(y.nb, y.sh.nbl, y.sh.ioff)), dim3(QN_SYM_TPB), 0, c->stream, y);
-            }
-            {
-                ProfScope ps(s, KC_HREDUCE);
-                hipLaunchKernelGGL(symsh_hpass_sum_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
-            }
-            HIPCHK(hipGetLastError());
-            {
-                ProfScope ps(s, KC_COMM);
-                c->n_xchg_vector++;
-                if (c->use_allreduce) QNCHK(exchange_sum(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
-                else QNCHK(exchange(c, s->symsh_xg, 2 * (size_t)s->T.n_pad));
-            }
-            {
-                ProfScope ps(s, KC_HREDUCE);
-                hipLaunchKernelGGL(symsh_hpass_epi_generic_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
-            }
-            s->stats.launches += 3;
-            HIPCHK(hipGetLastError());
-            return QN_OK;
-        }
-        {
-            ProfScope ps(s, KC_HPASS);
-            hipLaunchKernelGGL(sym_hpass_tile_kernel, dim3(y.nb * (y.nb + 1) / 2), dim3(QN_SYM_TPB), 0, c->stream, y);
-        }
-        {
-            ProfScope ps(s, KC_HREDUCE);
-            hipLaunchKernelGGL(sym_hpass_reduce_kernel, dim3(y.nb), dim3(256), 0, c->stream, y);
-        }
-        s->stats.launches += 2;
-        HIPCHK(hipGetLastError());
-        return QN_OK;
-    }
-    QnHPassArgs a = hpass_args(s, QN_PH_REQ_HPASS);
-    {
-        ProfScope ps(s, KC_HPASS);
-        QNCHK(launch_hpass_R(s, a));
-    }
-    if (c->world > 1) {
-        ProfScope ps(s, KC_COMM);
-        c->n_xchg_vector++;
-        QNCHK(exchange(c, s->V.hp, (size_t)s->hcs * 2 * s->T.rpr));
-    }
-    return QN_OK;
-}
-
-// The second stream of Newton's look-ahead (LU: the bulk of a trailing update beside the next panel's chain).  A panel step's
-// workgroups hold 8 waves of 232 registers -- a CU running even ONE workgroup of the update (4 waves of 196) has no room for them, and
-// a grid of 16 k update workgroups never leaves a CU empty: without a mask the chain waits for the bulk to drain and nothing overlaps
-// (measured: 65.6 ms with the second stream, 65.1 without).  So the bulk's stream may use only `QN_LU_BULK_CUS` of the 256 CUs
-// (default 192: the low mask bits -- 24 CUs of every XCD, tools/cu_mask_probe.hip; the panel's grid is 58 workgroups).
-static int ensure_masked_stream(qn_context* c) {
-    if (c->stream_lu) return QN_OK;
-    static const int bulk_cus = getenv("QN_LU_BULK_CUS") ? atoi(getenv("QN_LU_BULK_CUS")) : 192;
-    uint32_t mask[8];
-    for (int w = 0; w < 8; ++w) mask[w] = 0;
-    const int keep = std::max(32, std::min(256, bulk_cus));
-    for (int b = 0; b < keep; ++b) mask[b >> 5] |= 1u << (b & 31);
-    c->lu_bulk_cus = keep;
-    if (keep >= 256 || hipExtStreamCreateWithCUMask(&c->stream_lu, 8, mask) != hipSuccess) {
-        (void)hipGetLastError();
-        c->lu_bulk_cus = 256;
-        HIPCHK(hipStreamCreateWithFlags(&c->stream_lu, hipStreamNonBlocking));
-    }
-    return QN_OK;
-}
-
-// Pivoted LU of the staged Hessian and the two solves (qn_lu.hip.h); leaves d in V.d, z = H^-1 d in V.s, and newton_fail[0] = 1
-// when a pivot column is exactly zero (then QN_ST_AFTER_NEWTON takes -g, newton/mod.rs:43-46).
-// A bounded wait of the one-launch LU kernels expired (the bound is a number of polls: a co-tenant on the GPU, or workgroups that were
-// not resident together, can do that).  The factorisation is run again launch by launch -- same bits -- and so are the next
-// QN_LU_RETRY_AFTER ones; then the one-launch kernels get another chance (one transient used to cost the solver 54
-// instead of 47 ms per iteration for the rest of its life, invisibly).  Counted in qn_stats.newton_lu_sync_timeouts, said once on stderr.
-#define QN_LU_RETRY_AFTER 8
-static void lu_note_timeout(qn_solver* s) {
-    s->newton_lu_no_persist = 1;
-    s->newton_lu_timeout_fallback = 1;
-    s->newton_lu_sync_timeouts++;
-    s->stats.newton_lu_sync_timeouts = s->newton_lu_sync_timeouts;
-    s->newton_lu_runs--;
-    static std::atomic<int> said{0};
-    if (said.exchange(1) == 0)
-        fprintf(stderr, "[qn] Newton / LU: a bounded wait of the one-launch kernels expired; this factorisation and the next %d run launch by launch "
-                        "(same result, slower; qn_stats.newton_lu_sync_timeouts counts these)\n", QN_LU_RETRY_AFTER);
-}
-static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
-    hipStream_t st = s->ctx->stream;
-    if (s->newton_lu_timeout_fallback && ++s->newton_lu_timeout_fallback > 1 + QN_LU_RETRY_AFTER) { // (the re-run itself is the first)
-        s->newton_lu_timeout_fallback = 0;
-        s->newton_lu_no_persist = 0;
-    }
-    const int n = (int)s->n, n64 = (int)s->newton_n64;
-    const int nlu = (n + QN_NB - 1) / QN_NB * QN_NB; // the factorisation works on whole 64-blocks; identity padding
-    const size_t ld = s->newton_n64;
-    double* W = s->newton_w;
-    int* flag = s->newton_fail;
-    s->newton_lu_runs++;
-    HIPCHK(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
-    hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, W, ld, n, n64, hsrc, ld_src, 0); // both triangles
-    uint64_t launches = 1;
-    const size_t panel_doubles = (size_t)QN_NB * QN_LU_PT * QN_LU_RPT; // (two buffers: the look-ahead writes the next panel's while this one's is still read)
-    if (!s->newton_panel) HIPCHK(hipMalloc((void**)&s->newton_panel, 2 * panel_doubles * sizeof(double)));
-    if (!s->newton_sync) HIPCHK(hipMalloc((void**)&s->newton_sync, 128 * sizeof(int)));
-    HIPCHK(hipMemsetAsync(s->newton_sync, 0, 128 * sizeof(int), st));
-    static const int lu_persist_on = getenv("QN_LU_PERSIST") ? atoi(getenv("QN_LU_PERSIST")) : 1;
-    const bool persist = lu_persist_on && !s->newton_lu_no_persist;
-    const int spin_max = s->newton_lu_force_timeout ? 0 : QN_LU_SPIN_MAX; // (diagnostics: every wait that is not satisfied at once gives up -> the fallback below)
-    // LOOK-AHEAD (round 4, as in the Cholesky path: enqueue_newton).  A panel's factorisation is a chain of 17 small launches (one CU
-    // working through 64 pivot steps: 150-400 us); what it needs from the previous panel is its own 64 columns brought up to date.
-    // So after panel p: its swaps, U12 solve and update on the NEXT panel's columns on this stream, and everything else -- the swaps
-    // on the finished columns left of it, swaps / solve / MFMA update on the columns right of the next panel -- on the context's
-    // second stream beside panel p + 1's chain (events E_p: panel p and its pivots are final; F_p: the bulk of panel p is done, awaited
-    // before the same columns are touched again).  The bulk update caps its occupancy as the Cholesky one does.
-    qn_context* c = s->ctx;
-    static const int lu_la_on = getenv("QN_LU_LOOKAHEAD") ? atoi(getenv("QN_LU_LOOKAHEAD")) : 1;
-    const int npanels = nlu / QN_NB;
-    const bool la = lu_la_on && !s->newton_lu_no_la && npanels >= 8;
-    size_t bulk_lds = 0;
-    if (la) {
-        QNCHK(ensure_masked_stream(c));
-        while ((int)c->la_events.size() < 2 * npanels) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->la_events.push_back(e); }
-        static std::atomic<int> attr_state[64];
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        bulk_lds = (size_t)(80 * 1024 - 2 * QN_NB * (QN_NB + 1) * 8 - 1024); // (two workgroups per CU: room for the chain's on every CU)
-        if (dev >= 0 && dev < 64 && attr_state[dev].load() == 0) {
-            const bool ok = hipFuncSetAttribute((const void*)lu_gemm2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bulk_lds) == hipSuccess;
-            if (!ok) (void)hipGetLastError();
-            attr_state[dev].store(ok ? 1 : 2);
-        }
-        if (dev < 0 || dev >= 64 || attr_state[dev].load() != 1) bulk_lds = 0;
-    }
-    int last_f = -1;
-    static const int la_fused = getenv("QN_LU_LA_FUSED") ? atoi(getenv("QN_LU_LA_FUSED")) : 1;
-    bool p_ready = false; // the look-ahead update of the previous panel has already written this panel's buffer
-    for (int p0 = 0, pi = 0; p0 < nlu; p0 += QN_NB, ++pi) {
-        const int m = nlu - p0;
-        bool in_p = false; // this panel was factorised in its column-major buffer (and, with the fused look-ahead, is not yet back in W)
-        if (m <= QN_LU_PT * QN_LU_RPT && !s->newton_lu_percol) {
-            // the panel in a column-major buffer, four columns at a time (qn_lu.hip.h: 19 launches instead of 128)
-            double* P = s->newton_panel + (size_t)(pi & 1) * panel_doubles;
-            const size_t pld = (size_t)QN_LU_PT * QN_LU_RPT;
-            if (!p_ready) { hipLaunchKernelGGL(lu_panel_load_kernel, dim3(m / QN_NB), dim3(256), 0, st, W, ld, p0, P, pld, flag); launches++; }
-            p_ready = false;
-            in_p = true;
-            const int rpt_p = (m + QN_LU_PT - 1) / QN_LU_PT;
-            if (persist) { // the panel in one launch: 58 workgroups waiting for each other on counters (qn_lu.hip.h)
-                const dim3 pg(2 + QN_NB - 2 * QN_LU_SUB), pb(QN_LU_PT);
-                const int base = 32 * pi;
-                if (rpt_p <= 1) hipLaunchKernelGGL(lu_panel_persist_kernel<1>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max);
-                else if (rpt_p <= 2) hipLaunchKernelGGL(lu_panel_persist_kernel<2>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max);
-                else if (rpt_p <= 4) hipLaunchKernelGGL(lu_panel_persist_kernel<4>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max);
-                else if (rpt_p <= 8) hipLaunchKernelGGL(lu_panel_persist_kernel<8>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max);
-                else hipLaunchKernelGGL(lu_panel_persist_kernel<QN_LU_RPT>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max);
-                launches += 1;
-            } else
-            for (int sp = 0; sp <= QN_NB / QN_LU_SUB; ++sp) {
-                const int ncol_b = sp >= 1 ? std::max(0, QN_NB - QN_LU_SUB * (sp + 1)) : 0; // role B: the columns right of sub-panel sp
-                const int grid = sp == 0 ? 1 : 2 + ncol_b;                                    // (workgroup 1: role C)
-                const int rpt = (m + QN_LU_PT - 1) / QN_LU_PT; // rows per thread: the smallest instantiation that holds the panel
-                if (rpt <= 1) hipLaunchKernelGGL(lu_panel_step_kernel<1>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
-                else if (rpt <= 2) hipLaunchKernelGGL(lu_panel_step_kernel<2>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
-                else if (rpt <= 4) hipLaunchKernelGGL(lu_panel_step_kernel<4>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
-                else if (rpt <= 8) hipLaunchKernelGGL(lu_panel_step_kernel<8>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
-                else hipLaunchKernelGGL(lu_panel_step_kernel<QN_LU_RPT>, dim3(grid), dim3(QN_LU_PT), 0, st, P, pld, m, sp, p0, s->newton_piv, flag);
-            }
-            if (!(la && la_fused)) hipLaunchKernelGGL(lu_panel_store_kernel, dim3(m / QN_NB), dim3(256), 0, st, W, ld, p0, P, pld, flag); // (else: on the second stream, below)
-            launches += 1 + (persist ? 0 : 1 + QN_NB / QN_LU_SUB);
-        } else {
-            for (int k = p0; k < p0 + QN_NB; ++k) {
-                hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(1024), 0, st, W, ld, k, p0, nlu, s->newton_piv, flag);
-                const int below = nlu - k - 1;
-                if (below > 0)
-                    hipLaunchKernelGGL(lu_col_step_kernel, dim3(std::min(1024, (below + 31) / 32)), dim3(256), 0, st, W, ld, k, p0, nlu, flag);
-                launches += 2;
-            }
-        }
-        const int right = nlu - p0 - QN_NB;
-        if (!la) {
-            if (nlu > QN_NB)
-                hipLaunchKernelGGL(lu_swap_rows_kernel, dim3(std::min(256, (nlu + 255) / 256)), dim3(256), 0, st, W, ld, p0, nlu, s->newton_piv, flag);
-            if (right > 0) {
-                hipLaunchKernelGGL(lu_trsm_kernel, dim3((right + 255) / 256), dim3(256), 0, st, W, ld, p0, nlu, flag);
-                hipLaunchKernelGGL(lu_gemm_kernel, dim3(right / QN_NB, right / QN_NB), dim3(256), 0, st, W, ld, p0, flag);
-                launches += 2;
-            }
-            launches++;
-            continue;
-        }
-        const int la_lo = p0 + QN_NB, la_hi = std::min(la_lo + QN_NB, nlu); // the next panel's columns
-        const int below = nlu - la_lo;                                       // rows (and columns) right of / below this panel
-        const bool fused = la_fused && in_p; // the chain's part reads the panel from its buffer; the copy back into W goes to the second stream
-        double* Pc = s->newton_panel + (size_t)(pi & 1) * panel_doubles;
-        double* Pn = s->newton_panel + (size_t)((pi + 1) & 1) * panel_doubles;
-        const size_t pld_c = (size_t)QN_LU_PT * QN_LU_RPT;
-        // the next panel's columns on this stream -- once the previous panel's bulk, which wrote them too, is through
-        if (la_hi > la_lo) {
-            if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
-            if (fused) { // two launches, the second one leaving the next panel in its buffer (qn_lu.hip.h; the next panel is shorter: it fits)
-                hipLaunchKernelGGL(lu_la_swap_trsm_kernel, dim3((la_hi - la_lo + 3) / 4), dim3(256), 0, st, W, ld, p0, la_lo, la_hi, Pc, pld_c, s->newton_piv, flag);
-                hipLaunchKernelGGL(lu_la_gemm_kernel, dim3(below / QN_NB), dim3(256), 0, st, W, ld, p0, la_lo, Pc, pld_c, Pn, flag);
-                p_ready = true;
-                launches += 2;
-            } else {
-                hipLaunchKernelGGL(lu_swap_rows2_kernel, dim3(1), dim3(64), 0, st, W, ld, p0, la_lo, la_hi, s->newton_piv, flag);
-                hipLaunchKernelGGL(lu_trsm2_kernel<1>, dim3((la_hi - la_lo + 3) / 4), dim3(256), 0, st, W, ld, p0, la_lo, la_hi, flag);
-                hipLaunchKernelGGL(lu_gemm2_kernel, dim3(below / QN_NB), dim3(256), 0, st, W, ld, p0, la_lo, 1, below / QN_NB, flag, 1);
-                launches += 3;
-            }
-        }
-        // everything else beside the next panel's chain (the event behind the look-ahead launches, not in front of them: its packet and
-        // the wait's were 13 us between the panel and the first look-ahead kernel.  For the tall panels, whose bulk is as long as the
-        // next panel's chain, in front measured the same: 45.5 against 45.2 ms)
-        HIPCHK(hipEventRecord(c->la_events[2 * pi], st));
-        HIPCHK(hipStreamWaitEvent(c->stream_lu, c->la_events[2 * pi], 0));
-        if (fused) { // the panel back into W, in front of the bulk that reads it there
-            hipLaunchKernelGGL(lu_panel_store_kernel, dim3(m / QN_NB), dim3(256), 0, c->stream_lu, W, ld, p0, Pc, pld_c, flag);
-            launches++;
-        }
-        if (p0 > 0) hipLaunchKernelGGL(lu_swap_rows2_kernel, dim3(std::min(64, (p0 + 255) / 256)), dim3(256), 0, c->stream_lu, W, ld, p0, 0, p0, s->newton_piv, flag);
-        const int rest = nlu - la_hi;
-        if (rest > 0) {
-            hipLaunchKernelGGL(lu_swap_rows2_kernel, dim3(std::min(64, (rest + 255) / 256)), dim3(256), 0, c->stream_lu, W, ld, p0, la_hi, nlu, s->newton_piv, flag);
-            hipLaunchKernelGGL(lu_trsm2_kernel<2>, dim3((rest + 7) / 8), dim3(256), 0, c->stream_lu, W, ld, p0, la_hi, nlu, flag);
-            const int ncb = rest / QN_NB, ntiles = ncb * (below / QN_NB);
-            static const int persist = getenv("QN_LU_BULK_PERSIST") ? atoi(getenv("QN_LU_BULK_PERSIST")) : 0; // (a resident grid that loops: 54.1 ms against 53.5)
-            hipLaunchKernelGGL(lu_gemm2_kernel, dim3(persist ? std::min(ntiles, 2 * c->lu_bulk_cus) : ntiles), dim3(256), bulk_lds, c->stream_lu, W, ld, p0, la_hi, ncb,
-                               ntiles, flag, 0);
-            launches += 3;
-        }
-        HIPCHK(hipEventRecord(c->la_events[2 * pi + 1], c->stream_lu));
-        last_f = pi;
-        launches++;
-    }
-    if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
-    HIPCHK(hipGetLastError());
-    // row permutation: the swaps replayed on the identity (host; this path synchronises per Newton iteration anyway)
-    int lu_failed = 0;
-    HIPCHK(hipMemcpyAsync(s->newton_piv_host.data(), s->newton_piv, (size_t)nlu * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&lu_failed, flag, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    s->stats.host_syncs++;
-    s->stats.launches += launches;
-    if (lu_failed == 2) { // a bounded wait of the one-launch panel gave up (its workgroups were not placed together): one launch per sub-panel for a while
-        lu_note_timeout(s);
-        return enqueue_newton_lu(s, hsrc, ld_src); // (the abandoned attempt's launches stay counted: they ran)
-    }
-    if (lu_failed) return QN_OK; // singular: the control kernel falls back to -g
-    std::vector<int> perm((size_t)nlu);
-    for (int i = 0; i < nlu; ++i) perm[i] = i;
-    for (int k = 0; k < nlu; ++k) std::swap(perm[k], perm[s->newton_piv_host[k]]);
-    HIPCHK(hipMemcpyAsync(s->newton_perm, perm.data(), (size_t)nlu * sizeof(int), hipMemcpyHostToDevice, st));
-    double* x1 = s->newton_x;
-    double* x2 = s->newton_x + n64;
-    const dim3 vg(std::min(1024, (n64 + 255) / 256)), vb(256);
-    int sweeps = 0;
-    auto solve = [&](double* x, double* tmp) { // x <- U^-1 L^-1 x (x already permuted); tmp: scratch
-        if (persist) { // a sweep in one launch: workgroups taking each other's solution blocks as they are published (qn_lu.hip.h)
-            const int nb = nlu / QN_NB; // (`tmp` holds sentinels: lu_vec_perm_kernel; the forward sweep leaves them in `x`, the backward one in `tmp`)
-            hipLaunchKernelGGL(lu_sweep_kernel<false>, dim3(nb), dim3(256), 0, st, W, ld, nb, x, tmp, flag, spin_max);
-            hipLaunchKernelGGL(lu_sweep_kernel<true>, dim3(nb), dim3(256), 0, st, W, ld, nb, tmp, x, flag, spin_max);
-            sweeps += 2;
-            return;
-        }
-        for (int k0 = 0; k0 < nlu; k0 += QN_NB) {
-            const int below = nlu - k0 - QN_NB;
-            hipLaunchKernelGGL(lu_fwd_step_kernel, dim3(std::max(1, std::min(256, (below + 3) / 4))), dim3(256), 0, st, W, ld, k0, nlu, x, tmp);
-        }
-        for (int k0 = nlu - QN_NB; k0 >= 0; k0 -= QN_NB)
-            hipLaunchKernelGGL(lu_bwd_step_kernel, dim3(std::max(1, std::min(256, (k0 + 3) / 4))), dim3(256), 0, st, W, ld, k0, tmp, x);
-    };
-    hipLaunchKernelGGL(lu_vec_perm_kernel, vg, vb, 0, st, x1, s->V.g, s->newton_perm, n, nlu, -1.0, persist ? x2 : nullptr); // P (-g)
-    solve(x1, x2);
-    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.d, x1, n, s->T.n_pad, 1.0); // d = -(H^-1 g)
-    hipLaunchKernelGGL(lu_vec_perm_kernel, vg, vb, 0, st, x2, s->V.d, s->newton_perm, n, nlu, 1.0, persist ? x1 : nullptr); // P d
-    solve(x2, x1);
-    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.s, x2, n, s->T.n_pad, 1.0); // z = H^-1 d
-    HIPCHK(hipGetLastError());
-    s->stats.launches += 4 + (persist ? 4 : 4 * (uint64_t)(nlu / QN_NB));
-    if (persist) HIPCHK(hipMemcpyAsync(&lu_failed, flag, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st)); // `perm` is a local
-    if (persist && lu_failed == 2) { // a bounded wait of a one-launch sweep gave up: the whole factorisation again, launch by launch
-        lu_note_timeout(s);
-        return enqueue_newton_lu(s, hsrc, ld_src);
-    }
-    return QN_OK;
-}
-
-static int enqueue_newton(qn_solver* s, const qn_oracle* o, qn_objective* obj) {
-    qn_context* c = s->ctx;
-    hipStream_t st = c->stream;
-    QNCHK(newton_alloc(s));
-    const int n = (int)s->n, n64 = (int)s->newton_n64;
-    const size_t ld = s->newton_n64;
-    // the Hessian at x_k: a device objective's own matrix, or the host closure's (uploaded)
-    const double* hsrc = nullptr;
-    size_t ld_src = 0;
-    bool symmetric = true; // the Cholesky path reads the lower triangle only: it needs H == H' bit for bit
-    if (obj) { hsrc = obj->Q; ld_src = (size_t)obj->T.n_pad; symmetric = obj->q_symmetric; }
-    else {
-        if (!s->newton_hsrc) HIPCHK(hipMalloc((void**)&s->newton_hsrc, (size_t)n * n * sizeof(double)));
-        s->newton_hhost.resize((size_t)n * n * 2);
-        HIPCHK(hipMemcpyAsync(s->hx, s->V.x, s->n * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        double* hc = s->newton_hhost.data();           // column-major from the closure (DMatrix)
-        double* hr = s->newton_hhost.data() + (size_t)n * n; // row-major for the device
-        if (o->host_hessian_fn(o->host_user, s->hx, s->n, hc) != 0) return fail(QN_ABNORMAL_TERMINATION, "host Hessian callback failed");
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) {
-                hr[(size_t)i * n + j] = hc[i + (size_t)j * n];
-                if (j > i && hc[i + (size_t)j * n] != hc[j + (size_t)i * n]) symmetric = false;
-            }
-        HIPCHK(hipMemcpyAsync(s->newton_hsrc, hr, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, st));
-        hsrc = s->newton_hsrc; ld_src = (size_t)n;
-    }
-    HIPCHK(hipMemsetAsync(s->newton_fail, 0, 2 * sizeof(int), st));
-    if (s->hctl->small_n) { // reference-order arithmetic, one thread
-        hipLaunchKernelGGL(newton_small_kernel, dim3(1), dim3(64), 0, st, hsrc, ld_src, n, s->V.g, s->V.d, s->V.s, s->newton_fail);
-        HIPCHK(hipGetLastError());
-        return QN_OK;
-    }
-    if (!symmetric || s->newton_force_lu) return enqueue_newton_lu(s, hsrc, ld_src);
-    s->newton_chol_runs++;
-    hipLaunchKernelGGL(newton_stage_kernel, dim3(2048), dim3(256), 0, st, s->newton_w, ld, n, n64, hsrc, ld_src, 1); // (the lower block triangle)
-    // blocked right-looking Cholesky, lower triangle in place.  Outer blocks of 256 columns: each 64-column panel is
-    // factorised and applied to the REST OF ITS OUTER BLOCK only; the trailing matrix then takes one depth-256 update.
-    // (Look-ahead -- the next block's diag/panel chain on this stream beside the bulk update on a second, low-priority
-    // stream -- was measured and dropped: the chain's single-workgroup kernels sat behind the bulk kernel's ~10^4
-    // workgroups until it drained, 21 us -> 240-280 us each, and the iteration got 7 % slower.)
-    const int KB = 4 * QN_NB;
-    // LOOK-AHEAD (round 4).  The chain of an outer block -- 4 x (diagonal block, panel, in-block update): ~150 us of small, dependent
-    // kernels -- needs only the block's own 256 columns up to date; the rest of the trailing matrix (up to 0.4 ms of MFMA work per
-    // block at n = 8192) is needed one block later.  So the trailing update is cut in two: the next block's columns on the solver's
-    // stream, the rest on a second stream, ordered by events (E_b: block b's panel columns are final; F_b: the bulk of block b is
-    // done, awaited before the look-ahead columns of block b + 1 are touched again).  Round 1 measured this and dropped it: the
-    // chain's one-workgroup kernels starved behind the bulk grid's 10^4 workgroups (21 us -> 240-280 us each).  What is different
-    // now: the bulk launch asks for so much LDS that only QN_CHOL_BULK_WGS (2) of its workgroups fit a CU, which leaves wave slots,
-    // registers and LDS on EVERY CU for the chain's workgroups the moment they are launched, and the chain's kernels raise their
-    // waves' priority (s_setprio).  Measured at n = 8192 (tools/newton_time.py, tools/chol_timeline.py): 9.93-9.97 -> 9.34-9.41 ms per
-    // Newton iteration.  The bulk keeps its pace (16.3 GFLOP in 360 us = 45 TFLOP/s for the first block), the chain's kernels take
-    // twice their solo time beside it (diagonal block 22 -> 29-40 us, panel 7 -> 10-19, in-block update 9 -> 20-26): the first ten
-    // blocks are bound by the bulk, the rest by the chain.  Also measured: the bulk stream restricted to 192-240 CUs
-    // (hipExtStreamCreateWithCUMask; the chain's workgroups still land on busy CUs: no gain), 1, 3 and 4 bulk workgroups per CU.
-    static const int la_on = getenv("QN_CHOL_LOOKAHEAD") ? atoi(getenv("QN_CHOL_LOOKAHEAD")) : 1;
-    static const int bulk_wgs = getenv("QN_CHOL_BULK_WGS") ? std::max(1, atoi(getenv("QN_CHOL_BULK_WGS"))) : 2;
-    const int nblocks = (n64 + KB - 1) / KB;
-    const bool la = la_on && nblocks >= 4;
-    static const int chol_masked = getenv("QN_CHOL_BULK_MASKED") ? atoi(getenv("QN_CHOL_BULK_MASKED")) : 0;
-    if (la) {
-        if (!c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        if (chol_masked) QNCHK(ensure_masked_stream(c));
-        while ((int)c->la_events.size() < 2 * nblocks) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->la_events.push_back(e); }
-    }
-    // (static LDS of chol_syrk_kernel: 2 x 32 x 65 doubles + the diagonal step's vectors = 35 KB; the CU has 160 KB: the dynamic part tops a workgroup up to 160 / bulk_wgs)
-    size_t bulk_lds = (size_t)std::max(0, (160 * 1024) / bulk_wgs - 36 * 1024);
-    if (la && bulk_lds > 0) { // (more than the default 64 KB per workgroup needs the attribute; refused: run the bulk without the cap)
-        static std::atomic<int> attr_state[64];
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && attr_state[dev].load() == 0) {
-            const bool ok = hipFuncSetAttribute((const void*)chol_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bulk_lds) == hipSuccess;
-            if (!ok) (void)hipGetLastError();
-            attr_state[dev].store(ok ? 1 : 2);
-        }
-        if (dev < 0 || dev >= 64 || attr_state[dev].load() != 1) bulk_lds = 0;
-    }
-    int last_f = -1;
-    static const int chol_fuse = getenv("QN_CHOL_FUSE_DIAG") ? atoi(getenv("QN_CHOL_FUSE_DIAG")) : 1;
-    static const int chol_left = getenv("QN_CHOL_LEFT") ? atoi(getenv("QN_CHOL_LEFT")) : 0;
-    bool diag_done = false;
-    hipStream_t bulk_st = (la && chol_masked) ? c->stream_lu : c->stream2;
-    for (int K0 = 0, b = 0; K0 < n64; K0 += KB, ++b) {
-        const int Kend = std::min(K0 + KB, n64);
-        for (int k0 = K0; k0 < Kend; k0 += QN_NB) {
-            double* invl = s->newton_invl + (size_t)(k0 / QN_NB) * QN_NB * QN_NB;
-            // (the diagonal block's factor and inverse: a launch of its own for the first block only -- afterwards the update that
-            // produced the block went on to factorise it, chol_syrk_kernel's invL_next)
-            if (!diag_done) { hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(256), 0, st, s->newton_w, ld, k0, invl, s->newton_fail); s->stats.launches++; }
-            diag_done = false;
-            const int nrt = (n64 - k0 - QN_NB) / QN_NB; // row tiles below the diagonal block
-            if (nrt > 0) hipLaunchKernelGGL(chol_panel_kernel, dim3(nrt), dim3(256), 0, st, s->newton_w, ld, k0, invl, s->newton_fail);
-            const int nct = (Kend - k0 - QN_NB) / QN_NB; // column tiles left in this outer block
-            if (nrt > 0 && nct > 0) {
-                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nrt, nct)), dim3(256), 0, st, s->newton_w, ld, k0, QN_NB, k0 + QN_NB, nct, s->newton_fail, 1,
-                                   chol_fuse ? invl + QN_NB * QN_NB : nullptr);
-                diag_done = chol_fuse;
-            }
-            s->stats.launches += 2;
-        }
-        const int nt = (n64 - Kend) / QN_NB;
-        if (nt > 0 && la && chol_left) {
-            // LEFT-LOOKING second stream (round 4; measured, NOT the default: QN_CHOL_LEFT=1).  With the right-looking bulk -- block b's panel
-            // applied to everything right of the next block, beside chain b + 1 -- the first ten outer blocks are bound by the bulk (345 us
-            // of MFMA work against a 240 us chain) and the last twenty by the chain with the second stream nearly idle: 9.1 ms where the
-            // chain alone is ~5.5.  The same flops in another order: what block column b + 2 owes to ALL the panels so far (0 .. b) as ONE
-            // update of depth 256 (b + 1), launched on the second stream as soon as chain b is through and awaited a whole chain period
-            // later, before this stream adds panel b + 1's part.  Every tile is then read and written once, and the chain never waits for
-            // more than four tile columns.  Measured: 10.7 ms against 9.1 -- the deep, narrow updates of the last third (10-150 tiles of
-            // depth 5000-7700: one workgroup per CU, each 32-deep chunk a global-load round trip nothing hides: 1.2 us against 0.43 us of
-            // MFMA work) take 220-380 us where a chain period is 170, and in the middle third a panel kernel of the chain was seen
-            // waiting 150 us for CUs beside them (profiles/r04_j_*).  What it needs is an update kernel that is efficient at one workgroup
-            // per CU (deeper prefetch, 64 x 128 tiles: a 64 x 64 tile at full MFMA rate asks a CU for 77 KB/us, more than it takes in).
-            const int nla = std::min(KB / QN_NB, nt);
-            if (nt > nla) { // J_{b+2}: block column b + 2 (tile columns nla .. 2 nla - 1 right of Kend) -= panels [0, Kend) ...
-                const int ncj = std::min(KB / QN_NB, nt - nla);
-                HIPCHK(hipEventRecord(c->la_events[2 * b], st));
-                HIPCHK(hipStreamWaitEvent(bulk_st, c->la_events[2 * b], 0));
-                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt - nla, ncj)), dim3(256), bulk_lds, bulk_st, s->newton_w, ld, 0, Kend, Kend + nla * QN_NB, ncj,
-                                   s->newton_fail, 0);
-                HIPCHK(hipEventRecord(c->la_events[2 * b + 1], bulk_st));
-                s->stats.launches++;
-            }
-            // ... and block column b + 1 -= panel b on this stream, once J_{b+1} (launched a chain period ago) has brought it up to panel b - 1
-            if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
-            last_f = nt > nla ? b : -1;
-            hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt, nla)), dim3(256), 0, st, s->newton_w, ld, K0, Kend - K0, Kend, nla, s->newton_fail, 1,
-                               chol_fuse ? s->newton_invl + (size_t)(Kend / QN_NB) * QN_NB * QN_NB : nullptr);
-            diag_done = chol_fuse;
-            s->stats.launches++;
-        } else if (nt > 0) {
-            const int nla = la ? std::min(KB / QN_NB, nt) : nt; // tile columns of the next outer block
-            // Round 5: in the FIRST THIRD of the outer blocks -- where the bulk, not the chain, sets the pace (tools/chol_timeline.py: periods of
-            // 470 ... 250 us against a chain of 240) -- the bulk may start as soon as this block's panels are final, BESIDE the look-ahead
-            // columns' update instead of behind it: the two touch different columns.  The second stream then never idles there.  Not later:
-            // where the chain is the pace, the look-ahead update is a link of it and runs slower beside a bulk.  Measured at n = 8192, alternating:
-            // 9.00-9.14 -> 8.92-8.98 ms per Newton iteration (QN_CHOL_EARLY_BULK = 0 / 6 / 10 / 14 / 32 blocks: 9.05 / 8.96 / 8.95 / 8.96 / 9.05).
-            // The gain is small because the first third does MFMA work back to back either way: what would shorten it is moving flops into the last
-            // two thirds, where the second stream is mostly idle -- the left-looking order, which needs an update kernel that is efficient on
-            // deep, narrow updates (see above).
-            // Also measured and dropped in round 5 (same tool, alternating): the look-ahead columns in TWO launches -- the first 64-column strip,
-            // which the chain's next link needs, on this stream, strips 1..3 on a third stream beside it, awaited in front of the next block's first
-            // in-block update: the strip-0 launch is 42 us instead of 60, but two more event pairs sit in the chain (7-8 us each) and the first
-            // in-block update still runs beside the freshly started bulk at twice its solo time: 8.9-9.0 -> 9.2-9.4 ms; and the bulk at ONE
-            // workgroup per CU in the chain-paced blocks: 9.03-9.06 ms either way.
-            static const int chol_early_env = getenv("QN_CHOL_EARLY_BULK") ? atoi(getenv("QN_CHOL_EARLY_BULK")) : -1;
-            const int chol_early = chol_early_env >= 0 ? chol_early_env : nblocks / 3;
-            const bool early = la && nt > nla && b < chol_early;
-            if (early) {
-                HIPCHK(hipEventRecord(c->la_events[2 * b], st));
-                HIPCHK(hipStreamWaitEvent(bulk_st, c->la_events[2 * b], 0));
-            }
-            // the next block's columns on this stream -- once the PREVIOUS bulk, which wrote them too, is through -- ...
-            if (la && last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
-            hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt, nla)), dim3(256), 0, st, s->newton_w, ld, K0, Kend - K0, Kend, nla, s->newton_fail, la ? 1 : 0,
-                               chol_fuse ? s->newton_invl + (size_t)(Kend / QN_NB) * QN_NB * QN_NB : nullptr);
-            diag_done = chol_fuse;
-            s->stats.launches++;
-            // ... then the bulk, beside the next block's chain.  (Launched BEFORE the look-ahead columns -- it needs only this block's
-            // panel -- it measured slower: 9.43-9.64 ms per Newton iteration against 9.34-9.41, three alternating runs; the chain of
-            // the next block then runs under contention from its first kernel on.)
-            if (nt > nla) {
-                if (!early) {
-                    HIPCHK(hipEventRecord(c->la_events[2 * b], st));
-                    HIPCHK(hipStreamWaitEvent(bulk_st, c->la_events[2 * b], 0));
-                }
-                hipLaunchKernelGGL(chol_syrk_kernel, dim3(qn_tri_tiles(nt - nla, nt - nla)), dim3(256), bulk_lds, bulk_st, s->newton_w, ld, K0, Kend - K0,
-                                   Kend + nla * QN_NB, nt - nla, s->newton_fail, 0);
-                s->stats.launches++;
-            }
-            if (nt > nla) { HIPCHK(hipEventRecord(c->la_events[2 * b + 1], bulk_st)); last_f = b; }
-        }
-    }
-    if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
-    HIPCHK(hipGetLastError());
-    if (s->newton_big) QNCHK(newton_build_block_inverses(s));
-    // d = -(H^-1 g) ; z = H^-1 d
-    double* x1 = s->newton_x;
-    double* x2 = s->newton_x + n64;
-    const dim3 vg(std::min(1024, (n64 + 255) / 256)), vb(256);
-    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, x1, s->V.g, n, n64, -1.0);
-    QNCHK(newton_tri_solve(s, x1, x2));
-    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.d, x1, n, s->T.n_pad, 1.0);
-    QNCHK(newton_tri_solve(s, x1, x2)); // the first solve's result is the second's right-hand side
-    hipLaunchKernelGGL(newton_vec_kernel, vg, vb, 0, st, s->V.s, x1, n, s->T.n_pad, 1.0);
-    HIPCHK(hipGetLastError());
-    s->stats.launches += 4 + (s->newton_big ? 0 : 4 * (uint64_t)(n64 / QN_NB));
-    // Not positive definite?  The reference's LU inverts any non-singular matrix (newton/mod.rs:36-41): take the pivoted-LU path.
-    // (The flag is read here, after everything was enqueued, so the convex case keeps its launch pipeline; the caller
-    // synchronises right after this function anyway.)
-    int chol_failed = 0;
-    HIPCHK(hipMemcpyAsync(&chol_failed, s->newton_fail, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    s->stats.host_syncs++;
-    if (chol_failed) return enqueue_newton_lu(s, hsrc, ld_src);
-    return QN_OK;
-}
-
-static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, size_t max_iter_solver, size_t max_iter_line_search,
-                         qn_callback_fn callback, void* callback_user, int ls_only, double ls_f0);
-
-extern "C" int qn_minimize(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, size_t max_iter_solver,
-                           size_t max_iter_line_search, qn_callback_fn callback, void* callback_user) {
-    return minimize_impl(s, ls, o, max_iter_solver, max_iter_line_search, callback, callback_user, 0, 0.0);
-}
-
-// LineSearch::compute_step_len (line_search/mod.rs:14-23) on its own: the same device state machine entered at the line search
-extern "C" int qn_compute_step_len(qn_context* ctx, qn_linesearch* ls, const double* x_k_host, double f_k, const double* g_k_host,
-                                   const double* direction_host, size_t n, const qn_oracle* oracle, size_t max_iter, double* step_out) {
-    if (!ctx || !ls || !x_k_host || !g_k_host || !direction_host || !oracle || !step_out || n == 0)
-        return fail(QN_ERROR_INPUT_PARAMS, "null argument");
-    qn_solver* s = nullptr;
-    QNCHK(qn_solver_create(ctx, QN_GRADIENT_DESCENT, 0.0, x_k_host, n, &s)); // owns x and the work vectors; no inverse Hessian
-    int st = QN_OK;
-    hipError_t e = hipMemcpyAsync(s->V.g, g_k_host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(s->V.d, direction_host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) st = fail(QN_ABNORMAL_TERMINATION, std::string("compute_step_len upload: ") + hipGetErrorString(e));
-    if (st == QN_OK) st = minimize_impl(s, ls, oracle, 1, max_iter, nullptr, nullptr, 1, f_k);
-    if (st == QN_OK) *step_out = s->hctl->ls_result;
-    qn_solver_destroy(s);
-    return st;
-}
-
-static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, size_t max_iter_solver, size_t max_iter_line_search,
-                         qn_callback_fn callback, void* callback_user, int ls_only, double ls_f0) {
-    if (!s || !ls || !o) return fail(QN_ERROR_INPUT_PARAMS, "null argument");
-    qn_context* c = s->ctx;
-    HIPCHK(hipSetDevice(c->device));
-    Run r{s, o, nullptr, QN_ORACLE_GENERIC, false};
-    const uint64_t xv0 = c->n_xchg_vector, xs0 = c->n_xchg_scalar; // (collectives of this call, for qn_stats)
-    if (o->kind == QN_ORACLE_OBJECTIVE) {
-        if (!o->objective) return fail(QN_ERROR_INPUT_PARAMS, "objective is null");
-        if (o->objective->ctx != c || o->objective->n != s->n) return fail(QN_ERROR_INPUT_PARAMS, "objective does not match the solver");
-        r.obj = o->objective;
-        if (r.obj->kind == OBJ_QUADRATIC) { r.oracle_tpl = QN_ORACLE_QUAD; s->V.b = r.obj->b; }
-        else if (r.obj->kind == OBJ_LOGSUMEXP) r.oracle_tpl = QN_ORACLE_GENERIC; // evaluated by its own kernels into (f_dev, gt)
-        else return fail(QN_ERROR_INPUT_PARAMS, "unsupported objective");
-    } else if (o->kind == QN_ORACLE_HOST) {
-        if (!o->host_fn) return fail(QN_ERROR_INPUT_PARAMS, "host oracle is null");
-    } else if (o->kind == QN_ORACLE_DEVICE_FN) {
-        if (!o->device_fn) return fail(QN_ERROR_INPUT_PARAMS, "device oracle is null");
-    } else return fail(QN_ERROR_INPUT_PARAMS, "unknown oracle kind");
-    if (ls->kind < QN_LS_MORETHUENTE || ls->kind > QN_LS_BACKTRACKING_B) return fail(QN_ERROR_INPUT_PARAMS, "unknown line search");
-    const bool ls_bounded = ls->kind == QN_LS_MORETHUENTE_B || ls->kind == QN_LS_BACKTRACKING_B;
-    if (ls_bounded || s->bounded) {
-        QNCHK(bounds_alloc(s));
-        if (ls_bounded) {
-            QNCHK(bounds_upload(s, s->bounds_block + 2 * (size_t)s->T.n_pad, ls->lower_bound_host, -INFINITY));
-            QNCHK(bounds_upload(s, s->bounds_block + 3 * (size_t)s->T.n_pad, ls->upper_bound_host, INFINITY));
-        }
-    }
-    { // what the stored direction of a bounded second-generation run was formed FOR: the line search's kind and box.  A warm call keeps the direction
-      // (and the clip of t_max, QnCtl.mtb_cand) only when both are what they were (the reference recomputes the clip in every
-      // compute_step_len, morethuente_b.rs:185-201 -- a call with another box must go through QN_PH_REQ_DIR again).
-        std::vector<double> box;
-        if (ls_bounded) {
-            box.assign(2 * s->n, 0.0);
-            for (size_t i = 0; i < s->n; ++i) { box[i] = ls->lower_bound_host ? ls->lower_bound_host[i] : -INFINITY; box[s->n + i] = ls->upper_bound_host ? ls->upper_bound_host[i] : INFINITY; }
-        }
-        s->ls_box_changed = ls->kind != s->last_ls_kind || box.size() != s->last_ls_box.size() ||
-                            (!box.empty() && memcmp(box.data(), s->last_ls_box.data(), box.size() * sizeof(double)) != 0);
-        s->last_ls_kind = ls->kind;
-        s->last_ls_box.swap(box);
-    }
-    if (s->method == QN_NEWTON) {
-        if (c->world > 1) return fail(QN_ERROR_INPUT_PARAMS, "Newton is single-GPU (SURVEY.md 8(f) row f2)");
-        if (!(r.obj && r.obj->kind == OBJ_QUADRATIC) && !(o->kind == QN_ORACLE_HOST && o->host_hessian_fn))
-            return fail(QN_ERROR_INPUT_PARAMS, "Hessian not available in the oracle"); // newton/mod.rs:34 .expect(...)
-        QNCHK(newton_alloc(s));
-    }
-
-    // configuration -> control block (state carried over from earlier runs: x, H, pending update, s_norm, y_norm)
-    QnCtl* h = s->hctl;
-    h->tol = s->tol;
-    h->max_iter = (int64_t)std::min<size_t>(max_iter_solver, (size_t)1 << 62);
-    h->max_iter_ls = (int64_t)std::min<size_t>(max_iter_line_search, (size_t)1 << 62);
-    h->method = s->method;
-    h->ls_kind = ls->kind;
-    h->memoize = o->memoize ? 1 : 0;
-    h->callback_mode = callback ? 1 : 0;
-    h->mt_c1 = ls->c1; h->mt_c2 = ls->c2; h->mt_tmin = ls->t_min; h->mt_tmax = ls->t_max; h->mt_delta = ls->delta;
-    h->bt_c1 = ls->bt_c1; h->bt_beta = ls->bt_beta;
-    h->trace_cap = (int64_t)s->trace_cap;
-    h->trace_x = s->trace_x;
-    h->bounded = s->bounded;
-    h->req_project = 0; h->last_projected = 0; s->mtb_cand_keep = h->mtb_cand; h->mtb_cand = INFINITY;
-    h->ls_only = ls_only;
-    if (ls_only) { h->f_k = ls_f0; h->have_cur_eval = 0; h->have_dir = 0; h->last_valid = 0; }
-    h->small_n = (s->n <= QN_SMALL_N && c->world == 1) ? 1 : 0;
-    if (h->small_n && h->pending) QNCHK(flush_pending(s));
-    // fused fast path: device quadratic, memoised, BFGS/DFP, no callback, one column split, n > 5
-    // Bounded variants (row f4): BFGSB / DFPB and MoreThuenteB run on the second-generation symmetric path when everything that path needs
-    // holds (one rank, whole 128-blocks without padding, a symmetric Q, bitwise symmetric H) -- s2_dir_kernel, qn_sym2.hip.h; BackTrackingB
-    // (projected trial points), SR1B and everything else bounded keep the generic path.  QN_S2_BND=0 switches it off (tests: generic path).
-    const bool s2b = (s->bounded || ls_bounded) && ls->kind != QN_LS_BACKTRACKING_B && !ls_only && c->world == 1 && (s->T.n_pad % QN_TB) == 0 &&
-                     s->T.n_pad >= 8 * QN_TB && (size_t)s->T.n_pad == s->n && !s->no_sym && !s->no_sym2 && !s->h_nonsym && r.obj && r.obj->q_symmetric &&
-                     !s->no_s2bnd && !(getenv("QN_S2_BND") && atoi(getenv("QN_S2_BND")) == 0);
-    // SR1 (sr1_b.rs; row f4) has its three-term update only in the second-generation kernels (s2_hpass_kernel<.., SR1>): it takes the fused path
-    // exactly when that path will be taken -- the same structural conditions as the bounded variants'.
-    const bool s2_struct = !ls_only && c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && (size_t)s->T.n_pad == s->n && !s->no_sym &&
-                           !s->no_sym2 && !s->h_nonsym && r.obj && r.obj->q_symmetric && !s->no_s2bnd && !(getenv("QN_S2_BND") && atoi(getenv("QN_S2_BND")) == 0);
-    const bool sr1_s2 = s->method == QN_SR1 && s2_struct && ls->kind != QN_LS_BACKTRACKING_B;
-    r.fused = r.oracle_tpl == QN_ORACLE_QUAD && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP || sr1_s2) && !callback && s->hcs == 1 &&
-              s->qcs == 1 && !h->small_n && !s->no_fused && (!(s->bounded || ls_bounded) || s2b);
-    // ... and the log-sum-exp objective in the structure of the second-generation path (qn_sym2g.hip.h; round 5): one rank, its one-pass
-    // evaluation (n <= 16384), whole 128-blocks without padding, a bitwise symmetric H.  Everything else keeps the generic path.
-    r.gobj = r.obj && r.obj->kind == OBJ_LOGSUMEXP && r.obj->lse_kch && !r.obj->lse_two_pass && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP) &&
-             !callback && s->hcs == 1 && !h->small_n && !s->no_fused && !s->bounded && !ls_bounded && !ls_only &&
-             (c->world == 1 ? (s->T.n_pad % QN_TB) == 0 : ((s->T.rpr % QN_TB) == 0 && c->world <= 64 && (c->comm || c->host_xchg || c->host_async))) &&
-             s->T.n_pad >= 8 * QN_TB && (size_t)s->T.n_pad == s->n && !s->no_sym && !s->no_sym2 && !s->h_nonsym &&
-             !(getenv("QN_S2G") && atoi(getenv("QN_S2G")) == 0);
-    if (r.gobj) r.fused = true;
-    h->fused = r.fused ? 1 : 0;
-    s->V.fused_hint = h->fused;
-    // ... and on the upper block triangle only (half the bytes) when H and Q are whole 128-tiles on one rank
-    const bool sym_ok = c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
-    // ... row-sharded: every rank streams the circulant half of its own block-rows (whole 128-row blocks per rank)
-    const bool symsh_ok = c->world > 1 && (s->T.rpr % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && !s->no_sym && !s->h_nonsym;
-    r.sym = r.fused && (sym_ok || symsh_ok) && r.obj && (r.obj->q_symmetric || r.gobj);
-    // the generic path's H pass alone (closures, log-sum-exp objective, SR1, bounded variants): same tiles, sums into V.hp
-    r.sym_generic = !r.fused && (sym_ok || symsh_ok) && s->H && s->hcs == 1 && (s->method == QN_BFGS || s->method == QN_DFP || s->method == QN_SR1);
-    if ((r.sym || r.sym_generic) && c->world > 1) QNCHK(solver_alloc_symsh_lists(s));
-    if (r.sym_generic) {
-        if (c->world > 1 && !s->symsh_xg) QNCHK(dev_alloc_zero(&s->symsh_xg, (size_t)c->world * 2 * s->T.n_pad, c->stream));
-        const int nb = s->T.n_pad / QN_TB;
-        if (s->sym_nb != nb) {
-            if (s->sym_part) { HIPCHK(hipFree(s->sym_part)); s->sym_part = nullptr; }
-            QNCHK(dev_alloc_zero(&s->sym_part, (size_t)nb * nb * 2 * QN_TB, c->stream));
-            s->sym_nb = nb;
-        }
-    }
-    // (the second-generation kernels keep no padding entries at zero; row-sharded: the SHARD instantiations, qn_sym2sh.hip.h)
-    r.sym2 = r.sym && !s->no_sym2 && (size_t)s->T.n_pad == s->n && (c->world == 1 || c->world <= 64);
-    h->sym2 = r.sym2 ? 1 : 0;
-    r.bnd = r.sym2 && (s->bounded || ls_bounded || s->method == QN_SR1); // (SR1: the BND prologues also carry its third update-reduce column)
-    if ((s->bounded || ls_bounded) && r.fused && !r.bnd) return fail(QN_ABNORMAL_TERMINATION, "bounded run on a fused path that is not the second-generation one");
-    if (s->method == QN_SR1 && r.fused && !r.sym2) return fail(QN_ABNORMAL_TERMINATION, "SR1 on a fused path that is not the second-generation one");
-    h->s2_dir = r.bnd ? ((s->bounded ? 1 : 0) | (ls->kind == QN_LS_MORETHUENTE_B ? 2 : 0)) : 0;
-    r.dirq = h->s2_dir != 0; // (the stored-direction launch is part of the pattern only where a direction asks for it)
-    if (r.bnd && ls->kind == QN_LS_MORETHUENTE_B) h->ls_kind = QN_LS_MORETHUENTE; // (the clip of t_max is applied where the direction's request is consumed: from there on it IS More-Thuente)
-    // WHICH KERNEL STREAMS THE UPDATE PASS OF A ROW-SHARDED RUN (round 5).  The one-workgroup-per-CU kernel of
-    // qn_sym2.hip.h (16-row register windows, the machine in its prologue) was built for n = 4096, where a launch is a twelfth of the
-    // iteration.  On one rank of the P = 8, n = 32768 partition -- 4112 tiles, 16 per workgroup, 1074 MB read and written back -- it takes
-    // 222 us (4.85 TB/s); the first-generation tile kernel (one workgroup per tile, two per CU, 8-row windows: nothing to balance, no
-    // prologue, no per-workgroup ramp) streams the same tiles in 166 us = 6.47 TB/s = 0.81 of the roofline, and the one-workgroup
-    // launch that then runs the machine in front of it costs 7.6 us: 459.6 -> 413.4 us of kernels per iteration on that rank
-    // (profiles/r05_l_*; one rank replayed alone with the other ranks' recorded data, the replay reproducing the recorded bits).
-    // On ONE GPU the choice does not matter past the cache -- the lists are long, the fixed parts amortised: n = 16384 404 -> 382 us per
-    // pass but 1249 -> 1241 it/s with the extra launch, n = 32768 1.575 -> 1.562 ms, 320 -> 324 it/s (profiles/r05_m_*) -- and inside the
-    // cache the second-generation kernel is the faster one.  So: a row-sharded run whose share of H's half is beyond 320 MB (the size
-    // from which both matrices are streamed non-temporally anyway) -> first-generation tiles; everything else -> the second-
-    // generation kernel.  QN_S2_GEN1_TILES=0 / 1 overrides (any rank count).
-    {
-        const size_t hhalf = c->world > 1 ? (size_t)s->T.rpr * s->T.n_pad * 8 / 2 : (size_t)s->T.n_pad * s->T.n_pad * 8 / 2;
-        r.tiles1 = r.sym2 && !r.gobj && c->world > 1 && hhalf > ((size_t)320 << 20);
-        if (r.sym2 && !r.gobj && getenv("QN_S2_GEN1_TILES")) r.tiles1 = atoi(getenv("QN_S2_GEN1_TILES")) != 0;
-    }
-    h->serviced = 0; h->ev_par = 0; h->ev_kind = QN_REQ_X; h->ev_t = 0.0; h->spec_tiles = 0;
-    h->defer_u = 0;
-    h->no_defer = s->no_defer;
-    if (!r.fused) QNCHK(fused_export(s)); // another path takes over: it works on the canonical buffers
-    if (!(r.sym || r.sym_generic) || (s->h_diag_stale && (!r.sym2 || (r.gobj && c->world == 1) || r.tiles1))) QNCHK(ensure_full_h(s)); // ... and on whole rows of H (or whole diagonal tiles: the first-generation tile kernel, which the generic-objective path runs too, reads them whole)
-    if (r.fused) {
-        QNCHK(solver_alloc_fused(s, r.sym));
-        s->V.F.pworld = r.sym ? 1 : c->world; // symmetric storage: every rank forms all the per-block partial sums itself
-        if (r.sym && c->world > 1 && !s->symsh_xg) QNCHK(dev_alloc_zero(&s->symsh_xg, (size_t)c->world * 2 * s->T.n_pad, c->stream));
-        s->V.F.b = r.gobj ? nullptr : r.obj->b; // (the quadratic's linear term; the log-sum-exp path's kernels do not read it)
-        if (!s->fused_live) { // import the canonical state (x, pending s and u) into the fused buffers
-            const size_t vb = (size_t)s->T.n_pad * sizeof(double);
-            HIPCHK(hipMemcpyAsync(s->V.F.X0, s->V.x, vb, hipMemcpyDeviceToDevice, c->stream));
-            if (h->pending) {
-                HIPCHK(hipMemcpyAsync(s->V.F.S0, s->V.sp, vb, hipMemcpyDeviceToDevice, c->stream));
-                HIPCHK(hipMemcpyAsync(s->V.F.UN, s->V.up, vb, hipMemcpyDeviceToDevice, c->stream));
-            }
-            h->xc = 0; h->sc = 0;
-        } // (else: a fused run left them there; xc / sc in the control block say which halves are current)
-        h->warm = (s->fused_live && s->warm_obj != 0 && s->warm_obj == r.obj->serial && h->memoize && h->pending && !ls_only) ? 1 : 0;
-        if (!h->warm) { h->dir_mode = 0; h->gd0_valid = 0; h->dir_ready = 0; }
-        if (!r.bnd || s->ls_box_changed) h->dir_ready = 0;
-        // (a warm bounded call whose direction has been through its request keeps mtb_cand: the machine clips this call's t_max with it)
-        if (r.bnd && h->dir_ready) h->mtb_cand = s->mtb_cand_keep;
-    } else {
-        h->warm = 0;
-    }
-    h->phase = QN_PH_IDLE;
-    h->status = -1;
-    if (r.sym2) {
-        QNCHK(solver_alloc_sym2(s));
-        QnS2Args& a = r.s2;
-        a.Q = r.obj->Q; a.H = s->H; a.n = (int)s->n; a.np = s->T.n_pad; a.nb = s->s2_nb; a.G = s->s2_G;
-        a.item_ij = s->s2_items; a.maxk = s->s2_maxk; a.inorder = s->s2_inorder; a.F = s->V.F; a.part = s->sym_part;
-        a.wgS = s->s2_wgS; a.trows = s->s2_trows; a.ctl2 = s->s2_ctl; a.partE = s->s2_partE;
-        a.gw = r.gobj ? s->T.n_pad / 64 : 0;
-        a.gmu = r.gobj ? r.obj->mu : 0.0;
-        // (allocated only for the runs that use them: the tail reduce's counters, the sharded log-sum-exp path's weights)
-        if (r.gobj && c->world > 1 && !s->s2_gws) QNCHK(dev_alloc_zero(&s->s2_gws, 80, c->stream)); // the ranks' weights and S, world <= 64
-        a.gws = s->s2_gws;
-        if (r.gobj && !s->s2_wgV) QNCHK(dev_alloc_zero(&s->s2_wgV, (size_t)2 * s->s2_trows * QN_S2_ROW, c->stream));
-        a.wgV = s->s2_wgV;
-        if (r.gobj && a.gw > s->s2_trows) return fail(QN_ABNORMAL_TERMINATION, "sym2 (generic objective): more combine workgroups than table rows");
-        // folded accept-reduce (s2_hpass_kernel): every workgroup holds at most three items, so the blocks whose slots it sums fit
-        // its LDS staging area -- n <= 4096 with 256 workgroups; larger n keeps the accept-reduce launch (7 us of 250+)
-        a.fold = (s->s2_maxk <= 3 && s->s2_nb <= 32 && s->fold) ? 1 : 0;
-        a.sl_first = s->s2_sl_first; a.sl_per = s->s2_sl_per;
-        a.pair = (a.sl_per != 0 && s->s2_maxk == 2 && s->s2_inorder == 2 * s->s2_G && !s->no_pair) ? 1 : 0;
-        // sliver rows read the diagonal tiles sl_first .. nb - 1 whole: a run of another kind since the last sliver-mode update
-        // pass (or none yet) may have left their lower sub-blocks behind -- restore them once
-        if (a.sl_per && !s->h_sliver_whole) { QNCHK(ensure_full_h(s)); s->h_sliver_whole = true; }
-        a.trace = s->V.trace; a.xtrace = s->V.xtrace;
-        a.sh_world = c->world; a.sh_rank = c->rank; a.sh_ioff = c->rank * (s->T.rpr / QN_TB);
-        a.sh_nsum = c->use_allreduce ? 1 : c->world;
-        a.evS = s->s2_evS; a.xg = s->symsh_xg; a.sl_off = s->s2_sl_off; a.sl_idx = s->s2_sl_idx;
-        if (c->world > 1 || r.gobj) { a.fold = 0; a.pair = 0; }
-        { // the pair instance's evaluation as mover + multiplier waves (qn_sym2r.hip.h): the same bits as round 5's kernel, 14.3 us against 15.3 per launch
-          // (profiles/r06_a_*).  QN_S2_RING=0 / QN_OPT_EVAL_MOVER_MULTIPLIER 0: round 5's kernel.  It needs every workgroup's FIRST item off the diagonal.
-            a.ring = (a.pair && s->ring && s->s2_nb * (s->s2_nb - 1) / 2 >= s->s2_G) ? 1 : 0;
-        }
-        if (r.bnd) a.fold = 0;
-        a.method = s->method;
-        if (s->method == QN_SR1) a.fold = 0;
-        a.lb = (r.bnd && s->bounded) ? s->V.lb : nullptr; a.ub = (r.bnd && s->bounded) ? s->V.ub : nullptr;
-        a.llb = (r.bnd && ls->kind == QN_LS_MORETHUENTE_B) ? s->V.llb : nullptr; a.lub = (r.bnd && ls->kind == QN_LS_MORETHUENTE_B) ? s->V.lub : nullptr;
-        if (r.tiles1) a.fold = 0;
-        // tail reduce (s2_hpass_kernel<.., TRED>): the update-reduce in the tail of the update-tile launch, 4 launches per iteration
-        // instead of 5 -- one rank, lists short enough for one wave to announce (n <= ~15 k).  BUILT, BIT-IDENTICAL, SLOWER, OFF BY
-        // DEFAULT (QN_S2_TRED=1 / QN_OPT_TAIL_REDUCE switch it on; the note in front of the kernel has the stamps): the update kernel
-        // 23.5 -> 36.7 us for a 5.0 us launch saved.
-        a.cnt = s->s2_cnt;
-        a.cnt_stride = getenv("QN_S2_CNT_STRIDE") ? std::max(1, std::min(QN_S2_CNT_STRIDE, atoi(getenv("QN_S2_CNT_STRIDE")))) : QN_S2_CNT_STRIDE; // (diagnostics)
-        const bool want_tred = getenv("QN_S2_TRED") ? atoi(getenv("QN_S2_TRED")) != 0 : s->tred;
-        if (want_tred && !s->s2_cnt) {
-            HIPCHK(hipMalloc((void**)&s->s2_cnt, (size_t)a.nb * QN_S2_CNT_STRIDE * sizeof(int)));
-            HIPCHK(hipMemsetAsync(s->s2_cnt, 0, (size_t)a.nb * QN_S2_CNT_STRIDE * sizeof(int), c->stream));
-        }
-        a.cnt = s->s2_cnt;
-        a.tred = (c->world == 1 && !a.fold && !r.gobj && !r.tiles1 && s->s2_maxk <= QN_S2_TRED_MAXK && want_tred && s->method != QN_SR1) ? 1 : 0;
-        // WHO GETS THE INFINITY CACHE (256 MB).  Per iteration a rank streams its half of Q twice (read) and its half of H once
-        // (read + written); non-temporal accesses pass the cache by.  Measured (round 4, bench.py same box, it/s for the policies
-        // H plain / Q plain, H plain / Q non-temporal, H non-temporal / Q plain, both non-temporal):
-        //     n =  4096 (2 x  67 MB): both plain (known since round 1)          n =  5120 (2 x 105 MB): 10 101   9 905   9 473   9 188
-        //     n =  6144 (2 x 151 MB):  7 624  *8 020*  7 676   7 421            n =  8192 (2 x 268 MB):  4 262  *4 860*  4 756   4 656
-        //     n = 10240 (2 x 419 MB):  2 738   2 962   2 941  *3 101*           n = 12288 (2 x 604 MB):  2 017   2 122   2 166  *2 271*
-        // While both halves fit, everything stays plain; when they do not, H is the better tenant (its bytes are touched twice per
-        // pass) and Q is streamed past it -- until H's half alone is well over the cache's size, where nothing is worth keeping.
-        // tools/stream_shape_probe.hip has the ceilings (a plain read 6.1-6.3 TB/s, non-temporal 6.5-6.85; read + write 5.2 / 5.5-5.6).
-        const size_t half = c->world > 1 ? (size_t)s->T.rpr * s->T.n_pad * 8 / 2 : (size_t)s->T.n_pad * s->T.n_pad * 8 / 2;
-        if (2 * half <= ((size_t)230 << 20)) { a.nt = 0; a.ntq = 0; }
-        else if (half <= ((size_t)320 << 20)) { a.nt = 0; a.ntq = 1; }
-        else { a.nt = 1; a.ntq = 1; }
-        if (getenv("QN_S2_NT")) a.nt = atoi(getenv("QN_S2_NT"));    // (diagnostics: tools/README.md)
-        if (getenv("QN_S2_NTQ")) a.ntq = atoi(getenv("QN_S2_NTQ"));
-        // (nothing is uploaded here: the FIRST launch of the call reads the control block from the pinned, device-mapped mirror
-        // itself -- QnS2Args.ctl_first.  Round 3 went from hipMemcpyAsync (~8 us in front of the first kernel of every call) to a
-        // one-workgroup upload launch (~4 us); now there is neither.  The host does not write the mirror again before the batch's
-        // last launch has reported, or s2_peek has synchronised.)
-    } else {
-        QNCHK(poke_ctl(s));
-    }
-
-    // only the quadratic objective's kernels are predicated on the control block; everything else is serviced synchronously
-    const bool can_pipeline = (r.oracle_tpl == QN_ORACLE_QUAD || r.gobj) && !callback && !(c->world > 1 && !c->comm && !c->host_async);
-    const bool sync = s->method == QN_NEWTON || s->sync_mode == 1 || (s->sync_mode == -1 && !(can_pipeline && o->memoize)) || !can_pipeline;
-
-    int status = QN_ABNORMAL_TERMINATION;
-    if (r.sym2 && !r.gobj) QNCHK(place_h(r)); // (once per solver: H where the update kernel runs fastest)
-    if (r.sym2) {
-        if (sync) { // one request at a time: [service launch(es), advance], the host reads the control block in between
-            QNCHK(s2_launch(r, QN_S2_ADVANCE));
-            for (;;) {
-                QNCHK(s2_peek(r));
-                const int ph = h->phase;
-                if (ph == QN_PH_DONE) { status = h->status; break; }
-                const bool tiles_done = ph == QN_PH_REQ_HPASS && h->serviced == 1; // (folded accept-reduce: the tiles ran with the vectors)
-                if (h->serviced != 0 && !tiles_done) return fail(QN_ABNORMAL_TERMINATION, "sym2: request in an unexpected service state");
-                if (ph == QN_PH_REQ_EVAL) QNCHK(s2_do_eval(r));
-                else if (ph == QN_PH_REQ_VEC) QNCHK(s2_do_vec(r));
-                else if (ph == QN_PH_REQ_DIR && r.bnd) QNCHK(s2_launch(r, QN_S2_DIR));
-                else if (ph == QN_PH_REQ_HPASS) QNCHK(s2_do_hpass(r, !tiles_done));
-                else return fail(QN_ABNORMAL_TERMINATION, "sym2: control block in an unexpected phase");
-                QNCHK(s2_launch(r, QN_S2_ADVANCE));
-            }
-        } else { // pipelined: [eval x slots, (accept-reduce,) update tiles, update-reduce] per period, each launch predicated in its prologue
-            // Row-sharded: every evaluation launch is followed by a collective whether the machine uses the slot or not (RCCL cannot
-            // be predicated from the device), so the pattern is sized to the line search in use: two slots per period to start
-            // with (More-Thuente on a quadratic: t = 1, then one interpolation; backtracking near the solution: t = 1), and from
-            // the second batch on what the run has needed so far -- the counters are replicated, every rank sizes alike.  An
-            // iteration that needs more evaluations than a period holds rolls over into the next one: only time is lost.
-            int slots = (ls->kind == QN_LS_MORETHUENTE) ? 2 : 4;
-            // (generic objective: an unused evaluation slot is three launches that find nothing to do, and on such objectives More-Thuente
-            // takes t = 1 almost every time -- the pattern is sized like the sharded one: one slot to start with, then what the run has needed)
-            const bool adaptive = r.s2.sh_world > 1 || r.gobj || r.bnd; // (bounded: MoreThuenteB's clipped first step is often the accepted one)
-            if (adaptive) slots = s->s2_slots_hint ? s->s2_slots_hint : (r.gobj ? 1 : 2);
-            bool first = true;
-            uint64_t ev0 = 0, it0 = 0;
-            unsigned long long seq = 0;
-            for (;;) {
-                if (!first) {
-                    QNCHK(s2_wait_report(r, seq));
-                    if (adaptive && h->n_iterations > it0) { // evaluations per iteration of the batch just run, rounded up
-                        const uint64_t di = h->n_iterations - it0;
-                        uint64_t de = h->n_oracle_evals - ev0;
-                        if (it0 == 0 && !h->warm && de > 0) de -= 1; // (the evaluation at x0 that opens a run had a period of its own)
-                        slots = (int)std::min<uint64_t>(4, std::max<uint64_t>(1, (de + di - 1) / di));
-                        s->s2_slots_hint = slots; // (the next call starts from it)
-                    }
-                    ev0 = h->n_oracle_evals; it0 = h->n_iterations;
-                    if (h->phase == QN_PH_DONE) { status = h->status; break; }
-                }
-                int64_t remaining = h->max_iter - (first ? 0 : h->k);
-                if (remaining < 1) remaining = 1;
-                // one period per iteration, one more for a run that has no direction yet (evaluation at x, direction pass), and
-                // a last evaluation launch whose prologue finds the iteration cap reached and writes DONE
-                const int64_t periods = std::min<int64_t>(remaining + ((first && !h->warm) ? 1 : 0), 256);
-                first = false;
-                auto one_period = [&]() -> int {
-                    if (r.dirq) QNCHK(s2_launch(r, QN_S2_DIR)); // (the direction the period's evaluations search along: stored, projected)
-                    for (int e = 0; e < slots; ++e) QNCHK(s2_do_eval(r));
-                    if (!r.s2.fold && !(r.gobj && r.s2.sh_world == 1)) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise; generic objective: staged by every evaluation's combine launch)
-                    QNCHK(s2_do_hpass(r, true));
-                    return QN_OK;
-                };
-                int64_t p = 0;
-                // MEASUREMENT (QN_S2_GRAPH=1; tools/README.md): the periods behind the first one as launches of ONE captured hipGraph of two
-                // periods (an even number of launches, so the control block's parity repeats; the first period carries ctl_first, the
-                // reporting launch stays outside).  Single rank, quadratic objective, profiling off.
-                static const bool want_graph = getenv("QN_S2_GRAPH") && atoi(getenv("QN_S2_GRAPH")) != 0;
-                if (want_graph && c->world == 1 && !r.gobj && !s->profiling && periods >= 3) {
-                    QNCHK(one_period()); ++p;
-                    const uint64_t l0 = r.s2_launches;
-                    if ((l0 & 1) != 0) { QNCHK(one_period()); ++p; } // (start the captured pair on an even launch count)
-                    if (periods - p >= 2) {
-                        const uint64_t lbase = r.s2_launches, stat0 = s->stats.launches;
-                        const bool reuse = s->s2_graph_exec && memcmp(&s->s2_graph_args, &r.s2, sizeof(QnS2Args)) == 0 && s->s2_graph_slots == slots && s->s2_graph_bnd == (int)r.bnd;
-                        if (!reuse) {
-                            if (s->s2_graph_exec) { (void)hipGraphExecDestroy(s->s2_graph_exec); s->s2_graph_exec = nullptr; }
-                            hipGraph_t g = nullptr;
-                            HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                            int rc = one_period(); if (rc == QN_OK) rc = one_period();
-                            const hipError_t e = hipStreamEndCapture(c->stream, &g);
-                            if (rc != QN_OK) return rc;
-                            HIPCHK(e);
-                            HIPCHK(hipGraphInstantiate(&s->s2_graph_exec, g, nullptr, nullptr, 0));
-                            (void)hipGraphDestroy(g);
-                            s->s2_graph_args = r.s2; s->s2_graph_slots = slots; s->s2_graph_bnd = (int)r.bnd;
-                            s->s2_graph_len = r.s2_launches - lbase; s->s2_graph_stat = s->stats.launches - stat0;
-                            r.s2_launches = lbase; s->stats.launches = stat0; // (captured, not run)
-                        }
-                        if ((s->s2_graph_len & 1) == 0) {
-                            for (; periods - p >= 2; p += 2) {
-                                HIPCHK(hipGraphLaunch(s->s2_graph_exec, c->stream));
-                                r.s2_launches += s->s2_graph_len; s->stats.launches += s->s2_graph_stat;
-                            }
-                        }
-                    }
-                }
-                for (; p < periods; ++p) QNCHK(one_period());
-                seq = ++s->rep_seq; // (the batch's last launch reports)
-                // One rank, quadratic objective: the reporting launch is the ONE-WORKGROUP machine launch, not an evaluation launch.  The
-                // evaluation kernel requests its first item before it knows whether there is anything to evaluate -- at the end of a call
-                // there is not: the machine finds the iteration cap and writes DONE -- which made the last launch of every call 10.7 us
-                // (kernel trace of the driver's 20-step call); the machine launch is 3-4.  Whatever request the machine leaves pending is
-                // served by the next batch's first launches.
-                if (r.s2.sh_world == 1 && !r.gobj) { r.report_seq = seq; QNCHK(s2_launch(r, QN_S2_ADVANCE)); }
-                else QNCHK(s2_do_eval(r, seq));
-            }
-        }
-    } else {
-    QNCHK(launch_ctl(r, QN_PH_IDLE));
-    if (sync) {
-        for (;;) {
-            QNCHK(peek_ctl(s));
-            const int ph = h->phase;
-            if (ph == QN_PH_DONE) { status = h->status; break; }
-            if (ph == QN_PH_REQ_EVAL) { QNCHK(enqueue_eval(r)); QNCHK(launch_ctl(r, QN_PH_REQ_EVAL)); }
-            else if (ph == QN_PH_REQ_HPASS) { QNCHK(enqueue_hpass_req(r)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS)); }
-            else if (ph == QN_PH_REQ_HPASS_EVAL) { // fused path: update pass, then the evaluation that derives the update's coefficients itself
-                QNCHK(enqueue_hpass_req(r)); QNCHK(enqueue_eval(r, 1)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS_EVAL));
-            }
-            else if (ph == QN_PH_REQ_NEWTON) { { ProfScope ps(s, KC_NEWTON); QNCHK(enqueue_newton(s, o, r.obj)); } QNCHK(launch_ctl(r, QN_PH_REQ_NEWTON)); }
-            else if (ph == QN_PH_ITER_DONE) { callback(callback_user, s); QNCHK(launch_ctl(r, QN_PH_ITER_DONE)); }
-            else return fail(QN_ABNORMAL_TERMINATION, "control block in an unexpected phase");
-        }
-    } else {
-        // pipelined: every kernel is predicated on the control block, so a fixed pattern can be enqueued ahead
-        // of the decisions; one period = [eval, step] x slots, [h_pass, step], and advances at most one iteration.
-        const int slots_max = (ls->kind == QN_LS_MORETHUENTE || ls->kind == QN_LS_MORETHUENTE_B) ? 2 : 4;
-        int slots = slots_max;
-        // The generic path (closures excluded: they are synchronous) sizes its periods like the sharded second-generation path does:
-        // an evaluation slot the line search does not use is two launches that find nothing to do (5.2 + 4.8 us at n = 4096 -- a tenth of a
-        // bounded iteration, where MoreThuenteB accepts t = 1: profiles/r05_q_*); from the second batch on a period carries what the run
-        // has needed per iteration so far, rounded up, and an iteration that needs more rolls over into the next period (every launch
-        // is predicated: only time is lost).  The counters are the control block's: the same on every rank.
-        const bool adaptive = !r.fused;
-        if (adaptive && s->gen_slots_hint) slots = std::min(slots_max, s->gen_slots_hint);
-        uint64_t ev0 = 0, it0 = 0;
-        bool first_batch = true;
-        const int gd = s->method == QN_GRADIENT_DESCENT;
-        for (;;) {
-            QNCHK(peek_ctl(s));
-            if (adaptive && !first_batch && h->n_iterations > it0) {
-                const uint64_t di = h->n_iterations - it0;
-                uint64_t de = h->n_oracle_evals - ev0;
-                if (it0 == 0 && de > 0) de -= 1; // (the evaluation at x0 that opens a run)
-                slots = (int)std::min<uint64_t>((uint64_t)slots_max, std::max<uint64_t>(1, (de + di - 1) / di));
-                s->gen_slots_hint = slots;
-            }
-            ev0 = h->n_oracle_evals; it0 = h->n_iterations;
-            first_batch = false;
-            if (h->phase == QN_PH_DONE) { status = h->status; break; }
-            int64_t remaining = h->max_iter - h->k;
-            if (remaining < 1) remaining = 1;
-            const int64_t periods = std::min<int64_t>(remaining, 256);
-            const int first_mask = (1 << QN_PH_REQ_EVAL) | (1 << QN_PH_REQ_HPASS) | (1 << QN_PH_REQ_HPASS_EVAL);
-            for (int64_t p = 0; p < periods; ++p) {
-                if (r.fused) {
-                    // [eval*, step*] [eval, step] x (slots-1) [h_pass]: the first evaluation of a period directly follows the
-                    // previous period's h_pass and may service QN_PH_REQ_HPASS_EVAL; its step also consumes a plain h_pass
-                    QNCHK(enqueue_eval(r, 1)); QNCHK(launch_ctl_mask(r, first_mask));
-                    for (int e = 1; e < slots; ++e) { QNCHK(enqueue_eval(r, 0)); QNCHK(launch_ctl(r, QN_PH_REQ_EVAL)); }
-                    QNCHK(enqueue_hpass_req(r));
-                } else {
-                    for (int e = 0; e < slots; ++e) { QNCHK(enqueue_eval(r)); QNCHK(launch_ctl(r, QN_PH_REQ_EVAL)); }
-                    if (!gd) { QNCHK(enqueue_hpass_req(r)); QNCHK(launch_ctl(r, QN_PH_REQ_HPASS)); }
-                }
-            }
-        }
-    }
-    } // (!r.sym2)
-    // Nothing is copied back here: the iterate and the pending vectors stay in the fused buffers (fused_export), the lower
-    // triangle of H stays stale (ensure_full_h) until a getter, a setter or a run on another path asks for them.  A solve made
-    // of several qn_minimize calls (warm restarts, a harness timing short calls) pays for neither.
-    if (r.fused) s->fused_live = true;
-    s->warm_obj = (r.fused && status == QN_MAX_ITER_REACHED && h->memoize && h->have_cur_eval && h->have_dir) ? r.obj->serial : 0;
-    if (ls->kind == QN_LS_MORETHUENTE_B) ls->t_max = h->mt_tmax; // morethuente_b.rs:201: the clipped t_max stays in the line search
-    s->stats.iterations = h->n_iterations;
-    s->stats.oracle_calls = h->n_oracle_calls;
-    s->stats.oracle_evals = h->n_oracle_evals;
-    s->stats.h_passes = h->n_hpasses;
-    uint64_t shard = (uint64_t)s->T.rpr * (uint64_t)s->T.n_pad * 8ull;
-    const uint64_t full_shard = shard;
-    if (r.sym || r.sym_generic) shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb + 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull; // the streamed tiles
-    if ((r.sym || r.sym_generic) && c->world > 1) shard = (uint64_t)qn_symsh_ntiles(s->sym_nb, s->T.rpr / QN_TB, c->rank * (s->T.rpr / QN_TB)) * (uint64_t)QN_TB * QN_TB * 8ull;
-    if (r.sym2 && !r.gobj && !r.tiles1) // diagonal tiles: wave w (rows 16 w ...) reads 64 - 8 w lanes of 16 bytes per row = 73 728 of the 131 072 bytes
-        shard = (uint64_t)s->sym_nb * (uint64_t)(s->sym_nb - 1) / 2ull * (uint64_t)QN_TB * QN_TB * 8ull + (uint64_t)s->sym_nb * 73728ull;
-    if (r.sym2 && c->world > 1 && !r.tiles1) { // this rank's windows: one diagonal tile per local block-row, the rest whole tiles
-        const uint64_t nbl = (uint64_t)(s->T.rpr / QN_TB);
-        const uint64_t nt = (uint64_t)qn_symsh_ntiles(s->sym_nb, (int)nbl, c->rank * (int)nbl);
-        shard = (nt - nbl) * (uint64_t)QN_TB * QN_TB * 8ull + nbl * 73728ull;
-    }
-    s->stats.h_bytes = (h->n_hpasses + h->n_hpass_rw) * shard;
-    if (r.sym2) s->stats.h_bytes = 2 * h->n_hpasses * shard; // (its one branch-free body writes every pass back, pending update or not)
-    s->stats.obj_bytes = (r.oracle_tpl == QN_ORACLE_QUAD) ? h->n_oracle_evals * (r.sym ? shard : full_shard) : 0;
-    if (r.obj && r.obj->kind == OBJ_LOGSUMEXP) // one pass over this rank's rows of A per evaluation (two for n > 16384)
-        s->stats.obj_bytes = h->n_oracle_evals * (uint64_t)r.obj->TA.rpr * (uint64_t)r.obj->T.n_pad * 8ull * ((r.obj->lse_kch && !r.obj->lse_two_pass) ? 1ull : 2ull);
-    s->stats.matrix_bytes_per_pass = shard;
-    s->stats.total_minimize_calls++;
-    s->stats.total_iterations += s->stats.iterations;
-    s->stats.total_oracle_calls += s->stats.oracle_calls;
-    s->stats.total_oracle_evals += s->stats.oracle_evals;
-    s->stats.total_h_passes += s->stats.h_passes;
-    s->stats.total_h_bytes += s->stats.h_bytes;
-    s->stats.total_obj_bytes += s->stats.obj_bytes;
-    s->stats.total_xchg_vector += c->n_xchg_vector - xv0;
-    s->stats.total_xchg_scalar += c->n_xchg_scalar - xs0;
-    s->stats.path = (r.fused ? QN_PATH_FUSED : 0u) | (r.sym ? QN_PATH_SYM : 0u) | (r.sym_generic ? QN_PATH_SYM_GENERIC : 0u) |
-                    (sync ? 0u : QN_PATH_PIPELINED) | (r.sym2 ? QN_PATH_SYM2 : 0u) | ((r.tiles1 || (r.gobj && c->world == 1)) ? QN_PATH_TILES1 : 0u);
-    if (c->host_async_failed) { c->host_async_failed = 0; return fail(QN_ABNORMAL_TERMINATION, "host exchange callback failed"); }
-    if (status == QN_ABNORMAL_TERMINATION) return fail(status, "solver state machine aborted");
-    return status;
-}
-
-// ------------------------------------------------------------------------------------------------
-// kernel-level FFI
-// ------------------------------------------------------------------------------------------------
-extern "C" int qn_dev_alloc(qn_context* c, size_t bytes, void** out) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipMalloc(out, bytes)); return QN_OK; }
-extern "C" int qn_dev_free(qn_context* c, void* p) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipFree(p)); return QN_OK; }
-extern "C" int qn_h2d(qn_context* c, void* dst, const void* src, size_t bytes) {
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return QN_OK;
-}
-extern "C" int qn_d2h(qn_context* c, void* dst, const void* src, size_t bytes) {
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return QN_OK;
-}
-extern "C" int qn_gemv(qn_context* c, const double* a, size_t ld, size_t nrows, size_t ncols, const double* x, double* y) {
-    HIPCHK(hipSetDevice(c->device));
-    if (nrows == 0) return QN_OK;
-    hipLaunchKernelGGL(prim_gemv_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, a, ld, (int)nrows, (int)ncols, x, y);
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-extern "C" int qn_rank2_update(qn_context* c, double* h, size_t ld, size_t row0, size_t nrows, size_t n, const double* s_dev,
-                               const double* u_dev, double c_ss, double c_su, double c_uu) {
-    HIPCHK(hipSetDevice(c->device));
-    if (nrows == 0 || n == 0) return QN_OK;
-    dim3 grid((unsigned)std::min<size_t>((n + 255) / 256, 64), (unsigned)nrows);
-    hipLaunchKernelGGL(prim_rank2_kernel, grid, dim3(256), 0, c->stream, h, ld, (int)row0, (int)nrows, (int)n, s_dev, u_dev, c_ss, c_su, c_uu);
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-extern "C" int qn_axpy(qn_context* c, size_t n, const double* x, double t, const double* d, double* out) {
-    HIPCHK(hipSetDevice(c->device));
-    if (n == 0) return QN_OK;
-    hipLaunchKernelGGL(prim_axpy_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, c->stream, (int)n, x, t, d, out);
-    HIPCHK(hipGetLastError());
-    return QN_OK;
-}
-extern "C" int qn_dot(qn_context* c, size_t n, const double* a, const double* b, double* out_host) {
-    HIPCHK(hipSetDevice(c->device));
-    double* tmp = nullptr;
-    HIPCHK(hipMalloc((void**)&tmp, sizeof(double)));
-    hipLaunchKernelGGL(prim_dot_kernel, dim3(1), dim3(QN_CTL_TPB), 0, c->stream, (int)n, a, b, tmp);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_host, tmp, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipFree(tmp));
-    return QN_OK;
-}
-extern "C" int qn_nrm2(qn_context* c, size_t n, const double* a, double* out_host) { // norm = sqrt(dot(a, a)), bfgs.rs:74,97,99
-    double d = 0.0;
-    QNCHK(qn_dot(c, n, a, a, &d));
-    *out_host = std::sqrt(d);
-    return QN_OK;
-}
+// The host side in parts (round 6): textual includes of this one translation unit, in dependency order.
+#include "qn_host_context.hip.h"
+#include "qn_host_linesearch.hip.h"
+#include "qn_host_objective.hip.h"
+#include "qn_host_solver.hip.h"
+#include "qn_host_launch.hip.h"
+#include "qn_host_newton.hip.h"
+#include "qn_host_minimize.hip.h"
+#include "qn_host_blas.hip.h"
