@@ -35,6 +35,7 @@ struct QnS2RSync {
     unsigned cnt0;              // rows of wave 0's share of the first item parked so far (16 when complete)
     unsigned eready;            // blocks of the trial point staged so far (5 when complete)
     unsigned mdone;             // the machine has run: L.c and L.mine are final
+    unsigned bad;               // a bounded spin ran out in some wave of this workgroup
 };
 
 __device__ __forceinline__ unsigned qn_s2r_peek(const unsigned* p) {
@@ -222,6 +223,9 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
             return a.Q + (size_t)(I * QN_TB + w * QN_S2_RPW) * np + (size_t)J * QN_TB + qn_s2_col(I == J, ln, w);
         };
         if (wave == 0) {
+            // (Measured and dropped: the barrier in front of wave 0's publish instead of inside its prologue, the movers behind ALL their first
+            // requests -- the stream starts at once, but the movers' nineteenth request is accepted 5-6 us in and the multipliers start that late:
+            // 14.3-14.4 us against 13.9-14.1; with eight requests in front 15.8.)
 #ifdef QN_S2_STAMPS
             { QnS2Args ap = a; ap.dbg = nullptr; qn_s2_prologue_w0<QN_S2_EVAL, false, decltype(entry_barrier)&, false, BND>(ap, L, entry_barrier); }
 #else
@@ -386,6 +390,7 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
         QN_S2R_STAMP(1, 512);  // (multiplier 0)
         QN_S2R_STAMP(10, 768); // (multiplier 4)
     }
+    if (bad) __hip_atomic_store(&Y.bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (read behind the exchange barrier)
     __syncthreads();
     QN_S2R_STAMP(4, 0);
     double wgk = 0.0;
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
         if (lane == 48) a.partE[(unsigned)((sl.D * a.nb + sl.D) * QN_TB + sl.row)] = row_c;
     }
     // a spin ran out somewhere in this workgroup: its sums are not to be believed -- NaN ends the run (out of domain) instead of a wrong step
-    const bool anybad = __syncthreads_or(bad ? 1 : 0) != 0;
+    const bool anybad = Y.bad != 0u;
     QN_S2R_STAMP(15, 0);
 #ifdef QN_S2_STAMPS
     __syncthreads();
