@@ -381,7 +381,10 @@ def extra_bounded(qn, ctx):
     out = {"workload": f"BFGSB + MoreThuenteB against BFGS + MoreThuente, n={n} convex quadratic (the headline's), a quarter of the box active at the constrained optimum, f64, 1xMI355X"}
     iters = 200
     for name, mk, mkls in (("unbounded", lambda: qn.BFGS(1e-10, x0, ctx=ctx), lambda: qn.MoreThuente()),
-                           ("bounded", lambda: qn.BFGSB.new(1e-10, x0, lb, ub, ctx=ctx), lambda: qn.MoreThuenteB.new(n).with_lower_bound(lb).with_upper_bound(ub))):
+                           ("bounded", lambda: qn.BFGSB.new(1e-10, x0, lb, ub, ctx=ctx), lambda: qn.MoreThuenteB.new(n).with_lower_bound(lb).with_upper_bound(ub)),
+                           # round 6: BackTrackingB on the second-generation path (s2_proj_kernel) against plain BackTracking
+                           ("unbounded_backtracking", lambda: qn.BFGS(1e-10, x0, ctx=ctx), lambda: qn.BackTracking(1e-4, 0.5)),
+                           ("bounded_backtracking_b", lambda: qn.BFGSB.new(1e-10, x0, lb, ub, ctx=ctx), lambda: qn.BackTrackingB.new(1e-4, 0.5, lb, ub))):
         s = mk()
         ls = mkls()
 
@@ -399,9 +402,13 @@ def extra_bounded(qn, ctx):
         st = s.stats()
         its = max(int(st["iterations"]), 1)
         out[name] = {"iterations_per_s": its / dt, "us_per_iteration": 1e6 * dt / its, "iterations": its, "path": st["path"],
-                     "second_generation_path": bool(st["path"] & 16), "launches_per_iteration": st["launches"] / its, "host_syncs": st["host_syncs"]}
+                     "second_generation_path": bool(st["path"] & 16), "launches_per_iteration": st["launches"] / its, "host_syncs": st["host_syncs"],
+                     "evaluations_per_iteration": st["oracle_evals"] / its}
         del s
     out["ratio_bounded_over_unbounded_time"] = out["bounded"]["us_per_iteration"] / out["unbounded"]["us_per_iteration"]
+    out["ratio_backtracking_b_over_backtracking_time"] = out["bounded_backtracking_b"]["us_per_iteration"] / out["unbounded_backtracking"]["us_per_iteration"]
+    out["backtracking_b_note"] = ("a BackTrackingB iteration evaluates every trial at a PROJECTED point (one more small launch each) and then the accepted "
+                                  "x + t d once more, unprojected (bfgs_b.rs:91-98): one evaluation more per iteration than BackTracking, whose accepted trial IS the next iterate")
     out["value"] = out["bounded"]["iterations_per_s"]
     out["unit"] = "iterations/s"
     return out

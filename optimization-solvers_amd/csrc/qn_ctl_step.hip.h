@@ -328,14 +328,14 @@ __device__ __forceinline__ void qn_st_mt_finish(QnCtl& c) { // morethuente.rs:29
 template <int LEAN>
 __device__ __forceinline__ void qn_st_bt_loop(QnCtl& c) { // backtracking.rs:31-34
     if (!(c.max_iter_ls > c.ls_i)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; } // :54
-    else { c.tr_ls_iters++; req_eval_t<LEAN>(c, c.t, QN_ST_BT_AFTER, 0, (!LEAN && c.ls_kind == 3) ? 1 : 0); }
+    else { c.tr_ls_iters++; req_eval_t<LEAN>(c, c.t, QN_ST_BT_AFTER, 0, (LEAN != 1 && c.ls_kind == 3) ? 1 : 0); } // (LEAN == 2: BackTrackingB on the second-generation path, round 6)
 }
 
 template <int LEAN>
 __device__ __forceinline__ void qn_st_bt_after(QnCtl& c) { // backtracking.rs:37-51
     const double f1 = c.f_e;
     if (isnan(f1) || isinf(f1)) { c.t *= c.bt_beta; c.state = QN_ST_BT_LOOP; } // shrink, iteration not counted
-    else if ((!LEAN && c.ls_kind == 3) ? (f1 - c.f_k <= (-c.bt_c1 / c.t) * c.bt_diff2) // backtracking_b.rs:24-34
+    else if ((LEAN != 1 && c.ls_kind == 3) ? (f1 - c.f_k <= (-c.bt_c1 / c.t) * c.bt_diff2) // backtracking_b.rs:24-34
                             : (f1 - c.f_k <= c.bt_c1 * c.t * c.gd0)) { c.ls_result = c.t; c.state = QN_ST_AFTER_LS; }
     else { c.t *= c.bt_beta; c.ls_i++; c.state = QN_ST_BT_LOOP; }
 }

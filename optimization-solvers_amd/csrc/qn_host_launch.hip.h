@@ -16,6 +16,7 @@ struct Run {
     bool sym2 = false;        // second-generation symmetric path (qn_sym2.hip.h)
     bool gobj = false;        // ... in its form for a device objective that is not the quadratic (qn_sym2g.hip.h: the log-sum-exp objective)
     bool dirq = false;        // ... whose pattern has the stored-direction launch (QnCtl.s2_dir != 0)
+    bool proj = false;        // ... whose line search is BackTrackingB: every evaluation slot has s2_proj_kernel in front of it (projected trial points)
     bool bnd = false;         // ... a bounded run on it (BFGSB / DFPB, MoreThuenteB): one more launch per iteration, s2_dir_kernel (qn_sym2.hip.h)
     bool tiles1 = false;      // the update pass's tiles through the first-generation tile kernel (one workgroup per tile, two per CU) behind a
                               // one-workgroup launch that runs the machine: H's share past the Infinity Cache (see minimize_impl)
@@ -113,7 +114,7 @@ static int s2_launch(Run& r, int kind) {
     a.swz = (getenv("QN_S2_SWZ") && a.pair) ? atoi(getenv("QN_S2_SWZ")) : 0; // (only where both items follow from the workgroup index: n = 4096)
 #endif
     r.s2_launches++;
-    const int cls = kind == QN_S2_EVAL ? KC_EVAL : (kind == QN_S2_VEC || kind == QN_S2_VSUM || kind == QN_S2_GCOMB || kind == QN_S2_DIR) ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS
+    const int cls = kind == QN_S2_EVAL ? KC_EVAL : (kind == QN_S2_VEC || kind == QN_S2_VSUM || kind == QN_S2_GCOMB || kind == QN_S2_DIR || kind == QN_S2_PROJ) ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS
                   : (kind == QN_S2_HREDUCE || kind == QN_S2_HSUM) ? KC_HREDUCE : KC_CTL;
     ProfScope ps(s, cls);
     const bool sh = a.sh_world > 1; // row-sharded: the SHARD instantiations (qn_sym2sh.hip.h)
@@ -133,6 +134,7 @@ static int s2_launch(Run& r, int kind) {
         else hipLaunchKernelGGL(s2_eval_kernel<false>, dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
         break;
     case QN_S2_DIR: hipLaunchKernelGGL(s2_dir_kernel, dim3(a.nb), dim3(QN_TB), 0, st, a); break;
+    case QN_S2_PROJ: hipLaunchKernelGGL(s2_proj_kernel, dim3(a.nb), dim3(QN_TB), 0, st, a); break;
     case QN_S2_VSUM:
         if (r.gobj) hipLaunchKernelGGL((s2_advance_kernel<true, true, QN_S2_VSUM>), dim3(1), dim3(128), 0, st, a); // (the machine sees the accepted point; the gather follows)
         else hipLaunchKernelGGL(s2sh_vsum_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
@@ -238,6 +240,7 @@ static int s2_do_eval(Run& r, unsigned long long report_seq = 0) {
         }
         return QN_OK;
     }
+    if (r.proj) QNCHK(s2_launch(r, QN_S2_PROJ)); // (BackTrackingB: a projected trial's point is stored first; any other request passes through)
     if (report_seq) r.report_seq = report_seq;
     QNCHK(s2_launch(r, QN_S2_EVAL));
     qn_solver* s = r.s;

@@ -95,16 +95,16 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     if (h->small_n && h->pending) QNCHK(flush_pending(s));
     // fused fast path: device quadratic, memoised, BFGS/DFP, no callback, one column split, n > 5
     // Bounded variants (row f4): BFGSB / DFPB and MoreThuenteB run on the second-generation symmetric path when everything that path needs
-    // holds (one rank, whole 128-blocks without padding, a symmetric Q, bitwise symmetric H) -- s2_dir_kernel, qn_sym2.hip.h; BackTrackingB
-    // (projected trial points), SR1B and everything else bounded keep the generic path.  QN_S2_BND=0 switches it off (tests: generic path).
-    const bool s2b = (s->bounded || ls_bounded) && ls->kind != QN_LS_BACKTRACKING_B && !ls_only && c->world == 1 && (s->T.n_pad % QN_TB) == 0 &&
+    // holds (one rank, whole 128-blocks without padding, a symmetric Q, bitwise symmetric H) -- s2_dir_kernel, qn_sym2.hip.h; BackTrackingB's
+    // projected trial points by s2_proj_kernel (round 6).  Everything else bounded keeps the generic path.  QN_S2_BND=0 switches it off (tests: generic path).
+    const bool s2b = (s->bounded || ls_bounded) && !ls_only && c->world == 1 && (s->T.n_pad % QN_TB) == 0 &&
                      s->T.n_pad >= 8 * QN_TB && (size_t)s->T.n_pad == s->n && !s->no_sym && !s->no_sym2 && !s->h_nonsym && r.obj && r.obj->q_symmetric &&
                      !s->no_s2bnd && !(getenv("QN_S2_BND") && atoi(getenv("QN_S2_BND")) == 0);
     // SR1 (sr1_b.rs; row f4) has its three-term update only in the second-generation kernels (s2_hpass_kernel<.., SR1>): it takes the fused path
     // exactly when that path will be taken -- the same structural conditions as the bounded variants'.
     const bool s2_struct = !ls_only && c->world == 1 && (s->T.n_pad % QN_TB) == 0 && s->T.n_pad >= 8 * QN_TB && (size_t)s->T.n_pad == s->n && !s->no_sym &&
                            !s->no_sym2 && !s->h_nonsym && r.obj && r.obj->q_symmetric && !s->no_s2bnd && !(getenv("QN_S2_BND") && atoi(getenv("QN_S2_BND")) == 0);
-    const bool sr1_s2 = s->method == QN_SR1 && s2_struct && ls->kind != QN_LS_BACKTRACKING_B;
+    const bool sr1_s2 = s->method == QN_SR1 && s2_struct;
     r.fused = r.oracle_tpl == QN_ORACLE_QUAD && h->memoize && (s->method == QN_BFGS || s->method == QN_DFP || sr1_s2) && !callback && s->hcs == 1 &&
               s->qcs == 1 && !h->small_n && !s->no_fused && (!(s->bounded || ls_bounded) || s2b);
     // ... and the log-sum-exp objective in the structure of the second-generation path (qn_sym2g.hip.h; round 5): one rank, its one-pass
@@ -142,6 +142,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     if (s->method == QN_SR1 && r.fused && !r.sym2) return fail(QN_ABNORMAL_TERMINATION, "SR1 on a fused path that is not the second-generation one");
     h->s2_dir = r.bnd ? ((s->bounded ? 1 : 0) | (ls->kind == QN_LS_MORETHUENTE_B ? 2 : 0)) : 0;
     r.dirq = h->s2_dir != 0; // (the stored-direction launch is part of the pattern only where a direction asks for it)
+    r.proj = r.bnd && ls->kind == QN_LS_BACKTRACKING_B;
     if (r.bnd && ls->kind == QN_LS_MORETHUENTE_B) h->ls_kind = QN_LS_MORETHUENTE; // (the clip of t_max is applied where the direction's request is consumed: from there on it IS More-Thuente)
     // WHICH KERNEL STREAMS THE UPDATE PASS OF A ROW-SHARDED RUN (round 5).  The one-workgroup-per-CU kernel of
     // qn_sym2.hip.h (16-row register windows, the machine in its prologue) was built for n = 4096, where a launch is a twelfth of the
@@ -224,7 +225,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         a.method = s->method;
         if (s->method == QN_SR1) a.fold = 0;
         a.lb = (r.bnd && s->bounded) ? s->V.lb : nullptr; a.ub = (r.bnd && s->bounded) ? s->V.ub : nullptr;
-        a.llb = (r.bnd && ls->kind == QN_LS_MORETHUENTE_B) ? s->V.llb : nullptr; a.lub = (r.bnd && ls->kind == QN_LS_MORETHUENTE_B) ? s->V.lub : nullptr;
+        a.llb = (r.bnd && ls_bounded) ? s->V.llb : nullptr; a.lub = (r.bnd && ls_bounded) ? s->V.lub : nullptr;
         if (r.tiles1) a.fold = 0;
         // tail reduce (s2_hpass_kernel<.., TRED>): the update-reduce in the tail of the update-tile launch, 4 launches per iteration
         // instead of 5 -- one rank, lists short enough for one wave to announce (n <= ~15 k).  BUILT, BIT-IDENTICAL, SLOWER, OFF BY
@@ -305,7 +306,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                         const uint64_t di = h->n_iterations - it0;
                         uint64_t de = h->n_oracle_evals - ev0;
                         if (it0 == 0 && !h->warm && de > 0) de -= 1; // (the evaluation at x0 that opens a run had a period of its own)
-                        slots = (int)std::min<uint64_t>(4, std::max<uint64_t>(1, (de + di - 1) / di));
+                        slots = (int)std::min<uint64_t>(4, std::max<uint64_t>(1, (de + di - 1) / di)); // (measured, round 6: up to 8 slots for BackTrackingB's ~8 evaluations per iteration -- 283 us against 250: an unused slot costs more than a short period's four unused launches)
                         s->s2_slots_hint = slots; // (the next call starts from it)
                     }
                     ev0 = h->n_oracle_evals; it0 = h->n_iterations;
@@ -320,6 +321,11 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                 auto one_period = [&]() -> int {
                     if (r.dirq) QNCHK(s2_launch(r, QN_S2_DIR)); // (the direction the period's evaluations search along: stored, projected)
                     for (int e = 0; e < slots; ++e) QNCHK(s2_do_eval(r));
+                    // (BackTrackingB: the accept-reduce, the update tiles and the update-reduce run the UNBOUNDED machine in their prologues -- they are the
+                    // benchmark's kernels, unchanged -- and must not be the ones that consume a projected trial: its Armijo rule and its memo are the
+                    // bounded machine's.  Every evaluation slot but the last is followed by the next slot's s2_proj_kernel, whose prologue is the bounded
+                    // one; behind the last a one-workgroup machine launch consumes.)
+                    if (r.proj) QNCHK(s2_launch(r, QN_S2_ADVANCE));
                     if (!r.s2.fold && !(r.gobj && r.s2.sh_world == 1)) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise; generic objective: staged by every evaluation's combine launch)
                     QNCHK(s2_do_hpass(r, true));
                     return QN_OK;

@@ -574,7 +574,7 @@ template <int LEAN = 0>
 __device__ __forceinline__ void req_eval_t(QnCtl& c, double t, int after_state, int need_vectors, int project = 0) {
     c.n_oracle_calls++;
     c.tr_n_evals++;
-    if (LEAN || (c.memoize && !project && !c.last_projected)) {
+    if ((LEAN && !project) || (!LEAN && c.memoize && !project && !c.last_projected)) { // (a projected trial is not x + t d: no memo; LEAN == 2 forgets the memo when it consumes one)
         if (!need_vectors && t == 0.0 && c.d_finite) { // x + 0*d == x: phi(0) = (f_k, g_k.d)
             c.f_e = c.f_k; c.gd_e = c.gd0; c.state = after_state;
             return;

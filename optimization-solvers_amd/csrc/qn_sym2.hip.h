@@ -60,7 +60,8 @@ enum { QN_S2_ADVANCE = 0, QN_S2_EVAL = 1, QN_S2_VEC = 2, QN_S2_HTILE = 3, QN_S2_
        QN_S2_VSUM = 5, QN_S2_HSUM = 6, // (row-sharded runs, qn_sym2sh.hip.h: this rank's slot sums, in front of the exchange of an n-vector)
        QN_S2_GEVAL_A = 7, QN_S2_GCOMB = 8, QN_S2_GHT_A = 9, // (generic objectives, qn_sym2g.hip.h: the machine in a one-workgroup launch in
                                                              // front of many-workgroup kernels that only READ the control block)
-       QN_S2_DIR = 10 }; // (bounded variants: s2_dir_kernel)
+       QN_S2_DIR = 10,   // (bounded variants: s2_dir_kernel)
+       QN_S2_PROJ = 11 }; // (BackTrackingB on this path, round 6: s2_proj_kernel -- the projected trial point, stored, and ||P(x + t d) - x||^2)
 
 struct QnS2Args {
     const double* Q;
@@ -174,12 +175,16 @@ __device__ __forceinline__ void qn_s2_advance(QnCtl& c, const double* tot, const
                 const double f = 0.5 * tot[0] - tot[1]; // f = 1/2 xt'(Q xt) - b'xt
                 const double gd = tot[2] - tot[3];      // g(xt)'d = d'(Q xt) - b'd
                 c.st_gd0 = tot[4]; c.st_dnf = tot[5];
-                if (c.req_kind == QN_REQ_T && !c.gd0_valid) { c.gd0 = tot[4]; c.d_finite = tot[5] == 0.0; c.gd0_valid = 1; }
+                // (BND: a PROJECTED trial -- BackTrackingB, s2_proj_kernel -- was evaluated at a stored point, with d = 0: it says nothing about
+                // g'd, and it is not the point x + t d the memo speaks of)
+                const bool proj = BND && c.req_project != 0;
+                if (c.req_kind == QN_REQ_T && !c.gd0_valid && !proj) { c.gd0 = tot[4]; c.d_finite = tot[5] == 0.0; c.gd0_valid = 1; }
                 c.f_e = f; c.gd_e = gd;
                 c.n_oracle_evals++;
                 c.ev_par ^= 1; c.ev_kind = c.req_kind; c.ev_t = c.req_t;
-                if (c.req_kind == QN_REQ_T) { c.last_valid = 1; c.last_t = c.req_t; c.f_last = f; c.gd_last = gd; }
+                if (c.req_kind == QN_REQ_T && !proj) { c.last_valid = 1; c.last_t = c.req_t; c.f_last = f; c.gd_last = gd; }
                 else c.last_valid = 0;
+                if (BND) c.last_projected = proj ? 1 : 0;
                 if (c.req_need_vectors) { c.phase = QN_PH_REQ_VEC; return; } // the caller wants g+, y, s of this point too
                 c.state = c.after_state;
             } else if (ph == QN_PH_REQ_VEC) {
@@ -444,6 +449,14 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
         for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
         tot[0] = m;
     }
+    if constexpr (BND) if (c.serviced == 5 && ph == QN_PH_REQ_EVAL) { // (uniform) column 0 of s2_proj_kernel's rows: ||P(x + t d) - x||^2, block-rows in order
+        double d2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < QN_S2_PCH; ++j) d2 = d2 + ((j * 64 + lane < a.nb) ? tr[j][0] : 0.0);
+        for (int b = QN_S2_MAXG + lane; b < a.nb; b += 64) d2 = d2 + T[b];
+        d2 = qn_wave_sum(d2);
+        if (lane == 0) c.bt_diff2 = d2; // (backtracking_b.rs:33-34; the evaluation this launch may run is AT the stored projected point)
+    }
     QN_S2_STAMP(10);
     QnVecs V{};
     V.n = a.n; V.n_pad = a.np; V.trace = a.trace;
@@ -493,7 +506,8 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     }
     QN_S2_STAMP(11);
     if (lane == 0) {
-        if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == 0;
+        if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == ((BND && c.req_project) ? 5 : 0); // (a projected trial: behind its s2_proj_kernel)
+        if (KIND == QN_S2_PROJ) mine = c.phase == QN_PH_REQ_EVAL && c.req_project && c.serviced == 0;
         if (KIND == QN_S2_VEC || KIND == QN_S2_VSUM) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
         if (KIND == QN_S2_HTILE) { // 2: the accepted point's slots -> vectors AND the update tiles (folded accept-reduce); 1: the tiles of a pending pass
             if (a.fold && c.phase == QN_PH_REQ_VEC && c.serviced == 0) mine = 2;
@@ -507,6 +521,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
         if (mine) { // as this launch leaves the request
             if (KIND == QN_S2_HTILE) { c.serviced = (mine == 2 || a.tred) ? 2 : 1; if (mine == 2) c.spec_tiles = c.ev_kind == QN_REQ_T ? 2 : 1; } // (tail reduce: the launch leaves the pass complete)
             else if (KIND == QN_S2_VSUM || KIND == QN_S2_GEVAL_A || KIND == QN_S2_GHT_A) c.serviced = 1; // (the exchange / the kernels that do the work follow)
+            else if (KIND == QN_S2_PROJ) c.serviced = 5; // (the trial point is stored: its evaluation launch follows)
             else c.serviced = 2;
         }
         L.mine = mine;
@@ -536,11 +551,13 @@ __device__ __forceinline__ void qn_s2_ctl_out(const QnS2Args& a, const QnS2Lds& 
 __device__ __forceinline__ double qn_uniform(const double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
-template <bool PIN>
+template <bool PIN, bool BNDREQ = false> // (BNDREQ: the bounded runs' evaluation kernels -- a request may name a STORED point)
 __device__ __forceinline__ QnEvalReq qn_s2_eval_req(const QnCtl& c, bool last_eval) {
     QnEvalReq q;
     q.is_t = (last_eval ? c.ev_kind : c.req_kind) == QN_REQ_T;
     q.t = last_eval ? c.ev_t : c.req_t;
+    const bool stored = BNDREQ && !last_eval && c.req_project != 0; // (BackTrackingB: evaluate AT the point s2_proj_kernel stored in the trial half of X0)
+    if (stored) q.is_t = false;
     q.mode = c.dir_mode;
     q.c_ss = c.c_ss; q.c_su = c.c_su; q.c_uu = c.c_uu; q.ug = c.dir_ug; q.sg = c.dir_sg;
     // The lazy direction -H+ g+ = -(v + c_su (s (u.g) + u (s.g)) + c_ss s (s.g) + c_uu u (u.g)) with the two vector coefficients
@@ -549,7 +566,7 @@ __device__ __forceinline__ QnEvalReq qn_s2_eval_req(const QnCtl& c, bool last_ev
     // the x+ that is stored is the point that was evaluated.)
     q.al = q.c_su * q.ug + q.c_ss * q.sg;
     q.be = q.c_su * q.sg + q.c_uu * q.ug;
-    q.xc = c.xc; q.sc = c.sc;
+    q.xc = stored ? 1 - c.xc : c.xc; q.sc = c.sc;
     if (PIN) { q.al = qn_uniform(q.al); q.be = qn_uniform(q.be); }
     if (PIN) { // (the tile kernel; the accept-reduce has registers to spare and only pays the readfirstlane latency)
         q.is_t = __builtin_amdgcn_readfirstlane(q.is_t) != 0;
@@ -926,7 +943,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_eval_kernel(const QnS2Args a)
     if (!L.mine) return;
     QN_S2_STAMP(2);
     if (wave == 0) window_load(parked ? ij1 : ij0); // (parked: its rows of the first item are in LDS)
-    const QnEvalReq q = qn_s2_eval_req<true>(L.c, false);
+    const QnEvalReq q = qn_s2_eval_req<true, BND>(L.c, false);
     const double* __restrict__ x = a.F.X0 + (size_t)q.xc * np;
     const double* __restrict__ sp = a.F.S0 + (size_t)q.sc * np;
     if (q.xc) { va.x_r = v1.x_r; va.x_c = v1.x_c; }
@@ -1820,6 +1837,44 @@ __global__ __launch_bounds__(QN_TB) void s2_dir_kernel(const QnS2Args a) {
     if (lane == 0) red[wave] = cand;
     __syncthreads();
     if (tid == 0) a.wgS[((size_t)a.parity * QN_S2_ROW + 0) * a.trows + R] = fmin(red[0], red[1]);
+}
+
+// BACKTRACKINGB ON THIS PATH (round 6; backtracking_b.rs:52-88).  Its trial point is P(x + t d) -- projected onto the LINE SEARCH's box --
+// and its Armijo rule reads ||P(x + t d) - x||^2 / t instead of g'd (:24-34).  The evaluation kernels form x + t d on the fly and know nothing of boxes;
+// so a projected trial takes ONE more launch of nb workgroups, this one, in front of its evaluation: block-row R forms the trial point at its 128
+// entries exactly as the evaluations would (qn_s2_trial on the lazy or the stored direction), projects it, STORES it in the trial half of the x
+// double buffer (the half the accept-reduce overwrites with x+ later) and leaves the block-row's share of ||P(x + t d) - x||^2 in the table.  The
+// evaluation launch behind it finds the request in service state 5: its prologue adds the shares up (QnCtl.bt_diff2) and the kernel evaluates AT
+// the stored point (qn_s2_eval_req<., true>: the other half of X0, no step) -- tiles, slots, scalars as for any point.  The accepted step's
+// x + t d is NOT the projected point (bfgs_b.rs:91-98 evaluates the oracle at x + step * direction): it gets the ordinary evaluation, with
+// vectors, that every iteration ends with.
+__global__ __launch_bounds__(QN_TB) void s2_proj_kernel(const QnS2Args a) {
+    __shared__ QnS2Lds L;
+    __shared__ double red[2];
+    const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gi = R * QN_TB + tid;
+    const size_t np = (size_t)a.np;
+    double x0 = 0.0, x1 = 0.0, s0 = 0.0, s1 = 0.0, vv = 0.0, un = 0.0, lo = -INFINITY, hi = INFINITY;
+    auto entries = [&]() { // (requested before the machine runs, for both settings of the two buffer toggles: see s2_vec_kernel)
+        x0 = a.F.X0[gi]; x1 = a.F.X0[np + gi]; s0 = a.F.S0[gi]; s1 = a.F.S0[np + gi]; vv = a.F.VV[gi]; un = a.F.UN[gi];
+        if (a.llb) { lo = a.llb[gi]; hi = a.lub[gi]; }
+    };
+    if (wave == 0) qn_s2_prologue_w0<QN_S2_PROJ, false, decltype(entries)&, false, true>(a, L, entries);
+    else entries();
+    __syncthreads();
+    qn_s2_ctl_out(a, L);
+    if (!L.mine) return;
+    const QnEvalReq q = qn_s2_eval_req<false>(L.c, false); // (the request as an evaluation would decode it: x + t d)
+    const double xi = q.xc ? x1 : x0, si = q.sc ? s1 : s0;
+    double d;
+    double z = qn_s2_trial(q, xi, vv, si, un, d);
+    z = fmin(fmax(z, lo), hi); // x_kp1.box_projection(&self.lower_bound, &self.upper_bound), backtracking_b.rs:67
+    a.F.X0[(size_t)(1 - q.xc) * np + gi] = z;
+    const double df = z - xi; // diff = x - x0, :31
+    double p = qn_wave_sum(df * df);
+    if (lane == 0) red[wave] = p;
+    __syncthreads();
+    if (tid == 0) a.wgS[((size_t)a.parity * QN_S2_ROW + 0) * a.trows + R] = red[0] + red[1];
 }
 
 // lower triangle <- transpose of the maintained upper one, 32 x 32 blocks through LDS; inside the diagonal blocks too

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
     // (0 = physical wave 0: the prologue addresses its lanes by threadIdx.x), 8..15 multipliers; 8 + w takes the rows mover w parks.
     const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = (pwave >> 2) * 2 + ((pwave & 3) >> 1) + ((((pwave >> 2) + (pwave & 3)) & 1) ? QN_S2_WAVES : 0);
-    const int ltid = wave * 64 + lane; // (the logical thread index: what the diagnostic stamps and the ring's clearing address)
+    const int ltid = wave * 64 + lane; // (the logical thread index: what the diagnostic stamps address)
+    (void)ltid;
     const size_t np = (size_t)a.np;
     // (the kernel's own first 32 KB -- the prologue and the movers' code -- are read as DATA by four multipliers at entry: qn_kernels.hip.h, CODE WARM-UP.
     // Round 5's kernel let waves 1..4 do it in front of their rows; a wave's loads return in order, so those four movers' rows -- and the
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
         entry_barrier();
         qn_s2r_wait_ge<8>(&Y.mdone, 1u, bad); // (long naps: the machine's wave shares its SIMD with three of the waiting ones)
         if (!L.mine) return;
-        const QnEvalReq q = qn_s2_eval_req<true>(L.c, false);
+        const QnEvalReq q = qn_s2_eval_req<true, BND>(L.c, false);
         if (mw < 5) { // the trial point at this wave's block: qn_s2_trial, entry by entry -- what every wave of round 5's kernel formed for itself
             const v2d ex = q.xc ? e_x1 : e_x0, es = q.sc ? e_s1 : e_s0;
             v2d xt, dd;

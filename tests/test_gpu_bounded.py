@@ -120,10 +120,12 @@ def test_bounded_run_to_termination_matches_oracle(qn, qo, method):
 
 
 @pytest.mark.parametrize("method", ["bfgsb", "dfpb", "sr1b"])
-@pytest.mark.parametrize("lsname", ["mt", "mtb"])
+@pytest.mark.parametrize("lsname", ["mt", "mtb", "btb"])
 @pytest.mark.parametrize("n", [1024, 1408])  # (work lists read from memory; the two-items-and-a-sliver instance: the test below)
 def test_bounded_second_generation_path_vs_oracle_and_generic(qn, qo, method, lsname, n):
-    """BFGSB / DFPB / SR1B with More-Thuente(B) on the second-generation symmetric path (s2_dir_kernel, qn_sym2.hip.h: the direction stored and
+    """BFGSB / DFPB / SR1B with More-Thuente(B) -- and, round 6, BackTrackingB: its projected trial points stored by s2_proj_kernel, the evaluation
+    AT the stored point, ||P(x + t d) - x||^2 through the table (backtracking_b.rs:24-34, 52-88) -- on the second-generation symmetric path
+    (s2_dir_kernel, qn_sym2.hip.h: the direction stored and
     projected by one more launch per iteration, t_max clipped where that request is consumed): against the oracle's restatement, against the
     generic path (set_option("bounded_second_generation", 0)), and pipelined against synchronous bit for bit."""
     q, b, x0, lb, ub = _box(qo, n)
@@ -219,6 +221,51 @@ def test_warm_call_with_another_line_search_box_forms_its_direction_again(qn, qo
         outs[mode] = (x7, ls.t_max())
     assert np.linalg.norm(outs["second generation"][0] - outs["generic"][0]) <= 1e-7 * max(1.0, np.linalg.norm(outs["generic"][0]))
     assert abs(outs["second generation"][1] - outs["generic"][1]) <= 1e-8 * max(1.0, abs(outs["generic"][1]))
+
+
+def test_backtracking_b_at_the_benchmark_size_on_the_second_generation_path(qn, qo):
+    """Round 6: BFGSB + BackTrackingB at n = 4096 -- the projected trial points stored by s2_proj_kernel, evaluated AT the stored
+    point by the mover / multiplier kernel's bounded instantiation (s2_evalr_kernel<true>) and, with set_option("eval_mover_multiplier", 0), by round
+    5's two-items-and-a-sliver instance: both equal the oracle's restatement (evaluation counts, steps, iterates over the window) and the generic
+    path, and each other bit for bit; pipelined equals synchronous bit for bit; no host round trip per request."""
+    n = 4096
+    q, b, x0, lb, ub = _box(qo, n)
+    iters = 16
+    ref = qo.Solver(qo.BFGS, 1e-9, x0, qo.UPDATE_RANK2, nthreads=qo.max_threads())
+    ref.set_bounds(lb, ub)
+    ref.minimize(_make_ls(qo, "btb", n, lb, ub), qo.QuadraticOracle(q, b, nthreads=qo.max_threads()), iters, 30, trace_cap=iters, trace_x=True)
+    obj = qn.Quadratic(q, b)
+    got = {}
+    for mode in ("ring", "ring sync", "pair", "generic"):
+        s = qn.BFGSB.new(1e-9, x0, lb, ub)
+        s.set_trace(iters, with_x=True)
+        if mode == "ring sync":
+            s.set_sync_mode(1)
+        if mode == "pair":
+            s.set_option("eval_mover_multiplier", 0)
+        if mode == "generic":
+            s.set_option("bounded_second_generation", 0)
+        try:
+            s.minimize(_make_ls(qn, "btb", n, lb, ub), obj, iters, 30)
+        except qn.MaxIterReached:
+            pass
+        tr, xs = s.trace()
+        st = s.stats()
+        assert bool(st["path"] & 16) == (mode != "generic")
+        w = min(len(tr), len(ref.trace))
+        assert w >= 12
+        for k in range(w):
+            assert tr[k]["n_evals"] == ref.trace[k]["n_evals"], (mode, k)
+            assert abs(tr[k]["t"] - ref.trace[k]["t"]) <= 1e-8 * abs(ref.trace[k]["t"]), (mode, k)
+            assert np.linalg.norm(xs[k] - ref.trace_x[k]) <= 1e-8 * max(1.0, np.linalg.norm(ref.trace_x[k])), (mode, k)
+        x = s.x()
+        assert np.all(x >= lb - 1e-12) and np.all(x <= ub + 1e-12)
+        got[mode] = (tr, xs, x)
+        if mode == "ring":
+            assert st["host_syncs"] <= 8  # (one per batch of periods, not one per request: the run makes ~130 requests)
+    assert got["ring"][0] == got["pair"][0] == got["ring sync"][0]
+    assert np.array_equal(got["ring"][1], got["pair"][1]) and np.array_equal(got["ring"][1], got["ring sync"][1])
+    assert np.linalg.norm(got["ring"][2] - got["generic"][2]) <= 1e-8 * max(1.0, np.linalg.norm(got["generic"][2]))
 
 
 def test_bounded_second_generation_path_at_the_benchmark_size(qn, qo):
