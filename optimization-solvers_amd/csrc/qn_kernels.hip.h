@@ -478,7 +478,15 @@ __global__ void identity_fill_kernel(double* __restrict__ H, const QnTile T) {
 // of a vector state's sums, which the control kernel does not need: inside one launch an entry of an n-vector is only ever touched by thread
 // (i mod blockDim) -- program order -- and the states are separated by the loop's own __syncthreads().  In-kernel stamps at n = 4096,
 // bounded run: the two-sweep state behind an update pass 15.6 us, the one-sweep state behind an evaluation 7.3 us (tools/ctl_stamps_bounded.py).
+// THE INVARIANT this rests on -- an n-vector entry is touched by ONE thread per launch -- is stated, not checked by the compiler: a state that reads a
+// neighbour's entry would race silently.  -DQN_CTL_FULL_BARRIERS (csrc/Makefile target `fullbar`, built by __graft_entry__.build()) turns every
+// LDS-only barrier back into __syncthreads(); tests/test_gpu_bounded.py::test_lds_only_barriers_equal_full_barriers_bit_for_bit runs the bounded
+// generic path through both builds and compares the bits.
+#ifdef QN_CTL_FULL_BARRIERS
+__device__ __forceinline__ void qn_lds_barrier() { __syncthreads(); }
+#else
 __device__ __forceinline__ void qn_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 template <int K, bool LDS_ONLY = false>
 __device__ __forceinline__ void ctl_block_sum(double (&v)[K], double* lds /* 16*K */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -309,3 +309,52 @@ def test_bounded_second_generation_path_at_the_benchmark_size(qn, qo):
             assert st["host_syncs"] <= 4
             assert st["launches"] <= 2 * (len(tr) * 4 + evals) + 16  # (dir + vec + tiles + reduce per iteration, the evaluations; slack for unused slots)
     assert np.linalg.norm(xs_by_mode["second generation"] - xs_by_mode["generic"]) <= 1e-8 * max(1.0, np.linalg.norm(xs_by_mode["generic"]))
+
+
+def test_lds_only_barriers_equal_full_barriers_bit_for_bit(qn, qo):
+    """the generic path's control kernel orders its vector states with barriers that wait for LDS only (qn_lds_barrier: no wait for the wave's
+    global stores) -- correct because an n-vector entry is touched by one thread per launch, an invariant nothing checks.  The same library built with
+    -DQN_CTL_FULL_BARRIERS (`make -C csrc fullbar`, part of build()) runs the bounded generic path -- BFGSB + BackTrackingB and MoreThuenteB, projections
+    and all -- in a child process; traces and iterates must be equal bit for bit."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "optimization-solvers_amd", "lib", "libqn_hip_fullbar.so")
+    if not os.path.exists(lib):
+        pytest.skip("libqn_hip_fullbar.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    code = r"""
+import sys, os, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import __graft_entry__ as ge
+qn = ge.load_package()
+from oracle import qn_oracle as qo
+import test_gpu_bounded as T
+h = hashlib.sha256()
+for n, lsname in ((1024, "btb"), (1100, "mtb"), (640, "btb")):
+    q, b, x0, lb, ub = T._box(qo, n)
+    s = qn.BFGSB.new(1e-9, x0, lb, ub)
+    s.set_option("bounded_second_generation", 0)
+    s.set_trace(12, with_x=True)
+    try:
+        s.minimize(T._make_ls(qn, lsname, n, lb, ub), qn.Quadratic(q, b), 12, 30)
+    except qn.MaxIterReached:
+        pass
+    tr, xs = s.trace()
+    assert not (s.stats()["path"] & 16)
+    h.update(repr(tr).encode()); h.update(np.ascontiguousarray(xs).tobytes()); h.update(np.ascontiguousarray(s.x()).tobytes())
+print("DIGEST", h.hexdigest())
+""" % (root, root)
+    digests = []
+    for env_lib in (None, lib):
+        env = dict(os.environ)
+        if env_lib:
+            env["QN_HIP_LIB"] = env_lib
+        else:
+            env.pop("QN_HIP_LIB", None)
+        cp = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert cp.returncode == 0, cp.stderr[-2000:]
+        digests.append([l for l in cp.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
