@@ -282,7 +282,7 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
             for (int r = 0; r < QN_S2_RPW; ++r) {
                 park[wave][r][lane] = h[r];
                 h[r] = ld2(q1 + (size_t)r * np);
-                if ((r & 3) == 3) qn_s2r_publish<false>(&Y.prod[wave], (unsigned)r + 1u);
+                if ((r & 3) == 3) qn_s2r_publish(&Y.prod[wave], (unsigned)r + 1u); // (with the wait for the wave's LDS writes: measured no slower than without -- the in-order variant stays a template switch)
             }
             QN_S2R_STAMP(7, 448); // (wave 7: its sixteen rows parked, the second item requested)
             qn_s2r_wait_ge<8>(&Y.mdone, 1u, bad); // (long naps: the machine's wave shares its SIMD with three of the waiting ones)

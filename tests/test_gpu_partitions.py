@@ -253,3 +253,27 @@ def test_logsumexp_partition_second_generation_structure(qn, qo, world, m, n, me
     ref = qo.Solver(qo.DFP if method == "dfp" else qo.BFGS, 1e-10, x0, qo.UPDATE_RANK2, nthreads=4)
     ref.minimize(mk(qo), o, iters, 20, trace_cap=iters, trace_x=True)
     _trace_close(res[0]["tr"], res[0]["xs"], ref.trace, ref.trace_x)
+
+
+def test_exchange_probe_on_a_host_staged_partition(qn):
+    """qn_context_exchange_probe (ABI 5, round 6): what bench.py --gpus N prints in front of its timed region -- the latency of ONE exchange of `count`
+    doubles per rank, launch to completion -- on a four-rank partition of the one GPU (ranks as threads, host-staged exchange): collective, positive,
+    ordered (min <= median <= max), larger for 2 n doubles than for 8 KB; a one-rank context reports zeros."""
+    world = 4
+
+    def body(rank, world_, group):
+        ctx = qn.Context(0, rank=rank, world=world_, host_allgather=group.allgather_fn(rank))
+        ctx.comm_check()
+        small, big = ctx.exchange_probe(1024, reps=6), ctx.exchange_probe(2 * 32768, reps=6)
+        group.sync()
+        ctx.close()
+        return small, big
+
+    for small, big in run_ranks(world, body):
+        for p in (small, big):
+            assert 0.0 < p["min_us"] <= p["median_us"] <= p["max_us"] < 1e7
+        assert small["bytes_per_rank"] == 8192 and big["bytes_per_rank"] == 8 * 2 * 32768
+    one = qn.Context(0)
+    z = one.exchange_probe(1024, reps=3)
+    assert z["median_us"] == 0.0 and z["max_us"] == 0.0
+    one.close()
