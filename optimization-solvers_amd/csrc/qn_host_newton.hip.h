@@ -150,6 +150,15 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     if (!s->newton_panel) HIPCHK(hipMalloc((void**)&s->newton_panel, 2 * panel_doubles * sizeof(double)));
     if (!s->newton_sync) HIPCHK(hipMalloc((void**)&s->newton_sync, 128 * sizeof(int)));
     HIPCHK(hipMemsetAsync(s->newton_sync, 0, 128 * sizeof(int), st));
+    // role A split over the workgroups of one XCD (qn_lu_split.hip.h): the parts' records, two panels' worth, all words the sentinel
+    // (measured at n = 8192, ms per Newton iteration: every panel split 44.2 = no split 44.2 -- a split pivot step costs 2.6-3.2 us at any height, one
+    // workgroup's 1.6 (1792 rows) ... 2.6 (7552 rows) us and what the split saves is column traffic --; from 2560 rows 42.1, 3136: 42.0, 4160: 41.4-41.7,
+    // 5184: 42.5.  The first ~16 panels gain nothing either way: there the previous panel's bulk update, not the chain, sets the period)
+    static const int lu_split_min = getenv("QN_LU_SPLIT_MIN") ? atoi(getenv("QN_LU_SPLIT_MIN")) : 4160; // panels of fewer rows: one workgroup
+    if (s->newton_lu_split > 1) {
+        if (!s->newton_rec) HIPCHK(hipMalloc((void**)&s->newton_rec, 2 * (size_t)QN_LUS_REC_WORDS * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(s->newton_rec, 0xff, 2 * (size_t)QN_LUS_REC_WORDS * sizeof(unsigned long long), st));
+    }
     static const int lu_persist_on = getenv("QN_LU_PERSIST") ? atoi(getenv("QN_LU_PERSIST")) : 1;
     const bool persist = lu_persist_on && !s->newton_lu_no_persist;
     const int spin_max = s->newton_lu_force_timeout ? 0 : QN_LU_SPIN_MAX; // (diagnostics: every wait that is not satisfied at once gives up -> the fallback below)
@@ -192,7 +201,22 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
             p_ready = false;
             in_p = true;
             const int rpt_p = (m + QN_LU_PT - 1) / QN_LU_PT;
-            if (persist) { // the panel in one launch: 58 workgroups waiting for each other on counters (qn_lu.hip.h)
+            const int G = (persist && m >= lu_split_min) ? s->newton_lu_split : 1;
+            if (G > 1) { // ... with role A split over G workgroups of one XCD (qn_lu_split.hip.h)
+                const dim3 pg(2 + QN_NB - 2 * QN_LU_SUB + (G - 1)), pb(QN_LU_PT);
+                const int base = 32 * pi;
+                unsigned long long* rec = s->newton_rec + (size_t)(pi & 1) * QN_LUS_REC_WORDS;
+                unsigned long long* rec_next = s->newton_rec + (size_t)((pi + 1) & 1) * QN_LUS_REC_WORDS;
+                const int rptl = ((m + QN_LU_PT - 1) / QN_LU_PT + G - 1) / G; // rows per thread of a part
+#define QN_LUS_LAUNCH(R, GG) hipLaunchKernelGGL((lu_panel_split_kernel<R, GG>), pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max, rec, rec_next)
+                if (G == 2) {
+                    if (rptl <= 1) QN_LUS_LAUNCH(1, 2); else if (rptl <= 2) QN_LUS_LAUNCH(2, 2); else if (rptl <= 4) QN_LUS_LAUNCH(4, 2); else QN_LUS_LAUNCH(8, 2);
+                } else {
+                    if (rptl <= 1) QN_LUS_LAUNCH(1, 4); else if (rptl <= 2) QN_LUS_LAUNCH(2, 4); else QN_LUS_LAUNCH(4, 4);
+                }
+#undef QN_LUS_LAUNCH
+                launches += 1;
+            } else if (persist) { // the panel in one launch: 58 workgroups waiting for each other on counters (qn_lu.hip.h)
                 const dim3 pg(2 + QN_NB - 2 * QN_LU_SUB), pb(QN_LU_PT);
                 const int base = 32 * pi;
                 if (rpt_p <= 1) hipLaunchKernelGGL(lu_panel_persist_kernel<1>, pg, pb, 0, st, P, pld, m, p0, s->newton_piv, flag, s->newton_sync, base, spin_max);

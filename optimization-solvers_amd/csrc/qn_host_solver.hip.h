@@ -78,6 +78,8 @@ struct qn_solver {
     int newton_lu_force_timeout = 0; // diagnostics (QN_OPT_LU_FORCE_WAIT_EXPIRY): the one-launch kernels' waits give up at once (exercises the fallback)
     int newton_lu_no_persist = 0; // diagnostics (QN_OPT_LU_ONE_LAUNCH_PANEL 0), or set after a bounded wait of the one-launch panel gave up: one launch per sub-panel
     int* newton_sync = nullptr;   // the one-launch panel's counters (qn_lu.hip.h, lu_panel_persist_kernel)
+    unsigned long long* newton_rec = nullptr; // ... and, with role A split over workgroups, the parts' records (qn_lu_split.hip.h)
+    int newton_lu_split = getenv("QN_LU_SPLIT") ? atoi(getenv("QN_LU_SPLIT")) : 4; // parts of role A: 1 (one workgroup, rounds 4-5), 2 or 4 (QN_OPT_LU_SPLIT_ROLE_A)
     uint64_t newton_lu_sync_timeouts = 0;
     int newton_lu_timeout_fallback = 0; // newton_lu_no_persist was set by an expired wait (not by the diagnostics switch): how many factorisations have run launch by launch since
     int newton_lu_no_la = 0; // diagnostics (QN_OPT_LU_LOOKAHEAD 0): the LU without the look-ahead on a second stream
@@ -412,7 +414,7 @@ extern "C" void qn_solver_destroy(qn_solver* s) {
     for (auto& e : s->event_pool) (void)hipEventDestroy(e);
     if (s->s2_graph_exec) (void)hipGraphExecDestroy(s->s2_graph_exec);
     (void)hipFree(s->H); (void)hipFree(s->vec_block); (void)hipFree(s->V.hp); (void)hipFree(s->V.q);
-    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->symsh_xg); (void)hipFree(s->symsh_gath); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm); (void)hipFree(s->newton_panel); (void)hipFree(s->newton_sync);
+    (void)hipFree(s->newton_w); (void)hipFree(s->newton_x); (void)hipFree(s->newton_invl); (void)hipFree(s->newton_inv2); (void)hipFree(s->sym_part); (void)hipFree(s->symsh_xg); (void)hipFree(s->symsh_gath); (void)hipFree(s->newton_hsrc); (void)hipFree(s->newton_fail); (void)hipFree(s->newton_piv); (void)hipFree(s->newton_perm); (void)hipFree(s->newton_panel); (void)hipFree(s->newton_sync); (void)hipFree(s->newton_rec);
     (void)hipFree(s->bounds_block);
     (void)hipFree(s->fused_block); (void)hipFree(s->fused_evp); (void)hipFree(s->fused_hpp);
     (void)hipFree(s->s2_items); (void)hipFree(s->s2_wgS); (void)hipFree(s->s2_partE); (void)hipFree(s->s2_ctl);
@@ -490,6 +492,10 @@ extern "C" int qn_solver_set_option(qn_solver* s, int option, int value) {
     case QN_OPT_LU_LOOKAHEAD: s->newton_lu_no_la = on ? 0 : 1; return QN_OK;
     case QN_OPT_LU_ONE_LAUNCH_PANEL: s->newton_lu_no_persist = on ? 0 : 1; return QN_OK;
     case QN_OPT_LU_FORCE_WAIT_EXPIRY: s->newton_lu_force_timeout = on ? 1 : 0; return QN_OK;
+    case QN_OPT_LU_SPLIT_ROLE_A:
+        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(QN_ERROR_INPUT_PARAMS, "role A runs as 1, 2 or 4 workgroups");
+        s->newton_lu_split = value == 0 ? 1 : value;
+        return QN_OK;
     case QN_OPT_CHUNKS_PER_TRIP:
         if (value != 1 && value != 2 && value != 4) return fail(QN_ERROR_INPUT_PARAMS, "chunks per trip must be 1, 2 or 4");
         s->U = value;

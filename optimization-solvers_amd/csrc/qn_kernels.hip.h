@@ -940,6 +940,7 @@ __global__ __launch_bounds__(256) void lse_finish1_kernel(const QnLseArgs a, con
 #include "qn_sym.hip.h"
 #include "qn_newton.hip.h"
 #include "qn_lu.hip.h"
+#include "qn_lu_split.hip.h"
 #include "qn_ctl_step.hip.h"
 #include "qn_sym2.hip.h"
 #include "qn_sym2r.hip.h"

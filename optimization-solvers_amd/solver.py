@@ -54,6 +54,7 @@ OPTIONS = {
     "lu_one_launch_panel": 14,
     "lu_force_wait_expiry": 15,
     "chunks_per_trip": 16,
+    "lu_split_role_a": 17,
 }
 OPT_GENERIC_KERNELS = 1
 OPT_DEFERRED_UPDATE_STEP = 2
@@ -71,6 +72,7 @@ OPT_LU_LOOKAHEAD = 13
 OPT_LU_ONE_LAUNCH_PANEL = 14
 OPT_LU_FORCE_WAIT_EXPIRY = 15
 OPT_CHUNKS_PER_TRIP = 16
+OPT_LU_SPLIT_ROLE_A = 17
 
 
 class SolverError(Exception):

@@ -336,15 +336,20 @@ def test_panel_lu_equals_the_per_column_lu_bit_for_bit(qn, qo, n):
     Round 4: from 8 panels on the default path also runs the LOOK-AHEAD (the trailing update split between the solver's stream and a
     CU-masked second stream, the U12 solve row by row with scalar multipliers, the update as a resident grid that loops);
     set_option("lu_lookahead", 0) is the single-stream path with rounds 1-3's kernels -- the same bits again.  And the panel itself is ONE launch
-    (58 workgroups waiting for each other on counters, lu_panel_persist_kernel); set_option("lu_one_launch_panel", 0) is round 3's launch per sub-panel."""
+    (58 workgroups waiting for each other on counters, lu_panel_persist_kernel); set_option("lu_one_launch_panel", 0) is round 3's launch per sub-panel.
+    Round 6: the pivot chain of that launch shared by the workgroups of one XCD (records through memory, one hop per pivot step):
+    set_option("lu_split_role_a", 1 | 2 | 4)."""
     fn, hess0, x0 = _double_well_chain(n)
     iters = 3 if n <= 2000 else 1
     rng = np.random.default_rng(8)
     k = 0.2 * np.triu(rng.standard_normal((n, n)), 1) / np.sqrt(n)
     hess = lambda x: hess0(x) + k - k.T  # noqa: E731
     runs = []
-    for percol, no_la, no_persist in ((False, False, False), (True, True, True), (False, True, False), (False, False, True)):
+    # (round 6) the default panel shares its pivot chain between FOUR workgroups (csrc/qn_lu_split.hip.h); parts = 1 is rounds 4-5's one workgroup, 2 the other split
+    for percol, no_la, no_persist, parts in ((False, False, False, 4), (True, True, True, 4), (False, True, False, 4), (False, False, True, 4),
+                                             (False, False, False, 1), (False, False, False, 2), (False, True, False, 2)):
         s = qn.Newton(1e-10, x0)
+        s.set_option("lu_split_role_a", parts)
         if percol:
             s.set_option("lu_per_column_panel", 1)
         if no_la:
@@ -358,10 +363,14 @@ def test_panel_lu_equals_the_per_column_lu_bit_for_bit(qn, qo, n):
             pass
         tr, xs = s.trace()
         runs.append((tr, xs, s.stats()["launches"]))
+        assert s.stats()["newton_lu_sync_timeouts"] == 0  # (no path got here through an expired wait's fallback)
     key = lambda tr: [(r["f"], r["gnorm"], r["t"], r["n_evals"], r["ls_cases"]) for r in tr]  # noqa: E731  (s_norm / y_norm are NaN: Newton has none)
     assert key(runs[0][0]) == key(runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
     assert key(runs[0][0]) == key(runs[2][0]) and np.array_equal(runs[0][1], runs[2][1])
     assert key(runs[0][0]) == key(runs[3][0]) and np.array_equal(runs[0][1], runs[3][1])
+    for other in runs[4:]:
+        assert key(runs[0][0]) == key(other[0]) and np.array_equal(runs[0][1], other[1])
+    assert runs[0][2] == runs[4][2]  # (the same launches: the split changes a grid, not a count)
     assert runs[0][2] < runs[1][2]
     # and the direction is the Newton direction of the matrix as given
     f0, g0 = fn(x0)

@@ -4,7 +4,7 @@ import csv, glob, sys
 f = glob.glob("gpurun_out/lu_prof/**/p_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-loads = [i for i, r in enumerate(rows) if "lu_panel_persist" in r["Kernel_Name"]]  # one per panel (the one-launch panel)
+loads = [i for i, r in enumerate(rows) if "lu_panel_persist" in r["Kernel_Name"] or "lu_panel_split" in r["Kernel_Name"]]  # one per panel (the one-launch panel)
 if len(loads) < 128:
     loads = [i for i, r in enumerate(rows) if "lu_panel_load" in r["Kernel_Name"]]
 start = loads[-128]
