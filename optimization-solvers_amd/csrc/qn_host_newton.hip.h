@@ -154,7 +154,7 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     // (measured at n = 8192, ms per Newton iteration: every panel split 44.2 = no split 44.2 -- a split pivot step costs 2.6-3.2 us at any height, one
     // workgroup's 1.6 (1792 rows) ... 2.6 (7552 rows) us and what the split saves is column traffic --; from 2560 rows 42.1, 3136: 42.0, 4160: 41.4-41.7,
     // 5184: 42.5.  The first ~16 panels gain nothing either way: there the previous panel's bulk update, not the chain, sets the period)
-    static const int lu_split_min = getenv("QN_LU_SPLIT_MIN") ? atoi(getenv("QN_LU_SPLIT_MIN")) : 4160; // panels of fewer rows: one workgroup
+    const int lu_split_min = s->newton_lu_split_min; // panels of fewer rows: one workgroup (QN_OPT_LU_SPLIT_MIN_ROWS, default 4160)
     if (s->newton_lu_split > 1) {
         if (!s->newton_rec) HIPCHK(hipMalloc((void**)&s->newton_rec, 2 * (size_t)QN_LUS_REC_WORDS * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(s->newton_rec, 0xff, 2 * (size_t)QN_LUS_REC_WORDS * sizeof(unsigned long long), st));

@@ -80,6 +80,7 @@ struct qn_solver {
     int* newton_sync = nullptr;   // the one-launch panel's counters (qn_lu.hip.h, lu_panel_persist_kernel)
     unsigned long long* newton_rec = nullptr; // ... and, with role A split over workgroups, the parts' records (qn_lu_split.hip.h)
     int newton_lu_split = getenv("QN_LU_SPLIT") ? atoi(getenv("QN_LU_SPLIT")) : 4; // parts of role A: 1 (one workgroup, rounds 4-5), 2 or 4 (QN_OPT_LU_SPLIT_ROLE_A)
+    int newton_lu_split_min = getenv("QN_LU_SPLIT_MIN") ? atoi(getenv("QN_LU_SPLIT_MIN")) : 4160; // ... for panels of at least this many rows (QN_OPT_LU_SPLIT_MIN_ROWS)
     uint64_t newton_lu_sync_timeouts = 0;
     int newton_lu_timeout_fallback = 0; // newton_lu_no_persist was set by an expired wait (not by the diagnostics switch): how many factorisations have run launch by launch since
     int newton_lu_no_la = 0; // diagnostics (QN_OPT_LU_LOOKAHEAD 0): the LU without the look-ahead on a second stream
@@ -495,6 +496,10 @@ extern "C" int qn_solver_set_option(qn_solver* s, int option, int value) {
     case QN_OPT_LU_SPLIT_ROLE_A:
         if (value != 0 && value != 1 && value != 2 && value != 4) return fail(QN_ERROR_INPUT_PARAMS, "role A runs as 1, 2 or 4 workgroups");
         s->newton_lu_split = value == 0 ? 1 : value;
+        return QN_OK;
+    case QN_OPT_LU_SPLIT_MIN_ROWS:
+        if (value < 0) return fail(QN_ERROR_INPUT_PARAMS, "a number of rows");
+        s->newton_lu_split_min = value;
         return QN_OK;
     case QN_OPT_CHUNKS_PER_TRIP:
         if (value != 1 && value != 2 && value != 4) return fail(QN_ERROR_INPUT_PARAMS, "chunks per trip must be 1, 2 or 4");

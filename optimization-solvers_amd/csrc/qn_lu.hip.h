@@ -175,6 +175,26 @@ template <bool COH> __device__ __forceinline__ void lu_sti(int* p, const int v) 
     if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
+// (best, idx) of every lane -> the first maximum among the WIDTH lanes of its group: the larger value, between equal values the smaller row index
+// (nalgebra's icamax takes the FIRST row of maximal magnitude).  Round 6: the value alone goes through the xor butterfly, then the smallest index
+// among the lanes that hold it -- half the instructions of carrying (value, index) through every level with the full comparison (the same
+// result in every lane: a maximum and a minimum do not depend on the order they are taken in).  `best` is never a NaN (lu_sub_factor).
+template <int WIDTH>
+__device__ __forceinline__ void lu_argmax_lanes(double& best, int& idx) {
+    double wm = best;
+#define QN_LU_LVL(OFF) if constexpr (WIDTH > OFF) { const double o = qn_xor_lanes<OFF>(wm); wm = o > wm ? o : wm; }
+    QN_LU_LVL(32) QN_LU_LVL(16) QN_LU_LVL(8) QN_LU_LVL(4) QN_LU_LVL(2) QN_LU_LVL(1)
+#undef QN_LU_LVL
+    int c = best == wm ? idx : 0x7fffffff;
+#define QN_LU_LVL(OFF) if constexpr (WIDTH > OFF) { const int o = qn_xor_lanes_i<OFF>(c); c = o < c ? o : c; }
+    QN_LU_LVL(32) QN_LU_LVL(16) QN_LU_LVL(8) QN_LU_LVL(4) QN_LU_LVL(2) QN_LU_LVL(1)
+#undef QN_LU_LVL
+    best = wm;
+    idx = c;
+}
+__device__ __forceinline__ double lu_uniform_d(const double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 struct QnLuLds {
     double U[QN_LU_SUB][QN_LU_SUB]; // U[q][j]: row r0 + q of column c0 + j after the solve
     double bv[QN_LU_SUB][16];
@@ -448,21 +468,17 @@ __device__ __forceinline__ bool lu_sub_factor(double* __restrict__ P, const size
         }
         // (xor butterfly on the VALU data path -- DPP / v_permlane*_swap, qn_xor_lanes -- instead of __shfl_xor: that is three
         // ds_bpermute round trips per level, ~2000 cycles of LDS-pipeline latency inside every pivot step of the chain)
-#define QN_LU_ARGMAX_LEVEL(OFF) { const double ov = qn_xor_lanes<OFF>(best); const int oi = qn_xor_lanes_i<OFF>(idx); \
-                                  if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; } }
-        QN_LU_ARGMAX_LEVEL(32) QN_LU_ARGMAX_LEVEL(16) QN_LU_ARGMAX_LEVEL(8) QN_LU_ARGMAX_LEVEL(4) QN_LU_ARGMAX_LEVEL(2) QN_LU_ARGMAX_LEVEL(1)
-#undef QN_LU_ARGMAX_LEVEL
+        lu_argmax_lanes<64>(best, idx);
         if (lane == 0) { L.bv[j][wave] = best; L.bi[j][wave] = idx; }
         if (j == 0) QN_LU_STAMP(3);
         __syncthreads();
         if (j == 0) QN_LU_STAMP(4);
-        best = L.bv[j][0]; idx = L.bi[j][0];
-#pragma unroll
-        for (int w = 1; w < QN_LU_PT / 64; ++w) {
-            const double ov = L.bv[j][w];
-            const int oi = L.bi[j][w];
-            if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
-        }
+        // the waves' candidates: lane w takes wave (w mod 8)'s, three more levels -- ONE trip through LDS (before round 6 a loop over the eight
+        // candidates: the compiler, seeing uniform values, read and compared them one after the other, a dependent LDS round trip each)
+        static_assert(QN_LU_PT / 64 == 8, "eight waves' candidates");
+        best = L.bv[j][lane & 7]; idx = L.bi[j][lane & 7];
+        lu_argmax_lanes<8>(best, idx);
+        best = lu_uniform_d(best); idx = __builtin_amdgcn_readfirstlane(idx);
         if (!(best > 0.0) || idx >= m) { failed = true; idx = k; } // no non-zero entry in this column: singular (newton/mod.rs:43-46)
         const int p = idx;
         pv[j] = p0 + p; // (stored after the four steps: a store here put a wait for the PREVIOUS step's store -- a write-through round trip -- into every step of the chain)

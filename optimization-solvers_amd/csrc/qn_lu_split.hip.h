@@ -159,21 +159,14 @@ __device__ __forceinline__ int lus_sub_factor(double* __restrict__ P, const size
             const double v = fabs(a[j][jr]);
             if (i >= k && i < m && v > best) { best = v; idx = i; } // ascending i per thread: the first maximum (nalgebra's icamax)
         }
-#define QN_LUS_ARGMAX_LEVEL(OFF) { const double ov = qn_xor_lanes<OFF>(best); const int oi = qn_xor_lanes_i<OFF>(idx); \
-                                   if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; } }
-        QN_LUS_ARGMAX_LEVEL(32) QN_LUS_ARGMAX_LEVEL(16) QN_LUS_ARGMAX_LEVEL(8) QN_LUS_ARGMAX_LEVEL(4) QN_LUS_ARGMAX_LEVEL(2) QN_LUS_ARGMAX_LEVEL(1)
-#undef QN_LUS_ARGMAX_LEVEL
+        lu_argmax_lanes<64>(best, idx);
         if (lane == 0) { L.bv[j][wave] = best; L.bi[j][wave] = idx; }
         if (j == 0) QN_LU_STAMP(3);
         __syncthreads();
         if (j == 0) QN_LU_STAMP(4);
-        best = L.bv[j][0]; idx = L.bi[j][0];
-#pragma unroll
-        for (int w = 1; w < QN_LU_PT / 64; ++w) {
-            const double ov = L.bv[j][w];
-            const int oi = L.bi[j][w];
-            if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
-        }
+        best = L.bv[j][lane & 7]; idx = L.bi[j][lane & 7]; // (lane-parallel: lu_sub_factor)
+        lu_argmax_lanes<8>(best, idx);
+        best = lu_uniform_d(best); idx = __builtin_amdgcn_readfirstlane(idx);
         // this part's candidate, its row, and (part 0) row k and the finished block's multipliers: the record
         unsigned long long* const r = rec + ((size_t)k * G + g) * QN_LUS_W;
         {
@@ -229,14 +222,12 @@ __device__ __forceinline__ int lus_sub_factor(double* __restrict__ P, const size
         __syncthreads();
         if (j == 0) QN_LU_STAMP(12);
         if (L.dead[j]) return 2; // (uniform)
-        double gb = lus_d(L.rec[j][0]);
-        int gi = (int)L.rec[j][1], gw = 0;
-#pragma unroll
-        for (int g2 = 1; g2 < G; ++g2) {
-            const double ob = lus_d(L.rec[j][g2 * QN_LUS_W]);
-            const int oi = (int)L.rec[j][g2 * QN_LUS_W + 1];
-            if (ob > gb || (ob == gb && oi < gi)) { gb = ob; gi = oi; gw = g2; }
-        }
+        // the parts' candidates, lane g2 = lane mod G taking part g2's (one trip through LDS); the winner's part follows from its row
+        double gb = lus_d(L.rec[j][(lane & (G - 1)) * QN_LUS_W]);
+        int gi = (int)L.rec[j][(lane & (G - 1)) * QN_LUS_W + 1];
+        lu_argmax_lanes<G>(gb, gi);
+        gb = lu_uniform_d(gb); gi = __builtin_amdgcn_readfirstlane(gi);
+        const int gw = (gi / QN_LU_PT) % G; // (no candidate anywhere: 0x7fffffff -- the singular exit below)
         if (!(gb > 0.0) || gi >= m) { status = 1; gi = k; } // no non-zero entry in this column: singular (newton/mod.rs:43-46)
         const int p = gi;
         pv[j] = p0 + p;

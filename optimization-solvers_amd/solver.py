@@ -55,6 +55,7 @@ OPTIONS = {
     "lu_force_wait_expiry": 15,
     "chunks_per_trip": 16,
     "lu_split_role_a": 17,
+    "lu_split_min_rows": 18,
 }
 OPT_GENERIC_KERNELS = 1
 OPT_DEFERRED_UPDATE_STEP = 2
@@ -73,6 +74,7 @@ OPT_LU_ONE_LAUNCH_PANEL = 14
 OPT_LU_FORCE_WAIT_EXPIRY = 15
 OPT_CHUNKS_PER_TRIP = 16
 OPT_LU_SPLIT_ROLE_A = 17
+OPT_LU_SPLIT_MIN_ROWS = 18
 
 
 class SolverError(Exception):

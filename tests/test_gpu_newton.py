@@ -257,7 +257,8 @@ def test_newton_exactly_singular_large_hessian_takes_the_gradient_direction(qn, 
     assert np.linalg.norm(xs[-1] - ref.trace_x[-1]) <= 1e-9 * max(1.0, np.linalg.norm(ref.trace_x[-1]))
 
 
-def test_one_launch_panel_whose_waits_expire_falls_back_to_step_launches(qn, qo):
+@pytest.mark.parametrize("split_min_rows", [4160, 0])  # (0: every panel's pivot chain shared by four workgroups, csrc/qn_lu_split.hip.h -- its waits expire too)
+def test_one_launch_panel_whose_waits_expire_falls_back_to_step_launches(qn, qo, split_min_rows):
     """qn_lu.hip.h: the one-launch panel / sweep kernels wait for each other on counters with BOUNDED waits; when one expires (their
     workgroups were not placed together) the kernel sets *fail = 2, everybody leaves, and the host runs the factorisation again with one
     launch per sub-panel -- for good.  set_option("lu_force_wait_expiry", 1) makes every wait that is not satisfied at once expire: same iterates, bit
@@ -270,6 +271,7 @@ def test_one_launch_panel_whose_waits_expire_falls_back_to_step_launches(qn, qo)
     runs = []
     for forced in (False, True):
         s = qn.Newton(1e-10, x0)
+        s.set_option("lu_split_min_rows", split_min_rows)
         if forced:
             s.set_option("lu_force_wait_expiry", 1)
         s.set_trace(2, with_x=True)
@@ -350,6 +352,7 @@ def test_panel_lu_equals_the_per_column_lu_bit_for_bit(qn, qo, n):
                                              (False, False, False, 1), (False, False, False, 2), (False, True, False, 2)):
         s = qn.Newton(1e-10, x0)
         s.set_option("lu_split_role_a", parts)
+        s.set_option("lu_split_min_rows", 0)  # (every panel; by default only panels of 4160 rows and more are split)
         if percol:
             s.set_option("lu_per_column_panel", 1)
         if no_la:
