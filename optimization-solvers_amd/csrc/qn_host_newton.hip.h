@@ -175,7 +175,7 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
     size_t bulk_lds = 0;
     if (la) {
         QNCHK(ensure_masked_stream(c));
-        while ((int)c->la_events.size() < 2 * npanels) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->la_events.push_back(e); }
+        while ((int)c->la_events.size() < 3 * npanels) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->la_events.push_back(e); }
         static std::atomic<int> attr_state[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -188,6 +188,8 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
         if (dev < 0 || dev >= 64 || attr_state[dev].load() != 1) bulk_lds = 0;
     }
     int last_f = -1;
+    bool last_strip = false; // the update of panel last_f ran its first tile column as a launch of its own (event 2 npanels + last_f behind it)
+    static const int lu_strip = getenv("QN_LU_STRIP") ? atoi(getenv("QN_LU_STRIP")) : 1;
     static const int la_fused = getenv("QN_LU_LA_FUSED") ? atoi(getenv("QN_LU_LA_FUSED")) : 1;
     bool p_ready = false; // the look-ahead update of the previous panel has already written this panel's buffer
     for (int p0 = 0, pi = 0; p0 < nlu; p0 += QN_NB, ++pi) {
@@ -267,7 +269,7 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
         const size_t pld_c = (size_t)QN_LU_PT * QN_LU_RPT;
         // the next panel's columns on this stream -- once the previous panel's bulk, which wrote them too, is through
         if (la_hi > la_lo) {
-            if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, c->la_events[2 * last_f + 1], 0));
+            if (last_f >= 0) HIPCHK(hipStreamWaitEvent(st, last_strip ? c->la_events[2 * npanels + last_f] : c->la_events[2 * last_f + 1], 0));
             if (fused) { // two launches, the second one leaving the next panel in its buffer (qn_lu.hip.h; the next panel is shorter: it fits)
                 hipLaunchKernelGGL(lu_la_swap_trsm_kernel, dim3((la_hi - la_lo + 3) / 4), dim3(256), 0, st, W, ld, p0, la_lo, la_hi, Pc, pld_c, s->newton_piv, flag);
                 hipLaunchKernelGGL(lu_la_gemm_kernel, dim3(below / QN_NB), dim3(256), 0, st, W, ld, p0, la_lo, Pc, pld_c, Pn, flag);
@@ -296,10 +298,23 @@ static int enqueue_newton_lu(qn_solver* s, const double* hsrc, size_t ld_src) {
             hipLaunchKernelGGL(lu_trsm2_kernel<2>, dim3((rest + 7) / 8), dim3(256), 0, c->stream_lu, W, ld, p0, la_hi, nlu, flag);
             const int ncb = rest / QN_NB, ntiles = ncb * (below / QN_NB);
             static const int persist = getenv("QN_LU_BULK_PERSIST") ? atoi(getenv("QN_LU_BULK_PERSIST")) : 0; // (a resident grid that loops: 54.1 ms against 53.5)
+            // (round 6) THE NEXT LOOK-AHEAD'S COLUMNS FIRST, in a launch of their own with an event behind it: the look-ahead kernels of panel pi + 1
+            // touch the 64 columns right of la_hi and nothing else of what this update writes.  While the bulk sets the period (the first ~28 panels
+            // at n = 8192 once the chain is split, qn_lu_split.hip.h) they no longer wait for the whole update -- the cycle was update, look-ahead
+            // kernels (30 us), this stream's swaps and U12 solve (44 us), update -- and the look-ahead leaves the cycle.
+            last_strip = false;
+            if (lu_strip && ncb >= 2 && !persist) {
+                const int nrt = below / QN_NB;
+                hipLaunchKernelGGL(lu_gemm2_kernel, dim3(nrt), dim3(256), bulk_lds, c->stream_lu, W, ld, p0, la_hi, 1, nrt, flag, 0);
+                HIPCHK(hipEventRecord(c->la_events[2 * npanels + pi], c->stream_lu));
+                hipLaunchKernelGGL(lu_gemm2_kernel, dim3((ncb - 1) * nrt), dim3(256), bulk_lds, c->stream_lu, W, ld, p0, la_hi + QN_NB, ncb - 1, (ncb - 1) * nrt, flag, 0);
+                last_strip = true;
+                launches++;
+            } else
             hipLaunchKernelGGL(lu_gemm2_kernel, dim3(persist ? std::min(ntiles, 2 * c->lu_bulk_cus) : ntiles), dim3(256), bulk_lds, c->stream_lu, W, ld, p0, la_hi, ncb,
                                ntiles, flag, 0);
             launches += 3;
-        }
+        } else last_strip = false;
         HIPCHK(hipEventRecord(c->la_events[2 * pi + 1], c->stream_lu));
         last_f = pi;
         launches++;
