@@ -87,12 +87,18 @@ def collectives_share(xprobe, scalars_per_it, vectors_per_it, ms_per_step):
     estimate -- probed latencies x counts, slowest rank -- printed beside the measured ms_per_step; it answers DESIGN section 5's open question
     (is a small RCCL collective ~20 us?) the first time the line is printed on a multi-GPU node."""
     out = {"exchange_probe": xprobe, "collectives_per_iteration": {"scalars_8KB": scalars_per_it, "n_vectors": vectors_per_it}}
+    if isinstance(xprobe, dict) and xprobe.get("trial_vector_exchange", {}).get("used"):
+        # (the trial's partial vector rode on every "scalar" collective: those moved 8 KB + n doubles per rank, the n-vector ones are the update pass's 2 n)
+        out["collectives_per_iteration"] = {"scalars_8KB_plus_n_vector": scalars_per_it, "two_n_vectors": vectors_per_it}
     try:
         ranks = [r for r in xprobe["per_rank"] if isinstance(r, dict) and "error" not in r]
         if not ranks:
             raise ValueError("no rank probed")
         worst = {k: max(r[k]["median_us"] for r in ranks) for k in ("scalars_8KB", "n_vector", "two_n_vectors")}
-        est_us = scalars_per_it * worst["scalars_8KB"] + 0.5 * vectors_per_it * (worst["n_vector"] + worst["two_n_vectors"])
+        if "two_n_vectors" in out["collectives_per_iteration"]:
+            est_us = scalars_per_it * max(worst["scalars_8KB"], worst["n_vector"]) + vectors_per_it * worst["two_n_vectors"]
+        else:
+            est_us = scalars_per_it * worst["scalars_8KB"] + 0.5 * vectors_per_it * (worst["n_vector"] + worst["two_n_vectors"])
         out.update({"slowest_rank_median_us": worst, "estimated_collective_us_per_iteration": est_us,
                     "estimated_fraction_of_ms_per_step": est_us / (1e3 * ms_per_step) if ms_per_step else None,
                     "design_budget_us_per_small_collective": 20.0})
@@ -579,6 +585,23 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, xprobe)  # (every rank's own clock: a slow link shows on the ranks at its ends)
         xprobe = {"ranks": world, "exchange": "host-staged" if host_exchange else "rccl", "per_rank": per_rank}
+        # DESIGN 9.1's fallback (round 6: qn_context_set_trial_vector_exchange): every evaluation's collective also carries the trial point's
+        # partial n-vector, the accepted point needs no exchange of its own -- it pays when the latency of a collective, not its bytes, is what
+        # costs: E (8 KB + n) against E (8 KB) + n per iteration, E ~ 2 -> when an n-vector exchange costs less than two 8 KB ones.  The rule is
+        # PRINTED with the probed numbers (every rank sees the same gathered list, so every rank would decide alike); it is APPLIED only on
+        # request (QN_BENCH_TRIAL_VECTOR=1, or =auto to follow the rule): the default line measures the default exchange.
+        tv = {"used": False, "recommended": None, "rule": "slowest rank's median: n_vector < 2 x scalars_8KB"}
+        try:
+            ok = [r for r in per_rank if isinstance(r, dict) and "error" not in r]
+            if ok and len(ok) == world:
+                tv["recommended"] = bool(max(r["n_vector"]["median_us"] for r in ok) < 2.0 * max(r["scalars_8KB"]["median_us"] for r in ok))
+            want = os.environ.get("QN_BENCH_TRIAL_VECTOR", "0")
+            if want == "1" or (want == "auto" and tv["recommended"]):
+                ctx.set_trial_vector_exchange(True)
+                tv["used"] = True
+        except Exception as e:  # noqa: BLE001
+            tv["error"] = repr(e)
+        xprobe["trial_vector_exchange"] = tv
 
     diag, b, x0 = synth_inputs(n)
     obj = qn.Quadratic.synthetic(n, SEED, diag, b, ctx=ctx)  # Q is generated shard-locally on the device

@@ -70,6 +70,12 @@ int qn_context_set_allreduce(qn_context* ctx, int on);
  * host node of the stream, pinned-to-device copy) with no synchronisation, so the pipelined launch logic -- which RCCL runs use
  * -- can be rehearsed with several ranks on one GPU.  The callback then runs on a runtime thread, not on the caller's. */
 int qn_context_set_host_exchange_async(qn_context* ctx, int on);
+/* Row-sharded second-generation runs on a quadratic objective (ABI 5, round 6; DESIGN.md 9.1's fallback): on != 0 lets every evaluation's
+ * collective carry the rank's partial n-vector of the TRIAL point beside its 8 KB of scalars (one grouped all-gather), so that an accepted
+ * evaluation needs no exchange of its own: E + 1 collectives per iteration instead of E + 2, n doubles per rank more per trial.  For nodes
+ * where a small collective between two launches costs much more than its bytes (bench.py --gpus N prints the probed latencies).  The same
+ * iterates, bit for bit.  Not together with qn_context_set_allreduce (QN_ERROR_INPUT_PARAMS). */
+int qn_context_set_trial_vector_exchange(qn_context* ctx, int on);
 void qn_context_destroy(qn_context* ctx);
 /* the row partition used for H and the objective's matrix: rows per rank (a multiple of 16) and padded dimension */
 int qn_partition(size_t n, int world, size_t* rows_per_rank, size_t* n_pad);

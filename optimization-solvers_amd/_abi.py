@@ -81,6 +81,7 @@ SYMBOLS = [
     ("qn_context_world", C.c_int, [C.c_void_p]),
     ("qn_context_stream", C.c_void_p, [C.c_void_p]),
     ("qn_context_set_host_exchange_async", C.c_int, [C.c_void_p, C.c_int]),
+    ("qn_context_set_trial_vector_exchange", C.c_int, [C.c_void_p, C.c_int]),
     ("qn_context_set_allreduce", C.c_int, [C.c_void_p, C.c_int]),
     ("qn_morethuente_default", None, [C.POINTER(LineSearchStruct)]),
     ("qn_morethuente_with_deltas", C.c_int, [C.POINTER(LineSearchStruct), C.c_double, C.c_double, C.c_double]),

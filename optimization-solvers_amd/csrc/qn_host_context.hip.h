@@ -76,6 +76,7 @@ struct qn_context {
     // hipLaunchHostFunc node between the two copies, nothing synchronises -- the pipelined launch logic can then be rehearsed
     // with several ranks on one GPU
     int use_allreduce = 0; // symmetric-storage sharded runs: ncclAllReduce of the partial n-vectors instead of all-gather + rank-order sum
+    int trial_vector = 0;  // ... the trial's partial n-vector in ONE grouped collective with its evaluation scalars (qn_context_set_trial_vector_exchange)
     int host_async = 0;
     double* pin = nullptr; // [send (cap) | recv (cap * world)]
     size_t pin_cap = 0;
@@ -174,7 +175,18 @@ extern "C" int qn_context_synchronize(qn_context* c) {
 extern "C" int qn_context_set_allreduce(qn_context* c, int on) {
     if (!c) return fail(QN_ERROR_INPUT_PARAMS, "context is null");
     if (on && c->comm && !g_rccl.AllReduce) return fail(QN_ERROR_INPUT_PARAMS, "librccl has no ncclAllReduce");
+    if (on && c->trial_vector) return fail(QN_ERROR_INPUT_PARAMS, "the trial-vector exchange is an all-gather: switch it off first");
     c->use_allreduce = on ? 1 : 0;
+    return QN_OK;
+}
+// Row-sharded second-generation runs (quadratic objective): every evaluation's collective also carries the rank's partial n-vector of the
+// trial point, so an accepted evaluation needs no exchange of its own -- E + 1 collectives per iteration instead of E + 2, n doubles per rank
+// more per trial (for nodes where a small collective between two launches costs much more than its bytes).  All-gather only: an
+// in-place all-reduce overwrites rank 0's slice, which an unused evaluation slot of the pipelined pattern would then send again.
+extern "C" int qn_context_set_trial_vector_exchange(qn_context* c, int on) {
+    if (!c) return fail(QN_ERROR_INPUT_PARAMS, "context is null");
+    if (on && c->use_allreduce) return fail(QN_ERROR_INPUT_PARAMS, "the trial-vector exchange is an all-gather: not with qn_context_set_allreduce");
+    c->trial_vector = on ? 1 : 0;
     return QN_OK;
 }
 extern "C" int qn_context_set_host_exchange_async(qn_context* c, int on) {

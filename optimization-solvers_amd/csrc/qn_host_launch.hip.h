@@ -114,7 +114,7 @@ static int s2_launch(Run& r, int kind) {
     a.swz = (getenv("QN_S2_SWZ") && a.pair) ? atoi(getenv("QN_S2_SWZ")) : 0; // (only where both items follow from the workgroup index: n = 4096)
 #endif
     r.s2_launches++;
-    const int cls = kind == QN_S2_EVAL ? KC_EVAL : (kind == QN_S2_VEC || kind == QN_S2_VSUM || kind == QN_S2_GCOMB || kind == QN_S2_DIR || kind == QN_S2_PROJ) ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS
+    const int cls = kind == QN_S2_EVAL ? KC_EVAL : (kind == QN_S2_VEC || kind == QN_S2_VECD || kind == QN_S2_VSUM || kind == QN_S2_GCOMB || kind == QN_S2_DIR || kind == QN_S2_PROJ) ? KC_EREDUCE : kind == QN_S2_HTILE ? KC_HPASS
                   : (kind == QN_S2_HREDUCE || kind == QN_S2_HSUM) ? KC_HREDUCE : KC_CTL;
     ProfScope ps(s, cls);
     const bool sh = a.sh_world > 1; // row-sharded: the SHARD instantiations (qn_sym2sh.hip.h)
@@ -145,6 +145,7 @@ static int s2_launch(Run& r, int kind) {
         else if (sh) hipLaunchKernelGGL(s2_vec_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
         else hipLaunchKernelGGL(s2_vec_kernel<false>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
         break;
+    case QN_S2_VECD: hipLaunchKernelGGL((s2_vec_kernel<true, true>), dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break; // (row-sharded, trial-vector exchange)
     case QN_S2_HTILE:
         if (s->method == QN_SR1) { // (one rank, no fold, no tail reduce: minimize_impl)
             if (a.nt) hipLaunchKernelGGL((s2_hpass_kernel<true, false, false, false, false, true>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a);
@@ -246,9 +247,24 @@ static int s2_do_eval(Run& r, unsigned long long report_seq = 0) {
     qn_solver* s = r.s;
     qn_context* c = s->ctx;
     if (r.s2.sh_world > 1) {
-        ProfScope ps(s, KC_COMM);
         const size_t cnt = (size_t)QN_S2SH_NEC * QN_S2_MAXG;
         double* half = s->s2_evS + (size_t)((r.s2_launches - 1) & 1) * (size_t)c->world * cnt; // the half the launch above wrote
+        if (c->trial_vector) { // the trial's partial n-vector rides on the scalar exchange (qn_sym2sh.hip.h: s2sh_vsumt_kernel; not a link of the control block's chain)
+            {
+                ProfScope ps(s, KC_EREDUCE);
+                QnS2Args a = r.s2;
+                a.parity = (int)(r.s2_launches & 1); // the block the evaluation launch has just handed on
+                hipLaunchKernelGGL(s2sh_vsumt_kernel, dim3(a.nb), dim3(QN_S2_TPB), 0, c->stream, a);
+                HIPCHK(hipGetLastError());
+                s->stats.launches++;
+            }
+            ProfScope ps(s, KC_COMM);
+            const XchgItem items[2] = {{half, cnt}, {s->symsh_xg, (size_t)s->T.n_pad}};
+            c->n_xchg_scalar++;
+            QNCHK(exchange_group(c, items, 2));
+            return QN_OK;
+        }
+        ProfScope ps(s, KC_COMM);
         c->n_xchg_scalar++;
         if (c->use_allreduce) QNCHK(exchange_sum(c, half, cnt));
         else QNCHK(exchange(c, half, cnt));
@@ -259,6 +275,7 @@ static int s2_do_eval(Run& r, unsigned long long report_seq = 0) {
 static int s2_do_vec(Run& r) {
     qn_solver* s = r.s;
     qn_context* c = s->ctx;
+    if (r.s2.sh_world > 1 && c->trial_vector && !r.gobj) return s2_launch(r, QN_S2_VECD); // (the vectors came with the evaluation's scalars)
     if (r.s2.sh_world > 1) {
         QNCHK(s2_launch(r, QN_S2_VSUM));
         {

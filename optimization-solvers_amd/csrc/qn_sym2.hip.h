@@ -61,7 +61,9 @@ enum { QN_S2_ADVANCE = 0, QN_S2_EVAL = 1, QN_S2_VEC = 2, QN_S2_HTILE = 3, QN_S2_
        QN_S2_GEVAL_A = 7, QN_S2_GCOMB = 8, QN_S2_GHT_A = 9, // (generic objectives, qn_sym2g.hip.h: the machine in a one-workgroup launch in
                                                              // front of many-workgroup kernels that only READ the control block)
        QN_S2_DIR = 10,   // (bounded variants: s2_dir_kernel)
-       QN_S2_PROJ = 11 }; // (BackTrackingB on this path, round 6: s2_proj_kernel -- the projected trial point, stored, and ||P(x + t d) - x||^2)
+       QN_S2_PROJ = 11, // (BackTrackingB on this path, round 6: s2_proj_kernel -- the projected trial point, stored, and ||P(x + t d) - x||^2)
+       QN_S2_VECD = 12 }; // (row-sharded, the trial's partial vector riding on the scalar exchange -- qn_context_set_trial_vector_exchange, qn_sym2sh.hip.h:
+                          //  the accept-reduce launch itself is where the machine sees the accepted evaluation: no partial-sum launch, no exchange in front of it)
 
 struct QnS2Args {
     const double* Q;
@@ -508,7 +510,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     if (lane == 0) {
         if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == ((BND && c.req_project) ? 5 : 0); // (a projected trial: behind its s2_proj_kernel)
         if (KIND == QN_S2_PROJ) mine = c.phase == QN_PH_REQ_EVAL && c.req_project && c.serviced == 0;
-        if (KIND == QN_S2_VEC || KIND == QN_S2_VSUM) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
+        if (KIND == QN_S2_VEC || KIND == QN_S2_VSUM || KIND == QN_S2_VECD) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
         if (KIND == QN_S2_HTILE) { // 2: the accepted point's slots -> vectors AND the update tiles (folded accept-reduce); 1: the tiles of a pending pass
             if (a.fold && c.phase == QN_PH_REQ_VEC && c.serviced == 0) mine = 2;
             else if (c.phase == QN_PH_REQ_HPASS && c.serviced == 0) mine = 1;
@@ -1128,7 +1130,9 @@ __device__ __forceinline__ double qn_s2_slot_sum(const double* __restrict__ part
 // (bfgs.rs:94-99), and the five sums the update needs
 // SHARD (row-sharded runs): q_i is the sum over the ranks, in rank order, of the partial vectors the exchange has gathered in xg
 // (each rank's share summed by s2sh_vsum_kernel, qn_sym2sh.hip.h); every rank forms every block-row: replicated work, the same bits.
-template <bool SHARD = false>
+// DECIDE (SHARD only): the partial vectors of the LAST evaluation are already gathered (they rode on its scalar exchange): this launch's
+// prologue is the deciding one -- it consumes the evaluation, accepts, and the launch serves the request it has just made.
+template <bool SHARD = false, bool DECIDE = false>
 __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
     __shared__ double qbuf[3][QN_TB];
@@ -1155,7 +1159,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) cw[k] = qn_code_warm_issue(k * 64 + lane);
     }
-    if (SHARD) { if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC, true>(a, L, entries); else entries(); }
+    if (SHARD) { if (wave == 0) qn_s2_prologue_w0<(DECIDE ? QN_S2_VECD : QN_S2_VEC), true>(a, L, entries); else entries(); }
     else if (wave == 0) qn_s2_prologue_w0<QN_S2_VEC>(a, L, [&]() { qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0); entries(); });
     else { qn_s2_slot_issue<1>(a.partE, a.nb, R, 0, S0); entries(); }
     __syncthreads();

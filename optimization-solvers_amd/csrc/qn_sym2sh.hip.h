@@ -85,6 +85,28 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2sh_vsum_kernel(const QnS2Args a) 
     if (tid < QN_TB) a.xg[(size_t)a.sh_rank * (size_t)a.np + (size_t)R * QN_TB + tid] = qn_s2sh_wave_total<1>(red, 0, tid);
 }
 
+// THE TRIAL'S PARTIAL VECTOR WITH ITS SCALARS (round 6; qn_context_set_trial_vector_exchange, DESIGN 9.1's fallback): behind EVERY evaluation
+// launch that evaluated, block-row R of this rank's share of q = Q (x + t d) goes into its slice of xg at once, and ONE grouped collective
+// carries the 8 KB of scalars and the n-vector; the acceptance then needs neither s2sh_vsum_kernel nor an exchange of its own
+// (s2_vec_kernel<true, true>): one collective per accepted iteration fewer, n doubles per rank more per REJECTED trial.
+// Not a link of the control block's chain: no prologue, no machine -- it reads the block the evaluation launch has just handed on
+// (a.parity: the NEXT launch's) and acts when that launch evaluated (REQ_EVAL, serviced 2: nobody has consumed it yet); an evaluation
+// slot the machine did not use leaves this rank's slice as it is, and the collective behind it re-sends the same values.
+__global__ __launch_bounds__(QN_S2_TPB) void s2sh_vsumt_kernel(const QnS2Args a) {
+    __shared__ double red[QN_S2_WAVES - 1][1][QN_TB];
+    __shared__ int live;
+    const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) {
+        if (lane == 0) { const QnCtl* c = a.ctl2 + a.parity; live = c->phase == QN_PH_REQ_EVAL && c->serviced == 2; }
+    } else {
+        const int lo = a.sl_off[R];
+        qn_s2sh_wave_sums<1>(a.partE, a.nb, R, a.sl_idx + lo, a.sl_off[R + 1] - lo, wave, lane, red);
+    }
+    __syncthreads();
+    if (!live) return;
+    if (tid < QN_TB) a.xg[(size_t)a.sh_rank * (size_t)a.np + (size_t)R * QN_TB + tid] = qn_s2sh_wave_total<1>(red, 0, tid);
+}
+
 // update pass, block-row R: this rank's share of [u, v] = H+ [y, g+] (direction pass: [H g, -]) into its slice of xg ([rank][2][np])
 __global__ __launch_bounds__(QN_S2_TPB) void s2sh_hsum_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;

@@ -206,6 +206,12 @@ class Context:
         """Sharded symmetric storage: all-reduce the partial n-vectors (RCCL's order) instead of all-gather + rank-order sum."""
         _check(A.lib().qn_context_set_allreduce(self.h, 1 if on else 0))
 
+    def set_trial_vector_exchange(self, on=True):
+        """Row-sharded second-generation runs, quadratic objective: every evaluation's collective also carries the rank's partial n-vector of
+        the trial point (one grouped all-gather), an accepted evaluation then needs no exchange of its own -- E + 1 collectives per
+        iteration instead of E + 2; the same iterates.  Not together with set_allreduce."""
+        _check(A.lib().qn_context_set_trial_vector_exchange(self.h, 1 if on else 0))
+
     def set_host_exchange_async(self, on=True):
         """Host-exchange contexts: run the exchange in stream order (no synchronisation), so sharded runs can be pipelined."""
         _check(A.lib().qn_context_set_host_exchange_async(self.h, 1 if on else 0))

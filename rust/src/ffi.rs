@@ -165,6 +165,7 @@ extern "C" {
     pub fn qn_context_create_sharded_host_exchange(device: c_int, rank: c_int, world: c_int, fn_: qn_host_allgather_fn, user: *mut c_void, out: *mut *mut qn_context) -> c_int;
     pub fn qn_context_set_allreduce(ctx: *mut qn_context, on: c_int) -> c_int;
     pub fn qn_context_set_host_exchange_async(ctx: *mut qn_context, on: c_int) -> c_int;
+    pub fn qn_context_set_trial_vector_exchange(ctx: *mut qn_context, on: c_int) -> c_int;
     pub fn qn_context_destroy(ctx: *mut qn_context);
     pub fn qn_partition(n: usize, world: c_int, rows_per_rank: *mut usize, n_pad: *mut usize) -> c_int;
     pub fn qn_comm_selftest(ctx: *mut qn_context) -> c_int;

@@ -314,6 +314,29 @@ def main():
             xa, xb = s_ar.trace()[1], s_sync.trace()[1]
             case["allreduce_ok"] = bool(np.array_equal(xa, xb)) if not rccl else bool(np.linalg.norm(xa - xb) <= 1e-9 * np.linalg.norm(xb))
             case["allreduce_x_hex"] = [float(v).hex() for v in xa[-1][:64]]
+            # the trial's partial n-vector riding on the scalar exchange (qn_context_set_trial_vector_exchange, DESIGN 9.1's fallback): the same
+            # bits as the default exchange, one collective per accepted iteration fewer -- in this context's mode (host exchange: the
+            # synchronous pump; RCCL: pipelined) and, host exchange, in stream order (pipelined: unused evaluation slots re-send the same vector)
+            tv = []
+            for asyn in ((False,) if rccl else (False, True)):
+                if asyn:
+                    ctx.set_host_exchange_async(True)
+                ctx.set_trial_vector_exchange(True)
+                s_tv = qn.BFGS(1e-10, x0, ctx=ctx)
+                s_tv.set_trace(iters, with_x=True)
+                try:
+                    s_tv.minimize(qn.MoreThuente(), obj, iters, 20)
+                except qn.MaxIterReached:
+                    pass
+                ctx.set_trial_vector_exchange(False)
+                if asyn:
+                    ctx.set_host_exchange_async(False)
+                st_tv = s_tv.stats()
+                tv.append({"equal": bool(s_tv.trace()[0] == s_sync.trace()[0] and np.array_equal(s_tv.trace()[1], s_sync.trace()[1])),
+                           "path": st_tv["path"], "iters": st_tv["iterations"], "evals": st_tv["oracle_evals"],
+                           "xchg": [st_tv["total_xchg_vector"], st_tv["total_xchg_scalar"]], "syncs": st_tv["host_syncs"]})
+            case["trial_vector"] = tv
+            case["default_xchg"] = [s_sync.stats()["total_xchg_vector"], s_sync.stats()["total_xchg_scalar"], s_sync.stats()["iterations"]]
             if rccl:  # RCCL runs are pipelined by default: the synchronous pump is the other mode to compare with
                 s_sync2 = qn.BFGS(1e-10, x0, ctx=ctx)
                 s_sync2.set_sync_mode(1)

@@ -34,7 +34,7 @@ def _run(qn, solver, ls, obj, iters):
     return solver.trace()
 
 
-def _sharded_quadratic(qn, n, world, iters, allreduce, want_h, first_generation=False):
+def _sharded_quadratic(qn, n, world, iters, allreduce, want_h, first_generation=False, trial_vector=False):
     diag = P.synth_diag(n)
     b, x0 = P.synth_vectors(n)
 
@@ -43,6 +43,8 @@ def _sharded_quadratic(qn, n, world, iters, allreduce, want_h, first_generation=
         ctx.comm_check()
         if allreduce:
             ctx.set_allreduce(True)
+        if trial_vector:
+            ctx.set_trial_vector_exchange(True)
         obj = qn.Quadratic.synthetic(n, P.SEED, diag, b, ctx=ctx)
         s = qn.BFGS(1e-10, x0, ctx=ctx)
         if first_generation:
@@ -121,6 +123,40 @@ def test_config3_partition_8_ranks_n4096_vs_single_rank_and_oracle(qn, qo, allre
     ref.minimize(qo.morethuente(), qo.QuadraticOracle(q, b, nthreads=qo.max_threads()), k, 20, trace_cap=k, trace_x=True)
     assert len(ref.trace) == k and ref.trace[-1]["gnorm"] >= 1e-6 * ref.trace[0]["gnorm"]
     _trace_close(res[0]["tr"][:k], res[0]["xs"][:k], ref.trace, ref.trace_x)
+
+
+@pytest.mark.parametrize("world,n", [(8, 4096), (3, 3072)])
+def test_trial_vector_rides_on_the_scalar_exchange_same_bits_one_collective_fewer(qn, world, n):
+    """DESIGN 9.1's fallback, qn_context_set_trial_vector_exchange: behind every evaluation launch the rank's partial
+    n-vector of the TRIAL point is summed at once (s2sh_vsumt_kernel) and ONE grouped collective carries it with the 8 KB of scalars; the
+    accept-reduce launch (s2_vec_kernel<true, true>) is then the deciding one and needs neither s2sh_vsum_kernel nor an exchange in front
+    of it.  Same iterates and trace as the default exchange, bit for bit, on every rank; per iteration E + 1 collectives instead of E + 2."""
+    iters = 12
+    res_d, _ = _sharded_quadratic(qn, n, world, iters, False, want_h=True)
+    res_t, _ = _sharded_quadratic(qn, n, world, iters, False, want_h=True, trial_vector=True)
+    for rd, rt in zip(res_d, res_t):
+        assert rt["path"] == rd["path"] and rt["path"] & 16
+        assert np.array_equal(rt["xs"], rd["xs"]) and rt["tr"] == rd["tr"] and np.array_equal(rt["h"], rd["h"])
+        assert rt["iters"] == rd["iters"] and rt["evals"] == rd["evals"]
+        it, ev = rt["iters"], rt["evals"]
+        assert rd["xchg"] == (2 * it + 2, ev)   # default: the accepted point's vector and the update pass's [u, v] (+ the two that open the run)
+        assert rt["xchg"] == (it + 1, ev)       # the accepted point's vector came with its evaluation's scalars
+        # launches (synchronous pump of this harness): one partial-sum launch per evaluation more, the accepted point's partial-sum launch gone
+        assert rt["launches"] == rd["launches"] + ev - (it + 1), (rt["launches"], rd["launches"], it, ev)
+    for r in res_t[1:]:
+        assert np.array_equal(r["xs"], res_t[0]["xs"]) and r["tr"] == res_t[0]["tr"]
+
+
+def test_trial_vector_exchange_is_an_all_gather(qn):
+    ctx = qn.Context(0)
+    ctx.set_allreduce(True)
+    with pytest.raises(qn.SolverError):
+        ctx.set_trial_vector_exchange(True)
+    ctx.set_allreduce(False)
+    ctx.set_trial_vector_exchange(True)
+    with pytest.raises(qn.SolverError):
+        ctx.set_allreduce(True)
+    ctx.close()
 
 
 def test_config3_partition_8_ranks_n32768(qn, qo):

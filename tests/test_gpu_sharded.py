@@ -22,8 +22,15 @@ def test_two_ranks_on_one_gpu_equal_single_rank_bitwise(tmp_path):
 
 
 def _device_count():
-    import torch
-    return torch.cuda.device_count()
+    # (in a child process: importing torch HERE, after libqn_hip.so has initialised HIP and loaded RCCL in this process, ends in a double free
+    # at interpreter exit when this file is run by itself -- two runtimes' teardown orders; with `-m gpu` conftest.py imports torch first)
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+    try:
+        return int(out.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
 
 
 def _check_sharded_symmetric(res, nproc):
@@ -70,6 +77,18 @@ def _check_sharded_symmetric(res, nproc):
             assert not case["pipelined_path"][0] & 8 and case["pipelined_path"][1] & 8 and case["pipelined_path"][1] & 2
             assert not case["rows_pipelined_path"][0] & 8 and case["rows_pipelined_path"][1] & 8
             assert case["pipelined_syncs"][1] * 4 < case["pipelined_syncs"][0]  # (the control-block reads; the exchanges' own waits are not even counted)
+            if "trial_vector" in case:  # (round 6) the trial's partial vector on the scalar exchange: the default exchange's bits, pump and pipelined
+                for tv in case["trial_vector"]:
+                    assert tv["equal"], case
+                tv0 = case["trial_vector"][0]
+                if case["n"] % 128 == 0 and tv0["path"] & 16 and not tv0["path"] & 8:  # second-generation structure, synchronous pump: exact counts
+                    dv, ds, dit = case["default_xchg"]
+                    assert dv == 2 * dit + 2 and tv0["xchg"] == [tv0["iters"] + 1, tv0["evals"]], case
+                if len(case["trial_vector"]) > 1:  # stream-ordered host exchange: pipelined
+                    tv1 = case["trial_vector"][1]
+                    assert tv1["path"] & 8 and tv1["syncs"] * 4 < tv0["syncs"], case
+                    if case["n"] % 128 == 0 and tv1["path"] & 16:
+                        assert tv1["xchg"][0] < case["default_xchg"][0] or tv1["iters"] == 0, case
             if "bt_pipelined_equal" in case:  # backtracking with a varying number of evaluations per iteration: sized pattern, roll-over
                 assert case["bt_pipelined_equal"] and case["bt_evals"][0] == case["bt_evals"][1], case
                 assert not case["bt_paths"][0] & 8 and case["bt_paths"][1] & 8
