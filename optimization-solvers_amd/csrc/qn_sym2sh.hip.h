@@ -19,6 +19,8 @@
 // One iteration with More-Thuente on the quadratic (two evaluations):
 //     eval | x | eval | x | vsum | X | vec | update tiles | hsum | XX | hreduce         (x: 8 KB of scalars, X: n doubles, XX: 2 n)
 // = 7 launches and 2 n-vector + E scalar collectives (first generation: 12.2 launches, E + 1 n-vector collectives).
+// (Round 6, qn_context_set_trial_vector_exchange: eval | vsumt | xX | eval | vsumt | xX | vec | update tiles | hsum | XX | hreduce -- the trial's partial
+// vector with its scalars in one grouped collective, E + 1 collectives per iteration: s2sh_vsumt_kernel below.)
 // Every sum has a fixed order (slots in list order, ranks in rank order): the ranks hold the same bits, and the host-staged
 // exchange of the tests gives the bits of the RCCL all-gather.
 #pragma once
