@@ -317,7 +317,8 @@ typedef enum {
     QN_OPT_LU_FORCE_WAIT_EXPIRY = 15,      /* [0] ... every bounded wait of the one-launch kernels expires at once (exercises the fallback) */
     QN_OPT_CHUNKS_PER_TRIP = 16,           /* [1] fused ROW kernels: column chunks per loop trip (1, 2 or 4) */
     QN_OPT_LU_SPLIT_ROLE_A = 17,           /* [4] ... the one-launch panel's pivot chain shared by 1 (0 too), 2 or 4 workgroups of one XCD (csrc/qn_lu_split.hip.h) -- the same bits */
-    QN_OPT_LU_SPLIT_MIN_ROWS = 18          /* [4160] ... for panels of at least `value` rows (a NUMBER, not a switch; shorter panels: one workgroup) */
+    QN_OPT_LU_SPLIT_MIN_ROWS = 18,         /* [4160] ... for panels of at least `value` rows (a NUMBER, not a switch; shorter panels: one workgroup) */
+    QN_OPT_BTB_PROJECT_IN_EVAL = 19        /* [1] BackTrackingB on the second-generation path: the trial point projected inside the evaluation kernel (n = 4096's mover + multiplier kernel); 0: a projection launch per trial -- the same bits */
 } qn_option;
 int qn_solver_set_option(qn_solver* s, int option, int value);
 

@@ -17,6 +17,7 @@ struct Run {
     bool gobj = false;        // ... in its form for a device objective that is not the quadratic (qn_sym2g.hip.h: the log-sum-exp objective)
     bool dirq = false;        // ... whose pattern has the stored-direction launch (QnCtl.s2_dir != 0)
     bool proj = false;        // ... whose line search is BackTrackingB: every evaluation slot has s2_proj_kernel in front of it (projected trial points)
+    bool btb = false;         // ... BackTrackingB on this path at all (proj: with the projection as a launch of its own; QnS2Args.projfold: inside the evaluation kernel)
     bool bnd = false;         // ... a bounded run on it (BFGSB / DFPB, MoreThuenteB): one more launch per iteration, s2_dir_kernel (qn_sym2.hip.h)
     bool tiles1 = false;      // the update pass's tiles through the first-generation tile kernel (one workgroup per tile, two per CU) behind a
                               // one-workgroup launch that runs the machine: H's share past the Infinity Cache (see minimize_impl)

@@ -142,7 +142,8 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
     if (s->method == QN_SR1 && r.fused && !r.sym2) return fail(QN_ABNORMAL_TERMINATION, "SR1 on a fused path that is not the second-generation one");
     h->s2_dir = r.bnd ? ((s->bounded ? 1 : 0) | (ls->kind == QN_LS_MORETHUENTE_B ? 2 : 0)) : 0;
     r.dirq = h->s2_dir != 0; // (the stored-direction launch is part of the pattern only where a direction asks for it)
-    r.proj = r.bnd && ls->kind == QN_LS_BACKTRACKING_B;
+    r.btb = r.bnd && ls->kind == QN_LS_BACKTRACKING_B;
+    r.proj = r.btb; // (unless the evaluation kernel projects itself: QnS2Args.projfold, below)
     if (r.bnd && ls->kind == QN_LS_MORETHUENTE_B) h->ls_kind = QN_LS_MORETHUENTE; // (the clip of t_max is applied where the direction's request is consumed: from there on it IS More-Thuente)
     // WHICH KERNEL STREAMS THE UPDATE PASS OF A ROW-SHARDED RUN (round 5).  The one-workgroup-per-CU kernel of
     // qn_sym2.hip.h (16-row register windows, the machine in its prologue) was built for n = 4096, where a launch is a twelfth of the
@@ -221,6 +222,10 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
           // (profiles/r06_a_*).  QN_S2_RING=0 / QN_OPT_EVAL_MOVER_MULTIPLIER 0: round 5's kernel.  It needs every workgroup's FIRST item off the diagonal.
             a.ring = (a.pair && s->ring && s->s2_nb * (s->s2_nb - 1) / 2 >= s->s2_G) ? 1 : 0;
         }
+        // BackTrackingB's projection INSIDE the evaluation kernel (round 6, s2_evalr_kernel<true>): no s2_proj_kernel launch per trial -- the trial point is clamped
+        // where it is formed, the shares of ||P(x + t d) - x||^2 leave the launch as column 6 of its table.  The same bits as the launch-per-trial flow.
+        a.projfold = (r.btb && a.pair && a.ring && !s->no_projfold) ? 1 : 0;
+        if (a.projfold) r.proj = false;
         if (r.bnd) a.fold = 0;
         a.method = s->method;
         if (s->method == QN_SR1) a.fold = 0;
@@ -325,7 +330,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
                     // benchmark's kernels, unchanged -- and must not be the ones that consume a projected trial: its Armijo rule and its memo are the
                     // bounded machine's.  Every evaluation slot but the last is followed by the next slot's s2_proj_kernel, whose prologue is the bounded
                     // one; behind the last a one-workgroup machine launch consumes.)
-                    if (r.proj) QNCHK(s2_launch(r, QN_S2_ADVANCE));
+                    if (r.btb) QNCHK(s2_launch(r, QN_S2_ADVANCE));
                     if (!r.s2.fold && !(r.gobj && r.s2.sh_world == 1)) QNCHK(s2_do_vec(r)); // (folded into the update tiles otherwise; generic objective: staged by every evaluation's combine launch)
                     QNCHK(s2_do_hpass(r, true));
                     return QN_OK;

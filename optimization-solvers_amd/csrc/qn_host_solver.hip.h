@@ -79,6 +79,7 @@ struct qn_solver {
     int newton_lu_no_persist = 0; // diagnostics (QN_OPT_LU_ONE_LAUNCH_PANEL 0), or set after a bounded wait of the one-launch panel gave up: one launch per sub-panel
     int* newton_sync = nullptr;   // the one-launch panel's counters (qn_lu.hip.h, lu_panel_persist_kernel)
     unsigned long long* newton_rec = nullptr; // ... and, with role A split over workgroups, the parts' records (qn_lu_split.hip.h)
+    bool no_projfold = getenv("QN_S2_PROJ_FOLD") && atoi(getenv("QN_S2_PROJ_FOLD")) == 0; // QN_OPT_BTB_PROJECT_IN_EVAL 0: BackTrackingB's projection as a launch per trial
     int newton_lu_split = getenv("QN_LU_SPLIT") ? atoi(getenv("QN_LU_SPLIT")) : 4; // parts of role A: 1 (one workgroup, rounds 4-5), 2 or 4 (QN_OPT_LU_SPLIT_ROLE_A)
     int newton_lu_split_min = getenv("QN_LU_SPLIT_MIN") ? atoi(getenv("QN_LU_SPLIT_MIN")) : 4160; // ... for panels of at least this many rows (QN_OPT_LU_SPLIT_MIN_ROWS)
     uint64_t newton_lu_sync_timeouts = 0;
@@ -493,6 +494,7 @@ extern "C" int qn_solver_set_option(qn_solver* s, int option, int value) {
     case QN_OPT_LU_LOOKAHEAD: s->newton_lu_no_la = on ? 0 : 1; return QN_OK;
     case QN_OPT_LU_ONE_LAUNCH_PANEL: s->newton_lu_no_persist = on ? 0 : 1; return QN_OK;
     case QN_OPT_LU_FORCE_WAIT_EXPIRY: s->newton_lu_force_timeout = on ? 1 : 0; return QN_OK;
+    case QN_OPT_BTB_PROJECT_IN_EVAL: s->no_projfold = !on; return QN_OK;
     case QN_OPT_LU_SPLIT_ROLE_A:
         if (value != 0 && value != 1 && value != 2 && value != 4) return fail(QN_ERROR_INPUT_PARAMS, "role A runs as 1, 2 or 4 workgroups");
         s->newton_lu_split = value == 0 ? 1 : value;

@@ -128,6 +128,8 @@ struct QnS2Args {
     const double *lb, *ub;   // bounded variants (s2_dir_kernel): the solver's box (BFGSB / DFPB; null: none) ...
     const double *llb, *lub; // ... and the line search's (MoreThuenteB; null: none)
     int ring;                // round 6: the pair instance's evaluation runs as s2_evalr_kernel (qn_sym2r.hip.h: mover waves + multiplier waves)
+    int projfold;            // round 6: BackTrackingB's projection inside s2_evalr_kernel<true> (no s2_proj_kernel launch per trial): the trial point is clamped where it is
+                             // formed, ||P(x + t d) - x||^2 leaves the launch as column 6 of its table (rows 0 .. nb - 1), the consuming prologue adds it up
 #ifdef QN_S2_STAMPS
     unsigned long long* dbg; // diagnostic build: dbg[((slot % 64) * 256 + workgroup) * 16 + k] = wall clock (10 ns) at stamp k
     int slot;
@@ -299,6 +301,11 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
 #pragma unroll
             for (int j = 0; j < QN_S2_PCH; ++j) tr[j][k] = T[(size_t)k * a.trows + j * 64 + lane]; // (trows >= 256)
     }
+    double t6[BND ? QN_S2_PCH : 1]; // (BackTrackingB projected inside the evaluation kernel: the shares of ||P(x + t d) - x||^2, column 6)
+    if constexpr (BND) {
+#pragma unroll
+        for (int j = 0; j < QN_S2_PCH; ++j) t6[j] = (a.projfold && !no_decision) ? T[(size_t)6 * a.trows + j * 64 + lane] : 0.0;
+    }
     // (Measured and dropped, round 5: the control block's and the table's addresses as LEADING SCALAR kernel arguments, preloaded into SGPRs by the
     // dispatcher -- -mllvm -amdgpu-kernarg-preload-count=16, .amdhsa_user_sgpr_kernarg_preload_length 4 on the accept-reduce -- so that the first
     // requests need no kernel-argument fetch in front of them: 5.93 -> 6.03 us, nothing.  HIP_FORCE_DEV_KERNARG=0, for scale: +2 us on EVERY kernel.)
@@ -451,6 +458,14 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
         for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
         tot[0] = m;
     }
+    if constexpr (BND) if (a.projfold && c.serviced == 2 && ph == QN_PH_REQ_EVAL && c.req_project) { // (uniform) the evaluation kernel projected itself: column 6
+        double d2 = 0.0; // of ITS table, rows 0 .. nb - 1 -- the same shares in the same order as the s2_proj_kernel flow below: the same bits
+#pragma unroll
+        for (int j = 0; j < QN_S2_PCH; ++j) d2 = d2 + ((j * 64 + lane < a.nb) ? t6[j] : 0.0);
+        for (int b = QN_S2_MAXG + lane; b < a.nb; b += 64) d2 = d2 + T[(size_t)6 * a.trows + b];
+        d2 = qn_wave_sum(d2);
+        if (lane == 0) c.bt_diff2 = d2; // (consumed by the machine below: backtracking_b.rs:24-34)
+    }
     if constexpr (BND) if (c.serviced == 5 && ph == QN_PH_REQ_EVAL) { // (uniform) column 0 of s2_proj_kernel's rows: ||P(x + t d) - x||^2, block-rows in order
         double d2 = 0.0;
 #pragma unroll
@@ -508,7 +523,7 @@ __device__ __forceinline__ void qn_s2_prologue_w0(const QnS2Args& a, QnS2Lds& L,
     }
     QN_S2_STAMP(11);
     if (lane == 0) {
-        if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == ((BND && c.req_project) ? 5 : 0); // (a projected trial: behind its s2_proj_kernel)
+        if (KIND == QN_S2_EVAL) mine = c.phase == QN_PH_REQ_EVAL && c.serviced == ((BND && c.req_project && !a.projfold) ? 5 : 0); // (a projected trial: behind its s2_proj_kernel, unless the evaluation kernel projects itself)
         if (KIND == QN_S2_PROJ) mine = c.phase == QN_PH_REQ_EVAL && c.req_project && c.serviced == 0;
         if (KIND == QN_S2_VEC || KIND == QN_S2_VSUM || KIND == QN_S2_VECD) mine = c.phase == QN_PH_REQ_VEC && c.serviced == 0;
         if (KIND == QN_S2_HTILE) { // 2: the accepted point's slots -> vectors AND the update tiles (folded accept-reduce); 1: the tiles of a pending pass
@@ -553,12 +568,12 @@ __device__ __forceinline__ void qn_s2_ctl_out(const QnS2Args& a, const QnS2Lds& 
 __device__ __forceinline__ double qn_uniform(const double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
-template <bool PIN, bool BNDREQ = false> // (BNDREQ: the bounded runs' evaluation kernels -- a request may name a STORED point)
-__device__ __forceinline__ QnEvalReq qn_s2_eval_req(const QnCtl& c, bool last_eval) {
+template <bool PIN, bool BNDREQ = false> // (BNDREQ: the bounded runs' evaluation kernels -- a request may name a STORED point; in_eval: the kernel projects itself, QnS2Args.projfold)
+__device__ __forceinline__ QnEvalReq qn_s2_eval_req(const QnCtl& c, bool last_eval, const bool in_eval = false) {
     QnEvalReq q;
     q.is_t = (last_eval ? c.ev_kind : c.req_kind) == QN_REQ_T;
     q.t = last_eval ? c.ev_t : c.req_t;
-    const bool stored = BNDREQ && !last_eval && c.req_project != 0; // (BackTrackingB: evaluate AT the point s2_proj_kernel stored in the trial half of X0)
+    const bool stored = BNDREQ && !last_eval && c.req_project != 0 && !in_eval; // (BackTrackingB: evaluate AT the point s2_proj_kernel stored in the trial half of X0)
     if (stored) q.is_t = false;
     q.mode = c.dir_mode;
     q.c_ss = c.c_ss; q.c_su = c.c_su; q.c_uu = c.c_uu; q.ug = c.dir_ug; q.sg = c.dir_sg;

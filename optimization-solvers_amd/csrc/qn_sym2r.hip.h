@@ -85,6 +85,7 @@ struct QnS2RShared {
     double xb_c[QN_TB], db_c[QN_TB];
     double xs_c[QN_TB];                                      // the sliver's diagonal block: columns ...
     double ss[8][4];                                         // ... and its eight rows: xt, d, b, g
+    double pjred[2];                                         // (BND, a.projfold) block blockIdx.x's share of ||P(x + t d) - x||^2: multipliers 6 and 7
     v2d park[QN_S2_WAVES][QN_S2_RPW][64]; // 128 KB: sixteen ring slots per mover
 };
 
@@ -332,11 +333,22 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
         // where a diagonal tile or the sliver needs them: two consecutive entries per lane, eight 1 KB requests per wave, BEFORE the movers' burst.
         const int blk = mw == 0 ? Ia : (mw == 1 ? Ja : (mw == 2 ? Ib : (mw == 3 ? Jb : slm.D))); // (uniform)
         v2d e_x0, e_x1, e_v, e_s0, e_s1, e_u, e_b, e_g;
+        v2d e_lo = {-INFINITY, -INFINITY}, e_hi = {INFINITY, INFINITY}; // BND, a.projfold: the line search's box at the block (BackTrackingB projects its trial points)
+        // ... and, BND with a.projfold, in workgroups 0 .. nb - 1: multipliers 6 and 7 hold block blockIdx.x's entries, 64 each -- the block's share of
+        // ||P(x + t d) - x||^2 (s2_proj_kernel's two waves: the same entries, the same wave sums, added in the same order)
+        const bool pj_wave = BND && a.projfold && (mw == 6 || mw == 7) && (int)blockIdx.x < a.nb; // (uniform)
+        double pj_x0 = 0.0, pj_x1 = 0.0, pj_s0 = 0.0, pj_s1 = 0.0, pj_v = 0.0, pj_u = 0.0, pj_lo = -INFINITY, pj_hi = INFINITY;
         if (mw < 5) {
             const unsigned ei = (unsigned)blk * QN_TB + 2u * (unsigned)lane;
             e_x0 = ld2(a.F.X0 + ei); e_x1 = ld2(a.F.X0 + np + ei); e_v = ld2(a.F.VV + ei);
             e_s0 = ld2(a.F.S0 + ei); e_s1 = ld2(a.F.S0 + np + ei); e_u = ld2(a.F.UN + ei);
             if (mw == 2 || mw == 4) { e_b = ld2(a.F.b + ei); e_g = ld2(a.F.G + ei); }
+            if (BND && a.projfold && a.llb) { e_lo = ld2(a.llb + ei); e_hi = ld2(a.lub + ei); }
+        }
+        if (pj_wave) {
+            const unsigned gi = blockIdx.x * QN_TB + (unsigned)(mw - 6) * 64u + (unsigned)lane;
+            pj_x0 = a.F.X0[gi]; pj_x1 = a.F.X0[np + gi]; pj_s0 = a.F.S0[gi]; pj_s1 = a.F.S0[np + gi]; pj_v = a.F.VV[gi]; pj_u = a.F.UN[gi];
+            if (a.llb) { pj_lo = a.llb[gi]; pj_hi = a.lub[gi]; }
         }
         unsigned cw = 0u;
         if (mw >= 4) cw = ((const volatile unsigned*)(pc0 & ~127ull))[(size_t)((mw - 4) * 64 + lane) * 32];
@@ -344,11 +356,27 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
         entry_barrier();
         qn_s2r_wait_ge<8>(&Y.mdone, 1u, bad); // (long naps: the machine's wave shares its SIMD with three of the waiting ones)
         if (!L.mine) return;
-        const QnEvalReq q = qn_s2_eval_req<true, BND>(L.c, false);
+        const QnEvalReq q = qn_s2_eval_req<true, BND>(L.c, false, BND && a.projfold != 0);
+        // (BND, a.projfold) a PROJECTED trial: x + t d clamped into the line search's box where it is formed -- the point s2_proj_kernel would have stored,
+        // entry by entry the same operations -- and evaluated like a stored point: with d = 0 (qn_s2_trial's `!is_t` branch; qn_s2_advance reads no g'd from it)
+        const bool pj = BND && a.projfold && __builtin_amdgcn_readfirstlane(L.c.req_project) != 0; // (uniform)
+        if (pj_wave && pj) { // backtracking_b.rs:31-34, :67 -- as s2_proj_kernel
+            const double xi = q.xc ? pj_x1 : pj_x0, si = q.sc ? pj_s1 : pj_s0;
+            double d;
+            double z = qn_s2_trial(q, xi, pj_v, si, pj_u, d);
+            z = fmin(fmax(z, pj_lo), pj_hi);
+            const double df = z - xi;
+            const double p = qn_wave_sum(df * df);
+            if (lane == 0) SH.pjred[mw - 6] = p;
+        }
         if (mw < 5) { // the trial point at this wave's block: qn_s2_trial, entry by entry -- what every wave of round 5's kernel formed for itself
             const v2d ex = q.xc ? e_x1 : e_x0, es = q.sc ? e_s1 : e_s0;
             v2d xt, dd;
             { double d0, d1; xt.x = qn_s2_trial(q, ex.x, e_v.x, es.x, e_u.x, d0); xt.y = qn_s2_trial(q, ex.y, e_v.y, es.y, e_u.y, d1); dd.x = d0; dd.y = d1; }
+            if (pj) {
+                xt.x = fmin(fmax(xt.x, e_lo.x), e_hi.x); xt.y = fmin(fmax(xt.y, e_lo.y), e_hi.y);
+                dd.x = 0.0; dd.y = 0.0;
+            }
             double* xdst = mw == 0 ? SH.xa_r : (mw == 1 ? SH.xa_c : (mw == 2 ? SH.xb_r : (mw == 3 ? SH.xb_c : SH.xs_c)));
             *reinterpret_cast<v2d*>(xdst + 2 * lane) = xt;
             if (mw < 4) {
@@ -423,6 +451,8 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
     __syncthreads();
     if (tid < 16 && a.dbg && blockIdx.x < 256) a.dbg[(((size_t)(a.slot & 63)) * 256 + blockIdx.x) * 16 + tid] = SH.stamps[tid];
 #endif
+    if (BND && a.projfold && tid == 0 && (int)blockIdx.x < a.nb && L.c.req_project != 0) // (behind the exchange barrier: multipliers 6 and 7 have left their sums)
+        a.wgS[((size_t)a.parity * QN_S2_ROW + 6) * a.trows + blockIdx.x] = SH.pjred[0] + SH.pjred[1];
     if (tid < QN_S2_NSE) { // sred column -> table column: xt'(Q xt - 2b), d'(Q xt - b), (b'xt = 0), (b'd = 0), g'd, #non-finite d
         const int col = tid == 1 ? 2 : (tid == 2 ? 1 : tid);
         a.wgS[((size_t)a.parity * QN_S2_ROW + col) * a.trows + blockIdx.x] = anybad ? __builtin_nan("") : wgk;

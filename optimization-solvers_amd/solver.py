@@ -56,6 +56,7 @@ OPTIONS = {
     "chunks_per_trip": 16,
     "lu_split_role_a": 17,
     "lu_split_min_rows": 18,
+    "btb_project_in_eval": 19,
 }
 OPT_GENERIC_KERNELS = 1
 OPT_DEFERRED_UPDATE_STEP = 2
@@ -75,6 +76,7 @@ OPT_LU_FORCE_WAIT_EXPIRY = 15
 OPT_CHUNKS_PER_TRIP = 16
 OPT_LU_SPLIT_ROLE_A = 17
 OPT_LU_SPLIT_MIN_ROWS = 18
+OPT_BTB_PROJECT_IN_EVAL = 19
 
 
 class SolverError(Exception):

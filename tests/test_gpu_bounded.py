@@ -224,9 +224,10 @@ def test_warm_call_with_another_line_search_box_forms_its_direction_again(qn, qo
 
 
 def test_backtracking_b_at_the_benchmark_size_on_the_second_generation_path(qn, qo):
-    """Round 6: BFGSB + BackTrackingB at n = 4096 -- the projected trial points stored by s2_proj_kernel, evaluated AT the stored
-    point by the mover / multiplier kernel's bounded instantiation (s2_evalr_kernel<true>) and, with set_option("eval_mover_multiplier", 0), by round
-    5's two-items-and-a-sliver instance: both equal the oracle's restatement (evaluation counts, steps, iterates over the window) and the generic
+    """Round 6: BFGSB + BackTrackingB at n = 4096 -- the trial points projected INSIDE the mover / multiplier kernel's bounded
+    instantiation (s2_evalr_kernel<true>: clamped where the trial point is formed, ||P(x + t d) - x||^2 as column 6 of the launch's table; default) or
+    stored by a s2_proj_kernel launch per trial and evaluated AT the stored point (set_option("btb_project_in_eval", 0); and, with
+    set_option("eval_mover_multiplier", 0), by round 5's two-items-and-a-sliver instance): both equal the oracle's restatement (evaluation counts, steps, iterates over the window) and the generic
     path, and each other bit for bit; pipelined equals synchronous bit for bit; no host round trip per request."""
     n = 4096
     q, b, x0, lb, ub = _box(qo, n)
@@ -236,11 +237,13 @@ def test_backtracking_b_at_the_benchmark_size_on_the_second_generation_path(qn, 
     ref.minimize(_make_ls(qo, "btb", n, lb, ub), qo.QuadraticOracle(q, b, nthreads=qo.max_threads()), iters, 30, trace_cap=iters, trace_x=True)
     obj = qn.Quadratic(q, b)
     got = {}
-    for mode in ("ring", "ring sync", "pair", "generic"):
+    for mode in ("ring", "ring sync", "ring proj-launch", "pair", "generic"):
         s = qn.BFGSB.new(1e-9, x0, lb, ub)
         s.set_trace(iters, with_x=True)
         if mode == "ring sync":
             s.set_sync_mode(1)
+        if mode == "ring proj-launch":  # (the projection as a launch per trial in front of the mover / multiplier kernel: the first version of this round)
+            s.set_option("btb_project_in_eval", 0)
         if mode == "pair":
             s.set_option("eval_mover_multiplier", 0)
         if mode == "generic":
@@ -260,11 +263,14 @@ def test_backtracking_b_at_the_benchmark_size_on_the_second_generation_path(qn, 
             assert np.linalg.norm(xs[k] - ref.trace_x[k]) <= 1e-8 * max(1.0, np.linalg.norm(ref.trace_x[k])), (mode, k)
         x = s.x()
         assert np.all(x >= lb - 1e-12) and np.all(x <= ub + 1e-12)
-        got[mode] = (tr, xs, x)
+        got[mode] = (tr, xs, x, st["launches"], st["oracle_evals"])
         if mode == "ring":
             assert st["host_syncs"] <= 8  # (one per batch of periods, not one per request: the run makes ~130 requests)
-    assert got["ring"][0] == got["pair"][0] == got["ring sync"][0]
+    assert got["ring"][0] == got["pair"][0] == got["ring sync"][0] == got["ring proj-launch"][0]
     assert np.array_equal(got["ring"][1], got["pair"][1]) and np.array_equal(got["ring"][1], got["ring sync"][1])
+    assert np.array_equal(got["ring"][1], got["ring proj-launch"][1])
+    # the projection inside the evaluation kernel: one launch per evaluation SLOT of the pipelined pattern fewer (at least one per evaluation)
+    assert got["ring"][4] == got["ring proj-launch"][4] and got["ring proj-launch"][3] - got["ring"][3] >= got["ring"][4]
     assert np.linalg.norm(got["ring"][2] - got["generic"][2]) <= 1e-8 * max(1.0, np.linalg.norm(got["generic"][2]))
 
 
