@@ -388,7 +388,7 @@ def extra_bounded(qn, ctx):
     iters = 200
     for name, mk, mkls in (("unbounded", lambda: qn.BFGS(1e-10, x0, ctx=ctx), lambda: qn.MoreThuente()),
                            ("bounded", lambda: qn.BFGSB.new(1e-10, x0, lb, ub, ctx=ctx), lambda: qn.MoreThuenteB.new(n).with_lower_bound(lb).with_upper_bound(ub)),
-                           # round 6: BackTrackingB on the second-generation path (s2_proj_kernel) against plain BackTracking
+                           # round 6: BackTrackingB on the second-generation path (projection inside s2_evalr_kernel<true>) against plain BackTracking
                            ("unbounded_backtracking", lambda: qn.BFGS(1e-10, x0, ctx=ctx), lambda: qn.BackTracking(1e-4, 0.5)),
                            ("bounded_backtracking_b", lambda: qn.BFGSB.new(1e-10, x0, lb, ub, ctx=ctx), lambda: qn.BackTrackingB.new(1e-4, 0.5, lb, ub))):
         s = mk()
@@ -413,7 +413,7 @@ def extra_bounded(qn, ctx):
         del s
     out["ratio_bounded_over_unbounded_time"] = out["bounded"]["us_per_iteration"] / out["unbounded"]["us_per_iteration"]
     out["ratio_backtracking_b_over_backtracking_time"] = out["bounded_backtracking_b"]["us_per_iteration"] / out["unbounded_backtracking"]["us_per_iteration"]
-    out["backtracking_b_note"] = ("a BackTrackingB iteration evaluates every trial at a PROJECTED point (one more small launch each) and then the accepted "
+    out["backtracking_b_note"] = ("a BackTrackingB iteration evaluates every trial at a PROJECTED point (projected inside the evaluation kernel at this size) and then the accepted "
                                   "x + t d once more, unprojected (bfgs_b.rs:91-98): one evaluation more per iteration than BackTracking, whose accepted trial IS the next iterate")
     out["value"] = out["bounded"]["iterations_per_s"]
     out["unit"] = "iterations/s"
