@@ -318,7 +318,10 @@ typedef enum {
     QN_OPT_CHUNKS_PER_TRIP = 16,           /* [1] fused ROW kernels: column chunks per loop trip (1, 2 or 4) */
     QN_OPT_LU_SPLIT_ROLE_A = 17,           /* [4] ... the one-launch panel's pivot chain shared by 1 (0 too), 2 or 4 workgroups of one XCD (csrc/qn_lu_split.hip.h) -- the same bits */
     QN_OPT_LU_SPLIT_MIN_ROWS = 18,         /* [4160] ... for panels of at least `value` rows (a NUMBER, not a switch; shorter panels: one workgroup) */
-    QN_OPT_BTB_PROJECT_IN_EVAL = 19        /* [1] BackTrackingB on the second-generation path: the trial point projected inside the evaluation kernel (n = 4096's mover + multiplier kernel); 0: a projection launch per trial -- the same bits */
+    QN_OPT_BTB_PROJECT_IN_EVAL = 19,       /* [1] BackTrackingB on the second-generation path: the trial point projected inside the evaluation kernel (n = 4096's mover + multiplier kernel); 0: a projection launch per trial -- the same bits */
+    QN_OPT_EVAL_ZIGZAG = 20,               /* [1] the mover + multiplier kernel streams its two tiles in the other order in launches of odd parity: an evaluation launch right behind another one starts with the tile the XCD's L2 still holds (csrc/qn_sym2r.hip.h, ZIG-ZAG); 0: the same order in every launch -- the same bits */
+    QN_OPT_TOUCH_H_ROWS = 21,              /* [8] n = 4096: the accept-reduce launch carries workgroups that only load the first `value` rows (of a wave's 16; 0, 4, 6, 8, 10, 12 or 16) of the tile the update-tile launch's workgroup of the same index streams first -- into the L2 of the XCD both run on (csrc/qn_sym2.hip.h, TOUCH WORKGROUPS); a NUMBER; loads only -- the same bits */
+    QN_OPT_TOUCH_Q_ROWS = 22               /* [6] ... and the update-reduce launch for the evaluation launch behind it (rows of Q's tiles) */
 } qn_option;
 int qn_solver_set_option(qn_solver* s, int option, int value);
 

@@ -144,6 +144,7 @@ static int s2_launch(Run& r, int kind) {
     case QN_S2_VEC:
         if (r.gobj) { const QnS2GArgs g = s2g_args(r); hipLaunchKernelGGL(s2g_vec_kernel, dim3(a.nb), dim3(QN_TB), 0, st, a, g); }
         else if (sh) hipLaunchKernelGGL(s2_vec_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
+        else if (a.touch) hipLaunchKernelGGL((s2_vec_kernel<false, false, 32>), dim3(a.G), dim3(QN_S2_TPB), 0, st, a); // (with the TOUCH workgroups, qn_s2_touch: G in all -- one workgroup per CU)
         else hipLaunchKernelGGL(s2_vec_kernel<false>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
         break;
     case QN_S2_VECD: hipLaunchKernelGGL((s2_vec_kernel<true, true>), dim3(a.nb), dim3(QN_S2_TPB), 0, st, a); break; // (row-sharded, trial-vector exchange)
@@ -183,6 +184,7 @@ static int s2_launch(Run& r, int kind) {
     case QN_S2_HREDUCE:
         if (sh) hipLaunchKernelGGL(s2_hreduce_kernel<true>, dim3(a.nb), dim3(QN_S2_TPB), 0, st, a);
         else if (s->method == QN_SR1) hipLaunchKernelGGL((s2_hreduce_kernel<false, true>), dim3(2 * a.nb), dim3(QN_S2_TPB), 0, st, a);
+        else if (a.touchq) hipLaunchKernelGGL((s2_hreduce_kernel<false, false, 32>), dim3(2 * a.nb + a.G), dim3(QN_S2_TPB), 0, st, a); // (+ the TOUCH workgroups)
         else hipLaunchKernelGGL(s2_hreduce_kernel<false>, dim3(2 * a.nb), dim3(QN_S2_TPB), 0, st, a); // (a workgroup per block-row and right-hand side)
         break;
     case QN_S2_GEVAL_A:

@@ -221,6 +221,7 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         { // the pair instance's evaluation as mover + multiplier waves (qn_sym2r.hip.h): the same bits as round 5's kernel, 14.3 us against 15.3 per launch
           // (profiles/r06_a_*).  QN_S2_RING=0 / QN_OPT_EVAL_MOVER_MULTIPLIER 0: round 5's kernel.  It needs every workgroup's FIRST item off the diagonal.
             a.ring = (a.pair && s->ring && s->s2_nb * (s->s2_nb - 1) / 2 >= s->s2_G) ? 1 : 0;
+            a.zig = (a.ring && s->zig) ? 1 : 0;
         }
         // BackTrackingB's projection INSIDE the evaluation kernel (round 6, s2_evalr_kernel<true>): no s2_proj_kernel launch per trial -- the trial point is clamped
         // where it is formed, the shares of ||P(x + t d) - x||^2 leave the launch as column 6 of its table.  The same bits as the launch-per-trial flow.
@@ -245,6 +246,16 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
         }
         a.cnt = s->s2_cnt;
         a.tred = (c->world == 1 && !a.fold && !r.gobj && !r.tiles1 && s->s2_maxk <= QN_S2_TRED_MAXK && want_tred && s->method != QN_SR1) ? 1 : 0;
+        // TOUCH workgroups (qn_s2_touch): where the two small launches are s2_vec_kernel<false> / s2_hreduce_kernel<false> in front of the pair instance's
+        // tile launches, and a workgroup's XCD survives the offset (nb a multiple of 8)
+        {
+            auto rows_ok = [](int v) { return v == 4 || v == 6 || v == 8 || v == 10 || v == 12 || v == 16; };
+            const bool can = a.ring && !r.bnd && !a.fold && !a.tred && s->method != QN_SR1 && a.nb == 32 && a.G == 256; // (the instantiations are nb = 32's)
+            a.touch = (can && rows_ok(s->touch)) ? s->touch : 0;
+            a.touchq = (can && rows_ok(s->touchq)) ? s->touchq : 0;
+            a.touch_delay = std::max(0, std::min(512, s->touch_delay));
+            a.touchq_delay = std::max(0, std::min(512, s->touchq_delay));
+        }
         // WHO GETS THE INFINITY CACHE (256 MB).  Per iteration a rank streams its half of Q twice (read) and its half of H once
         // (read + written); non-temporal accesses pass the cache by.  Measured (round 4, bench.py same box, it/s for the policies
         // H plain / Q plain, H plain / Q non-temporal, H non-temporal / Q plain, both non-temporal):

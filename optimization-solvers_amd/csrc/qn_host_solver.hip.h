@@ -35,6 +35,11 @@ struct qn_solver {
     bool no_sliver = false;    // diagnostics: sym2 without row slivers (round 2's work lists)
     bool no_pair = false;      // diagnostics: the general evaluation kernel where the two-items-and-a-sliver instance would run
     int ring = (getenv("QN_S2_RING") && atoi(getenv("QN_S2_RING")) == 0) ? 0 : 1; // the pair instance's evaluation as mover + multiplier waves (qn_sym2r.hip.h); QN_OPT_EVAL_MOVER_MULTIPLIER
+    int zig = (getenv("QN_S2_ZIGZAG") && atoi(getenv("QN_S2_ZIGZAG")) == 0) ? 0 : 1; // ... its two tiles in the other order in launches of odd parity (the L2 across evaluation launches); QN_OPT_EVAL_ZIGZAG
+    int touch = getenv("QN_S2_TOUCH") ? atoi(getenv("QN_S2_TOUCH")) : 8;    // TOUCH workgroups in the accept-reduce: rows per wave of H's tiles (0, 4, 6, 8, 10, 12, 16); QN_OPT_TOUCH_H_ROWS
+    int touchq = getenv("QN_S2_TOUCHQ") ? atoi(getenv("QN_S2_TOUCHQ")) : 6; // ... in the update-reduce: rows of Q's tiles; QN_OPT_TOUCH_Q_ROWS
+    int touch_delay = getenv("QN_S2_TOUCH_DELAY") ? atoi(getenv("QN_S2_TOUCH_DELAY")) : 32; // ... units of 64 clocks the accept-reduce's touching workgroups sleep first
+    int touchq_delay = getenv("QN_S2_TOUCHQ_DELAY") ? atoi(getenv("QN_S2_TOUCHQ_DELAY")) : 0; // ... and the update-reduce's
     bool tred = false;         // measurement: the update-reduce in the tail of the update-tile launch (s2_hpass_kernel<.., TRED>: bit-identical, slower)
     int* s2_cnt = nullptr;     // tail reduce: arrival counters of the block-rows
     int gen_slots_hint = 0;    // generic pipelined path: evaluation slots per period the last batch needed (0: none run yet)
@@ -495,6 +500,12 @@ extern "C" int qn_solver_set_option(qn_solver* s, int option, int value) {
     case QN_OPT_LU_ONE_LAUNCH_PANEL: s->newton_lu_no_persist = on ? 0 : 1; return QN_OK;
     case QN_OPT_LU_FORCE_WAIT_EXPIRY: s->newton_lu_force_timeout = on ? 1 : 0; return QN_OK;
     case QN_OPT_BTB_PROJECT_IN_EVAL: s->no_projfold = !on; return QN_OK;
+    case QN_OPT_EVAL_ZIGZAG: s->zig = on ? 1 : 0; return QN_OK;
+    case QN_OPT_TOUCH_H_ROWS:
+    case QN_OPT_TOUCH_Q_ROWS:
+        if (value != 0 && value != 4 && value != 6 && value != 8 && value != 10 && value != 12 && value != 16) return fail(QN_ERROR_INPUT_PARAMS, "rows per wave to touch: 0, 4, 6, 8, 10, 12 or 16");
+        (option == QN_OPT_TOUCH_H_ROWS ? s->touch : s->touchq) = value;
+        return QN_OK;
     case QN_OPT_LU_SPLIT_ROLE_A:
         if (value != 0 && value != 1 && value != 2 && value != 4) return fail(QN_ERROR_INPUT_PARAMS, "role A runs as 1, 2 or 4 workgroups");
         s->newton_lu_split = value == 0 ? 1 : value;

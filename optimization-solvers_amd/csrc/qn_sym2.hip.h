@@ -130,6 +130,11 @@ struct QnS2Args {
     int ring;                // round 6: the pair instance's evaluation runs as s2_evalr_kernel (qn_sym2r.hip.h: mover waves + multiplier waves)
     int projfold;            // round 6: BackTrackingB's projection inside s2_evalr_kernel<true> (no s2_proj_kernel launch per trial): the trial point is clamped where it is
                              // formed, ||P(x + t d) - x||^2 leaves the launch as column 6 of its table (rows 0 .. nb - 1), the consuming prologue adds it up
+    int touch, touchq;       // round 6: TOUCH workgroups in the accept-reduce (rows of H's tiles) and in the update-reduce (rows of Q's): rows per wave, of 16
+                             // (qn_s2_touch; 0: none -- the launches then are the instantiations without them; 4, 8, 12 or 16)
+    int touch_delay, touchq_delay; // ... units of 64 clocks the accept-reduce's / the update-reduce's touching workgroups sleep before their first load
+    int zig;                 // round 6: s2_evalr_kernel streams its two tiles in the other order in launches of odd parity (what the XCD's L2 still holds of the
+                             // evaluation launch in front comes first: qn_sym2r.hip.h, ZIG-ZAG) -- the same bits
 #ifdef QN_S2_STAMPS
     unsigned long long* dbg; // diagnostic build: dbg[((slot % 64) * 256 + workgroup) * 16 + k] = wall clock (10 ns) at stamp k
     int slot;
@@ -1141,18 +1146,85 @@ __device__ __forceinline__ double qn_s2_slot_sum(const double* __restrict__ part
     return tot;
 }
 
+// TOUCH WORKGROUPS (round 6; n = 4096's two-items-and-a-sliver instance).  The iteration's two small launches -- the accept-reduce (nb workgroups) and
+// the update-reduce (2 nb) -- leave the chip's fabric idle for ~10 of the iteration's 61 us, and the tile launch behind each of them starts by streaming,
+// in every workgroup, a tile whose address follows from the workgroup's index alone.  An XCD's 4 MB L2 keeps its bytes across a kernel boundary
+// (tools/l2_keep_probe.hip) and workgroup g of a launch runs on XCD g mod 8: so the small launch carries G extra workgroups, and extra workgroup b
+// TOUCHES the first a.touch rows of every wave's sixteen of the tile that workgroup b of the NEXT launch requests first -- plain loads, nothing kept.
+// The tile launch then finds those rows in its XCD's L2 (twice the fabric's rate) and has that much less to bring across.  Half a tile per workgroup
+// (8 rows per wave: 64 KB per CU, 2 MB per XCD) fits inside the small launches' own time (tools/l2_prefetch_probe.hip: small launch unchanged, update
+// tiles and the first evaluation each ~1 us shorter); whole tiles make the small launches as much longer as the tile launches get shorter.
+// What the first measurement of the real kernels added (profiles/r06_e_*): (1) the small launches' own workgroups want their inputs -- control block, table,
+// slots -- in the first 1.9 us, and 2 MB per XCD requested at the same moment stand in front of them: the accept-reduce's touching workgroups SLEEP first
+// (a.touch_delay), its machine runs on LDS from 1.9 to 3.3 us and that is when the fabric is theirs; the update-reduce's body is 2.5 us in all, it touches less;
+// (2) which workgroups touch must follow from the workgroup index and a CONSTANT: the test against a.nb put a scalar load and its wait in front of every
+// workgroup's first instruction (accept-reduce 5.65 -> 6.2 us with nobody touching) -- so the kernels with touching workgroups are instantiations of
+// their own (NBT = nb = 32: n = 4096, the one size with the two-items-and-a-sliver instance), and every other launch runs the code it ran before.
+// Loads only: whatever they bring -- or do not bring, if the placement of workgroups is not the one assumed -- no value in the run depends on it.
+template <int ROWS>
+__device__ __forceinline__ void qn_s2_touch_rows(const double* __restrict__ base, const size_t np) {
+    v2d h[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) h[r] = ld2(base + (size_t)r * np);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) asm volatile("" :: "v"(h[r].x), "v"(h[r].y));
+}
+__device__ __forceinline__ void qn_s2_touch(const double* __restrict__ M, const QnS2Args& a, const int ij, const int rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int I = ij >> 16, J = ij & 0xffff;
+    // (an opaque copy of np: as a value both sides of the caller's branch use, the compiler moved its first use -- and with it the wait for the kernel-argument
+    // load -- in FRONT of the branch: a scalar memory round trip ahead of every workgroup's first request)
+    int npi = a.np;
+    asm volatile("" : "+s"(npi));
+    const size_t np = (size_t)npi;
+    const double* base = M + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + 2 * lane;
+    switch (rows) { // (uniform)
+    case 4: qn_s2_touch_rows<4>(base, np); break;
+    case 6: qn_s2_touch_rows<6>(base, np); break;
+    case 8: qn_s2_touch_rows<8>(base, np); break;
+    case 10: qn_s2_touch_rows<10>(base, np); break;
+    case 12: qn_s2_touch_rows<12>(base, np); break;
+    case 16: qn_s2_touch_rows<16>(base, np); break;
+    default: break;
+    }
+}
+// ... rows j, j + 7, .. (< rows) of every wave's sixteen: a seventh of what qn_s2_touch takes of a tile (seven workgroups share it)
+__device__ __forceinline__ void qn_s2_touch_seventh(const double* __restrict__ M, const QnS2Args& a, const int ij, const int rows, const int j) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int I = ij >> 16, J = ij & 0xffff;
+    int npi = a.np;
+    asm volatile("" : "+s"(npi));
+    const size_t np = (size_t)npi;
+    const double* base = M + (size_t)(I * QN_TB + wave * QN_S2_RPW) * np + (size_t)J * QN_TB + 2 * lane;
+    v2d h0 = {0.0, 0.0}, h1 = {0.0, 0.0}, h2 = {0.0, 0.0};
+    if (j < rows) h0 = ld2(base + (size_t)j * np);
+    if (j + 7 < rows) h1 = ld2(base + (size_t)(j + 7) * np);
+    if (j + 14 < rows) h2 = ld2(base + (size_t)(j + 14) * np);
+    asm volatile("" :: "v"(h0.x), "v"(h0.y), "v"(h1.x), "v"(h1.y), "v"(h2.x), "v"(h2.y));
+}
+
 // accept-reduce: block-row R of the LAST evaluation becomes vectors: q_i, g+ = q - b, y = g+ - g, x+ and s = x+ - x
 // (bfgs.rs:94-99), and the five sums the update needs
 // SHARD (row-sharded runs): q_i is the sum over the ranks, in rank order, of the partial vectors the exchange has gathered in xg
 // (each rank's share summed by s2sh_vsum_kernel, qn_sym2sh.hip.h); every rank forms every block-row: replicated work, the same bits.
 // DECIDE (SHARD only): the partial vectors of the LAST evaluation are already gathered (they rode on its scalar exchange): this launch's
 // prologue is the deciding one -- it consumes the evaluation, accepts, and the launch serves the request it has just made.
-template <bool SHARD = false, bool DECIDE = false>
+template <bool SHARD = false, bool DECIDE = false, int NBT = 0> // (NBT: the instantiation with TOUCH workgroups behind its nb = NBT own)
 __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
     __shared__ QnS2Lds L;
     __shared__ double qbuf[3][QN_TB];
     __shared__ double bred[2][8];
     const int R = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (NBT > 0 && __builtin_expect((int)blockIdx.x >= NBT, 0)) { // TOUCH workgroup (uniform): the update tiles follow -- H, the first list item
+        // (this kernel's 150 registers admit ONE workgroup per CU: the grid stays at G -- nb + G workgroups would leave nb of them waiting for a CU -- and the
+        // last nb tiles are shared out, a seventh each, among the G - nb = 7 nb touching workgroups: tile G - nb + b mod nb belongs to the same XCD as b)
+        static_assert(NBT == 0 || NBT == 32, "seven touching workgroups share a tile: G = 8 nb");
+        const int b = (int)blockIdx.x - NBT;
+        for (int k = 0; k < a.touch_delay; k += 8) __builtin_amdgcn_s_sleep(8);
+        qn_s2_touch(a.H, a, qn_s2_first_item(b, NBT), a.touch);
+        qn_s2_touch_seventh(a.H, a, qn_s2_first_item(a.G - NBT + (b & (NBT - 1)), NBT), a.touch, b / NBT);
+        return;
+    }
     QnS2Slots S0;
     unsigned cw[4] = {0u, 0u, 0u, 0u};
     QN_S2_STAMP(0);
@@ -1718,7 +1790,7 @@ __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a
 // memory pipeline -- in-kernel stamps at n = 4096: control block 1.45 us after entry, barrier 2.0, totals 2.75: the slots, not the machine, were
 // what the epilogue waited for -- and nothing in the epilogue needs both totals: u goes with the two sums and the commit of g, v is stored and
 // that is all.  The same sums in the same order.
-template <bool SHARD = false, bool SR1 = false> // (row-sharded: the totals are the rank-order sums of the gathered partial [u, v]: see s2_vec_kernel)
+template <bool SHARD = false, bool SR1 = false, int NBT = 0> // (row-sharded: the totals are the rank-order sums of the gathered partial [u, v]: see s2_vec_kernel; NBT: as there)
 __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a) {
     static_assert(!(SHARD && SR1), "SR1 runs on one rank");
     __shared__ QnS2Lds L;
@@ -1726,6 +1798,14 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
     __shared__ double bred[2][8];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int R = SHARD ? (int)blockIdx.x : (int)(blockIdx.x >> 1), half = SHARD ? -1 : (int)(blockIdx.x & 1);
+    if (NBT > 0 && __builtin_expect((int)blockIdx.x >= 2 * NBT, 0)) { // TOUCH workgroup b (uniform): an evaluation follows -- Q, the tile s2_evalr_kernel's workgroup b
+        const int b = (int)blockIdx.x - 2 * NBT;                       // streams FIRST in a launch of the next parity (qn_sym2r.hip.h, ZIG-ZAG)
+        const int ij0 = qn_s2_item_of_index(b, NBT), ij1 = qn_s2_item_of_index(a.G + b, NBT);
+        const bool flip = a.zig != 0 && ((a.parity ^ 1) & 1) != 0 && (ij1 >> 16) != (ij1 & 0xffff);
+        for (int k = 0; k < a.touchq_delay; k += 8) __builtin_amdgcn_s_sleep(8);
+        qn_s2_touch(a.Q, a, flip ? ij1 : ij0, a.touchq);
+        return;
+    }
     QnS2Slots S0;
     QN_S2_STAMP(0);
     double gp = 0.0, yv = 0.0, s0e = 0.0, s1e = 0.0;

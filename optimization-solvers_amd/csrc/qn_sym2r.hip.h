@@ -212,6 +212,18 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
     const int Ia = ij0 >> 16, Ja = ij0 & 0xffff, Ib = ij1 >> 16, Jb = ij1 & 0xffff;
     constexpr bool diag_a = false; // (the host runs this kernel only where every workgroup's FIRST item is an off-diagonal tile: minimize_impl)
     const bool diag_b = Ib == Jb;
+    // ZIG-ZAG (a.zig): launches of odd parity stream the workgroup's two tiles in the OTHER order -- the second list item through the park, the first into
+    // the movers' registers.  An XCD's 4 MB L2 keeps its bytes across a kernel boundary (tools/l2_keep_probe.hip: a 4 MB footprint per XCD re-read by the
+    // next launch comes at twice the fabric's rate), but its 32 workgroups stream 8.25 MB per launch, in the same order every launch: a least-recently-used
+    // cache never hits.  The line search's evaluations are launches next to each other (an iteration is eval, eval, accept-reduce, update tiles,
+    // update-reduce: five launches, so two evaluations in a row always differ in parity); with the order turned round the later one STARTS with the tile
+    // the earlier one ended with.  Which item a wave multiplies from where does not change a sum: the items' products and folds are the same
+    // instructions from the park and from registers (the pair-instance test), every slot and column total is stored under the item's own (I, J), and
+    // the lane's scalars are (0 + x) + y with x, y the two items' shares -- commutative.  A workgroup whose second item is a diagonal tile keeps its order
+    // (the parked item's code has no diagonal form: sixteen workgroups of 256).
+    const bool flip = __builtin_amdgcn_readfirstlane(a.zig != 0 && (a.parity & 1) != 0 && !diag_b) != 0; // (uniform)
+    const int ijx = flip ? ij1 : ij0, ijy = flip ? ij0 : ij1; // X: streamed first, through the park to the multipliers; Y: second, multiplied out of the movers' registers
+    const int ey = flip ? 0 : 1;                              // Y's place in the pair (colred's first index): X's is 1 - ey
     double row_b = 0.0, row_c = 0.0; // (movers) the second item's row totals, the sliver row's total
     QnS2Sliver sl{};
     if (wave < QN_S2_WAVES) {
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
                 }
             }
             if (L.mine) { // its own sixteen rows of the second item (the first item's were parked by the other movers), then its sliver row
-                const double* q1 = tile_base(ij1, 0, opaque(lane));
+                const double* q1 = tile_base(ijy, 0, opaque(lane));
 #pragma unroll
                 for (int r = 0; r < QN_S2_RPW; ++r) h[r] = ld2(q1 + (size_t)r * np);
             }
@@ -263,17 +275,17 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
             // they are in flight while the workgroup's last waves arrive -- the barrier falls ~1.6 us after wave 0's first instruction)
             // wave 0's rows of the first item, three per mover, go out FIRST and are parked first: they come back in front of the wave's own
             const int r0 = (wave - 1) * 3;
-            const double* q0 = tile_base(ij0, 0, lane); // (wave 0 has no clone lanes: qn_s2_col(., ., 0) = 2 lane)
+            const double* q0 = tile_base(ijx, 0, lane); // (wave 0 has no clone lanes: qn_s2_col(., ., 0) = 2 lane)
             v2d t3[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) t3[k] = ld2(q0 + (size_t)min(r0 + k, QN_S2_RPW - 1) * np);
-            const double* qa = tile_base(ij0, wave, lane);
+            const double* qa = tile_base(ijx, wave, lane);
 #pragma unroll
             for (int r = 0; r < QN_S2R_HEAD; ++r) h[r] = ld2(qa + (size_t)r * np);
             entry_barrier();
 #pragma unroll
             for (int r = QN_S2R_HEAD; r < QN_S2_RPW; ++r) h[r] = ld2(qa + (size_t)r * np);
-            const double* q1 = tile_base(ij1, wave, lane);
+            const double* q1 = tile_base(ijy, wave, lane);
             unsigned n0 = 0u;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
@@ -297,14 +309,14 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
         qn_s2r_wait_ge(&Y.eready, 5u, bad); // the trial point is staged (multipliers 0..4, right behind the machine)
         const int rr = wave * QN_S2_RPW + (ln & 15);
         QnS2RTrial tb;
-        tb.xr = SH.xb_r[rr]; tb.dr = SH.db_r[rr]; tb.b_r = SH.bb_r[rr]; tb.g_r = SH.gb_r[rr];
-        tb.xtj = *reinterpret_cast<const v2d*>(SH.xb_c + 2 * ln); tb.dj = *reinterpret_cast<const v2d*>(SH.db_c + 2 * ln);
+        tb.xr = (flip ? SH.xa_r : SH.xb_r)[rr]; tb.dr = (flip ? SH.da_r : SH.db_r)[rr]; tb.b_r = SH.bb_r[rr]; tb.g_r = SH.gb_r[rr]; // (b, g: a diagonal Y only, and that is the second item)
+        tb.xtj = *reinterpret_cast<const v2d*>((flip ? SH.xa_c : SH.xb_c) + 2 * ln); tb.dj = *reinterpret_cast<const v2d*>((flip ? SH.da_c : SH.db_c) + 2 * ln);
         QnS2SliverVec slv; // (qn_s2_sliver_prep's values; the wave's sliver row is ONE row: its row-side values are the same in every lane -- scalar registers)
         slv.xtj = *reinterpret_cast<const v2d*>(SH.xs_c + 2 * ln);
         slv.xr = qn_uniform(SH.ss[wave][0]); slv.dr = qn_uniform(SH.ss[wave][1]); slv.b = qn_uniform(SH.ss[wave][2]);
         slv.gd = qn_uniform(SH.ss[wave][3] * slv.dr); slv.nf = isfinite(slv.dr) ? 0.0 : 1.0;
         QnS2RSums sb;
-        row_b = qn_s2r_item<false>(tb, diag_b, ln, wave, nullptr, h, slp, colred[1][wave], sb, QnS2RNoWait());
+        row_b = qn_s2r_item<false>(tb, diag_b, ln, wave, nullptr, h, slp, colred[ey][wave], sb, QnS2RNoWait()); // (diag_b: Y is the second item, or neither tile is diagonal)
         QN_S2R_STAMP(14, 448); // (wave 7: the second item done)
         // the lane's shares of the group's scalars in round 5's order: ((0 + first item) + second item) + sliver -- the first item's from its multiplier
         qn_s2r_wait_ge(&Y.adone[wave], 1u, bad);
@@ -397,8 +409,8 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
         QN_S2R_STAMP(9, 960); // (multiplier 7: the trial point is staged)
         const int rr = mw * QN_S2_RPW + (lane & 15);
         QnS2RTrial ta;
-        ta.xr = SH.xa_r[rr]; ta.dr = SH.da_r[rr]; ta.b_r = 0.0; ta.g_r = 0.0;
-        ta.xtj = *reinterpret_cast<const v2d*>(SH.xa_c + 2 * lane); ta.dj = *reinterpret_cast<const v2d*>(SH.da_c + 2 * lane);
+        ta.xr = (flip ? SH.xb_r : SH.xa_r)[rr]; ta.dr = (flip ? SH.db_r : SH.da_r)[rr]; ta.b_r = 0.0; ta.g_r = 0.0;
+        ta.xtj = *reinterpret_cast<const v2d*>((flip ? SH.xb_c : SH.xa_c) + 2 * lane); ta.dj = *reinterpret_cast<const v2d*>((flip ? SH.db_c : SH.da_c) + 2 * lane);
         unsigned have = 0u; // (uniform) the last count read from the mover: the word is polled only when it does not cover the rows yet
         if (mw == 0) { qn_s2r_wait_ge(&Y.cnt0, 16u, bad); have = 16u; } // (wave 0's share of the first item: parked by the other movers)
         // in front of rows r .. r + 3: wait for these four and the four that are read ahead, if the last count read does not cover them
@@ -409,8 +421,8 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
         };
         v2d hnone[QN_S2_RPW]; // (the from-park instance never touches a window)
         QnS2RSums sa;
-        const double row_a = qn_s2r_item<true>(ta, diag_a, lane, mw, &park[mw][0][0], hnone, nullptr, colred[0][mw], sa, row_hook);
-        if ((lane & 3) == 0) a.partE[(unsigned)((Ia * a.nb + Ja) * QN_TB + mw * QN_S2_RPW + (lane >> 2))] = row_a; // (off-diagonal: its slot is its own)
+        const double row_a = qn_s2r_item<true>(ta, diag_a, lane, mw, &park[mw][0][0], hnone, nullptr, colred[1 - ey][mw], sa, row_hook);
+        if ((lane & 3) == 0) a.partE[(unsigned)(((ijx >> 16) * a.nb + (ijx & 0xffff)) * QN_TB + mw * QN_S2_RPW + (lane >> 2))] = row_a; // (X is off-diagonal: its slot is its own)
         // the lane's shares of the two scalar sums go to the mover that holds the second item, through the first slot of the park (all of it has been read)
         park[mw][0][lane] = (v2d){sa.pf, sa.pg};
         qn_s2r_publish(&Y.adone[mw], 1u);
@@ -440,7 +452,7 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
             const int rl = wave * QN_S2_RPW + (lane >> 2);
             double v = row_b;
             if (diag_b) v = v + colsum[rl];
-            a.partE[(unsigned)((Ib * a.nb + Jb) * QN_TB + rl)] = v;
+            a.partE[(unsigned)(((ijy >> 16) * a.nb + (ijy & 0xffff)) * QN_TB + rl)] = v;
         }
         if (lane == 48) a.partE[(unsigned)((sl.D * a.nb + sl.D) * QN_TB + sl.row)] = row_c;
     }

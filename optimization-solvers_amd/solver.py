@@ -57,6 +57,9 @@ OPTIONS = {
     "lu_split_role_a": 17,
     "lu_split_min_rows": 18,
     "btb_project_in_eval": 19,
+    "eval_zigzag": 20,
+    "touch_h_rows": 21,
+    "touch_q_rows": 22,
 }
 OPT_GENERIC_KERNELS = 1
 OPT_DEFERRED_UPDATE_STEP = 2
@@ -77,6 +80,9 @@ OPT_CHUNKS_PER_TRIP = 16
 OPT_LU_SPLIT_ROLE_A = 17
 OPT_LU_SPLIT_MIN_ROWS = 18
 OPT_BTB_PROJECT_IN_EVAL = 19
+OPT_EVAL_ZIGZAG = 20
+OPT_TOUCH_H_ROWS = 21
+OPT_TOUCH_Q_ROWS = 22
 
 
 class SolverError(Exception):

@@ -48,6 +48,9 @@ pub const QN_OPT_CHUNKS_PER_TRIP: c_int = 16;
 pub const QN_OPT_LU_SPLIT_ROLE_A: c_int = 17;
 pub const QN_OPT_LU_SPLIT_MIN_ROWS: c_int = 18;
 pub const QN_OPT_BTB_PROJECT_IN_EVAL: c_int = 19;
+pub const QN_OPT_EVAL_ZIGZAG: c_int = 20;
+pub const QN_OPT_TOUCH_H_ROWS: c_int = 21;
+pub const QN_OPT_TOUCH_Q_ROWS: c_int = 22;
 
 pub const QN_UNIQUE_ID_BYTES: usize = 128;
 pub const QN_TRACE_LS_MODIFIED: i32 = 1 << 30;

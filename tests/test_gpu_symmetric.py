@@ -218,6 +218,49 @@ def test_ring_evaluation_is_the_pair_instance_bit_for_bit(qn, qo, method, lsname
         assert np.array_equal(s.approx_inv_hessian(), h0)
 
 
+@pytest.mark.parametrize("method,lsname", [("bfgs", "mt"), ("bfgs", "bt")])
+def test_zigzag_and_touch_workgroups_change_no_bit(qn, qo, method, lsname):
+    """Round 6, the XCDs' L2 across kernel boundaries (tools/l2_keep_probe*.hip, profiles/r06_e_*): (1) ZIG-ZAG -- s2_evalr_kernel streams its two
+    tiles in the other order in launches of odd parity, so that an evaluation launch right behind another one starts with the tile the L2 still
+    holds; the items change hands between the multipliers and the movers, every sum keeps its operands and its order.  (2) TOUCH WORKGROUPS -- the
+    accept-reduce and the update-reduce launches carry G workgroups that only LOAD rows of the tile the next tile launch's workgroup of the same
+    index streams first.  Both are cache policy: trace, iterates and inverse Hessian equal bit for bit with each switched off, with both off, and
+    with whole tiles touched; pipelined and synchronous; the launches per iteration do not change."""
+    n = 4096
+    diag = P.synth_diag(n); b, x0 = P.synth_vectors(n)
+    obj = qn.Quadratic.synthetic(n, P.SEED, diag, b)
+    iters = 24
+    def run(opts, sync=0):
+        s = (qn.BFGS if method == "bfgs" else qn.DFP)(1e-10, x0)
+        s.set_trace(iters, with_x=True)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        s.set_sync_mode(sync)
+        ls = qn.MoreThuente() if lsname == "mt" else qn.BackTracking(1e-4, 0.5)
+        st = 0
+        try:
+            s.minimize(ls, obj, iters, 20)
+        except qn.MaxIterReached:
+            st = 1
+        return s, st
+    base, st0 = run({"eval_zigzag": 0, "touch_h_rows": 0, "touch_q_rows": 0})
+    tr0, xs0 = base.trace()
+    h0 = base.approx_inv_hessian()
+    l0 = base.stats()["launches"]
+    assert base.stats()["path"] & 16 and len(tr0) == iters and all(np.isfinite(r["f"]) for r in tr0)
+    for opts in ({}, {"touch_h_rows": 0, "touch_q_rows": 0}, {"eval_zigzag": 0}, {"touch_h_rows": 16, "touch_q_rows": 16}, {"touch_h_rows": 4, "touch_q_rows": 12},
+                 {"eval_zigzag": 0, "touch_h_rows": 10, "touch_q_rows": 0}):
+        for sync in (0, 1):
+            s, st = run(opts, sync)
+            tr, xs = s.trace()
+            assert st == st0 and tr == tr0 and np.array_equal(xs, xs0), (opts, sync)
+            assert np.array_equal(s.approx_inv_hessian(), h0), (opts, sync)
+            if sync == 0:
+                assert s.stats()["launches"] == l0, (opts, s.stats()["launches"], l0)
+    with pytest.raises(qn.ErrorInputParams):
+        base.set_option("touch_h_rows", 5)
+
+
 @pytest.mark.parametrize("n", [1152, 3200])
 def test_second_generation_without_slivers_and_without_the_pair_instance(qn, qo, n):
     """Sizes whose work lists carry NO row slivers (sl_per == 0) and where the two-items-and-a-sliver instance of the evaluation
