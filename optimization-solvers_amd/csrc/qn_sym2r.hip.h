@@ -296,8 +296,15 @@ __global__ __launch_bounds__(QN_S2R_TPB) void s2_evalr_kernel(const QnS2Args a) 
                 park[wave][r][lane] = h[r];
                 h[r] = ld2(q1 + (size_t)r * np);
                 if ((r & 3) == 3) qn_s2r_publish(&Y.prod[wave], (unsigned)r + 1u); // (with the wait for the wave's LDS writes: measured no slower than without -- the in-order variant stays a template switch)
+                if (r == 3) QN_S2R_STAMP(2, 448);  // (wave 7: four rows parked and published)
+                if (r == 11) QN_S2R_STAMP(5, 448); // (wave 7: twelve)
             }
             QN_S2R_STAMP(7, 448); // (wave 7: its sixteen rows parked, the second item requested)
+            QN_S2R_STAMP(6, 64);  // (wave 1)
+            QN_S2R_STAMP(8, 256); // (wave 4)
+            // (Measured and dropped, round 6, profiles/r06_e_eval_policies_ab_n4096.txt: in the launches that flip, ALL of X parked before the first request for Y --
+            // 13.2 -> 14.75 us: even there X's rows land at 5.5-5.8 us, and Y then starts that late; the sliver's row and Y's rows 12..15 as non-temporal loads, so
+            // that what the launch leaves in the L2 is three quarters of a tile per workgroup: -0.15 us, inside the noise; all of Y non-temporal in the flipping launches: nothing.)
             qn_s2r_wait_ge<8>(&Y.mdone, 1u, bad); // (long naps: the machine's wave shares its SIMD with three of the waiting ones)
         }
         if (!L.mine) return; // (every wave of the workgroup leaves here, or none does)

@@ -30,8 +30,8 @@ st = buf.reshape(64, 256, 16).astype(np.int64)
 # folded, 4 after the pair's barrier, 5 pair's slots stored, 15 end
 order = [9, 10, 11, 1, 6, 7, 8, 2, 13, 14, 12, 3, 4, 5, 15]
 if os.environ.get("QN_STAMPS_RING"):  # the mover / multiplier kernel (qn_sym2r.hip.h) stamps other things under the same numbers
-    order = [11, 9, 7, 13, 1, 10, 14, 12, 3, 4, 15]
-    label = {11: "machine + flag", 9: "m7 trial point staged", 7: "w7 first item parked, second requested", 13: "first item done: m7", 1: "m0", 10: "m4",
+    order = [11, 9, 6, 8, 2, 5, 7, 13, 1, 10, 14, 12, 3, 4, 15]
+    label = {11: "machine + flag", 9: "m7 trial point staged", 6: "w1 parked", 8: "w4 parked", 2: "w7 4 rows parked", 5: "w7 12 rows parked", 7: "w7 first item parked, second requested", 13: "first item done: m7", 1: "m0", 10: "m4",
              14: "w7 second item done", 12: "w7 folded", 3: "w0 folded", 4: "exchange barrier", 15: "end"}
 else:
   label = {12: "w7 pair folded", 13: "w7 item a done", 14: "w7 item b done", 6: "w7 requested", 7: "w7 parked", 8: "w7 at barrier", 9: "ctl", 10: "sums", 11: "machine", 1: "w0 at barrier", 2: "barrier", 3: "w0 pair folded", 4: "pair barrier", 5: "pair stored", 15: "end"}
