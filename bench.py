@@ -723,7 +723,9 @@ def main():
                  "exchanged as 8 KB per rank and summed in rank order by the next launch's prologue)" if (sym2 and world > 1) else
                  "s2_evalr_kernel (f(x + t d) and g(x + t d)'d from the symmetric half of Q; round 6: mover waves stream the workgroup's two tiles and "
                  "its sliver, multiplier waves take the first tile's rows out of the LDS park as they land while wave 0's state machine has long "
-                 "decided, the movers multiply the second tile out of their registers)" if (sym2 and n == 4096 and os.environ.get("QN_S2_RING", "1") != "0") else
+                 "decided, the movers multiply the second tile out of their registers; launches of odd parity stream the two tiles in the other order -- an "
+                 "evaluation right behind another one starts with the tile the XCD's L2 still holds -- and the update-reduce launch in front of an "
+                 "iteration's first evaluation carries workgroups that load rows of its first tiles into that L2)" if (sym2 and n == 4096 and os.environ.get("QN_S2_RING", "1") != "0") else
                  "s2_eval_kernel (f(x + t d) and g(x + t d)'d from the symmetric half of Q: first tile parked in LDS while wave 0 runs the "
                  "solver's state machine, items in groups with one exchange)" if sym2 else
                  "sym_eval_tile_kernel (Q (x + t d) from the upper block triangle of Q)" if sym_pass else
@@ -783,7 +785,9 @@ def main():
                 if roofline["traffic"] is not None:
                     roofline["traffic_source"] = (f"profiles/pmc_traffic.json[{key}]: HBM bytes per launch from separate rocprofv3 --pmc "
                                                   "FETCH_SIZE / WRITE_SIZE passes (gfx950 x2 correction on FETCH_SIZE); an offline figure, "
-                                                  "not a counter read during this run; recorded on: " + str(rec.get("build", "an earlier build")))
+                                                  "not a counter read during this run; recorded on: " + str(rec.get("build", "an earlier build"))
+                                                  + "; counter collection serialises the dispatches with a cache flush, so what an XCD's L2 keeps from "
+                                                    "one launch to the next (round 6: zig-zag order, touch workgroups) does not show: an upper bound")
             except Exception:  # noqa: BLE001
                 pass
 

@@ -1395,6 +1395,13 @@ __device__ __forceinline__ void qn_s2_hvec_load(const QnS2HReq& q, const unsigne
 // the launch is already waiting for; a designated, polling reducer would not have that problem and cannot be had without a
 // wait that a non-resident workgroup can hold up (two such launches of two solvers sharing the GPU deadlock).  The reduce launch
 // stays: 5 launches per iteration.
+// MEASURED AND DROPPED (round 6, profiles/r06_e_update_prefetch_ab_n4096.txt): a PRE instantiation for n = 4096's two-item lists -- the first eight rows (of every
+// wave's sixteen) of the SECOND item requested in front of the workgroup's barrier, straight into 64 KB of LDS (global_load_lds_dwordx4: one instruction per 1 KB row,
+// no register held), the first item's row loop refilling its window's first eight registers from there.  Until the machine has run nothing can be written,
+// and behind the barrier 264 KB of stores share the fabric with the second item's loads: 64 KB of those were to move into the quiet part.  Bit-identical
+// (the same loads of the same bytes), 252 registers, no scratch -- and 22.0 -> 23.0-23.3 us when requested at entry (in-kernel stamps: the machine done at 6.0 us
+// instead of 4.0 -- the requests stand in the CU's queue in front of what wave 0 waits for), 22.7 when requested behind the first item's rows (the barrier then
+// waits for them).  Round 2's look-ahead window in LDS went the same way.  The fabric is not idle before the barrier: the first item is still coming in.
 template <bool NT, bool BFGS, bool FOLD, bool SHARD = false, bool TRED = false, bool SR1 = false> // (SR1: s u' + u s', s s' AND u u' -- sr1_b.rs)
 __global__ __launch_bounds__(QN_S2_TPB, 2) void s2_hpass_kernel(const QnS2Args a) {
     static_assert(!(FOLD && SHARD), "the folded accept-reduce is a single-rank variant");
