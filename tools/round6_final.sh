@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box call at the end of round 6: the driver's bench line (with extra_configs), the default one, rocprofv3 kernel summaries of
 # the headline run and of config 5 on its new path, the PMC traffic passes.  usage (through gpurun): bash tools/round5_final.sh <tag>
-tag=${1:-r06_z}
+tag=${1:-r06_f}
 out=gpurun_out/$tag
 repo="${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel 2>/dev/null || pwd)}"
 mkdir -p $out
@@ -41,3 +41,5 @@ if [ -f optimization-solvers_amd/lib/libqn_hip_stamps.so ]; then
   grep -v "accept-reduce\|update" $out/ring_stamps.txt | sed -n 2,5p
   grep -v "accept-reduce\|update" $out/pair_stamps.txt | sed -n 2,4p
 fi
+# round 6, second half: what the XCDs' L2 keeps across kernel boundaries -- the zig-zag order and the touch workgroups against the kernels without them
+REPS=2 bash tools/prof_env_ab.sh "l2_off:QN_S2_ZIGZAG=0,QN_S2_TOUCH=0,QN_S2_TOUCHQ=0" "zigzag:QN_S2_TOUCH=0,QN_S2_TOUCHQ=0" "default:QN_S2_ZIGZAG=1" > $out/l2_ab.txt 2>&1; cat $out/l2_ab.txt
