@@ -253,8 +253,6 @@ static int minimize_impl(qn_solver* s, qn_linesearch* ls, const qn_oracle* o, si
             const bool can = a.ring && !r.bnd && !a.fold && !a.tred && s->method != QN_SR1 && a.nb == 32 && a.G == 256; // (the instantiations are nb = 32's)
             a.touch = (can && rows_ok(s->touch)) ? s->touch : 0;
             a.touchq = (can && rows_ok(s->touchq)) ? s->touchq : 0;
-            a.touch_odd = (a.touch && getenv("QN_S2_TOUCH_ODD") && rows_ok(atoi(getenv("QN_S2_TOUCH_ODD")))) ? atoi(getenv("QN_S2_TOUCH_ODD")) : a.touch;
-            a.touchq_odd = (a.touchq && getenv("QN_S2_TOUCHQ_ODD") && rows_ok(atoi(getenv("QN_S2_TOUCHQ_ODD")))) ? atoi(getenv("QN_S2_TOUCHQ_ODD")) : a.touchq;
             a.touch_delay = std::max(0, std::min(512, s->touch_delay));
             a.touchq_delay = std::max(0, std::min(512, s->touchq_delay));
         }

@@ -132,7 +132,6 @@ struct QnS2Args {
                              // formed, ||P(x + t d) - x||^2 leaves the launch as column 6 of its table (rows 0 .. nb - 1), the consuming prologue adds it up
     int touch, touchq;       // round 6: TOUCH workgroups in the accept-reduce (rows of H's tiles) and in the update-reduce (rows of Q's): rows per wave, of 16
                              // (qn_s2_touch; 0: none -- the launches then are the instantiations without them; 4, 8, 12 or 16)
-    int touch_odd, touchq_odd; // (experiment) rows for the touching workgroups of the ODD XCDs (the even ones end later: they get touch / touchq)
     int touch_delay, touchq_delay; // ... units of 64 clocks the accept-reduce's / the update-reduce's touching workgroups sleep before their first load
     int zig;                 // round 6: s2_evalr_kernel streams its two tiles in the other order in launches of odd parity (what the XCD's L2 still holds of the
                              // evaluation launch in front comes first: qn_sym2r.hip.h, ZIG-ZAG) -- the same bits
@@ -1222,9 +1221,8 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_vec_kernel(const QnS2Args a) {
         static_assert(NBT == 0 || NBT == 32, "seven touching workgroups share a tile: G = 8 nb");
         const int b = (int)blockIdx.x - NBT;
         for (int k = 0; k < a.touch_delay; k += 8) __builtin_amdgcn_s_sleep(8);
-        const int rows = (blockIdx.x & 1) ? a.touch_odd : a.touch;
-        qn_s2_touch(a.H, a, qn_s2_first_item(b, NBT), rows);
-        qn_s2_touch_seventh(a.H, a, qn_s2_first_item(a.G - NBT + (b & (NBT - 1)), NBT), rows, b / NBT);
+        qn_s2_touch(a.H, a, qn_s2_first_item(b, NBT), a.touch);
+        qn_s2_touch_seventh(a.H, a, qn_s2_first_item(a.G - NBT + (b & (NBT - 1)), NBT), a.touch, b / NBT);
         return;
     }
     QnS2Slots S0;
@@ -1812,7 +1810,7 @@ __global__ __launch_bounds__(QN_S2_TPB) void s2_hreduce_kernel(const QnS2Args a)
         const int ij0 = qn_s2_item_of_index(b, NBT), ij1 = qn_s2_item_of_index(a.G + b, NBT);
         const bool flip = a.zig != 0 && ((a.parity ^ 1) & 1) != 0 && (ij1 >> 16) != (ij1 & 0xffff);
         for (int k = 0; k < a.touchq_delay; k += 8) __builtin_amdgcn_s_sleep(8);
-        qn_s2_touch(a.Q, a, flip ? ij1 : ij0, (blockIdx.x & 1) ? a.touchq_odd : a.touchq);
+        qn_s2_touch(a.Q, a, flip ? ij1 : ij0, a.touchq);
         return;
     }
     QnS2Slots S0;
