@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box call at the end of round 6: the driver's bench line (with extra_configs), the default one, rocprofv3 kernel summaries of
-# the headline run and of config 5 on its new path, the PMC traffic passes.  usage (through gpurun): bash tools/round5_final.sh <tag>
+# the headline run and of config 5 on its new path, the PMC traffic passes.  usage (through gpurun): bash tools/round6_final.sh <tag>
 tag=${1:-r06_f}
 out=gpurun_out/$tag
 repo="${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel 2>/dev/null || pwd)}"
